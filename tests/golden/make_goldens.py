@@ -1,0 +1,227 @@
+"""Generate golden vectors by running the REFERENCE implementation on CPU.
+
+Runs only in the build container (needs /root/reference, read-only).  It imports the reference's
+own modules (shot_vae_model.vae, lib.criterion, lib.utils.mixup) behind a ``.cuda()`` no-op shim
+(SURVEY.md Appendix B), loads closed-form weights (oracle/closed_form.py), feeds explicit noise by
+temporarily replacing torch.randn / torch.rand / torch.randperm / numpy.random.beta, and drives the
+step of main_shot_vae.py:280-366 (that script cannot be imported: argparse + torchvision at import).
+
+Outputs: tests/golden/*.npz  (reference OUTPUTS only -- inputs are regenerated from closed forms).
+
+    python tests/golden/make_goldens.py
+"""
+import contextlib
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+from oracle import closed_form as C          # noqa: E402
+from oracle import shotvae_oracle as O       # noqa: E402  (only alpha schedule defaults + key helpers)
+
+REF = "/root/reference"
+
+
+def import_reference():
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    nn.Module.cuda = lambda self, *a, **k: self
+    sys.path.insert(0, REF)
+    from shot_vae_model.vae import VariationalAutoEncoder
+    from lib.criterion import VAECriterion, ClsCriterion
+    from lib.utils.mixup import mixup_vae_data, label_smoothing
+    return VariationalAutoEncoder, VAECriterion, ClsCriterion, mixup_vae_data, label_smoothing
+
+
+@contextlib.contextmanager
+def scripted_rng(randn=(), rand=(), randperm=(), beta=()):
+    """Replace the host RNG entry points the reference uses with scripted queues."""
+    q = dict(randn=list(randn), rand=list(rand), randperm=list(randperm), beta=list(beta))
+    saved = (torch.randn, torch.rand, torch.randperm, np.random.beta)
+
+    def pop(kind, size=None):
+        v = q[kind].pop(0)
+        if size is not None:
+            assert tuple(v.shape) == tuple(size), (kind, v.shape, size)
+        return v.clone() if torch.is_tensor(v) else v
+
+    torch.randn = lambda *s, **k: pop("randn", s[0] if len(s) == 1 and not isinstance(s[0], int) else s)
+    torch.rand = lambda *s, **k: pop("rand", s[0] if len(s) == 1 and not isinstance(s[0], int) else s)
+    torch.randperm = lambda n, **k: pop("randperm", (n,))
+    np.random.beta = lambda a, b: pop("beta")
+    try:
+        yield
+    finally:
+        torch.randn, torch.rand, torch.randperm, np.random.beta = saved
+        for k, v in q.items():
+            assert not v, "unused scripted %s draws: %d" % (k, len(v))
+
+
+def alpha_schedule(epoch, max_epoch, alpha_max):
+    import math
+    return alpha_max * math.exp(-5 * (1 - min(1, epoch / max_epoch)) ** 2)
+
+
+def reference_step(model, elbo_criterion, cls_criterion, label_smoothing, mixup_vae_data,
+                   image_l, label_l, image_u, label_u, K, sch, epsilon, om):
+    """Body of the loop at main_shot_vae.py:281-364 (one iteration), driving reference objects."""
+    import torch.nn.functional as F
+    batch_size_l, batch_size_u = image_l.size(0), image_u.size(0)
+    label_onehot_l = torch.zeros(batch_size_l, K).scatter_(1, label_l.view(-1, 1), 1)
+    rec1, mu1, ls1, la1 = model(image_l, disc_label=label_l)
+    recon_l, klc_l, kld_l = elbo_criterion(image_l, rec1, mu1, ls1, la1)
+    prior_l = sch["kl_beta_c"] * torch.abs(klc_l - sch["cmi"]) + sch["kl_beta_d"] * torch.abs(kld_l - sch["dmi"])
+    elbo_l = recon_l + prior_l
+    with torch.no_grad():
+        sm_img, sm_mu, sm_sigma, sm_alpha, sm_label, lam_l = label_smoothing(
+            image_l, mu1, ls1, la1, epsilon=epsilon, disc_label=label_l)
+        sm_onehot = torch.zeros(batch_size_l, K).scatter_(1, sm_label.view(-1, 1), 1)
+    rec2, mu2, ls2, la2, *_ = model(sm_img, True, label_l, sm_label, lam_l)
+    disc_post_l = lam_l * cls_criterion(la2, label_onehot_l) + (1 - lam_l) * cls_criterion(la2, sm_onehot)
+    cont_post_l = (F.mse_loss(mu2, sm_mu, reduction="sum")
+                   + F.mse_loss(torch.exp(ls2), sm_sigma, reduction="sum")) / batch_size_l
+    elbo_l = elbo_l + sch["kl_beta_c"] * sch["pwm"] * cont_post_l
+    loss_sup = sch["ew"] * elbo_l + disc_post_l
+    loss_sup.backward()
+    rec3, mu3, ls3, la3 = model(image_u)
+    recon_u, klc_u, kld_u = elbo_criterion(image_u, rec3, mu3, ls3, la3)
+    prior_u = sch["kl_beta_c"] * torch.abs(klc_u - sch["cmi"]) + sch["kl_beta_d"] * torch.abs(kld_u - sch["dmi"])
+    elbo_u = recon_u + prior_u
+    with torch.no_grad():
+        mx_img, mx_mu, mx_sigma, mx_alpha, lam_u = mixup_vae_data(image_u, mu3, ls3, la3, optimal_match=om)
+    rec4, mu4, ls4, la4, *_ = model(mx_img)
+    disc_post_u = cls_criterion(la4, mx_alpha)
+    cont_post_u = (F.mse_loss(mu4, mx_mu, reduction="sum")
+                   + F.mse_loss(torch.exp(ls4), mx_sigma, reduction="sum")) / batch_size_u
+    elbo_u = elbo_u + sch["kl_beta_c"] * sch["pwm"] * cont_post_u
+    loss_unsup = sch["ew"] * elbo_u + sch["ucw"] * disc_post_u
+    loss_unsup.backward()
+    loc = dict(locals())
+    keys = ["recon_l", "klc_l", "kld_l", "recon_u", "klc_u", "kld_u", "disc_post_l", "cont_post_l",
+            "disc_post_u", "cont_post_u", "loss_sup", "loss_unsup"] + \
+           ["%s%d" % (n, i) for i in (1, 2, 3, 4) for n in ("rec", "mu", "ls", "la")] + ["sm_img", "mx_img"]
+    return {k: loc[k].detach().clone() for k in keys}
+
+
+def grad_sample_idx(n, k=16):
+    return np.unique(np.linspace(0, n - 1, num=min(k, n)).astype(np.int64))
+
+
+def run_step_case(tag, name, K, Bl, Bu, bce, x_sigma=1.0, om=False, epoch=10, dmi=2.3, steps=1):
+    VAE, VAECriterion, ClsCriterion, mixup_vae_data, label_smoothing = import_reference()
+    model = VAE(encoder_name=name, num_input_channels=3, drop_rate=0, img_size=(32, 32),
+                data_parallel=False, continuous_latent_dim=128, disc_latent_dim=K,
+                sample_temperature=0.67, small_input=True)
+    st = C.make_state(name, K=K)
+    sd = model.state_dict()
+    assert list(sd.keys()) == list(st.keys()), "state_dict key order mismatch"
+    model.load_state_dict(st)
+    model.train()
+    elbo = VAECriterion(discrete_dim=K, x_sigma=x_sigma, bce_reconstruction=bce)
+    cls = ClsCriterion()
+    opt = torch.optim.SGD(model.parameters(), lr=0.1, momentum=0.9, weight_decay=5e-4)
+    opt.zero_grad()
+    sch = dict(cmi=alpha_schedule(epoch, 200, 0.0), dmi=alpha_schedule(epoch, 200, dmi),
+               ew=alpha_schedule(epoch, 400, 1e-3), kl_beta_c=alpha_schedule(epoch, 200, 1e-3),
+               kl_beta_d=alpha_schedule(epoch, 200, 1e-3), pwm=alpha_schedule(epoch, 200, 1.0),
+               ucw=alpha_schedule(epoch, round(0.4 * 600), 1.0))
+    rec = {}
+    for s in range(steps):
+        il, ll, iu, lu = C.make_batch(Bl, Bu, K, stream0=7000 + 10 * s)
+        nz = C.make_noise(Bl, Bu, K, stream0=9000 + 100 * s)
+        randperm = [nz["perm_l"]] + ([] if om else [nz["perm_u"]])
+        with scripted_rng(randn=[nz["eps1"], nz["eps2"], nz["eps3"], nz["eps4"]],
+                          rand=[nz["u3"], nz["u4"]], randperm=randperm,
+                          beta=[nz["lam_l"], nz["lam_u"]]):
+            out = reference_step(model, elbo, cls, label_smoothing, mixup_vae_data, il, ll, iu, lu,
+                                 K, sch, 0.1, om)
+        pre = "s%d." % s
+        for k, v in out.items():
+            rec[pre + k] = v.numpy()
+        names = [k for k, _ in model.named_parameters()]
+        gn = np.array([float(p.grad.double().norm()) for _, p in model.named_parameters()])
+        rec[pre + "grad_norm"] = gn
+        rec[pre + "grad_sample"] = np.concatenate(
+            [p.grad.reshape(-1)[torch.from_numpy(grad_sample_idx(p.numel()))].numpy()
+             for _, p in model.named_parameters()])
+        opt.step()
+        opt.zero_grad()
+    sd = model.state_dict()
+    rec["final.param_norm"] = np.array([float(sd[k].double().norm()) for k in names])
+    rec["final.param_sample"] = np.concatenate(
+        [sd[k].reshape(-1)[torch.from_numpy(grad_sample_idx(sd[k].numel()))].numpy() for k in names])
+    for k, v in sd.items():
+        if k.endswith("running_mean") or k.endswith("running_var") or k.endswith("num_batches_tracked"):
+            rec["final.buf." + k] = v.numpy()
+    rec["meta.param_names"] = np.array(names)
+    np.savez_compressed(os.path.join(HERE, tag + ".npz"), **rec)
+    print(tag, "loss_sup", float(out["loss_sup"]), "loss_unsup", float(out["loss_unsup"]),
+          "bytes", os.path.getsize(os.path.join(HERE, tag + ".npz")))
+
+
+def run_eval_case(tag, name, K, B):
+    VAE, *_ = import_reference()
+    model = VAE(encoder_name=name, num_input_channels=3, drop_rate=0, img_size=(32, 32),
+                data_parallel=False, continuous_latent_dim=128, disc_latent_dim=K,
+                sample_temperature=0.67, small_input=True)
+    model.load_state_dict(C.make_state(name, K=K))
+    model.eval()
+    il, ll, iu, lu = C.make_batch(B, B, K)
+    nz = C.make_noise(B, B, K)
+    with torch.no_grad(), scripted_rng(randn=[nz["eps3"]], rand=[nz["u3"]]):
+        rec, mu, ls, la = model(iu)
+    np.savez_compressed(os.path.join(HERE, tag + ".npz"), rec=rec.numpy(), mu=mu.numpy(), ls=ls.numpy(),
+                        la=la.numpy())
+    print(tag, float(rec.abs().mean()))
+
+
+def run_fn_cases(tag):
+    """Direct calls of the reference criteria / mixup functions."""
+    _, VAECriterion, ClsCriterion, mixup_vae_data, label_smoothing = import_reference()
+    B, K, D = 6, 10, 128
+    x = C.uniform((B, 3, 32, 32), 11)
+    xr = C.normal((B, 3, 32, 32), 12) * 2.0
+    mu = C.normal((B, D), 13) * 0.7
+    ls = C.normal((B, D), 14) * 0.3 - 0.5
+    la = torch.log_softmax(C.normal((B, K), 15) * 2.0, dim=1)
+    lab = (torch.arange(B) * 3 + 1) % K
+    rec = {}
+    for bce, sig in ((True, 1.0), (False, 1.0), (False, 0.5)):
+        r, kc, kd = VAECriterion(discrete_dim=K, x_sigma=sig, bce_reconstruction=bce)(x, xr, mu, ls, la)
+        rec["crit_bce%d_sig%g" % (int(bce), sig)] = np.array([float(r), float(kc), float(kd)])
+    soft = torch.softmax(C.normal((B, K), 16), dim=1)
+    w = C.uniform((B,), 17)
+    rec["cls_soft"] = np.array(float(ClsCriterion()(la, soft)))
+    rec["cls_weighted"] = np.array(float(ClsCriterion()(la, soft, w)))
+    perm = C.permutation(B, 18)
+    with scripted_rng(randperm=[perm], beta=[0.81]):
+        outs = label_smoothing(x, mu, ls, la, epsilon=0.1, disc_label=lab)
+    for i, n in enumerate(["img", "mu", "sigma", "alpha", "label"]):
+        rec["ls_" + n] = outs[i].numpy()
+    rec["ls_lam"] = np.array(outs[5])
+    with scripted_rng(randperm=[perm], beta=[0.42]):
+        outs = mixup_vae_data(x, mu, ls, la, optimal_match=False)
+    for i, n in enumerate(["img", "mu", "sigma", "alpha"]):
+        rec["mx_" + n] = outs[i].numpy()
+    with scripted_rng(beta=[0.42]):
+        outs = mixup_vae_data(x, mu, ls, la, optimal_match=True)
+    for i, n in enumerate(["img", "mu", "sigma", "alpha"]):
+        rec["om_" + n] = outs[i].numpy()
+    np.savez_compressed(os.path.join(HERE, tag + ".npz"), **rec)
+    print(tag, "ok")
+
+
+if __name__ == "__main__":
+    assert os.path.isdir(REF), "reference not mounted; goldens are generated in the build container"
+    torch.set_num_threads(8)
+    run_fn_cases("ref_functions")
+    run_eval_case("ref_eval_wrn10_1", "wideresnet-10-1", 10, 4)
+    run_step_case("ref_step_wrn10_1_br", "wideresnet-10-1", 10, 4, 6, True, steps=2)
+    run_step_case("ref_step_wrn10_1_om", "wideresnet-10-1", 10, 4, 6, True, om=True)
+    run_step_case("ref_step_wrn28_2_br", "wideresnet-28-2", 10, 4, 4, True)
+    run_step_case("ref_step_wrn28_2_mse", "wideresnet-28-2", 10, 4, 4, False, x_sigma=0.5)
+    run_step_case("ref_step_wrn28_10_k100", "wideresnet-28-10", 100, 2, 2, True, dmi=4.6)
