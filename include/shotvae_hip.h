@@ -1,0 +1,191 @@
+/*
+ * shotvae_hip.h  --  C ABI of libshotvae_hip.so: the MI355X (gfx950) compute path of the
+ * SHOT-VAE training step.
+ *
+ * The reference (FengHZ/SHOT-VAE) is pure Python on torch.nn; it has no FFI.  Each entry point
+ * below replaces the torch operator(s) that the cited reference lines dispatch (SURVEY.md §2.1
+ * K1-K20).  Conventions for every function:
+ *   - plain pointers + sizes, no torch types; all pointers are DEVICE pointers unless noted;
+ *   - asynchronous on `stream` (a hipStream_t passed as void*); no allocation, no host sync,
+ *     no exceptions -- safe to capture into a hipGraph;
+ *   - returns 0 on success, <0 on error (SV_E_*); sv_last_error() gives the message;
+ *   - activations are NHWC with an explicit channel stride, element type `dtype`
+ *     (SV_F32 exact-fp32 MFMA mode for parity, SV_BF16 throughput mode); statistics,
+ *     parameters, gradients of parameters and loss terms are always fp32.
+ */
+#ifndef SHOTVAE_HIP_H
+#define SHOTVAE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SV_ABI_VERSION 1
+
+enum { SV_F32 = 0, SV_BF16 = 1 };
+enum { SV_OK = 0, SV_E_ARG = -1, SV_E_SHAPE = -2, SV_E_HIP = -3 };
+enum { SV_MAX_TAPS = 16, SV_MAX_PHASES = 4 };
+
+/* One sub-pixel phase of a (transposed / strided) convolution written as a gather-GEMM. */
+typedef struct {
+    int32_t ooy, oox;               /* output offset: oy = qy*osy + ooy                              */
+    int32_t ntap;                   /* taps of this phase (0 => the phase's outputs are zero)        */
+    int8_t dy[SV_MAX_TAPS];         /* input offset per tap: iy = qy*sy + dy[t] (zero outside)       */
+    int8_t dx[SV_MAX_TAPS];
+    int8_t torig[SV_MAX_TAPS];      /* tap index in the MASTER weight layout [N][T_orig][Cin]        */
+    int64_t w_off;                  /* element offset of this phase's packed weights [N][ntap][Cin]  */
+} sv_phase;
+
+/* Geometry of one conv-like layer:  out[b, qy*osy+ooy, qx*osx+oox, n] =
+ *     sum_{t,c} act(x[b, qy*sy+dy[t], qx*sx+dx[t], c]) * w[n][t][c]                                  */
+typedef struct {
+    int32_t B, Hin, Win, Cin, ldx;          /* input  tensor [B,Hin,Win,ldx],  Cin  % 16 == 0        */
+    int32_t Hq, Wq, sy, sx;                 /* per-phase output grid and input stride                */
+    int32_t Hout, Wout, N, ldo, osy, osx;   /* output tensor [B,Hout,Wout,ldo], N % 16 == 0          */
+    int32_t T_orig;                         /* taps in the master weight layout                      */
+    int32_t nphase;
+    sv_phase phase[SV_MAX_PHASES];
+} sv_geom;
+
+/* ---- K1/K2/K3/K12/K13 forward and every dgrad: fused gather-GEMM on MFMA -----------------------
+ * Replaces nn.Conv2d / nn.ConvTranspose2d forward (wideresnet.py:13-14,29-30,34-35,41-43;
+ * decoder.py:13-58) fused with the preceding BatchNorm2d-apply + LeakyReLU/ReLU (wideresnet.py:
+ * 27-28,32-33,39-40; decoder.py:19-20,...) as a load prologue, and with the residual add
+ * (wideresnet.py:49) and the *next* BatchNorm's batch statistics as an epilogue.  With the
+ * `ex` fields set it is the conv/convT input-gradient fused with the activation backward and the
+ * two BatchNorm-backward reductions (autograd of the same lines).                                  */
+typedef struct {
+    const void* x;              /* input activations                                                 */
+    const float* pro_scale;     /* [Cin] BN-apply scale (NULL: no prologue)                          */
+    const float* pro_shift;     /* [Cin]                                                             */
+    float pro_slope;            /* LeakyReLU slope (0 = ReLU)                                        */
+    const void* w;              /* packed weights, element type = dtype                              */
+    const float* bias;          /* [N] or NULL                                                       */
+    const void* residual;       /* same layout as out, or NULL                                       */
+    void* out;
+    float* stats;               /* [2N] += (sum y, sum y^2) or NULL                                  */
+    const void* ex;             /* act-backward epilogue: raw tensor at the output positions / NULL  */
+    const float* ex_scale;      /* [N] each                                                          */
+    const float* ex_shift;
+    const float* ex_mean;
+    const float* ex_rstd;
+    float ex_slope;
+    float* bsums;               /* [2N] += (sum g, sum g*xhat)                                       */
+} sv_igemm_args;
+
+int sv_igemm(const sv_geom* g, int dtype, const sv_igemm_args* a, void* stream);
+
+/* ---- K19 weight gradient: dW[n][torig][c] += sum_m dy[m][n] * act(x[m,t][c])  (fp32 atomics) ----
+ * Replaces autograd's convolution_backward (weight part) for the same layers.  `splits` = number
+ * of M ranges (0 = choose).                                                                         */
+int sv_wgrad(const sv_geom* g, int dtype, const void* x, const float* pro_scale, const float* pro_shift,
+             float pro_slope, const void* dy, float* dw, int splits, int use_tr, void* stream);
+
+/* column sums: out[n] += sum_m y[m*ld + n]   (conv0 bias gradient)                                  */
+int sv_colsum(int dtype, const void* y, int64_t M, int N, int ld, float* out, void* stream);
+
+/* ---- K4 BatchNorm2d train-mode finalize (nn.BatchNorm2d semantics, eps/momentum explicit) -------
+ * stats=[sum, sumsq] -> scale=gamma*rstd, shift=beta-mean*scale; saves mean/rstd; updates running
+ * stats (unbiased var) unless running_mean is NULL.                                                 */
+int sv_bn_finalize(const float* stats, int C, float count, const float* gamma, const float* beta,
+                   float eps, float momentum, float* running_mean, float* running_var,
+                   float* scale, float* shift, float* mean, float* rstd, void* stream);
+/* eval-mode affine from running statistics (main_shot_vae.py:409-510 path)                         */
+int sv_bn_eval_affine(int C, const float* gamma, const float* beta, const float* running_mean,
+                      const float* running_var, float eps, float* scale, float* shift, void* stream);
+/* BatchNorm backward, second phase: dx = sum_br gamma*rstd*(g - mean(g) - xhat*mean(g*xhat)) (+res)
+ * for one or two BN branches that share the input x; dgamma/dbeta accumulate (+=).                  */
+typedef struct {
+    const void* g; const float* bsums; const float* gamma; float* dgamma; float* dbeta;
+} sv_bn_branch;
+int sv_bn_bwd_apply(int dtype, int64_t M, int C, int ld, const void* x, const float* mean,
+                    const float* rstd, float count, const sv_bn_branch* br, int nbranch,
+                    const void* residual, void* dx, void* stream);
+
+/* ---- K8 global average pool fused with the transition BN+LeakyReLU (vae.py:107,143) ------------- */
+int sv_pool_fwd(int dtype, const void* x, const float* scale, const float* shift, float slope,
+                int B, int HW, int C, int ld, float* feat, void* stream);
+int sv_pool_bwd(int dtype, const void* x, const float* scale, const float* shift, float slope,
+                const float* mean, const float* rstd, const float* dfeat, int B, int HW, int C, int ld,
+                void* g, float* bsums, void* stream);
+
+/* ---- K9 the three inference heads + LogSoftmax (vae.py:10-15,144-146) ----------------------------
+ * W is [2*ldc+K][C] (rows: mean, log_sigma, disc), bias [2*ldc+K].                                   */
+int sv_head_fwd(const float* feat, int B, int C, const float* W, const float* bias, int ldc, int K,
+                float* mu, float* ls, float* la, void* stream);
+/* dW/dbias accumulate (+=); dout_ws is a caller-owned [B][2*ldc+K] fp32 workspace                    */
+int sv_head_bwd(const float* feat, int B, int C, const float* W, int ldc, int K, const float* la,
+                const float* dmu, const float* dls, const float* dla, float* dfeat, float* dW,
+                float* dbias, float* dout_ws, void* stream);
+
+/* ---- K10/K11 reparameterisation sampler (vae.py:23-86) -------------------------------------------
+ * mode 0: gumbel-softmax from u; 1: one-hot(label); 2: lam*onehot(label)+(1-lam)*onehot(label_mix).
+ * latent is [B][Lpad] of `dtype` = [z | c | 0-pad]; csoft [B][K] fp32 keeps c for the backward.     */
+int sv_sample_fwd(int dtype, const float* mu, const float* ls, const float* la, const float* eps,
+                  const float* u, const int64_t* label, const int64_t* label_mix, float lam, int mode,
+                  float temperature, int B, int ldc, int K, int Lpad, void* latent, float* csoft,
+                  void* stream);
+/* dmu/dls/dla accumulate (+=) the sampler path of the latent gradient                              */
+int sv_sample_bwd(int dtype, const void* dlatent, const float* ls, const float* eps, const float* csoft,
+                  int mode, float temperature, int B, int ldc, int K, int Lpad,
+                  float* dmu, float* dls, float* dla, void* stream);
+
+/* ---- K14/K15 smooth-ELBO terms (lib/criterion.py:32-57) -----------------------------------------
+ * out3 = [recon, KL_c, KL_d] already divided by B (and 2*sigma^2 for MSE); must be zeroed by the
+ * caller.  x / x_rec are NCHW fp32 (API edge).                                                      */
+int sv_elbo_fwd(const float* x, const float* x_rec, int64_t n_per_img, const float* mu, const float* ls,
+                const float* la, int B, int ldc, int K, int bce, float x_sigma, float* out3, void* stream);
+/* gout3: device pointer to the three upstream gradients; writes dx_rec, dmu, dls, dla (=, not +=)  */
+int sv_elbo_bwd(const float* x, const float* x_rec, int64_t n_per_img, const float* mu, const float* ls,
+                const float* la, int B, int ldc, int K, int bce, float x_sigma, const float* gout3,
+                float* dx_rec, float* dmu, float* dls, float* dla, void* stream);
+
+/* ---- K16 ClsCriterion (lib/criterion.py:97-108): out += -mean_b sum_c predict*label*weight ------ */
+int sv_cls_fwd(const float* predict, const float* label, const float* weight, int B, int K, float* out,
+               void* stream);
+int sv_cls_bwd(const float* label, const float* weight, int B, int K, const float* gout, float* dpredict,
+               void* stream);
+/* posterior terms of main_shot_vae.py:319-321,359-361: out += (sum (mu-mt)^2 + sum (exp(ls)-st)^2)/B */
+int sv_post_fwd(const float* mu, const float* ls, const float* mu_t, const float* sigma_t, int B, int D,
+                float* out, void* stream);
+int sv_post_bwd(const float* mu, const float* ls, const float* mu_t, const float* sigma_t, int B, int D,
+                const float* gout, float* dmu, float* dls, void* stream);
+
+/* ---- K17 mixup / label smoothing gather-lerp (lib/utils/mixup.py:22-25,36-39) --------------------
+ * out[b] = lam*f(a[b]) + (1-lam)*f(a[index[b]]), f = exp when `exp_space` else identity.           */
+int sv_mix_lerp(const float* a, const int64_t* index, float lam, int B, int64_t row, int exp_space,
+                float* out, void* stream);
+
+/* ---- K18 optimal-match pairing (lib/utils/mixup.py:9-18,93-99): index[i] = argmin_{j!=rank0} ----
+ * second-smallest entry of row i of the pairwise Gaussian-KL matrix.                               */
+int sv_optimal_match(const float* mu, const float* ls, int B, int D, int64_t* index, void* stream);
+
+/* ---- K20 SGD(momentum, weight decay) on the flat parameter buffer (torch.optim.SGD semantics) ---- */
+int sv_sgd(float* p, const float* g, float* v, int64_t n, float lr, float momentum, float weight_decay,
+           float grad_scale, int first_step, void* stream);
+
+/* ---- layout / packing helpers --------------------------------------------------------------------*/
+/* NCHW fp32 [B,C,H,W] -> NHWC `dtype` [B,H,W,Cpad] (channels >= C zero-filled)                     */
+int sv_nchw_to_nhwc(int dtype, const float* in, int B, int C, int H, int W, int Cpad, void* out, void* stream);
+/* NHWC `dtype` [B,H,W,ld] (first C channels) -> NCHW fp32                                           */
+int sv_nhwc_to_nchw(int dtype, const void* in, int B, int C, int H, int W, int ld, float* out, void* stream);
+/* master fp32 [N][T_orig][C] -> packed `dtype` per phase [n'][ntap][c'] (transpose swaps n and c)  */
+int sv_repack(int dtype, const float* master, int N, int T_orig, int C, int transpose,
+              const sv_geom* g, void* dst, void* stream);
+
+/* ---- in-situ kernel timing (HIP events around launches of sv_igemm / sv_wgrad) -------------------
+ * sv_prof_enable(1) starts recording; every launch is filed under the current tag (sv_prof_tag).
+ * sv_prof_collect synchronises the device and returns, per tag, total milliseconds and launches.   */
+int sv_prof_enable(int on);
+int sv_prof_tag(int tag);
+int sv_prof_collect(int max_tags, double* ms, int* count);
+
+int sv_version(void);
+const char* sv_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,116 @@
+"""ctypes binding of libshotvae_hip.so (the C ABI declared in include/shotvae_hip.h).
+
+There is deliberately NO fallback: if the shared library is missing or a call fails, the product
+path raises.  ``build()`` compiles the library in-tree with hipcc for gfx950."""
+import ctypes as C
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libshotvae_hip.so")
+CSRC = os.path.join(HERE, "csrc")
+
+SV_F32, SV_BF16 = 0, 1
+MAX_TAPS, MAX_PHASES = 16, 4
+
+
+class SvPhase(C.Structure):
+    _fields_ = [("ooy", C.c_int32), ("oox", C.c_int32), ("ntap", C.c_int32),
+                ("dy", C.c_int8 * MAX_TAPS), ("dx", C.c_int8 * MAX_TAPS), ("torig", C.c_int8 * MAX_TAPS),
+                ("w_off", C.c_int64)]
+
+
+class SvGeom(C.Structure):
+    _fields_ = [("B", C.c_int32), ("Hin", C.c_int32), ("Win", C.c_int32), ("Cin", C.c_int32), ("ldx", C.c_int32),
+                ("Hq", C.c_int32), ("Wq", C.c_int32), ("sy", C.c_int32), ("sx", C.c_int32),
+                ("Hout", C.c_int32), ("Wout", C.c_int32), ("N", C.c_int32), ("ldo", C.c_int32),
+                ("osy", C.c_int32), ("osx", C.c_int32), ("T_orig", C.c_int32), ("nphase", C.c_int32),
+                ("phase", SvPhase * MAX_PHASES)]
+
+
+class SvIgemmArgs(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("pro_scale", C.c_void_p), ("pro_shift", C.c_void_p), ("pro_slope", C.c_float),
+                ("w", C.c_void_p), ("bias", C.c_void_p), ("residual", C.c_void_p), ("out", C.c_void_p),
+                ("stats", C.c_void_p), ("ex", C.c_void_p), ("ex_scale", C.c_void_p), ("ex_shift", C.c_void_p),
+                ("ex_mean", C.c_void_p), ("ex_rstd", C.c_void_p), ("ex_slope", C.c_float), ("bsums", C.c_void_p)]
+
+
+class SvBnBranch(C.Structure):
+    _fields_ = [("g", C.c_void_p), ("bsums", C.c_void_p), ("gamma", C.c_void_p), ("dgamma", C.c_void_p),
+                ("dbeta", C.c_void_p)]
+
+
+P, I, I64, F = C.c_void_p, C.c_int, C.c_int64, C.c_float
+_PROTOS = {
+    "sv_igemm": [C.POINTER(SvGeom), I, C.POINTER(SvIgemmArgs), P],
+    "sv_wgrad": [C.POINTER(SvGeom), I, P, P, P, F, P, P, I, I, P],
+    "sv_colsum": [I, P, I64, I, I, P, P],
+    "sv_bn_finalize": [P, I, F, P, P, F, F, P, P, P, P, P, P, P],
+    "sv_bn_eval_affine": [I, P, P, P, P, F, P, P, P],
+    "sv_bn_bwd_apply": [I, I64, I, I, P, P, P, F, C.POINTER(SvBnBranch), I, P, P, P],
+    "sv_pool_fwd": [I, P, P, P, F, I, I, I, I, P, P],
+    "sv_pool_bwd": [I, P, P, P, F, P, P, P, I, I, I, I, P, P, P],
+    "sv_head_fwd": [P, I, I, P, P, I, I, P, P, P, P],
+    "sv_head_bwd": [P, I, I, P, I, I, P, P, P, P, P, P, P, P, P],
+    "sv_sample_fwd": [I, P, P, P, P, P, P, P, F, I, F, I, I, I, I, P, P, P],
+    "sv_sample_bwd": [I, P, P, P, P, I, F, I, I, I, I, P, P, P, P],
+    "sv_elbo_fwd": [P, P, I64, P, P, P, I, I, I, I, F, P, P],
+    "sv_elbo_bwd": [P, P, I64, P, P, P, I, I, I, I, F, P, P, P, P, P, P],
+    "sv_cls_fwd": [P, P, P, I, I, P, P],
+    "sv_cls_bwd": [P, P, I, I, P, P, P],
+    "sv_post_fwd": [P, P, P, P, I, I, P, P],
+    "sv_post_bwd": [P, P, P, P, I, I, P, P, P, P],
+    "sv_mix_lerp": [P, P, F, I, I64, I, P, P],
+    "sv_optimal_match": [P, P, I, I, P, P],
+    "sv_sgd": [P, P, P, I64, F, F, F, F, I, P],
+    "sv_nchw_to_nhwc": [I, P, I, I, I, I, I, P, P],
+    "sv_nhwc_to_nchw": [I, P, I, I, I, I, I, P, P],
+    "sv_repack": [I, P, I, I, I, I, C.POINTER(SvGeom), P, P],
+    "sv_prof_enable": [I],
+    "sv_prof_tag": [I],
+    "sv_prof_collect": [I, C.POINTER(C.c_double), C.POINTER(C.c_int)],
+    "sv_version": [],
+}
+EXPORTS = sorted(list(_PROTOS) + ["sv_last_error"])
+
+_lib = None
+
+
+class ShotVaeHipError(RuntimeError):
+    pass
+
+
+def build(verbose=False):
+    """Compile libshotvae_hip.so in-tree (hipcc --offload-arch=gfx950)."""
+    r = subprocess.run(["make", "-C", CSRC, "-j4"], capture_output=True, text=True)
+    if verbose or r.returncode != 0:
+        print(r.stdout[-4000:])
+        print(r.stderr[-4000:])
+    if r.returncode != 0:
+        raise ShotVaeHipError("building libshotvae_hip.so failed")
+    return LIB_PATH
+
+
+def lib():
+    """The loaded library; raises (never falls back) when it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ShotVaeHipError(
+                "libshotvae_hip.so is missing (%s): run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C shot-vae_amd/csrc`.  There is no CPU / PyTorch fallback." % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, args in _PROTOS.items():
+            fn = getattr(L, name)
+            fn.argtypes = args
+            fn.restype = C.c_int
+        L.sv_last_error.argtypes = []
+        L.sv_last_error.restype = C.c_char_p
+        _lib = L
+    return _lib
+
+
+def call(name, *args):
+    rc = getattr(lib(), name)(*args)
+    if rc != 0:
+        raise ShotVaeHipError("%s failed (%d): %s" % (name, rc, lib().sv_last_error().decode()))

@@ -1,0 +1,66 @@
+// Shared device helpers for libshotvae_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "shotvae_hip.h"
+
+typedef __bf16 bf16;
+typedef bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+template <typename T> struct V8;
+template <> struct V8<float> { typedef f32x8 type; };
+template <> struct V8<bf16> { typedef bf16x8 type; };
+template <typename T> struct V4;
+template <> struct V4<float> { typedef f32x4 type; };
+template <> struct V4<bf16> { typedef bf16x4 type; };
+
+// D(16x16) += A(16xK) * B(Kx16) for one 32-deep k chunk.  Lane l supplies A[row l&15][k=8(l>>4)+j]
+// and B[k=8(l>>4)+j][col l&15], j=0..7.  bf16: one v_mfma_f32_16x16x32_bf16.  fp32: eight
+// v_mfma_f32_16x16x4_f32 (exact fp32), step j consuming element j of every lane group -- the k order
+// is a permutation of the same 32 products, so both dtypes share one fragment layout.
+__device__ __forceinline__ void mma32(f32x4& acc, const bf16x8& a, const bf16x8& b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
+}
+__device__ __forceinline__ void mma32(f32x4& acc, const f32x8& a, const f32x8& b) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j], acc, 0, 0, 0);
+}
+
+__device__ __forceinline__ float to_f(float v) { return v; }
+__device__ __forceinline__ float to_f(bf16 v) { return (float)v; }
+
+__device__ __forceinline__ float act_fwd(float u, float slope) { return u > 0.f ? u : u * slope; }
+__device__ __forceinline__ float act_grad(float u, float slope) { return u > 0.f ? 1.f : slope; }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// packed per-tap offsets: 4 bits per tap, biased by 8
+__device__ __forceinline__ uint64_t pack_taps(const int8_t* d) {
+    uint64_t p = 0;
+#pragma unroll
+    for (int t = 0; t < SV_MAX_TAPS; ++t) p |= (uint64_t)((d[t] + 8) & 15) << (4 * t);
+    return p;
+}
+__device__ __forceinline__ int tap_off(uint64_t p, int t) { return (int)((p >> (4 * t)) & 15) - 8; }
+
+// host side ------------------------------------------------------------------------------------------
+void sv_set_error(const char* fmt, ...);
+int sv_check_launch(const char* what);
+void sv_prof_begin(hipStream_t s);
+void sv_prof_end(hipStream_t s);
+
+#define SV_REQUIRE(cond, code, ...)                \
+    do {                                           \
+        if (!(cond)) {                             \
+            sv_set_error(__VA_ARGS__);             \
+            return code;                           \
+        }                                          \
+    } while (0)

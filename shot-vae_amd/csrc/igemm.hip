@@ -1,0 +1,334 @@
+// Fused gather-GEMM ("implicit GEMM") on MFMA for every conv-like forward and data-gradient of the
+// SHOT-VAE step: conv3x3 s1/s2, conv1x1 s1/s2, ConvTranspose 4x4 s2 p1 (as 4 sub-pixel phases),
+// the 1x1 ConvTranspose (plain GEMM) and all of their dgrads.  NHWC, gfx950.
+//
+//   out[b, qy*osy+ooy, qx*osx+oox, n] = sum_{t,c} A(b,qy,qx,t,c) * W[n][t][c]
+//   A = LeakyReLU(x*scale[c]+shift[c])  (BatchNorm-apply prologue, zero outside the image)
+//
+// Tile: 128 output positions x (16*NT) channels x 32-deep k; 4 waves, wave w owns rows [32w,32w+32).
+// Weights are the MFMA A-operand (rows = n) and activations the B-operand (cols = m), so that each
+// lane ends up with 4 consecutive channels of one output pixel -> 8/16-byte epilogue accesses.
+// Epilogue: +bias, +residual, either per-channel (sum, sumsq) for the next BatchNorm or the
+// activation backward + the two BatchNorm-backward sums; wave shuffle -> LDS atomics -> one global
+// atomic per channel per block.
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128;
+constexpr int BK = 32;
+constexpr int LDK = BK + 8;   // LDS row stride in elements (pad keeps 16-byte alignment, spreads banks)
+
+template <typename T, int NT>
+__global__ __launch_bounds__(256) void igemm_kernel(const sv_geom g, const sv_igemm_args a) {
+    typedef typename V8<T>::type V;
+    typedef typename V4<T>::type Q;
+    constexpr int BN = 16 * NT;
+    constexpr int NBV = (BN * 4 + 255) / 256;   // weight vectors per thread per k-chunk
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* As = reinterpret_cast<T*>(smem);           // [2][BM][LDK]
+    T* Bs = As + 2 * BM * LDK;                    // [2][BN][LDK]
+    float* ssum = reinterpret_cast<float*>(Bs + 2 * BN * LDK);   // [2][BN]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int HWq = g.Hq * g.Wq;
+    const int M = g.B * HWq;
+    const int nMt = (M + BM - 1) / BM;
+    const int nNt = (g.N + BN - 1) / BN;
+    const int inner = nNt * g.nphase;
+    // XCD-aware mapping: blocks L and L+8 share an XCD (and its L2); all channel tiles and phases
+    // of one m-tile run back to back on the same XCD so the gathered input is fetched once.
+    const int L = blockIdx.x;
+    const int xcd = L & 7, slot = L >> 3;
+    const int in_i = slot % inner;
+    const int mt = (slot / inner) * 8 + xcd;
+    if (mt >= nMt) return;
+    const int ph = in_i / nNt;
+    const int n0 = (in_i % nNt) * BN;
+    const sv_phase& P = g.phase[ph];
+    const uint64_t pdy = pack_taps(P.dy), pdx = pack_taps(P.dx);
+    const int ntap = P.ntap;
+    const int Ktot = ntap * g.Cin;
+    const int nk = (Ktot + BK - 1) / BK;
+    const T* __restrict__ X = reinterpret_cast<const T*>(a.x);
+    const T* __restrict__ W = reinterpret_cast<const T*>(a.w) + P.w_off;
+    const bool has_pro = a.pro_scale != nullptr;
+
+    if (tid < 2 * BN) ssum[tid] = 0.f;
+    if (BN > 128 && tid + 256 < 2 * BN) ssum[tid + 256] = 0.f;
+
+    // ---- loader state -------------------------------------------------------------------------
+    const int v = tid & 3;                 // 8-element k vector inside the 32-deep chunk
+    const int lrow = tid >> 2;             // 0..63
+    int iy0[2], ix0[2], pixb[2];
+    bool mval[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = mt * BM + lrow + 64 * i;
+        mval[i] = m < M;
+        const int mm = mval[i] ? m : 0;
+        const int b = mm / HWq;
+        const int r = mm - b * HWq;
+        const int qy = r / g.Wq;
+        const int qx = r - qy * g.Wq;
+        iy0[i] = qy * g.sy;
+        ix0[i] = qx * g.sx;
+        pixb[i] = b * g.Hin * g.Win;
+    }
+    int tap = 0, c = 8 * v;
+    while (c >= g.Cin) { c -= g.Cin; ++tap; }
+
+    V ra[2], rb[NBV];
+    bool oka[2];
+    int ca = 0;
+
+    auto load_global = [&](int kc) {
+        const int tt = tap < SV_MAX_TAPS ? tap : SV_MAX_TAPS - 1;
+        const int dy = tap_off(pdy, tt), dx = tap_off(pdx, tt);
+        ca = c;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int iy = iy0[i] + dy, ix = ix0[i] + dx;
+            const bool ok = mval[i] && tap < ntap && (unsigned)iy < (unsigned)g.Hin &&
+                            (unsigned)ix < (unsigned)g.Win;
+            oka[i] = ok;
+            V val;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) val[j] = (T)0.f;
+            if (ok) val = *reinterpret_cast<const V*>(X + ((int64_t)(pixb[i] + iy * g.Win + ix) * g.ldx + c));
+            ra[i] = val;
+        }
+        const int k8 = kc * BK + 8 * v;
+#pragma unroll
+        for (int i = 0; i < NBV; ++i) {
+            const int nb = lrow + 64 * i;
+            V val;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) val[j] = (T)0.f;
+            if (nb < BN && n0 + nb < g.N && k8 < Ktot)
+                val = *reinterpret_cast<const V*>(W + (int64_t)(n0 + nb) * Ktot + k8);
+            rb[i] = val;
+        }
+        // advance (tap, c) to the next chunk
+        c += BK;
+        while (c >= g.Cin) { c -= g.Cin; ++tap; }
+    };
+
+    auto store_lds = [&](int buf) {
+        T* Ab = As + buf * BM * LDK;
+        T* Bb = Bs + buf * BN * LDK;
+        if (has_pro) {
+            f32x4 s0 = *reinterpret_cast<const f32x4*>(a.pro_scale + ca);
+            f32x4 s1 = *reinterpret_cast<const f32x4*>(a.pro_scale + ca + 4);
+            f32x4 t0 = *reinterpret_cast<const f32x4*>(a.pro_shift + ca);
+            f32x4 t1 = *reinterpret_cast<const f32x4*>(a.pro_shift + ca + 4);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                if (oka[i]) {
+                    V o;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        o[j] = (T)act_fwd(to_f(ra[i][j]) * s0[j] + t0[j], a.pro_slope);
+                        o[j + 4] = (T)act_fwd(to_f(ra[i][j + 4]) * s1[j] + t1[j], a.pro_slope);
+                    }
+                    ra[i] = o;
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            *reinterpret_cast<V*>(Ab + (lrow + 64 * i) * LDK + 8 * v) = ra[i];
+#pragma unroll
+        for (int i = 0; i < NBV; ++i) {
+            const int nb = lrow + 64 * i;
+            if (nb < BN) *reinterpret_cast<V*>(Bb + nb * LDK + 8 * v) = rb[i];
+        }
+    };
+
+    f32x4 acc[NT][2];
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int fr = lane & 15, fq = lane >> 4;
+    if (nk > 0) {
+        load_global(0);
+        store_lds(0);
+    }
+    __syncthreads();
+    for (int kc = 0; kc < nk; ++kc) {
+        const int buf = kc & 1;
+        if (kc + 1 < nk) load_global(kc + 1);   // in flight while this chunk's MFMAs run
+        const T* Ab = As + buf * BM * LDK + (32 * wave + fr) * LDK + 8 * fq;
+        const T* Bb = Bs + buf * BN * LDK + fr * LDK + 8 * fq;
+        V af[2];
+        af[0] = *reinterpret_cast<const V*>(Ab);
+        af[1] = *reinterpret_cast<const V*>(Ab + 16 * LDK);
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            const V wf = *reinterpret_cast<const V*>(Bb + 16 * i * LDK);
+            mma32(acc[i][0], wf, af[0]);
+            mma32(acc[i][1], wf, af[1]);
+        }
+        if (kc + 1 < nk) store_lds(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue ------------------------------------------------------------------------------
+    T* __restrict__ O = reinterpret_cast<T*>(a.out);
+    const T* __restrict__ R = reinterpret_cast<const T*>(a.residual);
+    const T* __restrict__ EX = reinterpret_cast<const T*>(a.ex);
+    const bool want_sums = (a.stats != nullptr) || (EX != nullptr);
+    int64_t obase[2];
+    bool oval[2];
+#pragma unroll
+    for (int ms = 0; ms < 2; ++ms) {
+        const int m = mt * BM + 32 * wave + 16 * ms + fr;
+        oval[ms] = m < M;
+        const int mm = oval[ms] ? m : 0;
+        const int b = mm / HWq;
+        const int r = mm - b * HWq;
+        const int qy = r / g.Wq;
+        const int qx = r - qy * g.Wq;
+        obase[ms] = ((int64_t)(b * g.Hout + qy * g.osy + P.ooy) * g.Wout + qx * g.osx + P.oox) * g.ldo;
+    }
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        const int nl = 16 * i + 4 * fq;      // local channel of this lane's 4-vector
+        const int n = n0 + nl;
+        const bool nval = n < g.N;
+        float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+        if (nval) {
+            f32x4 bias = {0.f, 0.f, 0.f, 0.f};
+            if (a.bias) bias = *reinterpret_cast<const f32x4*>(a.bias + n);
+            f32x4 esc, esh, emu, ers;
+            if (EX) {
+                esc = *reinterpret_cast<const f32x4*>(a.ex_scale + n);
+                esh = *reinterpret_cast<const f32x4*>(a.ex_shift + n);
+                emu = *reinterpret_cast<const f32x4*>(a.ex_mean + n);
+                ers = *reinterpret_cast<const f32x4*>(a.ex_rstd + n);
+            }
+#pragma unroll
+            for (int ms = 0; ms < 2; ++ms) {
+                if (!oval[ms]) continue;
+                f32x4 vv = acc[i][ms];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) vv[r] += bias[r];
+                if (R) {
+                    const Q rr = *reinterpret_cast<const Q*>(R + obase[ms] + n);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) vv[r] += to_f(rr[r]);
+                }
+                if (EX) {
+                    const Q xe = *reinterpret_cast<const Q*>(EX + obase[ms] + n);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float xf = to_f(xe[r]);
+                        const float u = xf * esc[r] + esh[r];
+                        const float gv = vv[r] * act_grad(u, a.ex_slope);
+                        vv[r] = gv;
+                        s1[r] += gv;
+                        s2[r] += gv * ((xf - emu[r]) * ers[r]);
+                    }
+                } else if (a.stats) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        s1[r] += vv[r];
+                        s2[r] += vv[r] * vv[r];
+                    }
+                }
+                Q o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = (T)vv[r];
+                *reinterpret_cast<Q*>(O + obase[ms] + n) = o;
+            }
+        }
+        if (want_sums) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) {
+                    s1[r] += __shfl_xor(s1[r], o);
+                    s2[r] += __shfl_xor(s2[r], o);
+                }
+            }
+            if (fr == 0 && nval) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    atomicAdd(&ssum[nl + r], s1[r]);
+                    atomicAdd(&ssum[BN + nl + r], s2[r]);
+                }
+            }
+        }
+    }
+    if (want_sums) {
+        __syncthreads();
+        float* dst = EX ? a.bsums : a.stats;
+        for (int i = tid; i < 2 * BN; i += 256) {
+            const int which = i / BN, nl = i - which * BN;
+            if (n0 + nl < g.N) atomicAdd(dst + which * g.N + n0 + nl, ssum[i]);
+        }
+    }
+}
+
+template <typename T, int NT>
+int launch(const sv_geom* g, const sv_igemm_args* a, hipStream_t s) {
+    constexpr int BN = 16 * NT;
+    const int M = g->B * g->Hq * g->Wq;
+    const int nMt = (M + BM - 1) / BM;
+    const int nNt = (g->N + BN - 1) / BN;
+    const int grid = ((nMt + 7) / 8) * 8 * nNt * g->nphase;
+    const size_t lds = (size_t)2 * (BM + BN) * LDK * sizeof(T) + 2 * BN * sizeof(float);
+    sv_prof_begin(s);
+    hipLaunchKernelGGL((igemm_kernel<T, NT>), dim3(grid), dim3(256), lds, s, *g, *a);
+    sv_prof_end(s);
+    return sv_check_launch("sv_igemm");
+}
+
+}  // namespace
+
+extern "C" int sv_igemm(const sv_geom* g, int dtype, const sv_igemm_args* a, void* stream) {
+    SV_REQUIRE(g && a && a->x && a->w && a->out, SV_E_ARG, "sv_igemm: null argument");
+    SV_REQUIRE(dtype == SV_F32 || dtype == SV_BF16, SV_E_ARG, "sv_igemm: bad dtype %d", dtype);
+    SV_REQUIRE(g->Cin % 16 == 0 && g->N % 16 == 0 && g->ldx % 8 == 0 && g->ldo % 4 == 0, SV_E_SHAPE,
+               "sv_igemm: Cin=%d N=%d must be multiples of 16 (ldx=%d ldo=%d)", g->Cin, g->N, g->ldx, g->ldo);
+    SV_REQUIRE(g->nphase >= 1 && g->nphase <= SV_MAX_PHASES, SV_E_SHAPE, "sv_igemm: nphase=%d", g->nphase);
+    for (int p = 0; p < g->nphase; ++p)
+        SV_REQUIRE(g->phase[p].ntap >= 0 && g->phase[p].ntap <= SV_MAX_TAPS, SV_E_SHAPE, "sv_igemm: ntap");
+    SV_REQUIRE(!(a->stats && a->ex), SV_E_ARG, "sv_igemm: stats and ex epilogues are exclusive");
+    SV_REQUIRE(!a->ex || (a->ex_scale && a->ex_shift && a->ex_mean && a->ex_rstd && a->bsums), SV_E_ARG,
+               "sv_igemm: incomplete act-backward epilogue");
+    SV_REQUIRE(!a->pro_scale || a->pro_shift, SV_E_ARG, "sv_igemm: prologue shift missing");
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t M = (int64_t)g->B * g->Hq * g->Wq;
+    const int64_t mtiles = (M + BM - 1) / BM * g->nphase;
+    // widest channel tile that still yields >= 2 blocks per CU; never below 32 channels unless N is
+    const int N = g->N;
+    int nt = 1;
+    const int cand[4] = {8, 4, 2, 1};
+    for (int i = 0; i < 4; ++i) {
+        const int c = cand[i];
+        if (N % (16 * c) != 0) continue;
+        if (dtype == SV_F32 && c > 4) continue;     // LDS budget (<= 64 KiB without opt-in)
+        nt = c;
+        if (mtiles * (N / (16 * c)) >= 512) break;
+        if (c <= 2) break;
+    }
+    if (N % 80 == 0 && N % 64 != 0 && mtiles * (N / 80) >= 256 && dtype == SV_BF16) nt = 5;
+    if (dtype == SV_BF16) {
+        switch (nt) {
+            case 8: return launch<bf16, 8>(g, a, s);
+            case 5: return launch<bf16, 5>(g, a, s);
+            case 4: return launch<bf16, 4>(g, a, s);
+            case 2: return launch<bf16, 2>(g, a, s);
+            default: return launch<bf16, 1>(g, a, s);
+        }
+    }
+    switch (nt) {
+        case 4: return launch<float, 4>(g, a, s);
+        case 2: return launch<float, 2>(g, a, s);
+        default: return launch<float, 1>(g, a, s);
+    }
+}

@@ -1,0 +1,87 @@
+// Host-side runtime glue of libshotvae_hip.so: error reporting and in-situ kernel timing.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <vector>
+
+#include "common.h"
+
+static thread_local char g_err[512] = "";
+
+void sv_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int sv_check_launch(const char* what) {
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        sv_set_error("%s: HIP error %d (%s)", what, (int)e, hipGetErrorString(e));
+        return SV_E_HIP;
+    }
+    return SV_OK;
+}
+
+namespace {
+struct Rec { hipEvent_t a, b; int tag; };
+int g_prof_on = 0, g_tag = 0;
+std::vector<Rec> g_recs;
+std::vector<Rec> g_pool;
+constexpr size_t kMaxRecs = 1 << 17;
+}  // namespace
+
+void sv_prof_begin(hipStream_t s) {
+    if (!g_prof_on || g_recs.size() >= kMaxRecs) return;
+    Rec r;
+    if (!g_pool.empty()) {
+        r = g_pool.back();
+        g_pool.pop_back();
+    } else {
+        if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
+    }
+    r.tag = g_tag;
+    hipEventRecord(r.a, s);
+    g_recs.push_back(r);
+}
+
+void sv_prof_end(hipStream_t s) {
+    if (!g_prof_on || g_recs.empty()) return;
+    hipEventRecord(g_recs.back().b, s);
+}
+
+extern "C" {
+
+int sv_prof_enable(int on) {
+    g_prof_on = on ? 1 : 0;
+    return SV_OK;
+}
+
+int sv_prof_tag(int tag) {
+    g_tag = tag;
+    return SV_OK;
+}
+
+int sv_prof_collect(int max_tags, double* ms, int* count) {
+    if (hipDeviceSynchronize() != hipSuccess) return sv_check_launch("sv_prof_collect");
+    for (int i = 0; i < max_tags; ++i) { ms[i] = 0.0; count[i] = 0; }
+    for (Rec& r : g_recs) {
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, r.a, r.b) == hipSuccess && r.tag >= 0 && r.tag < max_tags) {
+            ms[r.tag] += t;
+            count[r.tag] += 1;
+        }
+        g_pool.push_back(r);
+    }
+    g_recs.clear();
+    (void)hipGetLastError();
+    return SV_OK;
+}
+
+int sv_version(void) { return SV_ABI_VERSION; }
+
+const char* sv_last_error(void) { return g_err; }
+
+}  // extern "C"

@@ -1,0 +1,853 @@
+// Small fused kernels of the SHOT-VAE step (everything that is not a conv-like GEMM).  gfx950.
+#include "common.h"
+
+namespace {
+
+template <typename T> struct DT;
+template <> struct DT<float> { static constexpr int id = SV_F32; };
+template <> struct DT<bf16> { static constexpr int id = SV_BF16; };
+
+// block-wide sum of `v` (blockDim multiple of 64, <= 1024); result valid in thread 0
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    float t = 0.f;
+    if (threadIdx.x == 0)
+        for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += red[i];
+    return t;
+}
+
+// ---------------------------------------------------------------------------------------- BatchNorm
+__global__ void bn_finalize_kernel(const float* stats, int C, float count, const float* gamma,
+                                   const float* beta, float eps, float momentum, float* rm, float* rv,
+                                   float* scale, float* shift, float* mean, float* rstd) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float mu = stats[c] / count;
+    float var = stats[C + c] / count - mu * mu;
+    var = var > 0.f ? var : 0.f;
+    const float rs = rsqrtf(var + eps);
+    const float sc = gamma[c] * rs;
+    scale[c] = sc;
+    shift[c] = beta[c] - mu * sc;
+    mean[c] = mu;
+    rstd[c] = rs;
+    if (rm) {
+        rm[c] = (1.f - momentum) * rm[c] + momentum * mu;
+        const float unb = count > 1.f ? var * count / (count - 1.f) : var;
+        rv[c] = (1.f - momentum) * rv[c] + momentum * unb;
+    }
+}
+
+__global__ void bn_eval_affine_kernel(int C, const float* gamma, const float* beta, const float* rm,
+                                      const float* rv, float eps, float* scale, float* shift) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float sc = gamma[c] * rsqrtf(rv[c] + eps);
+    scale[c] = sc;
+    shift[c] = beta[c] - rm[c] * sc;
+}
+
+struct bnb_params {
+    int64_t M;
+    int C, ld, nbranch;
+    const void* x;
+    const float* mean;
+    const float* rstd;
+    float inv_count;
+    sv_bn_branch br[2];
+    const void* residual;
+    void* dx;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bnb_params p) {
+    typedef typename V8<T>::type V;
+    const int cv = p.C / 8;                       // vectors per row
+    const int64_t total = p.M * cv;
+    const T* X = reinterpret_cast<const T*>(p.x);
+    const T* R = reinterpret_cast<const T*>(p.residual);
+    T* DX = reinterpret_cast<T*>(p.dx);
+    if (blockIdx.x == 0) {
+        for (int c = threadIdx.x; c < p.C; c += blockDim.x)
+            for (int k = 0; k < p.nbranch; ++k) {
+                if (p.br[k].dbeta) p.br[k].dbeta[c] += p.br[k].bsums[c];
+                if (p.br[k].dgamma) p.br[k].dgamma[c] += p.br[k].bsums[p.C + c];
+            }
+    }
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t m = i / cv;
+        const int c = (int)(i - m * cv) * 8;
+        const int64_t off = m * p.ld + c;
+        const V xv = *reinterpret_cast<const V*>(X + off);
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = 0.f;
+        for (int k = 0; k < p.nbranch; ++k) {
+            const V gv = *reinterpret_cast<const V*>(reinterpret_cast<const T*>(p.br[k].g) + off);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float rs = p.rstd[c + j];
+                const float xh = (to_f(xv[j]) - p.mean[c + j]) * rs;
+                const float m1 = p.br[k].bsums[c + j] * p.inv_count;
+                const float m2 = p.br[k].bsums[p.C + c + j] * p.inv_count;
+                o[j] += p.br[k].gamma[c + j] * rs * (to_f(gv[j]) - m1 - xh * m2);
+            }
+        }
+        if (R) {
+            const V rv = *reinterpret_cast<const V*>(R + off);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] += to_f(rv[j]);
+        }
+        V ov;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ov[j] = (T)o[j];
+        *reinterpret_cast<V*>(DX + off) = ov;
+    }
+}
+
+template <typename T>
+__global__ void colsum_kernel(const T* y, int64_t M, int N, int ld, float* out) {
+    // thread (n, slice): blockDim = (N<=64 ? N : 64, 256/that)
+    const int n = blockIdx.y * blockDim.x + threadIdx.x;
+    const int64_t rows_per_block = (M + gridDim.x - 1) / gridDim.x;
+    const int64_t m0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t m1 = m0 + rows_per_block < M ? m0 + rows_per_block : M;
+    float s = 0.f;
+    if (n < N)
+        for (int64_t m = m0 + threadIdx.y; m < m1; m += blockDim.y) s += to_f(y[m * ld + n]);
+    __shared__ float red[256];
+    red[threadIdx.y * blockDim.x + threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.y == 0 && n < N) {
+        float t = 0.f;
+        for (int k = 0; k < (int)blockDim.y; ++k) t += red[k * blockDim.x + threadIdx.x];
+        atomicAdd(out + n, t);
+    }
+}
+
+// ---------------------------------------------------------------------------------------- pool
+template <typename T>
+__global__ void pool_fwd_kernel(const T* x, const float* scale, const float* shift, float slope, int B,
+                                int HW, int C, int ld, float* feat) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * C) return;
+    const int b = idx / C, c = idx - b * C;
+    const float sc = scale[c], sh = shift[c];
+    const T* px = x + (int64_t)b * HW * ld + c;
+    float s = 0.f;
+    for (int p = 0; p < HW; ++p) s += act_fwd(to_f(px[(int64_t)p * ld]) * sc + sh, slope);
+    feat[idx] = s / (float)HW;
+}
+
+template <typename T>
+__global__ void pool_bwd_kernel(const T* x, const float* scale, const float* shift, float slope,
+                                const float* mean, const float* rstd, const float* dfeat, int B, int HW,
+                                int C, int ld, T* g, float* bsums) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * C) return;
+    const int b = idx / C, c = idx - b * C;
+    const float sc = scale[c], sh = shift[c], mu = mean[c], rs = rstd[c];
+    const float d = dfeat[idx] / (float)HW;
+    const T* px = x + (int64_t)b * HW * ld + c;
+    T* pg = g + (int64_t)b * HW * ld + c;
+    float s1 = 0.f, s2 = 0.f;
+    for (int p = 0; p < HW; ++p) {
+        const float xf = to_f(px[(int64_t)p * ld]);
+        const float gv = d * act_grad(xf * sc + sh, slope);
+        pg[(int64_t)p * ld] = (T)gv;
+        s1 += gv;
+        s2 += gv * ((xf - mu) * rs);
+    }
+    atomicAdd(bsums + c, s1);
+    atomicAdd(bsums + C + c, s2);
+}
+
+// ---------------------------------------------------------------------------------------- heads
+constexpr int HS = 8;   // samples per block
+
+__global__ __launch_bounds__(256) void head_fwd_kernel(const float* feat, int B, int C, const float* W,
+                                                       const float* bias, int ldc, int K, float* mu,
+                                                       float* ls, float* la) {
+    extern __shared__ __attribute__((aligned(16))) float hs[];
+    const int NH = 2 * ldc + K;
+    float* f = hs;               // [HS][C]
+    float* o = hs + HS * C;      // [HS][NH]
+    const int b0 = blockIdx.x * HS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < HS * C; i += 256) {
+        const int s = i / C;
+        f[i] = (b0 + s < B) ? feat[(int64_t)(b0 + s) * C + (i - s * C)] : 0.f;
+    }
+    __syncthreads();
+    for (int n = wave; n < NH; n += 4) {
+        float acc[HS];
+#pragma unroll
+        for (int s = 0; s < HS; ++s) acc[s] = 0.f;
+        for (int k = lane; k < C; k += 64) {
+            const float w = W[(int64_t)n * C + k];
+#pragma unroll
+            for (int s = 0; s < HS; ++s) acc[s] += w * f[s * C + k];
+        }
+#pragma unroll
+        for (int s = 0; s < HS; ++s) acc[s] = wave_sum(acc[s]);
+        if (lane == 0) {
+            const float bb = bias[n];
+#pragma unroll
+            for (int s = 0; s < HS; ++s) o[s * NH + n] = acc[s] + bb;
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < HS * 2 * ldc; i += 256) {
+        const int s = i / (2 * ldc), j = i - s * 2 * ldc;
+        if (b0 + s >= B) continue;
+        if (j < ldc) mu[(int64_t)(b0 + s) * ldc + j] = o[s * NH + j];
+        else ls[(int64_t)(b0 + s) * ldc + (j - ldc)] = o[s * NH + j];
+    }
+    // log-softmax over the last K outputs: one wave per sample, two samples per wave
+    for (int s = wave; s < HS; s += 4) {
+        if (b0 + s >= B) continue;
+        const float* z = o + s * NH + 2 * ldc;
+        float mx = -INFINITY;
+        for (int k = lane; k < K; k += 64) mx = fmaxf(mx, z[k]);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+        float se = 0.f;
+        for (int k = lane; k < K; k += 64) se += expf(z[k] - mx);
+        se = wave_sum(se);
+        const float lse = mx + logf(se);
+        for (int k = lane; k < K; k += 64) la[(int64_t)(b0 + s) * K + k] = z[k] - lse;
+    }
+}
+
+// dout[b][n] = upstream gradient w.r.t. the pre-log-softmax head outputs; dfeat = dout * W
+__global__ __launch_bounds__(256) void head_bwd_data_kernel(int B, int C, const float* W, int ldc, int K,
+                                                            const float* la, const float* dmu,
+                                                            const float* dls, const float* dla,
+                                                            float* dfeat, float* dout) {
+    extern __shared__ __attribute__((aligned(16))) float hs[];
+    const int NH = 2 * ldc + K;
+    float* d = hs;   // [HS][NH]
+    const int b0 = blockIdx.x * HS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < HS * 2 * ldc; i += 256) {
+        const int s = i / (2 * ldc), j = i - s * 2 * ldc;
+        float v = 0.f;
+        if (b0 + s < B) v = j < ldc ? dmu[(int64_t)(b0 + s) * ldc + j] : dls[(int64_t)(b0 + s) * ldc + j - ldc];
+        d[s * NH + j] = v;
+    }
+    for (int s = wave; s < HS; s += 4) {
+        float* dz = d + s * NH + 2 * ldc;
+        if (b0 + s >= B) {
+            for (int k = lane; k < K; k += 64) dz[k] = 0.f;
+            continue;
+        }
+        const float* g = dla + (int64_t)(b0 + s) * K;
+        const float* l = la + (int64_t)(b0 + s) * K;
+        float sg = 0.f;
+        for (int k = lane; k < K; k += 64) sg += g[k];
+        sg = wave_sum(sg);
+        for (int k = lane; k < K; k += 64) dz[k] = g[k] - expf(l[k]) * sg;
+    }
+    __syncthreads();
+    for (int i = tid; i < HS * NH; i += 256) {
+        const int s = i / NH;
+        if (b0 + s < B) dout[(int64_t)(b0 + s) * NH + (i - s * NH)] = d[i];
+    }
+    for (int c = tid; c < C; c += 256) {
+        float acc[HS];
+#pragma unroll
+        for (int s = 0; s < HS; ++s) acc[s] = 0.f;
+        for (int n = 0; n < NH; ++n) {
+            const float w = W[(int64_t)n * C + c];
+#pragma unroll
+            for (int s = 0; s < HS; ++s) acc[s] += w * d[s * NH + n];
+        }
+#pragma unroll
+        for (int s = 0; s < HS; ++s)
+            if (b0 + s < B) dfeat[(int64_t)(b0 + s) * C + c] = acc[s];
+    }
+}
+
+// dW[n][c] += sum_b dout[b][n]*feat[b][c];  dbias[n] += sum_b dout[b][n].  grid = NH blocks.
+__global__ __launch_bounds__(256) void head_bwd_weight_kernel(const float* feat, const float* dout, int B,
+                                                              int C, int NH, float* dW, float* dbias) {
+    const int n = blockIdx.x;
+    const int tid = threadIdx.x;
+    __shared__ float red[4];
+    float sb = 0.f;
+    for (int b = tid; b < B; b += 256) sb += dout[(int64_t)b * NH + n];
+    sb = block_sum(sb, red);
+    if (tid == 0) dbias[n] += sb;
+    for (int c = tid; c < C; c += 256) {
+        float acc = 0.f;
+        for (int b = 0; b < B; ++b) acc += dout[(int64_t)b * NH + n] * feat[(int64_t)b * C + c];
+        dW[(int64_t)n * C + c] += acc;
+    }
+}
+
+// ---------------------------------------------------------------------------------------- sampler
+template <typename T>
+__global__ __launch_bounds__(128) void sample_fwd_kernel(const float* mu, const float* ls, const float* la,
+                                                         const float* eps, const float* u,
+                                                         const int64_t* label, const int64_t* label_mix,
+                                                         float lam, int mode, float temperature, int B,
+                                                         int ldc, int K, int Lpad, T* latent, float* csoft) {
+    const int b = blockIdx.x, tid = threadIdx.x;
+    __shared__ float red[2];
+    __shared__ float bc[2];
+    T* out = latent + (int64_t)b * Lpad;
+    for (int j = tid; j < ldc; j += 128) {
+        const int64_t i = (int64_t)b * ldc + j;
+        out[j] = (T)(mu[i] + expf(ls[i]) * eps[i]);
+    }
+    for (int j = ldc + K + tid; j < Lpad; j += 128) out[j] = (T)0.f;
+    if (mode == 0) {
+        const float EPS = 1e-12f;
+        // K <= 128 handled one class per thread (K up to 1024 via the strided loops)
+        float mx = -INFINITY;
+        for (int k = tid; k < K; k += 128) {
+            const float gum = -logf(-logf(u[(int64_t)b * K + k] + EPS) + EPS);
+            mx = fmaxf(mx, (la[(int64_t)b * K + k] + gum) / temperature);
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+        if ((tid & 63) == 0) red[tid >> 6] = mx;
+        __syncthreads();
+        mx = fmaxf(red[0], red[1]);
+        float se = 0.f;
+        for (int k = tid; k < K; k += 128) {
+            const float gum = -logf(-logf(u[(int64_t)b * K + k] + EPS) + EPS);
+            se += expf((la[(int64_t)b * K + k] + gum) / temperature - mx);
+        }
+        se = wave_sum(se);
+        if ((tid & 63) == 0) bc[tid >> 6] = se;
+        __syncthreads();
+        se = bc[0] + bc[1];
+        for (int k = tid; k < K; k += 128) {
+            const float gum = -logf(-logf(u[(int64_t)b * K + k] + EPS) + EPS);
+            const float c = expf((la[(int64_t)b * K + k] + gum) / temperature - mx) / se;
+            out[ldc + k] = (T)c;
+            csoft[(int64_t)b * K + k] = c;
+        }
+    } else {
+        const int la_ = (int)label[b];
+        const int lb_ = mode == 2 ? (int)label_mix[b] : -1;
+        for (int k = tid; k < K; k += 128) {
+            float c = (k == la_) ? 1.f : 0.f;
+            if (mode == 2) c = lam * c + (1.f - lam) * ((k == lb_) ? 1.f : 0.f);
+            out[ldc + k] = (T)c;
+            csoft[(int64_t)b * K + k] = c;
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(128) void sample_bwd_kernel(const T* dlatent, const float* ls, const float* eps,
+                                                         const float* csoft, int mode, float temperature,
+                                                         int B, int ldc, int K, int Lpad, float* dmu,
+                                                         float* dls, float* dla) {
+    const int b = blockIdx.x, tid = threadIdx.x;
+    __shared__ float bc[2];
+    const T* d = dlatent + (int64_t)b * Lpad;
+    for (int j = tid; j < ldc; j += 128) {
+        const int64_t i = (int64_t)b * ldc + j;
+        const float dz = to_f(d[j]);
+        dmu[i] += dz;
+        dls[i] += dz * eps[i] * expf(ls[i]);
+    }
+    if (mode == 0) {
+        float s = 0.f;
+        for (int k = tid; k < K; k += 128) s += csoft[(int64_t)b * K + k] * to_f(d[ldc + k]);
+        s = wave_sum(s);
+        if ((tid & 63) == 0) bc[tid >> 6] = s;
+        __syncthreads();
+        s = bc[0] + bc[1];
+        for (int k = tid; k < K; k += 128) {
+            const float c = csoft[(int64_t)b * K + k];
+            dla[(int64_t)b * K + k] += c * (to_f(d[ldc + k]) - s) / temperature;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------- losses
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+
+__global__ __launch_bounds__(256) void elbo_fwd_kernel(const float* x, const float* xr, int64_t n_img,
+                                                       const float* mu, const float* ls, const float* la,
+                                                       int B, int ldc, int K, int bce, float x_sigma,
+                                                       float log_prior, float* out3) {
+    __shared__ float red[4];
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    float s = 0.f;
+    const int64_t n4 = n_img / 4;
+    const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
+    const f32x4* r4 = reinterpret_cast<const f32x4*>(xr);
+    for (int64_t i = t0; i < n4; i += stride) {
+        const f32x4 a = x4[i], r = r4[i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (bce) s += fmaxf(r[j], 0.f) - r[j] * a[j] + log1pf(expf(-fabsf(r[j])));
+            else { const float d = sigmoidf_(r[j]) - a[j]; s += d * d; }
+        }
+    }
+    for (int64_t i = n4 * 4 + t0; i < n_img; i += stride) {
+        const float a = x[i], r = xr[i];
+        if (bce) s += fmaxf(r, 0.f) - r * a + log1pf(expf(-fabsf(r)));
+        else { const float d = sigmoidf_(r) - a; s += d * d; }
+    }
+    float kc = 0.f, kd = 0.f;
+    for (int64_t i = t0; i < (int64_t)B * ldc; i += stride) {
+        const float m = mu[i], l2 = 2.f * ls[i];
+        kc += m * m + expf(l2) - l2 - 1.f;
+    }
+    for (int64_t i = t0; i < (int64_t)B * K; i += stride) {
+        const float l = la[i];
+        kd += expf(l) * (l - log_prior);
+    }
+    const float rs = bce ? 1.f / (float)B : 1.f / (2.f * (float)B * x_sigma * x_sigma);
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) atomicAdd(out3, s * rs);
+    kc = block_sum(kc, red);
+    if (threadIdx.x == 0 && kc != 0.f) atomicAdd(out3 + 1, 0.5f * kc / (float)B);
+    kd = block_sum(kd, red);
+    if (threadIdx.x == 0 && kd != 0.f) atomicAdd(out3 + 2, kd / (float)B);
+}
+
+__global__ __launch_bounds__(256) void elbo_bwd_kernel(const float* x, const float* xr, int64_t n_img,
+                                                       const float* mu, const float* ls, const float* la,
+                                                       int B, int ldc, int K, int bce, float x_sigma,
+                                                       float log_prior, const float* gout3, float* dxr,
+                                                       float* dmu, float* dls, float* dla) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const float g0 = gout3[0], g1 = gout3[1], g2 = gout3[2];
+    const float rs = g0 * (bce ? 1.f / (float)B : 1.f / ((float)B * x_sigma * x_sigma));
+    for (int64_t i = t0; i < n_img; i += stride) {
+        const float sg = sigmoidf_(xr[i]);
+        const float d = sg - x[i];
+        dxr[i] = bce ? rs * d : rs * d * sg * (1.f - sg);
+    }
+    const float c1 = g1 / (float)B, c2 = g2 / (float)B;
+    for (int64_t i = t0; i < (int64_t)B * ldc; i += stride) {
+        dmu[i] = c1 * mu[i];
+        dls[i] = c1 * (expf(2.f * ls[i]) - 1.f);
+    }
+    for (int64_t i = t0; i < (int64_t)B * K; i += stride) {
+        const float l = la[i];
+        dla[i] = c2 * expf(l) * (l - log_prior + 1.f);
+    }
+}
+
+__global__ __launch_bounds__(256) void cls_fwd_kernel(const float* pred, const float* label, const float* w,
+                                                      int B, int K, float* out) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < (int64_t)B * K; i += (int64_t)gridDim.x * 256)
+        s += pred[i] * label[i] * (w ? w[i / K] : 1.f);
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) atomicAdd(out, -s / (float)B);
+}
+__global__ void cls_bwd_kernel(const float* label, const float* w, int B, int K, const float* gout, float* dp) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < (int64_t)B * K) dp[i] = -gout[0] * label[i] * (w ? w[i / K] : 1.f) / (float)B;
+}
+
+__global__ __launch_bounds__(256) void post_fwd_kernel(const float* mu, const float* ls, const float* mt,
+                                                       const float* st, int B, int D, float* out) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < (int64_t)B * D; i += (int64_t)gridDim.x * 256) {
+        const float a = mu[i] - mt[i], b = expf(ls[i]) - st[i];
+        s += a * a + b * b;
+    }
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) atomicAdd(out, s / (float)B);
+}
+__global__ void post_bwd_kernel(const float* mu, const float* ls, const float* mt, const float* st, int B,
+                                int D, const float* gout, float* dmu, float* dls) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)B * D) return;
+    const float g = gout[0] * 2.f / (float)B;
+    const float e = expf(ls[i]);
+    dmu[i] = g * (mu[i] - mt[i]);
+    dls[i] = g * (e - st[i]) * e;
+}
+
+// ---------------------------------------------------------------------------------------- mixup
+__global__ void mix_lerp_kernel(const float* a, const int64_t* index, float lam, int B, int64_t row,
+                                int exp_space, float* out) {
+    const int b = blockIdx.y;
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= row) return;
+    const int64_t src = index[b];
+    float p = a[(int64_t)b * row + j], q = a[src * row + j];
+    if (exp_space) { p = expf(p); q = expf(q); }
+    out[(int64_t)b * row + j] = lam * p + (1.f - lam) * q;
+}
+
+// pairwise Gaussian KL(N_i || N_j), second-smallest per row (torch.topk(k=2, largest=False)[:,1])
+__global__ __launch_bounds__(256) void optimal_match_kernel(const float* mu, const float* ls, int B, int D,
+                                                            int64_t* index) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* mi = sm;           // [D]
+    float* vi = sm + D;       // [D] sigma_i^2
+    float* kl = sm + 2 * D;   // [B]
+    const int i = blockIdx.x, tid = threadIdx.x;
+    float lsum_i = 0.f;
+    for (int d = tid; d < D; d += 256) {
+        mi[d] = mu[(int64_t)i * D + d];
+        vi[d] = expf(2.f * ls[(int64_t)i * D + d]);
+    }
+    __syncthreads();
+    for (int d = 0; d < D; ++d) lsum_i += ls[(int64_t)i * D + d];
+    for (int j = tid; j < B; j += 256) {
+        float acc = 0.f, lsum_j = 0.f;
+        for (int d = 0; d < D; ++d) {
+            const float l = ls[(int64_t)j * D + d];
+            const float iv = expf(-2.f * l);
+            const float dm = mi[d] - mu[(int64_t)j * D + d];
+            acc += 0.5f * (vi[d] + dm * dm) * iv;
+            lsum_j += l;
+        }
+        kl[j] = (lsum_j - lsum_i) + acc - 0.5f * (float)D;
+    }
+    __syncthreads();
+    if (tid < 64) {
+        // wave 0: two argmin passes
+        int skip = -1, best = -1;
+        for (int pass = 0; pass < 2; ++pass) {
+            float bv = INFINITY;
+            int bi = 0x7fffffff;
+            for (int j = tid; j < B; j += 64)
+                if (j != skip && (kl[j] < bv || (kl[j] == bv && j < bi))) { bv = kl[j]; bi = j; }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const float ov = __shfl_xor(bv, off);
+                const int oi = __shfl_xor(bi, off);
+                if (ov < bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+            }
+            skip = bi;
+            best = bi;
+        }
+        if (tid == 0) index[i] = best;
+    }
+}
+
+// ---------------------------------------------------------------------------------------- SGD
+__global__ __launch_bounds__(256) void sgd_kernel(float* p, const float* g, float* v, int64_t n, float lr,
+                                                  float momentum, float wd, float gscale, int first) {
+    const int64_t n4 = n / 4;
+    f32x4* p4 = reinterpret_cast<f32x4*>(p);
+    const f32x4* g4 = reinterpret_cast<const f32x4*>(g);
+    f32x4* v4 = reinterpret_cast<f32x4*>(v);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        f32x4 pp = p4[i], gg = g4[i], vv = v4[i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float d = gg[j] * gscale + wd * pp[j];
+            vv[j] = first ? d : momentum * vv[j] + d;
+            pp[j] -= lr * vv[j];
+        }
+        p4[i] = pp;
+        v4[i] = vv;
+    }
+    if (blockIdx.x == 0)
+        for (int64_t i = n4 * 4 + threadIdx.x; i < n; i += 256) {
+            const float d = g[i] * gscale + wd * p[i];
+            v[i] = first ? d : momentum * v[i] + d;
+            p[i] -= lr * v[i];
+        }
+}
+
+// ---------------------------------------------------------------------------------------- layout
+template <typename T>
+__global__ void nchw_to_nhwc_kernel(const float* in, int B, int C, int HW, int Cpad, T* out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // over B*HW*Cpad
+    if (i >= (int64_t)B * HW * Cpad) return;
+    const int c = (int)(i % Cpad);
+    const int64_t bp = i / Cpad;
+    const int64_t b = bp / HW, p = bp - b * HW;
+    out[i] = (T)(c < C ? in[(b * C + c) * HW + p] : 0.f);
+}
+template <typename T>
+__global__ void nhwc_to_nchw_kernel(const T* in, int B, int C, int HW, int ld, float* out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // over B*C*HW
+    if (i >= (int64_t)B * C * HW) return;
+    const int64_t p = i % HW;
+    const int64_t bc = i / HW;
+    const int64_t b = bc / C, c = bc - b * C;
+    out[i] = to_f(in[(b * HW + p) * ld + c]);
+}
+
+struct repack_params {
+    int N, T_orig, C, transpose, nphase;
+    int ntap[SV_MAX_PHASES];
+    int64_t w_off[SV_MAX_PHASES], size[SV_MAX_PHASES];
+    int8_t torig[SV_MAX_PHASES][SV_MAX_TAPS];
+};
+template <typename T>
+__global__ void repack_kernel(const float* master, const repack_params p, T* dst) {
+    // dst rows n' (= N or C when transposed), cols [ntap][c'] per phase
+    const int ph = blockIdx.y;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= p.size[ph]) return;
+    const int cp = p.transpose ? p.N : p.C;   // inner (c') extent
+    const int nt = p.ntap[ph];
+    const int c1 = (int)(i % cp);
+    const int t = (int)((i / cp) % nt);
+    const int n1 = (int)(i / ((int64_t)cp * nt));
+    const int n = p.transpose ? c1 : n1, c = p.transpose ? n1 : c1;
+    int to = 0;
+#pragma unroll
+    for (int k = 0; k < SV_MAX_TAPS; ++k)
+        if (k == t) to = p.torig[ph][k];
+    dst[p.w_off[ph] + i] = (T)master[((int64_t)n * p.T_orig + to) * p.C + c];
+}
+
+inline int nblocks(int64_t n, int bs, int cap = 2048) {
+    int64_t b = (n + bs - 1) / bs;
+    if (b < 1) b = 1;
+    return (int)(b > cap ? cap : b);
+}
+
+}  // namespace
+
+#define DISPATCH_T(dtype, ...)                          \
+    do {                                                \
+        if ((dtype) == SV_BF16) { typedef bf16 T; __VA_ARGS__; } \
+        else if ((dtype) == SV_F32) { typedef float T; __VA_ARGS__; } \
+        else { sv_set_error("bad dtype %d", (int)(dtype)); return SV_E_ARG; } \
+    } while (0)
+
+extern "C" {
+
+int sv_bn_finalize(const float* stats, int C, float count, const float* gamma, const float* beta, float eps,
+                   float momentum, float* rm, float* rv, float* scale, float* shift, float* mean,
+                   float* rstd, void* stream) {
+    SV_REQUIRE(stats && gamma && beta && scale && shift && mean && rstd && C > 0, SV_E_ARG, "sv_bn_finalize: null");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, stats, C,
+                       count, gamma, beta, eps, momentum, rm, rv, scale, shift, mean, rstd);
+    return sv_check_launch("sv_bn_finalize");
+}
+
+int sv_bn_eval_affine(int C, const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
+                      float* scale, float* shift, void* stream) {
+    SV_REQUIRE(gamma && beta && rm && rv && scale && shift && C > 0, SV_E_ARG, "sv_bn_eval_affine: null");
+    hipLaunchKernelGGL(bn_eval_affine_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, C, gamma,
+                       beta, rm, rv, eps, scale, shift);
+    return sv_check_launch("sv_bn_eval_affine");
+}
+
+int sv_bn_bwd_apply(int dtype, int64_t M, int C, int ld, const void* x, const float* mean, const float* rstd,
+                    float count, const sv_bn_branch* br, int nbranch, const void* residual, void* dx,
+                    void* stream) {
+    SV_REQUIRE(x && mean && rstd && br && dx && nbranch >= 1 && nbranch <= 2, SV_E_ARG, "sv_bn_bwd_apply: bad args");
+    SV_REQUIRE(C % 8 == 0 && ld % 8 == 0, SV_E_SHAPE, "sv_bn_bwd_apply: C=%d ld=%d must be multiples of 8", C, ld);
+    bnb_params p;
+    p.M = M; p.C = C; p.ld = ld; p.nbranch = nbranch; p.x = x; p.mean = mean; p.rstd = rstd;
+    p.inv_count = 1.f / count; p.residual = residual; p.dx = dx;
+    for (int k = 0; k < nbranch; ++k) {
+        p.br[k] = br[k];
+        SV_REQUIRE(br[k].g && br[k].bsums && br[k].gamma, SV_E_ARG, "sv_bn_bwd_apply: branch %d incomplete", k);
+    }
+    const int grid = nblocks(M * (C / 8), 256);
+    DISPATCH_T(dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p));
+    return sv_check_launch("sv_bn_bwd_apply");
+}
+
+int sv_colsum(int dtype, const void* y, int64_t M, int N, int ld, float* out, void* stream) {
+    SV_REQUIRE(y && out && N > 0, SV_E_ARG, "sv_colsum: null");
+    const int bx = N < 64 ? N : 64;
+    SV_REQUIRE(256 % bx == 0, SV_E_SHAPE, "sv_colsum: N=%d", N);
+    dim3 block(bx, 256 / bx);
+    dim3 grid(nblocks(M, 1024, 512), (N + bx - 1) / bx);
+    DISPATCH_T(dtype, hipLaunchKernelGGL((colsum_kernel<T>), grid, block, 0, (hipStream_t)stream, (const T*)y, M, N, ld, out));
+    return sv_check_launch("sv_colsum");
+}
+
+int sv_pool_fwd(int dtype, const void* x, const float* scale, const float* shift, float slope, int B, int HW,
+                int C, int ld, float* feat, void* stream) {
+    SV_REQUIRE(x && scale && shift && feat, SV_E_ARG, "sv_pool_fwd: null");
+    DISPATCH_T(dtype, hipLaunchKernelGGL((pool_fwd_kernel<T>), dim3((B * C + 255) / 256), dim3(256), 0,
+                                         (hipStream_t)stream, (const T*)x, scale, shift, slope, B, HW, C, ld, feat));
+    return sv_check_launch("sv_pool_fwd");
+}
+
+int sv_pool_bwd(int dtype, const void* x, const float* scale, const float* shift, float slope, const float* mean,
+                const float* rstd, const float* dfeat, int B, int HW, int C, int ld, void* g, float* bsums,
+                void* stream) {
+    SV_REQUIRE(x && scale && shift && mean && rstd && dfeat && g && bsums, SV_E_ARG, "sv_pool_bwd: null");
+    DISPATCH_T(dtype, hipLaunchKernelGGL((pool_bwd_kernel<T>), dim3((B * C + 255) / 256), dim3(256), 0,
+                                         (hipStream_t)stream, (const T*)x, scale, shift, slope, mean, rstd, dfeat,
+                                         B, HW, C, ld, (T*)g, bsums));
+    return sv_check_launch("sv_pool_bwd");
+}
+
+int sv_head_fwd(const float* feat, int B, int C, const float* W, const float* bias, int ldc, int K, float* mu,
+                float* ls, float* la, void* stream) {
+    SV_REQUIRE(feat && W && bias && mu && ls && la, SV_E_ARG, "sv_head_fwd: null");
+    const size_t lds = (size_t)HS * (C + 2 * ldc + K) * sizeof(float);
+    SV_REQUIRE(lds <= 64 * 1024, SV_E_SHAPE, "sv_head_fwd: C=%d too large", C);
+    hipLaunchKernelGGL(head_fwd_kernel, dim3((B + HS - 1) / HS), dim3(256), lds, (hipStream_t)stream, feat, B, C, W,
+                       bias, ldc, K, mu, ls, la);
+    return sv_check_launch("sv_head_fwd");
+}
+
+int sv_head_bwd(const float* feat, int B, int C, const float* W, int ldc, int K, const float* la,
+                   const float* dmu, const float* dls, const float* dla, float* dfeat, float* dW, float* dbias,
+                   float* dout_ws, void* stream) {
+    SV_REQUIRE(feat && W && la && dmu && dls && dla && dfeat && dW && dbias && dout_ws, SV_E_ARG, "sv_head_bwd: null");
+    const int NH = 2 * ldc + K;
+    const size_t lds = (size_t)HS * NH * sizeof(float);
+    hipLaunchKernelGGL(head_bwd_data_kernel, dim3((B + HS - 1) / HS), dim3(256), lds, (hipStream_t)stream, B, C, W,
+                       ldc, K, la, dmu, dls, dla, dfeat, dout_ws);
+    hipLaunchKernelGGL(head_bwd_weight_kernel, dim3(NH), dim3(256), 0, (hipStream_t)stream, feat, dout_ws, B, C, NH,
+                       dW, dbias);
+    return sv_check_launch("sv_head_bwd");
+}
+
+int sv_sample_fwd(int dtype, const float* mu, const float* ls, const float* la, const float* eps, const float* u,
+                  const int64_t* label, const int64_t* label_mix, float lam, int mode, float temperature, int B,
+                  int ldc, int K, int Lpad, void* latent, float* csoft, void* stream) {
+    SV_REQUIRE(mu && ls && la && eps && latent && csoft, SV_E_ARG, "sv_sample_fwd: null");
+    SV_REQUIRE((mode == 0 && u) || (mode == 1 && label) || (mode == 2 && label && label_mix), SV_E_ARG,
+               "sv_sample_fwd: mode %d inputs missing", mode);
+    SV_REQUIRE(Lpad >= ldc + K, SV_E_SHAPE, "sv_sample_fwd: Lpad");
+    DISPATCH_T(dtype, hipLaunchKernelGGL((sample_fwd_kernel<T>), dim3(B), dim3(128), 0, (hipStream_t)stream, mu, ls,
+                                         la, eps, u, label, label_mix, lam, mode, temperature, B, ldc, K, Lpad,
+                                         (T*)latent, csoft));
+    return sv_check_launch("sv_sample_fwd");
+}
+
+int sv_sample_bwd(int dtype, const void* dlatent, const float* ls, const float* eps, const float* csoft, int mode,
+                  float temperature, int B, int ldc, int K, int Lpad, float* dmu, float* dls, float* dla,
+                  void* stream) {
+    SV_REQUIRE(dlatent && ls && eps && csoft && dmu && dls && dla, SV_E_ARG, "sv_sample_bwd: null");
+    DISPATCH_T(dtype, hipLaunchKernelGGL((sample_bwd_kernel<T>), dim3(B), dim3(128), 0, (hipStream_t)stream,
+                                         (const T*)dlatent, ls, eps, csoft, mode, temperature, B, ldc, K, Lpad, dmu,
+                                         dls, dla));
+    return sv_check_launch("sv_sample_bwd");
+}
+
+static float log_prior_f32(int K) {
+    // the reference builds log(float32(1/K)) in float32 (lib/criterion.py:29-30)
+    const float p = (float)(1.0 / (double)K);
+    return logf(p);
+}
+
+int sv_elbo_fwd(const float* x, const float* x_rec, int64_t n_per_img, const float* mu, const float* ls,
+                const float* la, int B, int ldc, int K, int bce, float x_sigma, float* out3, void* stream) {
+    SV_REQUIRE(x && x_rec && mu && ls && la && out3, SV_E_ARG, "sv_elbo_fwd: null");
+    const int64_t n = n_per_img * B;
+    hipLaunchKernelGGL(elbo_fwd_kernel, dim3(nblocks(n / 4, 256, 1024)), dim3(256), 0, (hipStream_t)stream, x, x_rec,
+                       n, mu, ls, la, B, ldc, K, bce, x_sigma, log_prior_f32(K), out3);
+    return sv_check_launch("sv_elbo_fwd");
+}
+
+int sv_elbo_bwd(const float* x, const float* x_rec, int64_t n_per_img, const float* mu, const float* ls,
+                const float* la, int B, int ldc, int K, int bce, float x_sigma, const float* gout3, float* dx_rec,
+                float* dmu, float* dls, float* dla, void* stream) {
+    SV_REQUIRE(x && x_rec && mu && ls && la && gout3 && dx_rec && dmu && dls && dla, SV_E_ARG, "sv_elbo_bwd: null");
+    const int64_t n = n_per_img * B;
+    hipLaunchKernelGGL(elbo_bwd_kernel, dim3(nblocks(n, 256, 2048)), dim3(256), 0, (hipStream_t)stream, x, x_rec, n,
+                       mu, ls, la, B, ldc, K, bce, x_sigma, log_prior_f32(K), gout3, dx_rec, dmu, dls, dla);
+    return sv_check_launch("sv_elbo_bwd");
+}
+
+int sv_cls_fwd(const float* predict, const float* label, const float* weight, int B, int K, float* out, void* stream) {
+    SV_REQUIRE(predict && label && out, SV_E_ARG, "sv_cls_fwd: null");
+    hipLaunchKernelGGL(cls_fwd_kernel, dim3(nblocks((int64_t)B * K, 256, 64)), dim3(256), 0, (hipStream_t)stream,
+                       predict, label, weight, B, K, out);
+    return sv_check_launch("sv_cls_fwd");
+}
+int sv_cls_bwd(const float* label, const float* weight, int B, int K, const float* gout, float* dpredict, void* stream) {
+    SV_REQUIRE(label && gout && dpredict, SV_E_ARG, "sv_cls_bwd: null");
+    hipLaunchKernelGGL(cls_bwd_kernel, dim3(((int64_t)B * K + 255) / 256), dim3(256), 0, (hipStream_t)stream, label,
+                       weight, B, K, gout, dpredict);
+    return sv_check_launch("sv_cls_bwd");
+}
+int sv_post_fwd(const float* mu, const float* ls, const float* mu_t, const float* sigma_t, int B, int D, float* out,
+                void* stream) {
+    SV_REQUIRE(mu && ls && mu_t && sigma_t && out, SV_E_ARG, "sv_post_fwd: null");
+    hipLaunchKernelGGL(post_fwd_kernel, dim3(nblocks((int64_t)B * D, 256, 64)), dim3(256), 0, (hipStream_t)stream, mu,
+                       ls, mu_t, sigma_t, B, D, out);
+    return sv_check_launch("sv_post_fwd");
+}
+int sv_post_bwd(const float* mu, const float* ls, const float* mu_t, const float* sigma_t, int B, int D,
+                const float* gout, float* dmu, float* dls, void* stream) {
+    SV_REQUIRE(mu && ls && mu_t && sigma_t && gout && dmu && dls, SV_E_ARG, "sv_post_bwd: null");
+    hipLaunchKernelGGL(post_bwd_kernel, dim3(((int64_t)B * D + 255) / 256), dim3(256), 0, (hipStream_t)stream, mu, ls,
+                       mu_t, sigma_t, B, D, gout, dmu, dls);
+    return sv_check_launch("sv_post_bwd");
+}
+
+int sv_mix_lerp(const float* a, const int64_t* index, float lam, int B, int64_t row, int exp_space, float* out,
+                void* stream) {
+    SV_REQUIRE(a && index && out, SV_E_ARG, "sv_mix_lerp: null");
+    if (B == 0 || row == 0) return SV_OK;
+    hipLaunchKernelGGL(mix_lerp_kernel, dim3((unsigned)((row + 255) / 256), B), dim3(256), 0, (hipStream_t)stream, a,
+                       index, lam, B, row, exp_space, out);
+    return sv_check_launch("sv_mix_lerp");
+}
+
+int sv_optimal_match(const float* mu, const float* ls, int B, int D, int64_t* index, void* stream) {
+    SV_REQUIRE(mu && ls && index && B >= 2, SV_E_ARG, "sv_optimal_match: bad args");
+    const size_t lds = (size_t)(2 * D + B) * sizeof(float);
+    SV_REQUIRE(lds <= 64 * 1024, SV_E_SHAPE, "sv_optimal_match: B=%d D=%d too large", B, D);
+    hipLaunchKernelGGL(optimal_match_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, mu, ls, B, D, index);
+    return sv_check_launch("sv_optimal_match");
+}
+
+int sv_sgd(float* p, const float* g, float* v, int64_t n, float lr, float momentum, float weight_decay,
+           float grad_scale, int first_step, void* stream) {
+    SV_REQUIRE(p && g && v && n >= 0, SV_E_ARG, "sv_sgd: null");
+    if (n == 0) return SV_OK;
+    hipLaunchKernelGGL(sgd_kernel, dim3(nblocks(n / 4, 256, 2048)), dim3(256), 0, (hipStream_t)stream, p, g, v, n, lr,
+                       momentum, weight_decay, grad_scale, first_step);
+    return sv_check_launch("sv_sgd");
+}
+
+int sv_nchw_to_nhwc(int dtype, const float* in, int B, int C, int H, int W, int Cpad, void* out, void* stream) {
+    SV_REQUIRE(in && out && Cpad >= C, SV_E_ARG, "sv_nchw_to_nhwc: bad args");
+    const int64_t n = (int64_t)B * H * W * Cpad;
+    DISPATCH_T(dtype, hipLaunchKernelGGL((nchw_to_nhwc_kernel<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                                         (hipStream_t)stream, in, B, C, H * W, Cpad, (T*)out));
+    return sv_check_launch("sv_nchw_to_nhwc");
+}
+int sv_nhwc_to_nchw(int dtype, const void* in, int B, int C, int H, int W, int ld, float* out, void* stream) {
+    SV_REQUIRE(in && out && ld >= C, SV_E_ARG, "sv_nhwc_to_nchw: bad args");
+    const int64_t n = (int64_t)B * H * W * C;
+    DISPATCH_T(dtype, hipLaunchKernelGGL((nhwc_to_nchw_kernel<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                                         (hipStream_t)stream, (const T*)in, B, C, H * W, ld, out));
+    return sv_check_launch("sv_nhwc_to_nchw");
+}
+
+int sv_repack(int dtype, const float* master, int N, int T_orig, int C, int transpose, const sv_geom* g, void* dst,
+              void* stream) {
+    SV_REQUIRE(master && g && dst, SV_E_ARG, "sv_repack: null");
+    repack_params p;
+    p.N = N; p.T_orig = T_orig; p.C = C; p.transpose = transpose; p.nphase = g->nphase;
+    int64_t mx = 0;
+    for (int i = 0; i < SV_MAX_PHASES; ++i) {
+        p.ntap[i] = 0; p.w_off[i] = 0; p.size[i] = 0;
+        for (int t = 0; t < SV_MAX_TAPS; ++t) p.torig[i][t] = 0;
+    }
+    for (int i = 0; i < g->nphase; ++i) {
+        p.ntap[i] = g->phase[i].ntap;
+        p.w_off[i] = g->phase[i].w_off;
+        p.size[i] = (int64_t)N * C * g->phase[i].ntap;
+        for (int t = 0; t < SV_MAX_TAPS; ++t) p.torig[i][t] = g->phase[i].torig[t];
+        if (p.size[i] > mx) mx = p.size[i];
+    }
+    if (mx == 0) return SV_OK;
+    DISPATCH_T(dtype, hipLaunchKernelGGL((repack_kernel<T>), dim3((unsigned)((mx + 255) / 256), g->nphase), dim3(256),
+                                         0, (hipStream_t)stream, master, p, (T*)dst));
+    return sv_check_launch("sv_repack");
+}
+
+}  // extern "C"

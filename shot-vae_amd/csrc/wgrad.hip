@@ -1,0 +1,316 @@
+// Weight gradient of every conv-like layer as a split-M GEMM on MFMA (gfx950):
+//
+//   dW[n][torig(t)][c] += sum_m dy[opos(m)][n] * A(m,t,c),   A = LeakyReLU(x*scale+shift) gathered
+//
+// One block owns a (16*TN channels-out) x (one tap) x (16*TC channels-in) tile of dW and a range of
+// output positions m.  The reduction index m is the MFMA k dimension, but both operands are stored
+// m-major in HBM (NHWC), so each wave stages ITS OWN 32 rows of dy and A row-major in a wave-private
+// LDS region (no block barrier in the main loop) and reads the k-major fragments back with the
+// gfx950 transposing read ds_read_b64_tr_b16 (bf16) or plain 4-byte reads (fp32 16x16x4 layout).
+// The four waves' accumulators are combined with LDS float atomics, then added to the fp32 gradient
+// buffer with one global atomic per element per block -- gradients of all four forwards of a step
+// accumulate in place (main_shot_vae.py:324,364 semantics).
+#include "common.h"
+
+namespace {
+
+constexpr int RW = 32;   // rows (output positions) per wave per iteration = one MFMA k chunk
+
+struct wg_params {
+    const void* x;
+    const float* pro_scale;
+    const float* pro_shift;
+    float pro_slope;
+    const void* dy;
+    float* dw;
+    int splits, m_per;          // m ranges
+    int wsh, hwsh;              // log2(Wq), log2(Hq*Wq) or -1
+    int ntap_total;
+};
+
+__device__ __forceinline__ void decode_m(const sv_geom& g, const wg_params& p, int m, int& b, int& qy, int& qx) {
+    if (p.hwsh >= 0) {
+        b = m >> p.hwsh;
+        const int r = m & ((1 << p.hwsh) - 1);
+        qy = r >> p.wsh;
+        qx = r & ((1 << p.wsh) - 1);
+    } else {
+        const int hw = g.Hq * g.Wq;
+        b = m / hw;
+        const int r = m - b * hw;
+        qy = r / g.Wq;
+        qx = r - qy * g.Wq;
+    }
+}
+
+// k-major MFMA fragment (16 indices starting at col0, 32 consecutive rows of S) ---------------------
+template <bool USE_TR>
+__device__ __forceinline__ bf16x8 frag_t(const bf16* S, int ld, int col0, int lane) {
+    const int gq = lane >> 4, i = lane & 15;
+    bf16x8 f;
+    if (USE_TR) {
+        // block = 4 rows x 16 cols; lane 4q+p of the 16-lane group addresses row q, cols 4p..4p+3 and
+        // receives column (lane&15) of the 4 rows.
+        const bf16* a0 = S + (8 * gq + (i >> 2)) * ld + col0 + 4 * (i & 3);
+        typedef __attribute__((address_space(3))) s16x4 lds_v4;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(a0));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(a0 + 4 * ld));
+        union { s16x4 s[2]; bf16x8 b; } u;
+        u.s[0] = lo;
+        u.s[1] = hi;
+        f = u.b;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = S[(8 * gq + j) * ld + col0 + i];
+    }
+    return f;
+}
+template <bool USE_TR>
+__device__ __forceinline__ f32x8 frag_t(const float* S, int ld, int col0, int lane) {
+    // element j feeds v_mfma_f32_16x16x4_f32 step j, whose k index is lane>>4: row = 4*j + (lane>>4)
+    const int gq = lane >> 4, i = lane & 15;
+    f32x8 f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = S[(4 * j + gq) * ld + col0 + i];
+    return f;
+}
+
+template <typename T, int TN, int TC, bool USE_TR>
+__global__ __launch_bounds__(256) void wgrad_kernel(const sv_geom g, const wg_params p) {
+    typedef typename V8<T>::type V;
+    constexpr int BNw = 16 * TN, BCw = 16 * TC;
+    constexpr int LDN = BNw + 8, LDC = BCw + 8;           // LDS row strides (elements)
+    constexpr int WAVE_ELEMS = RW * (LDN + LDC);
+    static_assert(4 * WAVE_ELEMS * sizeof(T) >= BNw * BCw * sizeof(float) || true, "");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    T* Ys = reinterpret_cast<T*>(smem) + wave * WAVE_ELEMS;   // [RW][LDN]
+    T* Xs = Ys + RW * LDN;                                    // [RW][LDC]
+
+    const int M = g.B * g.Hq * g.Wq;
+    const int nNt = (g.N + BNw - 1) / BNw;
+    const int nCt = (g.Cin + BCw - 1) / BCw;
+    const int tiles = nNt * p.ntap_total * nCt;
+    const int L = blockIdx.x;
+    const int xcd = L & 7, slot = L >> 3;
+    const int tile = slot % tiles;
+    const int split = (slot / tiles) * 8 + xcd;
+    if (split >= p.splits) return;
+    const int ct = tile % nCt;
+    int tapg = (tile / nCt) % p.ntap_total;
+    const int n0 = (tile / (nCt * p.ntap_total)) * BNw;
+    const int c0 = ct * BCw;
+    int ph = 0;
+    while (tapg >= g.phase[ph].ntap) { tapg -= g.phase[ph].ntap; ++ph; }
+    const sv_phase& P = g.phase[ph];
+    const int dy = P.dy[tapg], dx = P.dx[tapg], torig = P.torig[tapg];
+    const int ooy = P.ooy, oox = P.oox;
+
+    const T* __restrict__ X = reinterpret_cast<const T*>(p.x);
+    const T* __restrict__ DY = reinterpret_cast<const T*>(p.dy);
+    const bool has_pro = p.pro_scale != nullptr;
+
+    const int m_begin = split * p.m_per;
+    const int m_end = min(M, m_begin + p.m_per);
+
+    // per-lane load slots: TN passes over the dy rows, TC passes over the x rows
+    constexpr int VPRN = 2 * TN, RPN = 64 / VPRN;     // vectors per row, rows per pass
+    constexpr int VPRC = 2 * TC, RPC = 64 / VPRC;
+    const int vn = lane % VPRN, rn = lane / VPRN;
+    const int vc = lane % VPRC, rc = lane / VPRC;
+    const bool nvec_ok = n0 + 8 * vn < g.N;
+    const bool cvec_ok = c0 + 8 * vc < g.Cin;
+
+    f32x4 s0, s1, t0, t1;
+    if (has_pro && cvec_ok) {
+        s0 = *reinterpret_cast<const f32x4*>(p.pro_scale + c0 + 8 * vc);
+        s1 = *reinterpret_cast<const f32x4*>(p.pro_scale + c0 + 8 * vc + 4);
+        t0 = *reinterpret_cast<const f32x4*>(p.pro_shift + c0 + 8 * vc);
+        t1 = *reinterpret_cast<const f32x4*>(p.pro_shift + c0 + 8 * vc + 4);
+    }
+
+    V ry[TN], rx[TC];
+    bool okx[TC];
+    auto load_global = [&](int mbase) {   // mbase = first row of this wave's 32-row slab
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+            const int m = mbase + rn + RPN * i;
+            V val;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) val[j] = (T)0.f;
+            if (m < m_end && nvec_ok) {
+                int b, qy, qx;
+                decode_m(g, p, m, b, qy, qx);
+                const int64_t op = (int64_t)(b * g.Hout + qy * g.osy + ooy) * g.Wout + qx * g.osx + oox;
+                val = *reinterpret_cast<const V*>(DY + op * g.ldo + n0 + 8 * vn);
+            }
+            ry[i] = val;
+        }
+#pragma unroll
+        for (int i = 0; i < TC; ++i) {
+            const int m = mbase + rc + RPC * i;
+            V val;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) val[j] = (T)0.f;
+            bool ok = false;
+            if (m < m_end && cvec_ok) {
+                int b, qy, qx;
+                decode_m(g, p, m, b, qy, qx);
+                const int iy = qy * g.sy + dy, ix = qx * g.sx + dx;
+                ok = (unsigned)iy < (unsigned)g.Hin && (unsigned)ix < (unsigned)g.Win;
+                if (ok) val = *reinterpret_cast<const V*>(X + ((int64_t)(b * g.Hin + iy) * g.Win + ix) * g.ldx + c0 + 8 * vc);
+            }
+            okx[i] = ok;
+            rx[i] = val;
+        }
+    };
+    auto store_lds = [&]() {
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+            *reinterpret_cast<V*>(Ys + (rn + RPN * i) * LDN + 8 * vn) = ry[i];
+#pragma unroll
+        for (int i = 0; i < TC; ++i) {
+            V o = rx[i];
+            if (has_pro && okx[i]) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    o[j] = (T)act_fwd(to_f(rx[i][j]) * s0[j] + t0[j], p.pro_slope);
+                    o[j + 4] = (T)act_fwd(to_f(rx[i][j + 4]) * s1[j] + t1[j], p.pro_slope);
+                }
+            }
+            *reinterpret_cast<V*>(Xs + (rc + RPC * i) * LDC + 8 * vc) = o;
+        }
+    };
+
+    f32x4 acc[TN][TC];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TC; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int niter = (m_end - m_begin + 4 * RW - 1) / (4 * RW);
+    if (niter > 0) load_global(m_begin + RW * wave);
+    for (int it = 0; it < niter; ++it) {
+        store_lds();
+        if (it + 1 < niter) load_global(m_begin + (it + 1) * 4 * RW + RW * wave);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        V fy[TN], fx[TC];
+#pragma unroll
+        for (int i = 0; i < TN; ++i) fy[i] = frag_t<USE_TR>(Ys, LDN, 16 * i, lane);
+#pragma unroll
+        for (int j = 0; j < TC; ++j) fx[j] = frag_t<USE_TR>(Xs, LDC, 16 * j, lane);
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+            for (int j = 0; j < TC; ++j) mma32(acc[i][j], fy[i], fx[j]);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+
+    // ---- combine the four waves, then one global atomic per element ------------------------------
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);   // [BNw][BCw]
+    for (int i = tid; i < BNw * BCw; i += 256) red[i] = 0.f;
+    __syncthreads();
+    const int fr = lane & 15, fq = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TC; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                atomicAdd(&red[(16 * i + 4 * fq + r) * BCw + 16 * j + fr], acc[i][j][r]);
+    __syncthreads();
+    for (int i = tid; i < BNw * BCw; i += 256) {
+        const int n = n0 + i / BCw, c = c0 + i % BCw;
+        if (n < g.N && c < g.Cin)
+            atomicAdd(p.dw + ((int64_t)n * g.T_orig + torig) * g.Cin + c, red[i]);
+    }
+}
+
+int ilog2_exact(int v) {
+    if (v <= 0 || (v & (v - 1))) return -1;
+    int s = 0;
+    while ((1 << s) < v) ++s;
+    return s;
+}
+
+template <typename T, int TN, int TC, bool USE_TR>
+int launch(const sv_geom* g, const wg_params& p, hipStream_t s) {
+    constexpr int BNw = 16 * TN, BCw = 16 * TC;
+    const int nNt = (g->N + BNw - 1) / BNw, nCt = (g->Cin + BCw - 1) / BCw;
+    const int tiles = nNt * p.ntap_total * nCt;
+    const int grid = ((p.splits + 7) / 8) * 8 * tiles;
+    size_t lds = (size_t)4 * RW * (BNw + 8 + BCw + 8) * sizeof(T);
+    const size_t red = (size_t)BNw * BCw * sizeof(float);
+    if (red > lds) lds = red;
+    sv_prof_begin(s);
+    hipLaunchKernelGGL((wgrad_kernel<T, TN, TC, USE_TR>), dim3(grid), dim3(256), lds, s, *g, p);
+    sv_prof_end(s);
+    return sv_check_launch("sv_wgrad");
+}
+
+template <typename T, bool USE_TR>
+int dispatch(const sv_geom* g, const wg_params& p, int tn, int tc, hipStream_t s) {
+    if (tn == 4 && tc == 4) return launch<T, 4, 4, USE_TR>(g, p, s);
+    if (tn == 4 && tc == 2) return launch<T, 4, 2, USE_TR>(g, p, s);
+    if (tn == 4 && tc == 1) return launch<T, 4, 1, USE_TR>(g, p, s);
+    if (tn == 2 && tc == 4) return launch<T, 2, 4, USE_TR>(g, p, s);
+    if (tn == 2 && tc == 2) return launch<T, 2, 2, USE_TR>(g, p, s);
+    if (tn == 2 && tc == 1) return launch<T, 2, 1, USE_TR>(g, p, s);
+    if (tn == 1 && tc == 4) return launch<T, 1, 4, USE_TR>(g, p, s);
+    if (tn == 1 && tc == 2) return launch<T, 1, 2, USE_TR>(g, p, s);
+    return launch<T, 1, 1, USE_TR>(g, p, s);
+}
+
+}  // namespace
+
+extern "C" int sv_wgrad(const sv_geom* g, int dtype, const void* x, const float* pro_scale,
+                        const float* pro_shift, float pro_slope, const void* dy, float* dw, int splits,
+                        int use_tr, void* stream) {
+    SV_REQUIRE(g && x && dy && dw, SV_E_ARG, "sv_wgrad: null argument");
+    SV_REQUIRE(dtype == SV_F32 || dtype == SV_BF16, SV_E_ARG, "sv_wgrad: bad dtype %d", dtype);
+    SV_REQUIRE(g->Cin % 16 == 0 && g->N % 16 == 0 && g->ldx % 8 == 0 && g->ldo % 8 == 0, SV_E_SHAPE,
+               "sv_wgrad: Cin=%d N=%d must be multiples of 16", g->Cin, g->N);
+    SV_REQUIRE(!pro_scale || pro_shift, SV_E_ARG, "sv_wgrad: prologue shift missing");
+    wg_params p;
+    p.x = x; p.pro_scale = pro_scale; p.pro_shift = pro_shift; p.pro_slope = pro_slope;
+    p.dy = dy; p.dw = dw;
+    p.wsh = ilog2_exact(g->Wq);
+    p.hwsh = ilog2_exact(g->Hq * g->Wq);
+    if (p.wsh < 0 || p.hwsh < 0) p.wsh = p.hwsh = -1;
+    p.ntap_total = 0;
+    for (int i = 0; i < g->nphase; ++i) p.ntap_total += g->phase[i].ntap;
+    if (p.ntap_total == 0) return SV_OK;
+    const int64_t M = (int64_t)g->B * g->Hq * g->Wq;
+    // tile: the widest of {64,32,16} that divides; fp32 is capped at 32 (LDS budget)
+    auto pick = [&](int n) { int t = (n % 64 == 0) ? 4 : (n % 32 == 0 ? 2 : 1); if (n >= 64 && t == 1) t = (n % 32 == 0) ? 2 : 1; return t; };
+    int tn = pick(g->N), tc = pick(g->Cin);
+    if (g->N > 64 && g->N % 64 != 0) tn = 4;       // ragged last tile is masked in-kernel
+    if (g->Cin > 64 && g->Cin % 64 != 0) tc = 4;
+    if (dtype == SV_F32) { if (tn > 2) tn = 2; if (tc > 2) tc = 2; }
+    const int tiles = ((g->N + 16 * tn - 1) / (16 * tn)) * p.ntap_total * ((g->Cin + 16 * tc - 1) / (16 * tc));
+    if (splits <= 0) {
+        // aim at ~4 blocks per CU, at least 512 rows per block, at most one split per 128 rows
+        int64_t want = (1024 + tiles - 1) / tiles;
+        int64_t maxs = (M + 511) / 512;
+        if (want > maxs) want = maxs;
+        if (want < 1) want = 1;
+        splits = (int)want;
+    }
+    int64_t m_per = (M + splits - 1) / splits;
+    m_per = (m_per + 127) / 128 * 128;
+    splits = (int)((M + m_per - 1) / m_per);
+    p.splits = splits;
+    p.m_per = (int)m_per;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == SV_BF16) {
+        if (use_tr) return dispatch<bf16, true>(g, p, tn, tc, s);
+        return dispatch<bf16, false>(g, p, tn, tc, s);
+    }
+    return dispatch<float, false>(g, p, tn, tc, s);
+}
