@@ -1,0 +1,481 @@
+"""Kernel-level parity on a real MI355X: every C-ABI entry point against plain torch fp32 on CPU.
+
+fp32 mode (exact-fp32 MFMA) must agree to ~1e-4 of the tensor scale; bf16 mode to 2e-2 (operand
+rounding; SURVEY.md §8d tolerances)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from shot_vae_amd import _lib as L          # noqa: E402
+from shot_vae_amd import geometry as G      # noqa: E402
+
+DT = {"f32": (L.SV_F32, torch.float32, 2e-4), "bf16": (L.SV_BF16, torch.bfloat16, 2.5e-2)}
+
+
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch.device("cuda:0")
+
+
+def st():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+_KEEP = []
+
+
+def p(t):
+    """device pointer of t; keeps t alive (an inline temporary would otherwise be freed -- and its
+    block reused by the next temporary -- before the asynchronous kernel runs)."""
+    if t is None:
+        return None
+    _KEEP.append(t)
+    if len(_KEEP) > 4096:
+        torch.cuda.synchronize()
+        del _KEEP[:2048]
+    return C.c_void_p(t.data_ptr())
+
+
+def rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-20))
+
+
+def nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(x):
+    return x.permute(0, 3, 1, 2).contiguous()
+
+
+def repack(master, g, transpose, dt):
+    code, tdt, _ = DT[dt]
+    N, T, Cc = master.shape
+    dst = torch.zeros(max(G.packed_size(g), 1), dtype=tdt, device=dev())
+    m = master.to(dev()).contiguous()
+    L.call("sv_repack", code, p(m), N, T, Cc, int(transpose), C.byref(g), p(dst), st())
+    return dst
+
+
+def run_igemm(g, dt, x, w, pro=None, bias=None, residual=None, stats=False, ex=None):
+    code, tdt, _ = DT[dt]
+    d = dev()
+    xd = x.to(d, tdt).contiguous()
+    out = torch.full((g.B, g.Hout, g.Wout, g.ldo), 7.0, dtype=tdt, device=d)
+    a = L.SvIgemmArgs()
+    keep = [xd, out, w]
+    a.x, a.w, a.out = xd.data_ptr(), w.data_ptr(), out.data_ptr()
+    if pro is not None:
+        sc, sh = pro[0].to(d).float().contiguous(), pro[1].to(d).float().contiguous()
+        keep += [sc, sh]
+        a.pro_scale, a.pro_shift, a.pro_slope = sc.data_ptr(), sh.data_ptr(), pro[2]
+    if bias is not None:
+        bd = bias.to(d).float().contiguous()
+        keep.append(bd)
+        a.bias = bd.data_ptr()
+    if residual is not None:
+        rd = residual.to(d, tdt).contiguous()
+        keep.append(rd)
+        a.residual = rd.data_ptr()
+    sums = None
+    if stats:
+        sums = torch.zeros(2 * g.N, device=d)
+        a.stats = sums.data_ptr()
+    if ex is not None:
+        exd = ex["x"].to(d, tdt).contiguous()
+        vec = [ex[k].to(d).float().contiguous() for k in ("scale", "shift", "mean", "rstd")]
+        keep += [exd] + vec
+        sums = torch.zeros(2 * g.N, device=d)
+        a.ex, a.ex_scale, a.ex_shift, a.ex_mean, a.ex_rstd = [t.data_ptr() for t in [exd] + vec]
+        a.ex_slope, a.bsums = ex["slope"], sums.data_ptr()
+    L.call("sv_igemm", C.byref(g), code, C.byref(a), st())
+    torch.cuda.synchronize()
+    return out.float().cpu(), (None if sums is None else sums.cpu())
+
+
+def bq(t, dt):
+    """round to the storage dtype (so the CPU reference sees the same operands)"""
+    return t.to(DT[dt][1]).float()
+
+
+CONV_CASES = [
+    # B, Cin, N, H, k, stride, pad
+    (4, 16, 32, 8, 3, 1, 1),
+    (8, 32, 32, 16, 3, 1, 1),
+    (3, 32, 64, 16, 3, 2, 1),
+    (5, 64, 128, 8, 3, 2, 1),
+    (4, 16, 32, 8, 1, 1, 0),
+    (4, 32, 64, 16, 1, 2, 0),
+    (2, 160, 160, 8, 3, 1, 1),
+    (6, 128, 128, 8, 3, 1, 1),
+    (2, 16, 16, 32, 3, 1, 1),
+]
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_forward_fused(dt, case):
+    B, Cin, N, H, k, stride, pad = case
+    tol = DT[dt][2]
+    torch.manual_seed(1)
+    x = bq(torch.randn(B, Cin, H, H), dt)
+    w = bq(torch.randn(N, Cin, k, k) / (Cin * k * k) ** 0.5, dt)
+    scale, shift = torch.rand(Cin) + 0.5, torch.randn(Cin) * 0.3
+    bias = torch.randn(N) * 0.2
+    a = bq(F.leaky_relu(x * scale[None, :, None, None] + shift[None, :, None, None], 0.01), dt)
+    Ho = (H + 2 * pad - k) // stride + 1
+    res = bq(torch.randn(B, N, Ho, Ho), dt)
+    y = F.conv2d(a, w, bias, stride, pad) + res
+    g = G.conv_like(B, H, H, Cin, N, k, stride, pad)
+    master = w.permute(0, 2, 3, 1).reshape(N, k * k, Cin).contiguous()
+    wp = repack(master, g, False, dt)
+    out, sums = run_igemm(g, dt, nhwc(x), wp, pro=(scale, shift, 0.01), bias=bias, residual=nhwc(res), stats=True)
+    assert rel(nchw(out), y) < tol, ("out", rel(nchw(out), y))
+    s1, s2 = y.sum((0, 2, 3)), (y * y).sum((0, 2, 3))
+    assert rel(sums[:N], s1) < max(tol, 1e-3) * 3 and rel(sums[N:], s2) < max(tol, 1e-3) * 3
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_dgrad_with_activation_backward(dt, case):
+    B, Cin, N, H, k, stride, pad = case
+    tol = DT[dt][2]
+    torch.manual_seed(2)
+    w = bq(torch.randn(N, Cin, k, k) / (Cin * k * k) ** 0.5, dt)
+    Ho = (H + 2 * pad - k) // stride + 1
+    dy = bq(torch.randn(B, N, Ho, Ho), dt)
+    xraw = bq(torch.randn(B, Cin, H, H), dt)            # the raw tensor whose BN+act fed this conv
+    scale, shift = torch.rand(Cin) + 0.5, torch.randn(Cin) * 0.3
+    mean, rstd = torch.randn(Cin) * 0.1, torch.rand(Cin) + 0.5
+    da = F.conv_transpose2d(dy, w, None, stride, pad, output_padding=H - ((Ho - 1) * stride - 2 * pad + k))
+    u = xraw * scale[None, :, None, None] + shift[None, :, None, None]
+    gref = da * torch.where(u > 0, torch.ones_like(u), torch.full_like(u, 0.01))
+    xh = (xraw - mean[None, :, None, None]) * rstd[None, :, None, None]
+    g = G.convT_like(B, Ho, Ho, N, Cin, k, stride, pad)
+    master = w.permute(0, 2, 3, 1).reshape(N, k * k, Cin).contiguous()
+    wp = repack(master, g, True, dt)
+    out, sums = run_igemm(g, dt, nhwc(dy), wp,
+                          ex=dict(x=nhwc(xraw), scale=scale, shift=shift, mean=mean, rstd=rstd, slope=0.01))
+    assert rel(nchw(out), gref) < tol, ("g", rel(nchw(out), gref))
+    assert rel(sums[:Cin], gref.sum((0, 2, 3))) < max(tol, 1e-3) * 3
+    assert rel(sums[Cin:], (gref * xh).sum((0, 2, 3))) < max(tol, 1e-3) * 3
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("H,Cin,N,B", [(1, 1024, 512, 6), (2, 512, 256, 4), (8, 128, 64, 3), (16, 64, 16, 2)])
+def test_convT_forward_and_dgrad(dt, H, Cin, N, B):
+    tol = DT[dt][2]
+    torch.manual_seed(3)
+    x = bq(torch.randn(B, Cin, H, H), dt)
+    w = bq(torch.randn(Cin, N, 4, 4) / (Cin * 4) ** 0.5, dt)
+    scale, shift = torch.rand(Cin) + 0.5, torch.randn(Cin) * 0.3
+    a = bq(F.relu(x * scale[None, :, None, None] + shift[None, :, None, None]), dt)
+    y = F.conv_transpose2d(a, w, None, 2, 1)
+    master = w.permute(1, 2, 3, 0).reshape(N, 16, Cin).contiguous()
+    g = G.convT_like(B, H, H, Cin, N, 4, 2, 1)
+    out, sums = run_igemm(g, dt, nhwc(x), repack(master, g, False, dt), pro=(scale, shift, 0.0), stats=True)
+    assert rel(nchw(out), y) < tol
+    assert rel(sums[:N], y.sum((0, 2, 3))) < max(tol, 1e-3) * 3
+    dy = bq(torch.randn_like(y), dt)
+    dx = F.conv2d(dy, w, None, 2, 1)
+    gd = G.conv_like(B, 2 * H, 2 * H, N, Cin, 4, 2, 1)
+    out, _ = run_igemm(gd, dt, nhwc(dy), repack(master, gd, True, dt))
+    assert rel(nchw(out), dx) < tol
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_gemm_ragged_batch(dt):
+    """ConvTranspose2d(latent,1024,k=1) on a 1x1 map == GEMM; batch not a multiple of the tile."""
+    tol = DT[dt][2]
+    torch.manual_seed(4)
+    B, Cin, N = 37, 144, 1024
+    x = bq(torch.randn(B, Cin), dt)
+    w = bq(torch.randn(N, Cin) / Cin ** 0.5, dt)
+    g = G.conv_like(B, 1, 1, Cin, N, 1, 1, 0)
+    out, sums = run_igemm(g, dt, x.view(B, 1, 1, Cin), repack(w.view(N, 1, Cin), g, False, dt), stats=True)
+    y = x @ w.t()
+    assert rel(out.view(B, N), y) < tol
+    assert rel(sums[N:], (y * y).sum(0)) < max(tol, 1e-3) * 3
+
+
+WG_CASES = CONV_CASES + [(40, 16, 16, 32, 3, 1, 1)]
+
+
+@pytest.mark.parametrize("dt,use_tr", [("f32", 0), ("bf16", 0), ("bf16", 1)])
+@pytest.mark.parametrize("case", WG_CASES)
+def test_conv_wgrad(dt, use_tr, case):
+    B, Cin, N, H, k, stride, pad = case
+    code, tdt, tol = DT[dt]
+    torch.manual_seed(5)
+    x = bq(torch.randn(B, Cin, H, H), dt)
+    scale, shift = torch.rand(Cin) + 0.5, torch.randn(Cin) * 0.3
+    a = bq(F.leaky_relu(x * scale[None, :, None, None] + shift[None, :, None, None], 0.01), dt)
+    Ho = (H + 2 * pad - k) // stride + 1
+    dy = bq(torch.randn(B, N, Ho, Ho), dt)
+    wref = torch.nn.grad.conv2d_weight(a, (N, Cin, k, k), dy, stride, pad)
+    g = G.conv_like(B, H, H, Cin, N, k, stride, pad)
+    d = dev()
+    xd, dyd = nhwc(x).to(d, tdt), nhwc(dy).to(d, tdt)
+    sc, sh = scale.to(d), shift.to(d)
+    dw = torch.zeros(N, k * k, Cin, device=d)
+    for _ in range(2):   # accumulates: two calls == 2x
+        L.call("sv_wgrad", C.byref(g), code, p(xd), p(sc), p(sh), 0.01, p(dyd), p(dw), 0, use_tr, st())
+    torch.cuda.synchronize()
+    got = dw.cpu().view(N, k, k, Cin).permute(0, 3, 1, 2) / 2
+    assert rel(got, wref) < tol, rel(got, wref)
+
+
+@pytest.mark.parametrize("dt,use_tr", [("f32", 0), ("bf16", 1)])
+@pytest.mark.parametrize("H,Cin,N,B", [(1, 1024, 512, 6), (4, 256, 128, 4), (16, 64, 16, 2)])
+def test_convT_wgrad(dt, use_tr, H, Cin, N, B):
+    code, tdt, tol = DT[dt]
+    torch.manual_seed(6)
+    x = bq(torch.randn(B, Cin, H, H), dt)
+    dy = bq(torch.randn(B, N, 2 * H, 2 * H), dt)
+    w = torch.zeros(Cin, N, 4, 4, requires_grad=True)
+    F.conv_transpose2d(x, w, None, 2, 1).backward(dy)
+    g = G.convT_like(B, H, H, Cin, N, 4, 2, 1)
+    d = dev()
+    dw = torch.zeros(N, 16, Cin, device=d)
+    L.call("sv_wgrad", C.byref(g), code, p(nhwc(x).to(d, tdt)), None, None, 0.0, p(nhwc(dy).to(d, tdt)), p(dw), 0,
+           use_tr, st())
+    torch.cuda.synchronize()
+    got = dw.cpu().view(N, 4, 4, Cin).permute(3, 0, 1, 2)
+    assert rel(got, w.grad) < tol
+
+
+# ------------------------------------------------------------------------------------------ small kernels
+def test_bn_finalize_and_bwd_apply():
+    torch.manual_seed(7)
+    d = dev()
+    B, Cc, H = 6, 32, 4
+    x = torch.randn(B, Cc, H, H) * 1.5 + 0.3
+    gamma, beta = torch.rand(Cc) + 0.5, torch.randn(Cc)
+    rm, rv = torch.randn(Cc) * 0.1, torch.rand(Cc) + 0.5
+    xr = x.clone().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    rm2, rv2 = rm.clone(), rv.clone()
+    y = F.batch_norm(xr, rm2, rv2, gr, br, True, 0.1, 1e-5)
+    gup = torch.randn_like(y)
+    res = torch.randn_like(y)
+    (y * gup).sum().backward()
+    n = B * H * H
+    xn = nhwc(x).to(d)
+    stats = torch.cat([xn.reshape(-1, Cc).sum(0), (xn.reshape(-1, Cc) ** 2).sum(0)]).contiguous()
+    outs = [torch.zeros(Cc, device=d) for _ in range(4)]
+    rmd, rvd = rm.to(d), rv.to(d)
+    L.call("sv_bn_finalize", p(stats), Cc, float(n), p(gamma.to(d)), p(beta.to(d)), 1e-5, 0.1, p(rmd), p(rvd),
+           p(outs[0]), p(outs[1]), p(outs[2]), p(outs[3]), st())
+    assert rel(rmd, rm2) < 1e-5 and rel(rvd, rv2) < 1e-5
+    mean, var = x.mean((0, 2, 3)), x.var((0, 2, 3), unbiased=False)
+    assert rel(outs[2], mean) < 1e-4 and rel(outs[3], torch.rsqrt(var + 1e-5)) < 1e-4
+    yk = xn * outs[0] + outs[1]
+    assert rel(yk, nhwc(y.detach())) < 1e-4
+    # backward apply (g = upstream gradient w.r.t. y)
+    gn = nhwc(gup).to(d)
+    xh = (xn - outs[2]) * outs[3]
+    bsums = torch.cat([gn.reshape(-1, Cc).sum(0), (gn * xh).reshape(-1, Cc).sum(0)]).contiguous()
+    dgam, dbet = torch.zeros(Cc, device=d), torch.zeros(Cc, device=d)
+    br_ = (L.SvBnBranch * 1)()
+    gmd = gamma.to(d)
+    br_[0].g, br_[0].bsums, br_[0].gamma = gn.data_ptr(), bsums.data_ptr(), gmd.data_ptr()
+    br_[0].dgamma, br_[0].dbeta = dgam.data_ptr(), dbet.data_ptr()
+    dx = torch.empty_like(xn)
+    rn = nhwc(res).to(d)
+    L.call("sv_bn_bwd_apply", L.SV_F32, n, Cc, Cc, p(xn), p(outs[2]), p(outs[3]), float(n), br_, 1, p(rn), p(dx), st())
+    torch.cuda.synchronize()
+    assert rel(nchw(dx.cpu()), xr.grad + res) < 1e-4
+    assert rel(dgam, gr.grad) < 1e-4 and rel(dbet, br.grad) < 1e-4
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_pool_head_sample(dt):
+    code, tdt, tol = DT[dt]
+    torch.manual_seed(8)
+    d = dev()
+    B, Cc, HW, ldc, K = 11, 64, 16, 128, 10
+    x = bq(torch.randn(B, HW, Cc), dt)
+    scale, shift = torch.rand(Cc) + 0.5, torch.randn(Cc) * 0.2
+    mean, rstd = torch.randn(Cc) * 0.1, torch.rand(Cc) + 0.5
+    W = torch.randn(2 * ldc + K, Cc) / 8
+    bias = torch.randn(2 * ldc + K) * 0.1
+    eps, u = torch.randn(B, ldc), torch.rand(B, K)
+    xr = x.clone().requires_grad_(True)
+    Wr, br = W.clone().requires_grad_(True), bias.clone().requires_grad_(True)
+    feat = F.leaky_relu(xr * scale + shift, 0.01).mean(1)
+    o = F.linear(feat, Wr, br)
+    mu, ls, la = o[:, :ldc], o[:, ldc:2 * ldc], F.log_softmax(o[:, 2 * ldc:], 1)
+    z = mu + torch.exp(ls) * eps
+    gum = -torch.log(-torch.log(u + 1e-12) + 1e-12)
+    c = torch.softmax((la + gum) / 0.67, 1)
+    lat = torch.cat([z, c], 1)
+    dlat = bq(torch.randn(B, ldc + K), dt)
+    dmu0, dls0, dla0 = torch.randn(B, ldc), torch.randn(B, ldc), torch.randn(B, K)
+    ((lat * dlat).sum() + (mu * dmu0).sum() + (ls * dls0).sum() + (la * dla0).sum()).backward()
+    # --- forward on device
+    xd = x.to(d, tdt)
+    featd = torch.empty(B, Cc, device=d)
+    sc, sh, mn, rs = scale.to(d), shift.to(d), mean.to(d), rstd.to(d)
+    L.call("sv_pool_fwd", code, p(xd), p(sc), p(sh), 0.01, B, HW, Cc, Cc, p(featd), st())
+    assert rel(featd, feat.detach()) < 1e-4
+    mud, lsd, lad = torch.empty(B, ldc, device=d), torch.empty(B, ldc, device=d), torch.empty(B, K, device=d)
+    Wd, bd = W.to(d), bias.to(d)
+    L.call("sv_head_fwd", p(featd), B, Cc, p(Wd), p(bd), ldc, K, p(mud), p(lsd), p(lad), st())
+    assert rel(mud, mu.detach()) < 1e-4 and rel(lsd, ls.detach()) < 1e-4 and rel(lad, la.detach()) < 1e-4
+    Lpad = 144
+    latd = torch.full((B, Lpad), 5.0, device=d, dtype=tdt)
+    csoft = torch.empty(B, K, device=d)
+    epsd, ud = eps.to(d), u.to(d)
+    L.call("sv_sample_fwd", code, p(mud), p(lsd), p(lad), p(epsd), p(ud), None, None, 0.0, 0, 0.67, B, ldc, K, Lpad,
+           p(latd), p(csoft), st())
+    assert rel(latd[:, :ldc + K].float(), lat.detach()) < max(tol, 1e-4)
+    assert float(latd[:, ldc + K:].float().abs().max()) == 0.0
+    # --- backward on device
+    dmud, dlsd, dlad = dmu0.to(d).clone(), dls0.to(d).clone(), dla0.to(d).clone()
+    dl = torch.zeros(B, Lpad, device=d, dtype=tdt)
+    dl[:, :ldc + K] = dlat.to(d, tdt)
+    L.call("sv_sample_bwd", code, p(dl), p(lsd), p(epsd), p(csoft), 0, 0.67, B, ldc, K, Lpad, p(dmud), p(dlsd), p(dlad), st())
+    dfeat = torch.empty(B, Cc, device=d)
+    dW, db = torch.zeros_like(Wd), torch.zeros_like(bd)
+    ws = torch.empty(B, 2 * ldc + K, device=d)
+    L.call("sv_head_bwd", p(featd), B, Cc, p(Wd), ldc, K, p(lad), p(dmud), p(dlsd), p(dlad), p(dfeat), p(dW), p(db),
+           p(ws), st())
+    assert rel(dW, Wr.grad) < 2e-3 and rel(db, br.grad) < 2e-3
+    g = torch.empty(B, HW, Cc, device=d, dtype=tdt)
+    bs = torch.zeros(2 * Cc, device=d)
+    L.call("sv_pool_bwd", code, p(xd), p(sc), p(sh), 0.01, p(mn), p(rs), p(dfeat), B, HW, Cc, Cc, p(g), p(bs), st())
+    torch.cuda.synchronize()
+    gref = xr.grad / scale     # the kernel emits dL/d(BN output); gamma*rstd is applied by sv_bn_bwd_apply
+    assert rel(g.float(), gref) < max(tol, 2e-3)
+    xh = (x - mean) * rstd
+    assert rel(bs[:Cc], gref.sum((0, 1))) < max(tol, 2e-3)
+    assert rel(bs[Cc:], (gref * xh).sum((0, 1))) < max(tol, 2e-3)
+
+
+def test_sampler_label_modes():
+    d = dev()
+    B, ldc, K, Lpad = 5, 128, 10, 144
+    torch.manual_seed(9)
+    mu, ls, la = torch.randn(B, ldc), torch.randn(B, ldc) * 0.1, F.log_softmax(torch.randn(B, K), 1)
+    eps = torch.randn(B, ldc)
+    la_, lb_ = torch.randint(0, K, (B,)), torch.randint(0, K, (B,))
+    for mode, lam in ((1, 0.0), (2, 0.8)):
+        lat = torch.empty(B, Lpad, device=d)
+        cs = torch.empty(B, K, device=d)
+        L.call("sv_sample_fwd", L.SV_F32, p(mu.to(d)), p(ls.to(d)), p(la.to(d)), p(eps.to(d)), None, p(la_.to(d)),
+               p(lb_.to(d)), lam, mode, 0.67, B, ldc, K, Lpad, p(lat), p(cs), st())
+        c = F.one_hot(la_, K).float()
+        if mode == 2:
+            c = lam * c + (1 - lam) * F.one_hot(lb_, K).float()
+        assert rel(lat[:, ldc:ldc + K], c) < 1e-6
+        assert rel(lat[:, :ldc], mu + torch.exp(ls) * eps) < 1e-6
+
+
+@pytest.mark.parametrize("bce", [1, 0])
+def test_elbo_cls_post(bce):
+    d = dev()
+    torch.manual_seed(10)
+    B, ldc, K = 7, 128, 10
+    x = torch.rand(B, 3, 32, 32)
+    xr = (torch.randn(B, 3, 32, 32) * 2).requires_grad_(True)
+    mu = (torch.randn(B, ldc) * 0.7).requires_grad_(True)
+    ls = (torch.randn(B, ldc) * 0.3 - 0.5).requires_grad_(True)
+    la = F.log_softmax(torch.randn(B, K) * 2, 1).requires_grad_(True)
+    sig = 0.5
+    if bce:
+        r = F.binary_cross_entropy_with_logits(xr, x, reduction="sum") / B
+    else:
+        r = F.mse_loss(torch.sigmoid(xr), x, reduction="sum") / (2 * B * sig ** 2)
+    kc = 0.5 * torch.sum(mu * mu + torch.exp(2 * ls) - 2 * ls - 1) / B
+    kd = torch.sum(torch.exp(la) * (la - torch.log(torch.tensor(1.0 / K)))) / B
+    gw = torch.tensor([0.7, -1.3, 2.1])
+    (gw[0] * r + gw[1] * kc + gw[2] * kd).backward()
+    out3 = torch.zeros(3, device=d)
+    args = [p(x.to(d)), p(xr.detach().to(d)), 3 * 32 * 32, p(mu.detach().to(d)), p(ls.detach().to(d)),
+            p(la.detach().to(d)), B, ldc, K, bce, sig]
+    keep = [x.to(d), xr.detach().to(d), mu.detach().to(d), ls.detach().to(d), la.detach().to(d)]
+    args = [p(keep[0]), p(keep[1]), 3 * 32 * 32, p(keep[2]), p(keep[3]), p(keep[4]), B, ldc, K, bce, sig]
+    L.call("sv_elbo_fwd", *args, p(out3), st())
+    ref = torch.stack([r, kc, kd]).detach()
+    assert torch.allclose(out3.cpu(), ref, rtol=2e-5, atol=1e-6), (out3.cpu(), ref)
+    dxr, dmu, dls, dla = (torch.empty_like(k) for k in (keep[1], keep[2], keep[3], keep[4]))
+    gd = gw.to(d)
+    L.call("sv_elbo_bwd", *args, p(gd), p(dxr), p(dmu), p(dls), p(dla), st())
+    assert rel(dxr, xr.grad) < 1e-4 and rel(dmu, mu.grad) < 1e-5 and rel(dls, ls.grad) < 1e-5
+    assert rel(dla, la.grad) < 1e-5
+    # ClsCriterion + posterior terms
+    lab = torch.softmax(torch.randn(B, K), 1)
+    wgt = torch.rand(B)
+    la2 = la.detach().clone().requires_grad_(True)
+    c = -torch.mean(torch.sum(la2 * lab, 1) * wgt)
+    c.backward()
+    o = torch.zeros(1, device=d)
+    L.call("sv_cls_fwd", p(keep[4]), p(lab.to(d)), p(wgt.to(d)), B, K, p(o), st())
+    assert abs(float(o) - float(c.detach())) < 1e-5
+    dp = torch.empty(B, K, device=d)
+    one = torch.ones(1, device=d)
+    L.call("sv_cls_bwd", p(lab.to(d)), p(wgt.to(d)), B, K, p(one), p(dp), st())
+    assert rel(dp, la2.grad) < 1e-5
+    mt, stt = torch.randn(B, ldc), torch.rand(B, ldc)
+    mu2, ls2 = mu.detach().clone().requires_grad_(True), ls.detach().clone().requires_grad_(True)
+    q = (F.mse_loss(mu2, mt, reduction="sum") + F.mse_loss(torch.exp(ls2), stt, reduction="sum")) / B
+    q.backward()
+    o.zero_()
+    L.call("sv_post_fwd", p(keep[2]), p(keep[3]), p(mt.to(d)), p(stt.to(d)), B, ldc, p(o), st())
+    assert abs(float(o) - float(q.detach())) < 1e-4 * abs(float(q.detach()))
+    d1, d2 = torch.empty(B, ldc, device=d), torch.empty(B, ldc, device=d)
+    L.call("sv_post_bwd", p(keep[2]), p(keep[3]), p(mt.to(d)), p(stt.to(d)), B, ldc, p(one), p(d1), p(d2), st())
+    assert rel(d1, mu2.grad) < 1e-5 and rel(d2, ls2.grad) < 1e-5
+
+
+def test_mix_lerp_optimal_match_sgd_layout():
+    d = dev()
+    torch.manual_seed(11)
+    B, D = 9, 128
+    a = torch.randn(B, 3, 8, 8)
+    idx = torch.randperm(B)
+    out = torch.empty_like(a, device=d)
+    L.call("sv_mix_lerp", p(a.to(d)), p(idx.to(d)), 0.3, B, 3 * 64, 0, p(out), st())
+    assert rel(out, 0.3 * a + 0.7 * a[idx]) < 1e-6
+    L.call("sv_mix_lerp", p(a.to(d)), p(idx.to(d)), 0.3, B, 3 * 64, 1, p(out), st())
+    assert rel(out, 0.3 * a.exp() + 0.7 * a[idx].exp()) < 1e-5
+    mu, ls = torch.randn(B, D), torch.randn(B, D) * 0.3
+    kl = torch.zeros(B, B)
+    for i in range(B):
+        for j in range(B):
+            s1, s2 = torch.exp(ls[i]), torch.exp(ls[j])
+            kl[i, j] = torch.sum(ls[j] - ls[i]) + 0.5 * torch.sum(s1 ** 2 / s2 ** 2) + \
+                0.5 * torch.sum((mu[i] - mu[j]) ** 2 / s2 ** 2) - 0.5 * D
+    ref = torch.topk(kl, 2, largest=False)[1][:, 1]
+    got = torch.empty(B, dtype=torch.int64, device=d)
+    L.call("sv_optimal_match", p(mu.to(d)), p(ls.to(d)), B, D, p(got), st())
+    assert torch.equal(got.cpu(), ref)
+    # SGD, two steps, vs torch.optim.SGD
+    n = 1003
+    w = torch.randn(n)
+    pr = torch.nn.Parameter(w.clone())
+    opt = torch.optim.SGD([pr], lr=0.1, momentum=0.9, weight_decay=5e-4)
+    pd, vd = w.to(d).clone(), torch.zeros(n, device=d)
+    for step in range(2):
+        g = torch.randn(n)
+        pr.grad = g.clone()
+        opt.step()
+        L.call("sv_sgd", p(pd), p((g * 4).to(d)), p(vd), n, 0.1, 0.9, 5e-4, 0.25, int(step == 0), st())
+    assert rel(pd, pr.detach()) < 1e-6
+    # layout round trip
+    img = torch.rand(3, 3, 4, 4)
+    for dt in ("f32", "bf16"):
+        code, tdt, _ = DT[dt]
+        o = torch.empty(3, 4, 4, 16, device=d, dtype=tdt)
+        L.call("sv_nchw_to_nhwc", code, p(img.to(d)), 3, 3, 4, 4, 16, p(o), st())
+        assert rel(o[..., :3].float(), nhwc(bq(img, dt))) < 1e-6 and float(o[..., 3:].float().abs().max()) == 0
+        back = torch.empty(3, 3, 4, 4, device=d)
+        L.call("sv_nhwc_to_nchw", code, p(o), 3, 3, 4, 4, 16, p(back), st())
+        assert rel(back, bq(img, dt)) < 1e-6
+    torch.cuda.synchronize()
