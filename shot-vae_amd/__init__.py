@@ -1,3 +1,8 @@
 """shot-vae_amd: MI355X-native (gfx950 HIP) implementation of the SHOT-VAE training hot path behind
 the reference's Python API (FengHZ/SHOT-VAE: shot_vae_model/vae.py, lib/criterion.py,
 lib/utils/mixup.py, the step of main_shot_vae.py)."""
+from .vae import VariationalAutoEncoder          # noqa: F401
+from .criterion import VAECriterion, ClsCriterion, continuous_posterior_loss   # noqa: F401
+from .mixup import mixup_vae_data, label_smoothing, optimal_match_index        # noqa: F401
+from .optim import FlatSGD                        # noqa: F401
+from .train import train_step, schedule, alpha_schedule                        # noqa: F401

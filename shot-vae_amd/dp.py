@@ -1,0 +1,49 @@
+"""Data parallelism, MI355X-native: one process per GPU, each with a full replica and its shard of the
+labelled + unlabelled minibatch; ONE RCCL all-reduce (sum) of the flat fp32 gradient buffer per step
+over xGMI, the 1/world scaling folded into the SGD kernel.
+
+Replaces the 11 nn.DataParallel wrappers of the reference (wideresnet.py:78-93, vae.py:108-132,
+decoder.py:63-64): no per-forward parameter broadcast, no activation scatter/gather.  Same semantics
+where it matters: per-replica BatchNorm statistics, global-batch gradient (equal shards: mean of
+per-rank gradients whose losses use the local batch size).  Deviation: mixup / label-smoothing pairs
+are drawn inside the shard."""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """Initialise torch.distributed from torchrun-style env (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"      # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def shard(t, rank, world):
+    """Rows [rank*B/world, (rank+1)*B/world) of a batch (SURVEY.md §8e partitioning)."""
+    B = t.shape[0]
+    per = B // world
+    return t[rank * per: (rank + 1) * per]
+
+
+def broadcast_parameters(flat_param, flat_bufs=None, src=0):
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.broadcast(flat_param, src)
+        if flat_bufs is not None:
+            dist.broadcast(flat_bufs, src)
+
+
+def all_reduce_gradients(flat_grad):
+    """The single collective of a step.  Returns the scale the optimizer must apply (1/world)."""
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM)
+        return 1.0 / dist.get_world_size()
+    return 1.0

@@ -1,0 +1,625 @@
+"""Host-side plan of the SHOT-VAE network on MI355X: flat fp32 parameter / gradient buffers, packed
+weight shadows, and the launch sequences of one forward and one backward over the C ABI
+(include/shotvae_hip.h).  PyTorch is used for device memory and streams only.
+
+Reference being replaced: shot_vae_model/wideresnet.py:8-114 (encoder), shot_vae_model/decoder.py:4-69,
+shot_vae_model/vae.py:10-151 (heads, sampler, assembly) and autograd's backward of those.
+
+Data layout in HBM
+  activations     NHWC, element type = compute dtype (bf16 throughput mode / fp32 parity mode)
+  master weights  fp32, conv-like layers as [Cout][ky*k+kx][Cin] (so torch's OIHW / IOHW tensors are
+                  plain strided views of it), everything in ONE flat buffer -> one SGD launch, one
+                  RCCL all-reduce of the matching flat gradient buffer
+  packed weights  compute dtype, per layer one forward pack and one data-gradient pack
+                  ([n][tap][c], k contiguous = MFMA operand order), refreshed after each optimizer step
+"""
+import ctypes as C
+import math
+import re
+
+import torch
+
+from . import _lib as L
+from . import geometry as G
+
+LEAKY_SLOPE = 0.01     # nn.LeakyReLU default, wideresnet.py:28
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+CPAD = 16              # channel padding granule of the MFMA kernels
+
+
+def _align(n, a=64):
+    return (n + a - 1) // a * a
+
+
+def _pad16(c):
+    return (c + CPAD - 1) // CPAD * CPAD
+
+
+def parse_wideresnet(name):
+    """'wideresnet-D-W' (wideresnet.py:102-114).  Errors mirror the reference's."""
+    depth, width = re.findall(r"\d+", name)           # ValueError if not exactly two integers
+    depth, width = int(depth), int(width)
+    assert (depth - 4) % 6 == 0, "depth should be 6n+4"
+    return depth, width, (depth - 4) // 6
+
+
+class ConvSpec:
+    """One conv-like layer (Conv2d / ConvTranspose2d / the k=1 ConvTranspose GEMM)."""
+
+    def __init__(self, key, kind, k, stride, pad, cin, n, hin, cin_real=None, n_real=None):
+        self.key, self.kind, self.k, self.stride, self.pad = key, kind, k, stride, pad
+        self.Cin, self.N, self.Hin = cin, n, hin
+        self.cin_real, self.n_real = cin_real or cin, n_real or n
+        self.T = k * k
+        self.master_off = None
+        self.fwd_off = self.dgrad_off = None
+        self._g = {}
+
+    @property
+    def Hout(self):
+        if self.kind == "conv":
+            return (self.Hin + 2 * self.pad - self.k) // self.stride + 1
+        return self.Hin * self.stride
+
+    def geom_fwd(self, B):
+        g = self._g.get(("f", B))
+        if g is None:
+            if self.kind == "conv":
+                g = G.conv_like(B, self.Hin, self.Hin, self.Cin, self.N, self.k, self.stride, self.pad)
+            else:
+                g = G.convT_like(B, self.Hin, self.Hin, self.Cin, self.N, self.k, self.stride, self.pad)
+            self._g[("f", B)] = g
+        return g
+
+    def geom_dgrad(self, B):
+        """input = gradient w.r.t. this layer's output, output = gradient w.r.t. its input."""
+        g = self._g.get(("d", B))
+        if g is None:
+            ho = self.Hout
+            if self.kind == "conv":
+                g = G.convT_like(B, ho, ho, self.N, self.Cin, self.k, self.stride, self.pad)
+            else:
+                g = G.conv_like(B, ho, ho, self.N, self.Cin, self.k, self.stride, self.pad)
+            self._g[("d", B)] = g
+        return g
+
+    def torch_view(self, master):
+        """The reference-shaped (OIHW for Conv2d, IOHW for ConvTranspose2d) strided view."""
+        m = master[self.master_off: self.master_off + self.N * self.T * self.Cin].view(self.N, self.k, self.k, self.Cin)
+        if self.kind == "conv":
+            return m.permute(0, 3, 1, 2)[: self.n_real, : self.cin_real]
+        return m.permute(3, 0, 1, 2)[: self.cin_real, : self.n_real]
+
+
+class BNSpec:
+    def __init__(self, key, c, slope):
+        self.key, self.C, self.slope = key, c, slope
+        self.gamma_off = self.beta_off = self.rm_off = self.rv_off = None
+        self.buf_off = None      # offset into the per-forward (scale, shift, mean, rstd) scratch
+        self.index = None
+
+
+class Plan:
+    """Architecture + memory layout (device independent)."""
+
+    def __init__(self, encoder_name, in_ch=3, img=32, ldc=128, K=10):
+        if "wideresnet" not in encoder_name:
+            raise NotImplementedError("{} not implemented".format(encoder_name))
+        if img != 32 or in_ch > CPAD:
+            raise NotImplementedError("the MI355X path covers 32x32 inputs with <= 16 channels "
+                                      "(BASELINE.json configs); got img=%s ch=%s" % (img, in_ch))
+        self.name, self.in_ch, self.img, self.ldc, self.K = encoder_name, in_ch, img, ldc, K
+        _, width, n_units = parse_wideresnet(encoder_name)
+        self.widths = [int(16 * width), int(32 * width), int(64 * width)]
+        self.cfeat = self.widths[-1]
+        self.Lpad = _pad16(ldc + K)
+        self.NH = 2 * ldc + K
+        self.convs, self.bns, self.params = [], [], []     # params: (key, offset, shape-or-spec)
+        self.units = []
+        off = [0]
+
+        def alloc(n):
+            o = off[0]
+            off[0] = _align(o + n)
+            return o
+
+        def add_conv(spec):
+            spec.master_off = alloc(spec.N * spec.T * spec.Cin)
+            self.convs.append(spec)
+            self.params.append((spec.key + ".weight" if not spec.key.endswith("weight") else spec.key, spec))
+            return spec
+
+        def add_vec(key, n):
+            o = alloc(n)
+            self.params.append((key, (o, n)))
+            return o
+
+        def add_bn(key, c, slope):
+            b = BNSpec(key, c, slope)
+            b.gamma_off = add_vec(key + ".weight", c)
+            b.beta_off = add_vec(key + ".bias", c)
+            b.index = len(self.bns)
+            self.bns.append(b)
+            return b
+
+        enc = "feature_extractor.encoder."
+        self.stem = add_conv(ConvSpec(enc + "pre_process.conv0", "conv", 3, 1, 1, CPAD, 16, img,
+                                      cin_real=in_ch))
+        self.stem_bias_off = add_vec(enc + "pre_process.conv0.bias", 16)
+        cin, h = 16, img
+        for s, w in enumerate(self.widths):
+            for u in range(n_units):
+                stride = 2 if (s > 0 and u == 0) else 1
+                ci = cin if u == 0 else w
+                p = enc + "wideblock%d.wide_block.wideunit%d." % (s + 1, u + 1)
+                unit = dict(cin=ci, cout=w, stride=stride, hin=h)
+                unit["bn1"] = add_bn(p + "f_block.norm1", ci, LEAKY_SLOPE)
+                unit["conv1"] = add_conv(ConvSpec(p + "f_block.conv1", "conv", 3, stride, 1, ci, w, h))
+                unit["bn2"] = add_bn(p + "f_block.norm2", w, LEAKY_SLOPE)
+                unit["conv2"] = add_conv(ConvSpec(p + "f_block.conv2", "conv", 3, 1, 1, w, w, h // stride))
+                if ci != w or stride != 1:
+                    unit["bni"] = add_bn(p + "i_block.norm", ci, LEAKY_SLOPE)
+                    unit["convi"] = add_conv(ConvSpec(p + "i_block.conv", "conv", 1, stride, 0, ci, w, h))
+                h //= stride
+                self.units.append(unit)
+            cin = w
+        self.hfeat = h
+        self.bn_t = add_bn(enc + "transition.norm", self.cfeat, LEAKY_SLOPE)
+        # the three heads share one [2*ldc+K][C] matrix (vae.py:113-129)
+        self.head_w_off = alloc(self.NH * self.cfeat)
+        self.head_b_off = alloc(self.NH)
+        c = self.cfeat
+        for nm, r0, r1 in (("continuous_inference.mean.fc", 0, ldc),
+                           ("continuous_inference.log_sigma.fc", ldc, 2 * ldc),
+                           ("disc_latent_inference.fc", 2 * ldc, self.NH)):
+            self.params.append((nm + ".weight", (self.head_w_off + r0 * c, (r1 - r0, c))))
+            self.params.append((nm + ".bias", (self.head_b_off + r0, r1 - r0)))
+        # decoder (decoder.py:12-58): ConvT(latent,1024,k=img/32) then 5x ConvT(4,2,1)
+        dec = "feature_reconstructor.decoder."
+        chans = [1024, 512, 256, 128, 64]
+        self.dec_convs, self.dec_bns = [], []
+        self.dec_convs.append(add_conv(ConvSpec(dec + "0", "convT", 1, 1, 0, self.Lpad, chans[0], 1,
+                                                cin_real=ldc + K)))
+        hh = 1
+        for i in range(5):
+            self.dec_bns.append(add_bn(dec + "%d" % (3 * i + 1), chans[i], 0.0))
+            nout = chans[i + 1] if i < 4 else _pad16(in_ch)
+            self.dec_convs.append(add_conv(ConvSpec(dec + "%d" % (3 * i + 3), "convT", 4, 2, 1, chans[i], nout, hh,
+                                                    n_real=(chans[i + 1] if i < 4 else in_ch))))
+            hh *= 2
+        self.n_param = off[0]
+        # BN running statistics and per-forward scratch
+        o = 0
+        for b in self.bns:
+            b.rm_off, b.rv_off = o, o + _align(b.C)
+            o += 2 * _align(b.C)
+        self.n_buf = o
+        o = 0
+        for b in self.bns:
+            b.buf_off = o
+            o += 4 * _align(b.C)
+        self.n_bnbuf = o
+        # packed weights
+        o = 0
+        for cv in self.convs:
+            cv.fwd_off = o
+            o = _align(o + G.packed_size(cv.geom_fwd(1)))
+            cv.dgrad_off = o
+            o = _align(o + G.packed_size(cv.geom_dgrad(1)))
+        self.n_pack = o
+
+    # -- reference state_dict keys (data_parallel=False naming) in the reference's order ---------
+    def state_items(self):
+        """yield (key, kind, payload): kind in {'conv','vec','mat','rm','rv','nbt'}."""
+        bn_by_key = {b.key: b for b in self.bns}
+        out = []
+        for key, payload in self.params:
+            if isinstance(payload, ConvSpec):
+                out.append((key, "conv", payload))
+            elif isinstance(payload[1], tuple):
+                out.append((key, "mat", payload))
+            else:
+                out.append((key, "vec", payload))
+            if key.endswith(".bias") and key[:-5] in bn_by_key:
+                b = bn_by_key[key[:-5]]
+                out.append((b.key + ".running_mean", "rm", b))
+                out.append((b.key + ".running_var", "rv", b))
+                out.append((b.key + ".num_batches_tracked", "nbt", b))
+        return out
+
+
+def _vp(x):
+    return C.c_void_p(x)
+
+
+class FwdCtx:
+    """Everything one forward leaves behind for its backward."""
+    pass
+
+
+class Engine:
+    """Device state + launch sequences.  All methods enqueue on torch's current stream."""
+
+    def __init__(self, plan, compute_dtype="bf16"):
+        self.plan = plan
+        self.set_compute_dtype(compute_dtype)
+        p = plan
+        self.param = torch.zeros(p.n_param, dtype=torch.float32)
+        self.grad = torch.zeros(p.n_param, dtype=torch.float32)
+        self.mom = None
+        self.bufs = torch.zeros(p.n_buf, dtype=torch.float32)
+        self.nbt = torch.zeros(len(p.bns), dtype=torch.int64)
+        self.packs = None
+        self._pack_key = None
+        self._manual_epoch = 0
+        self.use_tr = 1
+        self.prof_tags = None
+        self.version_probe = None     # callable: summed version counters of the nn.Parameters (set by the module)
+        for b in p.bns:
+            self.bufs[b.rv_off: b.rv_off + b.C] = 1.0
+
+    def set_compute_dtype(self, compute_dtype):
+        assert compute_dtype in ("bf16", "fp32"), compute_dtype
+        self.compute_dtype = compute_dtype
+        self.code = L.SV_BF16 if compute_dtype == "bf16" else L.SV_F32
+        self.tdtype = torch.bfloat16 if compute_dtype == "bf16" else torch.float32
+        self.packs = None
+        self._pack_key = None
+
+    # ------------------------------------------------------------------------------- storage
+    def to(self, fn):
+        """Apply a torch `_apply` function (device move) to the flat buffers."""
+        new = fn(self.param)
+        if new.dtype != torch.float32:
+            raise TypeError("shot-vae_amd keeps fp32 master weights; choose the compute dtype with "
+                            "compute_dtype='bf16'|'fp32' instead of .half()/.bfloat16()")
+        self.param, self.grad = new, fn(self.grad)
+        self.bufs, self.nbt = fn(self.bufs), fn(self.nbt)
+        if self.mom is not None:
+            self.mom = fn(self.mom)
+        self.packs, self._pack_key = None, None
+
+    def init_default(self, seed=None):
+        """PyTorch default initialisation (the reference defines no custom init):
+        conv / convT / linear weights and biases U(+-1/sqrt(fan_in)), BN gamma 1, beta 0."""
+        g = torch.Generator()
+        if seed is not None:
+            g.manual_seed(seed)
+        else:
+            g.manual_seed(int(torch.randint(0, 2 ** 31 - 1, (1,))))
+        p = self.plan
+        self.param.zero_()
+        for key, kind, payload in p.state_items():
+            if kind == "conv":
+                v = payload.torch_view(self.param)
+                fan_in = v.shape[1] * v.shape[2] * v.shape[3]
+                v.copy_((torch.rand(v.shape, generator=g) * 2 - 1) / math.sqrt(fan_in))
+            elif kind == "mat":
+                off, (r, c) = payload
+                self.param[off: off + r * c] = ((torch.rand(r * c, generator=g) * 2 - 1) / math.sqrt(c)).to(self.param.device)
+            elif kind == "vec":
+                off, n = payload
+                if key.endswith("conv0.bias"):
+                    fan = p.in_ch * 9
+                    self.param[off: off + n] = ((torch.rand(n, generator=g) * 2 - 1) / math.sqrt(fan)).to(self.param.device)
+                elif key.endswith("fc.bias"):
+                    self.param[off: off + n] = ((torch.rand(n, generator=g) * 2 - 1) / math.sqrt(p.cfeat)).to(self.param.device)
+                elif key.endswith(".weight"):
+                    self.param[off: off + n] = 1.0
+        self.mark_dirty()
+
+    def mark_dirty(self):
+        self._manual_epoch += 1
+
+    # ------------------------------------------------------------------------------- helpers
+    def _stream(self):
+        return _vp(torch.cuda.current_stream().cuda_stream)
+
+    def _require_gpu(self, t):
+        if not t.is_cuda or not self.param.is_cuda:
+            raise L.ShotVaeHipError("shot-vae_amd runs on an MI355X only (HIP kernels, no CPU fallback): "
+                                    "move the model and its inputs to cuda first")
+        L.lib()
+
+    def _tag(self, name):
+        if self.prof_tags is not None:
+            t = self.prof_tags.setdefault(name, len(self.prof_tags))
+            L.lib().sv_prof_tag(t)
+
+    def ensure_packs(self):
+        ver = self.param._version + (self.version_probe() if self.version_probe is not None else 0)
+        key = (ver, self._manual_epoch, self.param.data_ptr(), self.compute_dtype)
+        if self.packs is not None and key == self._pack_key:
+            return
+        p = self.plan
+        if self.packs is None or self.packs.dtype != self.tdtype or self.packs.device != self.param.device:
+            self.packs = torch.zeros(p.n_pack, dtype=self.tdtype, device=self.param.device)
+        st = self._stream()
+        base, pb, es = self.param.data_ptr(), self.packs.data_ptr(), self.packs.element_size()
+        for cv in p.convs:
+            m = _vp(base + 4 * cv.master_off)
+            L.call("sv_repack", self.code, m, cv.N, cv.T, cv.Cin, 0, C.byref(cv.geom_fwd(1)),
+                   _vp(pb + es * cv.fwd_off), st)
+            L.call("sv_repack", self.code, m, cv.N, cv.T, cv.Cin, 1, C.byref(cv.geom_dgrad(1)),
+                   _vp(pb + es * cv.dgrad_off), st)
+        self._pack_key = key
+
+    def _igemm(self, g, x, w_ptr, out, pro=None, bias=None, residual=None, stats=None, ex=None, tag=None):
+        a = L.SvIgemmArgs()
+        a.x, a.w, a.out = x.data_ptr(), w_ptr, out.data_ptr()
+        if pro is not None:
+            a.pro_scale, a.pro_shift, a.pro_slope = pro[0], pro[1], pro[2]
+        if bias is not None:
+            a.bias = bias
+        if residual is not None:
+            a.residual = residual.data_ptr()
+        if stats is not None:
+            a.stats = stats
+        if ex is not None:
+            a.ex = ex[0].data_ptr()
+            a.ex_scale, a.ex_shift, a.ex_mean, a.ex_rstd, a.ex_slope, a.bsums = ex[1:]
+        if tag:
+            self._tag(tag)
+        L.call("sv_igemm", C.byref(g), self.code, C.byref(a), self._stream())
+
+    def _wgrad(self, g, x, pro, dy, dw_ptr, tag=None):
+        if tag:
+            self._tag(tag)
+        ps, pt, sl = (pro[0], pro[1], pro[2]) if pro is not None else (None, None, 0.0)
+        L.call("sv_wgrad", C.byref(g), self.code, _vp(x.data_ptr()), _vp(ps) if ps else None,
+               _vp(pt) if pt else None, sl, _vp(dy.data_ptr()), _vp(dw_ptr), 0, self.use_tr, self._stream())
+
+    # ------------------------------------------------------------------------------- forward
+    def forward(self, image, mode, label, label_mix, lam, eps, u, temperature, training, keep):
+        """image NCHW fp32 on device.  Returns (rec NCHW fp32, mu, ls, la, ctx-or-None)."""
+        self._require_gpu(image)
+        p = self.plan
+        B = image.shape[0]
+        dev = image.device
+        T = self.tdtype
+        st = self._stream()
+        self.ensure_packs()
+        image = image.contiguous().float()
+        pbase, bbase = self.param.data_ptr(), self.bufs.data_ptr()
+        pk, es = self.packs.data_ptr(), self.packs.element_size()
+
+        # per-forward scratch: BN statistics (zeroed), BN affine/mean/rstd
+        n_stat = 0
+        stat_off = {}
+
+        def stat_slot(name, c):
+            nonlocal n_stat
+            stat_off[name] = n_stat
+            n_stat += 2 * _align(c)
+
+        stat_slot("t0", 16)
+        for i, un in enumerate(p.units):
+            stat_slot("c1_%d" % i, un["cout"])
+            stat_slot("t%d" % (i + 1), un["cout"])
+        for i in range(5):
+            stat_slot("h%d" % i, p.dec_convs[i].N)
+        stats = torch.zeros(n_stat, dtype=torch.float32, device=dev)
+        sbase = stats.data_ptr()
+        bnbuf = torch.empty(p.n_bnbuf, dtype=torch.float32, device=dev)
+        nb = bnbuf.data_ptr()
+
+        def bn_ptrs(b):
+            a = _align(b.C)
+            o = nb + 4 * b.buf_off
+            return o, o + 4 * a, o + 8 * a, o + 12 * a       # scale, shift, mean, rstd
+
+        def finalize(b, stat_name, count):
+            sc, sh, mn, rs = bn_ptrs(b)
+            if training:
+                L.call("sv_bn_finalize", _vp(sbase + 4 * stat_off[stat_name]), b.C, float(count),
+                       _vp(pbase + 4 * b.gamma_off), _vp(pbase + 4 * b.beta_off), BN_EPS, BN_MOMENTUM,
+                       _vp(bbase + 4 * b.rm_off), _vp(bbase + 4 * b.rv_off), _vp(sc), _vp(sh), _vp(mn), _vp(rs), st)
+            else:
+                L.call("sv_bn_eval_affine", b.C, _vp(pbase + 4 * b.gamma_off), _vp(pbase + 4 * b.beta_off),
+                       _vp(bbase + 4 * b.rm_off), _vp(bbase + 4 * b.rv_off), BN_EPS, _vp(sc), _vp(sh), st)
+            return (sc, sh, b.slope)
+
+        def sptr(name):
+            # in eval mode BN uses running statistics; batch statistics are not accumulated
+            return (sbase + 4 * stat_off[name]) if training else None
+
+        f = FwdCtx()
+        f.B, f.mode, f.lam, f.temperature, f.training = B, mode, lam, temperature, training
+        f.bnbuf = bnbuf
+        # stem (wideresnet.py:13-14): NCHW fp32 -> NHWC16, conv3x3 + bias, stats of t0
+        x16 = torch.empty(B, p.img, p.img, CPAD, dtype=T, device=dev)
+        L.call("sv_nchw_to_nhwc", self.code, _vp(image.data_ptr()), B, p.in_ch, p.img, p.img, CPAD,
+               _vp(x16.data_ptr()), st)
+        t = torch.empty(B, p.img, p.img, 16, dtype=T, device=dev)
+        self._igemm(p.stem.geom_fwd(B), x16, pk + es * p.stem.fwd_off, t, bias=pbase + 4 * p.stem_bias_off,
+                    stats=sptr("t0"), tag="fwd:stem")
+        f.x16, f.t, f.c1, f.pro = x16, [t], [], []
+        h = p.img
+        for i, un in enumerate(p.units):
+            cnt_in = B * h * h
+            tin = f.t[-1]
+            pro1 = finalize(un["bn1"], "t%d" % i, cnt_in)
+            ho = h // un["stride"]
+            c1 = torch.empty(B, ho, ho, un["cout"], dtype=T, device=dev)
+            self._igemm(un["conv1"].geom_fwd(B), tin, pk + es * un["conv1"].fwd_off, c1, pro=pro1,
+                        stats=sptr("c1_%d" % i), tag="fwd:conv3x3_c%d_s%d" % (un["cout"], un["stride"]))
+            pro2 = finalize(un["bn2"], "c1_%d" % i, B * ho * ho)
+            tout = torch.empty(B, ho, ho, un["cout"], dtype=T, device=dev)
+            if "convi" in un:
+                proi = finalize(un["bni"], "t%d" % i, cnt_in)
+                sc = torch.empty(B, ho, ho, un["cout"], dtype=T, device=dev)
+                self._igemm(un["convi"].geom_fwd(B), tin, pk + es * un["convi"].fwd_off, sc, pro=proi,
+                            tag="fwd:conv1x1")
+                res = sc
+            else:
+                proi = None
+                res = tin
+            self._igemm(un["conv2"].geom_fwd(B), c1, pk + es * un["conv2"].fwd_off, tout, pro=pro2, residual=res,
+                        stats=sptr("t%d" % (i + 1)), tag="fwd:conv3x3_c%d_s1" % un["cout"])
+            f.c1.append(c1)
+            f.t.append(tout)
+            f.pro.append((pro1, pro2, proi))
+            h = ho
+        # transition BN + LeakyReLU + global average pool (wideresnet.py:90-91, vae.py:143)
+        prot = finalize(p.bn_t, "t%d" % len(p.units), B * h * h)
+        feat = torch.empty(B, p.cfeat, dtype=torch.float32, device=dev)
+        L.call("sv_pool_fwd", self.code, _vp(f.t[-1].data_ptr()), _vp(prot[0]), _vp(prot[1]), prot[2], B, h * h,
+               p.cfeat, p.cfeat, _vp(feat.data_ptr()), st)
+        mu = torch.empty(B, p.ldc, dtype=torch.float32, device=dev)
+        ls = torch.empty(B, p.ldc, dtype=torch.float32, device=dev)
+        la = torch.empty(B, p.K, dtype=torch.float32, device=dev)
+        L.call("sv_head_fwd", _vp(feat.data_ptr()), B, p.cfeat, _vp(pbase + 4 * p.head_w_off),
+               _vp(pbase + 4 * p.head_b_off), p.ldc, p.K, _vp(mu.data_ptr()), _vp(ls.data_ptr()),
+               _vp(la.data_ptr()), st)
+        latent = torch.empty(B, p.Lpad, dtype=T, device=dev)
+        csoft = torch.empty(B, p.K, dtype=torch.float32, device=dev)
+        L.call("sv_sample_fwd", self.code, _vp(mu.data_ptr()), _vp(ls.data_ptr()), _vp(la.data_ptr()),
+               _vp(eps.data_ptr()), _vp(u.data_ptr()) if u is not None else None,
+               _vp(label.data_ptr()) if label is not None else None,
+               _vp(label_mix.data_ptr()) if label_mix is not None else None,
+               float(lam), mode, float(temperature), B, p.ldc, p.K, p.Lpad, _vp(latent.data_ptr()),
+               _vp(csoft.data_ptr()), st)
+        # decoder (decoder.py:12-58)
+        f.h = []
+        hh = 1
+        x = latent.view(B, 1, 1, p.Lpad)
+        pro = None
+        f.dpro = []
+        for i, cv in enumerate(p.dec_convs):
+            ho = cv.Hout
+            out = torch.empty(B, ho, ho, cv.N, dtype=T, device=dev)
+            self._igemm(cv.geom_fwd(B), x, pk + es * cv.fwd_off, out, pro=pro,
+                        stats=sptr("h%d" % i) if i < 5 else None, tag="fwd:dec%d" % i)
+            f.h.append(out)
+            if i < 5:
+                pro = finalize(p.dec_bns[i], "h%d" % i, B * ho * ho)
+                f.dpro.append(pro)
+                x = out
+        rec = torch.empty(B, p.in_ch, p.img, p.img, dtype=torch.float32, device=dev)
+        L.call("sv_nhwc_to_nchw", self.code, _vp(f.h[5].data_ptr()), B, p.in_ch, p.img, p.img, p.dec_convs[5].N,
+               _vp(rec.data_ptr()), st)
+        if training:
+            self.nbt += 1
+        if not keep:
+            return rec, mu, ls, la, None
+        f.prot, f.feat, f.mu, f.ls, f.la = prot, feat, mu, ls, la
+        f.eps, f.csoft, f.latent = eps, csoft, latent
+        f.keep = (label, label_mix, u, stats)
+        return rec, mu, ls, la, f
+
+    # ------------------------------------------------------------------------------- backward
+    def backward(self, f, d_rec, d_mu, d_ls, d_la):
+        """Gradients accumulate (+=) into self.grad; nothing is returned (inputs need no grad)."""
+        p = self.plan
+        B, T = f.B, self.tdtype
+        dev = f.mu.device
+        st = self._stream()
+        pbase, gbase = self.param.data_ptr(), self.grad.data_ptr()
+        pk, es = self.packs.data_ptr(), self.packs.element_size()
+        nb = f.bnbuf.data_ptr()
+        # one zeroed scratch for every (sum g, sum g*xhat) pair of this backward
+        tot = sum(2 * _align(b.C) for b in p.bns)
+        bsums = torch.zeros(tot, dtype=torch.float32, device=dev)
+        bs_off = {}
+        o = 0
+        for b in p.bns:
+            bs_off[b.index] = bsums.data_ptr() + 4 * o
+            o += 2 * _align(b.C)
+
+        def bnp(b):
+            a = _align(b.C)
+            q = nb + 4 * b.buf_off
+            return q, q + 4 * a, q + 8 * a, q + 12 * a
+
+        def ex_of(b, raw):
+            sc, sh, mn, rs = bnp(b)
+            return (raw, sc, sh, mn, rs, b.slope, bs_off[b.index])
+
+        def bn_apply(raw, branches, residual, count):
+            """branches: [(g tensor, BNSpec)] sharing `raw`; returns dL/d(raw) (+ residual)."""
+            arr = (L.SvBnBranch * len(branches))()
+            for k, (g, b) in enumerate(branches):
+                arr[k].g = g.data_ptr()
+                arr[k].bsums = bs_off[b.index]
+                arr[k].gamma = pbase + 4 * b.gamma_off
+                arr[k].dgamma = gbase + 4 * b.gamma_off
+                arr[k].dbeta = gbase + 4 * b.beta_off
+            b0 = branches[0][1]
+            _, _, mn, rs = bnp(b0)
+            dx = torch.empty_like(raw)
+            cc = raw.shape[-1]
+            L.call("sv_bn_bwd_apply", self.code, raw.numel() // cc, cc, cc, _vp(raw.data_ptr()), _vp(mn), _vp(rs),
+                   float(count), arr, len(branches), _vp(residual.data_ptr()) if residual is not None else None,
+                   _vp(dx.data_ptr()), st)
+            return dx
+
+        # ---- decoder ------------------------------------------------------------------------
+        last = p.dec_convs[5]
+        D = torch.empty(B, p.img, p.img, last.N, dtype=T, device=dev)
+        L.call("sv_nchw_to_nhwc", self.code, _vp(d_rec.data_ptr()), B, p.in_ch, p.img, p.img, last.N,
+               _vp(D.data_ptr()), st)
+        for i in range(5, 0, -1):
+            cv, b = p.dec_convs[i], p.dec_bns[i - 1]
+            hin = f.h[i - 1]
+            self._wgrad(cv.geom_fwd(B), hin, f.dpro[i - 1], D, gbase + 4 * cv.master_off, tag="wgrad:dec%d" % i)
+            g = torch.empty_like(hin)
+            self._igemm(cv.geom_dgrad(B), D, pk + es * cv.dgrad_off, g, ex=ex_of(b, hin), tag="dgrad:dec%d" % i)
+            D = bn_apply(hin, [(g, b)], None, hin.numel() // hin.shape[-1])
+        cv = p.dec_convs[0]
+        lat4 = f.latent.view(B, 1, 1, p.Lpad)
+        self._wgrad(cv.geom_fwd(B), lat4, None, D, gbase + 4 * cv.master_off, tag="wgrad:dec0")
+        dlat = torch.empty(B, 1, 1, p.Lpad, dtype=T, device=dev)
+        self._igemm(cv.geom_dgrad(B), D, pk + es * cv.dgrad_off, dlat, tag="dgrad:dec0")
+        # ---- sampler + heads + pool -----------------------------------------------------------
+        dmu = d_mu.contiguous().float().clone() if d_mu is not None else torch.zeros_like(f.mu)
+        dls = d_ls.contiguous().float().clone() if d_ls is not None else torch.zeros_like(f.ls)
+        dla = d_la.contiguous().float().clone() if d_la is not None else torch.zeros_like(f.la)
+        L.call("sv_sample_bwd", self.code, _vp(dlat.data_ptr()), _vp(f.ls.data_ptr()), _vp(f.eps.data_ptr()),
+               _vp(f.csoft.data_ptr()), f.mode, float(f.temperature), B, p.ldc, p.K, p.Lpad, _vp(dmu.data_ptr()),
+               _vp(dls.data_ptr()), _vp(dla.data_ptr()), st)
+        dfeat = torch.empty(B, p.cfeat, dtype=torch.float32, device=dev)
+        ws = torch.empty(B, p.NH, dtype=torch.float32, device=dev)
+        L.call("sv_head_bwd", _vp(f.feat.data_ptr()), B, p.cfeat, _vp(pbase + 4 * p.head_w_off), p.ldc, p.K,
+               _vp(f.la.data_ptr()), _vp(dmu.data_ptr()), _vp(dls.data_ptr()), _vp(dla.data_ptr()),
+               _vp(dfeat.data_ptr()), _vp(gbase + 4 * p.head_w_off), _vp(gbase + 4 * p.head_b_off),
+               _vp(ws.data_ptr()), st)
+        tl = f.t[-1]
+        hw = tl.shape[1] * tl.shape[2]
+        g = torch.empty_like(tl)
+        sc, sh, mn, rs = bnp(p.bn_t)
+        L.call("sv_pool_bwd", self.code, _vp(tl.data_ptr()), _vp(sc), _vp(sh), p.bn_t.slope, _vp(mn), _vp(rs),
+               _vp(dfeat.data_ptr()), B, hw, p.cfeat, p.cfeat, _vp(g.data_ptr()), _vp(bs_off[p.bn_t.index]), st)
+        D = bn_apply(tl, [(g, p.bn_t)], None, B * hw)
+        # ---- encoder units, last to first (wideresnet.py:45-49 backward) ------------------------
+        for i in range(len(p.units) - 1, -1, -1):
+            un = p.units[i]
+            tin, c1 = f.t[i], f.c1[i]
+            pro1, pro2, proi = f.pro[i]
+            c = un["cout"]
+            self._wgrad(un["conv2"].geom_fwd(B), c1, pro2, D, gbase + 4 * un["conv2"].master_off,
+                        tag="wgrad:conv3x3_c%d_s1" % c)
+            g2 = torch.empty_like(c1)
+            self._igemm(un["conv2"].geom_dgrad(B), D, pk + es * un["conv2"].dgrad_off, g2, ex=ex_of(un["bn2"], c1),
+                        tag="dgrad:conv3x3_c%d_s1" % c)
+            dc1 = bn_apply(c1, [(g2, un["bn2"])], None, c1.numel() // c)
+            del g2
+            self._wgrad(un["conv1"].geom_fwd(B), tin, pro1, dc1, gbase + 4 * un["conv1"].master_off,
+                        tag="wgrad:conv3x3_c%d_s%d" % (c, un["stride"]))
+            g1 = torch.empty_like(tin)
+            self._igemm(un["conv1"].geom_dgrad(B), dc1, pk + es * un["conv1"].dgrad_off, g1, ex=ex_of(un["bn1"], tin),
+                        tag="dgrad:conv3x3_c%d_s%d" % (c, un["stride"]))
+            del dc1
+            cnt = tin.numel() // tin.shape[-1]
+            if "convi" in un:
+                self._wgrad(un["convi"].geom_fwd(B), tin, proi, D, gbase + 4 * un["convi"].master_off,
+                            tag="wgrad:conv1x1")
+                gi = torch.empty_like(tin)
+                self._igemm(un["convi"].geom_dgrad(B), D, pk + es * un["convi"].dgrad_off, gi,
+                            ex=ex_of(un["bni"], tin), tag="dgrad:conv1x1")
+                D = bn_apply(tin, [(g1, un["bn1"]), (gi, un["bni"])], None, cnt)
+            else:
+                D = bn_apply(tin, [(g1, un["bn1"])], D, cnt)
+        # ---- stem: weight + bias gradients (the image needs none) ---------------------------------
+        self._wgrad(p.stem.geom_fwd(B), f.x16, None, D, gbase + 4 * p.stem.master_off, tag="wgrad:stem")
+        L.call("sv_colsum", self.code, _vp(D.data_ptr()), D.numel() // 16, 16, 16, _vp(gbase + 4 * p.stem_bias_off), st)

@@ -58,3 +58,41 @@ def oracle_run(tag):
         outs.append(out)
         O.sgd_step(st, mom, lr=0.1, momentum=0.9, weight_decay=5e-4)
     return outs, st
+
+
+# ---- scripted host RNG (same technique as tests/golden/make_goldens.py) -------------------------
+import contextlib
+
+
+@contextlib.contextmanager
+def scripted_rng(randn=(), rand=(), randperm=(), beta=()):
+    """Replace torch.randn / torch.rand / torch.randperm / numpy.random.beta with scripted queues so
+    that the reference-compatible host-RNG code paths consume exactly the fixture's noise."""
+    q = dict(randn=list(randn), rand=list(rand), randperm=list(randperm), beta=list(beta))
+    saved = (torch.randn, torch.rand, torch.randperm, np.random.beta)
+
+    def pop(kind, size=None):
+        v = q[kind].pop(0)
+        if size is not None and torch.is_tensor(v):
+            assert tuple(v.shape) == tuple(size), (kind, tuple(v.shape), tuple(size))
+        return v.clone() if torch.is_tensor(v) else v
+
+    def _sz(s):
+        return s[0] if len(s) == 1 and not isinstance(s[0], int) else s
+
+    torch.randn = lambda *s, **k: pop("randn", _sz(s))
+    torch.rand = lambda *s, **k: pop("rand", _sz(s))
+    torch.randperm = lambda n, **k: pop("randperm", (n,))
+    np.random.beta = lambda a, b: pop("beta")
+    try:
+        yield
+    finally:
+        torch.randn, torch.rand, torch.randperm, np.random.beta = saved
+        for k, v in q.items():
+            assert not v, "unused scripted %s draws: %d" % (k, len(v))
+
+
+def rng_for_step(nz, om=False):
+    return scripted_rng(randn=[nz["eps1"], nz["eps2"], nz["eps3"], nz["eps4"]], rand=[nz["u3"], nz["u4"]],
+                        randperm=[nz["perm_l"]] + ([] if om else [nz["perm_u"]]),
+                        beta=[nz["lam_l"], nz["lam_u"]])
