@@ -65,14 +65,16 @@ typedef struct {
     const float* bias;          /* [N] or NULL                                                       */
     const void* residual;       /* same layout as out, or NULL                                       */
     void* out;
-    float* stats;               /* [2N] += (sum y, sum y^2) or NULL                                  */
+    float* stats;               /* [R][2N] += (sum y, sum y^2) or NULL; block b adds to replica b % R  */
     const void* ex;             /* act-backward epilogue: raw tensor at the output positions / NULL  */
     const float* ex_scale;      /* [N] each                                                          */
     const float* ex_shift;
     const float* ex_mean;
     const float* ex_rstd;
     float ex_slope;
-    float* bsums;               /* [2N] += (sum g, sum g*xhat)                                       */
+    float* bsums;               /* [R][2N] += (sum g, sum g*xhat)                                    */
+    int32_t replicas;           /* R: power of two >= 1; spreads the per-channel atomics of the many
+                                   blocks of a launch over R copies (consumers sum the copies)        */
 } sv_igemm_args;
 
 int sv_igemm(const sv_geom* g, int dtype, const sv_igemm_args* a, void* stream);
@@ -87,9 +89,9 @@ int sv_wgrad(const sv_geom* g, int dtype, const void* x, const float* pro_scale,
 int sv_colsum(int dtype, const void* y, int64_t M, int N, int ld, float* out, void* stream);
 
 /* ---- K4 BatchNorm2d train-mode finalize (nn.BatchNorm2d semantics, eps/momentum explicit) -------
- * stats=[sum, sumsq] -> scale=gamma*rstd, shift=beta-mean*scale; saves mean/rstd; updates running
+ * stats=[R][sum, sumsq] -> scale=gamma*rstd, shift=beta-mean*scale; saves mean/rstd; updates running
  * stats (unbiased var) unless running_mean is NULL.                                                 */
-int sv_bn_finalize(const float* stats, int C, float count, const float* gamma, const float* beta,
+int sv_bn_finalize(const float* stats, int replicas, int C, float count, const float* gamma, const float* beta,
                    float eps, float momentum, float* running_mean, float* running_var,
                    float* scale, float* shift, float* mean, float* rstd, void* stream);
 /* eval-mode affine from running statistics (main_shot_vae.py:409-510 path)                         */
@@ -99,6 +101,7 @@ int sv_bn_eval_affine(int C, const float* gamma, const float* beta, const float*
  * for one or two BN branches that share the input x; dgamma/dbeta accumulate (+=).                  */
 typedef struct {
     const void* g; const float* bsums; const float* gamma; float* dgamma; float* dbeta;
+    int32_t replicas;           /* bsums is [replicas][2C]                                           */
 } sv_bn_branch;
 int sv_bn_bwd_apply(int dtype, int64_t M, int C, int ld, const void* x, const float* mean,
                     const float* rstd, float count, const sv_bn_branch* br, int nbranch,

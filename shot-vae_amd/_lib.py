@@ -32,12 +32,13 @@ class SvIgemmArgs(C.Structure):
     _fields_ = [("x", C.c_void_p), ("pro_scale", C.c_void_p), ("pro_shift", C.c_void_p), ("pro_slope", C.c_float),
                 ("w", C.c_void_p), ("bias", C.c_void_p), ("residual", C.c_void_p), ("out", C.c_void_p),
                 ("stats", C.c_void_p), ("ex", C.c_void_p), ("ex_scale", C.c_void_p), ("ex_shift", C.c_void_p),
-                ("ex_mean", C.c_void_p), ("ex_rstd", C.c_void_p), ("ex_slope", C.c_float), ("bsums", C.c_void_p)]
+                ("ex_mean", C.c_void_p), ("ex_rstd", C.c_void_p), ("ex_slope", C.c_float), ("bsums", C.c_void_p),
+                ("replicas", C.c_int32)]
 
 
 class SvBnBranch(C.Structure):
     _fields_ = [("g", C.c_void_p), ("bsums", C.c_void_p), ("gamma", C.c_void_p), ("dgamma", C.c_void_p),
-                ("dbeta", C.c_void_p)]
+                ("dbeta", C.c_void_p), ("replicas", C.c_int32)]
 
 
 P, I, I64, F = C.c_void_p, C.c_int, C.c_int64, C.c_float
@@ -45,7 +46,7 @@ _PROTOS = {
     "sv_igemm": [C.POINTER(SvGeom), I, C.POINTER(SvIgemmArgs), P],
     "sv_wgrad": [C.POINTER(SvGeom), I, P, P, P, F, P, P, I, I, P],
     "sv_colsum": [I, P, I64, I, I, P, P],
-    "sv_bn_finalize": [P, I, F, P, P, F, F, P, P, P, P, P, P, P],
+    "sv_bn_finalize": [P, I, I, F, P, P, F, F, P, P, P, P, P, P, P],
     "sv_bn_eval_affine": [I, P, P, P, P, F, P, P, P],
     "sv_bn_bwd_apply": [I, I64, I, I, P, P, P, F, C.POINTER(SvBnBranch), I, P, P, P],
     "sv_pool_fwd": [I, P, P, P, F, I, I, I, I, P, P],

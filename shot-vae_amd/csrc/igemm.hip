@@ -40,10 +40,16 @@ __global__ __launch_bounds__(256) void igemm_kernel(const sv_geom g, const sv_ig
     // XCD-aware mapping: blocks L and L+8 share an XCD (and its L2); all channel tiles and phases
     // of one m-tile run back to back on the same XCD so the gathered input is fetched once.
     const int L = blockIdx.x;
-    const int xcd = L & 7, slot = L >> 3;
-    const int in_i = slot % inner;
-    const int mt = (slot / inner) * 8 + xcd;
-    if (mt >= nMt) return;
+    int in_i, mt;
+    if (nMt >= 64) {
+        const int xcd = L & 7, slot = L >> 3;
+        in_i = slot % inner;
+        mt = (slot / inner) * 8 + xcd;
+        if (mt >= nMt) return;
+    } else {            // few m-tiles: plain mapping so that every XCD gets work
+        in_i = L % inner;
+        mt = L / inner;
+    }
     const int ph = in_i / nNt;
     const int n0 = (in_i % nNt) * BN;
     const sv_phase& P = g.phase[ph];
@@ -83,6 +89,10 @@ __global__ __launch_bounds__(256) void igemm_kernel(const sv_geom g, const sv_ig
     bool oka[2];
     int ca = 0;
 
+    V zero;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) zero[j] = (T)0.f;
+    // Branch-free loader: clamped addresses, unconditional loads (all in flight together), select.
     auto load_global = [&](int kc) {
         const int tt = tap < SV_MAX_TAPS ? tap : SV_MAX_TAPS - 1;
         const int dy = tap_off(pdy, tt), dx = tap_off(pdx, tt);
@@ -93,22 +103,18 @@ __global__ __launch_bounds__(256) void igemm_kernel(const sv_geom g, const sv_ig
             const bool ok = mval[i] && tap < ntap && (unsigned)iy < (unsigned)g.Hin &&
                             (unsigned)ix < (unsigned)g.Win;
             oka[i] = ok;
-            V val;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) val[j] = (T)0.f;
-            if (ok) val = *reinterpret_cast<const V*>(X + ((int64_t)(pixb[i] + iy * g.Win + ix) * g.ldx + c));
-            ra[i] = val;
+            const int iyc = min(max(iy, 0), g.Hin - 1), ixc = min(max(ix, 0), g.Win - 1);
+            const V val = *reinterpret_cast<const V*>(X + ((int64_t)(pixb[i] + iyc * g.Win + ixc) * g.ldx + c));
+            ra[i] = ok ? val : zero;
         }
         const int k8 = kc * BK + 8 * v;
+        const int k8c = min(k8, Ktot - 8);
 #pragma unroll
         for (int i = 0; i < NBV; ++i) {
             const int nb = lrow + 64 * i;
-            V val;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) val[j] = (T)0.f;
-            if (nb < BN && n0 + nb < g.N && k8 < Ktot)
-                val = *reinterpret_cast<const V*>(W + (int64_t)(n0 + nb) * Ktot + k8);
-            rb[i] = val;
+            const bool ok = nb < BN && n0 + nb < g.N && k8 < Ktot;
+            const V val = *reinterpret_cast<const V*>(W + (int64_t)min(n0 + nb, g.N - 1) * Ktot + k8c);
+            rb[i] = ok ? val : zero;
         }
         // advance (tap, c) to the next chunk
         c += BK;
@@ -265,7 +271,9 @@ __global__ __launch_bounds__(256) void igemm_kernel(const sv_geom g, const sv_ig
     }
     if (want_sums) {
         __syncthreads();
-        float* dst = EX ? a.bsums : a.stats;
+        // replica chosen by block index: keeps the number of adders per address low (contended float
+        // atomics on a handful of addresses were 2/3 of this kernel's time before)
+        float* dst = (EX ? a.bsums : a.stats) + (size_t)(blockIdx.x & (a.replicas - 1)) * 2 * g.N;
         for (int i = tid; i < 2 * BN; i += 256) {
             const int which = i / BN, nl = i - which * BN;
             if (n0 + nl < g.N) atomicAdd(dst + which * g.N + n0 + nl, ssum[i]);
@@ -279,7 +287,7 @@ int launch(const sv_geom* g, const sv_igemm_args* a, hipStream_t s) {
     const int M = g->B * g->Hq * g->Wq;
     const int nMt = (M + BM - 1) / BM;
     const int nNt = (g->N + BN - 1) / BN;
-    const int grid = ((nMt + 7) / 8) * 8 * nNt * g->nphase;
+    const int grid = (nMt >= 64 ? ((nMt + 7) / 8) * 8 : nMt) * nNt * g->nphase;
     const size_t lds = (size_t)2 * (BM + BN) * LDK * sizeof(T) + 2 * BN * sizeof(float);
     sv_prof_begin(s);
     hipLaunchKernelGGL((igemm_kernel<T, NT>), dim3(grid), dim3(256), lds, s, *g, *a);
@@ -301,6 +309,8 @@ extern "C" int sv_igemm(const sv_geom* g, int dtype, const sv_igemm_args* a, voi
     SV_REQUIRE(!a->ex || (a->ex_scale && a->ex_shift && a->ex_mean && a->ex_rstd && a->bsums), SV_E_ARG,
                "sv_igemm: incomplete act-backward epilogue");
     SV_REQUIRE(!a->pro_scale || a->pro_shift, SV_E_ARG, "sv_igemm: prologue shift missing");
+    SV_REQUIRE(!(a->stats || a->ex) || (a->replicas >= 1 && (a->replicas & (a->replicas - 1)) == 0), SV_E_ARG,
+               "sv_igemm: replicas=%d must be a power of two", a->replicas);
     hipStream_t s = (hipStream_t)stream;
     const int64_t M = (int64_t)g->B * g->Hq * g->Wq;
     const int64_t mtiles = (M + BM - 1) / BM * g->nphase;

@@ -21,13 +21,18 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
 }
 
 // ---------------------------------------------------------------------------------------- BatchNorm
-__global__ void bn_finalize_kernel(const float* stats, int C, float count, const float* gamma,
+__global__ void bn_finalize_kernel(const float* stats, int R, int C, float count, const float* gamma,
                                    const float* beta, float eps, float momentum, float* rm, float* rv,
                                    float* scale, float* shift, float* mean, float* rstd) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    const float mu = stats[c] / count;
-    float var = stats[C + c] / count - mu * mu;
+    float s1 = 0.f, s2 = 0.f;
+    for (int r = 0; r < R; ++r) {
+        s1 += stats[(size_t)r * 2 * C + c];
+        s2 += stats[(size_t)r * 2 * C + C + c];
+    }
+    const float mu = s1 / count;
+    float var = s2 / count - mu * mu;
     var = var > 0.f ? var : 0.f;
     const float rs = rsqrtf(var + eps);
     const float sc = gamma[c] * rs;
@@ -66,18 +71,36 @@ struct bnb_params {
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bnb_params p) {
     typedef typename V8<T>::type V;
+    // per-channel coefficients in LDS: [mean, rstd] + per branch [gamma*rstd, mean(g), mean(g*xhat)]
+    extern __shared__ __attribute__((aligned(16))) float coef[];
+    float* cmean = coef;
+    float* crstd = coef + p.C;
+    for (int c = threadIdx.x; c < p.C; c += blockDim.x) {
+        const float rs = p.rstd[c];
+        cmean[c] = p.mean[c];
+        crstd[c] = rs;
+        for (int k = 0; k < p.nbranch; ++k) {
+            float s1 = 0.f, s2 = 0.f;
+            for (int r = 0; r < p.br[k].replicas; ++r) {
+                s1 += p.br[k].bsums[(size_t)r * 2 * p.C + c];
+                s2 += p.br[k].bsums[(size_t)r * 2 * p.C + p.C + c];
+            }
+            float* cb = coef + (2 + 3 * k) * p.C;
+            cb[c] = p.br[k].gamma[c] * rs;
+            cb[p.C + c] = s1 * p.inv_count;
+            cb[2 * p.C + c] = s2 * p.inv_count;
+            if (blockIdx.x == 0) {
+                if (p.br[k].dbeta) p.br[k].dbeta[c] += s1;
+                if (p.br[k].dgamma) p.br[k].dgamma[c] += s2;
+            }
+        }
+    }
+    __syncthreads();
     const int cv = p.C / 8;                       // vectors per row
     const int64_t total = p.M * cv;
     const T* X = reinterpret_cast<const T*>(p.x);
     const T* R = reinterpret_cast<const T*>(p.residual);
     T* DX = reinterpret_cast<T*>(p.dx);
-    if (blockIdx.x == 0) {
-        for (int c = threadIdx.x; c < p.C; c += blockDim.x)
-            for (int k = 0; k < p.nbranch; ++k) {
-                if (p.br[k].dbeta) p.br[k].dbeta[c] += p.br[k].bsums[c];
-                if (p.br[k].dgamma) p.br[k].dgamma[c] += p.br[k].bsums[p.C + c];
-            }
-    }
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t m = i / cv;
         const int c = (int)(i - m * cv) * 8;
@@ -88,13 +111,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bnb_params p) {
         for (int j = 0; j < 8; ++j) o[j] = 0.f;
         for (int k = 0; k < p.nbranch; ++k) {
             const V gv = *reinterpret_cast<const V*>(reinterpret_cast<const T*>(p.br[k].g) + off);
+            const float* cb = coef + (2 + 3 * k) * p.C;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const float rs = p.rstd[c + j];
-                const float xh = (to_f(xv[j]) - p.mean[c + j]) * rs;
-                const float m1 = p.br[k].bsums[c + j] * p.inv_count;
-                const float m2 = p.br[k].bsums[p.C + c + j] * p.inv_count;
-                o[j] += p.br[k].gamma[c + j] * rs * (to_f(gv[j]) - m1 - xh * m2);
+                const float xh = (to_f(xv[j]) - cmean[c + j]) * crstd[c + j];
+                o[j] += cb[c + j] * (to_f(gv[j]) - cb[p.C + c + j] - xh * cb[2 * p.C + c + j]);
             }
         }
         if (R) {
@@ -626,11 +647,12 @@ inline int nblocks(int64_t n, int bs, int cap = 2048) {
 
 extern "C" {
 
-int sv_bn_finalize(const float* stats, int C, float count, const float* gamma, const float* beta, float eps,
+int sv_bn_finalize(const float* stats, int replicas, int C, float count, const float* gamma, const float* beta, float eps,
                    float momentum, float* rm, float* rv, float* scale, float* shift, float* mean,
                    float* rstd, void* stream) {
-    SV_REQUIRE(stats && gamma && beta && scale && shift && mean && rstd && C > 0, SV_E_ARG, "sv_bn_finalize: null");
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, stats, C,
+    SV_REQUIRE(stats && gamma && beta && scale && shift && mean && rstd && C > 0 && replicas >= 1, SV_E_ARG,
+               "sv_bn_finalize: bad args");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, stats, replicas, C,
                        count, gamma, beta, eps, momentum, rm, rv, scale, shift, mean, rstd);
     return sv_check_launch("sv_bn_finalize");
 }
@@ -653,10 +675,13 @@ int sv_bn_bwd_apply(int dtype, int64_t M, int C, int ld, const void* x, const fl
     p.inv_count = 1.f / count; p.residual = residual; p.dx = dx;
     for (int k = 0; k < nbranch; ++k) {
         p.br[k] = br[k];
-        SV_REQUIRE(br[k].g && br[k].bsums && br[k].gamma, SV_E_ARG, "sv_bn_bwd_apply: branch %d incomplete", k);
+        SV_REQUIRE(br[k].g && br[k].bsums && br[k].gamma && br[k].replicas >= 1, SV_E_ARG,
+                   "sv_bn_bwd_apply: branch %d incomplete", k);
     }
     const int grid = nblocks(M * (C / 8), 256);
-    DISPATCH_T(dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p));
+    const size_t lds = (size_t)(2 + 3 * nbranch) * C * sizeof(float);
+    SV_REQUIRE(lds <= 64 * 1024, SV_E_SHAPE, "sv_bn_bwd_apply: C=%d too large", C);
+    DISPATCH_T(dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(grid), dim3(256), lds, (hipStream_t)stream, p));
     return sv_check_launch("sv_bn_bwd_apply");
 }
 

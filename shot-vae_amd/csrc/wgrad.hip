@@ -28,8 +28,9 @@ struct wg_params {
     int ntap_total;
 };
 
+template <bool FAST>
 __device__ __forceinline__ void decode_m(const sv_geom& g, const wg_params& p, int m, int& b, int& qy, int& qx) {
-    if (p.hwsh >= 0) {
+    if (FAST) {
         b = m >> p.hwsh;
         const int r = m & ((1 << p.hwsh) - 1);
         qy = r >> p.wsh;
@@ -75,7 +76,7 @@ __device__ __forceinline__ f32x8 frag_t(const float* S, int ld, int col0, int la
     return f;
 }
 
-template <typename T, int TN, int TC, bool USE_TR>
+template <typename T, int TN, int TC, bool USE_TR, bool FAST>
 __global__ __launch_bounds__(256) void wgrad_kernel(const sv_geom g, const wg_params p) {
     typedef typename V8<T>::type V;
     constexpr int BNw = 16 * TN, BCw = 16 * TC;
@@ -92,11 +93,18 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const sv_geom g, const wg_pa
     const int nNt = (g.N + BNw - 1) / BNw;
     const int nCt = (g.Cin + BCw - 1) / BCw;
     const int tiles = nNt * p.ntap_total * nCt;
+    // splits is either < 8 (plain mapping) or a multiple of 8: then blocks L and L+8 share an XCD and all
+    // (tap, channel-tile) blocks of one m-range run on the same XCD, so dy / x are fetched into one L2.
     const int L = blockIdx.x;
-    const int xcd = L & 7, slot = L >> 3;
-    const int tile = slot % tiles;
-    const int split = (slot / tiles) * 8 + xcd;
-    if (split >= p.splits) return;
+    int tile, split;
+    if (p.splits % 8 == 0) {
+        const int xcd = L & 7, slot = L >> 3;
+        tile = slot % tiles;
+        split = (slot / tiles) * 8 + xcd;
+    } else {
+        tile = L % tiles;
+        split = L / tiles;
+    }
     const int ct = tile % nCt;
     int tapg = (tile / nCt) % p.ntap_total;
     const int n0 = (tile / (nCt * p.ntap_total)) * BNw;
@@ -132,37 +140,36 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const sv_geom g, const wg_pa
 
     V ry[TN], rx[TC];
     bool okx[TC];
+    // Branch-free loader: every address is clamped into the tensor, every load is issued
+    // unconditionally (so the 2*TN..2*TC loads of an iteration are in flight together), invalid
+    // rows / padding are zeroed by a select afterwards.
+    const int nvo = nvec_ok ? n0 + 8 * vn : 0;
+    const int cvo = cvec_ok ? c0 + 8 * vc : 0;
+    V zero;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) zero[j] = (T)0.f;
     auto load_global = [&](int mbase) {   // mbase = first row of this wave's 32-row slab
 #pragma unroll
         for (int i = 0; i < TN; ++i) {
             const int m = mbase + rn + RPN * i;
-            V val;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) val[j] = (T)0.f;
-            if (m < m_end && nvec_ok) {
-                int b, qy, qx;
-                decode_m(g, p, m, b, qy, qx);
-                const int64_t op = (int64_t)(b * g.Hout + qy * g.osy + ooy) * g.Wout + qx * g.osx + oox;
-                val = *reinterpret_cast<const V*>(DY + op * g.ldo + n0 + 8 * vn);
-            }
-            ry[i] = val;
+            const bool ok = m < m_end && nvec_ok;
+            int b, qy, qx;
+            decode_m<FAST>(g, p, min(m, m_end - 1), b, qy, qx);
+            const int64_t op = (int64_t)(b * g.Hout + qy * g.osy + ooy) * g.Wout + qx * g.osx + oox;
+            const V val = *reinterpret_cast<const V*>(DY + op * g.ldo + nvo);
+            ry[i] = ok ? val : zero;
         }
 #pragma unroll
         for (int i = 0; i < TC; ++i) {
             const int m = mbase + rc + RPC * i;
-            V val;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) val[j] = (T)0.f;
-            bool ok = false;
-            if (m < m_end && cvec_ok) {
-                int b, qy, qx;
-                decode_m(g, p, m, b, qy, qx);
-                const int iy = qy * g.sy + dy, ix = qx * g.sx + dx;
-                ok = (unsigned)iy < (unsigned)g.Hin && (unsigned)ix < (unsigned)g.Win;
-                if (ok) val = *reinterpret_cast<const V*>(X + ((int64_t)(b * g.Hin + iy) * g.Win + ix) * g.ldx + c0 + 8 * vc);
-            }
+            int b, qy, qx;
+            decode_m<FAST>(g, p, min(m, m_end - 1), b, qy, qx);
+            const int iy = qy * g.sy + dy, ix = qx * g.sx + dx;
+            const bool ok = m < m_end && cvec_ok && (unsigned)iy < (unsigned)g.Hin && (unsigned)ix < (unsigned)g.Win;
+            const int iyc = min(max(iy, 0), g.Hin - 1), ixc = min(max(ix, 0), g.Win - 1);
+            const V val = *reinterpret_cast<const V*>(X + ((int64_t)(b * g.Hin + iyc) * g.Win + ixc) * g.ldx + cvo);
             okx[i] = ok;
-            rx[i] = val;
+            rx[i] = ok ? val : zero;
         }
     };
     auto store_lds = [&]() {
@@ -189,8 +196,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const sv_geom g, const wg_pa
 #pragma unroll
         for (int j = 0; j < TC; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    if (m_end <= m_begin) return;      // (block-uniform) nothing to do for this m-range
     const int niter = (m_end - m_begin + 4 * RW - 1) / (4 * RW);
-    if (niter > 0) load_global(m_begin + RW * wave);
+    load_global(m_begin + RW * wave);
     for (int it = 0; it < niter; ++it) {
         store_lds();
         if (it + 1 < niter) load_global(m_begin + (it + 1) * 4 * RW + RW * wave);
@@ -239,19 +247,25 @@ int ilog2_exact(int v) {
     return s;
 }
 
-template <typename T, int TN, int TC, bool USE_TR>
-int launch(const sv_geom* g, const wg_params& p, hipStream_t s) {
+template <typename T, int TN, int TC, bool USE_TR, bool FAST>
+int launch2(const sv_geom* g, const wg_params& p, hipStream_t s) {
     constexpr int BNw = 16 * TN, BCw = 16 * TC;
     const int nNt = (g->N + BNw - 1) / BNw, nCt = (g->Cin + BCw - 1) / BCw;
     const int tiles = nNt * p.ntap_total * nCt;
-    const int grid = ((p.splits + 7) / 8) * 8 * tiles;
+    const int grid = p.splits * tiles;
     size_t lds = (size_t)4 * RW * (BNw + 8 + BCw + 8) * sizeof(T);
     const size_t red = (size_t)BNw * BCw * sizeof(float);
     if (red > lds) lds = red;
     sv_prof_begin(s);
-    hipLaunchKernelGGL((wgrad_kernel<T, TN, TC, USE_TR>), dim3(grid), dim3(256), lds, s, *g, p);
+    hipLaunchKernelGGL((wgrad_kernel<T, TN, TC, USE_TR, FAST>), dim3(grid), dim3(256), lds, s, *g, p);
     sv_prof_end(s);
     return sv_check_launch("sv_wgrad");
+}
+
+template <typename T, int TN, int TC, bool USE_TR>
+int launch(const sv_geom* g, const wg_params& p, hipStream_t s) {
+    if (p.hwsh >= 0) return launch2<T, TN, TC, USE_TR, true>(g, p, s);
+    return launch2<T, TN, TC, USE_TR, false>(g, p, s);
 }
 
 template <typename T, bool USE_TR>
@@ -302,9 +316,10 @@ extern "C" int sv_wgrad(const sv_geom* g, int dtype, const void* x, const float*
         if (want < 1) want = 1;
         splits = (int)want;
     }
+    if (splits >= 8) splits = splits / 8 * 8;     // multiple of 8: XCD-affine block mapping
     int64_t m_per = (M + splits - 1) / splits;
     m_per = (m_per + 127) / 128 * 128;
-    splits = (int)((M + m_per - 1) / m_per);
+    if (splits < 8) splits = (int)((M + m_per - 1) / m_per);
     p.splits = splits;
     p.m_per = (int)m_per;
     hipStream_t s = (hipStream_t)stream;

@@ -233,6 +233,15 @@ def _vp(x):
     return C.c_void_p(x)
 
 
+def _replicas(rows):
+    """Copies of a per-channel accumulator for a tensor with `rows` pixels: the gather-GEMM runs one
+    block per 128 rows and each block issues one atomic per channel, so keep ~<=128 adders per address."""
+    tiles, r = rows // 128, 1
+    while r < 32 and tiles // (2 * r) >= 16:
+        r *= 2
+    return r
+
+
 class FwdCtx:
     """Everything one forward leaves behind for its backward."""
     pass
@@ -255,6 +264,7 @@ class Engine:
         self._manual_epoch = 0
         self.use_tr = 1
         self.prof_tags = None
+        self.prof_cost = {}
         self.version_probe = None     # callable: summed version counters of the nn.Parameters (set by the module)
         for b in p.bns:
             self.bufs[b.rv_off: b.rv_off + b.C] = 1.0
@@ -322,10 +332,26 @@ class Engine:
                                     "move the model and its inputs to cuda first")
         L.lib()
 
-    def _tag(self, name):
-        if self.prof_tags is not None:
-            t = self.prof_tags.setdefault(name, len(self.prof_tags))
-            L.lib().sv_prof_tag(t)
+    def _tag(self, name, g=None, extra_out_reads=0, wgrad=False):
+        """File the next launch under `name` for sv_prof_collect and remember its algorithmic cost:
+        bytes = input + output (+ fused residual / raw-tensor reads) + weights, flops = 2*M*N*K."""
+        if self.prof_tags is None:
+            return
+        t = self.prof_tags.setdefault(name, len(self.prof_tags))
+        L.lib().sv_prof_tag(t)
+        if g is not None and name not in self.prof_cost:
+            es = self.packs.element_size()
+            taps = sum(g.phase[p].ntap for p in range(g.nphase))
+            rows = g.B * g.Hq * g.Wq
+            n_in = g.B * g.Hin * g.Win * g.Cin
+            n_out = g.B * g.Hout * g.Wout * g.N
+            n_w = taps * g.Cin * g.N
+            flops = 2.0 * rows * taps * g.Cin * g.N
+            if wgrad:
+                nbytes = es * (n_in + n_out) + 4 * n_w
+            else:
+                nbytes = es * (n_in + n_out * (1 + extra_out_reads) + n_w)
+            self.prof_cost[name] = (float(nbytes), flops)
 
     def ensure_packs(self):
         ver = self.param._version + (self.version_probe() if self.version_probe is not None else 0)
@@ -354,18 +380,19 @@ class Engine:
             a.bias = bias
         if residual is not None:
             a.residual = residual.data_ptr()
+        a.replicas = 1
         if stats is not None:
-            a.stats = stats
+            a.stats, a.replicas = stats
         if ex is not None:
             a.ex = ex[0].data_ptr()
-            a.ex_scale, a.ex_shift, a.ex_mean, a.ex_rstd, a.ex_slope, a.bsums = ex[1:]
+            a.ex_scale, a.ex_shift, a.ex_mean, a.ex_rstd, a.ex_slope, a.bsums, a.replicas = ex[1:]
         if tag:
-            self._tag(tag)
+            self._tag(tag, g, (residual is not None) + (ex is not None))
         L.call("sv_igemm", C.byref(g), self.code, C.byref(a), self._stream())
 
     def _wgrad(self, g, x, pro, dy, dw_ptr, tag=None):
         if tag:
-            self._tag(tag)
+            self._tag(tag, g, wgrad=True)
         ps, pt, sl = (pro[0], pro[1], pro[2]) if pro is not None else (None, None, 0.0)
         L.call("sv_wgrad", C.byref(g), self.code, _vp(x.data_ptr()), _vp(ps) if ps else None,
                _vp(pt) if pt else None, sl, _vp(dy.data_ptr()), _vp(dw_ptr), 0, self.use_tr, self._stream())
@@ -386,19 +413,22 @@ class Engine:
 
         # per-forward scratch: BN statistics (zeroed), BN affine/mean/rstd
         n_stat = 0
-        stat_off = {}
+        stat_off, stat_rep = {}, {}
 
-        def stat_slot(name, c):
+        def stat_slot(name, c, rows):
             nonlocal n_stat
             stat_off[name] = n_stat
-            n_stat += 2 * _align(c)
+            stat_rep[name] = _replicas(rows)
+            n_stat += _align(stat_rep[name] * 2 * c)
 
-        stat_slot("t0", 16)
+        stat_slot("t0", 16, B * p.img * p.img)
+        hs = p.img
         for i, un in enumerate(p.units):
-            stat_slot("c1_%d" % i, un["cout"])
-            stat_slot("t%d" % (i + 1), un["cout"])
+            hs //= un["stride"]
+            stat_slot("c1_%d" % i, un["cout"], B * hs * hs)
+            stat_slot("t%d" % (i + 1), un["cout"], B * hs * hs)
         for i in range(5):
-            stat_slot("h%d" % i, p.dec_convs[i].N)
+            stat_slot("h%d" % i, p.dec_convs[i].N, B * p.dec_convs[i].Hout ** 2)
         stats = torch.zeros(n_stat, dtype=torch.float32, device=dev)
         sbase = stats.data_ptr()
         bnbuf = torch.empty(p.n_bnbuf, dtype=torch.float32, device=dev)
@@ -412,7 +442,7 @@ class Engine:
         def finalize(b, stat_name, count):
             sc, sh, mn, rs = bn_ptrs(b)
             if training:
-                L.call("sv_bn_finalize", _vp(sbase + 4 * stat_off[stat_name]), b.C, float(count),
+                L.call("sv_bn_finalize", _vp(sbase + 4 * stat_off[stat_name]), stat_rep[stat_name], b.C, float(count),
                        _vp(pbase + 4 * b.gamma_off), _vp(pbase + 4 * b.beta_off), BN_EPS, BN_MOMENTUM,
                        _vp(bbase + 4 * b.rm_off), _vp(bbase + 4 * b.rv_off), _vp(sc), _vp(sh), _vp(mn), _vp(rs), st)
             else:
@@ -422,7 +452,7 @@ class Engine:
 
         def sptr(name):
             # in eval mode BN uses running statistics; batch statistics are not accumulated
-            return (sbase + 4 * stat_off[name]) if training else None
+            return (sbase + 4 * stat_off[name], stat_rep[name]) if training else None
 
         f = FwdCtx()
         f.B, f.mode, f.lam, f.temperature, f.training = B, mode, lam, temperature, training
@@ -443,20 +473,20 @@ class Engine:
             ho = h // un["stride"]
             c1 = torch.empty(B, ho, ho, un["cout"], dtype=T, device=dev)
             self._igemm(un["conv1"].geom_fwd(B), tin, pk + es * un["conv1"].fwd_off, c1, pro=pro1,
-                        stats=sptr("c1_%d" % i), tag="fwd:conv3x3_c%d_s%d" % (un["cout"], un["stride"]))
+                        stats=sptr("c1_%d" % i), tag="fwd:conv3x3_%dx%d_s%d" % (un["cin"], un["cout"], un["stride"]))
             pro2 = finalize(un["bn2"], "c1_%d" % i, B * ho * ho)
             tout = torch.empty(B, ho, ho, un["cout"], dtype=T, device=dev)
             if "convi" in un:
                 proi = finalize(un["bni"], "t%d" % i, cnt_in)
                 sc = torch.empty(B, ho, ho, un["cout"], dtype=T, device=dev)
                 self._igemm(un["convi"].geom_fwd(B), tin, pk + es * un["convi"].fwd_off, sc, pro=proi,
-                            tag="fwd:conv1x1")
+                            tag="fwd:conv1x1_%dx%d" % (un["cin"], un["cout"]))
                 res = sc
             else:
                 proi = None
                 res = tin
             self._igemm(un["conv2"].geom_fwd(B), c1, pk + es * un["conv2"].fwd_off, tout, pro=pro2, residual=res,
-                        stats=sptr("t%d" % (i + 1)), tag="fwd:conv3x3_c%d_s1" % un["cout"])
+                        stats=sptr("t%d" % (i + 1)), tag="fwd:conv3x3_%dx%d_s1" % (un["cout"], un["cout"]))
             f.c1.append(c1)
             f.t.append(tout)
             f.pro.append((pro1, pro2, proi))
@@ -508,6 +538,21 @@ class Engine:
         f.keep = (label, label_mix, u, stats)
         return rec, mu, ls, la, f
 
+    def _bn_rows(self, B):
+        """(BNSpec, pixels of the tensor it normalises) for every BatchNorm."""
+        p = self.plan
+        out, h = [], p.img
+        for un in p.units:
+            out.append((un["bn1"], B * h * h))
+            if "bni" in un:
+                out.append((un["bni"], B * h * h))
+            h //= un["stride"]
+            out.append((un["bn2"], B * h * h))
+        out.append((p.bn_t, 1))          # its sums come from sv_pool_bwd (plain atomics, one copy)
+        for i, b in enumerate(p.dec_bns):
+            out.append((b, B * p.dec_convs[i].Hout ** 2))
+        return out
+
     # ------------------------------------------------------------------------------- backward
     def backward(self, f, d_rec, d_mu, d_ls, d_la):
         """Gradients accumulate (+=) into self.grad; nothing is returned (inputs need no grad)."""
@@ -519,13 +564,13 @@ class Engine:
         pk, es = self.packs.data_ptr(), self.packs.element_size()
         nb = f.bnbuf.data_ptr()
         # one zeroed scratch for every (sum g, sum g*xhat) pair of this backward
-        tot = sum(2 * _align(b.C) for b in p.bns)
+        bs_rep, bs_rel, tot = {}, {}, 0
+        for b, rows in self._bn_rows(B):
+            bs_rep[b.index] = _replicas(rows)
+            bs_rel[b.index] = tot
+            tot += _align(bs_rep[b.index] * 2 * b.C)
         bsums = torch.zeros(tot, dtype=torch.float32, device=dev)
-        bs_off = {}
-        o = 0
-        for b in p.bns:
-            bs_off[b.index] = bsums.data_ptr() + 4 * o
-            o += 2 * _align(b.C)
+        bs_off = {k: bsums.data_ptr() + 4 * v for k, v in bs_rel.items()}
 
         def bnp(b):
             a = _align(b.C)
@@ -534,7 +579,7 @@ class Engine:
 
         def ex_of(b, raw):
             sc, sh, mn, rs = bnp(b)
-            return (raw, sc, sh, mn, rs, b.slope, bs_off[b.index])
+            return (raw, sc, sh, mn, rs, b.slope, bs_off[b.index], bs_rep[b.index])
 
         def bn_apply(raw, branches, residual, count):
             """branches: [(g tensor, BNSpec)] sharing `raw`; returns dL/d(raw) (+ residual)."""
@@ -545,6 +590,7 @@ class Engine:
                 arr[k].gamma = pbase + 4 * b.gamma_off
                 arr[k].dgamma = gbase + 4 * b.gamma_off
                 arr[k].dbeta = gbase + 4 * b.beta_off
+                arr[k].replicas = bs_rep[b.index]
             b0 = branches[0][1]
             _, _, mn, rs = bnp(b0)
             dx = torch.empty_like(raw)
@@ -598,25 +644,25 @@ class Engine:
             pro1, pro2, proi = f.pro[i]
             c = un["cout"]
             self._wgrad(un["conv2"].geom_fwd(B), c1, pro2, D, gbase + 4 * un["conv2"].master_off,
-                        tag="wgrad:conv3x3_c%d_s1" % c)
+                        tag="wgrad:conv3x3_%dx%d_s1" % (c, c))
             g2 = torch.empty_like(c1)
             self._igemm(un["conv2"].geom_dgrad(B), D, pk + es * un["conv2"].dgrad_off, g2, ex=ex_of(un["bn2"], c1),
-                        tag="dgrad:conv3x3_c%d_s1" % c)
+                        tag="dgrad:conv3x3_%dx%d_s1" % (c, c))
             dc1 = bn_apply(c1, [(g2, un["bn2"])], None, c1.numel() // c)
             del g2
             self._wgrad(un["conv1"].geom_fwd(B), tin, pro1, dc1, gbase + 4 * un["conv1"].master_off,
-                        tag="wgrad:conv3x3_c%d_s%d" % (c, un["stride"]))
+                        tag="wgrad:conv3x3_%dx%d_s%d" % (un["cin"], c, un["stride"]))
             g1 = torch.empty_like(tin)
             self._igemm(un["conv1"].geom_dgrad(B), dc1, pk + es * un["conv1"].dgrad_off, g1, ex=ex_of(un["bn1"], tin),
-                        tag="dgrad:conv3x3_c%d_s%d" % (c, un["stride"]))
+                        tag="dgrad:conv3x3_%dx%d_s%d" % (un["cin"], c, un["stride"]))
             del dc1
             cnt = tin.numel() // tin.shape[-1]
             if "convi" in un:
                 self._wgrad(un["convi"].geom_fwd(B), tin, proi, D, gbase + 4 * un["convi"].master_off,
-                            tag="wgrad:conv1x1")
+                            tag="wgrad:conv1x1_%dx%d" % (un["cin"], c))
                 gi = torch.empty_like(tin)
                 self._igemm(un["convi"].geom_dgrad(B), D, pk + es * un["convi"].dgrad_off, gi,
-                            ex=ex_of(un["bni"], tin), tag="dgrad:conv1x1")
+                            ex=ex_of(un["bni"], tin), tag="dgrad:conv1x1_%dx%d" % (un["cin"], c))
                 D = bn_apply(tin, [(g1, un["bn1"]), (gi, un["bni"])], None, cnt)
             else:
                 D = bn_apply(tin, [(g1, un["bn1"])], D, cnt)

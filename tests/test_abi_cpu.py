@@ -29,5 +29,5 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layout_matches_header():
     assert ctypes.sizeof(L.SvPhase) == 72
     assert ctypes.sizeof(L.SvGeom) == 72 + 4 * 72
-    assert ctypes.sizeof(L.SvIgemmArgs) == 16 * 8
-    assert ctypes.sizeof(L.SvBnBranch) == 40
+    assert ctypes.sizeof(L.SvIgemmArgs) == 17 * 8
+    assert ctypes.sizeof(L.SvBnBranch) == 48

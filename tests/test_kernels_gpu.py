@@ -84,19 +84,21 @@ def run_igemm(g, dt, x, w, pro=None, bias=None, residual=None, stats=False, ex=N
         keep.append(rd)
         a.residual = rd.data_ptr()
     sums = None
+    R = 4      # replicated accumulators: block b adds to copy b % R
+    a.replicas = R
     if stats:
-        sums = torch.zeros(2 * g.N, device=d)
+        sums = torch.zeros(R, 2 * g.N, device=d)
         a.stats = sums.data_ptr()
     if ex is not None:
         exd = ex["x"].to(d, tdt).contiguous()
         vec = [ex[k].to(d).float().contiguous() for k in ("scale", "shift", "mean", "rstd")]
         keep += [exd] + vec
-        sums = torch.zeros(2 * g.N, device=d)
+        sums = torch.zeros(R, 2 * g.N, device=d)
         a.ex, a.ex_scale, a.ex_shift, a.ex_mean, a.ex_rstd = [t.data_ptr() for t in [exd] + vec]
         a.ex_slope, a.bsums = ex["slope"], sums.data_ptr()
     L.call("sv_igemm", C.byref(g), code, C.byref(a), st())
     torch.cuda.synchronize()
-    return out.float().cpu(), (None if sums is None else sums.cpu())
+    return out.float().cpu(), (None if sums is None else sums.sum(0).cpu())
 
 
 def bq(t, dt):
@@ -268,9 +270,10 @@ def test_bn_finalize_and_bwd_apply():
     n = B * H * H
     xn = nhwc(x).to(d)
     stats = torch.cat([xn.reshape(-1, Cc).sum(0), (xn.reshape(-1, Cc) ** 2).sum(0)]).contiguous()
+    stats = torch.stack([stats * 0.25, stats * 0.75]).contiguous()        # two replicas
     outs = [torch.zeros(Cc, device=d) for _ in range(4)]
     rmd, rvd = rm.to(d), rv.to(d)
-    L.call("sv_bn_finalize", p(stats), Cc, float(n), p(gamma.to(d)), p(beta.to(d)), 1e-5, 0.1, p(rmd), p(rvd),
+    L.call("sv_bn_finalize", p(stats), 2, Cc, float(n), p(gamma.to(d)), p(beta.to(d)), 1e-5, 0.1, p(rmd), p(rvd),
            p(outs[0]), p(outs[1]), p(outs[2]), p(outs[3]), st())
     assert rel(rmd, rm2) < 1e-5 and rel(rvd, rv2) < 1e-5
     mean, var = x.mean((0, 2, 3)), x.var((0, 2, 3), unbiased=False)
@@ -281,11 +284,12 @@ def test_bn_finalize_and_bwd_apply():
     gn = nhwc(gup).to(d)
     xh = (xn - outs[2]) * outs[3]
     bsums = torch.cat([gn.reshape(-1, Cc).sum(0), (gn * xh).reshape(-1, Cc).sum(0)]).contiguous()
+    bsums = torch.stack([bsums * 0.5, bsums * 0.5]).contiguous()
     dgam, dbet = torch.zeros(Cc, device=d), torch.zeros(Cc, device=d)
     br_ = (L.SvBnBranch * 1)()
     gmd = gamma.to(d)
     br_[0].g, br_[0].bsums, br_[0].gamma = gn.data_ptr(), bsums.data_ptr(), gmd.data_ptr()
-    br_[0].dgamma, br_[0].dbeta = dgam.data_ptr(), dbet.data_ptr()
+    br_[0].dgamma, br_[0].dbeta, br_[0].replicas = dgam.data_ptr(), dbet.data_ptr(), 2
     dx = torch.empty_like(xn)
     rn = nhwc(res).to(d)
     L.call("sv_bn_bwd_apply", L.SV_F32, n, Cc, Cc, p(xn), p(outs[2]), p(outs[3]), float(n), br_, 1, p(rn), p(dx), st())
