@@ -79,11 +79,15 @@ typedef struct {
 
 int sv_igemm(const sv_geom* g, int dtype, const sv_igemm_args* a, void* stream);
 
-/* ---- K19 weight gradient: dW[n][torig][c] += sum_m dy[m][n] * act(x[m,t][c])  (fp32 atomics) ----
+/* ---- K19 weight gradient: dW[n][torig][c] += sum_m dy[m][n] * act(x[m,t][c]) --------------------
  * Replaces autograd's convolution_backward (weight part) for the same layers.  `splits` = number
- * of M ranges (0 = choose).                                                                         */
+ * of M ranges of the generic kernel (0 = choose).  `ws` is an optional caller-owned fp32 workspace
+ * (ws_elems floats, contents irrelevant on entry): stride-1 3x3 layers publish per-block partial
+ * slabs there with plain stores and reduce them in a second launch instead of contending on float
+ * atomics; without it (or when it is too small) partials go to dw through float atomics.           */
 int sv_wgrad(const sv_geom* g, int dtype, const void* x, const float* pro_scale, const float* pro_shift,
-             float pro_slope, const void* dy, float* dw, int splits, int use_tr, void* stream);
+             float pro_slope, const void* dy, float* dw, int splits, int use_tr, float* ws, int64_t ws_elems,
+             void* stream);
 
 /* column sums: out[n] += sum_m y[m*ld + n]   (conv0 bias gradient)                                  */
 int sv_colsum(int dtype, const void* y, int64_t M, int N, int ld, float* out, void* stream);

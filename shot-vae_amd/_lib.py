@@ -44,7 +44,7 @@ class SvBnBranch(C.Structure):
 P, I, I64, F = C.c_void_p, C.c_int, C.c_int64, C.c_float
 _PROTOS = {
     "sv_igemm": [C.POINTER(SvGeom), I, C.POINTER(SvIgemmArgs), P],
-    "sv_wgrad": [C.POINTER(SvGeom), I, P, P, P, F, P, P, I, I, P],
+    "sv_wgrad": [C.POINTER(SvGeom), I, P, P, P, F, P, P, I, I, P, I64, P],
     "sv_colsum": [I, P, I64, I, I, P, P],
     "sv_bn_finalize": [P, I, I, F, P, P, F, F, P, P, P, P, P, P, P],
     "sv_bn_eval_affine": [I, P, P, P, P, F, P, P, P],

@@ -1,0 +1,103 @@
+// Shared epilogue of the conv-like MFMA kernels (igemm.hip, conv3x3.hip).
+//
+// Accumulator layout (weights = MFMA A operand, activations = B operand): lane l holds, for output
+// pixel (l & 15) of m-subtile ms, the 4 consecutive channels 16*nt + 4*(l >> 4) + r.
+// Fuses: +bias, +residual, then either the per-channel (sum, sum of squares) of the NEXT BatchNorm or
+// the activation backward + the two BatchNorm-backward reductions (sum g, sum g*xhat); 8/16-byte
+// stores; wave shuffle -> LDS float atomics -> one global atomic per channel per block into the
+// accumulator replica (blockIdx % replicas).
+#pragma once
+#include "common.h"
+
+template <typename T, int NT>
+__device__ __forceinline__ void gemm_epilogue(const f32x4 (&acc)[NT][2], const int64_t (&obase)[2],
+                                              const bool (&oval)[2], int n0, int N, const sv_igemm_args& a,
+                                              float* ssum /* LDS [2][16*NT], zeroed, visible */) {
+    typedef typename V4<T>::type Q;
+    constexpr int BN = 16 * NT;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int fr = lane & 15, fq = lane >> 4;
+    T* __restrict__ O = reinterpret_cast<T*>(a.out);
+    const T* __restrict__ R = reinterpret_cast<const T*>(a.residual);
+    const T* __restrict__ EX = reinterpret_cast<const T*>(a.ex);
+    const bool want_sums = (a.stats != nullptr) || (EX != nullptr);
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        const int nl = 16 * i + 4 * fq;      // local channel of this lane's 4-vector
+        const int n = n0 + nl;
+        const bool nval = n < N;
+        float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+        if (nval) {
+            f32x4 bias = {0.f, 0.f, 0.f, 0.f};
+            if (a.bias) bias = *reinterpret_cast<const f32x4*>(a.bias + n);
+            f32x4 esc, esh, emu, ers;
+            if (EX) {
+                esc = *reinterpret_cast<const f32x4*>(a.ex_scale + n);
+                esh = *reinterpret_cast<const f32x4*>(a.ex_shift + n);
+                emu = *reinterpret_cast<const f32x4*>(a.ex_mean + n);
+                ers = *reinterpret_cast<const f32x4*>(a.ex_rstd + n);
+            }
+#pragma unroll
+            for (int ms = 0; ms < 2; ++ms) {
+                if (!oval[ms]) continue;
+                f32x4 vv = acc[i][ms];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) vv[r] += bias[r];
+                if (R) {
+                    const Q rr = *reinterpret_cast<const Q*>(R + obase[ms] + n);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) vv[r] += to_f(rr[r]);
+                }
+                if (EX) {
+                    const Q xe = *reinterpret_cast<const Q*>(EX + obase[ms] + n);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float xf = to_f(xe[r]);
+                        const float u = xf * esc[r] + esh[r];
+                        const float gv = vv[r] * act_grad(u, a.ex_slope);
+                        vv[r] = gv;
+                        s1[r] += gv;
+                        s2[r] += gv * ((xf - emu[r]) * ers[r]);
+                    }
+                } else if (a.stats) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        s1[r] += vv[r];
+                        s2[r] += vv[r] * vv[r];
+                    }
+                }
+                Q o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = (T)vv[r];
+                *reinterpret_cast<Q*>(O + obase[ms] + n) = o;
+            }
+        }
+        if (want_sums) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) {
+                    s1[r] += __shfl_xor(s1[r], o);
+                    s2[r] += __shfl_xor(s2[r], o);
+                }
+            }
+            if (fr == 0 && nval) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    atomicAdd(&ssum[nl + r], s1[r]);
+                    atomicAdd(&ssum[BN + nl + r], s2[r]);
+                }
+            }
+        }
+    }
+    if (want_sums) {
+        __syncthreads();
+        // replica chosen by block index: keeps the number of adders per address low (contended float
+        // atomics on a handful of addresses were 2/3 of the kernel time before)
+        float* dst = (EX ? a.bsums : a.stats) + (size_t)(blockIdx.x & (a.replicas - 1)) * 2 * N;
+        for (int i = tid; i < 2 * BN; i += 256) {
+            const int which = i / BN, nl = i - which * BN;
+            if (n0 + nl < N) atomicAdd(dst + which * N + n0 + nl, ssum[i]);
+        }
+    }
+}

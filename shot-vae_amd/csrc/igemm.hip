@@ -11,7 +11,10 @@
 // Epilogue: +bias, +residual, either per-channel (sum, sumsq) for the next BatchNorm or the
 // activation backward + the two BatchNorm-backward sums; wave shuffle -> LDS atomics -> one global
 // atomic per channel per block.
+#include <stdlib.h>
+
 #include "common.h"
+#include "epilogue.h"
 
 namespace {
 
@@ -183,10 +186,6 @@ __global__ __launch_bounds__(256) void igemm_kernel(const sv_geom g, const sv_ig
     }
 
     // ---- epilogue ------------------------------------------------------------------------------
-    T* __restrict__ O = reinterpret_cast<T*>(a.out);
-    const T* __restrict__ R = reinterpret_cast<const T*>(a.residual);
-    const T* __restrict__ EX = reinterpret_cast<const T*>(a.ex);
-    const bool want_sums = (a.stats != nullptr) || (EX != nullptr);
     int64_t obase[2];
     bool oval[2];
 #pragma unroll
@@ -200,85 +199,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const sv_geom g, const sv_ig
         const int qx = r - qy * g.Wq;
         obase[ms] = ((int64_t)(b * g.Hout + qy * g.osy + P.ooy) * g.Wout + qx * g.osx + P.oox) * g.ldo;
     }
-#pragma unroll
-    for (int i = 0; i < NT; ++i) {
-        const int nl = 16 * i + 4 * fq;      // local channel of this lane's 4-vector
-        const int n = n0 + nl;
-        const bool nval = n < g.N;
-        float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
-        if (nval) {
-            f32x4 bias = {0.f, 0.f, 0.f, 0.f};
-            if (a.bias) bias = *reinterpret_cast<const f32x4*>(a.bias + n);
-            f32x4 esc, esh, emu, ers;
-            if (EX) {
-                esc = *reinterpret_cast<const f32x4*>(a.ex_scale + n);
-                esh = *reinterpret_cast<const f32x4*>(a.ex_shift + n);
-                emu = *reinterpret_cast<const f32x4*>(a.ex_mean + n);
-                ers = *reinterpret_cast<const f32x4*>(a.ex_rstd + n);
-            }
-#pragma unroll
-            for (int ms = 0; ms < 2; ++ms) {
-                if (!oval[ms]) continue;
-                f32x4 vv = acc[i][ms];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) vv[r] += bias[r];
-                if (R) {
-                    const Q rr = *reinterpret_cast<const Q*>(R + obase[ms] + n);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) vv[r] += to_f(rr[r]);
-                }
-                if (EX) {
-                    const Q xe = *reinterpret_cast<const Q*>(EX + obase[ms] + n);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float xf = to_f(xe[r]);
-                        const float u = xf * esc[r] + esh[r];
-                        const float gv = vv[r] * act_grad(u, a.ex_slope);
-                        vv[r] = gv;
-                        s1[r] += gv;
-                        s2[r] += gv * ((xf - emu[r]) * ers[r]);
-                    }
-                } else if (a.stats) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        s1[r] += vv[r];
-                        s2[r] += vv[r] * vv[r];
-                    }
-                }
-                Q o;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] = (T)vv[r];
-                *reinterpret_cast<Q*>(O + obase[ms] + n) = o;
-            }
-        }
-        if (want_sums) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) {
-                    s1[r] += __shfl_xor(s1[r], o);
-                    s2[r] += __shfl_xor(s2[r], o);
-                }
-            }
-            if (fr == 0 && nval) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    atomicAdd(&ssum[nl + r], s1[r]);
-                    atomicAdd(&ssum[BN + nl + r], s2[r]);
-                }
-            }
-        }
-    }
-    if (want_sums) {
-        __syncthreads();
-        // replica chosen by block index: keeps the number of adders per address low (contended float
-        // atomics on a handful of addresses were 2/3 of this kernel's time before)
-        float* dst = (EX ? a.bsums : a.stats) + (size_t)(blockIdx.x & (a.replicas - 1)) * 2 * g.N;
-        for (int i = tid; i < 2 * BN; i += 256) {
-            const int which = i / BN, nl = i - which * BN;
-            if (n0 + nl < g.N) atomicAdd(dst + which * g.N + n0 + nl, ssum[i]);
-        }
-    }
+    gemm_epilogue<T, NT>(acc, obase, oval, n0, g.N, a, ssum);
 }
 
 template <typename T, int NT>
@@ -312,6 +233,11 @@ extern "C" int sv_igemm(const sv_geom* g, int dtype, const sv_igemm_args* a, voi
     SV_REQUIRE(!(a->stats || a->ex) || (a->replicas >= 1 && (a->replicas & (a->replicas - 1)) == 0), SV_E_ARG,
                "sv_igemm: replicas=%d must be a power of two", a->replicas);
     hipStream_t s = (hipStream_t)stream;
+    {   // stride-1 3x3 convolutions take the LDS-halo kernel (conv3x3.hip); SV_NO_CONV3X3=1 disables it (A/B)
+        static const bool no_fast = getenv("SV_NO_CONV3X3") != nullptr;
+        int rc = 0;
+        if (!no_fast && sv_conv3x3_try(g, dtype, a, s, &rc)) return rc;
+    }
     const int64_t M = (int64_t)g->B * g->Hq * g->Wq;
     const int64_t mtiles = (M + BM - 1) / BM * g->nphase;
     // widest channel tile that still yields >= 2 blocks per CU; never below 32 channels unless N is

@@ -10,6 +10,8 @@
 // The four waves' accumulators are combined with LDS float atomics, then added to the fp32 gradient
 // buffer with one global atomic per element per block -- gradients of all four forwards of a step
 // accumulate in place (main_shot_vae.py:324,364 semantics).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -285,12 +287,18 @@ int dispatch(const sv_geom* g, const wg_params& p, int tn, int tc, hipStream_t s
 
 extern "C" int sv_wgrad(const sv_geom* g, int dtype, const void* x, const float* pro_scale,
                         const float* pro_shift, float pro_slope, const void* dy, float* dw, int splits,
-                        int use_tr, void* stream) {
+                        int use_tr, float* ws, int64_t ws_elems, void* stream) {
     SV_REQUIRE(g && x && dy && dw, SV_E_ARG, "sv_wgrad: null argument");
     SV_REQUIRE(dtype == SV_F32 || dtype == SV_BF16, SV_E_ARG, "sv_wgrad: bad dtype %d", dtype);
     SV_REQUIRE(g->Cin % 16 == 0 && g->N % 16 == 0 && g->ldx % 8 == 0 && g->ldo % 8 == 0, SV_E_SHAPE,
                "sv_wgrad: Cin=%d N=%d must be multiples of 16", g->Cin, g->N);
     SV_REQUIRE(!pro_scale || pro_shift, SV_E_ARG, "sv_wgrad: prologue shift missing");
+    if (dtype == SV_F32 || use_tr) {   // stride-1 3x3: LDS-halo kernel (wgrad3x3.hip); SV_NO_WGRAD3X3=1 disables (A/B)
+        static const bool no_fast = getenv("SV_NO_WGRAD3X3") != nullptr;
+        int rc = 0;
+        if (!no_fast && sv_wgrad3x3_try(g, dtype, x, pro_scale, pro_shift, pro_slope, dy, dw, ws, ws_elems, (hipStream_t)stream, &rc))
+            return rc;
+    }
     wg_params p;
     p.x = x; p.pro_scale = pro_scale; p.pro_shift = pro_shift; p.pro_slope = pro_slope;
     p.dy = dy; p.dw = dw;

@@ -1,0 +1,292 @@
+// Weight gradient of stride-1 3x3 convolutions with an LDS-resident halo tile.  gfx950.
+//
+//   dW[n][torig(t)][c] += sum_pixels dy[p][n] * A[p + d(t)][c],   A = LeakyReLU(x*scale+shift)
+//
+// The generic sv_wgrad kernel gives every tap its own block, so dy and x are streamed nine times.
+// Here a persistent block owns a 32(n) x 32(c) slab of dW for ALL nine taps (36 MFMA accumulator
+// tiles = 144 registers per wave) and walks a range of 128-pixel tiles (whole image rows).  Per tile
+// it stages dy [128][32] and the BN-transformed x halo [(TR+2)(W+2)][32] once (the next tile's global
+// loads are already in flight while the current one is on the MFMAs); wave w reduces over pixels
+// 32w..32w+31 of the tile: both operands are read k-major with ds_read_b64_tr_b16, the tap shift being
+// nothing but a different LDS pixel address.  Waves are combined through LDS float atomics, blocks
+// through one global float atomic per dW element.
+#include <stdlib.h>
+
+#include "common.h"
+
+namespace {
+
+constexpr int TC32 = 32;
+constexpr int LDH = TC32 + 8;     // LDS row stride (elements) of both the dy tile and the halo
+
+struct wg3_params {
+    const void* x;
+    const float* pro_scale;
+    const float* pro_shift;
+    float pro_slope;
+    const void* dy;
+    float* dw;
+    float* ws;                    // [splits][N*T_orig*Cin] partial slabs (plain stores) or NULL (atomics into dw)
+    int splits, tiles_per;        // 128-pixel tiles: range [split*tiles_per, ...)
+};
+
+// 8 consecutive pixels (k = 8g + j) of one (shifted) image row, 16 channels starting at col0: k-major
+// fragment through the transposing read.  pix_elem_q = element offset of pixel 8g+q, q = (lane&15)>>2.
+__device__ __forceinline__ bf16x8 frag_tr(const bf16* S, int pix_elem_q, int col0, int lane) {
+    typedef __attribute__((address_space(3))) s16x4 lds_v4;
+    const bf16* a0 = S + pix_elem_q + col0 + 4 * (lane & 3);
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(a0));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(a0 + 4 * LDH));
+    union { s16x4 s[2]; bf16x8 b; } u;
+    u.s[0] = lo;
+    u.s[1] = hi;
+    return u.b;
+}
+
+// Block = 32(n) x 32(c) slab of dW, all nine taps.  Wave w owns the 16x16 sub-block (w>>1, w&1) for all
+// nine taps (9 accumulator tiles) and reduces over ALL 128 pixels of every staged tile, so no cross-wave
+// reduction is needed (LDS float atomics are far too slow for that: 92 us of a 140 us kernel).
+template <typename T, int WLOG>
+__global__ __launch_bounds__(256) void wgrad3x3_kernel(const sv_geom g, const wg3_params p) {
+    typedef typename V8<T>::type V;
+    constexpr int W = 1 << WLOG, TR = 128 / W, WP = W + 2;
+    constexpr int HP = (TR + 2) * WP;
+    constexpr int HV = HP * 4, HI = (HV + 255) / 256;     // halo vectors (8 channels each)
+    constexpr int YI = 2;                                  // 128 px * 4 vectors / 256 threads
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* Ys = reinterpret_cast<T*>(smem);          // [128][LDH]
+    T* halo = Ys + 128 * LDH;                    // [HP][LDH]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int wi = wave >> 1, wj = wave & 1;      // this wave's (n, c) 16x16 sub-block
+    const int H = g.Hin, BH = g.B * H, nT = BH / TR;
+    const int nCt = g.Cin / 32, nNt = g.N / 32, nNC = nCt * nNt;
+    const int L = blockIdx.x;
+    int nc, split;
+    if (p.splits % 8 == 0) {          // blocks L, L+8 share an XCD: all (n,c) slabs of one pixel range on one L2
+        const int xcd = L & 7, slot = L >> 3;
+        nc = slot % nNC;
+        split = (slot / nNC) * 8 + xcd;
+    } else {
+        nc = L % nNC;
+        split = L / nNC;
+    }
+    const int n0 = (nc / nCt) * 32, c0 = (nc % nCt) * 32;
+    const int t_begin = split * p.tiles_per, t_end = min(nT, t_begin + p.tiles_per);
+    const sv_phase& P = g.phase[0];
+    const uint64_t pdy = pack_taps(P.dy), pdx = pack_taps(P.dx);
+    const T* __restrict__ X = reinterpret_cast<const T*>(p.x);
+    const T* __restrict__ DY = reinterpret_cast<const T*>(p.dy);
+    const bool has_pro = p.pro_scale != nullptr;
+
+    V zero;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) zero[j] = (T)0.f;
+    const int v = tid & 3;
+    f32x4 s0, s1, t0, t1;
+    if (has_pro) {
+        s0 = *reinterpret_cast<const f32x4*>(p.pro_scale + c0 + 8 * v);
+        s1 = *reinterpret_cast<const f32x4*>(p.pro_scale + c0 + 8 * v + 4);
+        t0 = *reinterpret_cast<const f32x4*>(p.pro_shift + c0 + 8 * v);
+        t1 = *reinterpret_cast<const f32x4*>(p.pro_shift + c0 + 8 * v + 4);
+    }
+    // staging slots relative to the tile's first global row (tile-independent part precomputed)
+    int hj[HI], hx[HI], hlds[HI];
+#pragma unroll
+    for (int i = 0; i < HI; ++i) {
+        const int idx = tid + 256 * i;
+        const int pix = min(idx, HV - 1) >> 2;
+        hj[i] = pix / WP - 1;
+        hx[i] = pix - (pix / WP) * WP - 1;
+        hlds[i] = idx < HV ? pix * LDH + 8 * v : -1;
+    }
+
+    V ry[YI], rh[HI];
+    bool hok[HI];
+    auto load_tile = [&](int tile) {
+        const int gr0 = tile * TR;
+#pragma unroll
+        for (int i = 0; i < YI; ++i) {
+            const int pix = (tid >> 2) + 64 * i;            // tile pixel 0..127 (row-major over TR x W)
+            ry[i] = *reinterpret_cast<const V*>(DY + ((int64_t)gr0 * W + pix) * g.ldo + n0 + 8 * v);
+        }
+#pragma unroll
+        for (int i = 0; i < HI; ++i) {
+            const int gr = gr0 + hj[i], x = hx[i];
+            hok[i] = (unsigned)x < (unsigned)W && (unsigned)gr < (unsigned)BH;
+            const int grc = min(max(gr, 0), BH - 1), xc = min(max(x, 0), W - 1);
+            rh[i] = *reinterpret_cast<const V*>(X + ((int64_t)grc * W + xc) * g.ldx + c0 + 8 * v);
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < YI; ++i)
+            *reinterpret_cast<V*>(Ys + ((tid >> 2) + 64 * i) * LDH + 8 * v) = ry[i];
+#pragma unroll
+        for (int i = 0; i < HI; ++i) {
+            V o = zero;
+            if (hok[i]) {
+                o = rh[i];
+                if (has_pro) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        o[j] = (T)act_fwd(to_f(rh[i][j]) * s0[j] + t0[j], p.pro_slope);
+                        o[j + 4] = (T)act_fwd(to_f(rh[i][j + 4]) * s1[j] + t1[j], p.pro_slope);
+                    }
+                }
+            }
+            if (hlds[i] >= 0) *reinterpret_cast<V*>(halo + hlds[i]) = o;
+        }
+    };
+
+    f32x4 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    if (t_begin < t_end) load_tile(t_begin);
+    for (int tile = t_begin; tile < t_end; ++tile) {
+        store_tile();
+        __syncthreads();
+        if (tile + 1 < t_end) load_tile(tile + 1);        // in flight while this tile is on the MFMAs
+        const int gr0 = tile * TR;
+        if (sizeof(T) == 2) {
+            const bf16* Yb = reinterpret_cast<const bf16*>(Ys);
+            const bf16* Hb = reinterpret_cast<const bf16*>(halo);
+            bf16x8 zb;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) zb[j] = (bf16)0.f;
+#pragma unroll
+            for (int kc = 0; kc < 4; ++kc) {
+                // lane addresses pixel pq = 32*kc + 8*fq + q (q = fr>>2) of the tile (and pq + 4)
+                const int pq = 32 * kc + 8 * fq + (fr >> 2);
+                const int jrow = pq >> WLOG, xcol = pq & (W - 1);
+                const int yrow = (gr0 + jrow) & (H - 1);    // the lane's 8 k-pixels share this image row
+                const bf16x8 fy = frag_tr(Yb, pq * LDH, 16 * wi, lane);
+                const int hbase = ((jrow + 1) * WP + xcol + 1) * LDH;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const int dy = tap_off(pdy, t), dx = tap_off(pdx, t);
+                    const bool ok = !((dy < 0 && yrow == 0) || (dy > 0 && yrow == H - 1));
+                    bf16x8 fx = frag_tr(Hb, hbase + (dy * WP + dx) * LDH, 16 * wj, lane);
+                    fx = ok ? fx : zb;
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fy, fx, acc[t], 0, 0, 0);
+                }
+            }
+        } else {
+            // fp32 (parity mode): v_mfma_f32_16x16x4_f32 step j uses pixel 4*j + fq of each 32-pixel chunk
+            const float* Yf = reinterpret_cast<const float*>(Ys);
+            const float* Hf = reinterpret_cast<const float*>(halo);
+            for (int pj = 0; pj < 32; ++pj) {
+                const int pp = 4 * pj + fq;
+                const int jrow = pp >> WLOG, xcol = pp & (W - 1);
+                const int yrow = (gr0 + jrow) & (H - 1);
+                const float yv = Yf[pp * LDH + 16 * wi + fr];
+                const int hbase = ((jrow + 1) * WP + xcol + 1) * LDH + 16 * wj + fr;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const int dy = tap_off(pdy, t), dx = tap_off(pdx, t);
+                    const bool ok = !((dy < 0 && yrow == 0) || (dy > 0 && yrow == H - 1));
+                    const float xv = ok ? Hf[hbase + (dy * WP + dx) * LDH] : 0.f;
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(yv, xv, acc[t], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();          // everyone is done reading before the next tile overwrites LDS
+    }
+
+    // ---- publish: D layout = lane holds c = 16*wj + fr, n = 16*wi + 4*fq + r ----------------------------
+    const int64_t slab = (int64_t)g.N * g.T_orig * g.Cin;
+    float* dst = p.ws ? p.ws + (int64_t)split * slab : p.dw;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int to = P.torig[t];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float* q = dst + ((int64_t)(n0 + 16 * wi + 4 * fq + r) * g.T_orig + to) * g.Cin + c0 + 16 * wj + fr;
+            if (p.ws) *q = acc[t][r];
+            else atomicAdd(q, acc[t][r]);
+        }
+    }
+}
+
+// dw[i] += sum_s ws[s][i].  blockIdx.y = group of slabs (so that small slabs x many splits still fill
+// the chip); with more than one group the groups meet in dw through float atomics.
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* ws, int splits, int64_t n, float* dw) {
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= n) return;
+    const int groups = gridDim.y;
+    const int k0 = (int)((int64_t)splits * blockIdx.y / groups), k1 = (int)((int64_t)splits * (blockIdx.y + 1) / groups);
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int k = k0; k < k1; ++k) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(ws + (int64_t)k * n + i);
+        s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
+    }
+    if (groups == 1) {
+        f32x4* d = reinterpret_cast<f32x4*>(dw + i);
+        f32x4 o = *d;
+        o[0] += s[0]; o[1] += s[1]; o[2] += s[2]; o[3] += s[3];
+        *d = o;
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) atomicAdd(dw + i + r, s[r]);
+    }
+}
+
+template <typename T, int WLOG>
+int launch(const sv_geom* g, const wg3_params& p, hipStream_t s) {
+    constexpr int W = 1 << WLOG, TR = 128 / W;
+    const int nNC = (g->N / 32) * (g->Cin / 32);
+    const int grid = p.splits * nNC;
+    const size_t lds = (size_t)(128 + (TR + 2) * (W + 2)) * LDH * sizeof(T);
+    sv_prof_begin(s);
+    hipLaunchKernelGGL((wgrad3x3_kernel<T, WLOG>), dim3(grid), dim3(256), lds, s, *g, p);
+    if (p.ws) {
+        const int64_t n = (int64_t)g->N * g->T_orig * g->Cin;      // multiple of 4 (Cin % 32 == 0)
+        const unsigned gx = (unsigned)((n / 4 + 255) / 256);
+        int groups = 1;                                  // >= 16 slabs per group, ~<= 1024 blocks
+        while (groups * 2 * 16 <= p.splits && gx * groups * 2 <= 1024) groups *= 2;
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3(gx, groups), dim3(256), 0, s, p.ws, p.splits, n, p.dw);
+    }
+    sv_prof_end(s);
+    return sv_check_launch("sv_wgrad(3x3)");
+}
+
+}  // namespace
+
+// Returns 1 and sets *rc when the geometry is a stride-1 3x3 convolution this kernel covers.
+int sv_wgrad3x3_try(const sv_geom* g, int dtype, const void* x, const float* pro_scale, const float* pro_shift,
+                    float pro_slope, const void* dy, float* dw, float* ws, int64_t ws_elems, hipStream_t s, int* rc) {
+    if (g->nphase != 1 || g->phase[0].ntap != 9 || g->sy != 1 || g->sx != 1 || g->osy != 1 || g->osx != 1) return 0;
+    if (g->Hq != g->Hin || g->Wq != g->Win || g->Hout != g->Hin || g->Wout != g->Win || g->Hin != g->Win) return 0;
+    if (g->Win != 8 && g->Win != 16 && g->Win != 32) return 0;
+    if (g->Cin % 32 != 0 || g->N % 32 != 0 || g->ldx != g->Cin || g->ldo != g->N) return 0;
+    if (g->phase[0].ooy != 0 || g->phase[0].oox != 0) return 0;
+    for (int t = 0; t < 9; ++t)
+        if (g->phase[0].dy[t] < -1 || g->phase[0].dy[t] > 1 || g->phase[0].dx[t] < -1 || g->phase[0].dx[t] > 1) return 0;
+    const int TR = 128 / g->Win;
+    if ((g->B * g->Hin) % TR != 0) return 0;
+    wg3_params p;
+    p.x = x; p.pro_scale = pro_scale; p.pro_shift = pro_shift; p.pro_slope = pro_slope; p.dy = dy; p.dw = dw;
+    const int nT = g->B * g->Hin / TR;
+    const int nNC = (g->N / 32) * (g->Cin / 32);
+    // ~four persistent blocks per CU (SV_WG3_BLOCKS overrides); every block should still see a few tiles
+    static const int target = getenv("SV_WG3_BLOCKS") ? atoi(getenv("SV_WG3_BLOCKS")) : 512;
+    int splits = (target + nNC - 1) / nNC;
+    if (splits > nT) splits = nT;
+    if (splits >= 8) splits = splits / 8 * 8;
+    if (splits < 1) splits = 1;
+    p.tiles_per = (nT + splits - 1) / splits;
+    if (splits < 8) splits = (nT + p.tiles_per - 1) / p.tiles_per;
+    p.splits = splits;
+    const int64_t need = (int64_t)splits * g->N * g->T_orig * g->Cin;
+    p.ws = (ws && ws_elems >= need && splits > 1) ? ws : nullptr;    // no workspace: atomics straight into dw
+    switch (g->Win) {
+        case 32: *rc = dtype == SV_BF16 ? launch<bf16, 5>(g, p, s) : launch<float, 5>(g, p, s); break;
+        case 16: *rc = dtype == SV_BF16 ? launch<bf16, 4>(g, p, s) : launch<float, 4>(g, p, s); break;
+        default: *rc = dtype == SV_BF16 ? launch<bf16, 3>(g, p, s) : launch<float, 3>(g, p, s); break;
+    }
+    return 1;
+}

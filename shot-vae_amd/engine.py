@@ -390,12 +390,21 @@ class Engine:
             self._tag(tag, g, (residual is not None) + (ex is not None))
         L.call("sv_igemm", C.byref(g), self.code, C.byref(a), self._stream())
 
+    _ws_elems = 16 * 1024 * 1024       # 64 MiB of fp32 partial-slab workspace for sv_wgrad
+
+    def _wg_ws(self):
+        ws = getattr(self, "_ws", None)
+        if ws is None or ws.device != self.param.device:
+            ws = self._ws = torch.empty(self._ws_elems, dtype=torch.float32, device=self.param.device)
+        return ws
+
     def _wgrad(self, g, x, pro, dy, dw_ptr, tag=None):
         if tag:
             self._tag(tag, g, wgrad=True)
         ps, pt, sl = (pro[0], pro[1], pro[2]) if pro is not None else (None, None, 0.0)
         L.call("sv_wgrad", C.byref(g), self.code, _vp(x.data_ptr()), _vp(ps) if ps else None,
-               _vp(pt) if pt else None, sl, _vp(dy.data_ptr()), _vp(dw_ptr), 0, self.use_tr, self._stream())
+               _vp(pt) if pt else None, sl, _vp(dy.data_ptr()), _vp(dw_ptr), 0, self.use_tr,
+               _vp(self._wg_ws().data_ptr()), self._ws_elems, self._stream())
 
     # ------------------------------------------------------------------------------- forward
     def forward(self, image, mode, label, label_mix, lam, eps, u, temperature, training, keep):

@@ -117,6 +117,12 @@ CONV_CASES = [
     (2, 160, 160, 8, 3, 1, 1),
     (6, 128, 128, 8, 3, 1, 1),
     (2, 16, 16, 32, 3, 1, 1),
+    # shapes that take the LDS-halo 3x3 kernel (conv3x3.hip) in its different tilings
+    (4, 32, 32, 32, 3, 1, 1),
+    (4, 64, 64, 16, 3, 1, 1),
+    (4, 64, 128, 8, 3, 1, 1),
+    (2, 32, 96, 16, 3, 1, 1),
+    (1, 320, 320, 16, 3, 1, 1),
 ]
 
 
@@ -206,7 +212,7 @@ def test_gemm_ragged_batch(dt):
     assert rel(sums[N:], (y * y).sum(0)) < max(tol, 1e-3) * 3
 
 
-WG_CASES = CONV_CASES + [(40, 16, 16, 32, 3, 1, 1)]
+WG_CASES = CONV_CASES + [(40, 16, 16, 32, 3, 1, 1), (16, 32, 32, 32, 3, 1, 1), (32, 64, 64, 16, 3, 1, 1)]
 
 
 @pytest.mark.parametrize("dt,use_tr", [("f32", 0), ("bf16", 0), ("bf16", 1)])
@@ -226,8 +232,10 @@ def test_conv_wgrad(dt, use_tr, case):
     xd, dyd = nhwc(x).to(d, tdt), nhwc(dy).to(d, tdt)
     sc, sh = scale.to(d), shift.to(d)
     dw = torch.zeros(N, k * k, Cin, device=d)
-    for _ in range(2):   # accumulates: two calls == 2x
-        L.call("sv_wgrad", C.byref(g), code, p(xd), p(sc), p(sh), 0.01, p(dyd), p(dw), 0, use_tr, st())
+    ws = torch.full((4 * 1024 * 1024,), float("nan"), device=d)      # workspace contents are irrelevant on entry
+    for it in range(2):   # accumulates: two calls == 2x; once with and once without the slab workspace
+        L.call("sv_wgrad", C.byref(g), code, p(xd), p(sc), p(sh), 0.01, p(dyd), p(dw), 0, use_tr,
+               p(ws) if it else None, ws.numel() if it else 0, st())
     torch.cuda.synchronize()
     got = dw.cpu().view(N, k, k, Cin).permute(0, 3, 1, 2) / 2
     assert rel(got, wref) < tol, rel(got, wref)
@@ -246,7 +254,7 @@ def test_convT_wgrad(dt, use_tr, H, Cin, N, B):
     d = dev()
     dw = torch.zeros(N, 16, Cin, device=d)
     L.call("sv_wgrad", C.byref(g), code, p(nhwc(x).to(d, tdt)), None, None, 0.0, p(nhwc(dy).to(d, tdt)), p(dw), 0,
-           use_tr, st())
+           use_tr, None, 0, st())
     torch.cuda.synchronize()
     got = dw.cpu().view(N, 4, 4, Cin).permute(3, 0, 1, 2)
     assert rel(got, w.grad) < tol
