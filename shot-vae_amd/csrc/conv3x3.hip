@@ -7,13 +7,15 @@
 // padding written as zeros -- together with the [BN][9][32] weight chunk, and then runs all nine taps
 // x BN channels on MFMA straight out of LDS (the tap shift is just an LDS address offset).
 // Same sv_geom / packed weights / fused epilogue as sv_igemm: it is a drop-in fast path inside it.
+#include <stdlib.h>
+
 #include "common.h"
 #include "epilogue.h"
 
 namespace {
 
 constexpr int CK = 32;          // channel chunk = one MFMA k step
-constexpr int LDC = CK + 8;     // LDS pixel / weight-row stride (elements): 80 B (bf16) keeps b128 reads conflict-free
+constexpr int LDC = CK + 16;    // LDS pixel / weight-row stride (elements): 96 B (bf16) keeps the b128 fragment reads conflict-free
 
 template <typename T, int NT, int WLOG>
 __global__ __launch_bounds__(256) void conv3x3_kernel(const sv_geom g, const sv_igemm_args a) {
@@ -165,6 +167,289 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const sv_geom g, const sv_
     gemm_epilogue<T, NT>(acc, obase, oval, n0, g.N, a, ssum);
 }
 
+
+// ------------------------------------------------------------------------------------------------------
+// Persistent variant for layers whose whole weight slab fits in LDS (Cin <= 64 at 32 output channels per
+// block): weights are staged ONCE per block, the block then walks a contiguous range of pixel tiles with a
+// register-prefetch software pipeline -- while tile i is on the MFMAs, the halo of tile i+1 and the
+// residual / raw tensor needed by tile i's epilogue are already in flight -- and the BatchNorm sums are
+// kept in registers across tiles and flushed once per block (one shuffle tree, one atomic per channel).
+template <typename T, int WLOG, int CCH>      // CCH = Cin / 32
+__global__ __launch_bounds__(256) void conv3x3p_kernel(const sv_geom g, const sv_igemm_args a, int tiles_per) {
+    typedef typename V8<T>::type V;
+    typedef typename V4<T>::type Q;
+    constexpr int NT = 2, BN = 32;
+    constexpr int W = 1 << WLOG, TR = 128 / W, WP = W + 2;
+    constexpr int CIN = 32 * CCH, LDW = CIN + 16;           // +16 elements: conflict-free ds_read_b128 fragments
+    constexpr int VPP = CIN / 8;                             // 8-channel vectors per pixel
+    // LDS halo rows: row 0 / the last row are the vertical halo, and when a tile holds several whole images
+    // (W = 8: TR = 16 > H = 8) a zero spacer row separates them -- so zero padding is DATA in LDS and the nine
+    // taps need no per-lane masking at all.
+    constexpr int HH = (TR < W) ? TR : W;                    // image rows per segment (images are square: H == W)
+    constexpr int SEG = TR / HH;
+    constexpr int LROWS = TR + SEG + 1;
+    constexpr int HV = LROWS * WP * VPP;                     // halo vectors
+    constexpr int HI = (HV + 255) / 256;
+    constexpr int HPIX = (HI * 256 + VPP - 1) / VPP;         // LDS pixels incl. dummy tail (branch-free staging)
+    constexpr int WV = BN * 9 * VPP, WI = (WV + 255) / 256;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* halo = reinterpret_cast<T*>(smem);                    // [HPIX][LDW]
+    T* wl = halo + HPIX * LDW;                               // [BN*9][LDW]
+    float* ssum = reinterpret_cast<float*>(wl + BN * 9 * LDW);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int H = g.Hin, BH = g.B * H, nT = BH / TR;
+    const int nNt = g.N / BN;
+    const int in_i = blockIdx.x % nNt, chunk = blockIdx.x / nNt;
+    const int n0 = in_i * BN;
+    const int t_begin = chunk * tiles_per, t_end = min(nT, t_begin + tiles_per);
+    if (t_begin >= t_end) return;
+    const sv_phase& P = g.phase[0];
+    const uint64_t pdy = pack_taps(P.dy), pdx = pack_taps(P.dx);
+    const T* __restrict__ X = reinterpret_cast<const T*>(a.x);
+    const T* __restrict__ Wp = reinterpret_cast<const T*>(a.w) + P.w_off + (int64_t)n0 * 9 * CIN;
+    T* __restrict__ O = reinterpret_cast<T*>(a.out);
+    const T* __restrict__ R = reinterpret_cast<const T*>(a.residual);
+    const T* __restrict__ EX = reinterpret_cast<const T*>(a.ex);
+    const bool has_pro = a.pro_scale != nullptr;
+    const bool want_sums = (a.stats != nullptr) || (EX != nullptr);
+
+    if (tid < 2 * BN) ssum[tid] = 0.f;
+    V zero;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) zero[j] = (T)0.f;
+
+    // ---- weights: once per block ------------------------------------------------------------------
+#pragma unroll
+    for (int i = 0; i < WI; ++i) {
+        const int idx = min(tid + 256 * i, WV - 1);           // (duplicates of the last vector are harmless)
+        const int row = idx / VPP, vv = idx - row * VPP;
+        *reinterpret_cast<V*>(wl + row * LDW + 8 * vv) = *reinterpret_cast<const V*>(Wp + (int64_t)row * CIN + 8 * vv);
+    }
+    // ---- halo staging slots: everything that does not depend on the tile -----------------------------
+    // kind: 0 = always zero (padding column / spacer / dummy), 1 = image row of this tile,
+    //       2 = row above the tile, 3 = row below the tile (valid only inside the same image)
+    int hrel[HI], hxc[HI], hlds[HI], hc[HI], hkind[HI];
+#pragma unroll
+    for (int i = 0; i < HI; ++i) {
+        const int idx = tid + 256 * i;
+        const int pix = idx / VPP;
+        hc[i] = 8 * (idx - pix * VPP);
+        hlds[i] = pix * LDW + hc[i];
+        const int lr = pix / WP, xx = pix - lr * WP;
+        const int seg = lr / (HH + 1), off = lr - seg * (HH + 1);
+        int kind = 1, rel = lr - 1 - seg;
+        if (off == 0) {
+            if (SEG == 1) { kind = seg == 0 ? 2 : 3; rel = seg == 0 ? -1 : TR; }
+            else kind = 0;
+        }
+        if (idx >= HV || xx == 0 || xx == WP - 1) kind = 0;
+        hkind[i] = kind;
+        hrel[i] = rel;
+        hxc[i] = min(max(xx - 1, 0), W - 1);
+    }
+    V hv[HI];
+    bool hok[HI];
+    auto load_halo = [&](int tile) {
+        const int gr0 = tile * TR;
+        const bool top_ok = (gr0 & (H - 1)) != 0, bot_ok = ((gr0 + TR) & (H - 1)) != 0;
+#pragma unroll
+        for (int i = 0; i < HI; ++i) {
+            hok[i] = hkind[i] == 1 || (hkind[i] == 2 && top_ok) || (hkind[i] == 3 && bot_ok);
+            const int grc = min(max(gr0 + hrel[i], 0), BH - 1);
+            hv[i] = *reinterpret_cast<const V*>(X + ((int64_t)grc * W + hxc[i]) * g.ldx + hc[i]);
+        }
+    };
+    auto store_halo = [&]() {
+#pragma unroll
+        for (int i = 0; i < HI; ++i) {
+            V o = hv[i];
+            if (has_pro) {
+                const f32x4 s0 = *reinterpret_cast<const f32x4*>(a.pro_scale + hc[i]);
+                const f32x4 s1 = *reinterpret_cast<const f32x4*>(a.pro_scale + hc[i] + 4);
+                const f32x4 t0 = *reinterpret_cast<const f32x4*>(a.pro_shift + hc[i]);
+                const f32x4 t1 = *reinterpret_cast<const f32x4*>(a.pro_shift + hc[i] + 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float u0 = to_f(hv[i][j]) * s0[j] + t0[j], u1 = to_f(hv[i][j + 4]) * s1[j] + t1[j];
+                    o[j] = (T)fmaxf(u0, u0 * a.pro_slope);          // LeakyReLU / ReLU for slope in [0,1]
+                    o[j + 4] = (T)fmaxf(u1, u1 * a.pro_slope);
+                }
+            }
+            *reinterpret_cast<V*>(halo + hlds[i]) = hok[i] ? o : zero;
+        }
+    };
+
+    // this lane's two output pixels inside a tile, per-channel epilogue constants
+    int hbase[2], prow[2], pcol[2];
+#pragma unroll
+    for (int ms = 0; ms < 2; ++ms) {
+        const int p = 32 * wave + 16 * ms + fr;
+        prow[ms] = p >> WLOG;
+        pcol[ms] = p & (W - 1);
+        hbase[ms] = ((prow[ms] + 1 + prow[ms] / HH) * WP + pcol[ms] + 1) * LDW + 8 * fq;
+    }
+    f32x4 bias[NT], esc[NT], esh[NT], emu[NT], ers[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        const int n = n0 + 16 * i + 4 * fq;
+        bias[i] = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+        if (EX) {
+            esc[i] = *reinterpret_cast<const f32x4*>(a.ex_scale + n);
+            esh[i] = *reinterpret_cast<const f32x4*>(a.ex_shift + n);
+            emu[i] = *reinterpret_cast<const f32x4*>(a.ex_mean + n);
+            ers[i] = *reinterpret_cast<const f32x4*>(a.ex_rstd + n);
+        }
+    }
+    float s1[NT][4], s2[NT][4];
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s1[i][r] = s2[i][r] = 0.f;
+
+    load_halo(t_begin);
+    store_halo();
+    __syncthreads();
+    for (int tile = t_begin; tile < t_end; ++tile) {
+        const int gr0 = tile * TR;
+        // ---- issue next tile's halo + this tile's epilogue operands; they fly during the MFMAs ---------
+        const bool more = tile + 1 < t_end;
+        if (more) load_halo(tile + 1);
+        int64_t obase[2];
+        Q eop[NT][2];
+#pragma unroll
+        for (int ms = 0; ms < 2; ++ms) {
+            obase[ms] = ((int64_t)(gr0 + prow[ms]) * W + pcol[ms]) * g.ldo;
+#pragma unroll
+            for (int i = 0; i < NT; ++i) {
+                const int n = n0 + 16 * i + 4 * fq;
+                if (R) eop[i][ms] = *reinterpret_cast<const Q*>(R + obase[ms] + n);
+                else if (EX) eop[i][ms] = *reinterpret_cast<const Q*>(EX + obase[ms] + n);
+            }
+        }
+        // ---- nine taps x CCH channel chunks out of LDS (padding is data: no masks) ---------------------------
+        f32x4 acc[NT][2];
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int sh = (tap_off(pdy, t) * WP + tap_off(pdx, t)) * LDW;
+#pragma unroll
+            for (int ck = 0; ck < CCH; ++ck) {
+                const V af0 = *reinterpret_cast<const V*>(halo + hbase[0] + sh + 32 * ck);
+                const V af1 = *reinterpret_cast<const V*>(halo + hbase[1] + sh + 32 * ck);
+#pragma unroll
+                for (int i = 0; i < NT; ++i) {
+                    const V wf = *reinterpret_cast<const V*>(wl + ((16 * i + fr) * 9 + t) * LDW + 32 * ck + 8 * fq);
+                    mma32(acc[i][0], wf, af0);
+                    mma32(acc[i][1], wf, af1);
+                }
+            }
+        }
+        __syncthreads();                               // all waves are done reading this tile's halo
+        if (more) store_halo();                        // next tile's halo -> LDS (waits for its loads)
+        // ---- epilogue of this tile (operands already in registers) -----------------------------------------
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            const int n = n0 + 16 * i + 4 * fq;
+#pragma unroll
+            for (int ms = 0; ms < 2; ++ms) {
+                f32x4 vv = acc[i][ms];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) vv[r] += bias[i][r];
+                if (R) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) vv[r] += to_f(eop[i][ms][r]);
+                }
+                if (EX) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float xf = to_f(eop[i][ms][r]);
+                        const float gv = vv[r] * act_grad(xf * esc[i][r] + esh[i][r], a.ex_slope);
+                        vv[r] = gv;
+                        s1[i][r] += gv;
+                        s2[i][r] += gv * ((xf - emu[i][r]) * ers[i][r]);
+                    }
+                } else if (a.stats) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        s1[i][r] += vv[r];
+                        s2[i][r] += vv[r] * vv[r];
+                    }
+                }
+                Q o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = (T)vv[r];
+                *reinterpret_cast<Q*>(O + obase[ms] + n) = o;
+            }
+        }
+        __syncthreads();                               // next halo visible
+    }
+    // ---- flush the per-channel sums once per block ---------------------------------------------------------
+    if (want_sums) {
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) {
+                    s1[i][r] += __shfl_xor(s1[i][r], o);
+                    s2[i][r] += __shfl_xor(s2[i][r], o);
+                }
+                if (fr == 0) {
+                    atomicAdd(&ssum[16 * i + 4 * fq + r], s1[i][r]);
+                    atomicAdd(&ssum[BN + 16 * i + 4 * fq + r], s2[i][r]);
+                }
+            }
+        }
+        __syncthreads();
+        float* dst = (EX ? a.bsums : a.stats) + (size_t)(blockIdx.x & (a.replicas - 1)) * 2 * g.N;
+        if (tid < 2 * BN) {
+            const int which = tid / BN, nl = tid - which * BN;
+            atomicAdd(dst + which * g.N + n0 + nl, ssum[tid]);
+        }
+    }
+}
+
+template <typename T, int WLOG, int CCH>
+int launch_p(const sv_geom* g, const sv_igemm_args* a, hipStream_t s) {
+    constexpr int W = 1 << WLOG, TR = 128 / W, CIN = 32 * CCH, LDW = CIN + 16, VPP = CIN / 8;
+    constexpr int HH = (TR < W) ? TR : W, SEG = TR / HH, LROWS = TR + SEG + 1;
+    constexpr int HV = LROWS * (W + 2) * VPP, HI = (HV + 255) / 256, HPIX = (HI * 256 + VPP - 1) / VPP;
+    const int nT = g->B * g->Hin / TR;
+    const int nNt = g->N / 32;
+    static const int target = getenv("SV_C3P_BLOCKS") ? atoi(getenv("SV_C3P_BLOCKS")) : 512;
+    int chunks = (target + nNt - 1) / nNt;
+    if (chunks > nT) chunks = nT;
+    const int tiles_per = (nT + chunks - 1) / chunks;
+    chunks = (nT + tiles_per - 1) / tiles_per;
+    const size_t lds = (size_t)(HPIX + 32 * 9) * LDW * sizeof(T) + 2 * 32 * sizeof(float);
+    static bool optin = false;
+    if (lds > 64 * 1024 && !optin) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3p_kernel<T, WLOG, CCH>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return sv_check_launch("hipFuncSetAttribute(conv3x3p)");
+        optin = true;
+    }
+    sv_prof_begin(s);
+    hipLaunchKernelGGL((conv3x3p_kernel<T, WLOG, CCH>), dim3(chunks * nNt), dim3(256), lds, s, *g, *a, tiles_per);
+    sv_prof_end(s);
+    return sv_check_launch("sv_igemm(conv3x3p)");
+}
+
+template <typename T, int CCH>
+int launch_pw(const sv_geom* g, const sv_igemm_args* a, hipStream_t s) {
+    switch (g->Win) {
+        case 32: return launch_p<T, 5, CCH>(g, a, s);
+        case 16: return launch_p<T, 4, CCH>(g, a, s);
+        default: return launch_p<T, 3, CCH>(g, a, s);
+    }
+}
+
 template <typename T, int NT, int WLOG>
 int launch(const sv_geom* g, const sv_igemm_args* a, hipStream_t s) {
     constexpr int W = 1 << WLOG, TR = 128 / W, BN = 16 * NT;
@@ -207,6 +492,16 @@ int sv_conv3x3_try(const sv_geom* g, int dtype, const sv_igemm_args* a, hipStrea
         if (g->phase[0].dy[t] < -1 || g->phase[0].dy[t] > 1 || g->phase[0].dx[t] < -1 || g->phase[0].dx[t] > 1) return 0;
     const int TR = 128 / g->Win;
     if ((g->B * g->Hin) % TR != 0) return 0;
+    static const bool no_persist = getenv("SV_NO_CONV3X3P") != nullptr;
+    if (!no_persist && dtype == SV_BF16 && (g->Cin == 32 || g->Cin == 64)) {
+        // whole weight slab resident in LDS: persistent software-pipelined kernel
+        *rc = g->Cin == 32 ? launch_pw<bf16, 1>(g, a, s) : launch_pw<bf16, 2>(g, a, s);
+        return 1;
+    }
+    if (!no_persist && dtype == SV_F32 && g->Cin == 32) {
+        *rc = launch_pw<float, 1>(g, a, s);
+        return 1;
+    }
     if (dtype == SV_BF16) {
         // 64-channel tiles keep two blocks per CU resident (LDS); wider layers take several tiles
         if (g->N % 64 == 0) *rc = launch_w<bf16, 4>(g, a, s);

@@ -20,7 +20,7 @@ namespace {
 
 constexpr int BM = 128;
 constexpr int BK = 32;
-constexpr int LDK = BK + 8;   // LDS row stride in elements (pad keeps 16-byte alignment, spreads banks)
+constexpr int LDK = BK + 16;  // LDS row stride in elements: 96 B rows make the b128 fragment reads conflict-free
 
 template <typename T, int NT>
 __global__ __launch_bounds__(256) void igemm_kernel(const sv_geom g, const sv_igemm_args a) {
@@ -247,7 +247,7 @@ extern "C" int sv_igemm(const sv_geom* g, int dtype, const sv_igemm_args* a, voi
     for (int i = 0; i < 4; ++i) {
         const int c = cand[i];
         if (N % (16 * c) != 0) continue;
-        if (dtype == SV_F32 && c > 4) continue;     // LDS budget (<= 64 KiB without opt-in)
+        if (dtype == SV_F32 && c > 2) continue;     // LDS budget (<= 64 KiB without opt-in)
         nt = c;
         if (mtiles * (N / (16 * c)) >= 512) break;
         if (c <= 2) break;
@@ -263,7 +263,6 @@ extern "C" int sv_igemm(const sv_geom* g, int dtype, const sv_igemm_args* a, voi
         }
     }
     switch (nt) {
-        case 4: return launch<float, 4>(g, a, s);
         case 2: return launch<float, 2>(g, a, s);
         default: return launch<float, 1>(g, a, s);
     }

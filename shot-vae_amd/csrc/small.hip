@@ -21,16 +21,26 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
 }
 
 // ---------------------------------------------------------------------------------------- BatchNorm
-__global__ void bn_finalize_kernel(const float* stats, int R, int C, float count, const float* gamma,
-                                   const float* beta, float eps, float momentum, float* rm, float* rv,
-                                   float* scale, float* shift, float* mean, float* rstd) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+// 256 threads = 8 channels x 32 lanes; the lanes of a channel split the accumulator replicas (the loads
+// are independent and in flight together instead of one dependent chain per channel)
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* stats, int R, int C, float count,
+                                                          const float* gamma, const float* beta, float eps,
+                                                          float momentum, float* rm, float* rv, float* scale,
+                                                          float* shift, float* mean, float* rstd) {
+    const int c = blockIdx.x * 8 + (threadIdx.x >> 5);
+    const int r0 = threadIdx.x & 31;
     float s1 = 0.f, s2 = 0.f;
-    for (int r = 0; r < R; ++r) {
-        s1 += stats[(size_t)r * 2 * C + c];
-        s2 += stats[(size_t)r * 2 * C + C + c];
+    if (c < C)
+        for (int r = r0; r < R; r += 32) {
+            s1 += stats[(size_t)r * 2 * C + c];
+            s2 += stats[(size_t)r * 2 * C + C + c];
+        }
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) {
+        s1 += __shfl_xor(s1, o);
+        s2 += __shfl_xor(s2, o);
     }
+    if (c >= C || r0 != 0) return;
     const float mu = s1 / count;
     float var = s2 / count - mu * mu;
     var = var > 0.f ? var : 0.f;
@@ -188,7 +198,7 @@ __global__ void pool_bwd_kernel(const T* x, const float* scale, const float* shi
 }
 
 // ---------------------------------------------------------------------------------------- heads
-constexpr int HS = 8;   // samples per block
+constexpr int HS = 4;   // samples per block
 
 __global__ __launch_bounds__(256) void head_fwd_kernel(const float* feat, int B, int C, const float* W,
                                                        const float* bias, int ldc, int K, float* mu,
@@ -204,22 +214,25 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* feat, int B,
         f[i] = (b0 + s < B) ? feat[(int64_t)(b0 + s) * C + (i - s * C)] : 0.f;
     }
     __syncthreads();
-    for (int n = wave; n < NH; n += 4) {
+    // one output per thread: its weight row streams in as independent float4 loads (C % 4 == 0), the
+    // features are LDS broadcasts
+    for (int n = tid; n < NH; n += 256) {
         float acc[HS];
 #pragma unroll
         for (int s = 0; s < HS; ++s) acc[s] = 0.f;
-        for (int k = lane; k < C; k += 64) {
-            const float w = W[(int64_t)n * C + k];
+        const f32x4* wr = reinterpret_cast<const f32x4*>(W + (int64_t)n * C);
+#pragma unroll 8
+        for (int k4 = 0; k4 < C / 4; ++k4) {
+            const f32x4 w = wr[k4];
 #pragma unroll
-            for (int s = 0; s < HS; ++s) acc[s] += w * f[s * C + k];
+            for (int s = 0; s < HS; ++s) {
+                const f32x4 fv = *reinterpret_cast<const f32x4*>(f + s * C + 4 * k4);
+                acc[s] += w[0] * fv[0] + w[1] * fv[1] + w[2] * fv[2] + w[3] * fv[3];
+            }
         }
+        const float bb = bias[n];
 #pragma unroll
-        for (int s = 0; s < HS; ++s) acc[s] = wave_sum(acc[s]);
-        if (lane == 0) {
-            const float bb = bias[n];
-#pragma unroll
-            for (int s = 0; s < HS; ++s) o[s * NH + n] = acc[s] + bb;
-        }
+        for (int s = 0; s < HS; ++s) o[s * NH + n] = acc[s] + bb;
     }
     __syncthreads();
     for (int i = tid; i < HS * 2 * ldc; i += 256) {
@@ -282,6 +295,7 @@ __global__ __launch_bounds__(256) void head_bwd_data_kernel(int B, int C, const 
         float acc[HS];
 #pragma unroll
         for (int s = 0; s < HS; ++s) acc[s] = 0.f;
+#pragma unroll 8
         for (int n = 0; n < NH; ++n) {
             const float w = W[(int64_t)n * C + c];
 #pragma unroll
@@ -293,20 +307,24 @@ __global__ __launch_bounds__(256) void head_bwd_data_kernel(int B, int C, const 
     }
 }
 
-// dW[n][c] += sum_b dout[b][n]*feat[b][c];  dbias[n] += sum_b dout[b][n].  grid = NH blocks.
+// dW[n][c] += sum_b dout[b][n]*feat[b][c];  dbias[n] += sum_b dout[b][n].  grid = (NH, batch slices);
+// the slices meet through float atomics (dW / dbias accumulate anyway).
 __global__ __launch_bounds__(256) void head_bwd_weight_kernel(const float* feat, const float* dout, int B,
                                                               int C, int NH, float* dW, float* dbias) {
     const int n = blockIdx.x;
     const int tid = threadIdx.x;
+    const int per = (B + gridDim.y - 1) / gridDim.y;
+    const int b0 = blockIdx.y * per, b1 = min(B, b0 + per);
     __shared__ float red[4];
     float sb = 0.f;
-    for (int b = tid; b < B; b += 256) sb += dout[(int64_t)b * NH + n];
+    for (int b = b0 + tid; b < b1; b += 256) sb += dout[(int64_t)b * NH + n];
     sb = block_sum(sb, red);
-    if (tid == 0) dbias[n] += sb;
+    if (tid == 0) atomicAdd(dbias + n, sb);
     for (int c = tid; c < C; c += 256) {
         float acc = 0.f;
-        for (int b = 0; b < B; ++b) acc += dout[(int64_t)b * NH + n] * feat[(int64_t)b * C + c];
-        dW[(int64_t)n * C + c] += acc;
+#pragma unroll 8
+        for (int b = b0; b < b1; ++b) acc += dout[(int64_t)b * NH + n] * feat[(int64_t)b * C + c];
+        atomicAdd(dW + (int64_t)n * C + c, acc);
     }
 }
 
@@ -652,7 +670,7 @@ int sv_bn_finalize(const float* stats, int replicas, int C, float count, const f
                    float* rstd, void* stream) {
     SV_REQUIRE(stats && gamma && beta && scale && shift && mean && rstd && C > 0 && replicas >= 1, SV_E_ARG,
                "sv_bn_finalize: bad args");
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, stats, replicas, C,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 7) / 8), dim3(256), 0, (hipStream_t)stream, stats, replicas, C,
                        count, gamma, beta, eps, momentum, rm, rv, scale, shift, mean, rstd);
     return sv_check_launch("sv_bn_finalize");
 }
@@ -731,8 +749,8 @@ int sv_head_bwd(const float* feat, int B, int C, const float* W, int ldc, int K,
     const size_t lds = (size_t)HS * NH * sizeof(float);
     hipLaunchKernelGGL(head_bwd_data_kernel, dim3((B + HS - 1) / HS), dim3(256), lds, (hipStream_t)stream, B, C, W,
                        ldc, K, la, dmu, dls, dla, dfeat, dout_ws);
-    hipLaunchKernelGGL(head_bwd_weight_kernel, dim3(NH), dim3(256), 0, (hipStream_t)stream, feat, dout_ws, B, C, NH,
-                       dW, dbias);
+    hipLaunchKernelGGL(head_bwd_weight_kernel, dim3(NH, B >= 64 ? 8 : 1), dim3(256), 0, (hipStream_t)stream, feat,
+                       dout_ws, B, C, NH, dW, dbias);
     return sv_check_launch("sv_head_bwd");
 }
 
