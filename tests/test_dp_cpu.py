@@ -1,0 +1,72 @@
+"""Data-parallel path on CPU (gloo, world_size 2): the host logic of shot_vae_amd.dp -- batch sharding,
+parameter broadcast, the single all-reduce of the flat gradient buffer and the 1/world scaling -- using the
+oracle as the per-rank step (the HIP kernels need a GPU; the collective logic does not)."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _flat(st, keys, grad=False):
+    return torch.cat([(st[k].grad if grad else st[k].detach()).reshape(-1) for k in keys])
+
+
+def _worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from oracle import closed_form as C
+    from oracle import shotvae_oracle as O
+    from shot_vae_amd import dp
+    torch.set_num_threads(2)
+    r, w, _ = dp.init_from_env(backend="gloo")
+    assert (r, w) == (rank, world)
+    name, K, B = "wideresnet-10-1", 10, 8
+    st = C.make_state(name, K=K)
+    keys = [k for k in st if O.is_param(k)]
+    # rank 1 starts from different weights: broadcast_parameters must fix that
+    flat = _flat(st, keys) * (1.0 if rank == 0 else 0.5)
+    dp.broadcast_parameters(flat)
+    off = 0
+    for k in keys:
+        n = st[k].numel()
+        st[k] = flat[off:off + n].view_as(st[k]).clone().requires_grad_(True)
+        off += n
+    il, ll, iu, lu = C.make_batch(B, B, K)
+    nz = C.make_noise(B // world, B // world, K, stream0=9000 + 10 * rank)
+    nz["lam_l"], nz["lam_u"] = 0.8, 0.4                     # every rank must use the same lambdas
+    O.train_step(st, name, dp.shard(il, rank, world), dp.shard(ll, rank, world), dp.shard(iu, rank, world), nz,
+                 O.schedule(10))
+    g = _flat(st, keys, grad=True)
+    local = g.clone()
+    scale = dp.all_reduce_gradients(g)
+    gathered = [torch.zeros_like(local) for _ in range(world)]
+    dist.all_gather(gathered, local)
+    if rank == 0:
+        torch.save(dict(reduced=g, scale=scale, locals=gathered, params=flat), out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_rank_gradient_all_reduce(tmp_path):
+    out = str(tmp_path / "dp.pt")
+    port = 29500 + os.getpid() % 2000
+    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    r = torch.load(out)
+    assert r["scale"] == 0.5
+    assert torch.allclose(r["reduced"], r["locals"][0] + r["locals"][1], rtol=1e-6, atol=1e-9)
+    assert float((r["locals"][0] - r["locals"][1]).abs().max()) > 0      # the shards really differ
+
+
+def test_shard_partitions_the_batch():
+    from shot_vae_amd import dp
+    t = torch.arange(16).view(8, 2)
+    parts = [dp.shard(t, r, 4) for r in range(4)]
+    assert torch.equal(torch.cat(parts), t)
+    assert dp.all_reduce_gradients(torch.ones(3)) == 1.0      # no process group: identity, scale 1
