@@ -250,6 +250,16 @@ __global__ __launch_bounds__(256) void conv3x3p_kernel(const sv_geom g, const sv
         hrel[i] = rel;
         hxc[i] = min(max(xx - 1, 0), W - 1);
     }
+    // a thread's 8-channel group is the same for all of its slots (256 % VPP == 0): BN scale / shift live in
+    // registers for the whole kernel instead of being re-fetched (a dependent L2 round trip) every tile
+    static_assert(256 % VPP == 0, "");
+    f32x4 ps0 = {1.f, 1.f, 1.f, 1.f}, ps1 = ps0, pt0 = {0.f, 0.f, 0.f, 0.f}, pt1 = pt0;
+    if (has_pro) {
+        ps0 = *reinterpret_cast<const f32x4*>(a.pro_scale + hc[0]);
+        ps1 = *reinterpret_cast<const f32x4*>(a.pro_scale + hc[0] + 4);
+        pt0 = *reinterpret_cast<const f32x4*>(a.pro_shift + hc[0]);
+        pt1 = *reinterpret_cast<const f32x4*>(a.pro_shift + hc[0] + 4);
+    }
     V hv[HI];
     bool hok[HI];
     auto load_halo = [&](int tile) {
@@ -267,13 +277,9 @@ __global__ __launch_bounds__(256) void conv3x3p_kernel(const sv_geom g, const sv
         for (int i = 0; i < HI; ++i) {
             V o = hv[i];
             if (has_pro) {
-                const f32x4 s0 = *reinterpret_cast<const f32x4*>(a.pro_scale + hc[i]);
-                const f32x4 s1 = *reinterpret_cast<const f32x4*>(a.pro_scale + hc[i] + 4);
-                const f32x4 t0 = *reinterpret_cast<const f32x4*>(a.pro_shift + hc[i]);
-                const f32x4 t1 = *reinterpret_cast<const f32x4*>(a.pro_shift + hc[i] + 4);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const float u0 = to_f(hv[i][j]) * s0[j] + t0[j], u1 = to_f(hv[i][j + 4]) * s1[j] + t1[j];
+                    const float u0 = to_f(hv[i][j]) * ps0[j] + pt0[j], u1 = to_f(hv[i][j + 4]) * ps1[j] + pt1[j];
                     o[j] = (T)fmaxf(u0, u0 * a.pro_slope);          // LeakyReLU / ReLU for slope in [0,1]
                     o[j + 4] = (T)fmaxf(u1, u1 * a.pro_slope);
                 }

@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const sv_geom g, const sv_ig
 
     V ra[2], rb[NBV];
     bool oka[2];
-    int ca = 0;
+    f32x4 ps0, ps1, pt0, pt1;        // BN scale / shift of the chunk in flight (fetched WITH its data)
 
     V zero;
 #pragma unroll
@@ -99,7 +99,12 @@ __global__ __launch_bounds__(256) void igemm_kernel(const sv_geom g, const sv_ig
     auto load_global = [&](int kc) {
         const int tt = tap < SV_MAX_TAPS ? tap : SV_MAX_TAPS - 1;
         const int dy = tap_off(pdy, tt), dx = tap_off(pdx, tt);
-        ca = c;
+        if (has_pro) {
+            ps0 = *reinterpret_cast<const f32x4*>(a.pro_scale + c);
+            ps1 = *reinterpret_cast<const f32x4*>(a.pro_scale + c + 4);
+            pt0 = *reinterpret_cast<const f32x4*>(a.pro_shift + c);
+            pt1 = *reinterpret_cast<const f32x4*>(a.pro_shift + c + 4);
+        }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int iy = iy0[i] + dy, ix = ix0[i] + dx;
@@ -128,21 +133,16 @@ __global__ __launch_bounds__(256) void igemm_kernel(const sv_geom g, const sv_ig
         T* Ab = As + buf * BM * LDK;
         T* Bb = Bs + buf * BN * LDK;
         if (has_pro) {
-            f32x4 s0 = *reinterpret_cast<const f32x4*>(a.pro_scale + ca);
-            f32x4 s1 = *reinterpret_cast<const f32x4*>(a.pro_scale + ca + 4);
-            f32x4 t0 = *reinterpret_cast<const f32x4*>(a.pro_shift + ca);
-            f32x4 t1 = *reinterpret_cast<const f32x4*>(a.pro_shift + ca + 4);
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                if (oka[i]) {
-                    V o;
+                V o;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        o[j] = (T)act_fwd(to_f(ra[i][j]) * s0[j] + t0[j], a.pro_slope);
-                        o[j + 4] = (T)act_fwd(to_f(ra[i][j + 4]) * s1[j] + t1[j], a.pro_slope);
-                    }
-                    ra[i] = o;
+                for (int j = 0; j < 4; ++j) {
+                    const float u0 = to_f(ra[i][j]) * ps0[j] + pt0[j], u1 = to_f(ra[i][j + 4]) * ps1[j] + pt1[j];
+                    o[j] = (T)fmaxf(u0, u0 * a.pro_slope);          // LeakyReLU / ReLU for slope in [0,1]
+                    o[j + 4] = (T)fmaxf(u1, u1 * a.pro_slope);
                 }
+                ra[i] = oka[i] ? o : zero;
             }
         }
 #pragma unroll

@@ -78,65 +78,128 @@ struct bnb_params {
     void* dx;
 };
 
-template <typename T>
+// REG: (threads of the grid) % (C/8) == 0, so a thread always meets the same 8 channels and keeps their
+// coefficients [gamma*rstd, mean(g), mean(g*xhat)] (+ mean, rstd) in registers; otherwise they sit in LDS.
+template <typename T, bool REG>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bnb_params p) {
     typedef typename V8<T>::type V;
-    // per-channel coefficients in LDS: [mean, rstd] + per branch [gamma*rstd, mean(g), mean(g*xhat)]
     extern __shared__ __attribute__((aligned(16))) float coef[];
-    float* cmean = coef;
-    float* crstd = coef + p.C;
-    for (int c = threadIdx.x; c < p.C; c += blockDim.x) {
-        const float rs = p.rstd[c];
-        cmean[c] = p.mean[c];
-        crstd[c] = rs;
-        for (int k = 0; k < p.nbranch; ++k) {
-            float s1 = 0.f, s2 = 0.f;
-            for (int r = 0; r < p.br[k].replicas; ++r) {
-                s1 += p.br[k].bsums[(size_t)r * 2 * p.C + c];
-                s2 += p.br[k].bsums[(size_t)r * 2 * p.C + p.C + c];
+    const int cv = p.C / 8;                       // vectors per row
+    const int64_t gtid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    // per-channel coefficients once per block into LDS.  The replica sums are spread over all 256 threads
+    // (G = 256/C thread groups per channel, each summing every G-th replica, all loads independent): a
+    // serial 32-replica loop per channel put a ~15 us latency floor under every launch of this kernel.
+    {
+        float* cmean = coef;
+        float* crstd = coef + p.C;
+        float* part = coef + (2 + 3 * p.nbranch) * p.C;         // [nbranch][2][G][Cg]
+        const int Cg = p.C < 256 ? p.C : 256;
+        const int G = 256 / Cg;
+        const int grp = threadIdx.x / Cg, cl = threadIdx.x - grp * Cg;
+        for (int cb0 = 0; cb0 < p.C; cb0 += Cg) {
+            const int c = cb0 + cl;
+            if (grp < G && c < p.C)
+                for (int k = 0; k < p.nbranch; ++k) {
+                    float s1 = 0.f, s2 = 0.f;
+#pragma unroll 4
+                    for (int r = grp; r < p.br[k].replicas; r += G) {
+                        s1 += p.br[k].bsums[(size_t)r * 2 * p.C + c];
+                        s2 += p.br[k].bsums[(size_t)r * 2 * p.C + p.C + c];
+                    }
+                    part[((k * 2 + 0) * G + grp) * Cg + cl] = s1;
+                    part[((k * 2 + 1) * G + grp) * Cg + cl] = s2;
+                }
+            __syncthreads();
+            if (grp == 0 && c < p.C) {
+                const float rs = p.rstd[c];
+                cmean[c] = p.mean[c];
+                crstd[c] = rs;
+                for (int k = 0; k < p.nbranch; ++k) {
+                    float s1 = 0.f, s2 = 0.f;
+                    for (int q = 0; q < G; ++q) {
+                        s1 += part[((k * 2 + 0) * G + q) * Cg + cl];
+                        s2 += part[((k * 2 + 1) * G + q) * Cg + cl];
+                    }
+                    float* cb = coef + (2 + 3 * k) * p.C;
+                    cb[c] = p.br[k].gamma[c] * rs;
+                    cb[p.C + c] = s1 * p.inv_count;
+                    cb[2 * p.C + c] = s2 * p.inv_count;
+                    if (blockIdx.x == 0) {
+                        if (p.br[k].dbeta) p.br[k].dbeta[c] += s1;
+                        if (p.br[k].dgamma) p.br[k].dgamma[c] += s2;
+                    }
+                }
             }
-            float* cb = coef + (2 + 3 * k) * p.C;
-            cb[c] = p.br[k].gamma[c] * rs;
-            cb[p.C + c] = s1 * p.inv_count;
-            cb[2 * p.C + c] = s2 * p.inv_count;
-            if (blockIdx.x == 0) {
-                if (p.br[k].dbeta) p.br[k].dbeta[c] += s1;
-                if (p.br[k].dgamma) p.br[k].dgamma[c] += s2;
+            __syncthreads();
+        }
+    }
+    // ... and, when a thread always meets the same 8 channels, from there into registers
+    float cm[8], cr[8], ca[2][8], c1[2][8], c2[2][8];
+    if (REG) {
+        const int c0 = (int)(gtid % cv) * 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            cm[j] = coef[c0 + j];
+            cr[j] = coef[p.C + c0 + j];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                ca[k][j] = c1[k][j] = c2[k][j] = 0.f;
+                if (k < p.nbranch) {
+                    const float* cb = coef + (2 + 3 * k) * p.C;
+                    ca[k][j] = cb[c0 + j];
+                    c1[k][j] = cb[p.C + c0 + j];
+                    c2[k][j] = cb[2 * p.C + c0 + j];
+                }
             }
         }
     }
-    __syncthreads();
-    const int cv = p.C / 8;                       // vectors per row
     const int64_t total = p.M * cv;
     const T* X = reinterpret_cast<const T*>(p.x);
     const T* R = reinterpret_cast<const T*>(p.residual);
     T* DX = reinterpret_cast<T*>(p.dx);
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t m = i / cv;
-        const int c = (int)(i - m * cv) * 8;
+    // no 64-bit division in the loop: a thread's channel group is fixed (REG) and its row advances by a constant
+    int64_t m = gtid / cv;
+    int c = (int)(gtid - m * cv) * 8;
+    const int64_t m_step = gsz / cv;
+    const int c_step = (int)(gsz - m_step * cv) * 8;          // 0 in the REG case
+    for (int64_t i = gtid; i < total; i += gsz) {
         const int64_t off = m * p.ld + c;
         const V xv = *reinterpret_cast<const V*>(X + off);
+        V gv[2];
+        gv[0] = *reinterpret_cast<const V*>(reinterpret_cast<const T*>(p.br[0].g) + off);
+        if (p.nbranch > 1) gv[1] = *reinterpret_cast<const V*>(reinterpret_cast<const T*>(p.br[1].g) + off);
+        V rv;
+        if (R) rv = *reinterpret_cast<const V*>(R + off);
         float o[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = 0.f;
-        for (int k = 0; k < p.nbranch; ++k) {
-            const V gv = *reinterpret_cast<const V*>(reinterpret_cast<const T*>(p.br[k].g) + off);
-            const float* cb = coef + (2 + 3 * k) * p.C;
+        for (int j = 0; j < 8; ++j) {
+            float mu, rs;
+            if (REG) { mu = cm[j]; rs = cr[j]; } else { mu = coef[c + j]; rs = coef[p.C + c + j]; }
+            const float xh = (to_f(xv[j]) - mu) * rs;
+            float acc = 0.f;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float xh = (to_f(xv[j]) - cmean[c + j]) * crstd[c + j];
-                o[j] += cb[c + j] * (to_f(gv[j]) - cb[p.C + c + j] - xh * cb[2 * p.C + c + j]);
+            for (int k = 0; k < 2; ++k) {
+                if (k < p.nbranch) {
+                    float a_, m1, m2;
+                    if (REG) { a_ = ca[k][j]; m1 = c1[k][j]; m2 = c2[k][j]; }
+                    else {
+                        const float* cb = coef + (2 + 3 * k) * p.C;
+                        a_ = cb[c + j]; m1 = cb[p.C + c + j]; m2 = cb[2 * p.C + c + j];
+                    }
+                    acc += a_ * (to_f(gv[k][j]) - m1 - xh * m2);
+                }
             }
-        }
-        if (R) {
-            const V rv = *reinterpret_cast<const V*>(R + off);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] += to_f(rv[j]);
+            if (R) acc += to_f(rv[j]);
+            o[j] = acc;
         }
         V ov;
 #pragma unroll
         for (int j = 0; j < 8; ++j) ov[j] = (T)o[j];
         *reinterpret_cast<V*>(DX + off) = ov;
+        m += m_step;
+        c += c_step;
+        if (c >= p.C) { c -= p.C; ++m; }
     }
 }
 
@@ -606,21 +669,21 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* p, const float* g, floa
 // ---------------------------------------------------------------------------------------- layout
 template <typename T>
 __global__ void nchw_to_nhwc_kernel(const float* in, int B, int C, int HW, int Cpad, T* out) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // over B*HW*Cpad
-    if (i >= (int64_t)B * HW * Cpad) return;
-    const int c = (int)(i % Cpad);
-    const int64_t bp = i / Cpad;
-    const int64_t b = bp / HW, p = bp - b * HW;
-    out[i] = (T)(c < C ? in[(b * C + c) * HW + p] : 0.f);
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;           // over B*HW*Cpad (< 2^32)
+    if (i >= (unsigned)B * HW * Cpad) return;
+    const unsigned c = i % Cpad;
+    const unsigned bp = i / Cpad;
+    const unsigned b = bp / HW, p = bp - b * HW;
+    out[i] = (T)(c < (unsigned)C ? in[((size_t)b * C + c) * HW + p] : 0.f);
 }
 template <typename T>
 __global__ void nhwc_to_nchw_kernel(const T* in, int B, int C, int HW, int ld, float* out) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // over B*C*HW
-    if (i >= (int64_t)B * C * HW) return;
-    const int64_t p = i % HW;
-    const int64_t bc = i / HW;
-    const int64_t b = bc / C, c = bc - b * C;
-    out[i] = to_f(in[(b * HW + p) * ld + c]);
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;           // over B*C*HW (< 2^32)
+    if (i >= (unsigned)B * C * HW) return;
+    const unsigned p = i % HW;
+    const unsigned bc = i / HW;
+    const unsigned b = bc / C, c = bc - b * C;
+    out[i] = to_f(in[((size_t)b * HW + p) * ld + c]);
 }
 
 struct repack_params {
@@ -697,9 +760,14 @@ int sv_bn_bwd_apply(int dtype, int64_t M, int C, int ld, const void* x, const fl
                    "sv_bn_bwd_apply: branch %d incomplete", k);
     }
     const int grid = nblocks(M * (C / 8), 256);
-    const size_t lds = (size_t)(2 + 3 * nbranch) * C * sizeof(float);
+    const size_t lds = ((size_t)(2 + 3 * nbranch) * C + (size_t)nbranch * 2 * 256) * sizeof(float);
     SV_REQUIRE(lds <= 64 * 1024, SV_E_SHAPE, "sv_bn_bwd_apply: C=%d too large", C);
-    DISPATCH_T(dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(grid), dim3(256), lds, (hipStream_t)stream, p));
+    const int cv = C / 8;
+    if (256 % cv == 0 && (int64_t)grid * 256 >= cv) {     // every thread keeps one 8-channel group: coefficients in registers
+        DISPATCH_T(dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<T, true>), dim3(grid), dim3(256), lds, (hipStream_t)stream, p));
+    } else {
+        DISPATCH_T(dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<T, false>), dim3(grid), dim3(256), lds, (hipStream_t)stream, p));
+    }
     return sv_check_launch("sv_bn_bwd_apply");
 }
 

@@ -221,11 +221,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const sv_geom g, const wg_pa
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
 
-    // ---- combine the four waves, then one global atomic per element ------------------------------
+    // ---- combine the four waves (plain LDS stores + a summing pass: LDS float atomics are far too slow),
+    //      then one global atomic per element -----------------------------------------------------------
     __syncthreads();
-    float* red = reinterpret_cast<float*>(smem);   // [BNw][BCw]
-    for (int i = tid; i < BNw * BCw; i += 256) red[i] = 0.f;
-    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);   // [4 waves][BNw][BCw]
     const int fr = lane & 15, fq = lane >> 4;
 #pragma unroll
     for (int i = 0; i < TN; ++i)
@@ -233,12 +232,13 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const sv_geom g, const wg_pa
         for (int j = 0; j < TC; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                atomicAdd(&red[(16 * i + 4 * fq + r) * BCw + 16 * j + fr], acc[i][j][r]);
+                red[wave * BNw * BCw + (16 * i + 4 * fq + r) * BCw + 16 * j + fr] = acc[i][j][r];
     __syncthreads();
     for (int i = tid; i < BNw * BCw; i += 256) {
         const int n = n0 + i / BCw, c = c0 + i % BCw;
+        const float v = red[i] + red[BNw * BCw + i] + red[2 * BNw * BCw + i] + red[3 * BNw * BCw + i];
         if (n < g.N && c < g.Cin)
-            atomicAdd(p.dw + ((int64_t)n * g.T_orig + torig) * g.Cin + c, red[i]);
+            atomicAdd(p.dw + ((int64_t)n * g.T_orig + torig) * g.Cin + c, v);
     }
 }
 
@@ -256,7 +256,7 @@ int launch2(const sv_geom* g, const wg_params& p, hipStream_t s) {
     const int tiles = nNt * p.ntap_total * nCt;
     const int grid = p.splits * tiles;
     size_t lds = (size_t)4 * RW * (BNw + 8 + BCw + 8) * sizeof(T);
-    const size_t red = (size_t)BNw * BCw * sizeof(float);
+    const size_t red = (size_t)4 * BNw * BCw * sizeof(float);
     if (red > lds) lds = red;
     sv_prof_begin(s);
     hipLaunchKernelGGL((wgrad_kernel<T, TN, TC, USE_TR, FAST>), dim3(grid), dim3(256), lds, s, *g, p);
