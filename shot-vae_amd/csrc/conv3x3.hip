@@ -12,6 +12,10 @@
 #include "common.h"
 #include "epilogue.h"
 
+#ifndef SV_C3P_WAVES
+#define SV_C3P_WAVES 2          // waves per SIMD the persistent kernel is compiled for (3 => spills, measured slower)
+#endif
+
 namespace {
 
 constexpr int CK = 32;          // channel chunk = one MFMA k step
@@ -175,7 +179,7 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const sv_geom g, const sv_
 // residual / raw tensor needed by tile i's epilogue are already in flight -- and the BatchNorm sums are
 // kept in registers across tiles and flushed once per block (one shuffle tree, one atomic per channel).
 template <typename T, int WLOG, int CCH>      // CCH = Cin / 32
-__global__ __launch_bounds__(256) void conv3x3p_kernel(const sv_geom g, const sv_igemm_args a, int tiles_per) {
+__global__ __launch_bounds__(256, SV_C3P_WAVES) void conv3x3p_kernel(const sv_geom g, const sv_igemm_args a, int tiles_per) {
     typedef typename V8<T>::type V;
     typedef typename V4<T>::type Q;
     constexpr int NT = 2, BN = 32;
@@ -260,31 +264,33 @@ __global__ __launch_bounds__(256) void conv3x3p_kernel(const sv_geom g, const sv
         pt0 = *reinterpret_cast<const f32x4*>(a.pro_shift + hc[0]);
         pt1 = *reinterpret_cast<const f32x4*>(a.pro_shift + hc[0] + 4);
     }
-    V hv[HI];
-    bool hok[HI];
-    auto load_halo = [&](int tile) {
+    // two register stages: the halo of tile i+2 is requested while tile i is on the MFMAs, so every halo has
+    // two full tile periods to arrive (at 2 blocks per CU one tile period does not cover the memory latency)
+    struct HStage { V hv[HI]; bool hok[HI]; };
+    HStage HA, HB;
+    auto load_halo = [&](HStage& S, int tile) {
         const int gr0 = tile * TR;
         const bool top_ok = (gr0 & (H - 1)) != 0, bot_ok = ((gr0 + TR) & (H - 1)) != 0;
 #pragma unroll
         for (int i = 0; i < HI; ++i) {
-            hok[i] = hkind[i] == 1 || (hkind[i] == 2 && top_ok) || (hkind[i] == 3 && bot_ok);
+            S.hok[i] = hkind[i] == 1 || (hkind[i] == 2 && top_ok) || (hkind[i] == 3 && bot_ok);
             const int grc = min(max(gr0 + hrel[i], 0), BH - 1);
-            hv[i] = *reinterpret_cast<const V*>(X + ((int64_t)grc * W + hxc[i]) * g.ldx + hc[i]);
+            S.hv[i] = *reinterpret_cast<const V*>(X + ((int64_t)grc * W + hxc[i]) * g.ldx + hc[i]);
         }
     };
-    auto store_halo = [&]() {
+    auto store_halo = [&](HStage& S) {
 #pragma unroll
         for (int i = 0; i < HI; ++i) {
-            V o = hv[i];
+            V o = S.hv[i];
             if (has_pro) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const float u0 = to_f(hv[i][j]) * ps0[j] + pt0[j], u1 = to_f(hv[i][j + 4]) * ps1[j] + pt1[j];
+                    const float u0 = to_f(S.hv[i][j]) * ps0[j] + pt0[j], u1 = to_f(S.hv[i][j + 4]) * ps1[j] + pt1[j];
                     o[j] = (T)fmaxf(u0, u0 * a.pro_slope);          // LeakyReLU / ReLU for slope in [0,1]
                     o[j + 4] = (T)fmaxf(u1, u1 * a.pro_slope);
                 }
             }
-            *reinterpret_cast<V*>(halo + hlds[i]) = hok[i] ? o : zero;
+            *reinterpret_cast<V*>(halo + hlds[i]) = S.hok[i] ? o : zero;
         }
     };
 
@@ -315,14 +321,16 @@ __global__ __launch_bounds__(256) void conv3x3p_kernel(const sv_geom g, const sv
 #pragma unroll
         for (int r = 0; r < 4; ++r) s1[i][r] = s2[i][r] = 0.f;
 
-    load_halo(t_begin);
-    store_halo();
+    load_halo(HA, t_begin);
+    if (t_begin + 1 < t_end) load_halo(HB, t_begin + 1);
+    store_halo(HA);
     __syncthreads();
-    for (int tile = t_begin; tile < t_end; ++tile) {
+    // one tile of the pipeline; NEXT holds tile+1 (already requested), FREE receives the request for tile+2
+    auto do_tile = [&](int tile, HStage& NEXT, HStage& FREE) {
         const int gr0 = tile * TR;
-        // ---- issue next tile's halo + this tile's epilogue operands; they fly during the MFMAs ---------
+        // ---- request the halo two tiles ahead + this tile's epilogue operands; they fly during the MFMAs ----
         const bool more = tile + 1 < t_end;
-        if (more) load_halo(tile + 1);
+        if (tile + 2 < t_end) load_halo(FREE, tile + 2);
         int64_t obase[2];
         Q eop[NT][2];
 #pragma unroll
@@ -357,7 +365,7 @@ __global__ __launch_bounds__(256) void conv3x3p_kernel(const sv_geom g, const sv
             }
         }
         __syncthreads();                               // all waves are done reading this tile's halo
-        if (more) store_halo();                        // next tile's halo -> LDS (waits for its loads)
+        if (more) store_halo(NEXT);                    // next tile's halo -> LDS (requested a whole tile ago)
         // ---- epilogue of this tile (operands already in registers) -----------------------------------------
 #pragma unroll
         for (int i = 0; i < NT; ++i) {
@@ -394,6 +402,10 @@ __global__ __launch_bounds__(256) void conv3x3p_kernel(const sv_geom g, const sv
             }
         }
         __syncthreads();                               // next halo visible
+    };
+    for (int tile = t_begin; tile < t_end; tile += 2) {
+        do_tile(tile, HB, HA);
+        if (tile + 1 < t_end) do_tile(tile + 1, HA, HB);
     }
     // ---- flush the per-channel sums once per block ---------------------------------------------------------
     if (want_sums) {
