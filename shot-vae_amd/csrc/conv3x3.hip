@@ -433,6 +433,294 @@ __global__ __launch_bounds__(256, SV_C3P_WAVES) void conv3x3p_kernel(const sv_ge
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------
+// Wide layers (Cin >= 96: WRN-28-10 body, MFMA-bound): a block owns PT consecutive 128-pixel tiles x 16*NT
+// output channels with ALL accumulators in registers, and walks the input channels in 32-wide chunks.  The
+// [BN][9][32] weight chunk -- by far the largest staging item -- is staged ONCE per chunk and reused by the PT
+// pixel tiles (the 128-pixel kernel restaged it for every tile); the halo tiles alternate between two LDS
+// buffers and are register-prefetched one step ahead, the next weight chunk a whole chunk ahead.
+template <typename T, int NT, int WLOG, int PT>
+__global__ __launch_bounds__(256) void conv3x3m_kernel(const sv_geom g, const sv_igemm_args a) {
+    typedef typename V8<T>::type V;
+    typedef typename V4<T>::type Q;
+    static_assert(PT == 2 || PT == 4, "");
+    constexpr int BN = 16 * NT;
+    constexpr int W = 1 << WLOG, TR = 128 / W, WP = W + 2;
+    constexpr int LDW = CK + 16, VPP = CK / 8;
+    constexpr int HH = (TR < W) ? TR : W, SEG = TR / HH, LROWS = TR + SEG + 1;
+    constexpr int HV = LROWS * WP * VPP, HI = (HV + 255) / 256, HPIX = (HI * 256 + VPP - 1) / VPP;
+    constexpr int WV = BN * 9 * VPP, WI = (WV + 255) / 256, WROWS = (WI * 256 + VPP - 1) / VPP;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* halo = reinterpret_cast<T*>(smem);                    // [2][HPIX][LDW]
+    T* wl = halo + 2 * HPIX * LDW;                           // [WROWS][LDW]
+    float* ssum = reinterpret_cast<float*>(wl + WROWS * LDW);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int H = g.Hin, BH = g.B * H, nT = BH / TR, nG = nT / PT;      // tile groups
+    const int nNt = g.N / BN;
+    const int L = blockIdx.x;
+    int in_i, grp;
+    if (nG >= 64) {                                   // XCD-affine: channel tiles of one pixel group share an L2
+        const int xcd = L & 7, slot = L >> 3;
+        in_i = slot % nNt;
+        grp = (slot / nNt) * 8 + xcd;
+        if (grp >= nG) return;
+    } else {
+        in_i = L % nNt;
+        grp = L / nNt;
+    }
+    const int n0 = in_i * BN;
+    const int t0 = grp * PT;
+    const sv_phase& P = g.phase[0];
+    const uint64_t pdy = pack_taps(P.dy), pdx = pack_taps(P.dx);
+    const T* __restrict__ X = reinterpret_cast<const T*>(a.x);
+    const T* __restrict__ Wp = reinterpret_cast<const T*>(a.w) + P.w_off + (int64_t)n0 * 9 * g.Cin;
+    T* __restrict__ O = reinterpret_cast<T*>(a.out);
+    const T* __restrict__ R = reinterpret_cast<const T*>(a.residual);
+    const T* __restrict__ EX = reinterpret_cast<const T*>(a.ex);
+    const bool has_pro = a.pro_scale != nullptr;
+    const bool want_sums = (a.stats != nullptr) || (EX != nullptr);
+
+    if (tid < 2 * BN) ssum[tid] = 0.f;
+    V zero;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) zero[j] = (T)0.f;
+
+    // ---- staging slots (tile / chunk independent parts) ------------------------------------------------
+    const int v8 = 8 * (tid & 3);
+    int hrel[HI], hxc[HI], hlds[HI], hkind[HI];
+#pragma unroll
+    for (int i = 0; i < HI; ++i) {
+        const int idx = tid + 256 * i;
+        const int pix = idx / VPP;
+        hlds[i] = pix * LDW + v8;
+        const int lr = pix / WP, xx = pix - lr * WP;
+        const int seg = lr / (HH + 1), off = lr - seg * (HH + 1);
+        int kind = 1, rel = lr - 1 - seg;
+        if (off == 0) {
+            if (SEG == 1) { kind = seg == 0 ? 2 : 3; rel = seg == 0 ? -1 : TR; }
+            else kind = 0;
+        }
+        if (idx >= HV || xx == 0 || xx == WP - 1) kind = 0;
+        hkind[i] = kind;
+        hrel[i] = rel;
+        hxc[i] = min(max(xx - 1, 0), W - 1);
+    }
+    V hv[HI], wv[WI];
+    bool hok[HI];
+    f32x4 ps0, ps1, pt0, pt1;                                 // BN scale / shift of the halo in flight
+    auto load_halo = [&](int tile, int c0) {
+        const int gr0 = tile * TR;
+        const bool top_ok = (gr0 & (H - 1)) != 0, bot_ok = ((gr0 + TR) & (H - 1)) != 0;
+#pragma unroll
+        for (int i = 0; i < HI; ++i) {
+            hok[i] = hkind[i] == 1 || (hkind[i] == 2 && top_ok) || (hkind[i] == 3 && bot_ok);
+            const int grc = min(max(gr0 + hrel[i], 0), BH - 1);
+            hv[i] = *reinterpret_cast<const V*>(X + ((int64_t)grc * W + hxc[i]) * g.ldx + c0 + v8);
+        }
+        if (has_pro) {
+            ps0 = *reinterpret_cast<const f32x4*>(a.pro_scale + c0 + v8);
+            ps1 = *reinterpret_cast<const f32x4*>(a.pro_scale + c0 + v8 + 4);
+            pt0 = *reinterpret_cast<const f32x4*>(a.pro_shift + c0 + v8);
+            pt1 = *reinterpret_cast<const f32x4*>(a.pro_shift + c0 + v8 + 4);
+        }
+    };
+    auto store_halo = [&](int buf) {
+        T* hb = halo + buf * HPIX * LDW;
+#pragma unroll
+        for (int i = 0; i < HI; ++i) {
+            V o = hv[i];
+            if (has_pro) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float u0 = to_f(hv[i][j]) * ps0[j] + pt0[j], u1 = to_f(hv[i][j + 4]) * ps1[j] + pt1[j];
+                    o[j] = (T)fmaxf(u0, u0 * a.pro_slope);
+                    o[j + 4] = (T)fmaxf(u1, u1 * a.pro_slope);
+                }
+            }
+            *reinterpret_cast<V*>(hb + hlds[i]) = hok[i] ? o : zero;
+        }
+    };
+    auto load_w = [&](int c0) {
+#pragma unroll
+        for (int i = 0; i < WI; ++i) {
+            const int row = min((tid + 256 * i) >> 2, BN * 9 - 1);
+            wv[i] = *reinterpret_cast<const V*>(Wp + (int64_t)row * g.Cin + c0 + v8);
+        }
+    };
+    auto store_w = [&]() {
+#pragma unroll
+        for (int i = 0; i < WI; ++i) *reinterpret_cast<V*>(wl + ((tid + 256 * i) >> 2) * LDW + v8) = wv[i];
+    };
+
+    int hbase[2], prow[2], pcol[2];
+#pragma unroll
+    for (int ms = 0; ms < 2; ++ms) {
+        const int p = 32 * wave + 16 * ms + fr;
+        prow[ms] = p >> WLOG;
+        pcol[ms] = p & (W - 1);
+        hbase[ms] = ((prow[ms] + 1 + prow[ms] / HH) * WP + pcol[ms] + 1) * LDW + 8 * fq;
+    }
+    f32x4 acc[PT][NT][2];
+#pragma unroll
+    for (int q = 0; q < PT; ++q)
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[q][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nck = g.Cin / CK;
+    load_w(0);
+    load_halo(t0, 0);
+    store_w();
+    store_halo(0);
+    __syncthreads();
+    for (int ck = 0; ck < nck; ++ck) {
+        const bool more_ck = ck + 1 < nck;
+        if (more_ck) load_w((ck + 1) * CK);                 // lands while this chunk's PT tiles are on the MFMAs
+#pragma unroll
+        for (int q = 0; q < PT; ++q) {
+            const bool last = q == PT - 1;
+            const bool more = !last || more_ck;
+            if (more) load_halo(last ? t0 : t0 + q + 1, last ? (ck + 1) * CK : ck * CK);
+            const T* hb = halo + (q & 1) * HPIX * LDW;       // PT is even: step parity == q parity
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int sh = (tap_off(pdy, t) * WP + tap_off(pdx, t)) * LDW;
+                const V af0 = *reinterpret_cast<const V*>(hb + hbase[0] + sh);
+                const V af1 = *reinterpret_cast<const V*>(hb + hbase[1] + sh);
+#pragma unroll
+                for (int i = 0; i < NT; ++i) {
+                    const V wf = *reinterpret_cast<const V*>(wl + ((16 * i + fr) * 9 + t) * LDW + 8 * fq);
+                    mma32(acc[q][i][0], wf, af0);
+                    mma32(acc[q][i][1], wf, af1);
+                }
+            }
+            if (last && more_ck) {
+                __syncthreads();                              // every wave is done with this chunk's weights
+                store_w();
+            }
+            if (more) store_halo((q + 1) & 1);                // that buffer was last read one step ago (barrier since)
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue: PT tiles, BatchNorm sums kept in registers and flushed once ----------------------------------
+    float s1[NT][4], s2[NT][4];
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s1[i][r] = s2[i][r] = 0.f;
+#pragma unroll
+    for (int q = 0; q < PT; ++q) {
+        const int gr0 = (t0 + q) * TR;
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            const int n = n0 + 16 * i + 4 * fq;
+            f32x4 bias = {0.f, 0.f, 0.f, 0.f};
+            if (a.bias) bias = *reinterpret_cast<const f32x4*>(a.bias + n);
+            f32x4 esc, esh, emu, ers;
+            if (EX) {
+                esc = *reinterpret_cast<const f32x4*>(a.ex_scale + n);
+                esh = *reinterpret_cast<const f32x4*>(a.ex_shift + n);
+                emu = *reinterpret_cast<const f32x4*>(a.ex_mean + n);
+                ers = *reinterpret_cast<const f32x4*>(a.ex_rstd + n);
+            }
+#pragma unroll
+            for (int ms = 0; ms < 2; ++ms) {
+                const int64_t ob = ((int64_t)(gr0 + prow[ms]) * W + pcol[ms]) * g.ldo + n;
+                f32x4 vv = acc[q][i][ms];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) vv[r] += bias[r];
+                if (R) {
+                    const Q rr = *reinterpret_cast<const Q*>(R + ob);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) vv[r] += to_f(rr[r]);
+                }
+                if (EX) {
+                    const Q xe = *reinterpret_cast<const Q*>(EX + ob);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float xf = to_f(xe[r]);
+                        const float gv = vv[r] * act_grad(xf * esc[r] + esh[r], a.ex_slope);
+                        vv[r] = gv;
+                        s1[i][r] += gv;
+                        s2[i][r] += gv * ((xf - emu[r]) * ers[r]);
+                    }
+                } else if (a.stats) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        s1[i][r] += vv[r];
+                        s2[i][r] += vv[r] * vv[r];
+                    }
+                }
+                Q o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = (T)vv[r];
+                *reinterpret_cast<Q*>(O + ob) = o;
+            }
+        }
+    }
+    if (want_sums) {
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) {
+                    s1[i][r] += __shfl_xor(s1[i][r], o);
+                    s2[i][r] += __shfl_xor(s2[i][r], o);
+                }
+                if (fr == 0) {
+                    atomicAdd(&ssum[16 * i + 4 * fq + r], s1[i][r]);
+                    atomicAdd(&ssum[BN + 16 * i + 4 * fq + r], s2[i][r]);
+                }
+            }
+        }
+        __syncthreads();
+        float* dst = (EX ? a.bsums : a.stats) + (size_t)(blockIdx.x & (a.replicas - 1)) * 2 * g.N;
+        if (tid < 2 * BN) {
+            const int which = tid / BN, nl = tid - which * BN;
+            atomicAdd(dst + which * g.N + n0 + nl, ssum[tid]);
+        }
+    }
+}
+
+template <typename T, int NT, int WLOG, int PT>
+int launch_m(const sv_geom* g, const sv_igemm_args* a, hipStream_t s) {
+    constexpr int W = 1 << WLOG, TR = 128 / W, BN = 16 * NT, LDW = CK + 16, VPP = CK / 8;
+    constexpr int HH = (TR < W) ? TR : W, SEG = TR / HH, LROWS = TR + SEG + 1;
+    constexpr int HV = LROWS * (W + 2) * VPP, HI = (HV + 255) / 256, HPIX = (HI * 256 + VPP - 1) / VPP;
+    constexpr int WV = BN * 9 * VPP, WI = (WV + 255) / 256, WROWS = (WI * 256 + VPP - 1) / VPP;
+    const int nG = g->B * g->Hin / TR / PT;
+    const int nNt = g->N / BN;
+    const int grid = (nG >= 64 ? ((nG + 7) / 8) * 8 : nG) * nNt;
+    const size_t lds = (size_t)(2 * HPIX + WROWS) * LDW * sizeof(T) + 2 * BN * sizeof(float);
+    static bool optin = false;
+    if (lds > 64 * 1024 && !optin) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3m_kernel<T, NT, WLOG, PT>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return sv_check_launch("hipFuncSetAttribute(conv3x3m)");
+        optin = true;
+    }
+    sv_prof_begin(s);
+    hipLaunchKernelGGL((conv3x3m_kernel<T, NT, WLOG, PT>), dim3(grid), dim3(256), lds, s, *g, *a);
+    sv_prof_end(s);
+    return sv_check_launch("sv_igemm(conv3x3m)");
+}
+
+template <typename T, int NT, int PT>
+int launch_mw(const sv_geom* g, const sv_igemm_args* a, hipStream_t s) {
+    switch (g->Win) {
+        case 32: return launch_m<T, NT, 5, PT>(g, a, s);
+        case 16: return launch_m<T, NT, 4, PT>(g, a, s);
+        default: return launch_m<T, NT, 3, PT>(g, a, s);
+    }
+}
+
 template <typename T, int WLOG, int CCH>
 int launch_p(const sv_geom* g, const sv_igemm_args* a, hipStream_t s) {
     constexpr int W = 1 << WLOG, TR = 128 / W, CIN = 32 * CCH, LDW = CIN + 16, VPP = CIN / 8;
@@ -519,6 +807,17 @@ int sv_conv3x3_try(const sv_geom* g, int dtype, const sv_igemm_args* a, hipStrea
     if (!no_persist && dtype == SV_F32 && g->Cin == 32) {
         *rc = launch_pw<float, 1>(g, a, s);
         return 1;
+    }
+    static const bool no_multi = getenv("SV_NO_CONV3X3M") != nullptr;
+    if (!no_multi && dtype == SV_BF16 && g->Cin >= 96) {
+        // MFMA-bound wide layers: multi-tile kernel when the grid still fills the chip
+        // (measured at B=512: 160 ch 707 vs 796 us; the 64-channel-tile variant <4,4> lost to the 128-pixel kernel
+        //  on 320 / 640 channels -- 447 vs 418 us, 469 vs 356 us -- and is not dispatched)
+        const int nT = g->B * g->Hin / TR;
+        if (g->N % 80 == 0 && nT % 2 == 0 && (int64_t)(nT / 2) * (g->N / 80) >= 256) {
+            *rc = launch_mw<bf16, 5, 2>(g, a, s);
+            return 1;
+        }
     }
     if (dtype == SV_BF16) {
         // 64-channel tiles keep two blocks per CU resident (LDS); wider layers take several tiles

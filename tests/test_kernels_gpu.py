@@ -175,6 +175,14 @@ def test_conv_dgrad_with_activation_backward(dt, case):
     assert rel(sums[Cin:], (gref * xh).sum((0, 2, 3))) < max(tol, 1e-3) * 3
 
 
+@pytest.mark.parametrize("case", [(32, 160, 160, 32, 3, 1, 1), (64, 160, 160, 16, 3, 1, 1)])
+def test_conv3x3_wide_multitile(case):
+    """Shapes large enough to take the multi-tile MFMA-bound kernel (conv3x3m): forward with every fusion and
+    the data gradient with the activation-backward epilogue."""
+    test_conv_forward_fused("bf16", case)
+    test_conv_dgrad_with_activation_backward("bf16", case)
+
+
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
 @pytest.mark.parametrize("H,Cin,N,B", [(1, 1024, 512, 6), (2, 512, 256, 4), (8, 128, 64, 3), (16, 64, 16, 2)])
 def test_convT_forward_and_dgrad(dt, H, Cin, N, B):
