@@ -39,6 +39,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--prof-steps", type=int, default=3)
+    ap.add_argument("--overlap", type=int, default=1,
+                    help="1 (default): labelled / unlabelled branches of the step on two HIP streams; 0: one stream")
     return ap.parse_args()
 
 
@@ -96,7 +98,11 @@ def main():
     iu = torch.rand(B, 3, 32, 32, device="cuda", generator=g)
     ll = torch.randint(0, K, (B,), device="cuda", generator=g)
 
+    from shot_vae_amd.train import train_step_overlapped
+
     def step():
+        if a.overlap:
+            return train_step_overlapped(model, elbo, cls, opt, il, ll, iu, sch, distributed=world > 1)
         return S.train_step(model, elbo, cls, opt, il, ll, iu, sch, distributed=world > 1)
 
     def sync():
@@ -125,6 +131,7 @@ def main():
            "config": {"workload": "SHOT-VAE train step (4 fwd + 2 bwd + SGD) %s K=%d ldc=128, B_l=B_u=%d per GPU, "
                                   "synthetic 3x32x32 in HBM, random init" % (a.net, K, B),
                       "global_batch": 2 * B * world, "parallelism": "dp%d" % world,
+                      "schedule": "two-stream (labelled || unlabelled branch)" if a.overlap else "single stream",
                       "collective": "1 RCCL all-reduce of the flat fp32 gradient buffer per step" if world > 1 else "none"},
            "loss_sup": round(float(ls), 5), "loss_unsup": round(float(lu), 5)}
 

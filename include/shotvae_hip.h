@@ -98,6 +98,13 @@ int sv_colsum(int dtype, const void* y, int64_t M, int N, int ld, float* out, vo
 int sv_bn_finalize(const float* stats, int replicas, int C, float count, const float* gamma, const float* beta,
                    float eps, float momentum, float* running_mean, float* running_var,
                    float* scale, float* shift, float* mean, float* rstd, void* stream);
+/* Deferred running-statistics update of all nbn BatchNorms of ONE forward from the (mean, rstd) that
+ * sv_bn_finalize saved (called with running_mean = NULL): table[bn] = {offset of the BN's
+ * [scale|shift|mean|rstd] block (each `align`-padded) in bnbuf, running_mean offset, running_var offset
+ * (both into bufs), C}; counts[bn] = samples per channel.  Lets the four forwards of a step run on several
+ * streams while the momentum updates are still applied in the reference's order (1)(2)(3)(4).           */
+int sv_bn_running_update(const int32_t* table, const float* counts, int nbn, const float* bnbuf, float* bufs,
+                         float eps, float momentum, int align, void* stream);
 /* eval-mode affine from running statistics (main_shot_vae.py:409-510 path)                         */
 int sv_bn_eval_affine(int C, const float* gamma, const float* beta, const float* running_mean,
                       const float* running_var, float eps, float* scale, float* shift, void* stream);

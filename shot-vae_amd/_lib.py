@@ -48,6 +48,7 @@ _PROTOS = {
     "sv_colsum": [I, P, I64, I, I, P, P],
     "sv_bn_finalize": [P, I, I, F, P, P, F, F, P, P, P, P, P, P, P],
     "sv_bn_eval_affine": [I, P, P, P, P, F, P, P, P],
+    "sv_bn_running_update": [P, P, I, P, P, F, F, I, P],
     "sv_bn_bwd_apply": [I, I64, I, I, P, P, P, F, C.POINTER(SvBnBranch), I, P, P, P],
     "sv_pool_fwd": [I, P, P, P, F, I, I, I, I, P, P],
     "sv_pool_bwd": [I, P, P, P, F, P, P, P, I, I, I, I, P, P, P],

@@ -57,6 +57,27 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* stats, in
     }
 }
 
+// Deferred running-statistics update of ALL BatchNorms of one forward (block = one BN).  Used when the
+// forwards of a step are issued on several streams: every forward keeps its batch (mean, rstd) and the four
+// momentum updates are applied afterwards in the reference's order (1)(2)(3)(4), race free.
+// table[bn] = {offset of the BN's (scale,shift,mean,rstd) block in bnbuf, running_mean offset, running_var offset, C}
+__global__ __launch_bounds__(256) void bn_running_update_kernel(const int32_t* table, const float* counts,
+                                                                const float* bnbuf, float* bufs, float eps,
+                                                                float momentum, int align) {
+    const int bn = blockIdx.x;
+    const int boff = table[4 * bn], rmo = table[4 * bn + 1], rvo = table[4 * bn + 2], C = table[4 * bn + 3];
+    const int ca = (C + align - 1) / align * align;
+    const float n = counts[bn];
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const float mu = bnbuf[boff + 2 * ca + c], rs = bnbuf[boff + 3 * ca + c];
+        float var = 1.f / (rs * rs) - eps;
+        var = var > 0.f ? var : 0.f;
+        const float unb = n > 1.f ? var * n / (n - 1.f) : var;
+        bufs[rmo + c] = (1.f - momentum) * bufs[rmo + c] + momentum * mu;
+        bufs[rvo + c] = (1.f - momentum) * bufs[rvo + c] + momentum * unb;
+    }
+}
+
 __global__ void bn_eval_affine_kernel(int C, const float* gamma, const float* beta, const float* rm,
                                       const float* rv, float eps, float* scale, float* shift) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -125,9 +146,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bnb_params p) {
                     cb[c] = p.br[k].gamma[c] * rs;
                     cb[p.C + c] = s1 * p.inv_count;
                     cb[2 * p.C + c] = s2 * p.inv_count;
-                    if (blockIdx.x == 0) {
-                        if (p.br[k].dbeta) p.br[k].dbeta[c] += s1;
-                        if (p.br[k].dgamma) p.br[k].dgamma[c] += s2;
+                    if (blockIdx.x == 0) {      // atomics: another stream's backward may add to the same slots
+                        if (p.br[k].dbeta) atomicAdd(p.br[k].dbeta + c, s1);
+                        if (p.br[k].dgamma) atomicAdd(p.br[k].dgamma + c, s2);
                     }
                 }
             }
@@ -736,6 +757,14 @@ int sv_bn_finalize(const float* stats, int replicas, int C, float count, const f
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 7) / 8), dim3(256), 0, (hipStream_t)stream, stats, replicas, C,
                        count, gamma, beta, eps, momentum, rm, rv, scale, shift, mean, rstd);
     return sv_check_launch("sv_bn_finalize");
+}
+
+int sv_bn_running_update(const int32_t* table, const float* counts, int nbn, const float* bnbuf, float* bufs,
+                         float eps, float momentum, int align, void* stream) {
+    SV_REQUIRE(table && counts && bnbuf && bufs && nbn > 0 && align > 0, SV_E_ARG, "sv_bn_running_update: bad args");
+    hipLaunchKernelGGL(bn_running_update_kernel, dim3(nbn), dim3(256), 0, (hipStream_t)stream, table, counts, bnbuf,
+                       bufs, eps, momentum, align);
+    return sv_check_launch("sv_bn_running_update");
 }
 
 int sv_bn_eval_affine(int C, const float* gamma, const float* beta, const float* rm, const float* rv, float eps,

@@ -224,15 +224,9 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* ws, int s
         const f32x4 v = *reinterpret_cast<const f32x4*>(ws + (int64_t)k * n + i);
         s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
     }
-    if (groups == 1) {
-        f32x4* d = reinterpret_cast<f32x4*>(dw + i);
-        f32x4 o = *d;
-        o[0] += s[0]; o[1] += s[1]; o[2] += s[2]; o[3] += s[3];
-        *d = o;
-    } else {
+    // always atomic: the backward of the other branch of the step may be adding to dw concurrently
 #pragma unroll
-        for (int r = 0; r < 4; ++r) atomicAdd(dw + i + r, s[r]);
-    }
+    for (int r = 0; r < 4; ++r) atomicAdd(dw + i + r, s[r]);
 }
 
 template <typename T, int WLOG>

@@ -265,6 +265,9 @@ class Engine:
         self.use_tr = 1
         self.prof_tags = None
         self.prof_cost = {}
+        self.defer_slot = None        # k: this forward's running-stat update is deferred into slot k (apply_pending)
+        self._pending = {}
+        self._run_tables = {}
         self.version_probe = None     # callable: summed version counters of the nn.Parameters (set by the module)
         for b in p.bns:
             self.bufs[b.rv_off: b.rv_off + b.C] = 1.0
@@ -393,9 +396,14 @@ class Engine:
     _ws_elems = 16 * 1024 * 1024       # 64 MiB of fp32 partial-slab workspace for sv_wgrad
 
     def _wg_ws(self):
-        ws = getattr(self, "_ws", None)
-        if ws is None or ws.device != self.param.device:
-            ws = self._ws = torch.empty(self._ws_elems, dtype=torch.float32, device=self.param.device)
+        """wgrad partial-slab workspace, one per stream (two backwards may run concurrently)."""
+        pool = getattr(self, "_ws", None)
+        if pool is None:
+            pool = self._ws = {}
+        key = (torch.cuda.current_stream().cuda_stream, self.param.device)
+        ws = pool.get(key)
+        if ws is None:
+            ws = pool[key] = torch.empty(self._ws_elems, dtype=torch.float32, device=self.param.device)
         return ws
 
     def _wgrad(self, g, x, pro, dy, dw_ptr, tag=None):
@@ -451,9 +459,11 @@ class Engine:
         def finalize(b, stat_name, count):
             sc, sh, mn, rs = bn_ptrs(b)
             if training:
+                defer = self.defer_slot is not None
                 L.call("sv_bn_finalize", _vp(sbase + 4 * stat_off[stat_name]), stat_rep[stat_name], b.C, float(count),
                        _vp(pbase + 4 * b.gamma_off), _vp(pbase + 4 * b.beta_off), BN_EPS, BN_MOMENTUM,
-                       _vp(bbase + 4 * b.rm_off), _vp(bbase + 4 * b.rv_off), _vp(sc), _vp(sh), _vp(mn), _vp(rs), st)
+                       None if defer else _vp(bbase + 4 * b.rm_off), None if defer else _vp(bbase + 4 * b.rv_off),
+                       _vp(sc), _vp(sh), _vp(mn), _vp(rs), st)
             else:
                 L.call("sv_bn_eval_affine", b.C, _vp(pbase + 4 * b.gamma_off), _vp(pbase + 4 * b.beta_off),
                        _vp(bbase + 4 * b.rm_off), _vp(bbase + 4 * b.rv_off), BN_EPS, _vp(sc), _vp(sh), st)
@@ -539,13 +549,45 @@ class Engine:
         L.call("sv_nhwc_to_nchw", self.code, _vp(f.h[5].data_ptr()), B, p.in_ch, p.img, p.img, p.dec_convs[5].N,
                _vp(rec.data_ptr()), st)
         if training:
-            self.nbt += 1
+            if self.defer_slot is not None:
+                self._pending[self.defer_slot] = (bnbuf, B)      # running stats + counter applied by apply_pending()
+            else:
+                self.nbt += 1
         if not keep:
             return rec, mu, ls, la, None
         f.prot, f.feat, f.mu, f.ls, f.la = prot, feat, mu, ls, la
         f.eps, f.csoft, f.latent = eps, csoft, latent
         f.keep = (label, label_mix, u, stats)
         return rec, mu, ls, la, f
+
+    def _bn_counts(self, B):
+        """samples per channel of every BatchNorm (in plan order) for batch size B"""
+        cnt = {b.index: float(rows) for b, rows in self._bn_rows(B)}
+        cnt[self.plan.bn_t.index] = float(B * self.plan.hfeat * self.plan.hfeat)
+        return [cnt[b.index] for b in self.plan.bns]
+
+    def apply_pending(self):
+        """Apply the deferred running-statistic updates in slot order (= the reference's forward order) on the
+        current stream and advance num_batches_tracked."""
+        p = self.plan
+        dev = self.param.device
+        tab = self._run_tables.get(dev)
+        if tab is None:
+            rows = []
+            for b in p.bns:
+                rows += [b.buf_off, b.rm_off, b.rv_off, b.C]
+            tab = self._run_tables[dev] = torch.tensor(rows, dtype=torch.int32, device=dev)
+        for k in sorted(self._pending):
+            bnbuf, B = self._pending[k]
+            bnbuf.record_stream(torch.cuda.current_stream())      # allocated on a branch stream, read here
+            key = (dev, B)
+            cnt = self._run_tables.get(key)
+            if cnt is None:
+                cnt = self._run_tables[key] = torch.tensor(self._bn_counts(B), dtype=torch.float32, device=dev)
+            L.call("sv_bn_running_update", _vp(tab.data_ptr()), _vp(cnt.data_ptr()), len(p.bns), _vp(bnbuf.data_ptr()),
+                   _vp(self.bufs.data_ptr()), BN_EPS, BN_MOMENTUM, 64, self._stream())
+        self.nbt += len(self._pending)
+        self._pending = {}
 
     def _bn_rows(self, B):
         """(BNSpec, pixels of the tensor it normalises) for every BatchNorm."""

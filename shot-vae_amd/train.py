@@ -27,6 +27,67 @@ def one_hot(label, K):
     return torch.zeros(label.shape[0], K, device=label.device).scatter_(1, label.view(-1, 1), 1)
 
 
+def train_step_overlapped(model, elbo_criterion, cls_criterion, optimizer, image_l, label_l, image_u, sch,
+                          epsilon=0.1, distributed=False):
+    """Same step, the labelled branch ((1),(2), backward) and the unlabelled branch ((3),(4), backward) issued on two
+    HIP streams: they are independent until the optimizer step (both only read the weights and add to the flat
+    gradient buffer with atomics), so the latency-bound small kernels of one branch (decoder, heads, BN
+    finalisation) run beside the other branch's convolutions."""
+    K = model._plan.K
+    cur = torch.cuda.current_stream()
+    st = getattr(model, "_branch_streams", None)
+    if st is None:
+        st = model._branch_streams = (torch.cuda.Stream(), torch.cuda.Stream())
+    eng = model._engine
+    eng.ensure_packs()
+    model._attach_grads()
+    for s in st:
+        s.wait_stream(cur)
+    # BN running statistics: every forward defers its momentum update into its slot; they are applied after the
+    # join in the reference's order (1)(2)(3)(4) (apply_pending), so the result does not depend on stream timing
+    with torch.cuda.stream(st[0]):
+        onehot_l = one_hot(label_l, K)
+        eng.defer_slot = 0
+        rec1, mu1, ls1, la1 = model(image_l, disc_label=label_l)
+    with torch.cuda.stream(st[1]):
+        eng.defer_slot = 2
+        rec3, mu3, ls3, la3 = model(image_u)
+    with torch.cuda.stream(st[0]):
+        recon_l, klc_l, kld_l = elbo_criterion(image_l, rec1, mu1, ls1, la1)
+        elbo_l = recon_l + sch["kl_beta_c"] * torch.abs(klc_l - sch["cmi"]) + sch["kl_beta_d"] * torch.abs(kld_l - sch["dmi"])
+        with torch.no_grad():
+            sm_img, sm_mu, sm_sigma, sm_alpha, sm_label, lam_l = label_smoothing(
+                image_l, mu1, ls1, la1, epsilon=epsilon, disc_label=label_l)
+            sm_onehot = one_hot(sm_label, K)
+        eng.defer_slot = 1
+        rec2, mu2, ls2, la2, *_ = model(sm_img, True, label_l, sm_label, lam_l)
+    with torch.cuda.stream(st[1]):
+        recon_u, klc_u, kld_u = elbo_criterion(image_u, rec3, mu3, ls3, la3)
+        elbo_u = recon_u + sch["kl_beta_c"] * torch.abs(klc_u - sch["cmi"]) + sch["kl_beta_d"] * torch.abs(kld_u - sch["dmi"])
+        with torch.no_grad():
+            mx_img, mx_mu, mx_sigma, mx_alpha, lam_u = mixup_vae_data(image_u, mu3, ls3, la3)
+        eng.defer_slot = 3
+        rec4, mu4, ls4, la4, *_ = model(mx_img)
+    eng.defer_slot = None
+    with torch.cuda.stream(st[0]):
+        disc_post_l = lam_l * cls_criterion(la2, onehot_l) + (1 - lam_l) * cls_criterion(la2, sm_onehot)
+        elbo_l = elbo_l + sch["kl_beta_c"] * sch["pwm"] * continuous_posterior_loss(mu2, ls2, sm_mu, sm_sigma)
+        loss_sup = sch["ew"] * elbo_l + disc_post_l
+        loss_sup.backward()
+    with torch.cuda.stream(st[1]):
+        elbo_u = elbo_u + sch["kl_beta_c"] * sch["pwm"] * continuous_posterior_loss(mu4, ls4, mx_mu, mx_sigma)
+        loss_unsup = sch["ew"] * elbo_u + sch["ucw"] * cls_criterion(la4, mx_alpha)
+        loss_unsup.backward()
+    for s in st:
+        cur.wait_stream(s)
+    eng.apply_pending()
+    if optimizer is not None:
+        scale = dp.all_reduce_gradients(model.flat_parameters()[1]) if distributed else 1.0
+        optimizer.step(scale) if hasattr(optimizer, "_steps") else optimizer.step()
+        optimizer.zero_grad()
+    return loss_sup.detach(), loss_unsup.detach()
+
+
 def train_step(model, elbo_criterion, cls_criterion, optimizer, image_l, label_l, image_u, sch, epsilon=0.1,
                optimal_match=False, distributed=False, return_outputs=False):
     """One step: 4 forwards, 2 backwards, (all-reduce,) SGD.  Inputs are device tensors.

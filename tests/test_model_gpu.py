@@ -188,6 +188,37 @@ def test_torch_optimizer_dropin_and_zero_grad_semantics():
             assert T.rel_err(a[k].cpu().numpy(), b[k].cpu().numpy()) < 1e-4, k
 
 
+def test_overlapped_two_stream_step_equals_sequential():
+    """train_step_overlapped (labelled / unlabelled branches on two HIP streams, deferred BN running-stat updates)
+    must give the same parameters, BN buffers and counters as the sequential step."""
+    from shot_vae_amd.train import train_step_overlapped
+    name, K = "wideresnet-10-1", 10
+    st = C.make_state(name, K=K)
+    m1, m2 = make_model(name, K, "fp32", st), make_model(name, K, "fp32", st)
+    elbo, cls = S.VAECriterion(discrete_dim=K).cuda(), S.ClsCriterion()
+    o1, o2 = S.FlatSGD(m1), S.FlatSGD(m2)
+    o1.zero_grad()
+    o2.zero_grad()
+    sch = O.schedule(10)
+    for s in range(2):
+        il, ll, iu, lu = C.make_batch(4, 6, K, stream0=7000 + 10 * s)
+        nz = C.make_noise(4, 6, K, stream0=9000 + 100 * s)
+        with T.rng_for_step(nz):
+            a = S.train_step(m1, elbo, cls, o1, il.cuda(), ll.cuda(), iu.cuda(), sch)
+        # host-RNG consumption order of the overlapped schedule: (1), (3), smoothing, (2), mixup, (4)
+        with T.scripted_rng(randn=[nz["eps1"], nz["eps3"], nz["eps2"], nz["eps4"]], rand=[nz["u3"], nz["u4"]],
+                            randperm=[nz["perm_l"], nz["perm_u"]], beta=[nz["lam_l"], nz["lam_u"]]):
+            b = train_step_overlapped(m2, elbo, cls, o2, il.cuda(), ll.cuda(), iu.cuda(), sch)
+        torch.cuda.synchronize()
+        assert abs(float(a[0]) - float(b[0])) < 1e-4 * abs(float(a[0])) and abs(float(a[1]) - float(b[1])) < 1e-4
+    sa, sb = m1.state_dict(), m2.state_dict()
+    for k in sa:
+        if sa[k].dtype.is_floating_point:
+            assert T.rel_err(sb[k].cpu().numpy(), sa[k].cpu().numpy()) < 2e-4, k
+        else:
+            assert int(sa[k]) == int(sb[k]) == 8, k
+
+
 def test_full_size_step_properties_bf16():
     """BASELINE config 2 size (WRN-28-2, B_l=B_u=512, bf16): size-independent properties."""
     name, K, B = "wideresnet-28-2", 10, 512
