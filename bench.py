@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--prof-steps", type=int, default=3)
+    ap.add_argument("--graph", type=int, default=1, help="1 (default): replay the step from a captured hipGraph")
     ap.add_argument("--overlap", type=int, default=1,
                     help="1 (default): labelled / unlabelled branches of the step on two HIP streams; 0: one stream")
     return ap.parse_args()
@@ -98,9 +99,20 @@ def main():
     iu = torch.rand(B, 3, 32, 32, device="cuda", generator=g)
     ll = torch.randint(0, K, (B,), device="cuda", generator=g)
 
-    from shot_vae_amd.train import train_step_overlapped
+    from shot_vae_amd.train import GraphedTrainStep, train_step_overlapped
+
+    graphed, graph_note = None, "eager"
+    if a.graph and a.overlap:
+        try:
+            graphed = GraphedTrainStep(model, elbo, cls, opt, il, ll, iu, sch, distributed=world > 1)
+            graph_note = "hipGraph replay"
+        except Exception as e:        # capture unsupported on this stack: run eagerly, say so in the output
+            graphed, graph_note = None, "eager (graph capture failed: %s)" % type(e).__name__
+            torch.cuda.synchronize()
 
     def step():
+        if graphed is not None:
+            return graphed()
         if a.overlap:
             return train_step_overlapped(model, elbo, cls, opt, il, ll, iu, sch, distributed=world > 1)
         return S.train_step(model, elbo, cls, opt, il, ll, iu, sch, distributed=world > 1)
@@ -132,6 +144,7 @@ def main():
                                   "synthetic 3x32x32 in HBM, random init" % (a.net, K, B),
                       "global_batch": 2 * B * world, "parallelism": "dp%d" % world,
                       "schedule": "two-stream (labelled || unlabelled branch)" if a.overlap else "single stream",
+                      "launch": graph_note,
                       "collective": "1 RCCL all-reduce of the flat fp32 gradient buffer per step" if world > 1 else "none"},
            "loss_sup": round(float(ls), 5), "loss_unsup": round(float(lu), 5)}
 
@@ -140,8 +153,8 @@ def main():
         eng = model._engine
         eng.prof_tags, eng.prof_cost = {}, {}
         L.lib().sv_prof_enable(1)
-        for _ in range(a.prof_steps):
-            step()
+        for _ in range(a.prof_steps):       # eager, single stream: HIP events bracket every conv-like launch
+            S.train_step(model, elbo, cls, opt, il, ll, iu, sch, distributed=world > 1)
         ntag = len(eng.prof_tags) + 1
         ms = (ctypes.c_double * ntag)()
         cnt = (ctypes.c_int * ntag)()

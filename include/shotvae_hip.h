@@ -137,8 +137,9 @@ int sv_head_bwd(const float* feat, int B, int C, const float* W, int ldc, int K,
 /* ---- K10/K11 reparameterisation sampler (vae.py:23-86) -------------------------------------------
  * mode 0: gumbel-softmax from u; 1: one-hot(label); 2: lam*onehot(label)+(1-lam)*onehot(label_mix).
  * latent is [B][Lpad] of `dtype` = [z | c | 0-pad]; csoft [B][K] fp32 keeps c for the backward.     */
+/* lam_dev (optional, device scalar) overrides lam: keeps the step capturable into a hipGraph             */
 int sv_sample_fwd(int dtype, const float* mu, const float* ls, const float* la, const float* eps,
-                  const float* u, const int64_t* label, const int64_t* label_mix, float lam, int mode,
+                  const float* u, const int64_t* label, const int64_t* label_mix, float lam, const float* lam_dev, int mode,
                   float temperature, int B, int ldc, int K, int Lpad, void* latent, float* csoft,
                   void* stream);
 /* dmu/dls/dla accumulate (+=) the sampler path of the latent gradient                              */
@@ -169,8 +170,8 @@ int sv_post_bwd(const float* mu, const float* ls, const float* mu_t, const float
 
 /* ---- K17 mixup / label smoothing gather-lerp (lib/utils/mixup.py:22-25,36-39) --------------------
  * out[b] = lam*f(a[b]) + (1-lam)*f(a[index[b]]), f = exp when `exp_space` else identity.           */
-int sv_mix_lerp(const float* a, const int64_t* index, float lam, int B, int64_t row, int exp_space,
-                float* out, void* stream);
+int sv_mix_lerp(const float* a, const int64_t* index, float lam, const float* lam_dev, int B, int64_t row,
+                int exp_space, float* out, void* stream);
 
 /* ---- K18 optimal-match pairing (lib/utils/mixup.py:9-18,93-99): index[i] = argmin_{j!=rank0} ----
  * second-smallest entry of row i of the pairwise Gaussian-KL matrix.                               */

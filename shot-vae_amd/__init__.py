@@ -5,4 +5,5 @@ from .vae import VariationalAutoEncoder          # noqa: F401
 from .criterion import VAECriterion, ClsCriterion, continuous_posterior_loss   # noqa: F401
 from .mixup import mixup_vae_data, label_smoothing, optimal_match_index        # noqa: F401
 from .optim import FlatSGD                        # noqa: F401
-from .train import train_step, train_step_overlapped, schedule, alpha_schedule  # noqa: F401
+from .train import (train_step, train_step_overlapped, GraphedTrainStep, DeviceRng, schedule,   # noqa: F401
+                    alpha_schedule)

@@ -54,7 +54,7 @@ _PROTOS = {
     "sv_pool_bwd": [I, P, P, P, F, P, P, P, I, I, I, I, P, P, P],
     "sv_head_fwd": [P, I, I, P, P, I, I, P, P, P, P],
     "sv_head_bwd": [P, I, I, P, I, I, P, P, P, P, P, P, P, P, P],
-    "sv_sample_fwd": [I, P, P, P, P, P, P, P, F, I, F, I, I, I, I, P, P, P],
+    "sv_sample_fwd": [I, P, P, P, P, P, P, P, F, P, I, F, I, I, I, I, P, P, P],
     "sv_sample_bwd": [I, P, P, P, P, I, F, I, I, I, I, P, P, P, P],
     "sv_elbo_fwd": [P, P, I64, P, P, P, I, I, I, I, F, P, P],
     "sv_elbo_bwd": [P, P, I64, P, P, P, I, I, I, I, F, P, P, P, P, P, P],
@@ -62,7 +62,7 @@ _PROTOS = {
     "sv_cls_bwd": [P, P, I, I, P, P, P],
     "sv_post_fwd": [P, P, P, P, I, I, P, P],
     "sv_post_bwd": [P, P, P, P, I, I, P, P, P, P],
-    "sv_mix_lerp": [P, P, F, I, I64, I, P, P],
+    "sv_mix_lerp": [P, P, F, P, I, I64, I, P, P],
     "sv_optimal_match": [P, P, I, I, P, P],
     "sv_sgd": [P, P, P, I64, F, F, F, F, I, P],
     "sv_nchw_to_nhwc": [I, P, I, I, I, I, I, P, P],

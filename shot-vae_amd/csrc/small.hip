@@ -417,9 +417,11 @@ template <typename T>
 __global__ __launch_bounds__(128) void sample_fwd_kernel(const float* mu, const float* ls, const float* la,
                                                          const float* eps, const float* u,
                                                          const int64_t* label, const int64_t* label_mix,
-                                                         float lam, int mode, float temperature, int B,
+                                                         float lam, const float* lam_dev, int mode,
+                                                         float temperature, int B,
                                                          int ldc, int K, int Lpad, T* latent, float* csoft) {
     const int b = blockIdx.x, tid = threadIdx.x;
+    if (lam_dev) lam = lam_dev[0];
     __shared__ float red[2];
     __shared__ float bc[2];
     T* out = latent + (int64_t)b * Lpad;
@@ -602,8 +604,9 @@ __global__ void post_bwd_kernel(const float* mu, const float* ls, const float* m
 }
 
 // ---------------------------------------------------------------------------------------- mixup
-__global__ void mix_lerp_kernel(const float* a, const int64_t* index, float lam, int B, int64_t row,
-                                int exp_space, float* out) {
+__global__ void mix_lerp_kernel(const float* a, const int64_t* index, float lam, const float* lam_dev, int B,
+                                int64_t row, int exp_space, float* out) {
+    if (lam_dev) lam = lam_dev[0];
     const int b = blockIdx.y;
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= row) return;
@@ -852,14 +855,15 @@ int sv_head_bwd(const float* feat, int B, int C, const float* W, int ldc, int K,
 }
 
 int sv_sample_fwd(int dtype, const float* mu, const float* ls, const float* la, const float* eps, const float* u,
-                  const int64_t* label, const int64_t* label_mix, float lam, int mode, float temperature, int B,
+                  const int64_t* label, const int64_t* label_mix, float lam, const float* lam_dev, int mode,
+                  float temperature, int B,
                   int ldc, int K, int Lpad, void* latent, float* csoft, void* stream) {
     SV_REQUIRE(mu && ls && la && eps && latent && csoft, SV_E_ARG, "sv_sample_fwd: null");
     SV_REQUIRE((mode == 0 && u) || (mode == 1 && label) || (mode == 2 && label && label_mix), SV_E_ARG,
                "sv_sample_fwd: mode %d inputs missing", mode);
     SV_REQUIRE(Lpad >= ldc + K, SV_E_SHAPE, "sv_sample_fwd: Lpad");
     DISPATCH_T(dtype, hipLaunchKernelGGL((sample_fwd_kernel<T>), dim3(B), dim3(128), 0, (hipStream_t)stream, mu, ls,
-                                         la, eps, u, label, label_mix, lam, mode, temperature, B, ldc, K, Lpad,
+                                         la, eps, u, label, label_mix, lam, lam_dev, mode, temperature, B, ldc, K, Lpad,
                                          (T*)latent, csoft));
     return sv_check_launch("sv_sample_fwd");
 }
@@ -926,12 +930,12 @@ int sv_post_bwd(const float* mu, const float* ls, const float* mu_t, const float
     return sv_check_launch("sv_post_bwd");
 }
 
-int sv_mix_lerp(const float* a, const int64_t* index, float lam, int B, int64_t row, int exp_space, float* out,
-                void* stream) {
+int sv_mix_lerp(const float* a, const int64_t* index, float lam, const float* lam_dev, int B, int64_t row,
+                int exp_space, float* out, void* stream) {
     SV_REQUIRE(a && index && out, SV_E_ARG, "sv_mix_lerp: null");
     if (B == 0 || row == 0) return SV_OK;
     hipLaunchKernelGGL(mix_lerp_kernel, dim3((unsigned)((row + 255) / 256), B), dim3(256), 0, (hipStream_t)stream, a,
-                       index, lam, B, row, exp_space, out);
+                       index, lam, lam_dev, B, row, exp_space, out);
     return sv_check_launch("sv_mix_lerp");
 }
 

@@ -406,6 +406,37 @@ class Engine:
             ws = pool[key] = torch.empty(self._ws_elems, dtype=torch.float32, device=self.param.device)
         return ws
 
+    wgrad_side_stream = True      # weight gradients on a side stream (they are off the backward's critical path)
+
+    def _side(self):
+        """side stream paired with the current stream"""
+        pool = getattr(self, "_side_streams", None)
+        if pool is None:
+            pool = self._side_streams = {}
+        cur = torch.cuda.current_stream()
+        s = pool.get(cur.cuda_stream)
+        if s is None:
+            s = pool[cur.cuda_stream] = torch.cuda.Stream()
+        return cur, s
+
+    def _wgrad_async(self, g, x, pro, dy, dw_ptr, tag=None):
+        """Enqueue the weight gradient behind everything issued so far, on the side stream: the dgrad -> BN-apply
+        chain continues on the main stream without waiting for it (joined at the end of backward)."""
+        if not self.wgrad_side_stream or self.prof_tags is not None:
+            return self._wgrad(g, x, pro, dy, dw_ptr, tag)
+        cur, side = self._side()
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            self._wgrad(g, x, pro, dy, dw_ptr, tag)
+        if not torch.cuda.is_current_stream_capturing():    # (graph-private pools keep memory until the graph dies)
+            x.record_stream(side)
+            dy.record_stream(side)
+
+    def _join_side(self):
+        if self.wgrad_side_stream and self.prof_tags is None:
+            cur, side = self._side()
+            cur.wait_stream(side)
+
     def _wgrad(self, g, x, pro, dy, dw_ptr, tag=None):
         if tag:
             self._tag(tag, g, wgrad=True)
@@ -527,7 +558,8 @@ class Engine:
                _vp(eps.data_ptr()), _vp(u.data_ptr()) if u is not None else None,
                _vp(label.data_ptr()) if label is not None else None,
                _vp(label_mix.data_ptr()) if label_mix is not None else None,
-               float(lam), mode, float(temperature), B, p.ldc, p.K, p.Lpad, _vp(latent.data_ptr()),
+               0.0 if torch.is_tensor(lam) else float(lam), _vp(lam.data_ptr()) if torch.is_tensor(lam) else None,
+               mode, float(temperature), B, p.ldc, p.K, p.Lpad, _vp(latent.data_ptr()),
                _vp(csoft.data_ptr()), st)
         # decoder (decoder.py:12-58)
         f.h = []
@@ -579,7 +611,8 @@ class Engine:
             tab = self._run_tables[dev] = torch.tensor(rows, dtype=torch.int32, device=dev)
         for k in sorted(self._pending):
             bnbuf, B = self._pending[k]
-            bnbuf.record_stream(torch.cuda.current_stream())      # allocated on a branch stream, read here
+            if not torch.cuda.is_current_stream_capturing():
+                bnbuf.record_stream(torch.cuda.current_stream())      # allocated on a branch stream, read here
             key = (dev, B)
             cnt = self._run_tables.get(key)
             if cnt is None:
@@ -659,13 +692,13 @@ class Engine:
         for i in range(5, 0, -1):
             cv, b = p.dec_convs[i], p.dec_bns[i - 1]
             hin = f.h[i - 1]
-            self._wgrad(cv.geom_fwd(B), hin, f.dpro[i - 1], D, gbase + 4 * cv.master_off, tag="wgrad:dec%d" % i)
+            self._wgrad_async(cv.geom_fwd(B), hin, f.dpro[i - 1], D, gbase + 4 * cv.master_off, tag="wgrad:dec%d" % i)
             g = torch.empty_like(hin)
             self._igemm(cv.geom_dgrad(B), D, pk + es * cv.dgrad_off, g, ex=ex_of(b, hin), tag="dgrad:dec%d" % i)
             D = bn_apply(hin, [(g, b)], None, hin.numel() // hin.shape[-1])
         cv = p.dec_convs[0]
         lat4 = f.latent.view(B, 1, 1, p.Lpad)
-        self._wgrad(cv.geom_fwd(B), lat4, None, D, gbase + 4 * cv.master_off, tag="wgrad:dec0")
+        self._wgrad_async(cv.geom_fwd(B), lat4, None, D, gbase + 4 * cv.master_off, tag="wgrad:dec0")
         dlat = torch.empty(B, 1, 1, p.Lpad, dtype=T, device=dev)
         self._igemm(cv.geom_dgrad(B), D, pk + es * cv.dgrad_off, dlat, tag="dgrad:dec0")
         # ---- sampler + heads + pool -----------------------------------------------------------
@@ -694,14 +727,14 @@ class Engine:
             tin, c1 = f.t[i], f.c1[i]
             pro1, pro2, proi = f.pro[i]
             c = un["cout"]
-            self._wgrad(un["conv2"].geom_fwd(B), c1, pro2, D, gbase + 4 * un["conv2"].master_off,
+            self._wgrad_async(un["conv2"].geom_fwd(B), c1, pro2, D, gbase + 4 * un["conv2"].master_off,
                         tag="wgrad:conv3x3_%dx%d_s1" % (c, c))
             g2 = torch.empty_like(c1)
             self._igemm(un["conv2"].geom_dgrad(B), D, pk + es * un["conv2"].dgrad_off, g2, ex=ex_of(un["bn2"], c1),
                         tag="dgrad:conv3x3_%dx%d_s1" % (c, c))
             dc1 = bn_apply(c1, [(g2, un["bn2"])], None, c1.numel() // c)
             del g2
-            self._wgrad(un["conv1"].geom_fwd(B), tin, pro1, dc1, gbase + 4 * un["conv1"].master_off,
+            self._wgrad_async(un["conv1"].geom_fwd(B), tin, pro1, dc1, gbase + 4 * un["conv1"].master_off,
                         tag="wgrad:conv3x3_%dx%d_s%d" % (un["cin"], c, un["stride"]))
             g1 = torch.empty_like(tin)
             self._igemm(un["conv1"].geom_dgrad(B), dc1, pk + es * un["conv1"].dgrad_off, g1, ex=ex_of(un["bn1"], tin),
@@ -709,7 +742,7 @@ class Engine:
             del dc1
             cnt = tin.numel() // tin.shape[-1]
             if "convi" in un:
-                self._wgrad(un["convi"].geom_fwd(B), tin, proi, D, gbase + 4 * un["convi"].master_off,
+                self._wgrad_async(un["convi"].geom_fwd(B), tin, proi, D, gbase + 4 * un["convi"].master_off,
                             tag="wgrad:conv1x1_%dx%d" % (un["cin"], c))
                 gi = torch.empty_like(tin)
                 self._igemm(un["convi"].geom_dgrad(B), D, pk + es * un["convi"].dgrad_off, gi,
@@ -718,5 +751,6 @@ class Engine:
             else:
                 D = bn_apply(tin, [(g1, un["bn1"])], D, cnt)
         # ---- stem: weight + bias gradients (the image needs none) ---------------------------------
-        self._wgrad(p.stem.geom_fwd(B), f.x16, None, D, gbase + 4 * p.stem.master_off, tag="wgrad:stem")
+        self._wgrad_async(p.stem.geom_fwd(B), f.x16, None, D, gbase + 4 * p.stem.master_off, tag="wgrad:stem")
         L.call("sv_colsum", self.code, _vp(D.data_ptr()), D.numel() // 16, 16, 16, _vp(gbase + 4 * p.stem_bias_off), st)
+        self._join_side()

@@ -25,7 +25,10 @@ def _lerp(a, index, lam, exp_space):
     a = a.contiguous().float()
     out = torch.empty_like(a)
     B = a.shape[0]
-    L.call("sv_mix_lerp", _p(a), _p(index), float(lam), B, a[0].numel(), int(exp_space), _p(out), _st())
+    if torch.is_tensor(lam):
+        L.call("sv_mix_lerp", _p(a), _p(index), 0.0, _p(lam), B, a[0].numel(), int(exp_space), _p(out), _st())
+    else:
+        L.call("sv_mix_lerp", _p(a), _p(index), float(lam), None, B, a[0].numel(), int(exp_space), _p(out), _st())
     return out
 
 
@@ -38,26 +41,36 @@ def optimal_match_index(z_mean, z_log_sigma):
     return idx
 
 
-def mixup_vae_data(image, z_mean, z_log_sigma, disc_log_alpha, optimal_match=False):
-    """Returns mixed image, mean, sigma (linear space), alpha (linear space), lambda."""
-    lam = np.random.beta(2.0, 2.0)
+def device_permutation(n, device):
+    """random permutation drawn on the device (capturable into a hipGraph, unlike a CPU randperm + copy)"""
+    return torch.rand(n, device=device).argsort()
+
+
+def mixup_vae_data(image, z_mean, z_log_sigma, disc_log_alpha, optimal_match=False, lam=None, index=None):
+    """Returns mixed image, mean, sigma (linear space), alpha (linear space), lambda.  `lam` / `index` (extensions):
+    a device scalar / a device index tensor to use instead of the host draws (numpy beta, CPU randperm)."""
+    if lam is None:
+        lam = np.random.beta(2.0, 2.0)
     batch_size = image.size()[0]
     if optimal_match:
         index = optimal_match_index(z_mean, z_log_sigma)
-    else:
+    elif index is None:
         index = torch.randperm(batch_size).to(image.device)
     index = index.long().contiguous()
     return (_lerp(image, index, lam, False), _lerp(z_mean, index, lam, False),
             _lerp(z_log_sigma, index, lam, True), _lerp(disc_log_alpha, index, lam, True), lam)
 
 
-def label_smoothing(image, z_mean, z_log_sigma, disc_log_alpha, epsilon=0.1, disc_label=None):
-    if epsilon > 0:
-        lam = np.random.beta(epsilon, epsilon)
-    else:
-        lam = 1
+def label_smoothing(image, z_mean, z_log_sigma, disc_log_alpha, epsilon=0.1, disc_label=None, lam=None, index=None):
+    if lam is None:
+        if epsilon > 0:
+            lam = np.random.beta(epsilon, epsilon)
+        else:
+            lam = 1
     batch_size = image.size()[0]
-    index = torch.randperm(batch_size).to(image.device).long().contiguous()
+    if index is None:
+        index = torch.randperm(batch_size).to(image.device)
+    index = index.long().contiguous()
     return (_lerp(image, index, lam, False), _lerp(z_mean, index, lam, False),
             _lerp(z_log_sigma, index, lam, True), _lerp(disc_log_alpha, index, lam, True),
             disc_label[index], lam)

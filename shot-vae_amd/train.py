@@ -2,11 +2,12 @@
 per-epoch schedule (:270-279, :518-520)."""
 import math
 
+import numpy as np
 import torch
 
 from . import dp
 from .criterion import continuous_posterior_loss
-from .mixup import label_smoothing, mixup_vae_data
+from .mixup import device_permutation, label_smoothing, mixup_vae_data
 
 
 def alpha_schedule(epoch, max_epoch, alpha_max):
@@ -27,8 +28,29 @@ def one_hot(label, K):
     return torch.zeros(label.shape[0], K, device=label.device).scatter_(1, label.view(-1, 1), 1)
 
 
+class DeviceRng:
+    """Device-side source of the step's host-RNG draws, so that the step can be captured into a hipGraph: the two
+    mixup coefficients come from tables of numpy Beta draws (the reference's distributions: Beta(eps,eps) for label
+    smoothing, mixup.py:31; Beta(2,2) for mixup, mixup.py:7) indexed by a device counter, the pairings from a
+    device-side random permutation."""
+
+    def __init__(self, device, epsilon=0.1, n=4096, seed=0):
+        rs = np.random.RandomState(seed)
+        tl = rs.beta(epsilon, epsilon, size=n) if epsilon > 0 else np.ones(n)
+        self.lam_l = torch.tensor(tl, dtype=torch.float32, device=device)
+        self.lam_u = torch.tensor(rs.beta(2.0, 2.0, size=n), dtype=torch.float32, device=device)
+        self.counter = torch.zeros(1, dtype=torch.int64, device=device)
+        self.n = n
+
+    def next_lams(self):
+        i = torch.remainder(self.counter, self.n)
+        lam_l, lam_u = self.lam_l.index_select(0, i), self.lam_u.index_select(0, i)     # shape [1] each
+        self.counter += 1
+        return lam_l, lam_u
+
+
 def train_step_overlapped(model, elbo_criterion, cls_criterion, optimizer, image_l, label_l, image_u, sch,
-                          epsilon=0.1, distributed=False):
+                          epsilon=0.1, distributed=False, device_rng=None):
     """Same step, the labelled branch ((1),(2), backward) and the unlabelled branch ((3),(4), backward) issued on two
     HIP streams: they are independent until the optimizer step (both only read the weights and add to the flat
     gradient buffer with atomics), so the latency-bound small kernels of one branch (decoder, heads, BN
@@ -41,6 +63,9 @@ def train_step_overlapped(model, elbo_criterion, cls_criterion, optimizer, image
     eng = model._engine
     eng.ensure_packs()
     model._attach_grads()
+    dl_l = dl_u = None
+    if device_rng is not None:           # capturable: lambdas / pairings drawn on the device
+        dl_l, dl_u = device_rng.next_lams()
     for s in st:
         s.wait_stream(cur)
     # BN running statistics: every forward defers its momentum update into its slot; they are applied after the
@@ -56,8 +81,15 @@ def train_step_overlapped(model, elbo_criterion, cls_criterion, optimizer, image
         recon_l, klc_l, kld_l = elbo_criterion(image_l, rec1, mu1, ls1, la1)
         elbo_l = recon_l + sch["kl_beta_c"] * torch.abs(klc_l - sch["cmi"]) + sch["kl_beta_d"] * torch.abs(kld_l - sch["dmi"])
         with torch.no_grad():
-            sm_img, sm_mu, sm_sigma, sm_alpha, sm_label, lam_l = label_smoothing(
-                image_l, mu1, ls1, la1, epsilon=epsilon, disc_label=label_l)
+            if device_rng is None:
+                sm_img, sm_mu, sm_sigma, sm_alpha, sm_label, lam_l = label_smoothing(
+                    image_l, mu1, ls1, la1, epsilon=epsilon, disc_label=label_l)
+                lam_l0 = lam_l
+            else:
+                sm_img, sm_mu, sm_sigma, sm_alpha, sm_label, lam_l = label_smoothing(
+                    image_l, mu1, ls1, la1, epsilon=epsilon, disc_label=label_l, lam=dl_l,
+                    index=device_permutation(image_l.size(0), image_l.device))
+                lam_l0 = lam_l.reshape(())
             sm_onehot = one_hot(sm_label, K)
         eng.defer_slot = 1
         rec2, mu2, ls2, la2, *_ = model(sm_img, True, label_l, sm_label, lam_l)
@@ -65,12 +97,16 @@ def train_step_overlapped(model, elbo_criterion, cls_criterion, optimizer, image
         recon_u, klc_u, kld_u = elbo_criterion(image_u, rec3, mu3, ls3, la3)
         elbo_u = recon_u + sch["kl_beta_c"] * torch.abs(klc_u - sch["cmi"]) + sch["kl_beta_d"] * torch.abs(kld_u - sch["dmi"])
         with torch.no_grad():
-            mx_img, mx_mu, mx_sigma, mx_alpha, lam_u = mixup_vae_data(image_u, mu3, ls3, la3)
+            if device_rng is None:
+                mx_img, mx_mu, mx_sigma, mx_alpha, lam_u = mixup_vae_data(image_u, mu3, ls3, la3)
+            else:
+                mx_img, mx_mu, mx_sigma, mx_alpha, lam_u = mixup_vae_data(
+                    image_u, mu3, ls3, la3, lam=dl_u, index=device_permutation(image_u.size(0), image_u.device))
         eng.defer_slot = 3
         rec4, mu4, ls4, la4, *_ = model(mx_img)
     eng.defer_slot = None
     with torch.cuda.stream(st[0]):
-        disc_post_l = lam_l * cls_criterion(la2, onehot_l) + (1 - lam_l) * cls_criterion(la2, sm_onehot)
+        disc_post_l = lam_l0 * cls_criterion(la2, onehot_l) + (1 - lam_l0) * cls_criterion(la2, sm_onehot)
         elbo_l = elbo_l + sch["kl_beta_c"] * sch["pwm"] * continuous_posterior_loss(mu2, ls2, sm_mu, sm_sigma)
         loss_sup = sch["ew"] * elbo_l + disc_post_l
         loss_sup.backward()
@@ -139,3 +175,59 @@ def train_step(model, elbo_criterion, cls_criterion, optimizer, image_l, label_l
             "cont_post_u", "loss_sup", "loss_unsup", "sm_img", "mx_img"] + \
            ["%s%d" % (n, i) for i in (1, 2, 3, 4) for n in ("rec", "mu", "ls", "la")]
     return {k: loc[k].detach() for k in keys}
+
+
+class GraphedTrainStep:
+    """The two-stream step captured once into a hipGraph and replayed: ~1100 kernel launches per step stop costing
+    ~12 ms of host time (measured: the eager step is host-bound below that).  The graph holds the weight re-packing,
+    the four forwards, both backwards and the deferred BN running-stat updates; the gradient all-reduce and the SGD
+    kernel stay outside (eager), so the collective is an ordinary RCCL call and lr can change without re-capturing.
+    Needs rng="device".  Re-capture (build a new object) when the per-epoch schedule scalars change."""
+
+    def __init__(self, model, elbo_criterion, cls_criterion, optimizer, image_l, label_l, image_u, sch, epsilon=0.1,
+                 distributed=False, seed=0, warmup=2):
+        assert model.rng == "device", "graph capture needs device-side noise: VariationalAutoEncoder(..., rng='device')"
+        self.model, self.opt, self.distributed = model, optimizer, distributed
+        self.il, self.ll, self.iu = image_l.clone(), label_l.clone(), image_u.clone()
+        self.rng = DeviceRng(image_l.device, epsilon, seed=seed)
+        self.args = (elbo_criterion, cls_criterion, sch, epsilon)
+        self.stream = torch.cuda.Stream()
+        cur = torch.cuda.current_stream()
+        self.stream.wait_stream(cur)
+        with torch.cuda.stream(self.stream):
+            for _ in range(warmup):                 # also creates every per-stream cache the capture relies on
+                self._body()
+                self._update()
+        cur.wait_stream(self.stream)
+        torch.cuda.synchronize()
+        model._engine.mark_dirty()                  # the captured sequence must start with the weight re-packing
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph, stream=self.stream):
+            self.losses = self._body()
+
+    def _body(self):
+        e, c, sch, eps = self.args
+        eng = self.model._engine
+        keep = eng.wgrad_side_stream
+        # nested side streams inside the two branch streams crash hipGraph instantiation on ROCm 7.2 (and add
+        # nothing to the two-stream schedule, measured), so the captured body keeps wgrads on the branch streams
+        eng.wgrad_side_stream = False
+        try:
+            return train_step_overlapped(self.model, e, c, None, self.il, self.ll, self.iu, sch, epsilon=eps,
+                                         device_rng=self.rng)
+        finally:
+            eng.wgrad_side_stream = keep
+
+    def _update(self):
+        scale = dp.all_reduce_gradients(self.model.flat_parameters()[1]) if self.distributed else 1.0
+        self.opt.step(scale) if hasattr(self.opt, "_steps") else self.opt.step()
+        self.opt.zero_grad()
+
+    def __call__(self, image_l=None, label_l=None, image_u=None):
+        if image_l is not None:
+            self.il.copy_(image_l)
+            self.ll.copy_(label_l)
+            self.iu.copy_(image_u)
+        self.graph.replay()
+        self._update()
+        return self.losses

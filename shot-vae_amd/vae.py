@@ -206,7 +206,8 @@ class VariationalAutoEncoder(nn.Module):
         if disc_label is not None:
             label = disc_label.view(-1).long().contiguous()
             if mixup:
-                mode, label_mix, lam = 2, disc_pseudo_label.view(-1).long().contiguous(), float(mixup_lam)
+                lam = mixup_lam.reshape(1).float() if torch.is_tensor(mixup_lam) else float(mixup_lam)
+                mode, label_mix = 2, disc_pseudo_label.view(-1).long().contiguous()
             else:
                 mode, label_mix, lam = 1, None, 0.0
         else:

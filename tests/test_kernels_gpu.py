@@ -352,7 +352,7 @@ def test_pool_head_sample(dt):
     latd = torch.full((B, Lpad), 5.0, device=d, dtype=tdt)
     csoft = torch.empty(B, K, device=d)
     epsd, ud = eps.to(d), u.to(d)
-    L.call("sv_sample_fwd", code, p(mud), p(lsd), p(lad), p(epsd), p(ud), None, None, 0.0, 0, 0.67, B, ldc, K, Lpad,
+    L.call("sv_sample_fwd", code, p(mud), p(lsd), p(lad), p(epsd), p(ud), None, None, 0.0, None, 0, 0.67, B, ldc, K, Lpad,
            p(latd), p(csoft), st())
     assert rel(latd[:, :ldc + K].float(), lat.detach()) < max(tol, 1e-4)
     assert float(latd[:, ldc + K:].float().abs().max()) == 0.0
@@ -388,8 +388,9 @@ def test_sampler_label_modes():
     for mode, lam in ((1, 0.0), (2, 0.8)):
         lat = torch.empty(B, Lpad, device=d)
         cs = torch.empty(B, K, device=d)
+        lam_dev = torch.tensor([lam], device=d) if mode == 2 else None      # mode 2: lambda through the device pointer
         L.call("sv_sample_fwd", L.SV_F32, p(mu.to(d)), p(ls.to(d)), p(la.to(d)), p(eps.to(d)), None, p(la_.to(d)),
-               p(lb_.to(d)), lam, mode, 0.67, B, ldc, K, Lpad, p(lat), p(cs), st())
+               p(lb_.to(d)), -1.0 if mode == 2 else lam, p(lam_dev), mode, 0.67, B, ldc, K, Lpad, p(lat), p(cs), st())
         c = F.one_hot(la_, K).float()
         if mode == 2:
             c = lam * c + (1 - lam) * F.one_hot(lb_, K).float()
@@ -461,9 +462,9 @@ def test_mix_lerp_optimal_match_sgd_layout():
     a = torch.randn(B, 3, 8, 8)
     idx = torch.randperm(B)
     out = torch.empty_like(a, device=d)
-    L.call("sv_mix_lerp", p(a.to(d)), p(idx.to(d)), 0.3, B, 3 * 64, 0, p(out), st())
+    L.call("sv_mix_lerp", p(a.to(d)), p(idx.to(d)), 0.3, None, B, 3 * 64, 0, p(out), st())
     assert rel(out, 0.3 * a + 0.7 * a[idx]) < 1e-6
-    L.call("sv_mix_lerp", p(a.to(d)), p(idx.to(d)), 0.3, B, 3 * 64, 1, p(out), st())
+    L.call("sv_mix_lerp", p(a.to(d)), p(idx.to(d)), -5.0, p(torch.tensor([0.3], device=d)), B, 3 * 64, 1, p(out), st())
     assert rel(out, 0.3 * a.exp() + 0.7 * a[idx].exp()) < 1e-5
     mu, ls = torch.randn(B, D), torch.randn(B, D) * 0.3
     kl = torch.zeros(B, B)

@@ -219,6 +219,54 @@ def test_overlapped_two_stream_step_equals_sequential():
             assert int(sa[k]) == int(sb[k]) == 8, k
 
 
+def test_graphed_step_equals_eager_overlapped_step():
+    """GraphedTrainStep (hipGraph replay of the two-stream step) against the eager two-stream step, with the device
+    noise frozen (torch.randn / torch.rand return fixed device tensors per shape) so both are deterministic."""
+    from shot_vae_amd.train import GraphedTrainStep, DeviceRng, train_step_overlapped
+    name, K, Bl, Bu = "wideresnet-10-1", 10, 8, 8
+    st = C.make_state(name, K=K)
+    il, ll, iu, lu = C.make_batch(Bl, Bu, K)
+    il, ll, iu = il.cuda(), ll.cuda(), iu.cuda()
+    gen = torch.Generator(device="cuda").manual_seed(7)
+    frozen = {}
+    real_randn, real_rand = torch.randn, torch.rand
+
+    def fixed(kind, real):
+        def f(*shape, **kw):
+            key = (kind, tuple(shape))
+            if key not in frozen:
+                frozen[key] = real(*shape, device="cuda", generator=gen)
+            return frozen[key].clone()
+        return f
+
+    torch.randn, torch.rand = fixed("n", real_randn), fixed("u", real_rand)
+    try:
+        sch = O.schedule(10)
+        elbo, cls = S.VAECriterion(discrete_dim=K).cuda(), S.ClsCriterion()
+        m1, m2 = make_model(name, K, "fp32", st), make_model(name, K, "fp32", st)
+        m1.rng = m2.rng = "device"
+        o1, o2 = S.FlatSGD(m1, lr=0.05), S.FlatSGD(m2, lr=0.05)
+        o1.zero_grad()
+        o2.zero_grad()
+        steps, warm = 3, 2
+        rng1 = DeviceRng(il.device, seed=3)
+        for _ in range(warm + steps):
+            train_step_overlapped(m1, elbo, cls, o1, il, ll, iu, sch, device_rng=rng1)
+        g = GraphedTrainStep(m2, elbo, cls, o2, il, ll, iu, sch, seed=3, warmup=warm)
+        for _ in range(steps):
+            ls, lu_ = g()
+        torch.cuda.synchronize()
+        assert torch.isfinite(ls).all() and torch.isfinite(lu_).all()
+        sa, sb = m1.state_dict(), m2.state_dict()
+        for k in sa:
+            if sa[k].dtype.is_floating_point:
+                assert T.rel_err(sb[k].cpu().numpy(), sa[k].cpu().numpy()) < 5e-4, k
+            else:
+                assert int(sa[k]) == int(sb[k]) == 4 * (warm + steps), k
+    finally:
+        torch.randn, torch.rand = real_randn, real_rand
+
+
 def test_full_size_step_properties_bf16():
     """BASELINE config 2 size (WRN-28-2, B_l=B_u=512, bf16): size-independent properties."""
     name, K, B = "wideresnet-28-2", 10, 512
