@@ -808,6 +808,7 @@ int sv_conv3x3_try(const sv_geom* g, int dtype, const sv_igemm_args* a, hipStrea
         *rc = launch_pw<float, 1>(g, a, s);
         return 1;
     }
+    if (sv_conv3x3w_try(g, dtype, a, s, rc)) return 1;       // wide MFMA-bound layers: conv3x3w.hip
     static const bool no_multi = getenv("SV_NO_CONV3X3M") != nullptr;
     if (!no_multi && dtype == SV_BF16 && g->Cin >= 96) {
         // MFMA-bound wide layers: multi-tile kernel when the grid still fills the chip

@@ -183,6 +183,17 @@ def test_conv3x3_wide_multitile(case):
     test_conv_dgrad_with_activation_backward("bf16", case)
 
 
+@pytest.mark.parametrize("case", [(4, 160, 160, 8, 3, 1, 1), (8, 128, 128, 8, 3, 1, 1), (1, 96, 128, 32, 3, 1, 1),
+                                  (2, 128, 256, 16, 3, 1, 1), (3, 160, 320, 32, 3, 1, 1), (4, 640, 640, 8, 3, 1, 1)])
+def test_conv3x3_wide_mfma(case):
+    """Shapes that take the 256-pixel x 160/128-channel LDS-DMA pipelined kernel (conv3x3w.hip): both channel-tile
+    widths, the three image sizes (one / several images per tile), odd and even chunk counts, several channel tiles
+    per pixel tile, a grid with idle tail blocks; forward with every fusion and the data gradient with the
+    activation-backward epilogue (reversed tap order)."""
+    test_conv_forward_fused("bf16", case)
+    test_conv_dgrad_with_activation_backward("bf16", case)
+
+
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
 @pytest.mark.parametrize("H,Cin,N,B", [(1, 1024, 512, 6), (2, 512, 256, 4), (8, 128, 64, 3), (16, 64, 16, 2)])
 def test_convT_forward_and_dgrad(dt, H, Cin, N, B):

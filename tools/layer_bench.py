@@ -1,0 +1,89 @@
+"""Micro-benchmark of single conv-like layers through the C ABI (MI355X): forward with the fused BN prologue /
+residual / statistics epilogue, data gradient with the activation-backward epilogue, weight gradient.
+
+    python tools/layer_bench.py                 # the WRN-28-10 body shapes of SURVEY.md §8d at B=512
+    python tools/layer_bench.py 512 32 32 32    # B C H N: any stride-1 3x3 layer
+
+Prints microseconds per launch, TFLOP/s and the fraction of the 2.5 PFLOP/s dense bf16 MFMA peak."""
+import ctypes as C
+import sys
+
+import torch
+
+sys.path.insert(0, __file__.rsplit("/", 2)[0])
+from shot_vae_amd import _lib as L          # noqa: E402
+from shot_vae_amd import geometry as G      # noqa: E402
+
+PEAK = 2.5e15
+
+
+def timed(fn, iters=20, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / iters
+
+
+def bench_layer(B, Cin, H, N, what=("fwd", "dgrad", "wgrad")):
+    d = torch.device("cuda:0")
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    bf = torch.bfloat16
+    x = torch.randn(B, H, H, Cin, device=d).to(bf)
+    dy = torch.randn(B, H, H, N, device=d).to(bf)
+    master = (torch.randn(N, 9, Cin, device=d) / (9 * Cin) ** 0.5).contiguous()
+    flops = 2.0 * B * H * H * 9 * Cin * N
+    R = 8
+    res = {}
+    if "fwd" in what:
+        g = G.conv_like(B, H, H, Cin, N, 3, 1, 1)
+        wp = torch.zeros(G.packed_size(g), dtype=bf, device=d)
+        L.call("sv_repack", L.SV_BF16, C.c_void_p(master.data_ptr()), N, 9, Cin, 0, C.byref(g), C.c_void_p(wp.data_ptr()), st)
+        out = torch.empty(B, H, H, N, dtype=bf, device=d)
+        resid = torch.randn(B, H, H, N, device=d).to(bf)
+        sc, sh = torch.rand(Cin, device=d) + 0.5, torch.randn(Cin, device=d) * 0.3
+        stats = torch.zeros(R, 2 * N, device=d)
+        a = L.SvIgemmArgs()
+        a.x, a.w, a.out, a.residual = x.data_ptr(), wp.data_ptr(), out.data_ptr(), resid.data_ptr()
+        a.pro_scale, a.pro_shift, a.pro_slope = sc.data_ptr(), sh.data_ptr(), 0.01
+        a.stats, a.replicas = stats.data_ptr(), R
+        res["fwd"] = timed(lambda: L.call("sv_igemm", C.byref(g), L.SV_BF16, C.byref(a), st))
+    if "dgrad" in what:
+        g = G.convT_like(B, H, H, N, Cin, 3, 1, 1)
+        wp = torch.zeros(G.packed_size(g), dtype=bf, device=d)
+        L.call("sv_repack", L.SV_BF16, C.c_void_p(master.data_ptr()), N, 9, Cin, 1, C.byref(g), C.c_void_p(wp.data_ptr()), st)
+        out = torch.empty(B, H, H, Cin, dtype=bf, device=d)
+        vec = [torch.rand(Cin, device=d) + 0.5 for _ in range(4)]
+        bs = torch.zeros(R, 2 * Cin, device=d)
+        a = L.SvIgemmArgs()
+        a.x, a.w, a.out = dy.data_ptr(), wp.data_ptr(), out.data_ptr()
+        a.ex, a.ex_scale, a.ex_shift, a.ex_mean, a.ex_rstd = [t.data_ptr() for t in [x] + vec]
+        a.ex_slope, a.bsums, a.replicas = 0.01, bs.data_ptr(), R
+        res["dgrad"] = timed(lambda: L.call("sv_igemm", C.byref(g), L.SV_BF16, C.byref(a), st))
+    if "wgrad" in what:
+        g = G.conv_like(B, H, H, Cin, N, 3, 1, 1)
+        dw = torch.zeros(N, 9, Cin, device=d)
+        sc, sh = torch.rand(Cin, device=d) + 0.5, torch.randn(Cin, device=d) * 0.3
+        ws = torch.empty(16 << 20, device=d)
+        res["wgrad"] = timed(lambda: L.call("sv_wgrad", C.byref(g), L.SV_BF16, C.c_void_p(x.data_ptr()),
+                                            C.c_void_p(sc.data_ptr()), C.c_void_p(sh.data_ptr()), C.c_float(0.01),
+                                            C.c_void_p(dy.data_ptr()), C.c_void_p(dw.data_ptr()), 0, 1,
+                                            C.c_void_p(ws.data_ptr()), ws.numel(), st))
+    for k, us in res.items():
+        print(f"B={B} Cin={Cin} N={N} H={H} {k:6s} {us:9.1f} us  {flops / us / 1e6:8.1f} TFLOP/s  "
+              f"{flops / us / 1e-6 / PEAK:6.3f} of bf16 MFMA peak", flush=True)
+    return res
+
+
+if __name__ == "__main__":
+    if len(sys.argv) >= 5:
+        B, Cc, H, N = map(int, sys.argv[1:5])
+        bench_layer(B, Cc, H, N, tuple(sys.argv[5:]) or ("fwd", "dgrad", "wgrad"))
+    else:
+        for Cc, H in ((160, 32), (320, 16), (640, 8)):
+            bench_layer(512, Cc, H, Cc)
