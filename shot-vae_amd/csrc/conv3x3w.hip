@@ -3,18 +3,20 @@
 //
 // conv3x3.hip's tiles (32 pixels x 80 channels per wave) read ~7 LDS fragments per 10 MFMAs: LDS-bound on these
 // layers.  This kernel is built like a large-tile GEMM instead:
-//   * block = 256 output pixels (whole image rows) x 32*NF output channels, 4 waves, ONE wave per SIMD with the
-//     full 512-register file: every wave owns 64 pixels x 32*NF channels = 2 x NF accumulators of
-//     v_mfma_f32_32x32x16_bf16 (weights = A operand, pixels = B operand) -> 14 fragment reads per 20 MFMAs;
-//   * K loop = (32-channel chunk) x (9 taps).  The input halo of a chunk is staged ONCE (LDS-DMA, raw), gets
-//     BatchNorm-apply + LeakyReLU + zero padding in an LDS->LDS pass spread over the MFMA steps of the previous
-//     chunk, and serves all nine taps (tap shift = immediate LDS offset);
-//   * the [32*NF][32] weight slice of every (chunk, tap) step arrives by LDS-DMA (global_load_lds_dwordx4) three
-//     steps ahead into a ring of four buffers, XOR-swizzled on the SOURCE address so the lane-linear LDS image is
-//     conflict-free for ds_read_b128;
-//   * the first-half (k 0..15) fragments of step k+1 are read into a second register set while step k is on the
-//     MFMAs, the second-half fragments at the start of their own step behind the first-half MFMAs; one raw s_barrier
-//     per step with counted vmcnt (the DMA queue is never drained inside the loop);
+//   * block = 256 output pixels (whole image rows) x 32*NF output channels, 4 waves; every wave owns 64 pixels x
+//     32*NF channels = 2 x NF accumulators of v_mfma_f32_32x32x16_bf16 (weights = A operand, pixels = B operand)
+//     -> 14 fragment reads per 20 MFMAs;
+//   * TWO blocks per CU (<= 80 KB of LDS, <= 256 registers): one block's prologue, epilogue (HBM-bound: residual /
+//     raw-tensor reads + output stores) and barrier waits run under the other block's MFMAs;
+//   * K loop = (32-channel chunk) x (9 taps).  The input halo of a chunk is staged ONCE by LDS-DMA, raw, two buffers;
+//     BatchNorm-apply + LeakyReLU + zero padding are applied IN PLACE (LDS->LDS, spread over the MFMA steps of the
+//     previous chunk) and the tile then serves all nine taps (tap shift = immediate LDS offset);
+//   * the [32*NF][32] weight slice of every (chunk, tap) step arrives by LDS-DMA (global_load_lds_dwordx4) two steps
+//     ahead into a ring of three buffers; one raw s_barrier per step with counted vmcnt (the DMA queue is never
+//     drained inside the loop);
+//   * both LDS images are lane-linear (an LDS-DMA requirement) with 64-byte rows; the 16-byte k-quarter inside a row
+//     is XOR-swizzled on the DMA SOURCE address -- weights by (row/4)%4, pixels by a function of the halo column --
+//     which makes every ds_read_b128 fragment read conflict-free (checked by brute force for W = 32, 16, 8);
 //   * epilogue per 32-channel group through a wave-private LDS transpose: 16-byte coalesced residual / raw-tensor
 //     reads and output stores, BatchNorm sums (or activation-backward + BatchNorm-backward sums) in registers.
 // Same sv_geom / packed weights / sv_igemm_args contract as the other conv-like kernels.
@@ -33,6 +35,9 @@ typedef const __attribute__((address_space(1))) void* glb_ptr;
 __device__ __forceinline__ void glds16(const void* gsrc, void* ldst) {
     __builtin_amdgcn_global_load_lds((glb_ptr)gsrc, (lds_ptr)ldst, 16, 0, 0);
 }
+__device__ __forceinline__ void glds4(const void* gsrc, void* ldst) {
+    __builtin_amdgcn_global_load_lds((glb_ptr)gsrc, (lds_ptr)ldst, 4, 0, 0);
+}
 template <int N>
 __device__ __forceinline__ void wait_vm() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -49,37 +54,35 @@ struct WCfg {
     static constexpr int W = 1 << WLOG, TR = 256 / W, WP = W + 2;
     static constexpr int HH = TR < W ? TR : W, SEG = TR / HH, LROWS = TR + SEG + 1;   // images are square
     static constexpr int HPIX = LROWS * WP;                 // halo pixels (incl. padding columns / spacer rows)
-    static constexpr int HI = (4 * HPIX + 255) / 256;       // 16-byte slots per thread
-    static constexpr int HPIXF = HI * 64;                   // pixels incl. the dummy tail
-    static constexpr int LDH = 80;                          // bytes per pixel of the transformed halo (64 + 16 pad:
-                                                            // odd 16-byte stride -> conflict-free 32-lane fragments)
-    static constexpr int FIN = HPIXF * LDH;
-    static constexpr int RAW = HI * 256 * 16;
-    static constexpr int WI = (4 * BN + 255) / 256;
-    static constexpr int WBUF = WI * 256 * 16;
-    static constexpr int OFF_RAW = 2 * FIN, OFF_W = OFF_RAW + RAW, OFF_SSUM = OFF_W + 4 * WBUF,
-                         OFF_PS = OFF_SSUM + 2 * BN * 4;
+    static constexpr int HS = 4 * HPIX;                     // 16-byte slots of one halo buffer (64 B per pixel)
+    static constexpr int HI = (HS + 255) / 256;             // DMA instructions / transform slots per thread
+    static constexpr int HB = HS * 16;                      // bytes per halo buffer
+    static constexpr int SWS = WLOG == 5 ? 2 : 1;           // pixel swizzle: k-quarter ^= (halo column >> SWS) & 3
+    static constexpr int WS = 4 * BN;                       // 16-byte slots of one weight buffer
+    static constexpr int WI = (WS + 255) / 256;
+    static constexpr int WBUF = WS * 16;
+    static constexpr int OFF_W = 2 * HB, OFF_CO = OFF_W + 3 * WBUF, OFF_SSUM = OFF_CO + 2048,
+                         LDS = OFF_SSUM + 2 * BN * 4;
     static constexpr int SCR = 64 * 36 * 4;                 // epilogue transpose scratch per wave
-    static_assert(4 * SCR <= 2 * FIN, "epilogue scratch must fit in the halo buffers");
+    static_assert(4 * SCR <= 2 * HB, "epilogue scratch must fit in the halo buffers");
     static_assert(HI <= 6, "transform schedule covers at most 6 slots per thread");
+    static_assert(2 * LDS <= 160 * 1024, "two blocks per CU");
 };
 
 template <int NF, int WLOG, bool REV>
-__global__ __launch_bounds__(256, 1) void conv3x3w_kernel(const sv_geom g, const sv_igemm_args a) {
+__global__ __launch_bounds__(256, 2) void conv3x3w_kernel(const sv_geom g, const sv_igemm_args a) {
     using C = WCfg<NF, WLOG>;
     constexpr int BN = C::BN, W = C::W, TR = C::TR, WP = C::WP, HH = C::HH, SEG = C::SEG, HI = C::HI, WI = C::WI;
-    constexpr int LDH = C::LDH, FIN = C::FIN, WBUF = C::WBUF;
+    constexpr int HS = C::HS, HB = C::HB, WS = C::WS, WBUF = C::WBUF, SWS = C::SWS;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* const raw = smem + C::OFF_RAW;
     float* const ssum = reinterpret_cast<float*>(smem + C::OFF_SSUM);
-    float* const psc = reinterpret_cast<float*>(smem + C::OFF_PS);
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);        // scalar: DMA destinations stay in SGPRs
     const int r = lane & 31, h = lane >> 5;
     const int H = g.Hin, BH = g.B * H, nT = BH / TR, nNt = g.N / BN;
     const int Cin = g.Cin, nck = Cin / 32, KT = 9 * nck;
-    float* const psh = psc + Cin;
 
     // XCD-affine mapping: the 32 CUs of an XCD work on consecutive pixel tiles (shared halo rows and one copy of the
     // weights in that XCD's L2); the channel tiles of a pixel tile are neighbours on the same XCD
@@ -94,90 +97,133 @@ __global__ __launch_bounds__(256, 1) void conv3x3w_kernel(const sv_geom g, const
     const char* const Wb = reinterpret_cast<const char*>(reinterpret_cast<const bf16*>(a.w) + P.w_off + (int64_t)n0 * 9 * Cin);
     const bool has_pro = a.pro_scale != nullptr;
     const float slope = has_pro ? a.pro_slope : 1.f;
+    // BatchNorm coefficients of a chunk: one 4-byte DMA per wave (lanes 0..31 scale, 32..63 shift) into the wave's own
+    // 256-byte copy; without a prologue every wave reads the identity from a constant image instead
+    // (without a prologue the same DMA is issued from a dummy source, so every wave's vmcnt arithmetic is the same,
+    // and the transform only writes the padding zeros)
+    const char* const sclo = reinterpret_cast<const char*>(a.pro_scale < a.pro_shift ? a.pro_scale : a.pro_shift);
+    const char* const cob = has_pro ? sclo : Xb;               // uniform base + one 32-bit per-lane offset
+    const uint32_t cooff = has_pro ? (lane < 32 ? (uint32_t)(reinterpret_cast<const char*>(a.pro_scale) - sclo) + 4u * lane
+                                                : (uint32_t)(reinterpret_cast<const char*>(a.pro_shift) - sclo) + 4u * (lane - 32))
+                                   : 4u * lane;
+    const uint32_t costep = has_pro ? 128u : 0u;
 
-    for (int c = tid; c < Cin; c += 256) {
-        psc[c] = has_pro ? a.pro_scale[c] : 1.f;
-        psh[c] = has_pro ? a.pro_shift[c] : 0.f;
-    }
     for (int c = tid; c < 2 * BN; c += 256) ssum[c] = 0.f;
 
-    // ---- per-thread staging slots: slot s = 256 j + tid is DMA'd AND transformed by this thread ------------------
+    // ---- DMA slots (uniform instruction count per wave: the last, partial wave-instruction is shifted back so that it
+    //      ends at the end of the image and re-copies a few slots -- same source, same destination) -----------------
     uint32_t hsrc[HI];          // byte offset into x (channel chunk 0)
-    uint32_t hokm = 0;          // bit j: slot j is a real pixel (else: zero padding / spacer / dummy)
-    {
-        const bool top_ok = (gr0 & (H - 1)) != 0, bot_ok = ((gr0 + TR) & (H - 1)) != 0;
+    int hbase[HI];              // wave-uniform first slot of DMA instruction j
 #pragma unroll
-        for (int j = 0; j < HI; ++j) {
-            const int s = 256 * j + tid, pix = s >> 2, q = s & 3;
-            const int lr = pix / WP, xx = pix - lr * WP;
-            const int seg = lr / (HH + 1), off = lr - seg * (HH + 1);
-            int kind = 1, rel = lr - 1 - seg;
-            if (off == 0) {
-                if (SEG == 1) { kind = seg == 0 ? 2 : 3; rel = seg == 0 ? -1 : TR; }
-                else kind = 0;
-            }
-            if (pix >= C::HPIX || xx == 0 || xx == WP - 1) kind = 0;
-            if (kind == 1 || (kind == 2 && top_ok) || (kind == 3 && bot_ok)) hokm |= 1u << j;
-            const int grc = min(max(gr0 + rel, 0), BH - 1), xc = min(max(xx - 1, 0), W - 1);
-            hsrc[j] = (uint32_t)((grc * W + xc) * g.ldx + 8 * q) * 2u;
-        }
+    for (int j = 0; j < HI; ++j) {
+        hbase[j] = min((j * 4 + wave) * 64, HS - 64);
+        const int s = hbase[j] + lane, pix = s >> 2;
+        const int lr = pix / WP, xx = pix - lr * WP;
+        const int q = (s & 3) ^ ((xx >> SWS) & 3);
+        const int seg = lr / (HH + 1), off = lr - seg * (HH + 1);
+        int rel = lr - 1 - seg;
+        if (off == 0 && SEG == 1) rel = seg == 0 ? -1 : TR;
+        const int grc = min(max(gr0 + rel, 0), BH - 1), xc = min(max(xx - 1, 0), W - 1);
+        hsrc[j] = (uint32_t)((grc * W + xc) * g.ldx + 8 * q) * 2u;
     }
-    const int hdst0 = (tid >> 2) * LDH + 16 * (tid & 3);          // slot j lands at hdst0 + 64 j LDH
-    const int qc = 8 * (tid & 3);                                  // this thread's 8-channel group inside a chunk
-    // weight slots: row = 64 i + tid/4 (clamped for the dummy tail of the last slot), source k-quarter XOR-swizzled
-    const uint32_t wq = (uint32_t)((tid & 3) ^ ((tid >> 4) & 3));
-    const uint32_t wsrc0 = (uint32_t)((tid >> 2) * 9 * Cin + 8 * wq) * 2u;
-    const uint32_t wsrcL = (uint32_t)(min(64 * (WI - 1) + (tid >> 2), BN - 1) * 9 * Cin + 8 * wq) * 2u;
-    const uint32_t wstep = (uint32_t)(64 * 9 * Cin) * 2u;
-    auto issue_h = [&](int c) {
+    uint32_t wsrc[WI];
+    int wbase[WI];
+#pragma unroll
+    for (int i = 0; i < WI; ++i) {
+        wbase[i] = min((i * 4 + wave) * 64, WS - 64);
+        const int s = wbase[i] + lane, row = s >> 2, q = (s & 3) ^ ((row >> 2) & 3);
+        wsrc[i] = (uint32_t)(row * 9 * Cin + 8 * q) * 2u;
+    }
+    auto issue_h = [&](int c, int buf) {
 #pragma unroll
         for (int j = 0; j < HI; ++j) {
-            const uint32_t o = hsrc[j] + (uint32_t)(c * 64);      // one 32-bit offset: SGPR base + VGPR offset form
-            glds16(Xb + o, raw + (j * 4 + wave) * 1024);
+            uint32_t o = hsrc[j];
+            asm volatile("" : "+v"(o));                           // (keeps the per-tap sums out of loop-invariant hoisting)
+            o += (uint32_t)(c * 64);                              // one 32-bit offset: SGPR base + VGPR offset form
+            glds16(Xb + o, smem + buf * HB + hbase[j] * 16);
+        }
+        {
+            uint32_t o = cooff;
+            asm volatile("" : "+v"(o));
+            o += costep * (uint32_t)c;
+            glds4(cob + o, smem + C::OFF_CO + (c & 1) * 1024 + wave * 256);
         }
     };
     auto issue_w = [&](int c, int t, int buf) {
         const uint32_t o = (uint32_t)(t * Cin + c * 32) * 2u;
 #pragma unroll
         for (int i = 0; i < WI; ++i) {
-            const uint32_t oo = (i == WI - 1 ? wsrcL : wsrc0 + (uint32_t)i * wstep) + o;
-            glds16(Wb + oo, smem + C::OFF_W + buf * WBUF + (i * 4 + wave) * 1024);
+            uint32_t oo = wsrc[i];
+            asm volatile("" : "+v"(oo));
+            oo += o;
+            glds16(Wb + oo, smem + C::OFF_W + buf * WBUF + wbase[i] * 16);
         }
     };
-    bf16x8 zero;
+    // ---- in-place transform slots: thread handles slots 256 j + tid (a partition of the image) ----------------------
+    uint32_t hokm = 0;          // bit j: slot j is a real pixel (else: zero padding / spacer)
+    uint32_t qcm = 0;           // 2 bits per j: logical k-quarter (8-channel group) of slot j
+    {
+        const bool top_ok = (gr0 & (H - 1)) != 0, bot_ok = ((gr0 + TR) & (H - 1)) != 0;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) zero[e] = (bf16)0.f;
-    auto transform = [&](int c, auto jc, char* fin) __attribute__((always_inline)) {
-        constexpr int j = decltype(jc)::value;
-        // BatchNorm scale / shift of this thread's 8 channels of chunk c (LDS-resident: no registers held across steps)
-        const f32x4 sc0 = *reinterpret_cast<const f32x4*>(psc + 32 * c + qc);
-        const f32x4 sc1 = *reinterpret_cast<const f32x4*>(psc + 32 * c + qc + 4);
-        const f32x4 sh0 = *reinterpret_cast<const f32x4*>(psh + 32 * c + qc);
-        const f32x4 sh1 = *reinterpret_cast<const f32x4*>(psh + 32 * c + qc + 4);
-        const bf16x8 v = *reinterpret_cast<const bf16x8*>(raw + 16 * (256 * j + tid));
-        bf16x8 o;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float u0 = (float)v[e] * sc0[e] + sh0[e], u1 = (float)v[e + 4] * sc1[e] + sh1[e];
-            o[e] = (bf16)fmaxf(u0, u0 * slope);        // LeakyReLU / ReLU / identity for slope in [0, 1]
-            o[e + 4] = (bf16)fmaxf(u1, u1 * slope);
+        for (int j = 0; j < HI; ++j) {
+            const int s = 256 * j + tid, pix = s >> 2;
+            const int lr = pix / WP, xx = pix - lr * WP;
+            const int seg = lr / (HH + 1), off = lr - seg * (HH + 1);
+            int kind = 1;
+            if (off == 0) kind = SEG == 1 ? (seg == 0 ? 2 : 3) : 0;
+            if (xx == 0 || xx == WP - 1) kind = 0;
+            if (kind == 1 || (kind == 2 && top_ok) || (kind == 3 && bot_ok)) hokm |= 1u << j;
+            qcm |= (uint32_t)((s & 3) ^ ((xx >> SWS) & 3)) << (2 * j);
         }
-        *reinterpret_cast<bf16x8*>(fin + hdst0 + j * 64 * LDH) = ((hokm >> j) & 1u) ? o : zero;
+    }
+    auto transform = [&](int c, auto jc, int buf) __attribute__((always_inline)) {
+        constexpr int j = decltype(jc)::value;
+        if (256 * j + tid < HS) {
+            int toff = 16 * tid;
+            asm volatile("" : "+v"(toff));                         // (not hoisted: one address register, not HI)
+            bf16x8* ptr = reinterpret_cast<bf16x8*>(smem + buf * HB + 4096 * j + toff);
+            if (has_pro) {
+                uint32_t qm = qcm;
+                asm volatile("" : "+v"(qm));
+                const float* co = reinterpret_cast<const float*>(smem + C::OFF_CO + (c & 1) * 1024 + wave * 256) +
+                                  8 * ((qm >> (2 * j)) & 3);
+                const bool ok = (hokm >> j) & 1u;
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {               // four channels at a time: few live registers
+                    const f32x4 sc = *reinterpret_cast<const f32x4*>(co + 4 * hf);
+                    const f32x4 sh = *reinterpret_cast<const f32x4*>(co + 32 + 4 * hf);
+                    bf16x4* p4 = reinterpret_cast<bf16x4*>(ptr) + hf;
+                    const bf16x4 v = *p4;
+                    bf16x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float u = (float)v[e] * sc[e] + sh[e];
+                        o[e] = ok ? (bf16)fmaxf(u, u * slope) : (bf16)0.f;     // LeakyReLU (0.01) / ReLU (0)
+                    }
+                    *p4 = o;
+                }
+            } else if (!((hokm >> j) & 1u)) {
+                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                *reinterpret_cast<f32x4*>(ptr) = z;
+            }
+        }
     };
 
-    // ---- fragment addressing (tap / chunk parts are immediates, the weight ring slot one add per step) ------------
-    int bb[2];                  // pixel fragments: byte offset of (pixel - one halo row - one column) + lane half
+    // ---- fragment addressing -----------------------------------------------------------------------------------
+    // pixel fragments: 64 * (pixel - one halo row - one column) + 16 * (lane half ^ swizzle of the tap's column); the tap
+    // shift and the halo buffer are immediates; the second k half is the same address ^ 32
+    int bb[2], pc[2];
 #pragma unroll
     for (int f = 0; f < 2; ++f) {
-        const int p = 64 * wave + 32 * f + r, prow = p >> WLOG, pcol = p & (W - 1);
-        bb[f] = ((prow + prow / HH) * WP + pcol) * LDH + 16 * h;
+        const int p = 64 * wave + 32 * f + r, prow = p >> WLOG;
+        pc[f] = p & (W - 1);
+        bb[f] = ((prow + prow / HH) * WP + pc[f]) * 64;
     }
-    const int ab0 = C::OFF_W + 16 * (4 * r + (h ^ ((r >> 2) & 3)));           // k sub-step 0 (channels 0..15)
-    const int ab1 = C::OFF_W + 16 * (4 * r + ((2 + h) ^ ((r >> 2) & 3)));     // k sub-step 1 (channels 16..31)
+    int ab0 = C::OFF_W + 16 * (4 * r + (h ^ ((r >> 2) & 3)));           // k half 0 (channels 0..15)
+    int ab1 = C::OFF_W + 16 * (4 * r + ((2 + h) ^ ((r >> 2) & 3)));     // k half 1 (channels 16..31)
+    asm volatile("" : "+v"(ab0), "+v"(ab1));      // opaque bases: ring slot / fragment index stay 16-bit immediates
 
-    // register sets: the k-sub-step-0 fragments are double-buffered ACROSS steps (read during the previous step),
-    // the k-sub-step-1 fragments are read at the start of their own step, behind the sub-step-0 MFMAs
-    bf16x8 A0[2][NF], B0[2][2], A1[NF], B1[2];
+    bf16x8 A[2][NF], Bf[2][2];
     f32x16 acc[2][NF];
 #pragma unroll
     for (int f = 0; f < 2; ++f)
@@ -186,93 +232,101 @@ __global__ __launch_bounds__(256, 1) void conv3x3w_kernel(const sv_geom g, const
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[f][i][e] = 0.f;
 
-    // tap shift + halo buffer of (tap t, chunk parity par) as an immediate
-    auto load_k0 = [&](auto setc, auto tc, auto parc, int ring) __attribute__((always_inline)) {
-        constexpr int set = decltype(setc)::value, t = decltype(tc)::value, par = decltype(parc)::value;
-        constexpr int sh = (REV ? ((2 - t / 3) * WP + (2 - t % 3)) : ((t / 3) * WP + t % 3)) * LDH + par * FIN;
-        const int aw = ab0 + ring * WBUF;
-#pragma unroll
-        for (int i = 0; i < NF; ++i) A0[set][i] = *reinterpret_cast<const bf16x8*>(smem + aw + i * 2048);
-#pragma unroll
-        for (int f = 0; f < 2; ++f) B0[set][f] = *reinterpret_cast<const bf16x8*>(smem + bb[f] + sh);
-    };
-    auto load_k1 = [&](auto tc, auto parc, int ring) __attribute__((always_inline)) {
+    auto load_frags = [&](auto tc, auto parc) __attribute__((always_inline)) {
         constexpr int t = decltype(tc)::value, par = decltype(parc)::value;
-        constexpr int sh = (REV ? ((2 - t / 3) * WP + (2 - t % 3)) : ((t / 3) * WP + t % 3)) * LDH + par * FIN + 32;
-        const int aw = ab1 + ring * WBUF;
+        constexpr int ty = REV ? 2 - t / 3 : t / 3, tx = REV ? 2 - t % 3 : t % 3;
+        constexpr int sh = (ty * WP + tx) * 64 + par * HB;
+        constexpr int wo = (t % 3) * WBUF;
 #pragma unroll
-        for (int i = 0; i < NF; ++i) A1[i] = *reinterpret_cast<const bf16x8*>(smem + aw + i * 2048);
+        for (int i = 0; i < NF; ++i) A[0][i] = *reinterpret_cast<const bf16x8*>(smem + ab0 + wo + i * 2048);
+        int bx[2];
 #pragma unroll
-        for (int f = 0; f < 2; ++f) B1[f] = *reinterpret_cast<const bf16x8*>(smem + bb[f] + sh);
+        for (int f = 0; f < 2; ++f) {
+            int pcf = pc[f];
+            asm volatile("" : "+v"(pcf));        // recompute the swizzle here: hoisted out of the loop, the 12 addresses
+                                                  // of all tap columns would not fit in the 256-register budget
+            bx[f] = bb[f] + 16 * (h ^ (((pcf + tx) >> SWS) & 3));
+            Bf[0][f] = *reinterpret_cast<const bf16x8*>(smem + bx[f] + sh);
+        }
+#pragma unroll
+        for (int i = 0; i < NF; ++i) A[1][i] = *reinterpret_cast<const bf16x8*>(smem + ab1 + wo + i * 2048);
+#pragma unroll
+        for (int f = 0; f < 2; ++f) Bf[1][f] = *reinterpret_cast<const bf16x8*>(smem + (bx[f] ^ 32) + sh);
     };
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
 
     // ---- prologue ---------------------------------------------------------------------------------------------
-    __syncthreads();                                   // psc / psh / ssum visible (no DMA in flight yet)
-    issue_h(0);
+    __syncthreads();                                   // ssum / identity coefficients visible (no DMA in flight yet)
+    issue_h(0, 0);
     issue_w(0, 0, 0);
     issue_w(0, 1, 1);
-    issue_w(0, 2, 2);
     wait_vm<0>();
-    transform(0, std::integral_constant<int, 0>{}, smem);
-    if (HI > 1) transform(0, std::integral_constant<int, (HI > 1 ? 1 : 0)>{}, smem);
-    if (HI > 2) transform(0, std::integral_constant<int, (HI > 2 ? 2 : 0)>{}, smem);
-    if (HI > 3) transform(0, std::integral_constant<int, (HI > 3 ? 3 : 0)>{}, smem);
-    if (HI > 4) transform(0, std::integral_constant<int, (HI > 4 ? 4 : 0)>{}, smem);
-    if (HI > 5) transform(0, std::integral_constant<int, (HI > 5 ? 5 : 0)>{}, smem);
+    barrier();                                         // every wave's DMA has landed
+    transform(0, I0{}, 0);
+    if (HI > 1) transform(0, std::integral_constant<int, (HI > 1 ? 1 : 0)>{}, 0);
+    if (HI > 2) transform(0, std::integral_constant<int, (HI > 2 ? 2 : 0)>{}, 0);
+    if (HI > 3) transform(0, std::integral_constant<int, (HI > 3 ? 3 : 0)>{}, 0);
+    if (HI > 4) transform(0, std::integral_constant<int, (HI > 4 ? 4 : 0)>{}, 0);
+    if (HI > 5) transform(0, std::integral_constant<int, (HI > 5 ? 5 : 0)>{}, 0);
     wait_lds();
     barrier();
-    load_k0(I0{}, I0{}, I0{}, 0);
-    wait_lds();
 
-    // ---- one (chunk, tap) step: weights of step k live in ring slot k & 3 -------------------------------------------
+    // ---- one (chunk, tap) step: weights of step k live in ring slot k % 3 = t % 3 ---------------------------------------
     auto step = [&](int c, auto tc, auto parc) __attribute__((always_inline)) {
         constexpr int t = decltype(tc)::value, par = decltype(parc)::value;
-        constexpr int cur = (t + par) & 1, nxt = cur ^ 1;
-        constexpr int t1 = (t + 1) % 9, par1 = t == 8 ? par ^ 1 : par;
         const int k = c * 9 + t;
         const bool more_c = c + 1 < nck;
-        const bool w_issue = k + 3 < KT;
-        // (1) asynchronous copies: weights three steps ahead (into the slot step k-1 released), the next chunk's raw
-        //     halo at the chunk's first step
-        if (w_issue) issue_w(c + (t + 3) / 9, (t + 3) % 9, (k + 3) & 3);
-        if (t == 0 && more_c) issue_h(c + 1);
-        // (2) this step's second-half fragments, then the next step's first-half fragments (at the very last step the
-        //     latter reads stale but in-bounds LDS and is never used)
-        load_k1(tc, parc, k & 3);
-        load_k0(std::integral_constant<int, nxt>{}, std::integral_constant<int, t1>{},
-                std::integral_constant<int, par1>{}, (k + 1) & 3);
-        // (3) BatchNorm-apply + LeakyReLU + padding of the next chunk's halo, spread over steps 3..7 (unconditional:
-        //     after the last chunk it rewrites an unused buffer)
+        const bool w_issue = k + 2 < KT;
+        // (1) asynchronous copies: weights two steps ahead (into the slot step k-1 released), the next chunk's raw halo
+        //     and BatchNorm coefficients at the chunk's first step
+#ifndef SV_W3_NO_W
+        if (w_issue) issue_w(c + (t + 2) / 9, (t + 2) % 9, (t + 2) % 3);
+#endif
+#ifndef SV_W3_NO_H
+        if (t == 0 && more_c) issue_h(c + 1, par ^ 1);
+#endif
+        // (2) this step's fragments
+#ifndef SV_W3_NO_FRAG
+        load_frags(tc, parc);
+#endif
+        // (3) BatchNorm-apply + LeakyReLU + padding of the next chunk's halo, in place, spread over steps 3..7
+        //     (unconditional: after the last chunk it rewrites an unused buffer)
+#ifndef SV_W3_NO_XF
         if (t >= 3 && t <= 7) {
-            char* fin = smem + (par ^ 1) * FIN;
+#else
+        if (false) {
+#endif
             const int cn = min(c + 1, nck - 1);
             if (t == 3) {
-                transform(cn, I0{}, fin);
-                if (HI > 1) transform(cn, std::integral_constant<int, (HI > 1 ? 1 : 0)>{}, fin);
+                transform(cn, I0{}, par ^ 1);
+                if (HI > 1) transform(cn, std::integral_constant<int, (HI > 1 ? 1 : 0)>{}, par ^ 1);
             } else if (t - 2 < HI) {
-                transform(cn, std::integral_constant<int, (t - 2 < HI ? (t >= 4 ? t - 2 : 0) : 0)>{}, fin);
+                transform(cn, std::integral_constant<int, (t - 2 < HI ? (t >= 4 ? t - 2 : 0) : 0)>{}, par ^ 1);
             }
         }
         // (4) this step's 4 NF MFMAs
+#ifndef SV_W3_NO_MFMA
 #pragma unroll
-        for (int f = 0; f < 2; ++f)
+        for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-            for (int i = 0; i < NF; ++i)
-                acc[f][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0[cur][i], B0[cur][f], acc[f][i], 0, 0, 0);
+            for (int f = 0; f < 2; ++f)
 #pragma unroll
-        for (int f = 0; f < 2; ++f)
+                for (int i = 0; i < NF; ++i)
+                    acc[f][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[ks][i], Bf[ks][f], acc[f][i], 0, 0, 0);
+#else       // timing ablation: keep the fragment reads alive without the matrix work
 #pragma unroll
-            for (int i = 0; i < NF; ++i)
-                acc[f][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1[i], B1[f], acc[f][i], 0, 0, 0);
-        // (5) the weights of step k+2 (first read from LDS during step k+1) must have landed; everything issued
-        //     after them may stay in flight: this step's weights, and the raw halo for two more steps
+        for (int i = 0; i < NF; ++i) asm volatile("" ::"v"(A[0][i]), "v"(A[1][i]));
+#pragma unroll
+        for (int f = 0; f < 2; ++f) asm volatile("" ::"v"(Bf[0][f]), "v"(Bf[1][f]));
+#endif
+        // (5) the weights of step k+1 must have landed; everything issued after them may stay in flight: this step's
+        //     weights, and the raw halo (+ coefficients) for two more steps
         const bool h_fly = t <= 1 && more_c;
         if (w_issue) {
-            if (h_fly) wait_vm<WI + HI>(); else wait_vm<WI>();
+            if (h_fly) wait_vm<WI + HI + 1>(); else wait_vm<WI>();
         } else {
-            if (h_fly) wait_vm<HI>(); else wait_vm<0>();
+            if (h_fly) wait_vm<HI + 1>(); else wait_vm<0>();
         }
         wait_lds();
         barrier();
@@ -301,6 +355,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3w_kernel(const sv_geom g, const
     const bool want_stats = a.stats != nullptr && EX == nullptr;
     const int ipix = lane >> 2, cg = lane & 3;
     const int64_t gp0 = (int64_t)gr0 * W + 64 * wave;
+#ifdef SV_W3_NO_EPI
+    if (acc[0][0][0] != 1234.5f) return;
+#endif
 #pragma unroll
     for (int i = 0; i < NF; ++i) {
         const int nl = 32 * i + 8 * cg, n = n0 + nl;
@@ -405,15 +462,14 @@ int launch_w3(const sv_geom* g, const sv_igemm_args* a, hipStream_t s) {
     using C = WCfg<NF, WLOG>;
     const int nT = g->B * g->Hin / C::TR, nNt = g->N / C::BN;
     const int grid = 8 * ((nT + 7) / 8) * nNt;
-    const size_t lds = (size_t)C::OFF_PS + (size_t)g->Cin * 8;
+    const size_t lds = (size_t)C::LDS;
     static bool optin = false;
     if (!optin) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3w_kernel<NF, WLOG, REV>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return sv_check_launch("hipFuncSetAttribute(conv3x3w)");
         optin = true;
     }
-    if (lds > 160 * 1024) return -1;
     sv_prof_begin(s);
     hipLaunchKernelGGL((conv3x3w_kernel<NF, WLOG, REV>), dim3(grid), dim3(256), lds, s, *g, *a);
     sv_prof_end(s);
@@ -442,7 +498,6 @@ int sv_conv3x3w_try(const sv_geom* g, int dtype, const sv_igemm_args* a, hipStre
     if ((g->B * g->Hin) % TR != 0) return 0;
     if ((int64_t)g->B * g->Hin * g->Win * g->ldx * 2 >= ((int64_t)1 << 31)) return 0;
     if ((int64_t)g->N * 9 * g->Cin * 2 >= ((int64_t)1 << 31)) return 0;
-    if ((size_t)g->Cin * 8 + 144 * 1024 > 160 * 1024) return 0;
     // tap order: canonical (forward) or reversed (data gradient)
     const sv_phase& P = g->phase[0];
     bool fwd = true, rev = true;
@@ -452,6 +507,10 @@ int sv_conv3x3w_try(const sv_geom* g, int dtype, const sv_igemm_args* a, hipStre
         rev = rev && P.dy[t] == -dy && P.dx[t] == -dx;
     }
     if (!fwd && !rev) return 0;
+    if (a->pro_scale) {         // the coefficient DMA addresses scale and shift from one base with a 32-bit offset
+        const int64_t d = (const char*)a->pro_shift - (const char*)a->pro_scale;
+        if (d >= ((int64_t)1 << 31) || -d >= ((int64_t)1 << 31)) return 0;
+    }
     if (g->N % 160 == 0) *rc = fwd ? launch_w2<5, false>(g, a, s) : launch_w2<5, true>(g, a, s);
     else *rc = fwd ? launch_w2<4, false>(g, a, s) : launch_w2<4, true>(g, a, s);
     return 1;
