@@ -20,6 +20,7 @@
 //   * epilogue per 32-channel group through a wave-private LDS transpose: 16-byte coalesced residual / raw-tensor
 //     reads and output stores, BatchNorm sums (or activation-backward + BatchNorm-backward sums) in registers.
 // Same sv_geom / packed weights / sv_igemm_args contract as the other conv-like kernels.
+#include <stdio.h>
 #include <stdlib.h>
 
 #include <type_traits>
@@ -64,7 +65,7 @@ struct WCfg {
     static constexpr int OFF_W = 2 * HB, OFF_CO = OFF_W + 3 * WBUF, OFF_SSUM = OFF_CO + 2048,
                          LDS = OFF_SSUM + 2 * BN * 4;
     static constexpr int SCR = 64 * 36 * 4;                 // epilogue transpose scratch per wave
-    static_assert(4 * SCR <= 2 * HB, "epilogue scratch must fit in the halo buffers");
+    static_assert(4 * SCR + 4 * 4096 <= OFF_CO, "epilogue scratch must fit in the halo + weight buffers");
     static_assert(HI <= 6, "transform schedule covers at most 6 slots per thread");
     static_assert(2 * LDS <= 160 * 1024, "two blocks per CU");
 };
@@ -109,6 +110,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3w_kernel(const sv_geom g, const
     const uint32_t costep = has_pro ? 128u : 0u;
 
     for (int c = tid; c < 2 * BN; c += 256) ssum[c] = 0.f;
+#ifdef SV_W3_STAMP
+    const uint64_t st0 = __builtin_amdgcn_s_memtime();
+    const uint64_t rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
 
     // ---- DMA slots (uniform instruction count per wave: the last, partial wave-instruction is shifted back so that it
     //      ends at the end of the image and re-copies a few slots -- same source, same destination) -----------------
@@ -188,18 +193,25 @@ __global__ __launch_bounds__(256, 2) void conv3x3w_kernel(const sv_geom g, const
                 const float* co = reinterpret_cast<const float*>(smem + C::OFF_CO + (c & 1) * 1024 + wave * 256) +
                                   8 * ((qm >> (2 * j)) & 3);
                 const bool ok = (hokm >> j) & 1u;
+                typedef bf16 bf16x2 __attribute__((ext_vector_type(2)));
+                typedef float f32x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
                 for (int hf = 0; hf < 2; ++hf) {               // four channels at a time: few live registers
                     const f32x4 sc = *reinterpret_cast<const f32x4*>(co + 4 * hf);
                     const f32x4 sh = *reinterpret_cast<const f32x4*>(co + 32 + 4 * hf);
-                    bf16x4* p4 = reinterpret_cast<bf16x4*>(ptr) + hf;
-                    const bf16x4 v = *p4;
-                    bf16x4 o;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float u = (float)v[e] * sc[e] + sh[e];
-                        o[e] = ok ? (bf16)fmaxf(u, u * slope) : (bf16)0.f;     // LeakyReLU (0.01) / ReLU (0)
-                    }
+                    uint2* p4 = reinterpret_cast<uint2*>(ptr) + hf;
+                    const uint2 v = *p4;
+                    // bf16 -> f32 is a shift / mask of the packed word
+                    const float x0 = __uint_as_float(v.x << 16), x1 = __uint_as_float(v.x & 0xffff0000u);
+                    const float x2 = __uint_as_float(v.y << 16), x3 = __uint_as_float(v.y & 0xffff0000u);
+                    const float u0 = x0 * sc[0] + sh[0], u1 = x1 * sc[1] + sh[1];
+                    const float u2 = x2 * sc[2] + sh[2], u3 = x3 * sc[3] + sh[3];
+                    const f32x2 a01 = {fmaxf(u0, u0 * slope), fmaxf(u1, u1 * slope)};   // LeakyReLU (0.01) / ReLU (0)
+                    const f32x2 a23 = {fmaxf(u2, u2 * slope), fmaxf(u3, u3 * slope)};
+                    const bf16x2 b01 = __builtin_convertvector(a01, bf16x2), b23 = __builtin_convertvector(a23, bf16x2);
+                    uint2 o;
+                    o.x = ok ? *reinterpret_cast<const uint32_t*>(&b01) : 0u;          // packed select: padding stays zero
+                    o.y = ok ? *reinterpret_cast<const uint32_t*>(&b23) : 0u;
                     *p4 = o;
                 }
             } else if (!((hokm >> j) & 1u)) {
@@ -272,6 +284,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3w_kernel(const sv_geom g, const
     wait_lds();
     barrier();
 
+#ifdef SV_W3_STAMP
+    const uint64_t st1 = __builtin_amdgcn_s_memtime();
+#endif
     // ---- one (chunk, tap) step: weights of step k live in ring slot k % 3 = t % 3 ---------------------------------------
     auto step = [&](int c, auto tc, auto parc) __attribute__((always_inline)) {
         constexpr int t = decltype(tc)::value, par = decltype(parc)::value;
@@ -347,17 +362,50 @@ __global__ __launch_bounds__(256, 2) void conv3x3w_kernel(const sv_geom g, const
         if (c + 1 < nck) chunk(c + 1, I1{});
     }
 
+#ifdef SV_W3_STAMP
+    const uint64_t st2 = __builtin_amdgcn_s_memtime();
+#endif
     // ---- epilogue: per 32-channel group through a wave-private LDS transpose ------------------------------------------
-    float* const scr = reinterpret_cast<float*>(smem + wave * C::SCR);      // [64 pixels][36]
+    // (every wave is past the last barrier: the halo and weight buffers are free)
+    float* const scr = reinterpret_cast<float*>(smem + wave * C::SCR);              // [64 pixels][36]
+    float* const red = reinterpret_cast<float*>(smem + 4 * C::SCR + wave * 4096);   // [4 groups][16 pixel rows][16 sums]
+    static_assert(4 * C::SCR + 4 * 4096 <= C::OFF_CO, "epilogue scratch");
     bf16* const O = reinterpret_cast<bf16*>(a.out);
     const bf16* const R = reinterpret_cast<const bf16*>(a.residual);
     const bf16* const EX = reinterpret_cast<const bf16*>(a.ex);
     const bool want_stats = a.stats != nullptr && EX == nullptr;
+    const bool has_bias = a.bias != nullptr;
     const int ipix = lane >> 2, cg = lane & 3;
     const int64_t gp0 = (int64_t)gr0 * W + 64 * wave;
 #ifdef SV_W3_NO_EPI
     if (acc[0][0][0] != 1234.5f) return;
 #endif
+    // residual / raw-tensor operand of the epilogue: the rows of group i+1 are requested while group i is processed
+    // (one exposed HBM round trip per block instead of one per 32-channel group)
+    // per-channel constants of the block's channels: one cooperative copy into LDS instead of a dependent global
+    // round trip per 32-channel group
+    float* const cst = reinterpret_cast<float*>(smem + 4 * C::SCR + 4 * 4096);      // [5][BN]
+    static_assert(4 * C::SCR + 4 * 4096 + 5 * BN * 4 <= C::OFF_CO, "epilogue scratch");
+    if (has_bias || EX) {
+        for (int c = tid; c < BN; c += 256) {
+            if (has_bias) cst[c] = a.bias[n0 + c];
+            if (EX) {
+                const float rs = a.ex_rstd[n0 + c];
+                cst[BN + c] = a.ex_scale[n0 + c];
+                cst[2 * BN + c] = a.ex_shift[n0 + c];
+                cst[3 * BN + c] = -a.ex_mean[n0 + c] * rs;                         // xhat = x * rstd - mean * rstd
+                cst[4 * BN + c] = rs;
+            }
+        }
+        __syncthreads();
+    }
+    const bf16* const esrc = R ? R : EX;
+    bf16x8 eopn[4];
+    if (esrc) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it)
+            eopn[it] = *reinterpret_cast<const bf16x8*>(esrc + (gp0 + 16 * it + ipix) * g.ldo + n0 + 8 * cg);
+    }
 #pragma unroll
     for (int i = 0; i < NF; ++i) {
         const int nl = 32 * i + 8 * cg, n = n0 + nl;
@@ -368,30 +416,29 @@ __global__ __launch_bounds__(256, 2) void conv3x3w_kernel(const sv_geom g, const
                 const f32x4 v = {acc[f][i][4 * gq], acc[f][i][4 * gq + 1], acc[f][i][4 * gq + 2], acc[f][i][4 * gq + 3]};
                 *reinterpret_cast<f32x4*>(scr + (32 * f + r) * 36 + 8 * gq + 4 * h) = v;
             }
-        float bias[8], esc[8], esh[8], emu[8], ers[8];
+        float bias[8], esc[8], esh[8], ers[8], emr[8];
         auto load8 = [&](const float* p, float (&d)[8]) {
-            const f32x4 lo = *reinterpret_cast<const f32x4*>(p + n), hi = *reinterpret_cast<const f32x4*>(p + n + 4);
+            const f32x4 lo = *reinterpret_cast<const f32x4*>(p + nl), hi = *reinterpret_cast<const f32x4*>(p + nl + 4);
 #pragma unroll
             for (int e = 0; e < 4; ++e) { d[e] = lo[e]; d[e + 4] = hi[e]; }
         };
-#pragma unroll
-        for (int e = 0; e < 8; ++e) bias[e] = 0.f;
-        if (a.bias) load8(a.bias, bias);
+        if (has_bias) load8(cst, bias);
         if (EX) {
-            load8(a.ex_scale, esc);
-            load8(a.ex_shift, esh);
-            load8(a.ex_mean, emu);
-            load8(a.ex_rstd, ers);
+            load8(cst + BN, esc);
+            load8(cst + 2 * BN, esh);
+            load8(cst + 3 * BN, emr);
+            load8(cst + 4 * BN, ers);
         }
         float s1[8], s2[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
         bf16x8 eop[4];
-        if (R || EX) {
-            const bf16* src = R ? R : EX;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) eop[it] = eopn[it];
+        if (esrc && i + 1 < NF) {
 #pragma unroll
             for (int it = 0; it < 4; ++it)
-                eop[it] = *reinterpret_cast<const bf16x8*>(src + (gp0 + 16 * it + ipix) * g.ldo + n);
+                eopn[it] = *reinterpret_cast<const bf16x8*>(esrc + (gp0 + 16 * it + ipix) * g.ldo + n + 32);
         }
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
@@ -401,8 +448,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3w_kernel(const sv_geom g, const
             float vv[8];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                vv[e] = v0[e] + bias[e];
-                vv[e + 4] = v1[e] + bias[e + 4];
+                vv[e] = v0[e];
+                vv[e + 4] = v1[e];
+            }
+            if (has_bias) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) vv[e] += bias[e];
             }
             if (R) {
 #pragma unroll
@@ -412,10 +463,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3w_kernel(const sv_geom g, const
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const float xf = (float)eop[it][e];
-                    const float gv = vv[e] * act_grad(xf * esc[e] + esh[e], a.ex_slope);
+                    const float gv = (xf * esc[e] + esh[e] > 0.f) ? vv[e] : vv[e] * a.ex_slope;
                     vv[e] = gv;
                     s1[e] += gv;
-                    s2[e] += gv * ((xf - emu[e]) * ers[e]);
+                    s2[e] += gv * (xf * ers[e] + emr[e]);
                 }
             } else if (want_stats) {
 #pragma unroll
@@ -427,26 +478,47 @@ __global__ __launch_bounds__(256, 2) void conv3x3w_kernel(const sv_geom g, const
             bf16x8 o;
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] = (bf16)vv[e];
+#ifdef SV_W3_NO_STORE
+            if (vv[0] == 1234.5f)
+#endif
             *reinterpret_cast<bf16x8*>(O + (gp0 + pix) * g.ldo + n) = o;
         }
+#ifdef SV_W3_NO_RED
+        if (s1[0] == 1234.5f) {
+#else
         if (want_stats || EX) {
+#endif
+            // 16 partial sums per lane, 16 lanes per channel group: through LDS -- lane (group cg', sum e') adds the 16
+            // pixel rows of its column (4 b128 stores + 16 b32 loads + 16 adds instead of 64 shuffles + 64 adds)
+            float* mine = red + (cg * 16 + ipix) * 16;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-#pragma unroll
-                for (int o = 4; o < 64; o <<= 1) {
-                    s1[e] += __shfl_xor(s1[e], o);
-                    s2[e] += __shfl_xor(s2[e], o);
-                }
+            for (int q4 = 0; q4 < 2; ++q4) {
+                *reinterpret_cast<f32x4*>(mine + 4 * q4) = f32x4{s1[4 * q4], s1[4 * q4 + 1], s1[4 * q4 + 2], s1[4 * q4 + 3]};
+                *reinterpret_cast<f32x4*>(mine + 8 + 4 * q4) = f32x4{s2[4 * q4], s2[4 * q4 + 1], s2[4 * q4 + 2], s2[4 * q4 + 3]};
             }
-            if (ipix == 0) {
+            const float* col = red + (lane >> 4) * 256 + (lane & 15);
+            float t = 0.f;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    atomicAdd(&ssum[nl + e], s1[e]);
-                    atomicAdd(&ssum[BN + nl + e], s2[e]);
-                }
-            }
+            for (int q = 0; q < 16; ++q) t += col[16 * q];
+            const int e2 = lane & 15;
+            atomicAdd(&ssum[(e2 >> 3) * BN + 32 * i + 8 * (lane >> 4) + (e2 & 7)], t);
         }
     }
+#ifdef SV_W3_STAMP
+    {   // diagnostic build: cycles of prologue / main loop / epilogue of the first 64 blocks instead of the statistics
+        const uint64_t st3 = __builtin_amdgcn_s_memtime();
+        if (tid == 0) {     // (the stats buffer of tools/w3_stamp.py is large enough for 8 floats per block)
+            float* d = a.stats + 8 * blockIdx.x;
+            d[0] = (float)(st1 - st0); d[1] = (float)(st2 - st1); d[2] = (float)(st3 - st2);
+            d[3] = (float)(rt0 & 0xffffff); d[4] = (float)(__builtin_amdgcn_s_memrealtime() & 0xffffff);
+            d[5] = (float)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));    // HW_ID
+        }
+        return;
+    }
+#endif
+#ifdef SV_W3_NO_GATOM
+    if (acc[0][0][0] != 1234.5f) return;
+#endif
     if (want_stats || EX) {
         __syncthreads();
         float* dst = (EX ? a.bsums : a.stats) + (size_t)(blockIdx.x & (a.replicas - 1)) * 2 * g.N;
@@ -469,6 +541,11 @@ int launch_w3(const sv_geom* g, const sv_igemm_args* a, hipStream_t s) {
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return sv_check_launch("hipFuncSetAttribute(conv3x3w)");
         optin = true;
+        if (getenv("SV_W3_OCC")) {
+            int nb = -1;
+            hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(&conv3x3w_kernel<NF, WLOG, REV>), 256, lds);
+            fprintf(stderr, "conv3x3w<%d,%d,%d>: lds %zu B, max active blocks per CU %d (err %d)\n", NF, WLOG, (int)REV, lds, nb, (int)e);
+        }
     }
     sv_prof_begin(s);
     hipLaunchKernelGGL((conv3x3w_kernel<NF, WLOG, REV>), dim3(grid), dim3(256), lds, s, *g, *a);

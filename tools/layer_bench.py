@@ -6,6 +6,7 @@ residual / statistics epilogue, data gradient with the activation-backward epilo
 
 Prints microseconds per launch, TFLOP/s and the fraction of the 2.5 PFLOP/s dense bf16 MFMA peak."""
 import ctypes as C
+import os
 import sys
 
 import torch
@@ -38,7 +39,7 @@ def bench_layer(B, Cin, H, N, what=("fwd", "dgrad", "wgrad")):
     dy = torch.randn(B, H, H, N, device=d).to(bf)
     master = (torch.randn(N, 9, Cin, device=d) / (9 * Cin) ** 0.5).contiguous()
     flops = 2.0 * B * H * H * 9 * Cin * N
-    R = 8
+    R = int(os.environ.get("SV_BENCH_R", "8"))
     res = {}
     if "fwd" in what:
         g = G.conv_like(B, H, H, Cin, N, 3, 1, 1)
