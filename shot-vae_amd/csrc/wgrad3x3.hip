@@ -211,6 +211,177 @@ __global__ __launch_bounds__(256) void wgrad3x3_kernel(const sv_geom g, const wg
     }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// Wide layers (N % 160 == 0: the WRN-28-10 body, MFMA-bound).  With 32 x 32 slabs every block re-stages a dy tile
+// and a halo tile per 36 MFMAs per wave, and the per-CU load path (L2 -> LDS), not the matrix pipe, sets the pace.
+// Here a block owns 160 (n) x 32 (c) x 9 taps with ONE wave per SIMD: wave (wi, wj) owns 80 n x 16 c x 9 taps = 45
+// accumulator tiles (180 registers, all in the accumulation half of the register file), so one 128-pixel tile feeds
+// 4 x 45 MFMAs per wave from 14 transposing fragment reads per 32 pixels.  Same staging / masking / publishing scheme
+// as above (the 32-channel chunks of one pixel range run on one XCD, so the dy re-reads are L2 hits).
+constexpr int LDY = 160 + 8;      // LDS row stride (elements) of the wide dy tile: 336 B = 80 B mod 256, as LDH
+
+__device__ __forceinline__ bf16x8 frag_tr_ld(const bf16* S, int pix_elem_q, int col0, int lane, int ld) {
+    typedef __attribute__((address_space(3))) s16x4 lds_v4;
+    const bf16* a0 = S + pix_elem_q + col0 + 4 * (lane & 3);
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(a0));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(a0 + 4 * ld));
+    union { s16x4 s[2]; bf16x8 b; } u;
+    u.s[0] = lo;
+    u.s[1] = hi;
+    return u.b;
+}
+
+template <int WLOG>
+__global__ __launch_bounds__(256, 1) void wgrad3x3w_kernel(const sv_geom g, const wg3_params p) {
+    constexpr int W = 1 << WLOG, TR = 128 / W, WP = W + 2;
+    constexpr int HP = (TR + 2) * WP;
+    constexpr int YV = 128 * 20, YI = YV / 256;               // dy vectors (8 channels each): 10 per thread
+    constexpr int HV = HP * 4, HI = (HV + 255) / 256;         // halo vectors
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16* Ys = reinterpret_cast<bf16*>(smem);                 // [128][LDY]
+    bf16* halo = Ys + 128 * LDY;                              // [HP][LDH]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int wi = wave >> 1, wj = wave & 1;
+    const int H = g.Hin, BH = g.B * H, nT = BH / TR;
+    const int nC = g.Cin / 32, nNt = g.N / 160, nNC = nC * nNt;
+    const int L = blockIdx.x;
+    int nc, split;
+    if (p.splits % 8 == 0) {          // blocks L, L+8 share an XCD: all slabs of one pixel range on one L2
+        const int xcd = L & 7, slot = L >> 3;
+        nc = slot % nNC;
+        split = (slot / nNC) * 8 + xcd;
+    } else {
+        nc = L % nNC;
+        split = L / nNC;
+    }
+    const int n0 = (nc / nC) * 160, c0 = (nc % nC) * 32;
+    const int t_begin = split * p.tiles_per, t_end = min(nT, t_begin + p.tiles_per);
+    const sv_phase& P = g.phase[0];
+    const uint64_t pdy = pack_taps(P.dy), pdx = pack_taps(P.dx);
+    const bf16* __restrict__ X = reinterpret_cast<const bf16*>(p.x);
+    const bf16* __restrict__ DY = reinterpret_cast<const bf16*>(p.dy);
+    const bool has_pro = p.pro_scale != nullptr;
+
+    bf16x8 zero;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) zero[j] = (bf16)0.f;
+    const int v = tid & 3;
+    f32x4 s0, s1, t0, t1;
+    if (has_pro) {
+        s0 = *reinterpret_cast<const f32x4*>(p.pro_scale + c0 + 8 * v);
+        s1 = *reinterpret_cast<const f32x4*>(p.pro_scale + c0 + 8 * v + 4);
+        t0 = *reinterpret_cast<const f32x4*>(p.pro_shift + c0 + 8 * v);
+        t1 = *reinterpret_cast<const f32x4*>(p.pro_shift + c0 + 8 * v + 4);
+    }
+    int hj[HI], hx[HI], hlds[HI];
+#pragma unroll
+    for (int i = 0; i < HI; ++i) {
+        const int idx = tid + 256 * i;
+        const int pix = min(idx, HV - 1) >> 2;
+        hj[i] = pix / WP - 1;
+        hx[i] = pix - (pix / WP) * WP - 1;
+        hlds[i] = idx < HV ? pix * LDH + 8 * v : -1;
+    }
+    // dy slot i of this thread: pixel (tid + 256 i) / 20, vector (tid + 256 i) % 20; 256 = 12 * 20 + 16
+    const int yp0 = tid / 20, yv0 = tid - yp0 * 20;
+
+    bf16x8 ry[YI], rh[HI];
+    bool hok[HI];
+    auto load_tile = [&](int tile) {
+        const int gr0 = tile * TR;
+#pragma unroll
+        for (int i = 0; i < YI; ++i) {
+            int vv = yv0 + 16 * i, pp = yp0 + 12 * i;
+            pp += vv / 20;
+            vv = vv % 20;
+            ry[i] = *reinterpret_cast<const bf16x8*>(DY + ((int64_t)gr0 * W + pp) * g.ldo + n0 + 8 * vv);
+        }
+#pragma unroll
+        for (int i = 0; i < HI; ++i) {
+            const int gr = gr0 + hj[i], x = hx[i];
+            hok[i] = (unsigned)x < (unsigned)W && (unsigned)gr < (unsigned)BH;
+            const int grc = min(max(gr, 0), BH - 1), xc = min(max(x, 0), W - 1);
+            rh[i] = *reinterpret_cast<const bf16x8*>(X + ((int64_t)grc * W + xc) * g.ldx + c0 + 8 * v);
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < YI; ++i) {
+            int vv = yv0 + 16 * i, pp = yp0 + 12 * i;
+            pp += vv / 20;
+            vv = vv % 20;
+            *reinterpret_cast<bf16x8*>(Ys + pp * LDY + 8 * vv) = ry[i];
+        }
+#pragma unroll
+        for (int i = 0; i < HI; ++i) {
+            bf16x8 o = rh[i];
+            if (has_pro) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float u0 = (float)rh[i][j] * s0[j] + t0[j], u1 = (float)rh[i][j + 4] * s1[j] + t1[j];
+                    o[j] = (bf16)fmaxf(u0, u0 * p.pro_slope);
+                    o[j + 4] = (bf16)fmaxf(u1, u1 * p.pro_slope);
+                }
+            }
+            if (hlds[i] >= 0) *reinterpret_cast<bf16x8*>(halo + hlds[i]) = hok[i] ? o : zero;
+        }
+    };
+
+    f32x4 acc[5][9];
+#pragma unroll
+    for (int a = 0; a < 5; ++a)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc[a][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    if (t_begin < t_end) load_tile(t_begin);
+    for (int tile = t_begin; tile < t_end; ++tile) {
+        store_tile();
+        __syncthreads();
+        if (tile + 1 < t_end) load_tile(tile + 1);        // in flight while this tile is on the MFMAs
+        const int gr0 = tile * TR;
+#pragma unroll
+        for (int kc = 0; kc < 4; ++kc) {
+            // lane addresses pixel pq = 32*kc + 8*fq + q (q = fr>>2) of the tile (and pq + 4)
+            const int pq = 32 * kc + 8 * fq + (fr >> 2);
+            const int jrow = pq >> WLOG, xcol = pq & (W - 1);
+            const int yrow = (gr0 + jrow) & (H - 1);    // the lane's 8 k-pixels share this image row
+            bf16x8 fy[5];
+#pragma unroll
+            for (int a = 0; a < 5; ++a) fy[a] = frag_tr_ld(Ys, pq * LDY, 80 * wi + 16 * a, lane, LDY);
+            const int hbase = ((jrow + 1) * WP + xcol + 1) * LDH;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int dy = tap_off(pdy, t), dx = tap_off(pdx, t);
+                const bool ok = !((dy < 0 && yrow == 0) || (dy > 0 && yrow == H - 1));
+                bf16x8 fx = frag_tr(halo, hbase + (dy * WP + dx) * LDH, 16 * wj, lane);
+                fx = ok ? fx : zero;
+#pragma unroll
+                for (int a = 0; a < 5; ++a) acc[a][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fy[a], fx, acc[a][t], 0, 0, 0);
+            }
+        }
+        __syncthreads();          // everyone is done reading before the next tile overwrites LDS
+    }
+
+    // ---- publish: D layout = lane holds c = c0 + 16*wj + fr, n = n0 + 80*wi + 16*a + 4*fq + r --------------------
+    const int64_t slab = (int64_t)g.N * g.T_orig * g.Cin;
+    float* dst = p.ws ? p.ws + (int64_t)split * slab : p.dw;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int to = P.torig[t];
+#pragma unroll
+        for (int a = 0; a < 5; ++a)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float* o = dst + ((int64_t)(n0 + 80 * wi + 16 * a + 4 * fq + r) * g.T_orig + to) * g.Cin + c0 + 16 * wj + fr;
+                if (p.ws) *o = acc[a][t][r];
+                else atomicAdd(o, acc[a][t][r]);
+            }
+    }
+}
+
 // dw[i] += sum_s ws[s][i].  blockIdx.y = group of slabs (so that small slabs x many splits still fill
 // the chip); with more than one group the groups meet in dw through float atomics.
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* ws, int splits, int64_t n, float* dw) {
@@ -248,6 +419,32 @@ int launch(const sv_geom* g, const wg3_params& p, hipStream_t s) {
     return sv_check_launch("sv_wgrad(3x3)");
 }
 
+template <int WLOG>
+int launch_wide(const sv_geom* g, const wg3_params& p, hipStream_t s) {
+    constexpr int W = 1 << WLOG, TR = 128 / W;
+    const int nNC = (g->N / 160) * (g->Cin / 32);
+    const int grid = p.splits * nNC;
+    const size_t lds = (size_t)(128 * LDY + (TR + 2) * (W + 2) * LDH) * 2;
+    static bool optin = false;
+    if (!optin) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3x3w_kernel<WLOG>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return sv_check_launch("hipFuncSetAttribute(wgrad3x3w)");
+        optin = true;
+    }
+    sv_prof_begin(s);
+    hipLaunchKernelGGL((wgrad3x3w_kernel<WLOG>), dim3(grid), dim3(256), lds, s, *g, p);
+    sv_prof_end(s);
+    if (p.ws) {
+        const int64_t n = (int64_t)g->N * g->T_orig * g->Cin;
+        const unsigned gx = (unsigned)((n / 4 + 255) / 256);
+        int groups = 1;
+        while (groups * 2 * 16 <= p.splits && gx * groups * 2 <= 1024) groups *= 2;
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3(gx, groups), dim3(256), 0, s, p.ws, p.splits, n, p.dw);
+    }
+    return sv_check_launch("sv_wgrad(3x3 wide)");
+}
+
 }  // namespace
 
 // Returns 1 and sets *rc when the geometry is a stride-1 3x3 convolution this kernel covers.
@@ -265,6 +462,26 @@ int sv_wgrad3x3_try(const sv_geom* g, int dtype, const void* x, const float* pro
     wg3_params p;
     p.x = x; p.pro_scale = pro_scale; p.pro_shift = pro_shift; p.pro_slope = pro_slope; p.dy = dy; p.dw = dw;
     const int nT = g->B * g->Hin / TR;
+    static const bool no_wide = getenv("SV_NO_WGRAD3X3W") != nullptr;
+    if (!no_wide && dtype == SV_BF16 && g->N % 160 == 0 && g->Cin >= 96) {
+        // wide layers: 160 x 32 slabs, one block (one wave per SIMD) per CU
+        const int nNCw = (g->N / 160) * (g->Cin / 32);
+        int splits = (256 + nNCw - 1) / nNCw;
+        if (splits > nT) splits = nT;
+        if (splits >= 8) splits = splits / 8 * 8;
+        if (splits < 1) splits = 1;
+        p.tiles_per = (nT + splits - 1) / splits;
+        if (splits < 8) splits = (nT + p.tiles_per - 1) / p.tiles_per;
+        p.splits = splits;
+        const int64_t needw = (int64_t)splits * g->N * g->T_orig * g->Cin;
+        p.ws = (ws && ws_elems >= needw && splits > 1) ? ws : nullptr;
+        switch (g->Win) {
+            case 32: *rc = launch_wide<5>(g, p, s); break;
+            case 16: *rc = launch_wide<4>(g, p, s); break;
+            default: *rc = launch_wide<3>(g, p, s); break;
+        }
+        return 1;
+    }
     const int nNC = (g->N / 32) * (g->Cin / 32);
     // ~four persistent blocks per CU (SV_WG3_BLOCKS overrides); every block should still see a few tiles
     static const int target = getenv("SV_WG3_BLOCKS") ? atoi(getenv("SV_WG3_BLOCKS")) : 512;

@@ -231,7 +231,9 @@ def test_gemm_ragged_batch(dt):
     assert rel(sums[N:], (y * y).sum(0)) < max(tol, 1e-3) * 3
 
 
-WG_CASES = CONV_CASES + [(40, 16, 16, 32, 3, 1, 1), (16, 32, 32, 32, 3, 1, 1), (32, 64, 64, 16, 3, 1, 1)]
+WG_CASES = CONV_CASES + [(40, 16, 16, 32, 3, 1, 1), (16, 32, 32, 32, 3, 1, 1), (32, 64, 64, 16, 3, 1, 1),
+                         # wide layers (160 x 32 slabs, wgrad3x3w): several splits, two channel tiles, all image sizes
+                         (16, 160, 160, 32, 3, 1, 1), (8, 96, 320, 16, 3, 1, 1), (32, 160, 160, 8, 3, 1, 1)]
 
 
 @pytest.mark.parametrize("dt,use_tr", [("f32", 0), ("bf16", 0), ("bf16", 1)])
@@ -251,7 +253,7 @@ def test_conv_wgrad(dt, use_tr, case):
     xd, dyd = nhwc(x).to(d, tdt), nhwc(dy).to(d, tdt)
     sc, sh = scale.to(d), shift.to(d)
     dw = torch.zeros(N, k * k, Cin, device=d)
-    ws = torch.full((4 * 1024 * 1024,), float("nan"), device=d)      # workspace contents are irrelevant on entry
+    ws = torch.full((8 * 1024 * 1024,), float("nan"), device=d)      # workspace contents are irrelevant on entry
     for it in range(2):   # accumulates: two calls == 2x; once with and once without the slab workspace
         L.call("sv_wgrad", C.byref(g), code, p(xd), p(sc), p(sh), 0.01, p(dyd), p(dw), 0, use_tr,
                p(ws) if it else None, ws.numel() if it else 0, st())
