@@ -69,6 +69,23 @@ def cpu_baseline(net, K):
             "sample": "%s B_l=B_u=%d fp32 torch-CPU oracle, 2 timed steps (%.2f s/step)" % (net, B, t)}
 
 
+def pmc_traffic(tag, a):
+    """HBM bytes per launch of kernel `tag` from the PMC counters.  A counter pass cannot run inside this process (and a
+    GPU-initialised process must not start a profiler), so the per-launch traffic of the conv-like kernels at the
+    headline shapes is collected by tools/pmc_traffic.py (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes,
+    gfx950 correction applied) and committed under profiles/; it is deterministic for a given kernel and shape."""
+    import glob
+    if a.dtype != "bf16" or a.batch != 512:
+        return None, "no PMC profile for this batch / dtype"
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")))
+    if not files:
+        return None, "profiles/*pmc_traffic.json missing"
+    tab = json.load(open(files[-1]))
+    if tag not in tab:
+        return None, "kernel not in " + os.path.basename(files[-1])
+    return tab[tag]["traffic_bytes"], "profiles/%s: %s" % (os.path.basename(files[-1]), tab[tag]["formula"])
+
+
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -136,7 +153,10 @@ def main():
         dt = float(t)
     assert torch.isfinite(ls).all() and torch.isfinite(lu).all(), "non-finite loss"
     images = 2 * B * world * a.steps
-    out = {"metric": "images/sec/step WRN-28-2 SHOT-VAE CIFAR-10 bs512", "value": round(images / dt, 1),
+    headline = a.net == "wideresnet-28-2" and K == 10 and B == 512
+    metric = "images/sec/step WRN-28-2 SHOT-VAE CIFAR-10 bs512" if headline else \
+        "images/sec/step %s SHOT-VAE K=%d bs%d (not the BASELINE.json headline config)" % (a.net, K, B)
+    out = {"metric": metric, "value": round(images / dt, 1),
            "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
            "ms_per_step": round(1000 * dt / a.steps, 3), "higher_is_better": True, "scaling": "weak",
            "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
@@ -180,7 +200,8 @@ def main():
                 ach = d["flops"] / (d["avg_us"] * 1e-6) / 1e12
                 roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak_t, "unit": "TFLOP/s",
                         "frac": round(ach / peak_t, 4)}
-            roof.update(traffic=None, kernel=d["name"], avg_us=round(d["avg_us"], 2), launches_per_step=d["launches"] // a.prof_steps,
+            traffic, traffic_src = pmc_traffic(d["name"], a)
+            roof.update(traffic=traffic, traffic_source=traffic_src, kernel=d["name"], avg_us=round(d["avg_us"], 2), launches_per_step=d["launches"] // a.prof_steps,
                         algorithmic_bytes=d["bytes"], algorithmic_flops=d["flops"],
                         share_of_conv_kernel_time=round(d["total_ms"] / tot, 3),
                         conv_kernel_ms_per_step=round(tot / a.prof_steps, 3))

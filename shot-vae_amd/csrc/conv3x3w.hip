@@ -573,6 +573,11 @@ int sv_conv3x3w_try(const sv_geom* g, int dtype, const sv_igemm_args* a, hipStre
     if (g->N % 160 != 0 && g->N % 128 != 0) return 0;
     const int TR = 256 / g->Win;
     if ((g->B * g->Hin) % TR != 0) return 0;
+    // 256-pixel x 128/160-channel tiles: below one block per CU the small-tile kernels of conv3x3.hip are faster
+    // (measured: WRN-28-2 stage 3, 128 blocks, 38 vs 24 us); SV_W3_MIN_BLOCKS overrides (tests use 1)
+    const char* mb = getenv("SV_W3_MIN_BLOCKS");              // (read per call: the tests toggle it)
+    const int min_blocks = mb ? atoi(mb) : 256;
+    if ((int64_t)(g->B * g->Hin / TR) * (g->N / (g->N % 160 == 0 ? 160 : 128)) < min_blocks) return 0;
     if ((int64_t)g->B * g->Hin * g->Win * g->ldx * 2 >= ((int64_t)1 << 31)) return 0;
     if ((int64_t)g->N * 9 * g->Cin * 2 >= ((int64_t)1 << 31)) return 0;
     // tap order: canonical (forward) or reversed (data gradient)

@@ -18,7 +18,7 @@ from shot_vae_amd import geometry as G      # noqa: E402
 PEAK = 2.5e15
 
 
-def timed(fn, iters=20, warm=3):
+def timed(fn, iters=int(os.environ.get("SV_BENCH_ITERS", "20")), warm=int(os.environ.get("SV_BENCH_WARM", "3"))):
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()

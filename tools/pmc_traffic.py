@@ -1,0 +1,91 @@
+"""HBM traffic of the dominant conv-like kernels from the PMC counters (run ON the GPU box, from the repo root):
+
+    python tools/pmc_traffic.py [out.json]
+
+For every layer in LAYERS it runs tools/layer_bench.py (that one kernel, a few launches) under rocprofv3 in two separate
+counter passes -- FETCH_SIZE and WRITE_SIZE do not fit into the TCC slots of one pass -- with --kernel-trace only
+(MI355X_MICROARCH.md, "rocprofv3 PMC slots" / "HBM"), and prices the traffic per launch as
+
+    traffic = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 bytes
+
+(FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE tallies 128-byte requests of a wide coalesced stream at 64 bytes,
+hence the factor 2; WRITE_SIZE is exact for 16-byte-per-lane stores and float atomics).  This process never touches the
+GPU itself; the profiled program is started directly after `--`.  bench.py reads the JSON (profiles/rNN_pmc_traffic.json)
+to fill `roofline.traffic` for the kernel it finds dominant."""
+import csv
+import glob
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# tag (bench.py's name of the launch) -> (B, Cin, H, N, kind, substrings of the kernel names that make up one launch)
+LAYERS = {
+    "wgrad:conv3x3_32x32_s1": (512, 32, 32, 32, "wgrad", ["wgrad3x3_kernel", "slab_reduce_kernel"]),
+    "fwd:conv3x3_32x32_s1": (512, 32, 32, 32, "fwd", ["conv3x3p_kernel"]),
+    "dgrad:conv3x3_32x32_s1": (512, 32, 32, 32, "dgrad", ["conv3x3p_kernel"]),
+    "wgrad:conv3x3_64x64_s1": (512, 64, 16, 64, "wgrad", ["wgrad3x3_kernel", "slab_reduce_kernel"]),
+    "fwd:conv3x3_64x64_s1": (512, 64, 16, 64, "fwd", ["conv3x3p_kernel"]),
+    "dgrad:conv3x3_64x64_s1": (512, 64, 16, 64, "dgrad", ["conv3x3p_kernel"]),
+    "wgrad:conv3x3_128x128_s1": (512, 128, 8, 128, "wgrad", ["wgrad3x3_kernel", "slab_reduce_kernel"]),
+    "fwd:conv3x3_128x128_s1": (512, 128, 8, 128, "fwd", ["conv3x3_kernel", "conv3x3w_kernel"]),
+    "dgrad:conv3x3_128x128_s1": (512, 128, 8, 128, "dgrad", ["conv3x3_kernel", "conv3x3w_kernel"]),
+    "fwd:conv3x3_160x160_s1": (512, 160, 32, 160, "fwd", ["conv3x3w_kernel"]),
+    "wgrad:conv3x3_160x160_s1": (512, 160, 32, 160, "wgrad", ["wgrad3x3w_kernel", "slab_reduce_kernel"]),
+}
+ITERS, WARM = 4, 1
+
+
+def one_pass(tag, counter, outdir):
+    B, Cin, H, N, kind, names = LAYERS[tag]
+    d = os.path.join(outdir, tag.replace(":", "_") + "_" + counter)
+    env = dict(os.environ, SV_BENCH_ITERS=str(ITERS), SV_BENCH_WARM=str(WARM))
+    cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--",
+           "python3", os.path.join(ROOT, "tools", "layer_bench.py"), str(B), str(Cin), str(H), str(N), kind]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, cwd=ROOT)
+    if r.returncode != 0:
+        raise RuntimeError("rocprofv3 failed: " + r.stderr[-2000:])
+    files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+    assert files, "no counter_collection.csv under " + d
+    per = {}            # kernel-name substring -> list of counter values (one per dispatch, in order)
+    for row in csv.DictReader(open(files[0])):
+        if row.get("Counter_Name") != counter:
+            continue
+        for nm in names:
+            if nm in row["Kernel_Name"]:
+                per.setdefault(nm, []).append(float(row["Counter_Value"]))
+    total = 0.0
+    for nm, vals in per.items():
+        n_launch = ITERS + WARM
+        per_launch = len(vals) // n_launch           # dispatches of this kernel per launch of the layer
+        assert per_launch >= 1 and len(vals) == per_launch * n_launch, (tag, nm, len(vals))
+        total += sum(vals[per_launch * WARM:]) / ITERS
+    assert per, "kernels %s not found in %s" % (names, files[0])
+    return total, sorted(per)
+
+
+def main():
+    out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "pmc_traffic.json")
+    outdir = os.path.join(ROOT, "gpurun_out", "pmc")
+    os.makedirs(outdir, exist_ok=True)
+    res = {}
+    for tag in LAYERS:
+        B, Cin, H, N, kind, _ = LAYERS[tag]
+        fetch, k1 = one_pass(tag, "FETCH_SIZE", outdir)
+        write, _ = one_pass(tag, "WRITE_SIZE", outdir)
+        es = 2
+        if kind == "wgrad":
+            alg = es * B * H * H * (Cin + N) + 4 * 9 * Cin * N
+        else:       # forward: x, y, residual (+ weights); data gradient: dy, dx, the raw tensor of the activation backward
+            alg = es * B * H * H * (Cin + 2 * N) + es * 9 * Cin * N
+        res[tag] = {"FETCH_SIZE_KiB": fetch, "WRITE_SIZE_KiB": write,
+                    "traffic_bytes": (2 * fetch + write) * 1024, "algorithmic_bytes": alg,
+                    "kernels": k1, "shape": {"B": B, "Cin": Cin, "H": H, "N": N, "kind": kind},
+                    "formula": "(2*FETCH_SIZE + WRITE_SIZE)*1024, per launch, mean of %d launches" % ITERS}
+        print(tag, json.dumps(res[tag]), flush=True)
+    json.dump(res, open(out, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
