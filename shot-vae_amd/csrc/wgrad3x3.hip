@@ -28,6 +28,7 @@ struct wg3_params {
     float* dw;
     float* ws;                    // [splits][N*T_orig*Cin] partial slabs (plain stores) or NULL (atomics into dw)
     int splits, tiles_per;        // 128-pixel tiles: range [split*tiles_per, ...)
+    int unit;                     // wide kernel: channel chunks per XCD-affinity unit (0: plain block order)
 };
 
 // 8 consecutive pixels (k = 8g + j) of one (shifted) image row, 16 channels starting at col0: k-major
@@ -249,10 +250,17 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3w_kernel(const sv_geom g, cons
     const int nC = g.Cin / 32, nNt = g.N / 160, nNC = nC * nNt;
     const int L = blockIdx.x;
     int nc, split;
-    if (p.splits % 8 == 0) {          // blocks L, L+8 share an XCD: all slabs of one pixel range on one L2
+    if (p.unit > 0) {
+        // XCD affinity for any split count: an affinity unit = p.unit channel chunks of one (pixel range, n tile); the
+        // units are dealt round-robin to the XCDs (blocks L, L+8, ... share an L2), so the chunk blocks that re-read
+        // one dy range run on one XCD and only the first of them goes past its L2
         const int xcd = L & 7, slot = L >> 3;
-        nc = slot % nNC;
-        split = (slot / nNC) * 8 + xcd;
+        const int U = (slot / p.unit) * 8 + xcd, cu = slot % p.unit;
+        const int upg = nC / p.unit;                  // units per (split, n tile)
+        const int grp = U / upg, chunk = (U % upg) * p.unit + cu;
+        split = grp / nNt;
+        if (split >= p.splits) return;
+        nc = (grp % nNt) * nC + chunk;
     } else {
         nc = L % nNC;
         split = L / nNC;
@@ -422,8 +430,8 @@ int launch(const sv_geom* g, const wg3_params& p, hipStream_t s) {
 template <int WLOG>
 int launch_wide(const sv_geom* g, const wg3_params& p, hipStream_t s) {
     constexpr int W = 1 << WLOG, TR = 128 / W;
-    const int nNC = (g->N / 160) * (g->Cin / 32);
-    const int grid = p.splits * nNC;
+    const int nC = g->Cin / 32, nNt = g->N / 160;
+    const int grid = p.unit > 0 ? 8 * ((p.splits * nNt * (nC / p.unit) + 7) / 8) * p.unit : p.splits * nNt * nC;
     const size_t lds = (size_t)(128 * LDY + (TR + 2) * (W + 2) * LDH) * 2;
     static bool optin = false;
     if (!optin) {
@@ -461,18 +469,29 @@ int sv_wgrad3x3_try(const sv_geom* g, int dtype, const void* x, const float* pro
     if ((g->B * g->Hin) % TR != 0) return 0;
     wg3_params p;
     p.x = x; p.pro_scale = pro_scale; p.pro_shift = pro_shift; p.pro_slope = pro_slope; p.dy = dy; p.dw = dw;
+    p.unit = 0;
     const int nT = g->B * g->Hin / TR;
     static const bool no_wide = getenv("SV_NO_WGRAD3X3W") != nullptr;
     if (!no_wide && dtype == SV_BF16 && g->N % 160 == 0 && g->Cin >= 96) {
-        // wide layers: 160 x 32 slabs, one block (one wave per SIMD) per CU
-        const int nNCw = (g->N / 160) * (g->Cin / 32);
-        int splits = (256 + nNCw - 1) / nNCw;
-        if (splits > nT) splits = nT;
-        if (splits >= 8) splits = splits / 8 * 8;
-        if (splits < 1) splits = 1;
-        p.tiles_per = (nT + splits - 1) / splits;
-        if (splits < 8) splits = (nT + p.tiles_per - 1) / p.tiles_per;
+        // wide layers: 160 x 32 slabs, one block (one wave per SIMD) per CU.  Pick the split count and the affinity unit
+        // (a divisor of the chunk count) that minimise rounds-of-32-CUs-per-XCD x tiles per block
+        const int nC = g->Cin / 32, nNt = g->N / 160;
+        int splits = 1, unit = 0;
+        int64_t best = -1;
+        for (int sp = 1; sp <= nT && sp <= 128; ++sp) {
+            const int tp = (nT + sp - 1) / sp;
+            if ((nT + tp - 1) / tp != sp) continue;               // no empty splits
+            for (int u = 1; u <= nC && u <= 32; ++u) {
+                if (nC % u) continue;
+                const int units = sp * nNt * (nC / u);
+                const int per_xcd = (units + 7) / 8 * u;
+                const int64_t cost = (int64_t)((per_xcd + 31) / 32) * tp * 64 - u;     // ties: the larger unit
+                if (best < 0 || cost < best) { best = cost; splits = sp; unit = u; }
+            }
+        }
         p.splits = splits;
+        p.unit = unit;
+        p.tiles_per = (nT + splits - 1) / splits;
         const int64_t needw = (int64_t)splits * g->N * g->T_orig * g->Cin;
         p.ws = (ws && ws_elems >= needw && splits > 1) ? ws : nullptr;
         switch (g->Win) {
