@@ -42,8 +42,6 @@ def parse():
     ap.add_argument("--graph", type=int, default=1, help="1 (default): replay the step from a captured hipGraph")
     ap.add_argument("--overlap", type=int, default=1,
                     help="1 (default): labelled / unlabelled branches of the step on two HIP streams; 0: one stream")
-    ap.add_argument("--streams", type=int, default=2, choices=[2, 4],
-                    help="4: all four forwards (and their backwards) on their own HIP streams")
     return ap.parse_args()
 
 
@@ -123,7 +121,7 @@ def main():
     graphed, graph_note = None, "eager"
     if a.graph and a.overlap:
         try:
-            graphed = GraphedTrainStep(model, elbo, cls, opt, il, ll, iu, sch, distributed=world > 1, streams=a.streams)
+            graphed = GraphedTrainStep(model, elbo, cls, opt, il, ll, iu, sch, distributed=world > 1)
             graph_note = "hipGraph replay"
         except Exception as e:        # capture unsupported on this stack: run eagerly, say so in the output
             graphed, graph_note = None, "eager (graph capture failed: %s)" % type(e).__name__
@@ -165,8 +163,7 @@ def main():
            "config": {"workload": "SHOT-VAE train step (4 fwd + 2 bwd + SGD) %s K=%d ldc=128, B_l=B_u=%d per GPU, "
                                   "synthetic 3x32x32 in HBM, random init" % (a.net, K, B),
                       "global_batch": 2 * B * world, "parallelism": "dp%d" % world,
-                      "schedule": ("four-stream (the four forwards and their backwards side by side)" if a.streams == 4 else
-                                   "two-stream (labelled || unlabelled branch)") if a.overlap else "single stream",
+                      "schedule": "two-stream (labelled || unlabelled branch)" if a.overlap else "single stream",
                       "launch": graph_note,
                       "collective": "1 RCCL all-reduce of the flat fp32 gradient buffer per step" if world > 1 else "none"},
            "loss_sup": round(float(ls), 5), "loss_unsup": round(float(lu), 5)}

@@ -124,81 +124,6 @@ def train_step_overlapped(model, elbo_criterion, cls_criterion, optimizer, image
     return loss_sup.detach(), loss_unsup.detach()
 
 
-def train_step_overlapped4(model, elbo_criterion, cls_criterion, optimizer, image_l, label_l, image_u, sch,
-                           epsilon=0.1, distributed=False, device_rng=None):
-    """Same step with ALL FOUR forwards in flight at once, one HIP stream each.  The mixed forwards (2) and (4) only
-    need the mixed IMAGES (mixup.py:22,36), which depend on the inputs, the pairing and lambda -- not on the outputs
-    of (1) / (3); those outputs are mixed later, for the posterior targets of the two losses.  autograd runs every
-    forward's backward on that forward's stream, so the two backward passes of each loss overlap as well.  The step
-    is a few hundred small, latency-bound kernels per forward: four chains fill each other's gaps (and the launch
-    gaps of a replayed hipGraph) where two could not.  Pairings / lambdas must come from `device_rng` (drawn up
-    front); BN running statistics are deferred per forward and applied in the reference's order, as before."""
-    from .mixup import _lerp
-    assert device_rng is not None, "the four-stream schedule draws pairings and lambdas up front: pass a DeviceRng"
-    K = model._plan.K
-    cur = torch.cuda.current_stream()
-    st = getattr(model, "_branch_streams4", None)
-    if st is None:
-        st = model._branch_streams4 = tuple(torch.cuda.Stream() for _ in range(4))
-    eng = model._engine
-    eng.ensure_packs()
-    model._attach_grads()
-    lam_l, lam_u = device_rng.next_lams()
-    idx_l = device_permutation(image_l.size(0), image_l.device).long().contiguous()
-    idx_u = device_permutation(image_u.size(0), image_u.device).long().contiguous()
-    for s in st:
-        s.wait_stream(cur)
-    with torch.cuda.stream(st[0]):
-        onehot_l = one_hot(label_l, K)
-        eng.defer_slot = 0
-        rec1, mu1, ls1, la1 = model(image_l, disc_label=label_l)
-    with torch.cuda.stream(st[1]):
-        with torch.no_grad():
-            sm_img = _lerp(image_l, idx_l, lam_l, False)
-            sm_label = label_l[idx_l]
-            sm_onehot = one_hot(sm_label, K)
-        eng.defer_slot = 1
-        rec2, mu2, ls2, la2, *_ = model(sm_img, True, label_l, sm_label, lam_l)
-    with torch.cuda.stream(st[2]):
-        eng.defer_slot = 2
-        rec3, mu3, ls3, la3 = model(image_u)
-    with torch.cuda.stream(st[3]):
-        with torch.no_grad():
-            mx_img = _lerp(image_u, idx_u, lam_u, False)
-        eng.defer_slot = 3
-        rec4, mu4, ls4, la4, *_ = model(mx_img)
-    eng.defer_slot = None
-    lam_l0 = lam_l.reshape(())
-    with torch.cuda.stream(st[0]):
-        recon_l, klc_l, kld_l = elbo_criterion(image_l, rec1, mu1, ls1, la1)
-        elbo_l = recon_l + sch["kl_beta_c"] * torch.abs(klc_l - sch["cmi"]) + sch["kl_beta_d"] * torch.abs(kld_l - sch["dmi"])
-        with torch.no_grad():           # posterior targets: the outputs of (1) mixed with the same pairing / lambda
-            sm_mu, sm_sigma = _lerp(mu1, idx_l, lam_l, False), _lerp(ls1, idx_l, lam_l, True)
-        st[0].wait_stream(st[1])
-        disc_post_l = lam_l0 * cls_criterion(la2, onehot_l) + (1 - lam_l0) * cls_criterion(la2, sm_onehot)
-        elbo_l = elbo_l + sch["kl_beta_c"] * sch["pwm"] * continuous_posterior_loss(mu2, ls2, sm_mu, sm_sigma)
-        loss_sup = sch["ew"] * elbo_l + disc_post_l
-        loss_sup.backward()
-    with torch.cuda.stream(st[2]):
-        recon_u, klc_u, kld_u = elbo_criterion(image_u, rec3, mu3, ls3, la3)
-        elbo_u = recon_u + sch["kl_beta_c"] * torch.abs(klc_u - sch["cmi"]) + sch["kl_beta_d"] * torch.abs(kld_u - sch["dmi"])
-        with torch.no_grad():
-            mx_mu, mx_sigma = _lerp(mu3, idx_u, lam_u, False), _lerp(ls3, idx_u, lam_u, True)
-            mx_alpha = _lerp(la3, idx_u, lam_u, True)
-        st[2].wait_stream(st[3])
-        elbo_u = elbo_u + sch["kl_beta_c"] * sch["pwm"] * continuous_posterior_loss(mu4, ls4, mx_mu, mx_sigma)
-        loss_unsup = sch["ew"] * elbo_u + sch["ucw"] * cls_criterion(la4, mx_alpha)
-        loss_unsup.backward()
-    for s in st:
-        cur.wait_stream(s)
-    eng.apply_pending()
-    if optimizer is not None:
-        scale = dp.all_reduce_gradients(model.flat_parameters()[1]) if distributed else 1.0
-        optimizer.step(scale) if hasattr(optimizer, "_steps") else optimizer.step()
-        optimizer.zero_grad()
-    return loss_sup.detach(), loss_unsup.detach()
-
-
 def train_step(model, elbo_criterion, cls_criterion, optimizer, image_l, label_l, image_u, sch, epsilon=0.1,
                optimal_match=False, distributed=False, return_outputs=False):
     """One step: 4 forwards, 2 backwards, (all-reduce,) SGD.  Inputs are device tensors.
@@ -260,8 +185,7 @@ class GraphedTrainStep:
     Needs rng="device".  Re-capture (build a new object) when the per-epoch schedule scalars change."""
 
     def __init__(self, model, elbo_criterion, cls_criterion, optimizer, image_l, label_l, image_u, sch, epsilon=0.1,
-                 distributed=False, seed=0, warmup=2, streams=2):
-        self.streams = streams
+                 distributed=False, seed=0, warmup=2):
         assert model.rng == "device", "graph capture needs device-side noise: VariationalAutoEncoder(..., rng='device')"
         self.model, self.opt, self.distributed = model, optimizer, distributed
         self.il, self.ll, self.iu = image_l.clone(), label_l.clone(), image_u.clone()
@@ -289,8 +213,8 @@ class GraphedTrainStep:
         # nothing to the two-stream schedule, measured), so the captured body keeps wgrads on the branch streams
         eng.wgrad_side_stream = False
         try:
-            fn = train_step_overlapped4 if self.streams == 4 else train_step_overlapped
-            return fn(self.model, e, c, None, self.il, self.ll, self.iu, sch, epsilon=eps, device_rng=self.rng)
+            return train_step_overlapped(self.model, e, c, None, self.il, self.ll, self.iu, sch, epsilon=eps,
+                                         device_rng=self.rng)
         finally:
             eng.wgrad_side_stream = keep
 
