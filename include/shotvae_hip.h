@@ -186,6 +186,15 @@ int sv_sgd(float* p, const float* g, float* v, int64_t n, float lr, float moment
 int sv_nchw_to_nhwc(int dtype, const float* in, int B, int C, int H, int W, int Cpad, void* out, void* stream);
 /* NHWC `dtype` [B,H,W,ld] (first C channels) -> NCHW fp32                                           */
 int sv_nhwc_to_nchw(int dtype, const void* in, int B, int C, int H, int W, int ld, float* out, void* stream);
+/* ---- K21 device-side input pipeline (lib/dataloader.py:58-70: Pad(4, reflect) -> RandomHorizontalFlip ->
+ * RandomCrop(H) -> ToTensor) fused with the batch gather: sample b = data[index[b]] (uint8 HWC, [N][H][W][C]),
+ * reflect-padded by `pad`, flipped if params[3b+2] != 0, cropped at (params[3b], params[3b+1]) in the padded image
+ * (0 <= offset <= 2*pad), scaled by 1/255.  nhwc_cpad == 0: out = fp32 NCHW [B][C][H][W] (the model's API input);
+ * nhwc_cpad > 0: out = `dtype` NHWC [B][H][W][nhwc_cpad], channels >= C zero (the stem convolution's input layout).
+ * params == NULL: no augmentation (evaluation: ToTensor only).                                                  */
+int sv_augment(int dtype, const uint8_t* data, const int64_t* index, const int32_t* params, int B, int H, int W, int C,
+               int pad, int nhwc_cpad, void* out, void* stream);
+
 /* master fp32 [N][T_orig][C] -> packed `dtype` per phase [n'][ntap][c'] (transpose swaps n and c)  */
 int sv_repack(int dtype, const float* master, int N, int T_orig, int C, int transpose,
               const sv_geom* g, void* dst, void* stream);

@@ -7,3 +7,4 @@ from .mixup import mixup_vae_data, label_smoothing, optimal_match_index        #
 from .optim import FlatSGD                        # noqa: F401
 from .train import (train_step, train_step_overlapped, GraphedTrainStep, DeviceRng, schedule,   # noqa: F401
                     alpha_schedule)
+from .data import DeviceDataset, ssl_split      # noqa: F401

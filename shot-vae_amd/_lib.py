@@ -68,6 +68,7 @@ _PROTOS = {
     "sv_nchw_to_nhwc": [I, P, I, I, I, I, I, P, P],
     "sv_nhwc_to_nchw": [I, P, I, I, I, I, I, P, P],
     "sv_repack": [I, P, I, I, I, I, C.POINTER(SvGeom), P, P],
+    "sv_augment": [I, P, P, P, I, I, I, I, I, I, P, P],
     "sv_prof_enable": [I],
     "sv_prof_tag": [I],
     "sv_prof_collect": [I, C.POINTER(C.c_double), C.POINTER(C.c_int)],

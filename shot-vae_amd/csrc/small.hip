@@ -710,6 +710,43 @@ __global__ void nhwc_to_nchw_kernel(const T* in, int B, int C, int HW, int ld, f
     out[i] = to_f(in[((size_t)b * HW + p) * ld + c]);
 }
 
+// K21: gather + reflect pad + flip + crop + ToTensor in one pass (one thread per output element; the uint8 source of a
+// batch is 3 KB per image and L2-resident after the first touch)
+__device__ __forceinline__ int reflect_idx(int t, int n) { return t < 0 ? -t : (t >= n ? 2 * n - 2 - t : t); }
+template <typename T>
+__global__ void augment_kernel(const uint8_t* data, const int64_t* index, const int32_t* params, int B, int H, int W,
+                               int C, int pad, int cpad, T* out_nhwc, float* out_nchw) {
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned CC = cpad ? cpad : C;
+    if (i >= (unsigned)B * H * W * CC) return;
+    unsigned b, y, x, c;
+    if (cpad) {                      // NHWC: channel fastest
+        c = i % CC;
+        const unsigned p = i / CC;
+        x = p % W;
+        y = (p / W) % H;
+        b = p / (W * H);
+    } else {                         // NCHW: x fastest
+        x = i % W;
+        y = (i / W) % H;
+        c = (i / (W * H)) % C;
+        b = i / (W * H * C);
+    }
+    float v = 0.f;
+    if (c < (unsigned)C) {
+        int sy = y, sx = x;
+        if (params) {
+            const int oy = params[3 * b], ox = params[3 * b + 1], flip = params[3 * b + 2];
+            const int px = ox + (int)x;                              // column in the (flipped) padded image
+            sy = reflect_idx(oy + (int)y - pad, H);
+            sx = reflect_idx((flip ? (W + 2 * pad - 1 - px) : px) - pad, W);
+        }
+        v = (float)data[(((size_t)index[b] * H + sy) * W + sx) * C + c] / 255.0f;
+    }
+    if (cpad) out_nhwc[i] = (T)v;
+    else out_nchw[i] = v;
+}
+
 struct repack_params {
     int N, T_orig, C, transpose, nphase;
     int ntap[SV_MAX_PHASES];
@@ -963,6 +1000,24 @@ int sv_nchw_to_nhwc(int dtype, const float* in, int B, int C, int H, int W, int 
                                          (hipStream_t)stream, in, B, C, H * W, Cpad, (T*)out));
     return sv_check_launch("sv_nchw_to_nhwc");
 }
+int sv_augment(int dtype, const uint8_t* data, const int64_t* index, const int32_t* params, int B, int H, int W, int C,
+               int pad, int nhwc_cpad, void* out, void* stream) {
+    SV_REQUIRE(data && index && out, SV_E_ARG, "sv_augment: null");
+    SV_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && pad >= 0 && pad < H && pad < W && (nhwc_cpad == 0 || nhwc_cpad >= C),
+               SV_E_ARG, "sv_augment: bad shape (B=%d H=%d W=%d C=%d pad=%d cpad=%d)", B, H, W, C, pad, nhwc_cpad);
+    const int64_t n = (int64_t)B * H * W * (nhwc_cpad ? nhwc_cpad : C);
+    SV_REQUIRE(n < ((int64_t)1 << 32), SV_E_ARG, "sv_augment: batch too large");
+    if (nhwc_cpad) {
+        DISPATCH_T(dtype, hipLaunchKernelGGL((augment_kernel<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                                             (hipStream_t)stream, data, index, params, B, H, W, C, pad, nhwc_cpad,
+                                             (T*)out, (float*)nullptr));
+    } else {
+        hipLaunchKernelGGL((augment_kernel<float>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                           data, index, params, B, H, W, C, pad, 0, (float*)nullptr, (float*)out);
+    }
+    return sv_check_launch("sv_augment");
+}
+
 int sv_nhwc_to_nchw(int dtype, const void* in, int B, int C, int H, int W, int ld, float* out, void* stream) {
     SV_REQUIRE(in && out && ld >= C, SV_E_ARG, "sv_nhwc_to_nchw: bad args");
     const int64_t n = (int64_t)B * H * W * C;

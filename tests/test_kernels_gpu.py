@@ -515,3 +515,40 @@ def test_mix_lerp_optimal_match_sgd_layout():
         L.call("sv_nhwc_to_nchw", code, p(o), 3, 3, 4, 4, 16, p(back), st())
         assert rel(back, bq(img, dt)) < 1e-6
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("mode", ["nchw", "nhwc_bf16", "nhwc_f32", "eval"])
+def test_augment_pipeline(mode):
+    """sv_augment (gather + reflect pad + flip + crop + ToTensor, lib/dataloader.py:58-70) against the numpy oracle:
+    bit-exact in fp32, exact after bf16 rounding in the stem's NHWC16 layout; every crop corner / flip combination."""
+    from oracle import augment_oracle as A
+    from shot_vae_amd.data import DeviceDataset
+    rs = np.random.RandomState(3)
+    data = rs.randint(0, 256, size=(50, 32, 32, 3)).astype(np.uint8)
+    labels = rs.randint(0, 10, size=50)
+    ds = DeviceDataset(torch.from_numpy(data), labels, device=dev())
+    B = 37
+    index = torch.from_numpy(rs.randint(0, 50, size=B)).to(dev())
+    params = np.stack([rs.randint(0, 9, size=B), rs.randint(0, 9, size=B), rs.randint(0, 2, size=B)], 1).astype(np.int32)
+    params[:4] = [[0, 0, 0], [8, 8, 1], [0, 8, 1], [8, 0, 0]]
+    pd = torch.from_numpy(params).to(dev())
+    if mode == "eval":
+        out, lab = ds.batch(index, train=False)
+        ref = A.batch(data, index.cpu().numpy(), None)
+        assert np.array_equal(out.cpu().numpy(), ref)
+    elif mode == "nchw":
+        out, lab = ds.batch(index, train=True, params=pd)
+        ref = A.batch(data, index.cpu().numpy(), params)
+        assert np.array_equal(out.cpu().numpy(), ref)
+        assert out.shape == (B, 3, 32, 32) and float(out.min()) >= 0.0 and float(out.max()) <= 1.0
+    else:
+        dt = "bf16" if mode == "nhwc_bf16" else "fp32"
+        out, lab = ds.batch(index, train=True, params=pd, nhwc_dtype=dt, cpad=16)
+        ref = torch.from_numpy(A.batch(data, index.cpu().numpy(), params)).permute(0, 2, 3, 1)
+        ref = ref.to(torch.bfloat16).float() if dt == "bf16" else ref
+        assert np.array_equal(out[..., :3].float().cpu().numpy(), ref.numpy())
+        assert float(out[..., 3:].float().abs().max()) == 0.0
+    assert np.array_equal(lab.cpu().numpy(), labels[index.cpu().numpy()])
+    # the drawn parameters stay in range
+    dr = ds.draw(1000).cpu().numpy()
+    assert dr[:, :2].min() >= 0 and dr[:, :2].max() <= 8 and set(np.unique(dr[:, 2])) <= {0, 1}
