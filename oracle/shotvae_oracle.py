@@ -355,6 +355,38 @@ def train_step(st, name, image_l, label_l, image_u, noise, sch, bce=True, x_sigm
     return {k: (v.detach() if torch.is_tensor(v) else v) for k, v in out.items()}
 
 
+def m2_step(st, name, image_l, label_l, image_u, label_u, noise, sch, bce=True, x_sigma=1.0, temperature=0.67,
+            backward=True):
+    """One step of the M2 baseline loop (main_M2_vae.py:259-305): labelled forward with the one-hot label +
+    cross-entropy, unlabelled forward with the Gumbel-softmax sample, no mixup; gradients of both backward passes
+    accumulate.  ``noise``: eps1 (labelled), eps3 / u3 (unlabelled).  Also the monitored KL(q(y|x) || smoothed label)
+    of :285-291."""
+    K = st["disc_latent_inference.fc.bias"].shape[0]
+    B = image_l.shape[0]
+    onehot_l = F.one_hot(label_l, K).float()
+    rec1, mu1, ls1, la1 = vae_forward(st, name, image_l, noise["eps1"], label=label_l, temperature=temperature)
+    recon_l, klc_l, kld_l = vae_criterion(image_l, rec1, mu1, ls1, la1, x_sigma, bce)
+    elbo_l = recon_l + sch["kl_beta_c"] * torch.abs(klc_l - sch["cmi"]) + sch["kl_beta_d"] * torch.abs(kld_l - sch["dmi"])
+    disc_post_l = cls_criterion(la1, onehot_l)
+    loss_sup = sch["ew"] * elbo_l + disc_post_l
+    if backward:
+        loss_sup.backward()
+    rec3, mu3, ls3, la3 = vae_forward(st, name, image_u, noise["eps3"], u=noise["u3"], temperature=temperature)
+    with torch.no_grad():
+        smooth = torch.zeros(B, K).scatter_(1, label_u.view(-1, 1), 1 - 0.001 - 0.001 / (K - 1)) + 0.001 / (K - 1)
+        alpha = torch.exp(la3)
+        kl_inference = (alpha * la3 - alpha * torch.log(smooth)).sum() / B
+    recon_u, klc_u, kld_u = vae_criterion(image_u, rec3, mu3, ls3, la3, x_sigma, bce)
+    elbo_u = recon_u + sch["kl_beta_c"] * torch.abs(klc_u - sch["cmi"]) + sch["kl_beta_d"] * torch.abs(kld_u - sch["dmi"])
+    loss_unsup = sch["ew"] * elbo_u
+    if backward:
+        loss_unsup.backward()
+    out = dict(recon_l=recon_l, klc_l=klc_l, kld_l=kld_l, recon_u=recon_u, klc_u=klc_u, kld_u=kld_u,
+               disc_post_l=disc_post_l, kl_inference=kl_inference, loss_sup=loss_sup, loss_unsup=loss_unsup,
+               rec1=rec1, mu1=mu1, ls1=ls1, la1=la1, rec3=rec3, mu3=mu3, ls3=ls3, la3=la3)
+    return {k: v.detach() for k, v in out.items()}
+
+
 def sgd_step(st, momentum_buf, lr=0.1, momentum=0.9, weight_decay=5e-4):
     """torch.optim.SGD semantics (main_shot_vae.py:198,365): g += wd*p; v = mom*v + g (v = g on
     the first step); p -= lr*v.  Clears .grad afterwards (:366)."""

@@ -6,5 +6,5 @@ from .criterion import VAECriterion, ClsCriterion, continuous_posterior_loss   #
 from .mixup import mixup_vae_data, label_smoothing, optimal_match_index        # noqa: F401
 from .optim import FlatSGD                        # noqa: F401
 from .train import (train_step, train_step_overlapped, GraphedTrainStep, DeviceRng, schedule,   # noqa: F401
-                    alpha_schedule)
+                    alpha_schedule, m2_train_step)
 from .data import DeviceDataset, ssl_split      # noqa: F401

@@ -177,6 +177,43 @@ def train_step(model, elbo_criterion, cls_criterion, optimizer, image_l, label_l
     return {k: loc[k].detach() for k in keys}
 
 
+def m2_train_step(model, elbo_criterion, cls_criterion, optimizer, image_l, label_l, image_u, label_u, sch,
+                  distributed=False, return_outputs=False):
+    """One step of the M2 baseline loop (main_M2_vae.py:259-305) on the HIP path: the same model and criteria without
+    the mixup forwards -- labelled forward with the one-hot label + cross-entropy on q(y|x), unlabelled forward with
+    the Gumbel-softmax sample, two backward passes accumulating into the flat gradient buffer, (all-reduce,) SGD.
+    Also returns the monitored KL(q(y|x) || smoothed label) of :285-291."""
+    K = model._plan.K
+    B = image_l.size(0)
+    onehot_l = one_hot(label_l, K)
+    rec1, mu1, ls1, la1 = model(image_l, disc_label=label_l)
+    recon_l, klc_l, kld_l = elbo_criterion(image_l, rec1, mu1, ls1, la1)
+    elbo_l = recon_l + sch["kl_beta_c"] * torch.abs(klc_l - sch["cmi"]) + sch["kl_beta_d"] * torch.abs(kld_l - sch["dmi"])
+    disc_post_l = cls_criterion(la1, onehot_l)
+    loss_sup = sch["ew"] * elbo_l + disc_post_l
+    loss_sup.backward()
+    rec3, mu3, ls3, la3 = model(image_u)
+    with torch.no_grad():
+        smooth = torch.zeros(B, K, device=image_u.device).scatter_(1, label_u.view(-1, 1), 1 - 0.001 - 0.001 / (K - 1))
+        smooth = smooth + 0.001 / (K - 1)
+        alpha = torch.exp(la3)
+        kl_inference = (alpha * la3 - alpha * torch.log(smooth)).sum() / B
+    recon_u, klc_u, kld_u = elbo_criterion(image_u, rec3, mu3, ls3, la3)
+    elbo_u = recon_u + sch["kl_beta_c"] * torch.abs(klc_u - sch["cmi"]) + sch["kl_beta_d"] * torch.abs(kld_u - sch["dmi"])
+    loss_unsup = sch["ew"] * elbo_u
+    loss_unsup.backward()
+    if optimizer is not None:
+        scale = dp.all_reduce_gradients(model.flat_parameters()[1]) if distributed else 1.0
+        optimizer.step(scale) if hasattr(optimizer, "_steps") else optimizer.step()
+        optimizer.zero_grad()
+    if not return_outputs:
+        return loss_sup.detach(), loss_unsup.detach(), kl_inference
+    loc = dict(locals())
+    keys = ["recon_l", "klc_l", "kld_l", "recon_u", "klc_u", "kld_u", "disc_post_l", "kl_inference", "loss_sup",
+            "loss_unsup", "rec1", "mu1", "ls1", "la1", "rec3", "mu3", "ls3", "la3"]
+    return {k: loc[k].detach() for k in keys}
+
+
 class GraphedTrainStep:
     """The two-stream step captured once into a hipGraph and replayed: ~1100 kernel launches per step stop costing
     ~12 ms of host time (measured: the eager step is host-bound below that).  The graph holds the weight re-packing,

@@ -163,6 +163,64 @@ def run_step_case(tag, name, K, Bl, Bu, bce, x_sigma=1.0, om=False, epoch=10, dm
           "bytes", os.path.getsize(os.path.join(HERE, tag + ".npz")))
 
 
+def reference_m2_step(model, elbo_criterion, cls_criterion, image_l, label_l, image_u, label_u, K, sch):
+    """Body of the loop at main_M2_vae.py:259-305 (the M2 baseline: no mixup, two forwards, two backwards)."""
+    batch_size = image_l.size(0)
+    label_onehot_l = torch.zeros(batch_size, K).scatter_(1, label_l.view(-1, 1), 1)
+    rec1, mu1, ls1, la1 = model(image_l, disc_label=label_l)
+    recon_l, klc_l, kld_l = elbo_criterion(image_l, rec1, mu1, ls1, la1)
+    prior_l = sch["kl_beta_c"] * torch.abs(klc_l - sch["cmi"]) + sch["kl_beta_d"] * torch.abs(kld_l - sch["dmi"])
+    elbo_l = recon_l + prior_l
+    disc_post_l = cls_criterion(la1, label_onehot_l)
+    loss_sup = sch["ew"] * elbo_l + disc_post_l
+    loss_sup.backward()
+    rec3, mu3, ls3, la3 = model(image_u)
+    with torch.no_grad():
+        label_smooth_u = torch.zeros(batch_size, K).scatter_(1, label_u.view(-1, 1), 1 - 0.001 - 0.001 / (K - 1))
+        label_smooth_u = label_smooth_u + torch.ones(label_smooth_u.size()) * 0.001 / (K - 1)
+        disc_alpha_u = torch.exp(la3)
+        inference_kl = disc_alpha_u * la3 - disc_alpha_u * torch.log(label_smooth_u)
+        kl_inference = torch.sum(inference_kl) / batch_size
+    recon_u, klc_u, kld_u = elbo_criterion(image_u, rec3, mu3, ls3, la3)
+    prior_u = sch["kl_beta_c"] * torch.abs(klc_u - sch["cmi"]) + sch["kl_beta_d"] * torch.abs(kld_u - sch["dmi"])
+    elbo_u = recon_u + prior_u
+    loss_unsup = sch["ew"] * elbo_u
+    loss_unsup.backward()
+    loc = dict(locals())
+    keys = ["recon_l", "klc_l", "kld_l", "recon_u", "klc_u", "kld_u", "disc_post_l", "kl_inference", "loss_sup",
+            "loss_unsup", "rec1", "mu1", "ls1", "la1", "rec3", "mu3", "ls3", "la3"]
+    return {k: loc[k].detach().clone() for k in keys}
+
+
+def run_m2_case(tag, name, K, B, epoch=10, dmi=2.3):
+    VAE, VAECriterion, ClsCriterion, _, _ = import_reference()
+    model = VAE(encoder_name=name, num_input_channels=3, drop_rate=0, img_size=(32, 32), data_parallel=False,
+                continuous_latent_dim=128, disc_latent_dim=K, sample_temperature=0.67, small_input=True)
+    model.load_state_dict(C.make_state(name, K=K))
+    model.train()
+    elbo, cls = VAECriterion(discrete_dim=K, x_sigma=1.0, bce_reconstruction=True), ClsCriterion()
+    opt = torch.optim.SGD(model.parameters(), lr=0.1, momentum=0.9, weight_decay=5e-4)
+    opt.zero_grad()
+    sch = dict(cmi=alpha_schedule(epoch, 200, 0.0), dmi=alpha_schedule(epoch, 200, dmi),
+               ew=alpha_schedule(epoch, 400, 1e-3), kl_beta_c=alpha_schedule(epoch, 200, 1e-3),
+               kl_beta_d=alpha_schedule(epoch, 200, 1e-3))
+    il, ll, iu, lu = C.make_batch(B, B, K, stream0=7300)
+    nz = C.make_noise(B, B, K, stream0=9300)
+    with scripted_rng(randn=[nz["eps1"], nz["eps3"]], rand=[nz["u3"]]):
+        out = reference_m2_step(model, elbo, cls, il, ll, iu, lu, K, sch)
+    rec = {k: v.numpy() for k, v in out.items()}
+    names = [k for k, _ in model.named_parameters()]
+    rec["grad_norm"] = np.array([float(p.grad.double().norm()) for _, p in model.named_parameters()])
+    rec["grad_sample"] = np.concatenate(
+        [p.grad.reshape(-1)[torch.from_numpy(grad_sample_idx(p.numel()))].numpy() for _, p in model.named_parameters()])
+    opt.step()
+    sd = model.state_dict()
+    rec["final.param_norm"] = np.array([float(sd[k].double().norm()) for k in names])
+    np.savez_compressed(os.path.join(HERE, tag + ".npz"), **rec)
+    print(tag, "loss_sup", float(out["loss_sup"]), "loss_unsup", float(out["loss_unsup"]), "kl_inf",
+          float(out["kl_inference"]), "bytes", os.path.getsize(os.path.join(HERE, tag + ".npz")))
+
+
 def run_eval_case(tag, name, K, B):
     VAE, *_ = import_reference()
     model = VAE(encoder_name=name, num_input_channels=3, drop_rate=0, img_size=(32, 32),
@@ -218,6 +276,9 @@ def run_fn_cases(tag):
 if __name__ == "__main__":
     assert os.path.isdir(REF), "reference not mounted; goldens are generated in the build container"
     torch.set_num_threads(8)
+    if len(sys.argv) > 1 and sys.argv[1] == "m2":          # only the M2 fixture
+        run_m2_case("ref_m2_step_wrn10_1", "wideresnet-10-1", 10, 6)
+        sys.exit(0)
     run_fn_cases("ref_functions")
     run_eval_case("ref_eval_wrn10_1", "wideresnet-10-1", 10, 4)
     run_step_case("ref_step_wrn10_1_br", "wideresnet-10-1", 10, 4, 6, True, steps=2)
@@ -225,3 +286,4 @@ if __name__ == "__main__":
     run_step_case("ref_step_wrn28_2_br", "wideresnet-28-2", 10, 4, 4, True)
     run_step_case("ref_step_wrn28_2_mse", "wideresnet-28-2", 10, 4, 4, False, x_sigma=0.5)
     run_step_case("ref_step_wrn28_10_k100", "wideresnet-28-10", 100, 2, 2, True, dmi=4.6)
+    run_m2_case("ref_m2_step_wrn10_1", "wideresnet-10-1", 10, 6)

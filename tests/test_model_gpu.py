@@ -79,6 +79,43 @@ def test_step_matches_reference_goldens_fp32(tag):
             assert T.rel_err(sd[key].numpy(), g[k]) < 1e-3, key
 
 
+def test_m2_baseline_step_matches_reference_golden_fp32():
+    """m2_train_step (the M2 baseline loop, main_M2_vae.py:259-305) on the HIP path against
+    the reference's own run of that loop (tests/golden/ref_m2_step_wrn10_1.npz)."""
+    name, K, B = "wideresnet-10-1", 10, 6
+    g = T.load("ref_m2_step_wrn10_1")
+    model = make_model(name, K, "fp32", C.make_state(name, K=K))
+    elbo, cls = S.VAECriterion(discrete_dim=K, x_sigma=1.0, bce_reconstruction=True).cuda(), S.ClsCriterion()
+    opt = S.FlatSGD(model, lr=0.1, momentum=0.9, weight_decay=5e-4)
+    opt.zero_grad()
+    sch = O.schedule(10)
+    il, ll, iu, lu = C.make_batch(B, B, K, stream0=7300)
+    nz = C.make_noise(B, B, K, stream0=9300)
+    with T.scripted_rng(randn=[nz["eps1"], nz["eps3"]], rand=[nz["u3"]]):
+        out = S.m2_train_step(model, elbo, cls, None, il.cuda(), ll.cuda(), iu.cuda(), lu.cuda(), sch,
+                              return_outputs=True)
+    torch.cuda.synchronize()
+    for k in ("recon_l", "klc_l", "kld_l", "recon_u", "klc_u", "kld_u", "disc_post_l", "kl_inference", "loss_sup",
+              "loss_unsup"):
+        ref = float(g[k])
+        assert abs(float(out[k]) - ref) <= FP32_TOL * max(abs(ref), 1e-6), (k, float(out[k]), ref)
+    for k in ("rec1", "mu1", "ls1", "la1", "rec3", "mu3", "ls3", "la3"):
+        assert T.rel_err(out[k].float().cpu().numpy(), g[k]) < FP32_TOL, k
+    names = [k.replace(".module.", ".") for k, _ in model.named_parameters()]
+    grads = param_grads(model)
+    gn = np.array([float(grads[k].double().norm()) for k in names])
+    gr = g["grad_norm"]
+    bad = np.abs(gn - gr) > 1e-2 * gr + 1e-4 * gr.max()
+    assert not bad.any(), [(names[i], gn[i], gr[i]) for i in np.nonzero(bad)[0][:5]]
+    gs = np.concatenate([grads[k].reshape(-1)[torch.from_numpy(T.sample_idx(grads[k].numel()))].numpy() for k in names])
+    assert T.rel_err(gs, g["grad_sample"]) < 1e-2
+    opt.step()
+    torch.cuda.synchronize()
+    sd = {k.replace(".module.", "."): v.detach().float().cpu() for k, v in model.state_dict().items()}
+    pn = np.array([float(sd[k].double().norm()) for k in names])
+    assert np.max(np.abs(pn - g["final.param_norm"]) / g["final.param_norm"]) < 1e-3
+
+
 def test_eval_forward_matches_reference_golden():
     g = T.load("ref_eval_wrn10_1")
     model = make_model("wideresnet-10-1", 10, "fp32", C.make_state("wideresnet-10-1", K=10)).eval()

@@ -101,3 +101,25 @@ def test_known_answers():
     assert abs(float(O.vae_criterion(x, x, z, z, peaked)[2]) - np.log(K)) < 1e-4
     assert abs(O.alpha_schedule(0, 200, 2.0) - 2.0 * np.exp(-5.0)) < 1e-12
     assert O.alpha_schedule(200, 200, 2.0) == 2.0 and O.alpha_schedule(300, 200, 2.0) == 2.0
+
+
+def test_m2_baseline_step_matches_reference():
+    """oracle.m2_step (main_M2_vae.py:259-305) against the reference run by tests/golden/make_goldens.py (m2 case)."""
+    name, K, B = "wideresnet-10-1", 10, 6
+    g = T.load("ref_m2_step_wrn10_1")
+    st = C.make_state(name, K=K)
+    for k in st:
+        if O.is_param(k):
+            st[k].requires_grad_(True)
+    sch = O.schedule(10)
+    il, ll, iu, lu = C.make_batch(B, B, K, stream0=7300)
+    nz = C.make_noise(B, B, K, stream0=9300)
+    out = O.m2_step(st, name, il, ll, iu, lu, nz, sch)
+    for k in ("recon_l", "klc_l", "kld_l", "recon_u", "klc_u", "kld_u", "disc_post_l", "kl_inference", "loss_sup",
+              "loss_unsup"):
+        assert abs(float(out[k]) - float(g[k])) <= 2e-5 * max(1.0, abs(float(g[k]))), k
+    for k in ("rec1", "mu1", "ls1", "la1", "rec3", "mu3", "ls3", "la3"):
+        assert T.rel_err(out[k].numpy(), g[k]) < 2e-5, k
+    pk = [k for k in st if O.is_param(k)]
+    gn = np.array([float(st[k].grad.double().norm()) for k in pk])
+    assert np.max(np.abs(gn - g["grad_norm"])) < 2e-4 * np.max(g["grad_norm"])
