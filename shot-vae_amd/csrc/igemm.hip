@@ -20,14 +20,18 @@ namespace {
 
 constexpr int BM = 128;
 constexpr int BK = 32;
-constexpr int LDK = BK + 16;  // LDS row stride in elements: 96 B rows make the b128 fragment reads conflict-free
 
-template <typename T, int NT>
+// KV = 32-deep k sub-chunks per loop iteration (one barrier per iteration).  KV = 2 for deep-K layers with few tiles
+// (the decoder, the stride-2 convs): those are bound by one global->LDS round trip per iteration, so twice the bytes
+// in flight and twice the MFMAs per barrier nearly halve their time.
+template <typename T, int NT, int KV>
 __global__ __launch_bounds__(256) void igemm_kernel(const sv_geom g, const sv_igemm_args a) {
     typedef typename V8<T>::type V;
     typedef typename V4<T>::type Q;
     constexpr int BN = 16 * NT;
-    constexpr int NBV = (BN * 4 + 255) / 256;   // weight vectors per thread per k-chunk
+    constexpr int NBV = (BN * 4 + 255) / 256;   // weight vectors per thread per 32-deep sub-chunk
+    constexpr int BKK = BK * KV;
+    constexpr int LDK = BKK + 16;               // LDS row stride (elements): 96 / 160 B rows keep the b128 fragment reads conflict-free
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     T* As = reinterpret_cast<T*>(smem);           // [2][BM][LDK]
@@ -59,7 +63,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const sv_geom g, const sv_ig
     const uint64_t pdy = pack_taps(P.dy), pdx = pack_taps(P.dx);
     const int ntap = P.ntap;
     const int Ktot = ntap * g.Cin;
-    const int nk = (Ktot + BK - 1) / BK;
+    const int nk = (Ktot + BKK - 1) / BKK;
     const T* __restrict__ X = reinterpret_cast<const T*>(a.x);
     const T* __restrict__ W = reinterpret_cast<const T*>(a.w) + P.w_off;
     const bool has_pro = a.pro_scale != nullptr;
@@ -85,73 +89,86 @@ __global__ __launch_bounds__(256) void igemm_kernel(const sv_geom g, const sv_ig
         ix0[i] = qx * g.sx;
         pixb[i] = b * g.Hin * g.Win;
     }
-    int tap = 0, c = 8 * v;
-    while (c >= g.Cin) { c -= g.Cin; ++tap; }
+    int tap[KV], c[KV];
+#pragma unroll
+    for (int s = 0; s < KV; ++s) {
+        tap[s] = 0;
+        c[s] = 8 * v + BK * s;
+        while (c[s] >= g.Cin) { c[s] -= g.Cin; ++tap[s]; }
+    }
 
-    V ra[2], rb[NBV];
-    bool oka[2];
-    f32x4 ps0, ps1, pt0, pt1;        // BN scale / shift of the chunk in flight (fetched WITH its data)
+    V ra[KV][2], rb[KV][NBV];
+    bool oka[KV][2];
+    f32x4 ps0[KV], ps1[KV], pt0[KV], pt1[KV];        // BN scale / shift of the chunk in flight (fetched WITH its data)
 
     V zero;
 #pragma unroll
     for (int j = 0; j < 8; ++j) zero[j] = (T)0.f;
     // Branch-free loader: clamped addresses, unconditional loads (all in flight together), select.
     auto load_global = [&](int kc) {
-        const int tt = tap < SV_MAX_TAPS ? tap : SV_MAX_TAPS - 1;
-        const int dy = tap_off(pdy, tt), dx = tap_off(pdx, tt);
-        if (has_pro) {
-            ps0 = *reinterpret_cast<const f32x4*>(a.pro_scale + c);
-            ps1 = *reinterpret_cast<const f32x4*>(a.pro_scale + c + 4);
-            pt0 = *reinterpret_cast<const f32x4*>(a.pro_shift + c);
-            pt1 = *reinterpret_cast<const f32x4*>(a.pro_shift + c + 4);
-        }
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int iy = iy0[i] + dy, ix = ix0[i] + dx;
-            const bool ok = mval[i] && tap < ntap && (unsigned)iy < (unsigned)g.Hin &&
-                            (unsigned)ix < (unsigned)g.Win;
-            oka[i] = ok;
-            const int iyc = min(max(iy, 0), g.Hin - 1), ixc = min(max(ix, 0), g.Win - 1);
-            const V val = *reinterpret_cast<const V*>(X + ((int64_t)(pixb[i] + iyc * g.Win + ixc) * g.ldx + c));
-            ra[i] = ok ? val : zero;
-        }
-        const int k8 = kc * BK + 8 * v;
-        const int k8c = min(k8, Ktot - 8);
+        for (int s = 0; s < KV; ++s) {
+            const int tt = tap[s] < SV_MAX_TAPS ? tap[s] : SV_MAX_TAPS - 1;
+            const int dy = tap_off(pdy, tt), dx = tap_off(pdx, tt);
+            const int cc = min(c[s], g.Cin - 8);
+            if (has_pro) {
+                ps0[s] = *reinterpret_cast<const f32x4*>(a.pro_scale + cc);
+                ps1[s] = *reinterpret_cast<const f32x4*>(a.pro_scale + cc + 4);
+                pt0[s] = *reinterpret_cast<const f32x4*>(a.pro_shift + cc);
+                pt1[s] = *reinterpret_cast<const f32x4*>(a.pro_shift + cc + 4);
+            }
 #pragma unroll
-        for (int i = 0; i < NBV; ++i) {
-            const int nb = lrow + 64 * i;
-            const bool ok = nb < BN && n0 + nb < g.N && k8 < Ktot;
-            const V val = *reinterpret_cast<const V*>(W + (int64_t)min(n0 + nb, g.N - 1) * Ktot + k8c);
-            rb[i] = ok ? val : zero;
+            for (int i = 0; i < 2; ++i) {
+                const int iy = iy0[i] + dy, ix = ix0[i] + dx;
+                const bool ok = mval[i] && tap[s] < ntap && (unsigned)iy < (unsigned)g.Hin &&
+                                (unsigned)ix < (unsigned)g.Win;
+                oka[s][i] = ok;
+                const int iyc = min(max(iy, 0), g.Hin - 1), ixc = min(max(ix, 0), g.Win - 1);
+                const V val = *reinterpret_cast<const V*>(X + ((int64_t)(pixb[i] + iyc * g.Win + ixc) * g.ldx + cc));
+                ra[s][i] = ok ? val : zero;
+            }
+            const int k8 = kc * BKK + BK * s + 8 * v;
+            const int k8c = min(k8, Ktot - 8);
+#pragma unroll
+            for (int i = 0; i < NBV; ++i) {
+                const int nb = lrow + 64 * i;
+                const bool ok = nb < BN && n0 + nb < g.N && k8 < Ktot;
+                const V val = *reinterpret_cast<const V*>(W + (int64_t)min(n0 + nb, g.N - 1) * Ktot + k8c);
+                rb[s][i] = ok ? val : zero;
+            }
+            // advance (tap, c) to this sub-chunk's position in the next iteration
+            c[s] += BKK;
+            while (c[s] >= g.Cin) { c[s] -= g.Cin; ++tap[s]; }
         }
-        // advance (tap, c) to the next chunk
-        c += BK;
-        while (c >= g.Cin) { c -= g.Cin; ++tap; }
     };
 
     auto store_lds = [&](int buf) {
         T* Ab = As + buf * BM * LDK;
         T* Bb = Bs + buf * BN * LDK;
-        if (has_pro) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                V o;
+        for (int s = 0; s < KV; ++s) {
+            if (has_pro) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float u0 = to_f(ra[i][j]) * ps0[j] + pt0[j], u1 = to_f(ra[i][j + 4]) * ps1[j] + pt1[j];
-                    o[j] = (T)fmaxf(u0, u0 * a.pro_slope);          // LeakyReLU / ReLU for slope in [0,1]
-                    o[j + 4] = (T)fmaxf(u1, u1 * a.pro_slope);
+                for (int i = 0; i < 2; ++i) {
+                    V o;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float u0 = to_f(ra[s][i][j]) * ps0[s][j] + pt0[s][j];
+                        const float u1 = to_f(ra[s][i][j + 4]) * ps1[s][j] + pt1[s][j];
+                        o[j] = (T)fmaxf(u0, u0 * a.pro_slope);          // LeakyReLU / ReLU for slope in [0,1]
+                        o[j + 4] = (T)fmaxf(u1, u1 * a.pro_slope);
+                    }
+                    ra[s][i] = oka[s][i] ? o : zero;
                 }
-                ra[i] = oka[i] ? o : zero;
             }
-        }
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-            *reinterpret_cast<V*>(Ab + (lrow + 64 * i) * LDK + 8 * v) = ra[i];
+            for (int i = 0; i < 2; ++i)
+                *reinterpret_cast<V*>(Ab + (lrow + 64 * i) * LDK + BK * s + 8 * v) = ra[s][i];
 #pragma unroll
-        for (int i = 0; i < NBV; ++i) {
-            const int nb = lrow + 64 * i;
-            if (nb < BN) *reinterpret_cast<V*>(Bb + nb * LDK + 8 * v) = rb[i];
+            for (int i = 0; i < NBV; ++i) {
+                const int nb = lrow + 64 * i;
+                if (nb < BN) *reinterpret_cast<V*>(Bb + nb * LDK + BK * s + 8 * v) = rb[s][i];
+            }
         }
     };
 
@@ -172,14 +189,17 @@ __global__ __launch_bounds__(256) void igemm_kernel(const sv_geom g, const sv_ig
         if (kc + 1 < nk) load_global(kc + 1);   // in flight while this chunk's MFMAs run
         const T* Ab = As + buf * BM * LDK + (32 * wave + fr) * LDK + 8 * fq;
         const T* Bb = Bs + buf * BN * LDK + fr * LDK + 8 * fq;
-        V af[2];
-        af[0] = *reinterpret_cast<const V*>(Ab);
-        af[1] = *reinterpret_cast<const V*>(Ab + 16 * LDK);
 #pragma unroll
-        for (int i = 0; i < NT; ++i) {
-            const V wf = *reinterpret_cast<const V*>(Bb + 16 * i * LDK);
-            mma32(acc[i][0], wf, af[0]);
-            mma32(acc[i][1], wf, af[1]);
+        for (int s = 0; s < KV; ++s) {
+            V af[2];
+            af[0] = *reinterpret_cast<const V*>(Ab + BK * s);
+            af[1] = *reinterpret_cast<const V*>(Ab + 16 * LDK + BK * s);
+#pragma unroll
+            for (int i = 0; i < NT; ++i) {
+                const V wf = *reinterpret_cast<const V*>(Bb + 16 * i * LDK + BK * s);
+                mma32(acc[i][0], wf, af[0]);
+                mma32(acc[i][1], wf, af[1]);
+            }
         }
         if (kc + 1 < nk) store_lds(buf ^ 1);
         __syncthreads();
@@ -202,18 +222,37 @@ __global__ __launch_bounds__(256) void igemm_kernel(const sv_geom g, const sv_ig
     gemm_epilogue<T, NT>(acc, obase, oval, n0, g.N, a, ssum);
 }
 
-template <typename T, int NT>
-int launch(const sv_geom* g, const sv_igemm_args* a, hipStream_t s) {
-    constexpr int BN = 16 * NT;
+template <typename T, int NT, int KV>
+int launch_kv(const sv_geom* g, const sv_igemm_args* a, hipStream_t s) {
+    constexpr int BN = 16 * NT, LDK = BK * KV + 16;
     const int M = g->B * g->Hq * g->Wq;
     const int nMt = (M + BM - 1) / BM;
     const int nNt = (g->N + BN - 1) / BN;
     const int grid = (nMt >= 64 ? ((nMt + 7) / 8) * 8 : nMt) * nNt * g->nphase;
     const size_t lds = (size_t)2 * (BM + BN) * LDK * sizeof(T) + 2 * BN * sizeof(float);
+    static bool optin = false;
+    if (lds > 64 * 1024 && !optin) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<T, NT, KV>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return sv_check_launch("hipFuncSetAttribute(igemm)");
+        optin = true;
+    }
     sv_prof_begin(s);
-    hipLaunchKernelGGL((igemm_kernel<T, NT>), dim3(grid), dim3(256), lds, s, *g, *a);
+    hipLaunchKernelGGL((igemm_kernel<T, NT, KV>), dim3(grid), dim3(256), lds, s, *g, *a);
     sv_prof_end(s);
     return sv_check_launch("sv_igemm");
+}
+
+template <typename T, int NT>
+int launch(const sv_geom* g, const sv_igemm_args* a, hipStream_t s) {
+    // two sub-chunks per iteration when K is deep (>= 8 chunks in the shallowest phase) -- bf16 only (LDS budget)
+    static const bool no_kv2 = getenv("SV_NO_IGEMM_KV2") != nullptr;
+    if (sizeof(T) == 2 && NT <= 5 && !no_kv2) {
+        int kmin = 1 << 30;
+        for (int p = 0; p < g->nphase; ++p) kmin = min(kmin, g->phase[p].ntap * g->Cin);
+        if (kmin >= 8 * BK && kmin % (2 * BK) == 0) return launch_kv<T, NT, 2>(g, a, s);
+    }
+    return launch_kv<T, NT, 1>(g, a, s);
 }
 
 }  // namespace
