@@ -1,0 +1,309 @@
+"""One-stage smooth-ELBO VAEs on the HIP path: drop-ins for smooth_vae_model/svhn_vae.py
+(svhn_VAE), smooth_vae_model/mnist_vae.py (mnist_VAE), the loss of the Trainer in main_smooth_ELBO_svhn.py:228-388 and
+one iteration of its loop (:152-176).
+
+Every convolution, transposed convolution and Linear layer of these models is the same gather-GEMM the SHOT-VAE step
+uses (sv_igemm / sv_wgrad / sv_colsum through the C ABI): 4x4 stride-2 convs as `conv_like`, the 4x4 stride-2 transposed
+convs as `convT_like` (four sub-pixel phases), the Linear layers as 1x1 GEMMs (the two that touch the 4x4 feature map
+with their weights permuted between the reference's (c, y, x) flattening and the NHWC one); the ReLU between two layers is
+the consumer's load prologue (scale 1, shift 0, slope 0) and, in the backward, the producer's activation-backward
+epilogue, so no activation tensor is ever materialised.  Each layer is one torch.autograd.Function over those calls;
+the heads' softmax, the samplers and the scalar loss terms on [B, 32] / [B, 10] tensors are torch ops (plumbing), as is
+torch.optim.Adam on the parameters.  Parameters keep the reference's names and shapes (state_dict compatible).
+
+There is no CPU fallback: the layers raise when the HIP library or a GPU is missing."""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _lib as L
+from . import geometry as G
+
+EPS = 1e-12
+KINDS = {"svhn": dict(in_ch=3, widths=(32, 64, 128), dec=(64, 32), hidden=512),
+         "mnist": dict(in_ch=1, widths=(32, 64, 64), dec=(32, 32), hidden=256)}
+
+
+def _vp(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _st():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _pad16(n):
+    return (n + 15) // 16 * 16
+
+
+class _Layer:
+    """Static description of one conv-like layer: kind 'conv' (Conv2d / Linear-as-conv) or 'convT'."""
+
+    def __init__(self, kind, k, stride, pad, cin, n, hin, cin_real=None, n_real=None):
+        self.kind, self.k, self.stride, self.pad = kind, k, stride, pad
+        self.Cin, self.N, self.Hin = cin, n, hin
+        self.cin_real, self.n_real = cin_real or cin, n_real or n
+        self.T = k * k
+        self._g = {}
+
+    @property
+    def Hout(self):
+        if self.kind == "conv":
+            return (self.Hin + 2 * self.pad - self.k) // self.stride + 1
+        return self.Hin * self.stride
+
+    def geom_fwd(self, B):
+        g = self._g.get(("f", B))
+        if g is None:
+            f = G.conv_like if self.kind == "conv" else G.convT_like
+            g = self._g[("f", B)] = f(B, self.Hin, self.Hin, self.Cin, self.N, self.k, self.stride, self.pad)
+        return g
+
+    def geom_dgrad(self, B):
+        g = self._g.get(("d", B))
+        if g is None:
+            f = G.convT_like if self.kind == "conv" else G.conv_like
+            g = self._g[("d", B)] = f(B, self.Hout, self.Hout, self.N, self.Cin, self.k, self.stride, self.pad)
+        return g
+
+    def master(self, w):
+        """torch parameter (OIHW for conv, IOHW for convT, [out, in] for Linear given as OIHW view) -> fp32 master
+        [N][tap][Cin], zero-padded to the MFMA channel multiples.  Differentiable (torch ops), so the weight gradient
+        in master layout flows back to the parameter's own layout."""
+        m = w.permute(0, 2, 3, 1) if self.kind == "conv" else w.permute(1, 2, 3, 0)       # [n][ky][kx][c]
+        m = m.reshape(self.n_real, self.T, self.cin_real)
+        if self.n_real != self.N or self.cin_real != self.Cin:
+            m = F.pad(m, (0, self.Cin - self.cin_real, 0, 0, 0, self.N - self.n_real))
+        return m.contiguous().float()
+
+
+class _ConvLikeFn(torch.autograd.Function):
+    """out = conv_like(ReLU?(x)) + bias through sv_igemm; backward = sv_igemm (data gradient with the ReLU backward as
+    its epilogue), sv_wgrad, sv_colsum."""
+
+    @staticmethod
+    def forward(ctx, x, master, bias, layer, relu_in, dtype):
+        if not x.is_cuda:
+            raise L.ShotVaeHipError("shot-vae_amd runs on an MI355X only (no CPU fallback)")
+        code, tdt = (L.SV_BF16, torch.bfloat16) if dtype == "bf16" else (L.SV_F32, torch.float32)
+        x = x.contiguous()
+        B, dev = x.shape[0], x.device
+        gf = layer.geom_fwd(B)
+        wp = torch.zeros(max(G.packed_size(gf), 1), dtype=tdt, device=dev)
+        L.call("sv_repack", code, _vp(master), layer.N, layer.T, layer.Cin, 0, C.byref(gf), _vp(wp), _st())
+        out = torch.empty(B, layer.Hout, layer.Hout, layer.N, dtype=tdt, device=dev)
+        a = L.SvIgemmArgs()
+        a.x, a.w, a.out, a.replicas = x.data_ptr(), wp.data_ptr(), out.data_ptr(), 1
+        keep = [wp]
+        if relu_in:
+            one, zero = torch.ones(layer.Cin, device=dev), torch.zeros(layer.Cin, device=dev)
+            a.pro_scale, a.pro_shift, a.pro_slope = one.data_ptr(), zero.data_ptr(), 0.0
+            keep += [one, zero]
+        if bias is not None:
+            a.bias = bias.data_ptr()
+        L.call("sv_igemm", C.byref(gf), code, C.byref(a), _st())
+        ctx.save_for_backward(x, master)
+        ctx.layer, ctx.relu_in, ctx.code, ctx.tdt, ctx.has_bias = layer, relu_in, code, tdt, bias is not None
+        ctx.keep = keep
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, master = ctx.saved_tensors
+        layer, code, tdt = ctx.layer, ctx.code, ctx.tdt
+        B, dev = x.shape[0], x.device
+        dy = dy.contiguous()
+        gf, gd = layer.geom_fwd(B), layer.geom_dgrad(B)
+        one, zero = torch.ones(layer.Cin, device=dev), torch.zeros(layer.Cin, device=dev)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            wpd = torch.zeros(max(G.packed_size(gd), 1), dtype=tdt, device=dev)
+            L.call("sv_repack", code, _vp(master), layer.N, layer.T, layer.Cin, 1, C.byref(gd), _vp(wpd), _st())
+            dx = torch.empty_like(x)
+            a = L.SvIgemmArgs()
+            a.x, a.w, a.out, a.replicas = dy.data_ptr(), wpd.data_ptr(), dx.data_ptr(), 1
+            if ctx.relu_in:     # ReLU backward fused as the activation-backward epilogue (BN part: identity statistics)
+                bs = torch.zeros(2 * layer.Cin, device=dev)
+                a.ex, a.ex_scale, a.ex_shift = x.data_ptr(), one.data_ptr(), zero.data_ptr()
+                a.ex_mean, a.ex_rstd, a.ex_slope, a.bsums = zero.data_ptr(), one.data_ptr(), 0.0, bs.data_ptr()
+            L.call("sv_igemm", C.byref(gd), code, C.byref(a), _st())
+        dw = torch.zeros_like(master)
+        L.call("sv_wgrad", C.byref(gf), code, _vp(x), _vp(one) if ctx.relu_in else None,
+               _vp(zero) if ctx.relu_in else None, 0.0, _vp(dy), _vp(dw), 0, 1, None, 0, _st())
+        db = None
+        if ctx.has_bias:
+            db = torch.zeros(layer.N, device=dev)
+            L.call("sv_colsum", code, _vp(dy), dy.numel() // layer.N, layer.N, layer.N, _vp(db), _st())
+        return dx, dw, db, None, None, None
+
+
+class SmoothVAE(nn.Module):
+    """svhn_VAE / mnist_VAE (smooth_vae_model/svhn_vae.py:8-300): same constructor arguments, parameter names and
+    forward contract -- forward(x, label=None) -> (reconstruction after Tanh, {'cont': [mean, logvar], 'disc': [alpha]},
+    latent sample, [discrete sample]).  `kind` selects the widths ('svhn': 3x32x32 input, 'mnist': 1x32x32)."""
+
+    def __init__(self, img_size, latent_spec, temperature=.67, use_cuda=True, kind=None, compute_dtype="bf16"):
+        super().__init__()
+        kind = kind or ("svhn" if img_size[0] == 3 else "mnist")
+        k = KINDS[kind]
+        assert tuple(img_size) == (k["in_ch"], 32, 32), "the MI355X path covers the reference's 32x32 inputs"
+        assert "cont" in latent_spec and len(latent_spec.get("disc", [])) == 1, \
+            "one continuous block and one categorical latent (the trainers' latent_spec)"
+        self.kind, self.img_size, self.latent_spec, self.temperature = kind, tuple(img_size), latent_spec, temperature
+        self.use_cuda, self.compute_dtype = use_cuda, compute_dtype
+        self.num_pixels = img_size[0] * img_size[1] * img_size[2]
+        self.is_continuous = self.is_discrete = True
+        self.latent_cont_dim, self.latent_disc_dim = latent_spec["cont"], latent_spec["disc"][0]
+        self.latent_dim = self.latent_cont_dim + self.latent_disc_dim
+        self.hidden_dim = k["hidden"]
+        w1, w2, w3 = k["widths"]
+        d1, d2 = k["dec"]
+        self.reshape = (w3, 4, 4)
+        ch, h, lat = k["in_ch"], self.hidden_dim, self.latent_dim
+        # parameters in the reference's modules (same state_dict keys / shapes); only their tensors are used
+        self.img_to_features = nn.Sequential(nn.Conv2d(ch, w1, 4, 2, 1), nn.ReLU(), nn.Conv2d(w1, w2, 4, 2, 1), nn.ReLU(),
+                                             nn.Conv2d(w2, w3, 4, 2, 1), nn.ReLU())
+        self.features_to_hidden = nn.Sequential(nn.Linear(w3 * 16, h), nn.ReLU())
+        self.fc_mean, self.fc_log_var = nn.Linear(h, self.latent_cont_dim), nn.Linear(h, self.latent_cont_dim)
+        self.fc_alphas = nn.ModuleList([nn.Linear(h, self.latent_disc_dim)])
+        self.latent_to_features = nn.Sequential(nn.Linear(lat, h), nn.ReLU(), nn.Linear(h, w3 * 16), nn.ReLU())
+        self.features_to_img = nn.Sequential(nn.ConvTranspose2d(w3, d1, 4, 2, 1), nn.ReLU(),
+                                             nn.ConvTranspose2d(d1, d2, 4, 2, 1), nn.ReLU(),
+                                             nn.ConvTranspose2d(d2, ch, 4, 2, 1), nn.Tanh())
+        NH = 2 * self.latent_cont_dim + self.latent_disc_dim
+        self._L = dict(
+            c1=_Layer("conv", 4, 2, 1, 16, w1, 32, cin_real=ch), c2=_Layer("conv", 4, 2, 1, w1, w2, 16),
+            c3=_Layer("conv", 4, 2, 1, w2, w3, 8), f1=_Layer("conv", 1, 1, 0, w3 * 16, h, 1),
+            heads=_Layer("conv", 1, 1, 0, h, _pad16(NH), 1, n_real=NH),
+            g1=_Layer("conv", 1, 1, 0, _pad16(lat), h, 1, cin_real=lat), g2=_Layer("conv", 1, 1, 0, h, w3 * 16, 1),
+            t1=_Layer("convT", 4, 2, 1, w3, d1, 4), t2=_Layer("convT", 4, 2, 1, d1, d2, 8),
+            t3=_Layer("convT", 4, 2, 1, d2, 16, 16, n_real=ch))
+        self._tdt = torch.bfloat16 if compute_dtype == "bf16" else torch.float32
+
+    # ---- layers --------------------------------------------------------------------------------------------------
+    def _run(self, name, x, w, b, relu_in, npad=None):
+        layer = self._L[name]
+        if b is not None and layer.n_real != layer.N:
+            b = F.pad(b, (0, layer.N - layer.n_real))
+        return _ConvLikeFn.apply(x, layer.master(w), b.float().contiguous() if b is not None else None, layer, relu_in,
+                                 self.compute_dtype)
+
+    def encode(self, x):
+        """-> (mean, logvar, alpha) (svhn_vae.py:137-166)"""
+        B = x.shape[0]
+        x16 = F.pad(x.permute(0, 2, 3, 1), (0, 16 - x.shape[1])).to(self._tdt).contiguous()     # NHWC16 (layout edge)
+        e = self.img_to_features
+        y = self._run("c1", x16, e[0].weight, e[0].bias, False)
+        y = self._run("c2", y, e[2].weight, e[2].bias, True)
+        y = self._run("c3", y, e[4].weight, e[4].bias, True)
+        fh = self.features_to_hidden[0]
+        w3 = self.reshape[0]
+        # Linear over features.view(B, -1) of the NCHW map = a 1x1 GEMM over the NHWC map flattened as (y, x, c) with the
+        # weight's input index permuted from (c, y, x) to (y, x, c) (a differentiable view-permute of the parameter)
+        wf = fh.weight.view(self.hidden_dim, w3, 4, 4).permute(0, 2, 3, 1).reshape(self.hidden_dim, w3 * 16, 1, 1)
+        hid = self._run("f1", y.view(B, 1, 1, w3 * 16), wf, fh.bias, True)                       # [B,1,1,hidden] raw
+        wh = torch.cat([self.fc_mean.weight, self.fc_log_var.weight, self.fc_alphas[0].weight], 0)
+        bh = torch.cat([self.fc_mean.bias, self.fc_log_var.bias, self.fc_alphas[0].bias], 0)
+        o = self._run("heads", hid, wh.view(wh.shape[0], self.hidden_dim, 1, 1), bh, True).view(B, -1).float()
+        c = self.latent_cont_dim
+        return o[:, :c], o[:, c:2 * c], F.softmax(o[:, 2 * c:2 * c + self.latent_disc_dim], dim=1)
+
+    def sample_normal(self, mean, logvar):
+        if self.training:
+            return mean + torch.exp(0.5 * logvar) * torch.randn(mean.shape, device=mean.device).to(mean.device)
+        return mean
+
+    def sample_gumbel_softmax(self, alpha):
+        if self.training:
+            unif = torch.rand(alpha.shape, device=alpha.device).to(alpha.device)
+            gumbel = -torch.log(-torch.log(unif + EPS) + EPS)
+            return F.softmax((torch.log(alpha + EPS) + gumbel) / self.temperature, dim=1)
+        return F.one_hot(alpha.argmax(1), alpha.shape[1]).float()
+
+    def decode(self, latent_sample):
+        B = latent_sample.shape[0]
+        lat = self._L["g1"].Cin
+        z = F.pad(latent_sample, (0, lat - latent_sample.shape[1])).to(self._tdt).view(B, 1, 1, lat)
+        lf = self.latent_to_features
+        f = self._run("g1", z, lf[0].weight.view(self.hidden_dim, self.latent_dim, 1, 1), lf[0].bias, False)
+        w3 = self.reshape[0]
+        # Linear whose output is viewed as (c, 4, 4): rows permuted to (y, x, c) so that the GEMM writes NHWC directly
+        wg = lf[2].weight.view(w3, 4, 4, self.hidden_dim).permute(1, 2, 0, 3).reshape(w3 * 16, self.hidden_dim, 1, 1)
+        bg = lf[2].bias.view(w3, 4, 4).permute(1, 2, 0).reshape(-1)
+        f = self._run("g2", f, wg, bg, True).view(B, 4, 4, w3)                                            # NHWC
+        d = self.features_to_img
+        f = self._run("t1", f, d[0].weight, d[0].bias, True)
+        f = self._run("t2", f, d[2].weight, d[2].bias, True)
+        f = self._run("t3", f, d[4].weight, d[4].bias, True)                                              # [B,32,32,16]
+        return torch.tanh(f[..., :self.img_size[0]].permute(0, 3, 1, 2).float())
+
+    def forward(self, x, label=None):
+        mean, logvar, alpha = self.encode(x)
+        latent_dist = {"cont": [mean, logvar], "disc": [alpha]}
+        z = self.sample_normal(mean, logvar)
+        disc_sample = []
+        if label is None:
+            c = self.sample_gumbel_softmax(alpha)
+        else:
+            c = F.one_hot(label, self.latent_disc_dim).float()
+            disc_sample.append(self.sample_gumbel_softmax(alpha))       # drawn (and unused) as in svhn_vae.py:205-207
+        latent_sample = torch.cat([z, c], 1)
+        return self.decode(latent_sample), latent_dist, latent_sample, disc_sample
+
+
+svhn_VAE = mnist_VAE = SmoothVAE
+
+
+class SmoothELBOLoss:
+    """Trainer._loss_function (main_smooth_ELBO_svhn.py:228-310): num_pixels * MSE + gamma_c |C_c(t) - KL_c| +
+    gamma_d |C_d(t) - KL_d| + alpha * BCE(q(y|x), one-hot label); capacities grow linearly with `num_steps`."""
+
+    def __init__(self, cont_capacity=(0.0, 50, 50000, 1), disc_capacity=(0.0, 50, 50000, 1), alpha=1500.0):
+        self.cont_capacity, self.disc_capacity, self.alpha, self.num_steps = cont_capacity, disc_capacity, alpha, 0
+
+    @staticmethod
+    def _cap(cap, t, tmax=None):
+        c = min((cap[1] - cap[0]) * t / float(cap[2]) + cap[0], cap[1])
+        return c if tmax is None else min(c, tmax)
+
+    def __call__(self, data, recon_data, latent_dist, label=None):
+        B = data.shape[0]
+        npix = data[0].numel()
+        recon_loss = F.mse_loss(recon_data.reshape(B, npix), data.reshape(B, npix)) * npix
+        mean, logvar = latent_dist["cont"]
+        kl_c = (-0.5 * (1 + logvar - mean.pow(2) - logvar.exp())).mean(0).sum()
+        cont_loss = self.cont_capacity[3] * torch.abs(self._cap(self.cont_capacity, self.num_steps) - kl_c)
+        alpha = latent_dist["disc"][0]
+        D = alpha.shape[1]
+        kl_d = math.log(D) + (alpha * torch.log(alpha + EPS)).sum(1).mean(0)
+        disc_loss = self.disc_capacity[3] * torch.abs(self._cap(self.disc_capacity, self.num_steps, math.log(D)) - kl_d)
+        cls = torch.zeros((), device=data.device)
+        if label is not None:
+            cls = self.alpha * F.binary_cross_entropy(alpha, F.one_hot(label, D).float())
+        return recon_loss + cont_loss + disc_loss + cls, (recon_loss, cont_loss, disc_loss, cls)
+
+
+def smooth_train_step(model, loss_fn, optimizer, unlabeled_data, labeled_data, label, return_outputs=False):
+    """One iteration of Trainer._train_epoch (main_smooth_ELBO_svhn.py:152-176)."""
+    loss_fn.num_steps += 1
+    if optimizer is not None:
+        optimizer.zero_grad()
+    rec_u, dist_u, _, _ = model(unlabeled_data)
+    loss_u, split_u = loss_fn(unlabeled_data, rec_u, dist_u)
+    rec_l, dist_l, _, _ = model(labeled_data, label)
+    loss_l, split_l = loss_fn(labeled_data, rec_l, dist_l, label)
+    loss = loss_u + loss_l
+    loss.backward()
+    if optimizer is not None:
+        optimizer.step()
+    if not return_outputs:
+        return loss.detach()
+    out = dict(loss=loss, loss_u=loss_u, loss_l=loss_l, recon_u=split_u[0], cont_u=split_u[1], disc_u=split_u[2],
+               recon_l=split_l[0], cont_l=split_l[1], disc_l=split_l[2], cls_l=split_l[3], rec_u=rec_u,
+               mean_u=dist_u["cont"][0], logvar_u=dist_u["cont"][1], alpha_u=dist_u["disc"][0], rec_l=rec_l,
+               mean_l=dist_l["cont"][0], logvar_l=dist_l["cont"][1], alpha_l=dist_l["disc"][0])
+    return {k: v.detach() for k, v in out.items()}

@@ -221,6 +221,90 @@ def run_m2_case(tag, name, K, B, epoch=10, dmi=2.3):
           float(out["kl_inference"]), "bytes", os.path.getsize(os.path.join(HERE, tag + ".npz")))
 
 
+def run_smooth_case(tag, kind, Bu, Bl, num_steps=7):
+    """One iteration of the one-stage smooth-ELBO trainer on the REFERENCE model (smooth_vae_model/{svhn,mnist}_vae.py).
+    The trainer script (main_smooth_ELBO_svhn.py) has argparse at import, so the loop body (:152-176) and the loss
+    (:228-388) are restated here, driving the reference model and torch.optim.Adam."""
+    import math
+    import torch.nn.functional as F
+    from oracle import smooth_oracle as SO
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    nn.Module.cuda = lambda self, *a, **k: self
+    sys.path.insert(0, REF)
+    if kind == "svhn":
+        from smooth_vae_model.svhn_vae import svhn_VAE as Model
+        img = (3, 32, 32)
+    else:
+        from smooth_vae_model.mnist_vae import mnist_VAE as Model
+        img = (1, 32, 32)
+    spec = {"cont": 32, "disc": [10]}
+    model = Model(img_size=img, latent_spec=spec, temperature=0.67, use_cuda=False)
+    st = SO.make_state(kind)
+    sd = model.state_dict()
+    assert list(sd.keys()) == list(st.keys()), (list(sd.keys()), list(st.keys()))
+    assert all(tuple(sd[k].shape) == tuple(st[k].shape) for k in sd)
+    model.load_state_dict(st)
+    model.train()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    unl, lab, label, nz = SO.make_inputs(kind, Bu, Bl)
+    cap_c, cap_d, cls_alpha, EPS = (0.0, 50, 50000, 1), (0.0, 50, 50000, 1), 1500.0, 1e-12
+
+    def loss_function(data, recon, dist, lbl=None):
+        npix = img[0] * img[1] * img[2]
+        recon_loss = F.mse_loss(recon.view(-1, npix), data.view(-1, npix)) * npix
+        mean, logvar = dist["cont"]
+        kl_values = -0.5 * (1 + logvar - mean.pow(2) - logvar.exp())
+        kl_c = torch.sum(torch.mean(kl_values, dim=0))
+        cc = min((cap_c[1] - cap_c[0]) * num_steps / float(cap_c[2]) + cap_c[0], cap_c[1])
+        cont_loss = cap_c[3] * torch.abs(cc - kl_c)
+        alpha = dist["disc"][0]
+        neg_entropy = torch.sum(alpha * torch.log(alpha + EPS), dim=1)
+        kl_d = torch.Tensor([np.log(10)]) + torch.mean(neg_entropy, dim=0)
+        kl_d = torch.sum(torch.cat([kl_d]))
+        dc = min(min((cap_d[1] - cap_d[0]) * num_steps / float(cap_d[2]) + cap_d[0], cap_d[1]), float(np.log(10)))
+        disc_loss = cap_d[3] * torch.abs(dc - kl_d)
+        cls = 0
+        if lbl is not None:
+            one_hot = torch.Tensor(np.eye(10)[lbl.cpu()])
+            cls = cls_alpha * nn.BCELoss()(alpha, one_hot)
+        return recon_loss + cont_loss + disc_loss + cls, (recon_loss, cont_loss, disc_loss, cls)
+
+    # host RNG of the model: torch.zeros(size).normal_() and torch.rand(size) -- scripted in call order
+    q_n, q_u = [nz["eps_u"], nz["eps_l"]], [nz["u_u"], nz["u_l"]]
+    saved = (torch.Tensor.normal_, torch.rand)
+    torch.Tensor.normal_ = lambda self, *a, **k: self.copy_(q_n.pop(0))
+    torch.rand = lambda *s, **k: q_u.pop(0).clone()
+    try:
+        opt.zero_grad()
+        rec_u, dist_u, _, _ = model(unl)
+        loss_u, split_u = loss_function(unl, rec_u, dist_u)
+        rec_l, dist_l, _, dsamp = model(lab, label)
+        loss_l, split_l = loss_function(lab, rec_l, dist_l, label)
+        loss = loss_u + loss_l
+        loss.backward()
+    finally:
+        torch.Tensor.normal_, torch.rand = saved
+    assert not q_n and not q_u
+    rec = dict(loss=loss, loss_u=loss_u, loss_l=loss_l, recon_u=split_u[0], cont_u=split_u[1], disc_u=split_u[2],
+               recon_l=split_l[0], cont_l=split_l[1], disc_l=split_l[2], cls_l=split_l[3], rec_u=rec_u,
+               mean_u=dist_u["cont"][0], logvar_u=dist_u["cont"][1], alpha_u=dist_u["disc"][0], rec_l=rec_l,
+               mean_l=dist_l["cont"][0], logvar_l=dist_l["cont"][1], alpha_l=dist_l["disc"][0])
+    rec = {k: v.detach().numpy() for k, v in rec.items()}
+    names = [k for k, _ in model.named_parameters()]
+    rec["grad_norm"] = np.array([float(p.grad.double().norm()) for _, p in model.named_parameters()])
+    rec["grad_sample"] = np.concatenate(
+        [p.grad.reshape(-1)[torch.from_numpy(grad_sample_idx(p.numel()))].numpy() for _, p in model.named_parameters()])
+    opt.step()
+    sd = model.state_dict()
+    rec["final.param_norm"] = np.array([float(sd[k].double().norm()) for k in names])
+    rec["final.param_sample"] = np.concatenate(
+        [sd[k].reshape(-1)[torch.from_numpy(grad_sample_idx(sd[k].numel()))].numpy() for k in names])
+    rec["meta.num_steps"] = np.array(num_steps)
+    np.savez_compressed(os.path.join(HERE, tag + ".npz"), **rec)
+    print(tag, "loss", float(loss), "recon_u", float(split_u[0]), "cls", float(split_l[3]), "bytes",
+          os.path.getsize(os.path.join(HERE, tag + ".npz")))
+
+
 def run_eval_case(tag, name, K, B):
     VAE, *_ = import_reference()
     model = VAE(encoder_name=name, num_input_channels=3, drop_rate=0, img_size=(32, 32),
@@ -279,6 +363,10 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "m2":          # only the M2 fixture
         run_m2_case("ref_m2_step_wrn10_1", "wideresnet-10-1", 10, 6)
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "smooth":      # only the smooth-ELBO fixtures
+        run_smooth_case("ref_smooth_svhn", "svhn", 6, 4)
+        run_smooth_case("ref_smooth_mnist", "mnist", 4, 6)
+        sys.exit(0)
     run_fn_cases("ref_functions")
     run_eval_case("ref_eval_wrn10_1", "wideresnet-10-1", 10, 4)
     run_step_case("ref_step_wrn10_1_br", "wideresnet-10-1", 10, 4, 6, True, steps=2)
@@ -287,3 +375,5 @@ if __name__ == "__main__":
     run_step_case("ref_step_wrn28_2_mse", "wideresnet-28-2", 10, 4, 4, False, x_sigma=0.5)
     run_step_case("ref_step_wrn28_10_k100", "wideresnet-28-10", 100, 2, 2, True, dmi=4.6)
     run_m2_case("ref_m2_step_wrn10_1", "wideresnet-10-1", 10, 6)
+    run_smooth_case("ref_smooth_svhn", "svhn", 6, 4)
+    run_smooth_case("ref_smooth_mnist", "mnist", 4, 6)

@@ -123,3 +123,33 @@ def test_m2_baseline_step_matches_reference():
     pk = [k for k in st if O.is_param(k)]
     gn = np.array([float(st[k].grad.double().norm()) for k in pk])
     assert np.max(np.abs(gn - g["grad_norm"])) < 2e-4 * np.max(g["grad_norm"])
+
+
+SMOOTH_SCALARS = ["loss", "loss_u", "loss_l", "recon_u", "cont_u", "disc_u", "recon_l", "cont_l", "disc_l", "cls_l"]
+SMOOTH_TENSORS = ["rec_u", "mean_u", "logvar_u", "alpha_u", "rec_l", "mean_l", "logvar_l", "alpha_l"]
+
+
+@pytest.mark.parametrize("kind,Bu,Bl", [("svhn", 6, 4), ("mnist", 4, 6)])
+def test_smooth_elbo_iteration_matches_reference(kind, Bu, Bl):
+    """oracle.smooth_oracle (svhn_VAE / mnist_VAE forward, the trainer's loss, Adam) against one iteration of the
+    reference model driven by tests/golden/make_goldens.py (smooth cases)."""
+    from oracle import smooth_oracle as SO
+    g = T.load("ref_smooth_" + kind)
+    st = SO.make_state(kind)
+    for k in st:
+        st[k].requires_grad_(True)
+    unl, lab, label, nz = SO.make_inputs(kind, Bu, Bl)
+    out = SO.train_iteration(st, kind, unl, lab, label, nz, int(g["meta.num_steps"]))
+    for k in SMOOTH_SCALARS:
+        assert abs(float(out[k]) - float(g[k])) <= 2e-5 * max(1.0, abs(float(g[k]))), (k, float(out[k]), float(g[k]))
+    for k in SMOOTH_TENSORS:
+        assert T.rel_err(out[k].numpy(), g[k]) < 2e-5, k
+    gn = np.array([float(st[k].grad.double().norm()) for k in st])
+    assert np.max(np.abs(gn - g["grad_norm"])) < 2e-4 * np.max(g["grad_norm"])
+    gs = np.concatenate([st[k].grad.reshape(-1)[torch.from_numpy(T.sample_idx(st[k].numel()))].numpy() for k in st])
+    assert T.rel_err(gs, g["grad_sample"]) < 2e-4
+    SO.adam_step(st, {})
+    pn = np.array([float(st[k].detach().double().norm()) for k in st])
+    assert np.max(np.abs(pn - g["final.param_norm"]) / g["final.param_norm"]) < 1e-5
+    ps = np.concatenate([st[k].detach().reshape(-1)[torch.from_numpy(T.sample_idx(st[k].numel()))].numpy() for k in st])
+    assert T.rel_err(ps, g["final.param_sample"]) < 1e-5
