@@ -47,3 +47,24 @@ def all_reduce_gradients(flat_grad):
         dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM)
         return 1.0 / dist.get_world_size()
     return 1.0
+
+
+def all_reduce_module_gradients(module, average=True):
+    """Data parallelism for modules whose parameters are ordinary torch tensors (the smooth-ELBO SmoothVAE, config 5):
+    the .grad tensors are flattened into ONE bucket, all-reduced once (RCCL over xGMI) and scattered back, averaged over
+    the ranks -- the same single-collective scheme as the flat-buffer path.  Returns the number of elements reduced."""
+    grads = [p.grad for p in module.parameters() if p.grad is not None]
+    if not grads:
+        return 0
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return sum(g.numel() for g in grads)
+    flat = torch.cat([g.reshape(-1) for g in grads])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    if average:
+        flat /= dist.get_world_size()
+    off = 0
+    for g in grads:
+        n = g.numel()
+        g.copy_(flat[off:off + n].view_as(g))
+        off += n
+    return off

@@ -287,8 +287,10 @@ class SmoothELBOLoss:
         return recon_loss + cont_loss + disc_loss + cls, (recon_loss, cont_loss, disc_loss, cls)
 
 
-def smooth_train_step(model, loss_fn, optimizer, unlabeled_data, labeled_data, label, return_outputs=False):
-    """One iteration of Trainer._train_epoch (main_smooth_ELBO_svhn.py:152-176)."""
+def smooth_train_step(model, loss_fn, optimizer, unlabeled_data, labeled_data, label, return_outputs=False,
+                      distributed=False):
+    """One iteration of Trainer._train_epoch (main_smooth_ELBO_svhn.py:152-176).  distributed=True: one process per
+    GPU, every rank on its shard of both batches, ONE all-reduce of the bucketed gradients before the optimizer step."""
     loss_fn.num_steps += 1
     if optimizer is not None:
         optimizer.zero_grad()
@@ -298,6 +300,9 @@ def smooth_train_step(model, loss_fn, optimizer, unlabeled_data, labeled_data, l
     loss_l, split_l = loss_fn(labeled_data, rec_l, dist_l, label)
     loss = loss_u + loss_l
     loss.backward()
+    if distributed:
+        from . import dp
+        dp.all_reduce_module_gradients(model)
     if optimizer is not None:
         optimizer.step()
     if not return_outputs:

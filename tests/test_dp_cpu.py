@@ -70,3 +70,36 @@ def test_shard_partitions_the_batch():
     parts = [dp.shard(t, r, 4) for r in range(4)]
     assert torch.equal(torch.cat(parts), t)
     assert dp.all_reduce_gradients(torch.ones(3)) == 1.0      # no process group: identity, scale 1
+
+
+def _worker_module(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from shot_vae_amd import dp
+    dp.init_from_env(backend="gloo")
+    torch.manual_seed(0)
+    m = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.ReLU(), torch.nn.Linear(7, 3))
+    x = torch.arange(20, dtype=torch.float32).view(4, 5) / 10 + rank
+    m(x).square().sum().backward()
+    local = [p.grad.clone() for p in m.parameters()]
+    n = dp.all_reduce_module_gradients(m)
+    gathered = [[torch.zeros_like(g) for _ in range(world)] for g in local]
+    for g, lst in zip(local, gathered):
+        dist.all_gather(lst, g)
+    if rank == 0:
+        torch.save(dict(n=n, reduced=[p.grad.clone() for p in m.parameters()], locals=gathered), out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_module_gradient_bucket(tmp_path):
+    """dp.all_reduce_module_gradients (the smooth-ELBO DP path): one bucket, mean over ranks, scattered back."""
+    out = str(tmp_path / "dpm.pt")
+    port = 31500 + os.getpid() % 2000
+    mp.spawn(_worker_module, args=(2, port, out), nprocs=2, join=True)
+    r = torch.load(out)
+    assert r["n"] == 5 * 7 + 7 + 7 * 3 + 3
+    for red, per_rank in zip(r["reduced"], r["locals"]):
+        assert torch.allclose(red, (per_rank[0] + per_rank[1]) / 2, rtol=1e-6, atol=1e-7)
