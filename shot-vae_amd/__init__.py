@@ -8,4 +8,5 @@ from .optim import FlatSGD                        # noqa: F401
 from .train import (train_step, train_step_overlapped, GraphedTrainStep, DeviceRng, schedule,   # noqa: F401
                     alpha_schedule, m2_train_step)
 from .data import DeviceDataset, ssl_split      # noqa: F401
-from .smooth import SmoothVAE, svhn_VAE, mnist_VAE, SmoothELBOLoss, smooth_train_step      # noqa: F401
+from .smooth import (SmoothVAE, svhn_VAE, mnist_VAE, SmoothELBOLoss, smooth_train_step,      # noqa: F401
+                     GraphedSmoothStep)

@@ -264,9 +264,12 @@ class SmoothELBOLoss:
 
     def __init__(self, cont_capacity=(0.0, 50, 50000, 1), disc_capacity=(0.0, 50, 50000, 1), alpha=1500.0):
         self.cont_capacity, self.disc_capacity, self.alpha, self.num_steps = cont_capacity, disc_capacity, alpha, 0
+        self.steps_dev = None       # optional device scalar used instead of num_steps (hipGraph replay)
 
-    @staticmethod
-    def _cap(cap, t, tmax=None):
+    def _cap(self, cap, t, tmax=None):
+        if self.steps_dev is not None:          # same formula on a device scalar: the captured graph follows the counter
+            c = torch.clamp((cap[1] - cap[0]) * self.steps_dev / float(cap[2]) + cap[0], max=float(cap[1]))
+            return c if tmax is None else torch.clamp(c, max=float(tmax))
         c = min((cap[1] - cap[0]) * t / float(cap[2]) + cap[0], cap[1])
         return c if tmax is None else min(c, tmax)
 
@@ -312,3 +315,49 @@ def smooth_train_step(model, loss_fn, optimizer, unlabeled_data, labeled_data, l
                mean_u=dist_u["cont"][0], logvar_u=dist_u["cont"][1], alpha_u=dist_u["disc"][0], rec_l=rec_l,
                mean_l=dist_l["cont"][0], logvar_l=dist_l["cont"][1], alpha_l=dist_l["disc"][0])
     return {k: v.detach() for k, v in out.items()}
+
+
+class GraphedSmoothStep:
+    """One trainer iteration (both forwards, the loss, backward, Adam) captured once into a hipGraph and replayed: the
+    eager iteration is ~120 kernel launches plus torch glue and entirely host-bound (7 ms at batch 1024; SURVEY.md §8d
+    config 5).  The optimizer must be graph-capturable (torch.optim.Adam(..., capturable=True)); the capacity schedule
+    follows a device-side step counter; noise comes from torch's graph-safe Philox generator."""
+
+    def __init__(self, model, loss_fn, optimizer, unlabeled_data, labeled_data, label, warmup=3, distributed=False):
+        assert not distributed, "the captured iteration is single-GPU; use smooth_train_step(distributed=True) for DP"
+        self.model, self.loss_fn, self.opt = model, loss_fn, optimizer
+        self.u, self.l, self.y = unlabeled_data.clone(), labeled_data.clone(), label.clone()
+        loss_fn.steps_dev = torch.full((), float(loss_fn.num_steps), device=self.u.device)
+        self.stream = torch.cuda.Stream()
+        cur = torch.cuda.current_stream()
+        self.stream.wait_stream(cur)
+        with torch.cuda.stream(self.stream):
+            for _ in range(warmup):
+                self._body()
+        cur.wait_stream(self.stream)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph, stream=self.stream):
+            self.loss = self._body()
+
+    def _body(self):
+        lf = self.loss_fn
+        lf.steps_dev += 1
+        self.opt.zero_grad(set_to_none=False)
+        rec_u, dist_u, _, _ = self.model(self.u)
+        loss_u, _ = lf(self.u, rec_u, dist_u)
+        rec_l, dist_l, _, _ = self.model(self.l, self.y)
+        loss_l, _ = lf(self.l, rec_l, dist_l, self.y)
+        loss = loss_u + loss_l
+        loss.backward()
+        self.opt.step()
+        return loss.detach()
+
+    def __call__(self, unlabeled_data=None, labeled_data=None, label=None):
+        if unlabeled_data is not None:
+            self.u.copy_(unlabeled_data)
+            self.l.copy_(labeled_data)
+            self.y.copy_(label)
+        self.graph.replay()
+        self.loss_fn.num_steps += 1
+        return self.loss

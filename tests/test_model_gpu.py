@@ -186,6 +186,53 @@ def test_smooth_elbo_bf16_tracks_fp32_and_trains():
     assert abs(losses["bf16"][0] - losses["fp32"][0]) < 2e-2 * abs(losses["fp32"][0]), losses
 
 
+def test_smooth_elbo_graphed_iteration_equals_eager():
+    """GraphedSmoothStep (hipGraph replay of the smooth-ELBO iteration, capturable Adam, device step counter) against
+    the eager smooth_train_step with the device noise frozen."""
+    from oracle import smooth_oracle as SO
+    unl, lab, label, nz = SO.make_inputs("svhn", 16, 8)
+    unl, lab, label = unl.cuda(), lab.cuda(), label.cuda()
+    gen = torch.Generator(device="cuda").manual_seed(11)
+    frozen = {}
+    real_randn, real_rand = torch.randn, torch.rand
+
+    def fixed(kind, real):
+        def f(*shape, **kw):
+            shp = tuple(shape[0]) if len(shape) == 1 and not isinstance(shape[0], int) else tuple(shape)
+            key = (kind, shp)
+            if key not in frozen:
+                frozen[key] = real(*shp, device="cuda", generator=gen)
+            return frozen[key].clone()
+        return f
+
+    torch.randn, torch.rand = fixed("n", real_randn), fixed("u", real_rand)
+    try:
+        res = []
+        for graphed in (False, True):
+            model = S.SmoothVAE((3, 32, 32), {"cont": 32, "disc": [10]}, compute_dtype="fp32").cuda().train()
+            model.load_state_dict(SO.make_state("svhn"))
+            lf = S.SmoothELBOLoss(cont_capacity=(0.0, 50, 20, 1), disc_capacity=(0.0, 50, 20, 1))
+            # SGD for the comparison: Adam's m / sqrt(v) turns the float-atomic rounding noise of near-zero gradients
+            # into +-lr parameter differences (the Adam path is exercised by test_smooth_elbo_bf16_tracks_fp32_and_trains
+            # and tools/smooth_bench.py)
+            opt = torch.optim.SGD(model.parameters(), lr=1e-5)
+            if graphed:
+                g = S.GraphedSmoothStep(model, lf, opt, unl, lab, label, warmup=2)
+                for _ in range(4):
+                    last = g()
+            else:
+                for _ in range(6):
+                    last = S.smooth_train_step(model, lf, opt, unl, lab, label)
+            torch.cuda.synchronize()
+            assert lf.num_steps == 6 if not graphed else lf.num_steps == 4      # (replays; the warm-ups count on the device)
+            res.append((float(last), {k: v.detach().float().cpu() for k, v in model.state_dict().items()}))
+        assert abs(res[0][0] - res[1][0]) < 1e-4 * abs(res[0][0]), (res[0][0], res[1][0])
+        for k in res[0][1]:
+            assert T.rel_err(res[1][1][k].numpy(), res[0][1][k].numpy()) < 1e-4, k
+    finally:
+        torch.randn, torch.rand = real_randn, real_rand
+
+
 def test_eval_forward_matches_reference_golden():
     g = T.load("ref_eval_wrn10_1")
     model = make_model("wideresnet-10-1", 10, "fp32", C.make_state("wideresnet-10-1", K=10)).eval()

@@ -13,3 +13,10 @@ for dt in ("bf16", "fp32"):
     for _ in range(n): S.smooth_train_step(m, lf, opt, u, l, y)
     torch.cuda.synchronize(); dt_s = (time.time() - t0) / n
     print("svhn_VAE smooth-ELBO iteration, %s, B_u=B_l=%d: %.2f ms  (%.0f images/s)" % (dt, B, dt_s * 1e3, 2 * B / dt_s))
+    opt2 = torch.optim.Adam(m.parameters(), lr=1e-3, capturable=True)
+    g = S.GraphedSmoothStep(m, lf, opt2, u, l, y)
+    for _ in range(3): g()
+    torch.cuda.synchronize(); t0 = time.time()
+    for _ in range(n): g()
+    torch.cuda.synchronize(); dt_s = (time.time() - t0) / n
+    print("    hipGraph replay:                        %s, B_u=B_l=%d: %.2f ms  (%.0f images/s)" % (dt, B, dt_s * 1e3, 2 * B / dt_s))
