@@ -235,7 +235,10 @@ __device__ __forceinline__ bf16x8 frag_tr_ld(const bf16* S, int pix_elem_q, int 
 template <int WLOG>
 __global__ __launch_bounds__(256, 1) void wgrad3x3w_kernel(const sv_geom g, const wg3_params p) {
     constexpr int W = 1 << WLOG, TR = 128 / W, WP = W + 2;
-    constexpr int HP = (TR + 2) * WP;
+    // LDS halo rows: row 0 / the last row are the vertical halo, and when a tile holds several whole images (W = 8:
+    // TR = 16 > H = 8) a zero spacer row separates them -- zero padding is DATA in LDS, the nine taps need no masks
+    constexpr int HH = (TR < W) ? TR : W, SEG = TR / HH, LROWS = TR + SEG + 1;
+    constexpr int HP = LROWS * WP;
     constexpr int YV = 128 * 20, YI = YV / 256;               // dy vectors (8 channels each): 10 per thread
     constexpr int HV = HP * 4, HI = (HV + 255) / 256;         // halo vectors
 
@@ -284,13 +287,24 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3w_kernel(const sv_geom g, cons
         t0 = *reinterpret_cast<const f32x4*>(p.pro_shift + c0 + 8 * v);
         t1 = *reinterpret_cast<const f32x4*>(p.pro_shift + c0 + 8 * v + 4);
     }
-    int hj[HI], hx[HI], hlds[HI];
+    // halo staging slots.  kind: 0 = always zero (padding column / spacer / dummy), 1 = image row of this tile,
+    //                            2 = row above the tile, 3 = row below it (valid only inside the same image)
+    int hrel[HI], hxc[HI], hlds[HI], hkind[HI];
 #pragma unroll
     for (int i = 0; i < HI; ++i) {
         const int idx = tid + 256 * i;
         const int pix = min(idx, HV - 1) >> 2;
-        hj[i] = pix / WP - 1;
-        hx[i] = pix - (pix / WP) * WP - 1;
+        const int lr = pix / WP, xx = pix - lr * WP;
+        const int seg = lr / (HH + 1), off = lr - seg * (HH + 1);
+        int kind = 1, rel = lr - 1 - seg;
+        if (off == 0) {
+            if (SEG == 1) { kind = seg == 0 ? 2 : 3; rel = seg == 0 ? -1 : TR; }
+            else kind = 0;
+        }
+        if (xx == 0 || xx == WP - 1) kind = 0;
+        hkind[i] = kind;
+        hrel[i] = rel;
+        hxc[i] = min(max(xx - 1, 0), W - 1);
         hlds[i] = idx < HV ? pix * LDH + 8 * v : -1;
     }
     // dy slot i of this thread: pixel (tid + 256 i) / 20, vector (tid + 256 i) % 20; 256 = 12 * 20 + 16
@@ -300,6 +314,7 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3w_kernel(const sv_geom g, cons
     bool hok[HI];
     auto load_tile = [&](int tile) {
         const int gr0 = tile * TR;
+        const bool top_ok = (gr0 & (H - 1)) != 0, bot_ok = ((gr0 + TR) & (H - 1)) != 0;
 #pragma unroll
         for (int i = 0; i < YI; ++i) {
             int vv = yv0 + 16 * i, pp = yp0 + 12 * i;
@@ -309,10 +324,9 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3w_kernel(const sv_geom g, cons
         }
 #pragma unroll
         for (int i = 0; i < HI; ++i) {
-            const int gr = gr0 + hj[i], x = hx[i];
-            hok[i] = (unsigned)x < (unsigned)W && (unsigned)gr < (unsigned)BH;
-            const int grc = min(max(gr, 0), BH - 1), xc = min(max(x, 0), W - 1);
-            rh[i] = *reinterpret_cast<const bf16x8*>(X + ((int64_t)grc * W + xc) * g.ldx + c0 + 8 * v);
+            hok[i] = hkind[i] == 1 || (hkind[i] == 2 && top_ok) || (hkind[i] == 3 && bot_ok);
+            const int grc = min(max(gr0 + hrel[i], 0), BH - 1);
+            rh[i] = *reinterpret_cast<const bf16x8*>(X + ((int64_t)grc * W + hxc[i]) * g.ldx + c0 + 8 * v);
         }
     };
     auto store_tile = [&]() {
@@ -344,32 +358,42 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3w_kernel(const sv_geom g, cons
 #pragma unroll
         for (int t = 0; t < 9; ++t) acc[a][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // fragments of one 32-pixel k chunk: 5 dy fragments + 9 tap-shifted x fragments; two sets, so that chunk kc+1 is
+    // being read from LDS while chunk kc is on the MFMAs (one wave per SIMD: nobody else hides the LDS latency)
+    struct Frags { bf16x8 fy[5], fx[9]; };
+    Frags FA, FB;
+    auto load_frags = [&](Frags& F, int kc) {
+        // lane addresses pixel pq = 32*kc + 8*fq + q (q = fr>>2) of the tile (and pq + 4)
+        const int pq = 32 * kc + 8 * fq + (fr >> 2);
+        const int jrow = pq >> WLOG, xcol = pq & (W - 1);
+#pragma unroll
+        for (int a = 0; a < 5; ++a) F.fy[a] = frag_tr_ld(Ys, pq * LDY, 80 * wi + 16 * a, lane, LDY);
+        const int hbase = ((jrow + 1 + jrow / HH) * WP + xcol + 1) * LDH;
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+            F.fx[t] = frag_tr(halo, hbase + (tap_off(pdy, t) * WP + tap_off(pdx, t)) * LDH, 16 * wj, lane);
+    };
+    auto mma_frags = [&](const Frags& F) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int a = 0; a < 5; ++a)
+                acc[a][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F.fy[a], F.fx[t], acc[a][t], 0, 0, 0);
+    };
+
     if (t_begin < t_end) load_tile(t_begin);
     for (int tile = t_begin; tile < t_end; ++tile) {
         store_tile();
         __syncthreads();
         if (tile + 1 < t_end) load_tile(tile + 1);        // in flight while this tile is on the MFMAs
-        const int gr0 = tile * TR;
-#pragma unroll
-        for (int kc = 0; kc < 4; ++kc) {
-            // lane addresses pixel pq = 32*kc + 8*fq + q (q = fr>>2) of the tile (and pq + 4)
-            const int pq = 32 * kc + 8 * fq + (fr >> 2);
-            const int jrow = pq >> WLOG, xcol = pq & (W - 1);
-            const int yrow = (gr0 + jrow) & (H - 1);    // the lane's 8 k-pixels share this image row
-            bf16x8 fy[5];
-#pragma unroll
-            for (int a = 0; a < 5; ++a) fy[a] = frag_tr_ld(Ys, pq * LDY, 80 * wi + 16 * a, lane, LDY);
-            const int hbase = ((jrow + 1) * WP + xcol + 1) * LDH;
-#pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const int dy = tap_off(pdy, t), dx = tap_off(pdx, t);
-                const bool ok = !((dy < 0 && yrow == 0) || (dy > 0 && yrow == H - 1));
-                bf16x8 fx = frag_tr(halo, hbase + (dy * WP + dx) * LDH, 16 * wj, lane);
-                fx = ok ? fx : zero;
-#pragma unroll
-                for (int a = 0; a < 5; ++a) acc[a][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fy[a], fx, acc[a][t], 0, 0, 0);
-            }
-        }
+        load_frags(FA, 0);
+        load_frags(FB, 1);
+        mma_frags(FA);
+        load_frags(FA, 2);
+        mma_frags(FB);
+        load_frags(FB, 3);
+        mma_frags(FA);
+        mma_frags(FB);
         __syncthreads();          // everyone is done reading before the next tile overwrites LDS
     }
 
@@ -432,7 +456,8 @@ int launch_wide(const sv_geom* g, const wg3_params& p, hipStream_t s) {
     constexpr int W = 1 << WLOG, TR = 128 / W;
     const int nC = g->Cin / 32, nNt = g->N / 160;
     const int grid = p.unit > 0 ? 8 * ((p.splits * nNt * (nC / p.unit) + 7) / 8) * p.unit : p.splits * nNt * nC;
-    const size_t lds = (size_t)(128 * LDY + (TR + 2) * (W + 2) * LDH) * 2;
+    constexpr int HHc = (TR < W) ? TR : W, LROWSc = TR + TR / HHc + 1;
+    const size_t lds = (size_t)(128 * LDY + LROWSc * (W + 2) * LDH) * 2;
     static bool optin = false;
     if (!optin) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3x3w_kernel<WLOG>),
