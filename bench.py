@@ -92,9 +92,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == a.gpus, "launch with --nproc-per-node %d (WORLD_SIZE=%d)" % (a.gpus, world)
-    torch.cuda.set_device(local)
+    torch.cuda.set_device(local % max(torch.cuda.device_count(), 1))
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world)     # "nccl" is RCCL on ROCm
+        # "nccl" is RCCL on ROCm.  SV_DIST_BACKEND=gloo lets the N > 1 code path be exercised on a one-GPU box (both
+        # ranks on the same device, the collective through host memory): a functional check, not a measurement.
+        dist.init_process_group(os.environ.get("SV_DIST_BACKEND", "nccl"), rank=rank, world_size=world)
 
     import shot_vae_amd as S
     from shot_vae_amd import _lib as L

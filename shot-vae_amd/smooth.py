@@ -337,7 +337,7 @@ class GraphedSmoothStep:
         cur.wait_stream(self.stream)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph, stream=self.stream):
+        with torch.cuda.graph(self.graph, stream=self.stream, capture_error_mode="thread_local"):
             self.loss = self._body()
 
     def _body(self):

@@ -239,7 +239,9 @@ class GraphedTrainStep:
         torch.cuda.synchronize()
         model._engine.mark_dirty()                  # the captured sequence must start with the weight re-packing
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph, stream=self.stream):
+        # thread_local: other threads (RCCL's watchdog polling its events at N > 1, the autograd worker's allocator
+        # calls) must not abort the capture
+        with torch.cuda.graph(self.graph, stream=self.stream, capture_error_mode="thread_local"):
             self.losses = self._body()
 
     def _body(self):
