@@ -317,6 +317,45 @@ def test_step_matches_oracle_b64(dtype, tol_s, tol_t, tol_g):
             assert int(sd[k]) == int(st[k]) == 4
 
 
+def test_wrn28_10_bf16_step_through_wide_kernels_tracks_oracle(monkeypatch):
+    """WRN-28-10 (BASELINE config 4 family), K=100, B_l = B_u = 16, bf16: the whole step with the wide-layer kernels
+    (conv3x3w for all 21 body convs and their data gradients -- SV_W3_MIN_BLOCKS lowers the dispatcher's grid bound
+    for this small batch -- and wgrad3x3w) against the fp32 CPU oracle: loss terms, outputs, BN running statistics,
+    and the flat gradient's direction."""
+    monkeypatch.setenv("SV_W3_MIN_BLOCKS", "1")
+    name, K, Bl, Bu = "wideresnet-28-10", 100, 16, 16
+    torch.manual_seed(4)
+    il, ll = torch.rand(Bl, 3, 32, 32), torch.randint(0, K, (Bl,))
+    iu = torch.rand(Bu, 3, 32, 32)
+    nz = O.make_noise(Bl, Bu, K, seed=12)
+    nz["lam_l"] = 0.85
+    sch = O.schedule(10, dmi=4.6)
+    st, ref = _oracle_run(name, K, il, ll, iu, nz, sch, torch.float32)
+    init = O.default_init(name, K=K, seed=5)
+    model = make_model(name, K, "bf16", init, dp=True)
+    elbo, cls = S.VAECriterion(discrete_dim=K, bce_reconstruction=True).cuda(), S.ClsCriterion()
+    S.FlatSGD(model).zero_grad()
+    with T.rng_for_step(nz):
+        out = S.train_step(model, elbo, cls, None, il.cuda(), ll.cuda(), iu.cuda(), sch, return_outputs=True)
+    torch.cuda.synchronize()
+    for k in T.SCALARS:
+        r = float(ref[k])
+        assert abs(float(out[k]) - r) <= 1e-2 * max(abs(r), 1e-6), (k, float(out[k]), r)
+    for k in T.TENSORS:
+        e = T.rel_err(out[k].float().cpu().numpy(), ref[k].numpy())
+        assert e < 5e-2, (k, e)
+    grads = param_grads(model)
+    fa = torch.cat([grads[k].double().flatten() for k in st if O.is_param(k)])
+    fb = torch.cat([st[k].grad.double().flatten() for k in st if O.is_param(k)])
+    cos = float(fa @ fb / fa.norm() / fb.norm())
+    print("\n[wrn-28-10 bf16] flat-gradient cosine vs the fp32 oracle %.4f" % cos)
+    assert cos > 0.9, cos
+    sd = {k.replace(".module.", "."): v for k, v in model.state_dict().items()}
+    for k in st:
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            assert T.rel_err(sd[k].float().cpu().numpy(), st[k].numpy()) < 3e-2, k
+
+
 def test_torch_optimizer_dropin_and_zero_grad_semantics():
     """The reference loop uses torch.optim.SGD(model.parameters()) + optimizer.zero_grad() (which sets
     .grad to None on current torch): the flat gradient buffer must be re-zeroed and re-attached."""
