@@ -65,7 +65,7 @@ struct WCfg {
     static constexpr int OFF_W = 2 * HB, OFF_CO = OFF_W + 3 * WBUF, OFF_SSUM = OFF_CO + 2048,
                          LDS = OFF_SSUM + 2 * BN * 4;
     static constexpr int SCR = 64 * 36 * 4;                 // epilogue transpose scratch per wave
-    static_assert(4 * SCR + 4 * 4096 <= OFF_CO, "epilogue scratch must fit in the halo + weight buffers");
+    static_assert(4 * SCR + 4 * 4096 <= OFF_SSUM, "epilogue scratch must fit in the halo + weight + coefficient buffers");
     static_assert(HI <= 6, "transform schedule covers at most 6 slots per thread");
     static_assert(2 * LDS <= 160 * 1024, "two blocks per CU");
 };
@@ -369,7 +369,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3w_kernel(const sv_geom g, const
     // (every wave is past the last barrier: the halo and weight buffers are free)
     float* const scr = reinterpret_cast<float*>(smem + wave * C::SCR);              // [64 pixels][36]
     float* const red = reinterpret_cast<float*>(smem + 4 * C::SCR + wave * 4096);   // [4 groups][16 pixel rows][16 sums]
-    static_assert(4 * C::SCR + 4 * 4096 <= C::OFF_CO, "epilogue scratch");
+    static_assert(4 * C::SCR + 4 * 4096 <= C::OFF_SSUM, "epilogue scratch");
     bf16* const O = reinterpret_cast<bf16*>(a.out);
     const bf16* const R = reinterpret_cast<const bf16*>(a.residual);
     const bf16* const EX = reinterpret_cast<const bf16*>(a.ex);
@@ -385,7 +385,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3w_kernel(const sv_geom g, const
     // per-channel constants of the block's channels: one cooperative copy into LDS instead of a dependent global
     // round trip per 32-channel group
     float* const cst = reinterpret_cast<float*>(smem + 4 * C::SCR + 4 * 4096);      // [5][BN]
-    static_assert(4 * C::SCR + 4 * 4096 + 5 * BN * 4 <= C::OFF_CO, "epilogue scratch");
+    static_assert(4 * C::SCR + 4 * 4096 + 5 * BN * 4 <= C::OFF_SSUM, "epilogue scratch (halo, weight and coefficient buffers are free after the loop)");
     if (has_bias || EX) {
         for (int c = tid; c < BN; c += 256) {
             if (has_bias) cst[c] = a.bias[n0 + c];
@@ -570,14 +570,24 @@ int sv_conv3x3w_try(const sv_geom* g, int dtype, const sv_igemm_args* a, hipStre
     static const bool off = getenv("SV_NO_CONV3X3W") != nullptr;
     if (off || dtype != SV_BF16) return 0;
     if (g->Cin < 96 || g->Cin % 32 != 0 || g->ldx % 8 != 0 || g->ldo % 8 != 0) return 0;
-    if (g->N % 160 != 0 && g->N % 128 != 0) return 0;
+    if (g->N % 160 != 0 && g->N % 64 != 0) return 0;
     const int TR = 256 / g->Win;
     if ((g->B * g->Hin) % TR != 0) return 0;
-    // 256-pixel x 128/160-channel tiles: below one block per CU the small-tile kernels of conv3x3.hip are faster
-    // (measured: WRN-28-2 stage 3, 128 blocks, 38 vs 24 us); SV_W3_MIN_BLOCKS overrides (tests use 1)
+    // 256-pixel x 160/128/64-channel tiles: below one block per CU the small-tile kernels of conv3x3.hip are faster
+    // (measured: WRN-28-2 stage 3 as 128 blocks of 128 channels, 38 vs 24 us); SV_W3_MIN_BLOCKS overrides (tests use 1).
+    // Narrower channel tiles are taken only when the wider ones do not fill the chip.
     const char* mb = getenv("SV_W3_MIN_BLOCKS");              // (read per call: the tests toggle it)
     const int min_blocks = mb ? atoi(mb) : 256;
-    if ((int64_t)(g->B * g->Hin / TR) * (g->N / (g->N % 160 == 0 ? 160 : 128)) < min_blocks) return 0;
+    const int64_t nTiles = g->B * g->Hin / TR;
+    int bn = 0;
+    if (g->N % 160 == 0) bn = 160;
+    else if (g->N % 128 == 0 && nTiles * (g->N / 128) >= min_blocks) bn = 128;
+    else if (nTiles * (g->N / 64) >= min_blocks && (!a->pro_scale || min_blocks <= 1)) bn = 64;   // measured on 128 ch at
+                                        // 8x8: data gradient 21.6 vs 24.7 us, forward (BatchNorm pass) 26.7 vs 25.8 us
+    else if (g->N % 128 == 0 && min_blocks <= 1) bn = 128;
+    static const bool no64 = getenv("SV_W3_NO_BN64") != nullptr;
+    if (bn == 64 && no64) bn = 0;
+    if (bn == 0 || nTiles * (g->N / bn) < min_blocks) return 0;
     if ((int64_t)g->B * g->Hin * g->Win * g->ldx * 2 >= ((int64_t)1 << 31)) return 0;
     if ((int64_t)g->N * 9 * g->Cin * 2 >= ((int64_t)1 << 31)) return 0;
     // tap order: canonical (forward) or reversed (data gradient)
@@ -593,7 +603,8 @@ int sv_conv3x3w_try(const sv_geom* g, int dtype, const sv_igemm_args* a, hipStre
         const int64_t d = (const char*)a->pro_shift - (const char*)a->pro_scale;
         if (d >= ((int64_t)1 << 31) || -d >= ((int64_t)1 << 31)) return 0;
     }
-    if (g->N % 160 == 0) *rc = fwd ? launch_w2<5, false>(g, a, s) : launch_w2<5, true>(g, a, s);
-    else *rc = fwd ? launch_w2<4, false>(g, a, s) : launch_w2<4, true>(g, a, s);
+    if (bn == 160) *rc = fwd ? launch_w2<5, false>(g, a, s) : launch_w2<5, true>(g, a, s);
+    else if (bn == 128) *rc = fwd ? launch_w2<4, false>(g, a, s) : launch_w2<4, true>(g, a, s);
+    else *rc = fwd ? launch_w2<2, false>(g, a, s) : launch_w2<2, true>(g, a, s);
     return 1;
 }

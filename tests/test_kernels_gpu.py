@@ -184,9 +184,10 @@ def test_conv3x3_wide_multitile(case):
 
 
 @pytest.mark.parametrize("case", [(4, 160, 160, 8, 3, 1, 1), (8, 128, 128, 8, 3, 1, 1), (1, 96, 128, 32, 3, 1, 1),
-                                  (2, 128, 256, 16, 3, 1, 1), (3, 160, 320, 32, 3, 1, 1), (4, 640, 640, 8, 3, 1, 1)])
+                                  (2, 128, 256, 16, 3, 1, 1), (3, 160, 320, 32, 3, 1, 1), (4, 640, 640, 8, 3, 1, 1),
+                                  (2, 96, 192, 16, 3, 1, 1)])
 def test_conv3x3_wide_mfma(case, monkeypatch):
-    """Shapes that take the 256-pixel x 160/128-channel LDS-DMA pipelined kernel (conv3x3w.hip): both channel-tile
+    """Shapes that take the 256-pixel x 160/128/64-channel LDS-DMA pipelined kernel (conv3x3w.hip): all channel-tile
     widths, the three image sizes (one / several images per tile), odd and even chunk counts, several channel tiles
     per pixel tile, a grid with idle tail blocks; forward with every fusion and the data gradient with the
     activation-backward epilogue (reversed tap order).  (The dispatcher only picks this kernel for grids of at least
