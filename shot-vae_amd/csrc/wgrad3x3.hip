@@ -51,7 +51,10 @@ template <typename T, int WLOG>
 __global__ __launch_bounds__(256) void wgrad3x3_kernel(const sv_geom g, const wg3_params p) {
     typedef typename V8<T>::type V;
     constexpr int W = 1 << WLOG, TR = 128 / W, WP = W + 2;
-    constexpr int HP = (TR + 2) * WP;
+    // LDS halo rows: row 0 / the last row are the vertical halo, and when a tile holds several whole images (W = 8:
+    // TR = 16 > H = 8) a zero spacer row separates them -- zero padding is DATA in LDS, the nine taps need no masks
+    constexpr int HH = (TR < W) ? TR : W, SEG = TR / HH, LROWS = TR + SEG + 1;
+    constexpr int HP = LROWS * WP;
     constexpr int HV = HP * 4, HI = (HV + 255) / 256;     // halo vectors (8 channels each)
     constexpr int YI = 2;                                  // 128 px * 4 vectors / 256 threads
 
@@ -93,14 +96,24 @@ __global__ __launch_bounds__(256) void wgrad3x3_kernel(const sv_geom g, const wg
         t0 = *reinterpret_cast<const f32x4*>(p.pro_shift + c0 + 8 * v);
         t1 = *reinterpret_cast<const f32x4*>(p.pro_shift + c0 + 8 * v + 4);
     }
-    // staging slots relative to the tile's first global row (tile-independent part precomputed)
-    int hj[HI], hx[HI], hlds[HI];
+    // halo staging slots.  kind: 0 = always zero (padding column / spacer / dummy), 1 = image row of this tile,
+    //                            2 = row above the tile, 3 = row below it (valid only inside the same image)
+    int hrel[HI], hxc[HI], hlds[HI], hkind[HI];
 #pragma unroll
     for (int i = 0; i < HI; ++i) {
         const int idx = tid + 256 * i;
         const int pix = min(idx, HV - 1) >> 2;
-        hj[i] = pix / WP - 1;
-        hx[i] = pix - (pix / WP) * WP - 1;
+        const int lr = pix / WP, xx = pix - lr * WP;
+        const int seg = lr / (HH + 1), off = lr - seg * (HH + 1);
+        int kind = 1, rel = lr - 1 - seg;
+        if (off == 0) {
+            if (SEG == 1) { kind = seg == 0 ? 2 : 3; rel = seg == 0 ? -1 : TR; }
+            else kind = 0;
+        }
+        if (xx == 0 || xx == WP - 1) kind = 0;
+        hkind[i] = kind;
+        hrel[i] = rel;
+        hxc[i] = min(max(xx - 1, 0), W - 1);
         hlds[i] = idx < HV ? pix * LDH + 8 * v : -1;
     }
 
@@ -108,6 +121,7 @@ __global__ __launch_bounds__(256) void wgrad3x3_kernel(const sv_geom g, const wg
     bool hok[HI];
     auto load_tile = [&](int tile) {
         const int gr0 = tile * TR;
+        const bool top_ok = (gr0 & (H - 1)) != 0, bot_ok = ((gr0 + TR) & (H - 1)) != 0;
 #pragma unroll
         for (int i = 0; i < YI; ++i) {
             const int pix = (tid >> 2) + 64 * i;            // tile pixel 0..127 (row-major over TR x W)
@@ -115,10 +129,9 @@ __global__ __launch_bounds__(256) void wgrad3x3_kernel(const sv_geom g, const wg
         }
 #pragma unroll
         for (int i = 0; i < HI; ++i) {
-            const int gr = gr0 + hj[i], x = hx[i];
-            hok[i] = (unsigned)x < (unsigned)W && (unsigned)gr < (unsigned)BH;
-            const int grc = min(max(gr, 0), BH - 1), xc = min(max(x, 0), W - 1);
-            rh[i] = *reinterpret_cast<const V*>(X + ((int64_t)grc * W + xc) * g.ldx + c0 + 8 * v);
+            hok[i] = hkind[i] == 1 || (hkind[i] == 2 && top_ok) || (hkind[i] == 3 && bot_ok);
+            const int grc = min(max(gr0 + hrel[i], 0), BH - 1);
+            rh[i] = *reinterpret_cast<const V*>(X + ((int64_t)grc * W + hxc[i]) * g.ldx + c0 + 8 * v);
         }
     };
     auto store_tile = [&]() {
@@ -146,35 +159,57 @@ __global__ __launch_bounds__(256) void wgrad3x3_kernel(const sv_geom g, const wg
 #pragma unroll
     for (int t = 0; t < 9; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+#ifdef SV_WG3_STAMP
+    uint64_t st_store = 0, st_bar = 0, st_mma = 0, st_bar2 = 0, st_ld = 0;
+    const uint64_t st_begin = __builtin_amdgcn_s_memtime();
+#define WG3_STAMP(acc_)                                         \
+    {                                                           \
+        const uint64_t now_ = __builtin_amdgcn_s_memtime();     \
+        acc_ += now_ - st_last;                                 \
+        st_last = now_;                                         \
+    }
+    uint64_t st_last = st_begin;
+#else
+#define WG3_STAMP(acc_)
+#endif
     if (t_begin < t_end) load_tile(t_begin);
     for (int tile = t_begin; tile < t_end; ++tile) {
         store_tile();
+        WG3_STAMP(st_store)
         __syncthreads();
+        WG3_STAMP(st_bar)
         if (tile + 1 < t_end) load_tile(tile + 1);        // in flight while this tile is on the MFMAs
-        const int gr0 = tile * TR;
+        WG3_STAMP(st_ld)
         if (sizeof(T) == 2) {
             const bf16* Yb = reinterpret_cast<const bf16*>(Ys);
             const bf16* Hb = reinterpret_cast<const bf16*>(halo);
-            bf16x8 zb;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) zb[j] = (bf16)0.f;
-#pragma unroll
-            for (int kc = 0; kc < 4; ++kc) {
+            // fragments of one 32-pixel chunk: the dy fragment + the nine tap-shifted x fragments, requested together
+            // and double-buffered over the chunks (with one MFMA per fragment a read-then-multiply chain exposes the
+            // LDS latency nine times per chunk: stamped 3 700 of the 6 100 cycles of a tile iteration)
+            struct Frags { bf16x8 fy, fx[9]; };
+            Frags FA, FB;
+            auto load_frags = [&](Frags& F, int kc) {
                 // lane addresses pixel pq = 32*kc + 8*fq + q (q = fr>>2) of the tile (and pq + 4)
                 const int pq = 32 * kc + 8 * fq + (fr >> 2);
                 const int jrow = pq >> WLOG, xcol = pq & (W - 1);
-                const int yrow = (gr0 + jrow) & (H - 1);    // the lane's 8 k-pixels share this image row
-                const bf16x8 fy = frag_tr(Yb, pq * LDH, 16 * wi, lane);
-                const int hbase = ((jrow + 1) * WP + xcol + 1) * LDH;
+                F.fy = frag_tr(Yb, pq * LDH, 16 * wi, lane);
+                const int hbase = ((jrow + 1 + jrow / HH) * WP + xcol + 1) * LDH;
 #pragma unroll
-                for (int t = 0; t < 9; ++t) {
-                    const int dy = tap_off(pdy, t), dx = tap_off(pdx, t);
-                    const bool ok = !((dy < 0 && yrow == 0) || (dy > 0 && yrow == H - 1));
-                    bf16x8 fx = frag_tr(Hb, hbase + (dy * WP + dx) * LDH, 16 * wj, lane);
-                    fx = ok ? fx : zb;
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fy, fx, acc[t], 0, 0, 0);
-                }
-            }
+                for (int t = 0; t < 9; ++t)
+                    F.fx[t] = frag_tr(Hb, hbase + (tap_off(pdy, t) * WP + tap_off(pdx, t)) * LDH, 16 * wj, lane);
+            };
+            auto mma_frags = [&](const Frags& F) {
+#pragma unroll
+                for (int t = 0; t < 9; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F.fy, F.fx[t], acc[t], 0, 0, 0);
+            };
+            load_frags(FA, 0);
+            load_frags(FB, 1);
+            mma_frags(FA);
+            load_frags(FA, 2);
+            mma_frags(FB);
+            load_frags(FB, 3);
+            mma_frags(FA);
+            mma_frags(FB);
         } else {
             // fp32 (parity mode): v_mfma_f32_16x16x4_f32 step j uses pixel 4*j + fq of each 32-pixel chunk
             const float* Yf = reinterpret_cast<const float*>(Ys);
@@ -182,20 +217,26 @@ __global__ __launch_bounds__(256) void wgrad3x3_kernel(const sv_geom g, const wg
             for (int pj = 0; pj < 32; ++pj) {
                 const int pp = 4 * pj + fq;
                 const int jrow = pp >> WLOG, xcol = pp & (W - 1);
-                const int yrow = (gr0 + jrow) & (H - 1);
                 const float yv = Yf[pp * LDH + 16 * wi + fr];
-                const int hbase = ((jrow + 1) * WP + xcol + 1) * LDH + 16 * wj + fr;
+                const int hbase = ((jrow + 1 + jrow / HH) * WP + xcol + 1) * LDH + 16 * wj + fr;
 #pragma unroll
                 for (int t = 0; t < 9; ++t) {
-                    const int dy = tap_off(pdy, t), dx = tap_off(pdx, t);
-                    const bool ok = !((dy < 0 && yrow == 0) || (dy > 0 && yrow == H - 1));
-                    const float xv = ok ? Hf[hbase + (dy * WP + dx) * LDH] : 0.f;
+                    const float xv = Hf[hbase + (tap_off(pdy, t) * WP + tap_off(pdx, t)) * LDH];
                     acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(yv, xv, acc[t], 0, 0, 0);
                 }
             }
         }
+        WG3_STAMP(st_mma)
         __syncthreads();          // everyone is done reading before the next tile overwrites LDS
+        WG3_STAMP(st_bar2)
     }
+#ifdef SV_WG3_STAMP
+    if (tid == 0 && p.ws) {     // diagnostic build: per-block cycle shares into the tail of the caller's workspace
+        float* d = p.ws + (8u << 20) + 8 * blockIdx.x;
+        d[0] = (float)st_store; d[1] = (float)st_bar; d[2] = (float)st_mma; d[3] = (float)st_bar2;
+        d[4] = (float)(__builtin_amdgcn_s_memtime() - st_begin); d[5] = (float)(t_end - t_begin); d[6] = (float)st_ld;
+    }
+#endif
 
     // ---- publish: D layout = lane holds c = 16*wj + fr, n = 16*wi + 4*fq + r ----------------------------
     const int64_t slab = (int64_t)g.N * g.T_orig * g.Cin;
@@ -437,7 +478,8 @@ int launch(const sv_geom* g, const wg3_params& p, hipStream_t s) {
     constexpr int W = 1 << WLOG, TR = 128 / W;
     const int nNC = (g->N / 32) * (g->Cin / 32);
     const int grid = p.splits * nNC;
-    const size_t lds = (size_t)(128 + (TR + 2) * (W + 2)) * LDH * sizeof(T);
+    constexpr int HHn = (TR < W) ? TR : W, LROWSn = TR + TR / HHn + 1;
+    const size_t lds = (size_t)(128 + LROWSn * (W + 2)) * LDH * sizeof(T);
     sv_prof_begin(s);
     hipLaunchKernelGGL((wgrad3x3_kernel<T, WLOG>), dim3(grid), dim3(256), lds, s, *g, p);
     sv_prof_end(s);               // the event bracket times the main kernel only (comparable with rocprofv3)
