@@ -60,7 +60,7 @@ typedef struct {
     const void* x;              /* input activations                                                 */
     const float* pro_scale;     /* [Cin] BN-apply scale (NULL: no prologue)                          */
     const float* pro_shift;     /* [Cin]                                                             */
-    float pro_slope;            /* LeakyReLU slope (0 = ReLU)                                        */
+    float pro_slope;            /* LeakyReLU slope in [0,1] (0 = ReLU)                                     */
     const void* w;              /* packed weights, element type = dtype                              */
     const float* bias;          /* [N] or NULL                                                       */
     const void* residual;       /* same layout as out, or NULL                                       */

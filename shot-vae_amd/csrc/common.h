@@ -33,7 +33,8 @@ __device__ __forceinline__ void mma32(f32x4& acc, const f32x8& a, const f32x8& b
 __device__ __forceinline__ float to_f(float v) { return v; }
 __device__ __forceinline__ float to_f(bf16 v) { return (float)v; }
 
-__device__ __forceinline__ float act_fwd(float u, float slope) { return u > 0.f ? u : u * slope; }
+// LeakyReLU / ReLU; every entry point rejects slopes outside [0, 1], where max(u, slope*u) is the activation
+__device__ __forceinline__ float act_fwd(float u, float slope) { return fmaxf(u, u * slope); }
 __device__ __forceinline__ float act_grad(float u, float slope) { return u > 0.f ? 1.f : slope; }
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -269,6 +269,8 @@ extern "C" int sv_igemm(const sv_geom* g, int dtype, const sv_igemm_args* a, voi
     SV_REQUIRE(!a->ex || (a->ex_scale && a->ex_shift && a->ex_mean && a->ex_rstd && a->bsums), SV_E_ARG,
                "sv_igemm: incomplete act-backward epilogue");
     SV_REQUIRE(!a->pro_scale || a->pro_shift, SV_E_ARG, "sv_igemm: prologue shift missing");
+    SV_REQUIRE(!a->pro_scale || (a->pro_slope >= 0.f && a->pro_slope <= 1.f), SV_E_ARG,
+               "sv_igemm: activation slope %g outside [0, 1]", (double)a->pro_slope);
     SV_REQUIRE(!(a->stats || a->ex) || (a->replicas >= 1 && (a->replicas & (a->replicas - 1)) == 0), SV_E_ARG,
                "sv_igemm: replicas=%d must be a power of two", a->replicas);
     hipStream_t s = (hipStream_t)stream;

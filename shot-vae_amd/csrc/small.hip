@@ -853,6 +853,7 @@ int sv_colsum(int dtype, const void* y, int64_t M, int N, int ld, float* out, vo
 int sv_pool_fwd(int dtype, const void* x, const float* scale, const float* shift, float slope, int B, int HW,
                 int C, int ld, float* feat, void* stream) {
     SV_REQUIRE(x && scale && shift && feat, SV_E_ARG, "sv_pool_fwd: null");
+    SV_REQUIRE(slope >= 0.f && slope <= 1.f, SV_E_ARG, "sv_pool_fwd: activation slope %g outside [0, 1]", (double)slope);
     DISPATCH_T(dtype, hipLaunchKernelGGL((pool_fwd_kernel<T>), dim3((B * C + 255) / 256), dim3(256), 0,
                                          (hipStream_t)stream, (const T*)x, scale, shift, slope, B, HW, C, ld, feat));
     return sv_check_launch("sv_pool_fwd");

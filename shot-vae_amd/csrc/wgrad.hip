@@ -293,6 +293,8 @@ extern "C" int sv_wgrad(const sv_geom* g, int dtype, const void* x, const float*
     SV_REQUIRE(g->Cin % 16 == 0 && g->N % 16 == 0 && g->ldx % 8 == 0 && g->ldo % 8 == 0, SV_E_SHAPE,
                "sv_wgrad: Cin=%d N=%d must be multiples of 16", g->Cin, g->N);
     SV_REQUIRE(!pro_scale || pro_shift, SV_E_ARG, "sv_wgrad: prologue shift missing");
+    SV_REQUIRE(!pro_scale || (pro_slope >= 0.f && pro_slope <= 1.f), SV_E_ARG,
+               "sv_wgrad: activation slope %g outside [0, 1]", (double)pro_slope);
     if (dtype == SV_F32 || use_tr) {   // stride-1 3x3: LDS-halo kernel (wgrad3x3.hip); SV_NO_WGRAD3X3=1 disables (A/B)
         static const bool no_fast = getenv("SV_NO_WGRAD3X3") != nullptr;
         int rc = 0;

@@ -13,6 +13,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -50,6 +51,9 @@ __device__ __forceinline__ bf16x8 frag_tr(const bf16* S, int pix_elem_q, int col
 template <typename T, int WLOG>
 __global__ __launch_bounds__(256) void wgrad3x3_kernel(const sv_geom g, const wg3_params p) {
     typedef typename V8<T>::type V;
+#ifdef SV_WG3_STAMP
+    const uint64_t st_entry = __builtin_amdgcn_s_memtime();
+#endif
     constexpr int W = 1 << WLOG, TR = 128 / W, WP = W + 2;
     // LDS halo rows: row 0 / the last row are the vertical halo, and when a tile holds several whole images (W = 8:
     // TR = 16 > H = 8) a zero spacer row separates them -- zero padding is DATA in LDS, the nine taps need no masks
@@ -117,21 +121,29 @@ __global__ __launch_bounds__(256) void wgrad3x3_kernel(const sv_geom g, const wg
         hlds[i] = idx < HV ? pix * LDH + 8 * v : -1;
     }
 
+    // per-thread staging offsets are tile-invariant: a tile only moves the two (uniform) base pointers.  The halo base
+    // is the row ABOVE the tile, so that every offset is an unsigned 32-bit byte count (SGPR base + VGPR offset loads);
+    // slots that are zero for this tile read the tile's first pixel instead (always inside the tensor)
+    uint32_t hoff[HI], yoff[YI];
+#pragma unroll
+    for (int i = 0; i < HI; ++i) hoff[i] = (uint32_t)(((hrel[i] + 1) * W + hxc[i]) * g.ldx + c0 + 8 * v) * (uint32_t)sizeof(T);
+#pragma unroll
+    for (int i = 0; i < YI; ++i) yoff[i] = (uint32_t)(((tid >> 2) + 64 * i) * g.ldo + n0 + 8 * v) * (uint32_t)sizeof(T);
+    const uint32_t hsafe = (uint32_t)(W * g.ldx + c0 + 8 * v) * (uint32_t)sizeof(T);
+
     V ry[YI], rh[HI];
     bool hok[HI];
     auto load_tile = [&](int tile) {
         const int gr0 = tile * TR;
         const bool top_ok = (gr0 & (H - 1)) != 0, bot_ok = ((gr0 + TR) & (H - 1)) != 0;
+        const char* ybase = reinterpret_cast<const char*>(DY + (int64_t)gr0 * W * g.ldo);
+        const char* hbase = reinterpret_cast<const char*>(X) + ((int64_t)gr0 - 1) * W * g.ldx * (int64_t)sizeof(T);
 #pragma unroll
-        for (int i = 0; i < YI; ++i) {
-            const int pix = (tid >> 2) + 64 * i;            // tile pixel 0..127 (row-major over TR x W)
-            ry[i] = *reinterpret_cast<const V*>(DY + ((int64_t)gr0 * W + pix) * g.ldo + n0 + 8 * v);
-        }
+        for (int i = 0; i < YI; ++i) ry[i] = *reinterpret_cast<const V*>(ybase + yoff[i]);   // tile pixel (tid>>2) + 64 i
 #pragma unroll
         for (int i = 0; i < HI; ++i) {
             hok[i] = hkind[i] == 1 || (hkind[i] == 2 && top_ok) || (hkind[i] == 3 && bot_ok);
-            const int grc = min(max(gr0 + hrel[i], 0), BH - 1);
-            rh[i] = *reinterpret_cast<const V*>(X + ((int64_t)grc * W + hxc[i]) * g.ldx + c0 + 8 * v);
+            rh[i] = *reinterpret_cast<const V*>(hbase + (hok[i] ? hoff[i] : hsafe));
         }
     };
     auto store_tile = [&]() {
@@ -160,7 +172,7 @@ __global__ __launch_bounds__(256) void wgrad3x3_kernel(const sv_geom g, const wg
     for (int t = 0; t < 9; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
 #ifdef SV_WG3_STAMP
-    uint64_t st_store = 0, st_bar = 0, st_mma = 0, st_bar2 = 0, st_ld = 0;
+    uint64_t st_store = 0, st_bar = 0, st_mma = 0, st_bar2 = 0, st_ld = 0, st_wait = 0;
     const uint64_t st_begin = __builtin_amdgcn_s_memtime();
 #define WG3_STAMP(acc_)                                         \
     {                                                           \
@@ -174,6 +186,10 @@ __global__ __launch_bounds__(256) void wgrad3x3_kernel(const sv_geom g, const wg
 #endif
     if (t_begin < t_end) load_tile(t_begin);
     for (int tile = t_begin; tile < t_end; ++tile) {
+#ifdef SV_WG3_STAMP
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        WG3_STAMP(st_wait)
+#endif
         store_tile();
         WG3_STAMP(st_store)
         __syncthreads();
@@ -210,6 +226,15 @@ __global__ __launch_bounds__(256) void wgrad3x3_kernel(const sv_geom g, const wg
             load_frags(FB, 3);
             mma_frags(FA);
             mma_frags(FB);
+#ifndef SV_WG3_NO_SCHED
+            // keep the order written above (the scheduler otherwise re-serialises to two fragments in flight)
+            __builtin_amdgcn_sched_group_barrier(0x100, 40, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 9, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 20, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 9, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 20, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 18, 0);
+#endif
         } else {
             // fp32 (parity mode): v_mfma_f32_16x16x4_f32 step j uses pixel 4*j + fq of each 32-pixel chunk
             const float* Yf = reinterpret_cast<const float*>(Ys);
@@ -234,8 +259,9 @@ __global__ __launch_bounds__(256) void wgrad3x3_kernel(const sv_geom g, const wg
     if (tid == 0 && p.ws) {     // diagnostic build: per-block cycle shares into the tail of the caller's workspace
         float* d = p.ws + (8u << 20) + 8 * blockIdx.x;
         d[0] = (float)st_store; d[1] = (float)st_bar; d[2] = (float)st_mma; d[3] = (float)st_bar2;
-        d[4] = (float)(__builtin_amdgcn_s_memtime() - st_begin); d[5] = (float)(t_end - t_begin); d[6] = (float)st_ld;
+        d[4] = (float)(__builtin_amdgcn_s_memtime() - st_begin); d[5] = (float)(t_end - t_begin); d[6] = (float)st_ld; d[7] = (float)st_wait;
     }
+    const uint64_t st_loop_end = __builtin_amdgcn_s_memtime();
 #endif
 
     // ---- publish: D layout = lane holds c = 16*wj + fr, n = 16*wi + 4*fq + r ----------------------------
@@ -251,6 +277,15 @@ __global__ __launch_bounds__(256) void wgrad3x3_kernel(const sv_geom g, const wg
             else atomicAdd(q, acc[t][r]);
         }
     }
+#ifdef SV_WG3_STAMP
+    if (tid == 0 && p.ws) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        float* d = p.ws + (9u << 20) + 8 * blockIdx.x;
+        d[0] = (float)(st_begin - st_entry);
+        d[1] = (float)(__builtin_amdgcn_s_memtime() - st_loop_end);
+        d[2] = (float)(__builtin_amdgcn_s_memtime() - st_entry);
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -260,6 +295,8 @@ __global__ __launch_bounds__(256) void wgrad3x3_kernel(const sv_geom g, const wg
 // accumulator tiles (180 registers, all in the accumulation half of the register file), so one 128-pixel tile feeds
 // 4 x 45 MFMAs per wave from 14 transposing fragment reads per 32 pixels.  Same staging / masking / publishing scheme
 // as above (the 32-channel chunks of one pixel range run on one XCD, so the dy re-reads are L2 hits).
+typedef __attribute__((address_space(3))) void* wg_lds_ptr;
+typedef const __attribute__((address_space(1))) void* wg_glb_ptr;
 constexpr int LDY = 160 + 8;      // LDS row stride (elements) of the wide dy tile: 336 B = 80 B mod 256, as LDH
 
 __device__ __forceinline__ bf16x8 frag_tr_ld(const bf16* S, int pix_elem_q, int col0, int lane, int ld) {
@@ -280,16 +317,21 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3w_kernel(const sv_geom g, cons
     // TR = 16 > H = 8) a zero spacer row separates them -- zero padding is DATA in LDS, the nine taps need no masks
     constexpr int HH = (TR < W) ? TR : W, SEG = TR / HH, LROWS = TR + SEG + 1;
     constexpr int HP = LROWS * WP;
-    constexpr int YV = 128 * 20, YI = YV / 256;               // dy vectors (8 channels each): 10 per thread
+    // the dy tile goes global -> LDS by DMA, 64 consecutive 16-byte vectors per wave instruction, and an LDS row is 21
+    // vectors (20 of data + the LDY padding, which is fetched as a copy of vector 19): 2688 vectors = 42 instructions,
+    // wave w issues k*4 + w for k < 11 (the two past the end repeat the last one)
+    constexpr int YV = 128 * 21, YI = 11;
     constexpr int HV = HP * 4, HI = (HV + 255) / 256;         // halo vectors
 
+    // two LDS stages of {dy tile [128][LDY], halo [HP][LDH], 512 dummy elements for the unused staging slots}
+    constexpr int BUF = 128 * LDY + HP * LDH + 512;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    bf16* Ys = reinterpret_cast<bf16*>(smem);                 // [128][LDY]
-    bf16* halo = Ys + 128 * LDY;                              // [HP][LDH]
+    bf16* const lds0 = reinterpret_cast<bf16*>(smem);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fq = lane >> 4;
     const int wi = wave >> 1, wj = wave & 1;
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);      // scalar copy: DMA destinations stay in SGPRs
     const int H = g.Hin, BH = g.B * H, nT = BH / TR;
     const int nC = g.Cin / 32, nNt = g.N / 160, nNC = nC * nNt;
     const int L = blockIdx.x;
@@ -321,7 +363,10 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3w_kernel(const sv_geom g, cons
 #pragma unroll
     for (int j = 0; j < 8; ++j) zero[j] = (bf16)0.f;
     const int v = tid & 3;
-    f32x4 s0, s1, t0, t1;
+    // without a prologue the transform is the identity (scale 1, shift 0, slope 1: exact in bf16 -> fp32 -> bf16), so the
+    // tile loop below is ONE basic block whose instruction order the phases control
+    f32x4 s0 = {1.f, 1.f, 1.f, 1.f}, s1 = s0, t0 = {0.f, 0.f, 0.f, 0.f}, t1 = t0;
+    const float slope = has_pro ? p.pro_slope : 1.f;
     if (has_pro) {
         s0 = *reinterpret_cast<const f32x4*>(p.pro_scale + c0 + 8 * v);
         s1 = *reinterpret_cast<const f32x4*>(p.pro_scale + c0 + 8 * v + 4);
@@ -346,51 +391,52 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3w_kernel(const sv_geom g, cons
         hkind[i] = kind;
         hrel[i] = rel;
         hxc[i] = min(max(xx - 1, 0), W - 1);
-        hlds[i] = idx < HV ? pix * LDH + 8 * v : -1;
+        hlds[i] = idx < HV ? 128 * LDY + pix * LDH + 8 * v : 128 * LDY + HP * LDH + 8 * (tid & 63);   // or the dummy
     }
-    // dy slot i of this thread: pixel (tid + 256 i) / 20, vector (tid + 256 i) % 20; 256 = 12 * 20 + 16
-    const int yp0 = tid / 20, yv0 = tid - yp0 * 20;
+    // per-thread staging offsets are tile-invariant: a tile only moves the two (uniform) base pointers.  The halo base
+    // is the row ABOVE the tile, so that every offset is an unsigned 32-bit byte count (SGPR base + VGPR offset loads);
+    // slots that are zero for this tile read the tile's first pixel instead (always inside the tensor)
+    uint32_t hoff[HI];
+#pragma unroll
+    for (int i = 0; i < HI; ++i) hoff[i] = (uint32_t)(((hrel[i] + 1) * W + hxc[i]) * g.ldx + c0 + 8 * v) * 2u;
+    const uint32_t hsafe = (uint32_t)(W * g.ldx + c0 + 8 * v) * 2u;
+    uint32_t yoff[YI];
+#pragma unroll
+    for (int k = 0; k < YI; ++k) {
+        const int q = min((k * 4 + wave) * 64, YV - 64) + lane, pp = q / 21, vv = min(q - pp * 21, 19);
+        yoff[k] = (uint32_t)(pp * g.ldo + n0 + 8 * vv) * 2u;
+    }
 
-    bf16x8 ry[YI], rh[HI];
+    bf16x8 rh[HI];
     bool hok[HI];
-    auto load_tile = [&](int tile) {
+    const char* ybase;
+    const char* hbase;
+    auto tile_bases = [&](int tile) {
         const int gr0 = tile * TR;
         const bool top_ok = (gr0 & (H - 1)) != 0, bot_ok = ((gr0 + TR) & (H - 1)) != 0;
+        ybase = reinterpret_cast<const char*>(DY + (int64_t)gr0 * W * g.ldo);
+        hbase = reinterpret_cast<const char*>(X) + ((int64_t)gr0 - 1) * W * g.ldx * 2;
 #pragma unroll
-        for (int i = 0; i < YI; ++i) {
-            int vv = yv0 + 16 * i, pp = yp0 + 12 * i;
-            pp += vv / 20;
-            vv = vv % 20;
-            ry[i] = *reinterpret_cast<const bf16x8*>(DY + ((int64_t)gr0 * W + pp) * g.ldo + n0 + 8 * vv);
-        }
-#pragma unroll
-        for (int i = 0; i < HI; ++i) {
-            hok[i] = hkind[i] == 1 || (hkind[i] == 2 && top_ok) || (hkind[i] == 3 && bot_ok);
-            const int grc = min(max(gr0 + hrel[i], 0), BH - 1);
-            rh[i] = *reinterpret_cast<const bf16x8*>(X + ((int64_t)grc * W + hxc[i]) * g.ldx + c0 + 8 * v);
-        }
+        for (int i = 0; i < HI; ++i) hok[i] = hkind[i] == 1 || (hkind[i] == 2 && top_ok) || (hkind[i] == 3 && bot_ok);
     };
-    auto store_tile = [&]() {
+    // (spelled in assembly: through the builtin the compiler knows the instruction writes LDS and, unable to tell the two
+    // stages apart, waits for vmcnt(0) before the next fragment read -- the DMA is ordered by the explicit wait + barrier
+    // at the end of phase 2 instead; un-modelled VMEM instructions can only make the compiler's own vmcnt waits stricter)
+    auto dma_y = [&](bf16* buf, int k) {
+        const uint32_t dst = (uint32_t)(uintptr_t)(wg_lds_ptr)(buf + min((k * 4 + wave_s) * 64, YV - 64) * 8);
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                     :: "s"(dst), "v"(yoff[k]), "s"(ybase) : "memory");      // (m0 is reserved: the compiler never allocates it)
+    };
+    auto load_h = [&](int i) { rh[i] = *reinterpret_cast<const bf16x8*>(hbase + (hok[i] ? hoff[i] : hsafe)); };
+    auto store_h = [&](bf16* buf, int i) {
+        bf16x8 o;
 #pragma unroll
-        for (int i = 0; i < YI; ++i) {
-            int vv = yv0 + 16 * i, pp = yp0 + 12 * i;
-            pp += vv / 20;
-            vv = vv % 20;
-            *reinterpret_cast<bf16x8*>(Ys + pp * LDY + 8 * vv) = ry[i];
+        for (int j = 0; j < 4; ++j) {
+            const float u0 = (float)rh[i][j] * s0[j] + t0[j], u1 = (float)rh[i][j + 4] * s1[j] + t1[j];
+            o[j] = (bf16)fmaxf(u0, u0 * slope);
+            o[j + 4] = (bf16)fmaxf(u1, u1 * slope);
         }
-#pragma unroll
-        for (int i = 0; i < HI; ++i) {
-            bf16x8 o = rh[i];
-            if (has_pro) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float u0 = (float)rh[i][j] * s0[j] + t0[j], u1 = (float)rh[i][j + 4] * s1[j] + t1[j];
-                    o[j] = (bf16)fmaxf(u0, u0 * p.pro_slope);
-                    o[j + 4] = (bf16)fmaxf(u1, u1 * p.pro_slope);
-                }
-            }
-            if (hlds[i] >= 0) *reinterpret_cast<bf16x8*>(halo + hlds[i]) = hok[i] ? o : zero;
-        }
+        *reinterpret_cast<bf16x8*>(buf + hlds[i]) = hok[i] ? o : zero;
     };
 
     f32x4 acc[5][9];
@@ -399,44 +445,91 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3w_kernel(const sv_geom g, cons
 #pragma unroll
         for (int t = 0; t < 9; ++t) acc[a][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // fragments of one 32-pixel k chunk: 5 dy fragments + 9 tap-shifted x fragments; two sets, so that chunk kc+1 is
-    // being read from LDS while chunk kc is on the MFMAs (one wave per SIMD: nobody else hides the LDS latency)
-    struct Frags { bf16x8 fy[5], fx[9]; };
-    Frags FA, FB;
-    auto load_frags = [&](Frags& F, int kc) {
-        // lane addresses pixel pq = 32*kc + 8*fq + q (q = fr>>2) of the tile (and pq + 4)
+    // fragments of one 32-pixel k chunk: 5 dy fragments (two sets, used by all nine tap groups of a phase) and 9
+    // tap-shifted x fragments (ONE rolling set: tap t's registers are free once its five MFMAs have issued, and receive
+    // the next chunk's tap t right away -- eight tap groups before they are needed)
+    bf16x8 fy[2][5], fx[9];
+    // lane addresses pixel pq = 32*kc + 8*fq + (fr>>2) of the tile (and pq + 4)
+    auto load_fy = [&](int set, const bf16* buf, int kc, int a) {
+        const int pq = 32 * kc + 8 * fq + (fr >> 2);
+        fy[set][a] = frag_tr_ld(buf, pq * LDY, 80 * wi + 16 * a, lane, LDY);
+    };
+    auto load_fx = [&](const bf16* buf, int kc, int t) {
         const int pq = 32 * kc + 8 * fq + (fr >> 2);
         const int jrow = pq >> WLOG, xcol = pq & (W - 1);
-#pragma unroll
-        for (int a = 0; a < 5; ++a) F.fy[a] = frag_tr_ld(Ys, pq * LDY, 80 * wi + 16 * a, lane, LDY);
-        const int hbase = ((jrow + 1 + jrow / HH) * WP + xcol + 1) * LDH;
-#pragma unroll
-        for (int t = 0; t < 9; ++t)
-            F.fx[t] = frag_tr(halo, hbase + (tap_off(pdy, t) * WP + tap_off(pdx, t)) * LDH, 16 * wj, lane);
+        const int hb = 128 * LDY + ((jrow + 1 + jrow / HH) * WP + xcol + 1) * LDH;
+        fx[t] = frag_tr(buf, hb + (tap_off(pdy, t) * WP + tap_off(pdx, t)) * LDH, 16 * wj, lane);
     };
-    auto mma_frags = [&](const Frags& F) {
+    // One phase = the 45 MFMAs of one k chunk, in nine tap groups of five; between the groups (and only there: nothing
+    // crosses a sched_barrier) the wave issues its share of the other pipes' work -- the LDS reads of the next chunk's
+    // fragments, and per phase: the dy stores / the halo transform + stores into the OTHER stage / the global loads of
+    // the tile after next.  With one wave per SIMD nobody else would fill the matrix pipe while this wave stages.
+    //   phase 0: reads kc1, loads the next tile's halo vectors      phase 1: reads kc2
+    //   phase 2: reads kc3, transforms + stores that halo into the other stage;  barrier;
+    //   phase 3: reads kc0 of the next tile from the other stage, starts the dy DMA of the tile after next into this one
+    auto phase = [&](auto PH, const bf16* rd, bf16* wr) {
+        constexpr int ph = decltype(PH)::value;
+        constexpr int nkc = (ph + 1) & 3, set = ph & 1;
 #pragma unroll
-        for (int t = 0; t < 9; ++t)
+        for (int t = 0; t < 9; ++t) {
 #pragma unroll
-            for (int a = 0; a < 5; ++a)
-                acc[a][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F.fy[a], F.fx[t], acc[a][t], 0, 0, 0);
+            for (int a = 0; a < 5; ++a)       // in-place accumulation in the AGPR half, spelled out: left to itself the
+                                              // register allocator rotates the 180 accumulators through copies
+                asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[a][t]) : "v"(fy[set][a]), "v"(fx[t]));
+            load_fx(rd, nkc, t);
+            if (t < 5) load_fy(set ^ 1, rd, nkc, t);
+            if (ph == 0 && t < HI) load_h(t);
+            if (ph == 2 && (t & 1) == 1 && (t >> 1) < HI) store_h(wr, t >> 1);
+            if (ph == 3) {
+                dma_y(wr, t);
+                if (t + 9 < YI) dma_y(wr, t + 9);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
     };
+    static_assert(HI <= 4 && YI == 11, "phase work lists");
 
-    if (t_begin < t_end) load_tile(t_begin);
+#ifdef SV_WG3_STAMP
+    const uint64_t st_begin = __builtin_amdgcn_s_memtime();
+#endif
+    // prologue: tile t_begin into stage 0, the dy DMA of the second tile into stage 1, the first fragments
+    tile_bases(t_begin);
+#pragma unroll
+    for (int k = 0; k < YI; ++k) dma_y(lds0, k);
+#pragma unroll
+    for (int i = 0; i < HI; ++i) load_h(i);
+#pragma unroll
+    for (int i = 0; i < HI; ++i) store_h(lds0, i);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    tile_bases(min(t_begin + 1, t_end - 1));
+#pragma unroll
+    for (int k = 0; k < YI; ++k) dma_y(lds0 + BUF, k);
+#pragma unroll
+    for (int a = 0; a < 5; ++a) load_fy(0, lds0, 0, a);
+#pragma unroll
+    for (int t = 0; t < 9; ++t) load_fx(lds0, 0, t);
+    int cur = 0;
     for (int tile = t_begin; tile < t_end; ++tile) {
-        store_tile();
-        __syncthreads();
-        if (tile + 1 < t_end) load_tile(tile + 1);        // in flight while this tile is on the MFMAs
-        load_frags(FA, 0);
-        load_frags(FB, 1);
-        mma_frags(FA);
-        load_frags(FA, 2);
-        mma_frags(FB);
-        load_frags(FB, 3);
-        mma_frags(FA);
-        mma_frags(FB);
-        __syncthreads();          // everyone is done reading before the next tile overwrites LDS
+        const bf16* rd = lds0 + cur * BUF;
+        bf16* wr = lds0 + (cur ^ 1) * BUF;
+        phase(std::integral_constant<int, 0>{}, rd, wr);
+        phase(std::integral_constant<int, 1>{}, rd, wr);
+        phase(std::integral_constant<int, 2>{}, rd, wr);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's share of the dy DMA has landed
+        __syncthreads();          // the other stage is complete, and nobody reads this one any more (kc3 is in registers)
+        tile_bases(min(tile + 2, t_end - 1));          // past the end: a harmless re-load of the last tile
+        phase(std::integral_constant<int, 3>{}, wr, const_cast<bf16*>(rd));
+        cur ^= 1;
     }
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");   // the last (redundant) DMA, before the LDS goes
+                                                                            // away; the last MFMAs, before acc is read
+#ifdef SV_WG3_STAMP
+    if (tid == 0 && p.ws) {
+        float* d = p.ws + (24u << 20) + 8 * blockIdx.x;
+        d[4] = (float)(__builtin_amdgcn_s_memtime() - st_begin); d[5] = (float)(t_end - t_begin);
+    }
+#endif
 
     // ---- publish: D layout = lane holds c = c0 + 16*wj + fr, n = n0 + 80*wi + 16*a + 4*fq + r --------------------
     const int64_t slab = (int64_t)g.N * g.T_orig * g.Cin;
@@ -455,22 +548,46 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3w_kernel(const sv_geom g, cons
     }
 }
 
-// dw[i] += sum_s ws[s][i].  blockIdx.y = group of slabs (so that small slabs x many splits still fill
-// the chip); with more than one group the groups meet in dw through float atomics.
-__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* ws, int splits, int64_t n, float* dw) {
-    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
-    if (i >= n) return;
-    const int groups = gridDim.y;
-    const int k0 = (int)((int64_t)splits * blockIdx.y / groups), k1 = (int)((int64_t)splits * (blockIdx.y + 1) / groups);
+// dw[i] += sum_s ws[s][i].  A block owns 256/G float4 columns; its G thread groups each sum every G-th slab, meet in
+// LDS, and ONE float atomic per output leaves the block (many small slabs -- 512 x 36 KB for the 32-channel stage --
+// used to meet in dw through 32 atomics per output, which cost more than reading the slabs).
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* ws, int splits, int64_t n, float* dw, int G) {
+    __shared__ f32x4 part[256];
+    const int cols = 256 / G, col = threadIdx.x % cols, grp = threadIdx.x / cols;
+    const int64_t i = ((int64_t)blockIdx.x * cols + col) * 4;
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (i < n) {
 #pragma unroll 4
-    for (int k = k0; k < k1; ++k) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(ws + (int64_t)k * n + i);
-        s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
+        for (int k = grp; k < splits; k += G) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(ws + (int64_t)k * n + i);
+            s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
+        }
+    }
+    if (G > 1) {
+        part[threadIdx.x] = s;
+        __syncthreads();
+        for (int h = G >> 1; h >= 1; h >>= 1) {
+            if (grp < h) {
+                const f32x4 o = part[threadIdx.x + h * cols];
+                s[0] += o[0]; s[1] += o[1]; s[2] += o[2]; s[3] += o[3];
+                part[threadIdx.x] = s;
+            }
+            __syncthreads();
+        }
     }
     // always atomic: the backward of the other branch of the step may be adding to dw concurrently
+    if (grp == 0 && i < n) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) atomicAdd(dw + i + r, s[r]);
+        for (int r = 0; r < 4; ++r) atomicAdd(dw + i + r, s[r]);
+    }
+}
+
+static void launch_slab_reduce(const float* ws, int splits, int64_t n, float* dw, hipStream_t s) {
+    int G = 1;                                       // >= 8 slabs per thread group, >= ~256 blocks where possible
+    while (G < 32 && G * 2 * 8 <= splits && (n / 4 + 256 / G - 1) / (256 / G) < 256) G *= 2;
+    const int cols = 256 / G;
+    const unsigned gx = (unsigned)((n / 4 + cols - 1) / cols);
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(gx), dim3(256), 0, s, ws, splits, n, dw, G);
 }
 
 template <typename T, int WLOG>
@@ -485,10 +602,7 @@ int launch(const sv_geom* g, const wg3_params& p, hipStream_t s) {
     sv_prof_end(s);               // the event bracket times the main kernel only (comparable with rocprofv3)
     if (p.ws) {
         const int64_t n = (int64_t)g->N * g->T_orig * g->Cin;      // multiple of 4 (Cin % 32 == 0)
-        const unsigned gx = (unsigned)((n / 4 + 255) / 256);
-        int groups = 1;                                  // >= 16 slabs per group, ~<= 1024 blocks
-        while (groups * 2 * 16 <= p.splits && gx * groups * 2 <= 1024) groups *= 2;
-        hipLaunchKernelGGL(slab_reduce_kernel, dim3(gx, groups), dim3(256), 0, s, p.ws, p.splits, n, p.dw);
+        launch_slab_reduce(p.ws, p.splits, n, p.dw, s);
     }
     return sv_check_launch("sv_wgrad(3x3)");
 }
@@ -499,7 +613,7 @@ int launch_wide(const sv_geom* g, const wg3_params& p, hipStream_t s) {
     const int nC = g->Cin / 32, nNt = g->N / 160;
     const int grid = p.unit > 0 ? 8 * ((p.splits * nNt * (nC / p.unit) + 7) / 8) * p.unit : p.splits * nNt * nC;
     constexpr int HHc = (TR < W) ? TR : W, LROWSc = TR + TR / HHc + 1;
-    const size_t lds = (size_t)(128 * LDY + LROWSc * (W + 2) * LDH) * 2;
+    const size_t lds = (size_t)(128 * LDY + LROWSc * (W + 2) * LDH + 512) * 2 * 2;      // two stages
     static bool optin = false;
     if (!optin) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3x3w_kernel<WLOG>),
@@ -512,10 +626,7 @@ int launch_wide(const sv_geom* g, const wg3_params& p, hipStream_t s) {
     sv_prof_end(s);
     if (p.ws) {
         const int64_t n = (int64_t)g->N * g->T_orig * g->Cin;
-        const unsigned gx = (unsigned)((n / 4 + 255) / 256);
-        int groups = 1;
-        while (groups * 2 * 16 <= p.splits && gx * groups * 2 <= 1024) groups *= 2;
-        hipLaunchKernelGGL(slab_reduce_kernel, dim3(gx, groups), dim3(256), 0, s, p.ws, p.splits, n, p.dw);
+        launch_slab_reduce(p.ws, p.splits, n, p.dw, s);
     }
     return sv_check_launch("sv_wgrad(3x3 wide)");
 }
@@ -541,18 +652,27 @@ int sv_wgrad3x3_try(const sv_geom* g, int dtype, const void* x, const float* pro
     static const bool no_wide = getenv("SV_NO_WGRAD3X3W") != nullptr;
     if (!no_wide && dtype == SV_BF16 && g->N % 160 == 0 && g->Cin >= 96) {
         // wide layers: 160 x 32 slabs, one block (one wave per SIMD) per CU.  Pick the split count and the affinity unit
-        // (a divisor of the chunk count) that minimise rounds-of-32-CUs-per-XCD x tiles per block
+        // (a divisor of the chunk count) that minimise the modelled time, in units of one tile iteration of a block:
+        //   rounds-of-32-CUs-per-XCD x (tiles per block + publishing a 160 x 32 x 9 slab, ~3 tiles)
+        //   + the slab reduction (every split adds one slab read at ~4 TB/s; a tile iteration is ~3.5 us).
+        // Splits whose slabs do not fit the caller's workspace would have to meet in dw through float atomics
+        // (measured: 64 splits of the 320-channel layer = 59 M atomics, 393 us instead of ~300) and are only taken when
+        // nothing fits.
         const int nC = g->Cin / 32, nNt = g->N / 160;
+        const int64_t slab_elems = (int64_t)g->N * g->T_orig * g->Cin;
+        const double reduce_per_split = (double)slab_elems * 4.0 / (4.0e12 * 3.5e-6);
         int splits = 1, unit = 0;
-        int64_t best = -1;
+        double best = -1.0;
         for (int sp = 1; sp <= nT && sp <= 128; ++sp) {
             const int tp = (nT + sp - 1) / sp;
             if ((nT + tp - 1) / tp != sp) continue;               // no empty splits
+            const bool fits = sp == 1 || (ws && ws_elems >= sp * slab_elems);
             for (int u = 1; u <= nC && u <= 32; ++u) {
                 if (nC % u) continue;
                 const int units = sp * nNt * (nC / u);
                 const int per_xcd = (units + 7) / 8 * u;
-                const int64_t cost = (int64_t)((per_xcd + 31) / 32) * tp * 64 - u;     // ties: the larger unit
+                double cost = (double)((per_xcd + 31) / 32) * (tp + 3.0) + (sp > 1 ? reduce_per_split * sp : 0.0) - 1e-3 * u;
+                if (!fits) cost = 1e6 + cost;
                 if (best < 0 || cost < best) { best = cost; splits = sp; unit = u; }
             }
         }
@@ -561,6 +681,10 @@ int sv_wgrad3x3_try(const sv_geom* g, int dtype, const void* x, const float* pro
         p.tiles_per = (nT + splits - 1) / splits;
         const int64_t needw = (int64_t)splits * g->N * g->T_orig * g->Cin;
         p.ws = (ws && ws_elems >= needw && splits > 1) ? ws : nullptr;
+        static const bool dbg = getenv("SV_WG3_DEBUG") != nullptr;
+        if (dbg)
+            fprintf(stderr, "wgrad3x3w: Cin %d N %d W %d tiles %d -> splits %d unit %d tiles/block %d workspace %s (%lld of %lld)\n",
+                    g->Cin, g->N, g->Win, nT, splits, unit, p.tiles_per, p.ws ? "yes" : "NO", (long long)needw, (long long)ws_elems);
         switch (g->Win) {
             case 32: *rc = launch_wide<5>(g, p, s); break;
             case 16: *rc = launch_wide<4>(g, p, s); break;
