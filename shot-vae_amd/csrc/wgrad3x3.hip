@@ -18,7 +18,15 @@
 namespace {
 
 constexpr int TC32 = 32;
-constexpr int LDH = TC32 + 8;     // LDS row stride (elements) of both the dy tile and the halo
+#ifndef SV_WG3_LDH_PAD
+#define SV_WG3_LDH_PAD 16
+#endif
+#ifndef SV_WG3_LDY_PAD
+#define SV_WG3_LDY_PAD 16
+#endif
+// LDS row stride (elements) of both the dy tile and the halo.  96 B: the four pixel rows a 16-lane group of a transposing
+// 8-byte read touches (32 B each) land on disjoint banks (80 B wrapped the fourth onto the first: 2-way conflicts)
+constexpr int LDH = TC32 + SV_WG3_LDH_PAD;
 
 struct wg3_params {
     const void* x;
@@ -297,7 +305,22 @@ __global__ __launch_bounds__(256) void wgrad3x3_kernel(const sv_geom g, const wg
 // as above (the 32-channel chunks of one pixel range run on one XCD, so the dy re-reads are L2 hits).
 typedef __attribute__((address_space(3))) void* wg_lds_ptr;
 typedef const __attribute__((address_space(1))) void* wg_glb_ptr;
-constexpr int LDY = 160 + 8;      // LDS row stride (elements) of the wide dy tile: 336 B = 80 B mod 256, as LDH
+// ---- gap bookkeeping of the wide kernel's phases (see wgrad3x3w_kernel): gap g = 5 t + a follows MFMA a of tap group t
+constexpr bool gap_has_read(int g) { return (g % 5) < 2 || ((g % 5) == 2 && g / 5 < 8); }
+constexpr int gap_cap(int g) { return gap_has_read(g) ? 1 : 2; }            // single-instruction steps a gap hides
+constexpr int cap_before(int g) { int c = 0; for (int i = 0; i < g; ++i) c += gap_cap(i); return c; }
+constexpr int free_before(int g) { int c = 0; for (int i = 0; i < g; ++i) c += gap_has_read(i) ? 0 : 1; return c; }
+constexpr int PHASE_CAP = cap_before(45);                                    // 26 + 2 * 19 = 64
+
+template <int N, typename F, int I = 0>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<N, F, I + 1>(static_cast<F&&>(f));
+    }
+}
+constexpr int LDY = 160 + SV_WG3_LDY_PAD;      // LDS row stride (elements) of the wide dy tile: 352 B = 96 B mod 256, as LDH
+constexpr int YVR = LDY / 8;                   // 16-byte vectors per LDS row of the dy tile (20 of data + padding)
 
 __device__ __forceinline__ bf16x8 frag_tr_ld(const bf16* S, int pix_elem_q, int col0, int lane, int ld) {
     typedef __attribute__((address_space(3))) s16x4 lds_v4;
@@ -317,10 +340,10 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3w_kernel(const sv_geom g, cons
     // TR = 16 > H = 8) a zero spacer row separates them -- zero padding is DATA in LDS, the nine taps need no masks
     constexpr int HH = (TR < W) ? TR : W, SEG = TR / HH, LROWS = TR + SEG + 1;
     constexpr int HP = LROWS * WP;
-    // the dy tile goes global -> LDS by DMA, 64 consecutive 16-byte vectors per wave instruction, and an LDS row is 21
-    // vectors (20 of data + the LDY padding, which is fetched as a copy of vector 19): 2688 vectors = 42 instructions,
-    // wave w issues k*4 + w for k < 11 (the two past the end repeat the last one)
-    constexpr int YV = 128 * 21, YI = 11;
+    // the dy tile goes global -> LDS by DMA, 64 consecutive 16-byte vectors per wave instruction, and an LDS row is YVR
+    // vectors (20 of data + the LDY padding, which is fetched as copies of vector 19): 128 * 22 vectors = 44 instructions,
+    // wave w issues k*4 + w for k < 11 (any past the end repeat the last one)
+    constexpr int YV = 128 * YVR, YI = (YV + 255) / 256;
     constexpr int HV = HP * 4, HI = (HV + 255) / 256;         // halo vectors
 
     // two LDS stages of {dy tile [128][LDY], halo [HP][LDH], 512 dummy elements for the unused staging slots}
@@ -403,7 +426,7 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3w_kernel(const sv_geom g, cons
     uint32_t yoff[YI];
 #pragma unroll
     for (int k = 0; k < YI; ++k) {
-        const int q = min((k * 4 + wave) * 64, YV - 64) + lane, pp = q / 21, vv = min(q - pp * 21, 19);
+        const int q = (k * 4 + wave) * 64 + lane, pp = q / YVR, vv = min(q - pp * YVR, 19);
         yoff[k] = (uint32_t)(pp * g.ldo + n0 + 8 * vv) * 2u;
     }
 
@@ -422,21 +445,53 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3w_kernel(const sv_geom g, cons
     // (spelled in assembly: through the builtin the compiler knows the instruction writes LDS and, unable to tell the two
     // stages apart, waits for vmcnt(0) before the next fragment read -- the DMA is ordered by the explicit wait + barrier
     // at the end of phase 2 instead; un-modelled VMEM instructions can only make the compiler's own vmcnt waits stricter)
-    auto dma_y = [&](bf16* buf, int k) {
-        const uint32_t dst = (uint32_t)(uintptr_t)(wg_lds_ptr)(buf + min((k * 4 + wave_s) * 64, YV - 64) * 8);
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
-                     :: "s"(dst), "v"(yoff[k]), "s"(ybase) : "memory");      // (m0 is reserved: the compiler never allocates it)
+    static_assert(YV % 256 == 0, "every wave issues whole DMA instructions");
+    const uint32_t dma0 = (uint32_t)(uintptr_t)(wg_lds_ptr)lds0 + (uint32_t)wave_s * 1024u;   // + stage, + 4096 k
+    auto dma_y = [&](int stage, auto K) {
+        constexpr int k = decltype(K)::value;
+        const uint32_t base = dma0 + (uint32_t)stage * (uint32_t)(BUF * 2), yo = yoff[k];
+        const char* yb = ybase;
+        asm volatile("s_add_u32 m0, %0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3"
+                     :: "s"(base), "n"(k * 4096), "v"(yo), "s"(yb) : "memory", "scc");   // (m0 is reserved: the
+                                                                                    // compiler never allocates it)
     };
     auto load_h = [&](int i) { rh[i] = *reinterpret_cast<const bf16x8*>(hbase + (hok[i] ? hoff[i] : hsafe)); };
-    auto store_h = [&](bf16* buf, int i) {
-        bf16x8 o;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float u0 = (float)rh[i][j] * s0[j] + t0[j], u1 = (float)rh[i][j + 4] * s1[j] + t1[j];
-            o[j] = (bf16)fmaxf(u0, u0 * slope);
-            o[j + 4] = (bf16)fmaxf(u1, u1 * slope);
+    // The BN + activation transform of the halo vectors, as single-instruction MICRO-STEPS.  Measured with
+    // tools/probes/issue_probe.hip (one wave per SIMD): behind one 16x16x32 MFMA a wave issues two (unpacked) VALU
+    // instructions or one LDS read for free; every further VALU costs ~4 cycles, a second LDS read ~10, and
+    // v_pk_fma_f32 ~12 (so no packed fp32 here).  Halo vector i = four dwords of two bf16 channels; per dword d:
+    //   0,1: lo = x << 16, hi = x & 0xffff0000      2,3: u = f * scale + shift      4,5: m = u * slope
+    //   6,7: u = max(u, m)                           8: od = pack_bf16(u)            9: od = valid ? od : 0
+    // and step 40 stores the vector into the other stage.
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    constexpr int HSTEPS = 41;
+    float xlo, xhi, xmlo, xmhi;
+    u32x4 od;
+    auto hstep = [&](auto I, auto ST, bf16* wr) {
+        constexpr int i = decltype(I)::value, st = decltype(ST)::value, d = st / 10, q = st % 10;
+        if constexpr (st == 40) {
+            *reinterpret_cast<u32x4*>(wr + hlds[i]) = od;
+        } else {
+            const float sc_lo = d < 2 ? s0[2 * d] : s1[2 * d - 4], sc_hi = d < 2 ? s0[2 * d + 1] : s1[2 * d - 3];
+            const float sh_lo = d < 2 ? t0[2 * d] : t1[2 * d - 4], sh_hi = d < 2 ? t0[2 * d + 1] : t1[2 * d - 3];
+            if constexpr (q == 0) xlo = __builtin_bit_cast(float, __builtin_bit_cast(u32x4, rh[i])[d] << 16);
+            if constexpr (q == 1) xhi = __builtin_bit_cast(float, __builtin_bit_cast(u32x4, rh[i])[d] & 0xffff0000u);
+            if constexpr (q == 2) xlo = __builtin_fmaf(xlo, sc_lo, sh_lo);
+            if constexpr (q == 3) xhi = __builtin_fmaf(xhi, sc_hi, sh_hi);
+            if constexpr (q == 4) xmlo = xlo * slope;
+            if constexpr (q == 5) xmhi = xhi * slope;
+            if constexpr (q == 6) xlo = fmaxf(xlo, xmlo);
+            if constexpr (q == 7) xhi = fmaxf(xhi, xmhi);
+            if constexpr (q == 8) {
+                typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+                const bf16x2v pk = {(__bf16)xlo, (__bf16)xhi};
+                od[d] = __builtin_bit_cast(uint32_t, pk);
+            }
+            if constexpr (q == 9) od[d] = hok[i] ? od[d] : 0u;
         }
-        *reinterpret_cast<bf16x8*>(buf + hlds[i]) = hok[i] ? o : zero;
+    };
+    auto store_h = [&](bf16* buf, auto I) {
+        static_for<HSTEPS>([&](auto ST) { hstep(I, ST, buf); });
     };
 
     f32x4 acc[5][9];
@@ -447,79 +502,130 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3w_kernel(const sv_geom g, cons
 
     // fragments of one 32-pixel k chunk: 5 dy fragments (two sets, used by all nine tap groups of a phase) and 9
     // tap-shifted x fragments (ONE rolling set: tap t's registers are free once its five MFMAs have issued, and receive
-    // the next chunk's tap t right away -- eight tap groups before they are needed)
-    bf16x8 fy[2][5], fx[9];
-    // lane addresses pixel pq = 32*kc + 8*fq + (fr>>2) of the tile (and pq + 4)
-    auto load_fy = [&](int set, const bf16* buf, int kc, int a) {
-        const int pq = 32 * kc + 8 * fq + (fr >> 2);
-        fy[set][a] = frag_tr_ld(buf, pq * LDY, 80 * wi + 16 * a, lane, LDY);
+    // the next chunk's tap t right away -- eight tap groups before they are needed).  A fragment is two transposing
+    // 8-byte reads (k 0..3 and 4..7 of the lane's column), kept as halves so that each read gets a gap of its own.
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    s16x8 fy[2][5], fx[9];
+    auto put_half = [](s16x8& f, s16x4 h, int half) {
+        const s16x8 w = __builtin_shufflevector(h, h, 0, 1, 2, 3, -1, -1, -1, -1);
+        f = half == 0 ? __builtin_shufflevector(w, f, 0, 1, 2, 3, 12, 13, 14, 15)
+                      : __builtin_shufflevector(f, w, 0, 1, 2, 3, 8, 9, 10, 11);
     };
-    auto load_fx = [&](const bf16* buf, int kc, int t) {
-        const int pq = 32 * kc + 8 * fq + (fr >> 2);
-        const int jrow = pq >> WLOG, xcol = pq & (W - 1);
-        const int hb = 128 * LDY + ((jrow + 1 + jrow / HH) * WP + xcol + 1) * LDH;
-        fx[t] = frag_tr(buf, hb + (tap_off(pdy, t) * WP + tap_off(pdx, t)) * LDH, 16 * wj, lane);
+    // lane byte addresses in LDS, per stage: the lane reads pixel l = 8*fq + (fr>>2) (and l + 4) of every 32-pixel chunk;
+    // the chunk and the dy fragment number are immediates, the tap shift (layer-dependent order) is folded in here
+    const int lpix = 8 * fq + (fr >> 2);
+    uint32_t yaddr, xaddr[9];                // of the stage being read; flipped to the other stage once per tile
+    {
+        const uint32_t l0 = (uint32_t)(uintptr_t)(wg_lds_ptr)lds0;
+        const int yl = lpix * LDY + 80 * wi + 4 * (lane & 3);
+        const int hl = 128 * LDY + (((lpix >> WLOG) + 1) * WP + (lpix & (W - 1)) + 1) * LDH + 16 * wj + 4 * (lane & 3);
+        yaddr = l0 + (uint32_t)yl * 2u;
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+            xaddr[t] = l0 + (uint32_t)(hl + (tap_off(pdy, t) * WP + tap_off(pdx, t)) * LDH) * 2u;
+    }
+    typedef __attribute__((address_space(3))) s16x4 lds_v4;
+    auto load_fy = [&](int set, int kc, int a, int half) {
+        put_half(fy[set][a], __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (lds_v4*)(uintptr_t)(yaddr + (uint32_t)((32 * kc + 4 * half) * LDY + 16 * a) * 2u)), half);
     };
-    // One phase = the 45 MFMAs of one k chunk, in nine tap groups of five; between the groups (and only there: nothing
-    // crosses a sched_barrier) the wave issues its share of the other pipes' work -- the LDS reads of the next chunk's
-    // fragments, and per phase: the dy stores / the halo transform + stores into the OTHER stage / the global loads of
-    // the tile after next.  With one wave per SIMD nobody else would fill the matrix pipe while this wave stages.
-    //   phase 0: reads kc1, loads the next tile's halo vectors      phase 1: reads kc2
-    //   phase 2: reads kc3, transforms + stores that halo into the other stage;  barrier;
-    //   phase 3: reads kc0 of the next tile from the other stage, starts the dy DMA of the tile after next into this one
-    auto phase = [&](auto PH, const bf16* rd, bf16* wr) {
+    auto load_fx = [&](int kc, int t, int half) {
+        // chunk kc starts (32 / W) * kc image rows into the tile; the spacer rows of W = 8 tiles come every HH rows
+        const int r0 = (32 / W) * kc, rows = r0 + r0 / HH;
+        put_half(fx[t], __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (lds_v4*)(uintptr_t)(xaddr[t] + (uint32_t)((rows * WP + 4 * half) * LDH) * 2u)), half);
+    };
+    // One phase = the 45 MFMAs of one k chunk.  One wave per SIMD: nobody else fills the matrix pipe while this wave
+    // stages, so every other instruction of the tile iteration sits in the GAP behind one MFMA, sized by what the probe
+    // says a gap hides, and nothing crosses the sched_barrier that closes a gap.  Gap g = 5 t + a (tap group t, MFMA a):
+    //   a = 0, 1: one LDS read each -- tap t-1 of the next chunk (its registers were freed by tap group t-1); in group
+    //             0: dy fragment 0                    a = 2 (t < 8): one read of dy fragments 1..4 of the next chunk
+    //   the other 19 gaps:  phases 0..2: two micro-steps of the halo transform (and one in each read gap; the 41 * HI
+    //                       steps fill the capacity of the three phases from the back);  [end of phase 2: barrier]
+    //                       phase 3: reads kc0 of the next tile from the other stage; one global load of the halo of the
+    //                       tile after next, or one dy DMA instruction into the stage that just became free
+    // wr = the stage phase work writes (fragment reads follow yaddr / xaddr)
+    auto phase = [&](auto PH, bf16* wr, int dma_stage) {
         constexpr int ph = decltype(PH)::value;
         constexpr int nkc = (ph + 1) & 3, set = ph & 1;
-#pragma unroll
-        for (int t = 0; t < 9; ++t) {
-#pragma unroll
-            for (int a = 0; a < 5; ++a)       // in-place accumulation in the AGPR half, spelled out: left to itself the
-                                              // register allocator rotates the 180 accumulators through copies
-                asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[a][t]) : "v"(fy[set][a]), "v"(fx[t]));
-            load_fx(rd, nkc, t);
-            if (t < 5) load_fy(set ^ 1, rd, nkc, t);
-            if (ph == 0 && t < HI) load_h(t);
-            if (ph == 2 && (t & 1) == 1 && (t >> 1) < HI) store_h(wr, t >> 1);
-            if (ph == 3) {
-                dma_y(wr, t);
-                if (t + 9 < YI) dma_y(wr, t + 9);
+        static_for<45>([&](auto GP) {
+            constexpr int g = decltype(GP)::value, t = g / 5, a = g % 5;
+            // in-place accumulation in the AGPR half, spelled out: left to itself the register allocator rotates the
+            // 180 accumulators through copies
+            asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[a][t]) : "v"(fy[set][a]), "v"(fx[t]));
+#ifndef SV_WG3_NO_FRAG       // (timing ablations only: the results are wrong)
+            if constexpr (a < 2) {
+                if constexpr (t >= 1) load_fx(nkc, t - 1, a);
+                else load_fy(set ^ 1, nkc, 0, a);
             }
+            if constexpr (a == 2 && t < 8) load_fy(set ^ 1, nkc, 1 + t / 2, t & 1);
+#endif
+#ifndef SV_WG3_NO_SIDE
+            if constexpr (ph < 3) {
+                // the HSTEPS * HI micro-steps fill the capacity of phases 0..2 from the back
+                static_for<gap_cap(g)>([&](auto J) {
+                    constexpr int m = ph * PHASE_CAP + cap_before(g) + decltype(J)::value - (3 * PHASE_CAP - HSTEPS * HI);
+                    if constexpr (m >= 0)
+                        hstep(std::integral_constant<int, m / HSTEPS>{}, std::integral_constant<int, m % HSTEPS>{}, wr);
+                });
+            } else if constexpr (!gap_has_read(g)) {
+                constexpr int f = free_before(g);
+                if constexpr (f < HI) load_h(f);
+                else if constexpr (f >= 4 && f - 4 < YI) dma_y(dma_stage, std::integral_constant<int, f - 4>{});
+            }
+#endif
             __builtin_amdgcn_sched_barrier(0);
-        }
+        });
+        load_fx(nkc, 8, 0);
+        load_fx(nkc, 8, 1);
     };
-    static_assert(HI <= 4 && YI == 11, "phase work lists");
+    static_assert(HI <= 4 && YI == 11 && 4 + YI <= free_before(45) && HSTEPS * HI <= 3 * PHASE_CAP, "phase work lists");
 
 #ifdef SV_WG3_STAMP
     const uint64_t st_begin = __builtin_amdgcn_s_memtime();
+    uint64_t st_p0 = 0, st_p1 = 0, st_p2 = 0, st_p3 = 0, st_bar = 0, st_last = 0;
 #endif
     // prologue: tile t_begin into stage 0, the dy DMA of the second tile into stage 1, the first fragments
     tile_bases(t_begin);
-#pragma unroll
-    for (int k = 0; k < YI; ++k) dma_y(lds0, k);
+    static_for<YI>([&](auto K) { dma_y(0, K); });
 #pragma unroll
     for (int i = 0; i < HI; ++i) load_h(i);
-#pragma unroll
-    for (int i = 0; i < HI; ++i) store_h(lds0, i);
+    static_for<HI>([&](auto I) { store_h(lds0, I); });
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     tile_bases(min(t_begin + 1, t_end - 1));
 #pragma unroll
-    for (int k = 0; k < YI; ++k) dma_y(lds0 + BUF, k);
+    for (int i = 0; i < HI; ++i) load_h(i);
+    static_for<YI>([&](auto K) { dma_y(1, K); });
 #pragma unroll
-    for (int a = 0; a < 5; ++a) load_fy(0, lds0, 0, a);
+    for (int a = 0; a < 5; ++a) { load_fy(0, 0, a, 0); load_fy(0, 0, a, 1); }
 #pragma unroll
-    for (int t = 0; t < 9; ++t) load_fx(lds0, 0, t);
+    for (int t = 0; t < 9; ++t) { load_fx(0, t, 0); load_fx(0, t, 1); }
+#ifdef SV_WG3_STAMP
+    st_last = __builtin_amdgcn_s_memtime();
+#endif
     int cur = 0;
     for (int tile = t_begin; tile < t_end; ++tile) {
-        const bf16* rd = lds0 + cur * BUF;
-        bf16* wr = lds0 + (cur ^ 1) * BUF;
-        phase(std::integral_constant<int, 0>{}, rd, wr);
-        phase(std::integral_constant<int, 1>{}, rd, wr);
-        phase(std::integral_constant<int, 2>{}, rd, wr);
+        bf16* cur_stage = lds0 + cur * BUF;
+        bf16* other = lds0 + (cur ^ 1) * BUF;
+        phase(std::integral_constant<int, 0>{}, other, 0);
+        WG3_STAMP(st_p0)
+        phase(std::integral_constant<int, 1>{}, other, 0);
+        WG3_STAMP(st_p1)
+        phase(std::integral_constant<int, 2>{}, other, 0);
+        WG3_STAMP(st_p2)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's share of the dy DMA has landed
         __syncthreads();          // the other stage is complete, and nobody reads this one any more (kc3 is in registers)
+        WG3_STAMP(st_bar)
+        {   // from here on fragments come from the other stage
+            const uint32_t flip = cur ? (uint32_t)(-(BUF * 2)) : (uint32_t)(BUF * 2);
+            yaddr += flip;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) xaddr[t] += flip;
+        }
         tile_bases(min(tile + 2, t_end - 1));          // past the end: a harmless re-load of the last tile
-        phase(std::integral_constant<int, 3>{}, wr, const_cast<bf16*>(rd));
+        phase(std::integral_constant<int, 3>{}, cur_stage, cur);
+        WG3_STAMP(st_p3)
         cur ^= 1;
     }
     asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");   // the last (redundant) DMA, before the LDS goes
@@ -528,6 +634,7 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3w_kernel(const sv_geom g, cons
     if (tid == 0 && p.ws) {
         float* d = p.ws + (24u << 20) + 8 * blockIdx.x;
         d[4] = (float)(__builtin_amdgcn_s_memtime() - st_begin); d[5] = (float)(t_end - t_begin);
+        d[0] = (float)st_p0; d[1] = (float)st_p1; d[2] = (float)st_p2; d[3] = (float)st_p3; d[6] = (float)st_bar;
     }
 #endif
 

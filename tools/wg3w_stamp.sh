@@ -1,7 +1,7 @@
 #!/bin/bash
 # Diagnostic build of wgrad3x3w_kernel (wide layers) with in-kernel stamps.  usage: wg3w_stamp.sh B C H N
 cd "$(dirname "$0")/../shot-vae_amd/csrc" || exit 1
-FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -munsafe-fp-atomics -I../../include -Wno-unused-function"
+FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -munsafe-fp-atomics -I../../include -Wno-unused-function $SV_EXTRA_FLAGS"
 /opt/rocm/bin/hipcc $FLAGS -DSV_WG3_STAMP -c wgrad3x3.hip -o wgrad3x3.o 2>/dev/null && /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC igemm.o conv3x3.o conv3x3w.o wgrad.o wgrad3x3.o small.o runtime.o -o ../libshotvae_hip.so
 cd ../.. && python - "$@" <<'PY'
 import ctypes as C, sys, torch
@@ -21,5 +21,6 @@ t = ws[24 << 20:(24 << 20) + 8 * 2048].view(2048, 8).cpu().double()
 t = t[t[:, 5] > 0]
 per = t[:, :5] / t[:, 5:6]
 print("blocks %d, tiles per block %.1f (min %d max %d); block cycles mean %.0f max %.0f" % (len(t), t[:, 5].mean(), t[:, 5].min(), t[:, 5].max(), t[:, 4].mean(), t[:, 4].max()))
-print("cycles per tile: %.0f (ideal matrix pipe: 2880)" % per[:, 4].mean())
+print("cycles per tile: %.0f (ideal matrix pipe: 2880); phase 0 %.0f  phase 1 %.0f  phase 2 %.0f  wait+barrier %.0f  phase 3 %.0f (720 each)" % (
+    per[:, 4].mean(), per[:, 0].mean(), per[:, 1].mean(), per[:, 2].mean(), (t[:, 6] / t[:, 5]).mean(), per[:, 3].mean()))
 PY
