@@ -310,7 +310,100 @@ constexpr bool gap_has_read(int g) { return (g % 5) < 2 || ((g % 5) == 2 && g / 
 constexpr int gap_cap(int g) { return gap_has_read(g) ? 1 : 2; }            // single-instruction steps a gap hides
 constexpr int cap_before(int g) { int c = 0; for (int i = 0; i < g; ++i) c += gap_cap(i); return c; }
 constexpr int free_before(int g) { int c = 0; for (int i = 0; i < g; ++i) c += gap_has_read(i) ? 0 : 1; return c; }
-constexpr int PHASE_CAP = cap_before(45);                                    // 26 + 2 * 19 = 64
+
+// The per-tile program of everything that is not an MFMA or a fragment read, packed into the gaps at compile time.
+//   items: HSTEPS * HI transform micro-steps (code 1000 + 41 slot + step); the YI = 11 dy DMA instructions (2000 + k);
+//          the HI halo loads (3000 + slot); the vmcnt waits before a slot's first step (4000 + slot, free).
+//   VMEM instructions are spread over the whole tile -- the probe: one per four MFMAs is free, one per two is not (the
+//   CU's 64 B/clk L1 path) -- and a halo register is re-loaded (for the tile after next) as soon as its vector has been
+//   transformed, a whole tile iteration ahead of its use.
+constexpr int WG_HSTEPS = 41, WG_YI = 11;
+template <int HI>
+struct WSched {
+    int item[180][3];       // gap (phase * 45 + g) -> up to 3 item codes, executed in this order (0 = none)
+    int vm_wait[4];         // vmcnt for the wait before slot s: VMEM instructions issued since its load
+    int vm_barrier;         // vmcnt before the barrier: VMEM instructions issued since the last dy DMA of phases 0..2
+    bool ok;
+};
+template <int HI>
+constexpr WSched<HI> make_wsched() {
+    WSched<HI> S{};
+    for (int i = 0; i < 180; ++i) S.item[i][0] = S.item[i][1] = S.item[i][2] = 0;
+    // ---- region A (phases 0..2): forward packing from the latest start gap that still fits everything.  A read gap
+    //      hides one step, a free gap two steps or ONE VMEM instruction (at least six gaps after the previous one; a
+    //      slot's reload only after its last step); a wait is free and shares the gap of the step it precedes.
+    const int nsteps = WG_HSTEPS * HI;
+    int queue[16] = {};
+    int nq = 0;
+    for (int k = 4; k < 8; ++k) queue[nq++] = 2000 + k;
+    if (HI > 1) queue[nq++] = 3000;
+    for (int k = 8; k < WG_YI; ++k) queue[nq++] = 2000 + k;
+    for (int sl = 1; sl < HI - 1; ++sl) queue[nq++] = 3000 + sl;
+    S.ok = false;
+    for (int start = 134; start >= 0 && !S.ok; --start) {
+        for (int i = 0; i < 135; ++i) S.item[i][0] = S.item[i][1] = S.item[i][2] = 0;
+        int m = 0, qh = 0, last_v = -100;
+        for (int gi = start; gi < 135; ++gi) {
+            int nt = 0;
+            const bool fre = !gap_has_read(gi % 45);
+            bool vm = false;
+            if (fre && qh < nq && gi - last_v >= 6) {
+                const int c = queue[qh];
+                if (c / 1000 == 2 || m >= WG_HSTEPS * (c % 1000 + 1)) vm = true;
+            }
+            if (vm) {
+                S.item[gi][nt++] = queue[qh++];
+                last_v = gi;
+            } else {
+                for (int c = 0; c < (fre ? 2 : 1) && m < nsteps; ++c) {
+                    if (m % WG_HSTEPS == 0) S.item[gi][nt++] = 4000 + m / WG_HSTEPS;
+                    S.item[gi][nt++] = 1000 + m;
+                    ++m;
+                }
+            }
+        }
+        S.ok = m == nsteps && qh == nq;
+    }
+    // ---- region B (phase 3): the last slot's reload, then D0..D3, four free gaps apart
+    {
+        int f = 0, placed = 0;
+        const int lb[5] = {3000 + HI - 1, 2000, 2001, 2002, 2003};
+        for (int g = 0; g < 45 && placed < 5; ++g) {
+            if (gap_has_read(g)) continue;
+            if (f % 4 == 0) S.item[135 + g][0] = lb[placed++];
+            ++f;
+        }
+        S.ok = S.ok && placed == 5;
+    }
+    // ---- vmcnt bookkeeping over the steady-state order (one iteration = items of gaps 0..179 in order)
+    int order[64] = {};
+    int pos_gap[64] = {};
+    int nv = 0;
+    for (int gi = 0; gi < 180; ++gi)
+        for (int j = 0; j < 3; ++j) {
+            const int c = S.item[gi][j];
+            if (c / 1000 == 2 || c / 1000 == 3) { order[nv] = c; pos_gap[nv] = gi * 4 + j; ++nv; }
+        }
+    for (int sl = 0; sl < 4; ++sl) S.vm_wait[sl] = 0;
+    for (int sl = 0; sl < HI; ++sl) {
+        int wpos = -1, lpos = -1;
+        for (int gi = 0; gi < 180; ++gi)
+            for (int j = 0; j < 3; ++j) if (S.item[gi][j] == 4000 + sl) wpos = gi * 4 + j;
+        for (int i = 0; i < nv; ++i) if (order[i] == 3000 + sl) lpos = i;
+        int cnt = nv - 1 - lpos;                                   // issued after the load, to the end of its iteration
+        for (int i = 0; i < nv; ++i) if (pos_gap[i] < wpos) ++cnt; // and from the top of this one to the wait
+        S.vm_wait[sl] = cnt;
+        S.ok = S.ok && wpos >= 0 && lpos >= 0;
+    }
+    {
+        int last = -1;
+        for (int i = 0; i < nv; ++i) if (order[i] / 1000 == 2 && pos_gap[i] < 135 * 4) last = i;
+        int cnt = 0;
+        for (int i = last + 1; i < nv; ++i) if (pos_gap[i] < 135 * 4) ++cnt;
+        S.vm_barrier = cnt;
+    }
+    return S;
+}
 
 template <int N, typename F, int I = 0>
 __device__ __forceinline__ void static_for(F&& f) {
@@ -430,22 +523,22 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3w_kernel(const sv_geom g, cons
         yoff[k] = (uint32_t)(pp * g.ldo + n0 + 8 * vv) * 2u;
     }
 
+    // Every VMEM instruction of the tile loop is spelled in assembly and waited for by hand (WSched::vm_*): through the
+    // builtin the compiler knows that the DMA writes LDS and, unable to tell the two stages apart, waits for vmcnt(0)
+    // before the next fragment read; and its own vmcnt bookkeeping cannot see the assembly.
     bf16x8 rh[HI];
     bool hok[HI];
-    const char* ybase;
-    const char* hbase;
-    auto tile_bases = [&](int tile) {
+    const char* ybase = nullptr;       // dy rows of the tile whose DMA is in progress
+    const char* hbase = nullptr;       // x rows (from one above) of the tile whose halo is being loaded
+    bool top_ok = false, bot_ok = false;
+    auto halo_bases = [&](int tile) {
         const int gr0 = tile * TR;
-        const bool top_ok = (gr0 & (H - 1)) != 0, bot_ok = ((gr0 + TR) & (H - 1)) != 0;
-        ybase = reinterpret_cast<const char*>(DY + (int64_t)gr0 * W * g.ldo);
+        top_ok = (gr0 & (H - 1)) != 0;
+        bot_ok = ((gr0 + TR) & (H - 1)) != 0;
         hbase = reinterpret_cast<const char*>(X) + ((int64_t)gr0 - 1) * W * g.ldx * 2;
-#pragma unroll
-        for (int i = 0; i < HI; ++i) hok[i] = hkind[i] == 1 || (hkind[i] == 2 && top_ok) || (hkind[i] == 3 && bot_ok);
     };
-    // (spelled in assembly: through the builtin the compiler knows the instruction writes LDS and, unable to tell the two
-    // stages apart, waits for vmcnt(0) before the next fragment read -- the DMA is ordered by the explicit wait + barrier
-    // at the end of phase 2 instead; un-modelled VMEM instructions can only make the compiler's own vmcnt waits stricter)
-    static_assert(YV % 256 == 0, "every wave issues whole DMA instructions");
+    auto dy_base = [&](int tile) { ybase = reinterpret_cast<const char*>(DY + (int64_t)tile * TR * W * g.ldo); };
+    static_assert(YV % 256 == 0 && YI == WG_YI, "every wave issues whole DMA instructions");
     const uint32_t dma0 = (uint32_t)(uintptr_t)(wg_lds_ptr)lds0 + (uint32_t)wave_s * 1024u;   // + stage, + 4096 k
     auto dma_y = [&](int stage, auto K) {
         constexpr int k = decltype(K)::value;
@@ -455,7 +548,21 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3w_kernel(const sv_geom g, cons
                      :: "s"(base), "n"(k * 4096), "v"(yo), "s"(yb) : "memory", "scc");   // (m0 is reserved: the
                                                                                     // compiler never allocates it)
     };
-    auto load_h = [&](int i) { rh[i] = *reinterpret_cast<const bf16x8*>(hbase + (hok[i] ? hoff[i] : hsafe)); };
+    auto load_h = [&](auto I) {       // halo vector i of the tile halo_bases() was last called for
+        constexpr int i = decltype(I)::value;
+        hok[i] = (hkind[i] == 1) | ((hkind[i] == 2) & top_ok) | ((hkind[i] == 3) & bot_ok);      // (no short circuits)
+        const uint32_t o = hok[i] ? hoff[i] : hsafe;
+        const char* hb = hbase;
+        bf16x8 r;
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(r) : "v"(o), "s"(hb) : "memory");
+        rh[i] = r;
+    };
+    auto wait_h = [&](auto I, auto N) {       // ... and the wait that makes rh[i] usable
+        constexpr int i = decltype(I)::value, nn = decltype(N)::value;
+        bf16x8 r = rh[i];
+        asm volatile("s_waitcnt vmcnt(%1)" : "+v"(r) : "n"(nn) : "memory");
+        rh[i] = r;
+    };
     // The BN + activation transform of the halo vectors, as single-instruction MICRO-STEPS.  Measured with
     // tools/probes/issue_probe.hip (one wave per SIMD): behind one 16x16x32 MFMA a wave issues two (unpacked) VALU
     // instructions or one LDS read for free; every further VALU costs ~4 cycles, a second LDS read ~10, and
@@ -545,6 +652,8 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3w_kernel(const sv_geom g, cons
     //                       phase 3: reads kc0 of the next tile from the other stage; one global load of the halo of the
     //                       tile after next, or one dy DMA instruction into the stage that just became free
     // wr = the stage phase work writes (fragment reads follow yaddr / xaddr)
+    static constexpr WSched<HI> SCHED = make_wsched<HI>();
+    static_assert(SCHED.ok, "the tile program does not fit the gaps");
     auto phase = [&](auto PH, bf16* wr, int dma_stage) {
         constexpr int ph = decltype(PH)::value;
         constexpr int nkc = (ph + 1) & 3, set = ph & 1;
@@ -561,42 +670,39 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3w_kernel(const sv_geom g, cons
             if constexpr (a == 2 && t < 8) load_fy(set ^ 1, nkc, 1 + t / 2, t & 1);
 #endif
 #ifndef SV_WG3_NO_SIDE
-            if constexpr (ph < 3) {
-                // the HSTEPS * HI micro-steps fill the capacity of phases 0..2 from the back
-                static_for<gap_cap(g)>([&](auto J) {
-                    constexpr int m = ph * PHASE_CAP + cap_before(g) + decltype(J)::value - (3 * PHASE_CAP - HSTEPS * HI);
-                    if constexpr (m >= 0)
-                        hstep(std::integral_constant<int, m / HSTEPS>{}, std::integral_constant<int, m % HSTEPS>{}, wr);
-                });
-            } else if constexpr (!gap_has_read(g)) {
-                constexpr int f = free_before(g);
-                if constexpr (f < HI) load_h(f);
-                else if constexpr (f >= 4 && f - 4 < YI) dma_y(dma_stage, std::integral_constant<int, f - 4>{});
-            }
+            static_for<3>([&](auto J) {
+                constexpr int code = SCHED.item[ph * 45 + g][decltype(J)::value], kind = code / 1000, arg = code % 1000;
+                if constexpr (kind == 1)
+                    hstep(std::integral_constant<int, arg / HSTEPS>{}, std::integral_constant<int, arg % HSTEPS>{}, wr);
+                if constexpr (kind == 2) dma_y(dma_stage, std::integral_constant<int, arg>{});
+                if constexpr (kind == 3) load_h(std::integral_constant<int, arg>{});
+                if constexpr (kind == 4) wait_h(std::integral_constant<int, arg>{}, std::integral_constant<int, SCHED.vm_wait[arg]>{});
+            });
 #endif
             __builtin_amdgcn_sched_barrier(0);
         });
         load_fx(nkc, 8, 0);
         load_fx(nkc, 8, 1);
     };
-    static_assert(HI <= 4 && YI == 11 && 4 + YI <= free_before(45) && HSTEPS * HI <= 3 * PHASE_CAP, "phase work lists");
+    static_assert(HI >= 2 && HI <= 4 && HSTEPS == WG_HSTEPS, "phase work lists");
 
 #ifdef SV_WG3_STAMP
     const uint64_t st_begin = __builtin_amdgcn_s_memtime();
     uint64_t st_p0 = 0, st_p1 = 0, st_p2 = 0, st_p3 = 0, st_bar = 0, st_last = 0;
 #endif
-    // prologue: tile t_begin into stage 0, the dy DMA of the second tile into stage 1, the first fragments
-    tile_bases(t_begin);
+    // prologue: tile t_begin into stage 0; then the state the steady loop expects -- the halo of the second tile in rh,
+    // D0..D3 of its dy DMA on their way into stage 1 -- and the first fragments
+    halo_bases(t_begin);
+    dy_base(t_begin);
     static_for<YI>([&](auto K) { dma_y(0, K); });
-#pragma unroll
-    for (int i = 0; i < HI; ++i) load_h(i);
-    static_for<HI>([&](auto I) { store_h(lds0, I); });
+    static_for<HI>([&](auto I) { load_h(I); });
+    static_for<HI>([&](auto I) { wait_h(I, std::integral_constant<int, 0>{}); store_h(lds0, I); });
+    halo_bases(min(t_begin + 1, t_end - 1));
+    dy_base(min(t_begin + 1, t_end - 1));
+    static_for<HI>([&](auto I) { load_h(I); });
+    static_for<4>([&](auto K) { dma_y(1, K); });
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    tile_bases(min(t_begin + 1, t_end - 1));
-#pragma unroll
-    for (int i = 0; i < HI; ++i) load_h(i);
-    static_for<YI>([&](auto K) { dma_y(1, K); });
 #pragma unroll
     for (int a = 0; a < 5; ++a) { load_fy(0, 0, a, 0); load_fy(0, 0, a, 1); }
 #pragma unroll
@@ -608,13 +714,17 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3w_kernel(const sv_geom g, cons
     for (int tile = t_begin; tile < t_end; ++tile) {
         bf16* cur_stage = lds0 + cur * BUF;
         bf16* other = lds0 + (cur ^ 1) * BUF;
-        phase(std::integral_constant<int, 0>{}, other, 0);
+        // this iteration: the MFMAs of `tile` (stage cur); the halo of tile + 1 is transformed into the other stage, where
+        // the rest (D4..D10) of its dy DMA lands too; the halo registers are re-loaded for tile + 2 (past the end: a
+        // harmless re-load of the last tile), and after the barrier D0..D3 of tile + 2 start into this stage
+        halo_bases(min(tile + 2, t_end - 1));
+        phase(std::integral_constant<int, 0>{}, other, cur ^ 1);
         WG3_STAMP(st_p0)
-        phase(std::integral_constant<int, 1>{}, other, 0);
+        phase(std::integral_constant<int, 1>{}, other, cur ^ 1);
         WG3_STAMP(st_p1)
-        phase(std::integral_constant<int, 2>{}, other, 0);
+        phase(std::integral_constant<int, 2>{}, other, cur ^ 1);
         WG3_STAMP(st_p2)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's share of the dy DMA has landed
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(SCHED.vm_barrier) : "memory");    // this wave's share of the dy DMA landed
         __syncthreads();          // the other stage is complete, and nobody reads this one any more (kc3 is in registers)
         WG3_STAMP(st_bar)
         {   // from here on fragments come from the other stage
@@ -623,7 +733,7 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3w_kernel(const sv_geom g, cons
 #pragma unroll
             for (int t = 0; t < 9; ++t) xaddr[t] += flip;
         }
-        tile_bases(min(tile + 2, t_end - 1));          // past the end: a harmless re-load of the last tile
+        dy_base(min(tile + 2, t_end - 1));
         phase(std::integral_constant<int, 3>{}, cur_stage, cur);
         WG3_STAMP(st_p3)
         cur ^= 1;

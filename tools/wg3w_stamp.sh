@@ -21,6 +21,6 @@ t = ws[24 << 20:(24 << 20) + 8 * 2048].view(2048, 8).cpu().double()
 t = t[t[:, 5] > 0]
 per = t[:, :5] / t[:, 5:6]
 print("blocks %d, tiles per block %.1f (min %d max %d); block cycles mean %.0f max %.0f" % (len(t), t[:, 5].mean(), t[:, 5].min(), t[:, 5].max(), t[:, 4].mean(), t[:, 4].max()))
-print("cycles per tile: %.0f (ideal matrix pipe: 2880); phase 0 %.0f  phase 1 %.0f  phase 2 %.0f  wait+barrier %.0f  phase 3 %.0f (720 each)" % (
+print("s_memtime ticks per tile: %.0f (MFMA-only stream, tools/probes/issue_probe.hip: 19.5 ticks per MFMA = 3512); phase 0 %.0f  phase 1 %.0f  phase 2 %.0f  wait+barrier %.0f  phase 3 %.0f (878 each)" % (
     per[:, 4].mean(), per[:, 0].mean(), per[:, 1].mean(), per[:, 2].mean(), (t[:, 6] / t[:, 5]).mean(), per[:, 3].mean()))
 PY
