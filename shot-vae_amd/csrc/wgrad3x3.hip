@@ -869,15 +869,19 @@ int sv_wgrad3x3_try(const sv_geom* g, int dtype, const void* x, const float* pro
     static const bool no_wide = getenv("SV_NO_WGRAD3X3W") != nullptr;
     if (!no_wide && dtype == SV_BF16 && g->N % 160 == 0 && g->Cin >= 96) {
         // wide layers: 160 x 32 slabs, one block (one wave per SIMD) per CU.  Pick the split count and the affinity unit
-        // (a divisor of the chunk count) that minimise the modelled time, in units of one tile iteration of a block:
-        //   rounds-of-32-CUs-per-XCD x (tiles per block + publishing a 160 x 32 x 9 slab, ~3 tiles)
-        //   + the slab reduction (every split adds one slab read at ~4 TB/s; a tile iteration is ~3.5 us).
+        // (a divisor of the chunk count) that minimise the modelled time:
+        //   compute: rounds-of-32-CUs-per-XCD x (tiles per block + publishing a 160 x 32 x 9 slab, ~4 tiles) x 2.0 us
+        //   HBM    : dy is read once per affinity unit of chunks (the unit's blocks share an L2), x ~1.5 times (halo), the
+        //            slabs are written and read back; ~5 TB/s.  (Measured, 160-channel layer at B = 512: unit 1 = 1.27 GB
+        //            per launch, 5.7 TB/s -- the kernel was HBM-bound; the unit of 5 chunks reads dy once)
+        //   + the slab reduction after the kernel (every split adds one slab read at ~4 TB/s).
         // Splits whose slabs do not fit the caller's workspace would have to meet in dw through float atomics
         // (measured: 64 splits of the 320-channel layer = 59 M atomics, 393 us instead of ~300) and are only taken when
         // nothing fits.
         const int nC = g->Cin / 32, nNt = g->N / 160;
         const int64_t slab_elems = (int64_t)g->N * g->T_orig * g->Cin;
-        const double reduce_per_split = (double)slab_elems * 4.0 / (4.0e12 * 3.5e-6);
+        const double rows = (double)g->B * g->Hin * g->Win;
+        const double dy_bytes = rows * g->N * 2.0, x_bytes = rows * g->Cin * 2.0, slab_bytes = (double)slab_elems * 4.0;
         int splits = 1, unit = 0;
         double best = -1.0;
         for (int sp = 1; sp <= nT && sp <= 128; ++sp) {
@@ -888,8 +892,10 @@ int sv_wgrad3x3_try(const sv_geom* g, int dtype, const void* x, const float* pro
                 if (nC % u) continue;
                 const int units = sp * nNt * (nC / u);
                 const int per_xcd = (units + 7) / 8 * u;
-                double cost = (double)((per_xcd + 31) / 32) * (tp + 3.0) + (sp > 1 ? reduce_per_split * sp : 0.0) - 1e-3 * u;
-                if (!fits) cost = 1e6 + cost;
+                const double t_mma = (double)((per_xcd + 31) / 32) * (tp + 4.0) * 2.0e-6;
+                const double t_hbm = (dy_bytes * (nC / u) + 1.5 * x_bytes * nNt + (sp > 1 ? 2.0 * sp * slab_bytes : 0.0)) / 5.0e12;
+                double cost = (t_mma > t_hbm ? t_mma : t_hbm) + (sp > 1 ? sp * slab_bytes / 4.0e12 : 0.0) - 1e-9 * u;
+                if (!fits) cost += 1.0;
                 if (best < 0 || cost < best) { best = cost; splits = sp; unit = u; }
             }
         }
