@@ -206,6 +206,14 @@ int sv_prof_enable(int on);
 int sv_prof_tag(int tag);
 int sv_prof_collect(int max_tags, double* ms, int* count);
 
+/* ---- introspection (host only, no GPU): the compile-time "tile program" of the wide weight-gradient kernel.
+ * halo_vectors = 3 or 4 (halo 16-byte vectors per thread; 4 for 32 x 32 maps).  items = int[180][3]: for the gap behind
+ * every MFMA of one tile iteration (4 phases x 45) up to three item codes, 0 = none, 1000 + 41*vector + step = one
+ * single-instruction step of the halo transform (step 40 = its LDS store), 2000 + k = dy DMA instruction k,
+ * 3000 + v = global load of halo vector v, 4000 + v = the vmcnt wait before vector v's first step.
+ * waits = int[5]: the vmcnt of those waits (vector 0..3) and of the wait before the barrier.          */
+int sv_debug_wgrad_tile_program(int halo_vectors, int* items, int* waits);
+
 int sv_version(void);
 const char* sv_last_error(void);
 

@@ -344,7 +344,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3w_kernel(const sv_geom g, const
             if (h_fly) wait_vm<HI + 1>(); else wait_vm<0>();
         }
         wait_lds();
+#ifndef SV_W3_NO_BAR       // (timing ablation: races)
         barrier();
+#endif
     };
     auto chunk = [&](int c, auto parc) __attribute__((always_inline)) {
         step(c, std::integral_constant<int, 0>{}, parc);
@@ -511,7 +513,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3w_kernel(const sv_geom g, const
             float* d = a.stats + 8 * blockIdx.x;
             d[0] = (float)(st1 - st0); d[1] = (float)(st2 - st1); d[2] = (float)(st3 - st2);
             d[3] = (float)(rt0 & 0xffffff); d[4] = (float)(__builtin_amdgcn_s_memrealtime() & 0xffffff);
-            d[5] = (float)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));    // HW_ID
+            d[5] = (float)(__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) & 0xffff);    // HW_ID: cu 11:8, sh 12, se 15:13
+            d[6] = (float)(__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 0xf);        // XCC_ID
         }
         return;
     }
@@ -534,7 +537,8 @@ int launch_w3(const sv_geom* g, const sv_igemm_args* a, hipStream_t s) {
     using C = WCfg<NF, WLOG>;
     const int nT = g->B * g->Hin / C::TR, nNt = g->N / C::BN;
     const int grid = 8 * ((nT + 7) / 8) * nNt;
-    const size_t lds = (size_t)C::LDS;
+    static const bool one_per_cu = getenv("SV_W3_ONE_BLOCK") != nullptr;      // A/B: does the second block of a CU pay?
+    const size_t lds = one_per_cu ? (size_t)100 * 1024 : (size_t)C::LDS;
     static bool optin = false;
     if (!optin) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3w_kernel<NF, WLOG, REV>),

@@ -934,3 +934,18 @@ int sv_wgrad3x3_try(const sv_geom* g, int dtype, const void* x, const float* pro
     }
     return 1;
 }
+
+extern "C" int sv_debug_wgrad_tile_program(int halo_vectors, int* items, int* waits) {
+    SV_REQUIRE(items && waits, SV_E_ARG, "sv_debug_wgrad_tile_program: null argument");
+    SV_REQUIRE(halo_vectors == 3 || halo_vectors == 4, SV_E_ARG, "sv_debug_wgrad_tile_program: halo_vectors=%d", halo_vectors);
+    auto copy = [&](const auto& S) {
+        for (int i = 0; i < 180; ++i)
+            for (int j = 0; j < 3; ++j) items[3 * i + j] = S.item[i][j];
+        for (int v = 0; v < 4; ++v) waits[v] = S.vm_wait[v];
+        waits[4] = S.vm_barrier;
+        return S.ok ? SV_OK : SV_E_SHAPE;
+    };
+    static constexpr WSched<3> S3 = make_wsched<3>();
+    static constexpr WSched<4> S4 = make_wsched<4>();
+    return halo_vectors == 3 ? copy(S3) : copy(S4);
+}

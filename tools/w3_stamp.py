@@ -31,9 +31,23 @@ for lo in range(0, int(end.max().item()) + 1, 25):
     act = ((start <= lo) & (end > lo)).sum().item()
     print("t=%4d us: %4d blocks running, %4d started so far" % (lo, act, (start <= lo).sum().item()))
 hw = t[:, 5].long()
-cu = (hw >> 8) & 0xf; sh = (hw >> 12) & 1; se = (hw >> 13) & 0x7; xcc = (hw >> 20) & 0xf
+cu = (hw >> 8) & 0xf; sh = (hw >> 12) & 1; se = (hw >> 13) & 0x7; xcc = t[:, 6].long()
 key = ((xcc * 8 + se) * 2 + sh) * 16 + cu
 first = key[start < 5.0]
 import collections
 c = collections.Counter(first.tolist())
 print("first-wave blocks:", len(first), "distinct CUs:", len(c), "blocks per CU histogram:", collections.Counter(c.values()))
+# lockstep check: for every block, the start-time distance to the nearest OTHER block of the same CU that overlaps it
+import numpy as np
+keys = key.numpy(); s_ = start.numpy(); e_ = end.numpy()
+dist = []
+for k in np.unique(keys):
+    idx = np.where(keys == k)[0]
+    for i in idx:
+        others = [j for j in idx if j != i and s_[j] < e_[i] and e_[j] > s_[i]]
+        if others:
+            dist.append(min(abs(s_[j] - s_[i]) for j in others))
+dist = np.array(dist)
+dm = dur.mean().item()
+print("co-resident blocks: start-time distance to the partner, as a fraction of the block duration (0 = lockstep, 0.5 = ideal stagger):")
+print("  quantiles 10/25/50/75/90 %%: %s   (block duration %.1f us)" % (np.round(np.quantile(dist / dm, [0.1, 0.25, 0.5, 0.75, 0.9]), 2).tolist(), dm))
