@@ -27,6 +27,10 @@
 
 #include "common.h"
 
+#ifndef SV_W3_EPD
+#define SV_W3_EPD 1
+#endif
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -402,11 +406,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3w_kernel(const sv_geom g, const
         __syncthreads();
     }
     const bf16* const esrc = R ? R : EX;
-    bf16x8 eopn[4];
+    // EPD groups of residual / raw-tensor rows in flight: one group of work (~1.2 k cycles) does not cover an HBM round trip
+    constexpr int EPD = SV_W3_EPD;
+    bf16x8 eopn[EPD][4];
     if (esrc) {
 #pragma unroll
-        for (int it = 0; it < 4; ++it)
-            eopn[it] = *reinterpret_cast<const bf16x8*>(esrc + (gp0 + 16 * it + ipix) * g.ldo + n0 + 8 * cg);
+        for (int d = 0; d < EPD; ++d)
+            if (d < NF) {
+#pragma unroll
+                for (int it = 0; it < 4; ++it)
+                    eopn[d][it] = *reinterpret_cast<const bf16x8*>(esrc + (gp0 + 16 * it + ipix) * g.ldo + n0 + 8 * cg + 32 * d);
+            }
     }
 #pragma unroll
     for (int i = 0; i < NF; ++i) {
@@ -436,11 +446,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3w_kernel(const sv_geom g, const
         for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
         bf16x8 eop[4];
 #pragma unroll
-        for (int it = 0; it < 4; ++it) eop[it] = eopn[it];
-        if (esrc && i + 1 < NF) {
+        for (int it = 0; it < 4; ++it) eop[it] = eopn[i % EPD][it];
+        if (esrc && i + EPD < NF) {
 #pragma unroll
             for (int it = 0; it < 4; ++it)
-                eopn[it] = *reinterpret_cast<const bf16x8*>(esrc + (gp0 + 16 * it + ipix) * g.ldo + n + 32);
+                eopn[i % EPD][it] = *reinterpret_cast<const bf16x8*>(esrc + (gp0 + 16 * it + ipix) * g.ldo + n + 32 * EPD);
         }
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
