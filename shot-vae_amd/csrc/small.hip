@@ -371,11 +371,14 @@ __global__ __launch_bounds__(256) void head_bwd_data_kernel(int B, int C, const 
         for (int k = lane; k < K; k += 64) dz[k] = g[k] - expf(l[k]) * sg;
     }
     __syncthreads();
-    for (int i = tid; i < HS * NH; i += 256) {
-        const int s = i / NH;
-        if (b0 + s < B) dout[(int64_t)(b0 + s) * NH + (i - s * NH)] = d[i];
+    if (blockIdx.y == 0) {
+        for (int i = tid; i < HS * NH; i += 256) {
+            const int s = i / NH;
+            if (b0 + s < B) dout[(int64_t)(b0 + s) * NH + (i - s * NH)] = d[i];
+        }
     }
-    for (int c = tid; c < C; c += 256) {
+    // blockIdx.y = 256-channel slice of the features (wide encoders: 640 channels, K = 100 -> three times the blocks)
+    for (int c = blockIdx.y * 256 + tid; c < C; c += 256 * gridDim.y) {
         float acc[HS];
 #pragma unroll
         for (int s = 0; s < HS; ++s) acc[s] = 0.f;
@@ -885,7 +888,7 @@ int sv_head_bwd(const float* feat, int B, int C, const float* W, int ldc, int K,
     SV_REQUIRE(feat && W && la && dmu && dls && dla && dfeat && dW && dbias && dout_ws, SV_E_ARG, "sv_head_bwd: null");
     const int NH = 2 * ldc + K;
     const size_t lds = (size_t)HS * NH * sizeof(float);
-    hipLaunchKernelGGL(head_bwd_data_kernel, dim3((B + HS - 1) / HS), dim3(256), lds, (hipStream_t)stream, B, C, W,
+    hipLaunchKernelGGL(head_bwd_data_kernel, dim3((B + HS - 1) / HS, (C + 255) / 256), dim3(256), lds, (hipStream_t)stream, B, C, W,
                        ldc, K, la, dmu, dls, dla, dfeat, dout_ws);
     hipLaunchKernelGGL(head_bwd_weight_kernel, dim3(NH, B >= 64 ? 8 : 1), dim3(256), 0, (hipStream_t)stream, feat,
                        dout_ws, B, C, NH, dW, dbias);

@@ -768,6 +768,7 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3w_kernel(const sv_geom g, cons
 // dw[i] += sum_s ws[s][i].  A block owns 256/G float4 columns; its G thread groups each sum every G-th slab, meet in
 // LDS, and ONE float atomic per output leaves the block (many small slabs -- 512 x 36 KB for the 32-channel stage --
 // used to meet in dw through 32 atomics per output, which cost more than reading the slabs).
+template <bool ATOMIC>
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* ws, int splits, int64_t n, float* dw, int G) {
     __shared__ f32x4 part[256];
     const int cols = 256 / G, col = threadIdx.x % cols, grp = threadIdx.x / cols;
@@ -794,8 +795,14 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* ws, int s
     }
     // always atomic: the backward of the other branch of the step may be adding to dw concurrently
     if (grp == 0 && i < n) {
+        if (ATOMIC) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) atomicAdd(dw + i + r, s[r]);
+            for (int r = 0; r < 4; ++r) atomicAdd(dw + i + r, s[r]);
+        } else {          // (timing ablation SV_SLAB_PLAIN: wrong when two streams accumulate concurrently)
+            f32x4 o = *reinterpret_cast<f32x4*>(dw + i);
+            o[0] += s[0]; o[1] += s[1]; o[2] += s[2]; o[3] += s[3];
+            *reinterpret_cast<f32x4*>(dw + i) = o;
+        }
     }
 }
 
@@ -804,7 +811,9 @@ static void launch_slab_reduce(const float* ws, int splits, int64_t n, float* dw
     while (G < 32 && G * 2 * 8 <= splits && (n / 4 + 256 / G - 1) / (256 / G) < 256) G *= 2;
     const int cols = 256 / G;
     const unsigned gx = (unsigned)((n / 4 + cols - 1) / cols);
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3(gx), dim3(256), 0, s, ws, splits, n, dw, G);
+    static const bool plain = getenv("SV_SLAB_PLAIN") != nullptr;
+    if (plain) hipLaunchKernelGGL(slab_reduce_kernel<false>, dim3(gx), dim3(256), 0, s, ws, splits, n, dw, G);
+    else hipLaunchKernelGGL(slab_reduce_kernel<true>, dim3(gx), dim3(256), 0, s, ws, splits, n, dw, G);
 }
 
 template <typename T, int WLOG>
