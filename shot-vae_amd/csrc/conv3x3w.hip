@@ -371,175 +371,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3w_kernel(const sv_geom g, const
 #ifdef SV_W3_STAMP
     const uint64_t st2 = __builtin_amdgcn_s_memtime();
 #endif
-    // ---- epilogue: per 32-channel group through a wave-private LDS transpose ------------------------------------------
-    // (every wave is past the last barrier: the halo and weight buffers are free)
-    float* const scr = reinterpret_cast<float*>(smem + wave * C::SCR);              // [64 pixels][36]
-    float* const red = reinterpret_cast<float*>(smem + 4 * C::SCR + wave * 4096);   // [4 groups][16 pixel rows][16 sums]
-    static_assert(4 * C::SCR + 4 * 4096 <= C::OFF_SSUM, "epilogue scratch");
-    bf16* const O = reinterpret_cast<bf16*>(a.out);
-    const bf16* const R = reinterpret_cast<const bf16*>(a.residual);
-    const bf16* const EX = reinterpret_cast<const bf16*>(a.ex);
-    const bool want_stats = a.stats != nullptr && EX == nullptr;
-    const bool has_bias = a.bias != nullptr;
-    const int ipix = lane >> 2, cg = lane & 3;
-    const int64_t gp0 = (int64_t)gr0 * W + 64 * wave;
-#ifdef SV_W3_NO_EPI
-    if (acc[0][0][0] != 1234.5f) return;
-#endif
-    // residual / raw-tensor operand of the epilogue: the rows of group i+1 are requested while group i is processed
-    // (one exposed HBM round trip per block instead of one per 32-channel group)
-    // per-channel constants of the block's channels: one cooperative copy into LDS instead of a dependent global
-    // round trip per 32-channel group
-    float* const cst = reinterpret_cast<float*>(smem + 4 * C::SCR + 4 * 4096);      // [5][BN]
-    static_assert(4 * C::SCR + 4 * 4096 + 5 * BN * 4 <= C::OFF_SSUM, "epilogue scratch (halo, weight and coefficient buffers are free after the loop)");
-    if (has_bias || EX) {
-        for (int c = tid; c < BN; c += 256) {
-            if (has_bias) cst[c] = a.bias[n0 + c];
-            if (EX) {
-                const float rs = a.ex_rstd[n0 + c];
-                cst[BN + c] = a.ex_scale[n0 + c];
-                cst[2 * BN + c] = a.ex_shift[n0 + c];
-                cst[3 * BN + c] = -a.ex_mean[n0 + c] * rs;                         // xhat = x * rstd - mean * rstd
-                cst[4 * BN + c] = rs;
-            }
-        }
-        __syncthreads();
-    }
-    const bf16* const esrc = R ? R : EX;
-    // EPD groups of residual / raw-tensor rows in flight: one group of work (~1.2 k cycles) does not cover an HBM round trip
-    constexpr int EPD = SV_W3_EPD;
-    bf16x8 eopn[EPD][4];
-    if (esrc) {
-#pragma unroll
-        for (int d = 0; d < EPD; ++d)
-            if (d < NF) {
-#pragma unroll
-                for (int it = 0; it < 4; ++it)
-                    eopn[d][it] = *reinterpret_cast<const bf16x8*>(esrc + (gp0 + 16 * it + ipix) * g.ldo + n0 + 8 * cg + 32 * d);
-            }
-    }
-#pragma unroll
-    for (int i = 0; i < NF; ++i) {
-        const int nl = 32 * i + 8 * cg, n = n0 + nl;
-#pragma unroll
-        for (int f = 0; f < 2; ++f)
-#pragma unroll
-            for (int gq = 0; gq < 4; ++gq) {
-                const f32x4 v = {acc[f][i][4 * gq], acc[f][i][4 * gq + 1], acc[f][i][4 * gq + 2], acc[f][i][4 * gq + 3]};
-                *reinterpret_cast<f32x4*>(scr + (32 * f + r) * 36 + 8 * gq + 4 * h) = v;
-            }
-        float bias[8], esc[8], esh[8], ers[8], emr[8];
-        auto load8 = [&](const float* p, float (&d)[8]) {
-            const f32x4 lo = *reinterpret_cast<const f32x4*>(p + nl), hi = *reinterpret_cast<const f32x4*>(p + nl + 4);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { d[e] = lo[e]; d[e + 4] = hi[e]; }
-        };
-        if (has_bias) load8(cst, bias);
-        if (EX) {
-            load8(cst + BN, esc);
-            load8(cst + 2 * BN, esh);
-            load8(cst + 3 * BN, emr);
-            load8(cst + 4 * BN, ers);
-        }
-        float s1[8], s2[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
-        bf16x8 eop[4];
-#pragma unroll
-        for (int it = 0; it < 4; ++it) eop[it] = eopn[i % EPD][it];
-        if (esrc && i + EPD < NF) {
-#pragma unroll
-            for (int it = 0; it < 4; ++it)
-                eopn[i % EPD][it] = *reinterpret_cast<const bf16x8*>(esrc + (gp0 + 16 * it + ipix) * g.ldo + n + 32 * EPD);
-        }
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int pix = 16 * it + ipix;
-            const f32x4 v0 = *reinterpret_cast<const f32x4*>(scr + pix * 36 + 8 * cg);
-            const f32x4 v1 = *reinterpret_cast<const f32x4*>(scr + pix * 36 + 8 * cg + 4);
-            float vv[8];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                vv[e] = v0[e];
-                vv[e + 4] = v1[e];
-            }
-            if (has_bias) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) vv[e] += bias[e];
-            }
-            if (R) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) vv[e] += (float)eop[it][e];
-            }
-            if (EX) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float xf = (float)eop[it][e];
-                    const float gv = (xf * esc[e] + esh[e] > 0.f) ? vv[e] : vv[e] * a.ex_slope;
-                    vv[e] = gv;
-                    s1[e] += gv;
-                    s2[e] += gv * (xf * ers[e] + emr[e]);
-                }
-            } else if (want_stats) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    s1[e] += vv[e];
-                    s2[e] += vv[e] * vv[e];
-                }
-            }
-            bf16x8 o;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = (bf16)vv[e];
-#ifdef SV_W3_NO_STORE
-            if (vv[0] == 1234.5f)
-#endif
-            *reinterpret_cast<bf16x8*>(O + (gp0 + pix) * g.ldo + n) = o;
-        }
-#ifdef SV_W3_NO_RED
-        if (s1[0] == 1234.5f) {
-#else
-        if (want_stats || EX) {
-#endif
-            // 16 partial sums per lane, 16 lanes per channel group: through LDS -- lane (group cg', sum e') adds the 16
-            // pixel rows of its column (4 b128 stores + 16 b32 loads + 16 adds instead of 64 shuffles + 64 adds)
-            float* mine = red + (cg * 16 + ipix) * 16;
-#pragma unroll
-            for (int q4 = 0; q4 < 2; ++q4) {
-                *reinterpret_cast<f32x4*>(mine + 4 * q4) = f32x4{s1[4 * q4], s1[4 * q4 + 1], s1[4 * q4 + 2], s1[4 * q4 + 3]};
-                *reinterpret_cast<f32x4*>(mine + 8 + 4 * q4) = f32x4{s2[4 * q4], s2[4 * q4 + 1], s2[4 * q4 + 2], s2[4 * q4 + 3]};
-            }
-            const float* col = red + (lane >> 4) * 256 + (lane & 15);
-            float t = 0.f;
-#pragma unroll
-            for (int q = 0; q < 16; ++q) t += col[16 * q];
-            const int e2 = lane & 15;
-            atomicAdd(&ssum[(e2 >> 3) * BN + 32 * i + 8 * (lane >> 4) + (e2 & 7)], t);
-        }
-    }
-#ifdef SV_W3_STAMP
-    {   // diagnostic build: cycles of prologue / main loop / epilogue of the first 64 blocks instead of the statistics
-        const uint64_t st3 = __builtin_amdgcn_s_memtime();
-        if (tid == 0) {     // (the stats buffer of tools/w3_stamp.py is large enough for 8 floats per block)
-            float* d = a.stats + 8 * blockIdx.x;
-            d[0] = (float)(st1 - st0); d[1] = (float)(st2 - st1); d[2] = (float)(st3 - st2);
-            d[3] = (float)(rt0 & 0xffffff); d[4] = (float)(__builtin_amdgcn_s_memrealtime() & 0xffffff);
-            d[5] = (float)(__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) & 0xffff);    // HW_ID: cu 11:8, sh 12, se 15:13
-            d[6] = (float)(__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 0xf);        // XCC_ID
-        }
-        return;
-    }
-#endif
-#ifdef SV_W3_NO_GATOM
-    if (acc[0][0][0] != 1234.5f) return;
-#endif
-    if (want_stats || EX) {
-        __syncthreads();
-        float* dst = (EX ? a.bsums : a.stats) + (size_t)(blockIdx.x & (a.replicas - 1)) * 2 * g.N;
-        for (int i = tid; i < 2 * BN; i += 256) {
-            const int which = i / BN, nl = i - which * BN;
-            atomicAdd(dst + which * g.N + n0 + nl, ssum[i]);
-        }
-    }
+    constexpr int SV_EPD = SV_W3_EPD;
+#define SV_EPI_STAMP(k)
+#define SV_EPI_NSCR 1
+#include "conv3x3w_epilogue.inc"
+#undef SV_EPI_NSCR
+#undef SV_EPI_STAMP
 }
 
 template <int NF, int WLOG, bool REV>
@@ -617,6 +454,7 @@ int sv_conv3x3w_try(const sv_geom* g, int dtype, const sv_igemm_args* a, hipStre
         const int64_t d = (const char*)a->pro_shift - (const char*)a->pro_scale;
         if (d >= ((int64_t)1 << 31) || -d >= ((int64_t)1 << 31)) return 0;
     }
+    if (bn == 160 && sv_conv3x3x_try(g, a, fwd, s, rc)) return 1;      // one wave per SIMD, gap-scheduled (conv3x3x.hip)
     if (bn == 160) *rc = fwd ? launch_w2<5, false>(g, a, s) : launch_w2<5, true>(g, a, s);
     else if (bn == 128) *rc = fwd ? launch_w2<4, false>(g, a, s) : launch_w2<4, true>(g, a, s);
     else *rc = fwd ? launch_w2<2, false>(g, a, s) : launch_w2<2, true>(g, a, s);

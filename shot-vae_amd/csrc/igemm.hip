@@ -294,6 +294,11 @@ extern "C" int sv_igemm(const sv_geom* g, int dtype, const sv_igemm_args* a, voi
         if (c <= 2) break;
     }
     if (N % 80 == 0 && N % 64 != 0 && mtiles * (N / 80) >= 256 && dtype == SV_BF16) nt = 5;
+    {   // A/B: SV_IGEMM_NT=<8|4|2|1> forces the channel-tile width where it divides N; SV_IGEMM_MINBLK=<n> moves the
+        // block-count threshold of the choice above
+        static const int force = getenv("SV_IGEMM_NT") ? atoi(getenv("SV_IGEMM_NT")) : 0;
+        if (force && N % (16 * force) == 0 && !(dtype == SV_F32 && force > 2)) nt = force;
+    }
     if (dtype == SV_BF16) {
         switch (nt) {
             case 8: return launch<bf16, 8>(g, a, s);

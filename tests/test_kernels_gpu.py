@@ -197,6 +197,18 @@ def test_conv3x3_wide_mfma(case, monkeypatch):
     test_conv_dgrad_with_activation_backward("bf16", case)
 
 
+@pytest.mark.parametrize("case", [(4, 160, 160, 8, 3, 1, 1), (3, 160, 320, 32, 3, 1, 1), (4, 640, 640, 8, 3, 1, 1),
+                                  (2, 320, 160, 16, 3, 1, 1)])
+def test_conv3x3_one_wave_per_simd(case, monkeypatch):
+    """The gap-scheduled one-block-per-CU variant of the wide kernel (conv3x3x.hip, selected by SV_CONV3X3X=1): 160-channel
+    tiles, the three image sizes, odd / even chunk counts, one and several channel tiles; forward with every fusion
+    and the data gradient with the activation-backward epilogue."""
+    monkeypatch.setenv("SV_W3_MIN_BLOCKS", "1")
+    monkeypatch.setenv("SV_CONV3X3X", "1")
+    test_conv_forward_fused("bf16", case)
+    test_conv_dgrad_with_activation_backward("bf16", case)
+
+
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
 @pytest.mark.parametrize("H,Cin,N,B", [(1, 1024, 512, 6), (2, 512, 256, 4), (8, 128, 64, 3), (16, 64, 16, 2)])
 def test_convT_forward_and_dgrad(dt, H, Cin, N, B):

@@ -16,6 +16,8 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #define DSR(r) asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(r) : "v"(laddr));
 #define DSW() asm volatile("ds_write_b128 %0, %1" :: "v"(laddr), "v"(wv));
 #define NOP() asm volatile("s_nop 0");
+#define MFMA32(i) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(big[i]) : "v"(a), "v"(b));
+#define DSR128(r) asm volatile("ds_read_b128 %0, %1" : "=v"(r) : "v"(laddr));
 #define GLD(r) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(r) : "v"(goff), "s"(gsrc) : "memory");
 #define DMA() asm volatile("s_add_u32 m0, %0, 4096\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(lbase), "v"(goff), "s"(gsrc) : "memory", "scc");
 
@@ -24,6 +26,10 @@ __global__ __launch_bounds__(256, 1) void probe(float* out, uint32_t* cyc, int i
     __shared__ __attribute__((aligned(16))) char lds[16384];
     f32x4 acc[8];
     for (int i = 0; i < 8; ++i) acc[i] = f32x4{0, 0, 0, 0};
+    typedef float f32x16 __attribute__((ext_vector_type(16)));
+    f32x16 big[4];
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 16; ++j) big[i][j] = 0.f;
+    f32x4 q0 = {0, 0, 0, 0}, q1 = {0, 0, 0, 0};
     bf16x8 a, b;
     for (int j = 0; j < 8; ++j) { a[j] = (__bf16)(1.f + threadIdx.x); b[j] = (__bf16)0.5f; }
     float v0 = threadIdx.x, v1 = 1.f, v2 = 2.f, v3 = 3.f, c = 0.999f;
@@ -60,11 +66,24 @@ __global__ __launch_bounds__(256, 1) void probe(float* out, uint32_t* cyc, int i
         if (P == 16 && (i & 1) == 0) { GLD(g0) }                                            \
         if (P == 17 && (i & 1) == 0) { DMA() }                                              \
         if (P == 13) { VALU(v0) VALU(v1) VALU(v2) VALU(v3) VALU(v0) VALU(v1) VALU(v2) VALU(v3) }
-        G(0) G(1) G(2) G(3) G(4) G(5) G(6) G(7)
+        if (P < 20) { G(0) G(1) G(2) G(3) G(4) G(5) G(6) G(7) }
+#define H(i)                                                                                \
+        MFMA32(i)                                                                           \
+        if (P == 21) { VALU(v0) VALU(v1) }                                                  \
+        if (P == 22) { VALU(v0) VALU(v1) VALU(v2) VALU(v3) }                                \
+        if (P == 23) { VALU(v0) VALU(v1) VALU(v2) VALU(v3) VALU(v0) VALU(v1) }              \
+        if (P == 24) { VALU(v0) VALU(v1) VALU(v2) VALU(v3) VALU(v0) VALU(v1) VALU(v2) VALU(v3) } \
+        if (P == 25) { DSR128(q0) }                                                         \
+        if (P == 26) { DSR128(q0) DSR128(q1) }                                              \
+        if (P == 27) { DSR128(q0) VALU(v0) VALU(v1) }                                       \
+        if (P == 28) { DSR128(q0) VALU(v0) VALU(v1) VALU(v2) VALU(v3) }                     \
+        if (P == 29 && (i & 1) == 0) { DMA() }                                              \
+        if (P == 30) { DMA() }
+        if (P >= 20) { H(0) H(1) H(2) H(3) H(0) H(1) H(2) H(3) }
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15" : "+v"(g0), "+v"(g1) :: "memory");
     const uint64_t t1 = __builtin_amdgcn_s_memtime();
-    float s = g0[0] + g1[1] + v0 + v1 + v2 + v3 + p0[0] + p1[1] + (float)s0 + (float)s1 + (float)d0[0] + (float)d1[1];
+    float s = q0[0] + q1[1] + big[0][0] + big[1][1] + big[2][2] + big[3][3] + g0[0] + g1[1] + v0 + v1 + v2 + v3 + p0[0] + p1[1] + (float)s0 + (float)s1 + (float)d0[0] + (float)d1[1];
     for (int i = 0; i < 8; ++i) s += acc[i][0];
     out[blockIdx.x * 256 + threadIdx.x] = s;
     if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 4 + (threadIdx.x >> 6)] = (uint32_t)(t1 - t0);
@@ -108,5 +127,17 @@ int main() {
     run<15>("MFMA, every 4th + LDS-DMA (3 instr)", out, cyc);
     run<16>("MFMA, every 2nd + global_load_dwordx4", out, cyc);
     run<17>("MFMA, every 2nd + LDS-DMA (3 instr)", out, cyc);
+    printf("-- v_mfma_f32_32x32x16_bf16 (32 cycles of matrix pipe), per MFMA:\n");
+    run<20>("MFMA32 only", out, cyc);
+    run<21>("MFMA32 + 2 VALU", out, cyc);
+    run<22>("MFMA32 + 4 VALU", out, cyc);
+    run<23>("MFMA32 + 6 VALU", out, cyc);
+    run<24>("MFMA32 + 8 VALU", out, cyc);
+    run<25>("MFMA32 + 1 ds_read_b128", out, cyc);
+    run<26>("MFMA32 + 2 ds_read_b128", out, cyc);
+    run<27>("MFMA32 + 1 ds_read_b128 + 2 VALU", out, cyc);
+    run<28>("MFMA32 + 1 ds_read_b128 + 4 VALU", out, cyc);
+    run<29>("MFMA32, every 2nd + LDS-DMA (3 instr)", out, cyc);
+    run<30>("MFMA32 + LDS-DMA (3 instr)", out, cyc);
     return 0;
 }

@@ -1,0 +1,37 @@
+#!/bin/bash
+# Diagnostic build of conv3x3x.hip with per-block stamps: prologue / K loop / epilogue / (wait + barrier) cycles.
+cd "$(dirname "$0")/../shot-vae_amd/csrc" || exit 1
+FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -munsafe-fp-atomics -I../../include -Wno-unused-function $SV_EXTRA_FLAGS"
+/opt/rocm/bin/hipcc $FLAGS -DSV_X3_STAMP -c conv3x3x.hip -o conv3x3x.o 2>/dev/null && /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC igemm.o conv3x3.o conv3x3w.o conv3x3x.o wgrad.o wgrad3x3.o small.o runtime.o -o ../libshotvae_hip.so
+cd ../.. && for s in "512 160 32 160" "512 640 8 640"; do SV_CONV3X3X=1 python - $s <<'PY'
+import ctypes as C, sys, torch
+sys.path.insert(0, ".")
+from shot_vae_amd import _lib as L, geometry as G
+B, Cin, H, N = map(int, sys.argv[1:5])
+d = torch.device("cuda:0"); st = C.c_void_p(torch.cuda.current_stream().cuda_stream); bf = torch.bfloat16
+x = torch.randn(B, H, H, Cin, device=d).to(bf)
+master = (torch.randn(N, 9, Cin, device=d) / (9 * Cin) ** 0.5).contiguous()
+g = G.conv_like(B, H, H, Cin, N, 3, 1, 1)
+wp = torch.zeros(G.packed_size(g), dtype=bf, device=d)
+L.call("sv_repack", L.SV_BF16, C.c_void_p(master.data_ptr()), N, 9, Cin, 0, C.byref(g), C.c_void_p(wp.data_ptr()), st)
+out = torch.empty(B, H, H, N, dtype=bf, device=d); resid = torch.randn(B, H, H, N, device=d).to(bf)
+sc, sh = torch.rand(Cin, device=d) + 0.5, torch.randn(Cin, device=d) * 0.3
+stats = torch.zeros(8 * 4096 + 8 * 2 * N, device=d)
+a = L.SvIgemmArgs()
+a.x, a.w, a.out, a.residual = x.data_ptr(), wp.data_ptr(), out.data_ptr(), resid.data_ptr()
+a.pro_scale, a.pro_shift, a.pro_slope = sc.data_ptr(), sh.data_ptr(), 0.01
+a.stats, a.replicas = stats.data_ptr(), 8
+for _ in range(3):
+    L.call("sv_igemm", C.byref(g), L.SV_BF16, C.byref(a), st)
+torch.cuda.synchronize()
+TR = 256 // H
+nb = min(2048, 8 * ((B * H // TR + 7) // 8) * (N // 160))
+t = stats[16 * N:16 * N + 8 * nb].view(nb, 8).cpu().double()
+t = t[t[:, 1] > 0]
+m = t.mean(0)
+steps = 9 * Cin // 32
+print("Cin %d: blocks %d; cycles per block: prologue %.0f  K loop %.0f (%.0f per tap of 20 MFMAs; MFMA-only stream: 660)  of which wait+barrier %.0f  epilogue %.0f" % (
+    Cin, len(t), m[0], m[1], m[1] / steps, m[3], m[2]))
+print("   epilogue: setup + residual requests %.0f  group 0 %.0f  groups 1..4 %.0f  final sums %.0f" % (m[4], m[5], m[6], m[7]))
+PY
+done
