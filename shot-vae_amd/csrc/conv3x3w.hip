@@ -374,8 +374,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3w_kernel(const sv_geom g, const
     constexpr int SV_EPD = SV_W3_EPD;
 #define SV_EPI_STAMP(k)
 #define SV_EPI_NSCR 1
+#define SV_EPI_BASE 0
+#define SV_EPI_ALIAS 0
 #include "conv3x3w_epilogue.inc"
 #undef SV_EPI_NSCR
+#undef SV_EPI_BASE
+#undef SV_EPI_ALIAS
 #undef SV_EPI_STAMP
 }
 

@@ -12,10 +12,13 @@
 //     re-loaded right after its last MFMA of this tap), the BatchNorm + LeakyReLU pass over the next 32-channel chunk's
 //     halo as single-instruction micro-steps (global -> registers -> LDS; the registers are re-loaded a whole chunk
 //     ahead), the weight DMA.  The placement is a compile-time program (make_xsched) with hand-counted vmcnt waits;
-//   * LDS (1 block per CU): two halo stages (21.7 KB) + a NINE-slot weight ring, slot = tap (92 KB): every LDS address
-//     is a lane base + an immediate, and three barriers per chunk (after taps 1, 4, 7) are all the synchronisation:
-//     the slice of (chunk + 1, tap t) is copied as soon as the barrier after tap t's fragment reads has passed;
-//   * the epilogue is conv3x3w's (conv3x3w_epilogue.inc).
+//   * LDS (1 block per CU): two halo stages (21.7 KB) + a six-slot weight ring (slot = K step mod 6; 61 KB) + the epilogue's
+//     scratch apart from both (40 KB); every LDS address is a lane base + an immediate, and three barriers per chunk
+//     (after taps 1, 4, 7) are all the synchronisation: the slices of steps 3m+6..3m+8 are copied in steps 3m+2..3m+3 and
+//     awaited at the barrier after step 3m+4;
+//   * PERSISTENT blocks: one per CU, each walks its (pixel tile, channel tile) items; the K loop runs on across items --
+//     the first chunk of the next item is staged under the last chunk of this one -- so only the epilogue (conv3x3w's,
+//     conv3x3w_epilogue.inc) stands between two items; no per-item prologue.
 // Same fused prologue / epilogue contract as sv_igemm (include/shotvae_hip.h); replaces
 // shot_vae_model/wideresnet.py:13-43 (Conv2d 3x3 + BatchNorm2d + LeakyReLU + residual) for the wide layers.
 #include <hip/hip_runtime.h>
@@ -27,7 +30,7 @@
 #include "common.h"
 
 #ifndef SV_X3_EPD
-#define SV_X3_EPD 5        // residual rows of all five 32-channel groups requested up front (512 registers: 80 are spare)
+#define SV_X3_EPD 1
 #endif
 
 namespace {
@@ -48,8 +51,7 @@ __device__ __forceinline__ void static_for(F&& f) {
 // gap g = 20 * tap + m follows MFMA m of the tap (m = 10 ks + 2 i + f).  Fragment reads of the next tap are fixed:
 // weights (ks, i) in gap 10 ks + 2 i + 1, pixels (ks, f) in gap 10 ks + 8 + f.  Everything else is an item:
 //   1000 + 41 slot + step : one instruction of the BatchNorm pass over halo vector `slot` (step 40 = its LDS store)
-//   2000 + 3 s + i        : DMA instruction i of weight slice s: s < 6 -> (next chunk, tap s);  s = 6 -> (next chunk, 6);
-//                           s = 7, 8 -> (THIS chunk, tap s), issued in taps 0, 1
+//   2000 + 3 s + i        : DMA instruction i of weight slice s (see make_xsched: four of this chunk, five of the next)
 //   3000 + slot           : global load of halo vector `slot` of the chunk after next
 //   3500 + q              : global load q of the BatchNorm coefficients of the chunk after next
 //   4000 + slot / 4500    : the vmcnt wait before the slot's / the coefficients' first use
@@ -72,12 +74,20 @@ constexpr XSched make_xsched() {
         return false;
     };
     bool ok = true;
-    // weight DMA: one slice per tap, its three instructions in the read-free gaps 0, 2, 4
-    for (int t = 0; t < 9; ++t) {
-        const int s = t == 0 ? 7 : t == 1 ? 8 : t - 2;
-        for (int i = 0; i < 3; ++i) { ok = put(20 * t + 2 * i, 2000 + 3 * s + i) && ok; used[20 * t + 2 * i] = 1; }
+    // weight DMA (six ring slots): slice codes 2000 + 3 s + i, s = 0..8 meaning
+    //   s = 0: (this chunk, tap 5) in tap 0;  s = 1, 2: (this, 6), (this, 7) in tap 2;  s = 3: (this, 8) in tap 3;
+    //   s = 4, 5: (next, 0), (next, 1) in tap 5;  s = 6: (next, 2) in tap 6;  s = 7, 8: (next, 3), (next, 4) in tap 8
+    // -- each early in the three-step window its slot's previous fragments allow, in the read-free gaps 0, 2, 4 (10, 12, 14)
+    {
+        const int tap_of[9] = {0, 2, 2, 3, 5, 5, 6, 8, 8}, first_gap[9] = {0, 0, 10, 0, 0, 10, 0, 0, 10};
+        for (int sl = 0; sl < 9; ++sl)
+            for (int i = 0; i < 3; ++i) {
+                const int gp = 20 * tap_of[sl] + first_gap[sl] + 2 * i;
+                ok = put(gp, 2000 + 3 * sl + i) && ok;
+                used[gp] = 1;
+            }
     }
-    ok = put(20 * 8 + 6, 5000) && ok;
+    ok = put(20 * 8 + 0, 5000) && ok;          // before the first fragment read of tap 8 (gap 1)
     // the BatchNorm pass starts with tap 1 (the coefficients were requested at the end of the previous chunk's pass):
     // two or three steps per gap next to fragment reads, four otherwise; a halo register is re-loaded in the first read-free,
     // VMEM-free gap after its vector's store, the coefficients after the last vector
@@ -136,12 +146,12 @@ constexpr XSched make_xsched() {
     auto index_of = [&](int code) { for (int i = 0; i < nv; ++i) if (order[i] == code) return i; return -1; };
     for (int sl = 0; sl < X_HI; ++sl) S.vm_slot[sl] = since(index_of(3000 + sl), find_item(4000 + sl), true);
     S.vm_coef = since(index_of(3503), find_item(4500), true);
-    // barrier after tap 1: slices 3..5 of this chunk (issued in taps 5..7 of the previous one) must have landed
-    S.vm_b1 = since(index_of(2000 + 3 * 5 + 2), 40 * 8, true);
-    // barrier after tap 4: slices 6 (previous chunk's tap 8) and 7, 8 (taps 0, 1)
-    S.vm_b4 = since(index_of(2000 + 3 * 8 + 2), 100 * 8, false);
-    // barrier after tap 7: slices 0..2 of the next chunk (taps 2..4)
-    S.vm_b7 = since(index_of(2000 + 3 * 2 + 2), 160 * 8, false);
+    // barrier after tap 1: (this, 3), (this, 4) from the previous chunk's tap 8 and (this, 5) from tap 0 have landed
+    S.vm_b1 = since(index_of(2000 + 3 * 0 + 2), 40 * 8, false);
+    // barrier after tap 4: (this, 6..8) from taps 2, 3
+    S.vm_b4 = since(index_of(2000 + 3 * 3 + 2), 100 * 8, false);
+    // barrier after tap 7: (next, 0..2) from taps 5, 6
+    S.vm_b7 = since(index_of(2000 + 3 * 6 + 2), 160 * 8, false);
     return S;
 }
 
@@ -154,9 +164,10 @@ struct XCfg {
     static constexpr int HS = 4 * HPIX;                     // 16-byte vectors of one halo stage (64 B per pixel)
     static constexpr int HB = HS * 16 + 1024;               // bytes per halo stage (+ a dummy KB for the unused slots)
     static constexpr int SWS = WLOG == 5 ? 2 : 1;           // pixel swizzle: k-quarter ^= (halo column >> SWS) & 3
-    static constexpr int WS = 4 * BN, WI = 3, WBUF = WS * 16;
-    static constexpr int OFF_W = 2 * HB, OFF_SSUM = OFF_W + 9 * WBUF, LDS = OFF_SSUM + 2 * BN * 4;
+    static constexpr int WS = 4 * BN, WI = 3, WBUF = WS * 16, NSLOT = 6;
     static constexpr int SCR = 64 * 36 * 4;                 // epilogue transpose scratch per wave
+    static constexpr int OFF_W = 2 * HB, OFF_SCR = OFF_W + NSLOT * WBUF;
+    static constexpr int OFF_SSUM = OFF_SCR + 4 * SCR + 5 * BN * 4, LDS = OFF_SSUM + 2 * BN * 4;
     static_assert((HS + 255) / 256 == X_HI, "six halo vectors per thread");
     static_assert(LDS <= 160 * 1024, "one block per CU");
 };
@@ -176,61 +187,86 @@ __global__ __launch_bounds__(256, 1) void conv3x3x_kernel(const sv_geom g, const
     const int H = g.Hin, BH = g.B * H, nT = BH / TR, nNt = g.N / BN;
     const int Cin = g.Cin, nck = Cin / 32;
 
-    // XCD-affine mapping (as conv3x3w): the 32 CUs of an XCD work on consecutive pixel tiles
+    // ---- work items of this block.  XCD-affine: the 32-odd blocks of an XCD share a contiguous range of pixel tiles (one
+    //      copy of the weights and of the halo rows in that XCD's L2); item k = (pixel tile, channel tile) number
+    //      slot + k * blocks-per-XCD of the range
     const int per = (nT + 7) >> 3;
-    const int xcd = blockIdx.x & 7, slot_id = blockIdx.x >> 3;
-    const int in_i = slot_id % nNt, mt = xcd * per + slot_id / nNt;
-    if (mt >= nT) return;
-    const int n0 = in_i * BN, gr0 = mt * TR;
+    const int xcd = blockIdx.x & 7, slot_id = blockIdx.x >> 3, nbx = gridDim.x >> 3;
+    const int mt_lo = xcd * per, mt_hi = min(mt_lo + per, nT);
+    const int n_items_xcd = max(mt_hi - mt_lo, 0) * nNt;
+    const int cnt = slot_id < n_items_xcd ? (n_items_xcd - slot_id + nbx - 1) / nbx : 0;
+    if (cnt == 0) return;
 
     const sv_phase& P = g.phase[0];
     const char* const Xb = reinterpret_cast<const char*>(a.x);
-    const char* const Wb = reinterpret_cast<const char*>(reinterpret_cast<const bf16*>(a.w) + P.w_off + (int64_t)n0 * 9 * Cin);
+    const char* const Wp = reinterpret_cast<const char*>(reinterpret_cast<const bf16*>(a.w) + P.w_off);
     const bool has_pro = a.pro_scale != nullptr;
     const float slope = has_pro ? a.pro_slope : 1.f;
     const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_ptr)smem;
 
-#ifdef SV_X3_STAGGER       // experiment: desynchronise the CUs (first-round blocks start SV_X3_STAGGER cycles apart, 4 phases)
-    if (blockIdx.x < 256) {
-        const uint64_t until = __builtin_amdgcn_s_memtime() + (uint64_t)((blockIdx.x >> 3) & 3) * SV_X3_STAGGER;
-        while (__builtin_amdgcn_s_memtime() < until) __builtin_amdgcn_s_sleep(8);
-    }
-#endif
-    for (int c = tid; c < 2 * BN; c += 256) ssum[c] = 0.f;
+    // ---- a K-loop position: (item, chunk) and what staging needs to know about it -------------------------------------------
+    struct Pos {
+        int it, c;                 // item number of this block, 32-channel chunk
+        int gr0, n0;               // first image row of the pixel tile, first output channel
+        const char* xrow;          // x at (row gr0 - 1, column 0, channel 32 c)
+        const char* wsl;           // packed weights of (channel tile, tap 0, channel 32 c)
+        bool top_ok, bot_ok;       // the rows above / below the tile belong to the same image
+    };
+    auto make_pos = [&](int it, int c) {
+        Pos p;
+        p.it = it; p.c = c;
+        const int idx = slot_id + it * nbx;
+        p.gr0 = (mt_lo + idx / nNt) * TR;
+        p.n0 = (idx % nNt) * BN;
+        p.xrow = Xb + ((int64_t)(p.gr0 - 1) * W * g.ldx + 32 * c) * 2;
+        p.wsl = Wp + ((int64_t)p.n0 * 9 * Cin + 32 * c) * 2;
+        p.top_ok = (p.gr0 & (H - 1)) != 0;
+        p.bot_ok = ((p.gr0 + TR) & (H - 1)) != 0;
+        return p;
+    };
+    auto next_pos = [&](const Pos& p) {              // past the last position: itself (a harmless re-staging)
+        if (p.c + 1 < nck) {                         // same item: the next 32 channels (no divisions in the chunk loop)
+            Pos q = p;
+            q.c = p.c + 1;
+            q.xrow = p.xrow + 64;
+            q.wsl = p.wsl + 64;
+            return q;
+        }
+        if (p.it + 1 < cnt) return make_pos(p.it + 1, 0);
+        return p;
+    };
+
 #ifdef SV_X3_STAMP
     const uint64_t st0 = __builtin_amdgcn_s_memtime();
 #endif
 
     // ---- halo vectors of this thread: vector s = 256 j + tid = (halo pixel s >> 2, logical 8-channel quarter tid & 3),
-    //      stored at the swizzled quarter; kind: 0 zero (padding column / spacer / dummy), 1..3 image rows -----------------
+    //      stored at the swizzled quarter; kind: 0 zero (padding column / spacer / dummy), 1 row of the tile, 2 the row
+    //      above, 3 the row below.  Offsets are unsigned byte counts from (row gr0 - 1): tile-invariant ----------------------
     const int lq = tid & 3;
-    uint32_t hoff[HI];          // byte offset into x of channel chunk 0
-    int hlds[HI];               // byte offset inside a halo stage
-    bool hok[HI];
-    {
-        const bool top_ok = (gr0 & (H - 1)) != 0, bot_ok = ((gr0 + TR) & (H - 1)) != 0;
+    uint32_t hoff[HI];
+    int hlds[HI], hkind[HI];
 #pragma unroll
-        for (int j = 0; j < HI; ++j) {
-            const int s = 256 * j + tid, pix = min(s, HS - 1) >> 2;
-            const int lr = pix / WP, xx = pix - lr * WP;
-            const int seg = lr / (HH + 1), off = lr - seg * (HH + 1);
-            int kind = 1, rel = lr - 1 - seg;
-            if (off == 0) {
-                if (SEG == 1) { kind = seg == 0 ? 2 : 3; rel = seg == 0 ? -1 : TR; }
-                else kind = 0;
-            }
-            if (xx == 0 || xx == WP - 1) kind = 0;
-            if (s >= HS) kind = 0;
-            hok[j] = (kind == 1) | ((kind == 2) & top_ok) | ((kind == 3) & bot_ok);
-            const int grc = min(max(gr0 + rel, 0), BH - 1), xc = min(max(xx - 1, 0), W - 1);
-            hoff[j] = hok[j] ? (uint32_t)((grc * W + xc) * g.ldx + 8 * lq) * 2u : (uint32_t)(gr0 * W * g.ldx + 8 * lq) * 2u;
-            hlds[j] = s < HS ? pix * 64 + 16 * (lq ^ ((xx >> SWS) & 3)) : HS * 16 + 16 * (tid & 63);
+    for (int j = 0; j < HI; ++j) {
+        const int s = 256 * j + tid, pix = min(s, HS - 1) >> 2;
+        const int lr = pix / WP, xx = pix - lr * WP;
+        const int seg = lr / (HH + 1), off = lr - seg * (HH + 1);
+        int kind = 1, rel = lr - 1 - seg;
+        if (off == 0) {
+            if (SEG == 1) { kind = seg == 0 ? 2 : 3; rel = seg == 0 ? -1 : TR; }
+            else kind = 0;
         }
+        if (xx == 0 || xx == WP - 1) kind = 0;
+        if (s >= HS) kind = 0;
+        hkind[j] = kind;
+        const int xc = min(max(xx - 1, 0), W - 1);
+        hoff[j] = (uint32_t)(((rel + 1) * W + xc) * g.ldx + 8 * lq) * 2u;
+        hlds[j] = s < HS ? pix * 64 + 16 * (lq ^ ((xx >> SWS) & 3)) : HS * 16 + 16 * (tid & 63);
     }
+    const uint32_t hsafe = (uint32_t)(W * g.ldx + 8 * lq) * 2u;        // the tile's first pixel: always inside the tensor
     // ---- weight DMA: 64 consecutive 16-byte vectors of a [160][32] slice per wave instruction; the k-quarter swizzle
     //      (row >> 2) & 3 is applied to the source address
-    uint32_t wsrc[3];
-    uint32_t wdst[3];
+    uint32_t wsrc[3], wdst[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         const int base = min((i * 4 + wave) * 64, C::WS - 64);
@@ -238,24 +274,30 @@ __global__ __launch_bounds__(256, 1) void conv3x3x_kernel(const sv_geom g, const
         wsrc[i] = (uint32_t)(row * 9 * Cin + 8 * q) * 2u;
         wdst[i] = lds0 + C::OFF_W + (uint32_t)base * 16u;
     }
-    auto dma_w = [&](int c, int t, auto I) {             // instruction i of the slice of (chunk c, tap t) -> ring slot t
-        constexpr int i = decltype(I)::value;
-        const char* src = Wb + (int64_t)(t * Cin + c * 32) * 2;
-        const uint32_t dst = wdst[i] + (uint32_t)t * (uint32_t)WBUF, off = wsrc[i];
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(dst), "v"(off), "s"(src) : "memory");
+    // instruction i of the slice of tap t at position p, whose chunk has ring parity `par`: slot = (t + 3 par) mod 6
+    // = t mod 6 + 3 par for t mod 6 < 3, t mod 6 - 3 par otherwise -- an immediate on one of two scalar bases
+    auto dma_w = [&](const Pos& p, int par, auto TT, auto I) {
+        constexpr int i = decltype(I)::value, t = decltype(TT)::value;
+        const char* src = p.wsl + (int64_t)t * Cin * 2;
+        const uint32_t base = (t % 6) < 3 ? wdst[i] + (uint32_t)(par * 3 * WBUF) : wdst[i] - (uint32_t)(par * 3 * WBUF);
+        const uint32_t off = wsrc[i];
+        asm volatile("s_add_u32 m0, %0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3"
+                     :: "s"(base), "n"((t % 6) * WBUF), "v"(off), "s"(src) : "memory", "scc");
     };
-    // ---- halo registers + BatchNorm coefficients of the thread's quarter
+    // ---- halo registers (+ their validity: it travels with the data) and the BatchNorm coefficients of the thread's quarter
     u32x4 rh[HI];
+    bool hok[HI];
     f32x4 csc[2], csh[2];
     {
         const f32x4 one = {1.f, 1.f, 1.f, 1.f}, zer = {0.f, 0.f, 0.f, 0.f};
         csc[0] = csc[1] = one;
         csh[0] = csh[1] = zer;
     }
-    auto load_h = [&](u32x4* rh, int c, auto J) {
+    auto load_h = [&](u32x4* rh, bool* hok, const Pos& p, auto J) {
         constexpr int j = decltype(J)::value;
-        const char* src = Xb + (int64_t)c * 64;
-        const uint32_t off = hoff[j];
+        hok[j] = (hkind[j] == 1) | ((hkind[j] == 2) & p.top_ok) | ((hkind[j] == 3) & p.bot_ok);
+        const char* src = p.xrow;
+        const uint32_t off = hok[j] ? hoff[j] : hsafe;
         u32x4 v;
         asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(v) : "v"(off), "s"(src) : "memory");
         rh[j] = v;
@@ -266,10 +308,10 @@ __global__ __launch_bounds__(256, 1) void conv3x3x_kernel(const sv_geom g, const
         asm volatile("s_waitcnt vmcnt(%1)" : "+v"(v) : "n"(n) : "memory");
         rh[j] = v;
     };
-    auto load_coef = [&](f32x4* csc, f32x4* csh, int c, auto Q) {                // q: 0,1 = scale lo/hi, 2,3 = shift lo/hi
+    auto load_coef = [&](f32x4* csc, f32x4* csh, const Pos& p, auto Q) {     // q: 0,1 = scale lo/hi, 2,3 = shift lo/hi
         constexpr int q = decltype(Q)::value;
         if (!has_pro) return;
-        const char* src = reinterpret_cast<const char*>(q < 2 ? a.pro_scale : a.pro_shift) + (int64_t)c * 128;
+        const char* src = reinterpret_cast<const char*>(q < 2 ? a.pro_scale : a.pro_shift) + (int64_t)p.c * 128;
         const uint32_t off = (uint32_t)(8 * lq + 4 * (q & 1)) * 4u;
         f32x4 v;
         asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(v) : "v"(off), "s"(src) : "memory");
@@ -286,7 +328,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3x_kernel(const sv_geom g, const
     //   8: od = pack_bf16(u)   9: od = valid ? od : 0;   step 40 stores the vector into the stage `stage_off`
     float xlo, xhi, xmlo, xmhi;
     u32x4 od;
-    auto hstep = [&](const u32x4* rh, const f32x4* csc, const f32x4* csh, auto J, auto ST, uint32_t stage_off) {
+    auto hstep = [&](const u32x4* rh, const bool* hok, const f32x4* csc, const f32x4* csh, auto J, auto ST, uint32_t stage_off) {
         constexpr int j = decltype(J)::value, st = decltype(ST)::value, d = st / 10, q = st % 10;
         if constexpr (st == 40) {
             *reinterpret_cast<u32x4*>(smem + stage_off + hlds[j]) = od;
@@ -310,14 +352,13 @@ __global__ __launch_bounds__(256, 1) void conv3x3x_kernel(const sv_geom g, const
         }
     };
 
-    // ---- fragment addressing (byte addresses in LDS; the tap / slot / k half / channel group are immediates) --------------
-    // weights: lane (r, h) reads row 32 i + r, k-quarter (2 ks + h) ^ swizzle(row); two bases keep the immediates < 64 KB
+    // ---- fragment addressing (byte addresses in LDS; tap / k half / channel group are immediates) ---------------------------
+    // weights: lane (r, h) reads row 32 i + r, k-quarter (2 ks + h) ^ swizzle(row), of ring slot (t + 3 par) mod 6:
+    // base [ks][0] serves the taps whose slot is t mod 6 + 3 par (t mod 6 < 3), base [ks][1] those with t mod 6 - 3 par
     uint32_t wa[2][2];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-        wa[ks][0] = lds0 + C::OFF_W + 16 * (4 * r + ((2 * ks + h) ^ ((r >> 2) & 3)));
-        wa[ks][1] = wa[ks][0] + 5 * WBUF;
-    }
+    for (int ks = 0; ks < 2; ++ks)
+        wa[ks][0] = wa[ks][1] = lds0 + C::OFF_W + 16 * (4 * r + ((2 * ks + h) ^ ((r >> 2) & 3)));
     // pixels: 64 * (pixel - one halo row - one column) + 16 * ((2 ks + h) ^ swizzle of the tap's column)
     uint32_t px[2][3][2];
 #pragma unroll
@@ -333,44 +374,37 @@ __global__ __launch_bounds__(256, 1) void conv3x3x_kernel(const sv_geom g, const
     typedef __attribute__((address_space(3))) bf16x8 lds_v8;
     bf16x8 A[2][NF], Bf[2][2];
     auto read_w = [&](int t, int ks, int i) {
-        const int off = (t < 5 ? t : t - 5) * WBUF + i * 2048;
-        A[ks][i] = *reinterpret_cast<const lds_v8*>((uintptr_t)(wa[ks][t < 5 ? 0 : 1] + (uint32_t)off));
+        const int off = (t % 6) * WBUF + i * 2048;
+        A[ks][i] = *reinterpret_cast<const lds_v8*>((uintptr_t)(wa[ks][(t % 6) < 3 ? 0 : 1] + (uint32_t)off));
     };
     auto read_p = [&](int t, int ks, int f) {
         const int ty = REV ? 2 - t / 3 : t / 3, tx = REV ? 2 - t % 3 : t % 3;
         Bf[ks][f] = *reinterpret_cast<const lds_v8*>((uintptr_t)(px[f][tx][ks] + (uint32_t)((ty * WP + tx) * 64)));
     };
 
-    f32x16 acc[2][NF];
-#pragma unroll
-    for (int f = 0; f < 2; ++f)
-#pragma unroll
-        for (int i = 0; i < NF; ++i)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[f][i][e] = 0.f;
-
     static constexpr XSched SCHED = make_xsched();
     static_assert(SCHED.ok, "the chunk program does not fit the gaps");
 
-    // ---- prologue: every request first -- chunk 0's halo + coefficients (into a second register set), the halo registers
-    //      + coefficients of chunk 1, slices 0..6 of chunk 0 (7, 8 come with taps 0, 1) -- then chunk 0's BatchNorm pass
-    //      into stage 0 while the rest is still in flight, and one full wait: the waits of the loop count the VMEM
-    //      instructions of a steady-state chunk, which the first chunk has not issued yet
-    __syncthreads();                                   // ssum visible
-    const int c1 = min(1, nck - 1);
+    // ---- prologue (once per block): every request first -- the first position's halo + coefficients (into registers of
+    //      their own), the halo registers + coefficients of the second position, the weight slices of steps 0..5 -- then the
+    //      first BatchNorm pass into stage 0 while the rest is in flight, and one full wait: the waits of the loop count the
+    //      VMEM instructions of a steady-state chunk, which the first chunk has not issued yet
+    Pos cur = make_pos(0, 0);
+    Pos nxt = next_pos(cur);
     {
         u32x4 rh0[HI];
+        bool hok0[HI];
         f32x4 csc0[2] = {csc[0], csc[1]}, csh0[2] = {csh[0], csh[1]};
-        static_for<HI>([&](auto J) { load_h(rh0, 0, J); });
-        static_for<4>([&](auto Q) { load_coef(csc0, csh0, 0, Q); });
-        static_for<7>([&](auto S) { static_for<3>([&](auto I) { dma_w(0, decltype(S)::value, I); }); });
-        static_for<HI>([&](auto J) { load_h(rh, c1, J); });
-        static_for<4>([&](auto Q) { load_coef(csc, csh, c1, Q); });
-        // the first HI + 4 requests are the oldest: 21 DMA + HI + 4 younger ones may stay in flight
-        wait_coef(csc0, csh0, std::integral_constant<int, 21 + HI + 4>{});
+        static_for<HI>([&](auto J) { load_h(rh0, hok0, cur, J); });
+        static_for<4>([&](auto Q) { load_coef(csc0, csh0, cur, Q); });
+        static_for<6>([&](auto S) { static_for<3>([&](auto I) { dma_w(cur, 0, S, I); }); });
+        static_for<HI>([&](auto J) { load_h(rh, hok, nxt, J); });
+        static_for<4>([&](auto Q) { load_coef(csc, csh, nxt, Q); });
+        // the first HI + 4 requests are the oldest: 18 DMA + HI + 4 younger ones may stay in flight
+        wait_coef(csc0, csh0, std::integral_constant<int, 18 + HI + 4>{});
         static_for<HI>([&](auto J) {
-            wait_h(rh0, J, std::integral_constant<int, 21 + HI + 4>{});
-            static_for<HSTEPS>([&](auto ST) { hstep(rh0, csc0, csh0, J, ST, 0u); });
+            wait_h(rh0, J, std::integral_constant<int, 18 + HI + 4>{});
+            static_for<HSTEPS>([&](auto ST) { hstep(rh0, hok0, csc0, csh0, J, ST, 0u); });
         });
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -381,15 +415,29 @@ __global__ __launch_bounds__(256, 1) void conv3x3x_kernel(const sv_geom g, const
         static_for<NF>([&](auto I) { read_w(0, decltype(KS)::value, decltype(I)::value); });
         static_for<2>([&](auto F) { read_p(0, decltype(KS)::value, decltype(F)::value); });
     });
-
 #ifdef SV_X3_STAMP
     const uint64_t st1 = __builtin_amdgcn_s_memtime();
-    uint64_t stb = 0;
+    uint64_t stb = 0, st_loop = 0, st_epi = 0, ste[8] = {}, st_first = 0, st_mid = 0, st_last = 0;
+    uint64_t st_mark = st1;
 #endif
-    // ---- the K loop: one 32-channel chunk = nine taps = 180 MFMAs -------------------------------------------------------
-    int par = 0;
-    for (int c = 0; c < nck; ++c) {
-        const int cn = min(c + 1, nck - 1), cnn = min(c + 2, nck - 1);
+
+    // ---- the K loop over all positions of the block: one 32-channel chunk = nine taps = 180 MFMAs -------------------------
+    int par = 0;                       // halo stage and ring parity of the current chunk
+    for (int item = 0; item < cnt; ++item) {
+      // (two plain nested loops: the accumulators are loop-carried through the chunk loop only -- a conditional epilogue
+      //  inside one loop makes the register allocator merge two versions of all 160 of them)
+      f32x16 acc[2][NF];
+#pragma unroll
+      for (int f = 0; f < 2; ++f)
+#pragma unroll
+          for (int i = 0; i < NF; ++i)
+#pragma unroll
+              for (int e = 0; e < 16; ++e) acc[f][i][e] = 0.f;
+      for (int cc = 0; cc < nck; ++cc) {
+#ifdef SV_X3_STAMP
+        const uint64_t sc0 = __builtin_amdgcn_s_memtime();
+#endif
+        const Pos nn = next_pos(nxt);
         const uint32_t other = (uint32_t)((par ^ 1) * HB);
         static_for<9>([&](auto T) {
             constexpr int t = decltype(T)::value, tn = (t + 1) % 9;
@@ -399,18 +447,19 @@ __global__ __launch_bounds__(256, 1) void conv3x3x_kernel(const sv_geom g, const
                 static_for<6>([&](auto JJ) {
                     constexpr int code = SCHED.item[20 * t + m][decltype(JJ)::value];
                     if constexpr (code >= 1000 && code < 2000)
-                        hstep(rh, csc, csh, std::integral_constant<int, (code - 1000) / HSTEPS>{},
+                        hstep(rh, hok, csc, csh, std::integral_constant<int, (code - 1000) / HSTEPS>{},
                               std::integral_constant<int, (code - 1000) % HSTEPS>{}, other);
                     if constexpr (code >= 2000 && code < 3000) {
-                        constexpr int s = (code - 2000) / 3;
-                        dma_w(s >= 7 ? c : cn, s, std::integral_constant<int, (code - 2000) % 3>{});
+                        constexpr int sl = (code - 2000) / 3;
+                        constexpr int tap = sl < 4 ? 5 + sl : sl - 4;          // (this, 5..8), (next, 0..4)
+                        dma_w(sl < 4 ? cur : nxt, sl < 4 ? par : par ^ 1, std::integral_constant<int, tap>{}, std::integral_constant<int, (code - 2000) % 3>{});
                     }
-                    if constexpr (code >= 3000 && code < 3500) load_h(rh, cnn, std::integral_constant<int, code - 3000>{});
-                    if constexpr (code >= 3500 && code < 4000) load_coef(csc, csh, cnn, std::integral_constant<int, code - 3500>{});
+                    if constexpr (code >= 3000 && code < 3500) load_h(rh, hok, nn, std::integral_constant<int, code - 3000>{});
+                    if constexpr (code >= 3500 && code < 4000) load_coef(csc, csh, nn, std::integral_constant<int, code - 3500>{});
                     if constexpr (code >= 4000 && code < 4500)
                         wait_h(rh, std::integral_constant<int, code - 4000>{}, std::integral_constant<int, SCHED.vm_slot[code - 4000]>{});
                     if constexpr (code == 4500) wait_coef(csc, csh, std::integral_constant<int, SCHED.vm_coef>{});
-                    if constexpr (code == 5000) {          // the next tap 0 reads the other halo stage
+                    if constexpr (code == 5000) {          // the next tap 0 belongs to the next chunk: other halo stage, ring + 3
                         const uint32_t flip = par ? (uint32_t)(-HB) : (uint32_t)HB;
 #pragma unroll
                         for (int ff = 0; ff < 2; ++ff)
@@ -418,6 +467,12 @@ __global__ __launch_bounds__(256, 1) void conv3x3x_kernel(const sv_geom g, const
                             for (int tx = 0; tx < 3; ++tx)
 #pragma unroll
                                 for (int kk = 0; kk < 2; ++kk) px[ff][tx][kk] += flip;
+                        const uint32_t wflip = (uint32_t)(3 * WBUF);
+#pragma unroll
+                        for (int kk = 0; kk < 2; ++kk) {
+                            wa[kk][0] = par ? wa[kk][0] - wflip : wa[kk][0] + wflip;
+                            wa[kk][1] = par ? wa[kk][1] + wflip : wa[kk][1] - wflip;
+                        }
                     }
                 });
                 // the next tap's fragments, each right after the last MFMA that reads its registers
@@ -439,29 +494,53 @@ __global__ __launch_bounds__(256, 1) void conv3x3x_kernel(const sv_geom g, const
             }
         });
         par ^= 1;
-    }
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
-    __syncthreads();                                   // every wave is past its last fragment read: the LDS is free
-
+        if (cc + 1 < nck) { cur = nxt; nxt = nn; }
 #ifdef SV_X3_STAMP
-    const uint64_t st2 = __builtin_amdgcn_s_memtime();
+        { const uint64_t d = __builtin_amdgcn_s_memtime() - sc0; if (cc == 0) st_first += d; else if (cc + 1 == nck) st_last += d; else st_mid += d; }
 #endif
-    constexpr int SV_EPD = SV_X3_EPD;
+      }
+      {
+            // ---- the item is complete: epilogue (its scratch lies apart from the stages and the ring, which already hold
+            //      the next item's first chunk), accumulators back to zero.  The stores must have left before the loop's
+            //      hand-counted vmcnt waits resume (stores and loads share the counter but not its order)
+            asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+            const int n0 = cur.n0, gr0 = cur.gr0;
+            for (int c = tid; c < 2 * BN; c += 256) ssum[c] = 0.f;
+            __syncthreads();
 #ifdef SV_X3_STAMP
-    uint64_t ste[8] = {};
+            { const uint64_t now = __builtin_amdgcn_s_memtime(); st_loop += now - st_mark; st_mark = now; }
 #define SV_EPI_STAMP(k) ste[k] = __builtin_amdgcn_s_memtime();
 #else
 #define SV_EPI_STAMP(k)
 #endif
-#define SV_EPI_NSCR 2
+            {
+                constexpr int SV_EPD = SV_X3_EPD;
+#define SV_EPI_NSCR 1
+#define SV_EPI_BASE C::OFF_SCR
+#define SV_EPI_ALIAS 1
 #include "conv3x3w_epilogue.inc"
 #undef SV_EPI_NSCR
+#undef SV_EPI_BASE
+#undef SV_EPI_ALIAS
 #undef SV_EPI_STAMP
+            }
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __syncthreads();
 #ifdef SV_X3_STAMP
-    if (tid == 0 && blockIdx.x < 2048) {      // (overwrites the statistics: diagnostic build only)
-        float* d = a.stats + 8 * 2 * g.N + 8 * blockIdx.x;      // behind the eight statistics replicas
-        d[0] = (float)(st1 - st0); d[1] = (float)(st2 - st1); d[2] = (float)(__builtin_amdgcn_s_memtime() - st2); d[3] = (float)stb;
-        d[4] = (float)(ste[0] - st2); d[5] = (float)(ste[1] - ste[0]); d[6] = (float)(ste[5] - ste[1]); d[7] = (float)(ste[6] - ste[5]);
+            { const uint64_t now = __builtin_amdgcn_s_memtime(); st_epi += now - st_mark; st_mark = now; }
+#endif
+      }
+      {   // step to the next item's first chunk (staged during this item's last one)
+          const Pos nn2 = next_pos(nxt);
+          cur = nxt;
+          nxt = nn2;
+      }
+    }
+#ifdef SV_X3_STAMP
+    if (tid == 0 && blockIdx.x < 2048) {      // (diagnostic build: behind the eight statistics replicas)
+        float* d = a.stats + 8 * 2 * g.N + 8 * blockIdx.x;
+        d[0] = (float)(st1 - st0); d[1] = (float)st_loop; d[2] = (float)st_epi; d[3] = (float)stb;
+        d[4] = (float)cnt; d[5] = (float)st_first; d[6] = (float)st_mid; d[7] = (float)st_last;
     }
 #endif
 }
@@ -470,7 +549,9 @@ template <int WLOG, bool REV>
 int launch_x3(const sv_geom* g, const sv_igemm_args* a, hipStream_t s) {
     using C = XCfg<WLOG>;
     const int nT = g->B * g->Hin / C::TR, nNt = g->N / C::BN;
-    const int grid = 8 * ((nT + 7) / 8) * nNt;
+    // persistent: one block per CU (256 = 8 XCDs x 32), fewer when there are fewer items per XCD
+    const int per = (nT + 7) / 8, items_xcd = per * nNt;
+    const int grid = 8 * (items_xcd < 32 ? items_xcd : 32);
     const size_t lds = (size_t)C::LDS;
     static bool optin = false;
     if (!optin) {
@@ -499,10 +580,9 @@ int launch_x2(const sv_geom* g, const sv_igemm_args* a, hipStream_t s) {
 // Returns 1 and sets *rc when the geometry is a wide bf16 stride-1 3x3 convolution with 160-channel tiles.
 // (The caller, sv_conv3x3w_try, has already checked the stride-1 3x3 / tap-order / size conditions; fwd = canonical taps.)
 int sv_conv3x3x_try(const sv_geom* g, const sv_igemm_args* a, bool fwd, hipStream_t s, int* rc) {
-    // experimental (round 1): on par with conv3x3w -- the K loop is ~1.3x the matrix-pipe time, but with one block per CU
-    // nothing hides the prologue and the epilogue (tools/x3_stamp.sh); SV_CONV3X3X=1 selects it (read per call: tests)
+    // SV_CONV3X3X=0 (or SV_NO_CONV3X3X) falls back to conv3x3w (A/B; read per call: the tests toggle it)
     const char* on = getenv("SV_CONV3X3X");
-    if (!on || on[0] == '0') return 0;
+    if ((on && on[0] == '0') || getenv("SV_NO_CONV3X3X")) return 0;
     if (g->N % 160 != 0 || g->Cin % 32 != 0 || g->Cin < 96) return 0;
     *rc = fwd ? launch_x2<false>(g, a, s) : launch_x2<true>(g, a, s);
     return 1;

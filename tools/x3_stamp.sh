@@ -24,14 +24,12 @@ a.stats, a.replicas = stats.data_ptr(), 8
 for _ in range(3):
     L.call("sv_igemm", C.byref(g), L.SV_BF16, C.byref(a), st)
 torch.cuda.synchronize()
-TR = 256 // H
-nb = min(2048, 8 * ((B * H // TR + 7) // 8) * (N // 160))
-t = stats[16 * N:16 * N + 8 * nb].view(nb, 8).cpu().double()
-t = t[t[:, 1] > 0]
+t = stats[16 * N:16 * N + 8 * 256].view(256, 8).cpu().double()
+t = t[t[:, 4] > 0]
 m = t.mean(0)
+items = m[4]
 steps = 9 * Cin // 32
-print("Cin %d: blocks %d; cycles per block: prologue %.0f  K loop %.0f (%.0f per tap of 20 MFMAs; MFMA-only stream: 660)  of which wait+barrier %.0f  epilogue %.0f" % (
-    Cin, len(t), m[0], m[1], m[1] / steps, m[3], m[2]))
-print("   epilogue: setup + residual requests %.0f  group 0 %.0f  groups 1..4 %.0f  final sums %.0f" % (m[4], m[5], m[6], m[7]))
+print("Cin %d: %d persistent blocks, %.1f items each; cycles: prologue (once) %.0f;  per item: K loop %.0f (%.0f per tap of 20 MFMAs; MFMA-only stream: 660), of which wait+barrier %.0f;  epilogue %.0f;  chunk (9 taps): first of an item %.0f, middle %.0f, last %.0f" % (
+    Cin, len(t), items, m[0], m[1] / items, m[1] / items / steps, m[3] / items, m[2] / items, m[5] / items, m[6] / items / max(Cin // 32 - 2, 1), m[7] / items))
 PY
 done
