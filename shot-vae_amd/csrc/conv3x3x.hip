@@ -389,6 +389,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3x_kernel(const sv_geom g, const
     //      their own), the halo registers + coefficients of the second position, the weight slices of steps 0..5 -- then the
     //      first BatchNorm pass into stage 0 while the rest is in flight, and one full wait: the waits of the loop count the
     //      VMEM instructions of a steady-state chunk, which the first chunk has not issued yet
+    for (int c = tid; c < 2 * BN; c += 256) ssum[c] = 0.f;
     Pos cur = make_pos(0, 0);
     Pos nxt = next_pos(cur);
     {
@@ -503,10 +504,10 @@ __global__ __launch_bounds__(256, 1) void conv3x3x_kernel(const sv_geom g, const
             // ---- the item is complete: epilogue (its scratch lies apart from the stages and the ring, which already hold
             //      the next item's first chunk), accumulators back to zero.  The stores must have left before the loop's
             //      hand-counted vmcnt waits resume (stores and loads share the counter but not its order)
+            // (ssum is zero: cleared before the first item and by the flush at the end of every epilogue; the chunk loop's
+            //  barriers lie in between)
             asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
             const int n0 = cur.n0, gr0 = cur.gr0;
-            for (int c = tid; c < 2 * BN; c += 256) ssum[c] = 0.f;
-            __syncthreads();
 #ifdef SV_X3_STAMP
             { const uint64_t now = __builtin_amdgcn_s_memtime(); st_loop += now - st_mark; st_mark = now; }
 #define SV_EPI_STAMP(k) ste[k] = __builtin_amdgcn_s_memtime();
@@ -524,8 +525,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3x_kernel(const sv_geom g, const
 #undef SV_EPI_ALIAS
 #undef SV_EPI_STAMP
             }
+            // this thread's share of the sums is flushed (the include's last loop): clear it for the next item
+            for (int c = tid; c < 2 * BN; c += 256) ssum[c] = 0.f;
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            __syncthreads();
 #ifdef SV_X3_STAMP
             { const uint64_t now = __builtin_amdgcn_s_memtime(); st_epi += now - st_mark; st_mark = now; }
 #endif
