@@ -497,7 +497,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3x_kernel(const sv_geom g, const
         par ^= 1;
         if (cc + 1 < nck) { cur = nxt; nxt = nn; }
 #ifdef SV_X3_STAMP
+#ifdef SV_X3_STAMP_CHUNK    // (opt-in: with these three counters the 160-channel diagnostic build faults -- register pressure; unresolved)
         { const uint64_t d = __builtin_amdgcn_s_memtime() - sc0; if (cc == 0) st_first += d; else if (cc + 1 == nck) st_last += d; else st_mid += d; }
+#endif
 #endif
       }
       {
