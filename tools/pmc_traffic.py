@@ -31,7 +31,7 @@ LAYERS = {
     "wgrad:conv3x3_128x128_s1": (512, 128, 8, 128, "wgrad", ["wgrad3x3_kernel", "slab_reduce_kernel"]),
     "fwd:conv3x3_128x128_s1": (512, 128, 8, 128, "fwd", ["conv3x3_kernel", "conv3x3w_kernel"]),
     "dgrad:conv3x3_128x128_s1": (512, 128, 8, 128, "dgrad", ["conv3x3_kernel", "conv3x3w_kernel"]),
-    "fwd:conv3x3_160x160_s1": (512, 160, 32, 160, "fwd", ["conv3x3w_kernel"]),
+    "fwd:conv3x3_160x160_s1": (512, 160, 32, 160, "fwd", ["conv3x3x_kernel", "conv3x3w_kernel"]),
     "wgrad:conv3x3_160x160_s1": (512, 160, 32, 160, "wgrad", ["wgrad3x3w_kernel", "slab_reduce_kernel"]),
 }
 ITERS, WARM = 4, 1
