@@ -172,7 +172,9 @@ struct XCfg {
     static_assert(LDS <= 160 * 1024, "one block per CU");
 };
 
-template <int WLOG, bool REV>
+// MODE: the epilogue's fusion flags at compile time (conv3x3w_epilogue.inc: 0 = from the arguments, 1 = statistics,
+// 2 = residual + statistics, 3 = activation-backward)
+template <int WLOG, bool REV, int MODE>
 __global__ __launch_bounds__(256, 1) void conv3x3x_kernel(const sv_geom g, const sv_igemm_args a) {
     using C = XCfg<WLOG>;
     constexpr int NF = C::NF, BN = C::BN, W = C::W, TR = C::TR, WP = C::WP, HH = C::HH, SEG = C::SEG;
@@ -521,7 +523,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3x_kernel(const sv_geom g, const
 #define SV_EPI_NSCR 1
 #define SV_EPI_BASE C::OFF_SCR
 #define SV_EPI_ALIAS 1
+#define SV_EPI_MODE MODE
 #include "conv3x3w_epilogue.inc"
+#undef SV_EPI_MODE
 #undef SV_EPI_NSCR
 #undef SV_EPI_BASE
 #undef SV_EPI_ALIAS
@@ -549,8 +553,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3x_kernel(const sv_geom g, const
 #endif
 }
 
-template <int WLOG, bool REV>
-int launch_x3(const sv_geom* g, const sv_igemm_args* a, hipStream_t s) {
+template <int WLOG, bool REV, int MODE>
+int launch_x4(const sv_geom* g, const sv_igemm_args* a, hipStream_t s) {
     using C = XCfg<WLOG>;
     const int nT = g->B * g->Hin / C::TR, nNt = g->N / C::BN;
     // persistent: one block per CU (256 = 8 XCDs x 32), fewer when there are fewer items per XCD
@@ -559,15 +563,29 @@ int launch_x3(const sv_geom* g, const sv_igemm_args* a, hipStream_t s) {
     const size_t lds = (size_t)C::LDS;
     static bool optin = false;
     if (!optin) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3x_kernel<WLOG, REV>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3x_kernel<WLOG, REV, MODE>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return sv_check_launch("hipFuncSetAttribute(conv3x3x)");
         optin = true;
     }
     sv_prof_begin(s);
-    hipLaunchKernelGGL((conv3x3x_kernel<WLOG, REV>), dim3(grid), dim3(256), lds, s, *g, *a);
+    hipLaunchKernelGGL((conv3x3x_kernel<WLOG, REV, MODE>), dim3(grid), dim3(256), lds, s, *g, *a);
     sv_prof_end(s);
     return sv_check_launch("sv_igemm(conv3x3x)");
+}
+
+// forward launches come with statistics (+ residual), data gradients with the activation-backward epilogue; anything else
+// (bias, no statistics, ...) takes the binary that reads the flags at run time
+template <int WLOG, bool REV>
+int launch_x3(const sv_geom* g, const sv_igemm_args* a, hipStream_t s) {
+#ifdef SV_X3_MODES      // (measured: -0.3 % forward, -2.6 % data gradient for 2.5x the build time -- not instantiated by default)
+    static const bool generic_only = getenv("SV_X3_GENERIC_EPILOGUE") != nullptr;        // A/B
+    if (!generic_only && !a->bias) {
+        if (!REV && !a->ex && a->stats) return a->residual ? launch_x4<WLOG, REV, 2>(g, a, s) : launch_x4<WLOG, REV, 1>(g, a, s);
+        if (REV && a->ex && !a->residual) return launch_x4<WLOG, REV, 3>(g, a, s);
+    }
+#endif
+    return launch_x4<WLOG, REV, 0>(g, a, s);
 }
 
 template <bool REV>
