@@ -420,7 +420,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3x_kernel(const sv_geom g, const
     });
 #ifdef SV_X3_STAMP
     const uint64_t st1 = __builtin_amdgcn_s_memtime();
-    uint64_t stb = 0, st_loop = 0, st_epi = 0, ste[8] = {}, st_first = 0, st_mid = 0, st_last = 0;
+    uint64_t stb = 0, st_loop = 0, st_epi = 0, ste[8] = {}, sti[2] = {}, st_first = 0, st_mid = 0, st_last = 0;
     uint64_t st_mark = st1;
 #endif
 
@@ -515,6 +515,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3x_kernel(const sv_geom g, const
 #ifdef SV_X3_STAMP
             { const uint64_t now = __builtin_amdgcn_s_memtime(); st_loop += now - st_mark; st_mark = now; }
 #define SV_EPI_STAMP(k) ste[k] = __builtin_amdgcn_s_memtime();
+#define SV_EPI_STAMP_IN(k) sti[k] = __builtin_amdgcn_s_memtime();
 #else
 #define SV_EPI_STAMP(k)
 #endif
@@ -530,6 +531,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3x_kernel(const sv_geom g, const
 #undef SV_EPI_BASE
 #undef SV_EPI_ALIAS
 #undef SV_EPI_STAMP
+#undef SV_EPI_STAMP_IN
             }
             // this thread's share of the sums is flushed (the include's last loop): clear it for the next item
             for (int c = tid; c < 2 * BN; c += 256) ssum[c] = 0.f;
@@ -548,7 +550,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3x_kernel(const sv_geom g, const
     if (tid == 0 && blockIdx.x < 2048) {      // (diagnostic build: behind the eight statistics replicas)
         float* d = a.stats + 8 * 2 * g.N + 8 * blockIdx.x;
         d[0] = (float)(st1 - st0); d[1] = (float)st_loop; d[2] = (float)st_epi; d[3] = (float)stb;
-        d[4] = (float)cnt; d[5] = (float)st_first; d[6] = (float)st_mid; d[7] = (float)st_last;
+        d[4] = (float)cnt; d[5] = (float)(sti[0] - ste[1]); d[6] = (float)(sti[1] - sti[0]); d[7] = (float)(ste[2] - sti[1]);
     }
 #endif
 }

@@ -32,7 +32,7 @@ t = t[t[:, 4] > 0]
 m = t.mean(0)
 items = m[4]
 steps = 9 * Cin // 32
-print("Cin %d: %d persistent blocks, %.1f items each; cycles: prologue (once) %.0f;  per item: K loop %.0f (%.0f per tap of 20 MFMAs; MFMA-only stream: 660), of which wait+barrier %.0f;  epilogue %.0f" % (
-    Cin, len(t), items, m[0], m[1] / items, m[1] / items / steps, m[3] / items, m[2] / items))
+print("Cin %d: %d persistent blocks, %.1f items each; cycles: prologue (once) %.0f;  per item: K loop %.0f (%.0f per tap of 20 MFMAs; MFMA-only stream: 660), of which wait+barrier %.0f;  epilogue %.0f  (its second 32-channel group: accumulator dump to LDS %.0f, read back + residual + convert + store %.0f, statistics %.0f)" % (
+    Cin, len(t), items, m[0], m[1] / items, m[1] / items / steps, m[3] / items, m[2] / items, m[5], m[6], m[7]))
 PY
 done
