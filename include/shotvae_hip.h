@@ -214,6 +214,13 @@ int sv_prof_collect(int max_tags, double* ms, int* count);
  * waits = int[5]: the vmcnt of those waits (vector 0..3) and of the wait before the barrier.          */
 int sv_debug_wgrad_tile_program(int halo_vectors, int* items, int* waits);
 
+/* The chunk program of the wide forward / data-gradient kernel (conv3x3x.hip): items = int[180][6], the gap behind every
+ * MFMA of one 32-channel chunk (9 taps x 20).  Codes: 1000 + 41*vector + step (BatchNorm pass), 2000 + 3*slice + i (weight
+ * DMA instruction; slice 0..3 = this chunk's taps 5..8, 4..8 = the next chunk's taps 0..4), 3000 + v (halo load),
+ * 3500 + q (coefficient load), 4000 + v / 4500 (vmcnt waits), 5000 (stage flip).  waits = int[10]: vmcnt of the waits
+ * before vectors 0..5, before the coefficients, and before the barriers after taps 1, 4, 7.                          */
+int sv_debug_conv_chunk_program(int* items, int* waits);
+
 int sv_version(void);
 const char* sv_last_error(void);
 

@@ -73,6 +73,7 @@ _PROTOS = {
     "sv_prof_tag": [I],
     "sv_prof_collect": [I, C.POINTER(C.c_double), C.POINTER(C.c_int)],
     "sv_debug_wgrad_tile_program": [I, C.POINTER(C.c_int), C.POINTER(C.c_int)],
+    "sv_debug_conv_chunk_program": [C.POINTER(C.c_int), C.POINTER(C.c_int)],
     "sv_version": [],
 }
 EXPORTS = sorted(list(_PROTOS) + ["sv_last_error"])

@@ -611,3 +611,13 @@ int sv_conv3x3x_try(const sv_geom* g, const sv_igemm_args* a, bool fwd, hipStrea
     *rc = fwd ? launch_x2<false>(g, a, s) : launch_x2<true>(g, a, s);
     return 1;
 }
+
+extern "C" int sv_debug_conv_chunk_program(int* items, int* waits) {
+    SV_REQUIRE(items && waits, SV_E_ARG, "sv_debug_conv_chunk_program: null argument");
+    static constexpr XSched S = make_xsched();
+    for (int i = 0; i < X_NGAP; ++i)
+        for (int j = 0; j < 6; ++j) items[6 * i + j] = S.item[i][j];
+    for (int v = 0; v < X_HI; ++v) waits[v] = S.vm_slot[v];
+    waits[6] = S.vm_coef; waits[7] = S.vm_b1; waits[8] = S.vm_b4; waits[9] = S.vm_b7;
+    return S.ok ? SV_OK : SV_E_SHAPE;
+}

@@ -75,3 +75,52 @@ def test_wide_wgrad_tile_program_is_consistent():
         for gi, items in enumerate(gaps[:135]):
             n = sum(1 for c in items if c // 1000 == 1)
             assert n <= (1 if has_read(gi % 45) else 2)
+
+
+def test_wide_conv_chunk_program_is_consistent():
+    """The compile-time schedule of conv3x3x_kernel (conv3x3x.hip, make_xsched): the 246 BatchNorm steps exactly once, in
+    order and finished before the barrier after tap 7; every VMEM instruction alone in a gap without fragment reads; halo
+    registers re-loaded after their vector's store, the coefficients after the last step; the weight slices inside the
+    window the six-slot ring allows; and the hand-counted vmcnt values equal to the VMEM instructions issued in between
+    (steady state)."""
+    items = (ctypes.c_int * (180 * 6))()
+    waits = (ctypes.c_int * 10)()
+    assert L.lib().sv_debug_conv_chunk_program(items, waits) == 0
+    gaps = [[items[6 * i + j] for j in range(6) if items[6 * i + j]] for i in range(180)]
+    waits = list(waits)
+    has_read = lambda m: (m & 1) == 1 or m in (8, 18)
+    flat = [(gi, c) for gi, it in enumerate(gaps) for c in it]
+    steps = [c - 1000 for _, c in flat if 1000 <= c < 2000]
+    assert steps == list(range(41 * 6))
+    assert all(gi < 160 for gi, c in flat if 1000 <= c < 2000 or 4000 <= c < 5000)
+    vmem = [(gi, c) for gi, c in flat if 2000 <= c < 4000]
+    assert sorted(c for _, c in vmem if c < 3000) == [2000 + k for k in range(27)]
+    assert sorted(c for _, c in vmem if 3000 <= c < 3500) == [3000 + v for v in range(6)]
+    assert sorted(c for _, c in vmem if c >= 3500) == [3500 + q for q in range(4)]
+    for gi, c in vmem:
+        assert not has_read(gi % 20), "VMEM next to a fragment read"
+        assert sum(1 for x in gaps[gi] if 2000 <= x < 4000) == 1
+    for (g0, _), (g1, _) in zip(vmem, vmem[1:]):
+        assert g1 - g0 >= 2, "at most one VMEM instruction per two MFMAs"
+    pos = {c: i for i, (_, c) in enumerate(flat)}
+    gap_of = {c: gi for gi, c in flat}
+    # ring windows: slice s of step k = 5 + s (this chunk's taps 5..8, the next chunk's 0..4 = steps 9..13) may be written
+    # after the barrier that follows the fragment reads of step k - 6 (those happen during step k - 7), and must be awaited
+    # at a barrier before step k - 1
+    barrier_after = lambda step: next(b for b in (1, 4, 7, 10, 13) if b >= step)
+    for sl in range(9):
+        k = 5 + sl
+        first_gap = min(gap_of[2000 + 3 * sl + i] for i in range(3))
+        assert first_gap // 20 > barrier_after(k - 7) if k - 7 >= 0 else True, (sl, first_gap)
+    order = [c for _, c in vmem]
+    since_wrap = lambda code, until: (len(order) - 1 - order.index(code)) + sum(1 for gi, c in vmem if pos[c] < until)
+    since = lambda code, until_gap: sum(1 for gi, c in vmem[order.index(code) + 1:] if gi < until_gap)
+    for v in range(6):
+        assert pos[3000 + v] > pos[1000 + 41 * v + 40], "reload only after the vector's store"
+        assert waits[v] == since_wrap(3000 + v, pos[4000 + v])
+    assert pos[3500] > pos[1000 + 41 * 6 - 1]
+    assert waits[6] == since_wrap(3503, pos[4500])
+    assert waits[7] == since(2000 + 3 * 0 + 2, 40)          # (this, 5), issued in tap 0, awaited after tap 1
+    assert waits[8] == since(2000 + 3 * 3 + 2, 100)         # (this, 8), tap 3 -> barrier after tap 4
+    assert waits[9] == since(2000 + 3 * 6 + 2, 160)         # (next, 2), tap 6 -> barrier after tap 7
+    assert gap_of[5000] == 160, "the stage flip precedes the first fragment read of tap 8"
