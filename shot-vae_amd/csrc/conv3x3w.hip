@@ -377,8 +377,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3w_kernel(const sv_geom g, const
 #define SV_EPI_BASE 0
 #define SV_EPI_ALIAS 0
 #define SV_EPI_MODE 0
+#define SV_EPI_WAVE_SUMS 0
 #include "conv3x3w_epilogue.inc"
 #undef SV_EPI_MODE
+#undef SV_EPI_WAVE_SUMS
 #undef SV_EPI_NSCR
 #undef SV_EPI_BASE
 #undef SV_EPI_ALIAS

@@ -167,7 +167,7 @@ struct XCfg {
     static constexpr int WS = 4 * BN, WI = 3, WBUF = WS * 16, NSLOT = 6;
     static constexpr int SCR = 64 * 36 * 4;                 // epilogue transpose scratch per wave
     static constexpr int OFF_W = 2 * HB, OFF_SCR = OFF_W + NSLOT * WBUF;
-    static constexpr int OFF_SSUM = OFF_SCR + 4 * SCR + 5 * BN * 4, LDS = OFF_SSUM + 2 * BN * 4;
+    static constexpr int OFF_SSUM = OFF_SCR + 4 * SCR + 5 * BN * 4, LDS = OFF_SSUM + 4 * 2 * BN * 4;     // sums: one copy per wave
     static_assert((HS + 255) / 256 == X_HI, "six halo vectors per thread");
     static_assert(LDS <= 160 * 1024, "one block per CU");
 };
@@ -391,7 +391,6 @@ __global__ __launch_bounds__(256, 1) void conv3x3x_kernel(const sv_geom g, const
     //      their own), the halo registers + coefficients of the second position, the weight slices of steps 0..5 -- then the
     //      first BatchNorm pass into stage 0 while the rest is in flight, and one full wait: the waits of the loop count the
     //      VMEM instructions of a steady-state chunk, which the first chunk has not issued yet
-    for (int c = tid; c < 2 * BN; c += 256) ssum[c] = 0.f;
     Pos cur = make_pos(0, 0);
     Pos nxt = next_pos(cur);
     {
@@ -508,8 +507,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3x_kernel(const sv_geom g, const
             // ---- the item is complete: epilogue (its scratch lies apart from the stages and the ring, which already hold
             //      the next item's first chunk), accumulators back to zero.  The stores must have left before the loop's
             //      hand-counted vmcnt waits resume (stores and loads share the counter but not its order)
-            // (ssum is zero: cleared before the first item and by the flush at the end of every epilogue; the chunk loop's
-            //  barriers lie in between)
+            // (the per-wave sums need no clearing: every address is written once per item; the flush of item i and the
+            //  writes of item i + 1 are separated by the chunk loop's barriers)
             asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
             const int n0 = cur.n0, gr0 = cur.gr0;
 #ifdef SV_X3_STAMP
@@ -525,16 +524,16 @@ __global__ __launch_bounds__(256, 1) void conv3x3x_kernel(const sv_geom g, const
 #define SV_EPI_BASE C::OFF_SCR
 #define SV_EPI_ALIAS 1
 #define SV_EPI_MODE MODE
+#define SV_EPI_WAVE_SUMS 1
 #include "conv3x3w_epilogue.inc"
 #undef SV_EPI_MODE
+#undef SV_EPI_WAVE_SUMS
 #undef SV_EPI_NSCR
 #undef SV_EPI_BASE
 #undef SV_EPI_ALIAS
 #undef SV_EPI_STAMP
 #undef SV_EPI_STAMP_IN
             }
-            // this thread's share of the sums is flushed (the include's last loop): clear it for the next item
-            for (int c = tid; c < 2 * BN; c += 256) ssum[c] = 0.f;
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 #ifdef SV_X3_STAMP
             { const uint64_t now = __builtin_amdgcn_s_memtime(); st_epi += now - st_mark; st_mark = now; }
