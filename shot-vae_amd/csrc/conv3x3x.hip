@@ -406,10 +406,11 @@ __global__ __launch_bounds__(256, 1) void conv3x3x_kernel(const sv_geom g, const
         static_for<6>([&](auto S) { static_for<3>([&](auto I) { dma_w(cur, 0, S, I); }); });
         static_for<HI>([&](auto J) { load_h(rh, hok, nxt, J); });
         static_for<4>([&](auto Q) { load_coef(csc, csh, nxt, Q); });
-        // the first HI + 4 requests are the oldest: 18 DMA + HI + 4 younger ones may stay in flight
-        wait_coef(csc0, csh0, std::integral_constant<int, 18 + HI + 4>{});
+        // (a full drain, once per block: counting on the first HI + 4 requests -- HBM -- to return before the 18 younger
+        //  weight DMAs -- L2 -- is not safe: LDS-DMA and register loads do not retire in one common order)
+        wait_coef(csc0, csh0, std::integral_constant<int, 0>{});
         static_for<HI>([&](auto J) {
-            wait_h(rh0, J, std::integral_constant<int, 18 + HI + 4>{});
+            wait_h(rh0, J, std::integral_constant<int, 0>{});
             static_for<HSTEPS>([&](auto ST) { hstep(rh0, hok0, csc0, csh0, J, ST, 0u); });
         });
     }
@@ -486,6 +487,13 @@ __global__ __launch_bounds__(256, 1) void conv3x3x_kernel(const sv_geom g, const
                 if constexpr (i == 4) read_p(tn, ks, f);
                 __builtin_amdgcn_sched_barrier(0);
             });
+#ifdef SV_X3_BARRIER_EVERY_TAP      // experiment
+            if constexpr (t != 1 && t != 4 && t != 7) {
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+            }
+#endif
             if constexpr (t == 1 || t == 4 || t == 7) {
                 constexpr int n = t == 1 ? SCHED.vm_b1 : t == 4 ? SCHED.vm_b4 : SCHED.vm_b7;
 #ifdef SV_X3_STAMP
@@ -526,6 +534,10 @@ __global__ __launch_bounds__(256, 1) void conv3x3x_kernel(const sv_geom g, const
             // (the per-wave sums need no clearing: every address is written once per item; the flush of item i and the
             //  writes of item i + 1 are separated by the chunk loop's barriers)
             asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+#ifdef SV_X3_SYNC_AROUND_EPILOGUE      // experiment
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __syncthreads();
+#endif
             const int n0 = cur.n0, gr0 = cur.gr0;
 #ifdef SV_X3_STAMP
             { const uint64_t now = __builtin_amdgcn_s_memtime(); st_loop += now - st_mark; st_mark = now; }
@@ -551,6 +563,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3x_kernel(const sv_geom g, const
 #undef SV_EPI_STAMP_IN
             }
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#ifdef SV_X3_SYNC_AROUND_EPILOGUE
+            __syncthreads();
+#endif
 #ifdef SV_X3_STAMP
             { const uint64_t now = __builtin_amdgcn_s_memtime(); st_epi += now - st_mark; st_mark = now; }
 #endif
