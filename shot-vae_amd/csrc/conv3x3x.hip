@@ -634,12 +634,15 @@ int launch_x2(const sv_geom* g, const sv_igemm_args* a, hipStream_t s) {
 // Returns 1 and sets *rc when the geometry is a wide bf16 stride-1 3x3 convolution with 160-channel tiles.
 // (The caller, sv_conv3x3w_try, has already checked the stride-1 3x3 / tap-order / size conditions; fwd = canonical taps.)
 int sv_conv3x3x_try(const sv_geom* g, const sv_igemm_args* a, bool fwd, hipStream_t s, int* rc) {
-    // Opt-in (SV_CONV3X3X=1; read per call: the tests toggle it).  Faster than conv3x3w on every WRN-28-10 body shape and
-    // bitwise equal to it in isolation (tools/x3_stress.py), but inside the two-stream training step ~5 % of the config-4
-    // bench runs end in a non-finite loss (tools/cfg4_repeat.sh; 0 of 40 with conv3x3w) -- an unresolved race, so it is not
-    // the default.
+    // Default for 160-channel tiles; SV_CONV3X3X=0 (or SV_NO_CONV3X3X) falls back to conv3x3w (read per call: tests, A/B).
+    // History: the first persistent version lost ~5 % of the config-4 training runs to a non-finite loss -- its prologue
+    // counted on the oldest (HBM) register loads to retire before 18 younger (L2) LDS-DMA instructions; the two kinds do not
+    // share one completion order.  With the prologue draining the queue: 140 training runs, 1 300 bitwise comparisons
+    // against conv3x3w and 900 launches under concurrent HBM load without a difference (tools/cfg4_repeat.sh,
+    // x3_stress.py, load_stress.py).  The waits inside the K loop still count across both kinds, with a whole chunk
+    // (~7 k cycles) of lead.
     const char* on = getenv("SV_CONV3X3X");
-    if (!on || on[0] == '0') return 0;
+    if ((on && on[0] == '0') || getenv("SV_NO_CONV3X3X")) return 0;
     if (g->N % 160 != 0 || g->Cin % 32 != 0 || g->Cin < 96) return 0;
     *rc = fwd ? launch_x2<false>(g, a, s) : launch_x2<true>(g, a, s);
     return 1;

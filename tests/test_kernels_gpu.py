@@ -193,6 +193,7 @@ def test_conv3x3_wide_mfma(case, monkeypatch):
     activation-backward epilogue (reversed tap order).  (The dispatcher only picks this kernel for grids of at least
     one block per CU; SV_W3_MIN_BLOCKS lowers that bound for these small parity shapes.)"""
     monkeypatch.setenv("SV_W3_MIN_BLOCKS", "1")
+    monkeypatch.setenv("SV_CONV3X3X", "0")          # (the 160-channel-tile shapes would otherwise take conv3x3x.hip)
     test_conv_forward_fused("bf16", case)
     test_conv_dgrad_with_activation_backward("bf16", case)
 
@@ -200,8 +201,8 @@ def test_conv3x3_wide_mfma(case, monkeypatch):
 @pytest.mark.parametrize("case", [(4, 160, 160, 8, 3, 1, 1), (3, 160, 320, 32, 3, 1, 1), (4, 640, 640, 8, 3, 1, 1),
                                   (2, 320, 160, 16, 3, 1, 1), (72, 160, 160, 32, 3, 1, 1), (70, 96, 320, 16, 3, 1, 1)])
 def test_conv3x3_one_wave_per_simd(case, monkeypatch):
-    """The gap-scheduled, persistent one-block-per-CU variant of the wide kernel (conv3x3x.hip, opt-in with
-    SV_CONV3X3X=1): the three image sizes, odd / even chunk counts, one and several channel tiles, blocks with one,
+    """The gap-scheduled, persistent one-block-per-CU variant of the wide kernel (conv3x3x.hip, the default for
+    160-channel tiles): the three image sizes, odd / even chunk counts, one and several channel tiles, blocks with one,
     two and three items (the last two cases: 288 / 140 items on 256 blocks); forward with every fusion and the data gradient
     with the activation-backward epilogue."""
     monkeypatch.setenv("SV_W3_MIN_BLOCKS", "1")
