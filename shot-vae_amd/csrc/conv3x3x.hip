@@ -144,8 +144,22 @@ constexpr XSched make_xsched() {
         return cnt;
     };
     auto index_of = [&](int code) { for (int i = 0; i < nv; ++i) if (order[i] == code) return i; return -1; };
+    // Waits for REGISTER loads count only the younger register loads: LDS-DMA instructions retire out of order with
+    // respect to older register loads (a younger weight copy may leave the counter first), so they must not be relied
+    // upon to keep it up.  (The price: such a wait also drains every DMA older than those register loads.)
+    auto since_reg = [&](int idx, int p) {
+        int cnt = 0;
+        for (int i = idx + 1; i < nv; ++i) if (order[i] >= 3000) ++cnt;
+        for (int i = 0; i < nv; ++i) if (pos[i] < p && order[i] >= 3000) ++cnt;
+        return cnt;
+    };
+#ifdef SV_X3_COUNT_ALL_VMEM
     for (int sl = 0; sl < X_HI; ++sl) S.vm_slot[sl] = since(index_of(3000 + sl), find_item(4000 + sl), true);
     S.vm_coef = since(index_of(3503), find_item(4500), true);
+#else
+    for (int sl = 0; sl < X_HI; ++sl) S.vm_slot[sl] = since_reg(index_of(3000 + sl), find_item(4000 + sl));
+    S.vm_coef = since_reg(index_of(3503), find_item(4500));
+#endif
     // barrier after tap 1: (this, 3), (this, 4) from the previous chunk's tap 8 and (this, 5) from tap 0 have landed
     S.vm_b1 = since(index_of(2000 + 3 * 0 + 2), 40 * 8, false);
     // barrier after tap 4: (this, 6..8) from taps 2, 3

@@ -390,8 +390,14 @@ constexpr WSched<HI> make_wsched() {
         for (int gi = 0; gi < 180; ++gi)
             for (int j = 0; j < 3; ++j) if (S.item[gi][j] == 4000 + sl) wpos = gi * 4 + j;
         for (int i = 0; i < nv; ++i) if (order[i] == 3000 + sl) lpos = i;
+#ifdef SV_WG3_COUNT_REG_ONLY     // (conv3x3x.hip's rule: count only the younger REGISTER loads; measured here: see DESIGN.md)
+        int cnt = 0;
+        for (int i = lpos + 1; i < nv; ++i) if (order[i] / 1000 == 3) ++cnt;
+        for (int i = 0; i < nv; ++i) if (pos_gap[i] < wpos && order[i] / 1000 == 3) ++cnt;
+#else
         int cnt = nv - 1 - lpos;                                   // issued after the load, to the end of its iteration
         for (int i = 0; i < nv; ++i) if (pos_gap[i] < wpos) ++cnt; // and from the top of this one to the wait
+#endif
         S.vm_wait[sl] = cnt;
         S.ok = S.ok && wpos >= 0 && lpos >= 0;
     }
