@@ -6,7 +6,7 @@ keys are the reference's ``state_dict`` names (``data_parallel=False`` layout),
 so that it shares nothing structurally with the reference's nn.Module code.
 
 Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline``
-leg may import it.  The product package (``shot-vae_amd/``) never does; the
+leg may import it.  The product package (``shot_vae_amd/``) never does; the
 product path fails loudly when the HIP extension is missing.
 
 Parity pin: the reference has no tests or golden vectors of its own

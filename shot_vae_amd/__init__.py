@@ -1,9 +1,12 @@
-"""Import shim: the package sources live in ``shot-vae_amd/`` (a directory name Python cannot
-import directly).  ``import shot_vae_amd`` resolves here and continues in that directory."""
-import os as _os
-
-_real = _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "shot-vae_amd")
-__path__ = [_real]
-with open(_os.path.join(_real, "__init__.py")) as _f:
-    exec(compile(_f.read(), _os.path.join(_real, "__init__.py"), "exec"))
-del _f
+"""shot_vae_amd: MI355X-native (gfx950 HIP) implementation of the SHOT-VAE training hot path behind
+the reference's Python API (FengHZ/SHOT-VAE: shot_vae_model/vae.py, lib/criterion.py,
+lib/utils/mixup.py, the step of main_shot_vae.py)."""
+from .vae import VariationalAutoEncoder          # noqa: F401
+from .criterion import VAECriterion, ClsCriterion, continuous_posterior_loss   # noqa: F401
+from .mixup import mixup_vae_data, label_smoothing, optimal_match_index        # noqa: F401
+from .optim import FlatSGD                        # noqa: F401
+from .train import (train_step, train_step_overlapped, GraphedTrainStep, DeviceRng, schedule,   # noqa: F401
+                    alpha_schedule, m2_train_step)
+from .data import DeviceDataset, ssl_split      # noqa: F401
+from .smooth import (SmoothVAE, svhn_VAE, mnist_VAE, SmoothELBOLoss, smooth_train_step,      # noqa: F401
+                     GraphedSmoothStep)

@@ -103,7 +103,7 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise ShotVaeHipError(
                 "libshotvae_hip.so is missing (%s): run `python -c 'import __graft_entry__ as g; g.build()'` "
-                "or `make -C shot-vae_amd/csrc`.  There is no CPU / PyTorch fallback." % LIB_PATH)
+                "or `make -C shot_vae_amd/csrc`.  There is no CPU / PyTorch fallback." % LIB_PATH)
         L = C.CDLL(LIB_PATH)
         for name, args in _PROTOS.items():
             fn = getattr(L, name)

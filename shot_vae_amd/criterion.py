@@ -19,7 +19,7 @@ def _st():
 def _need_gpu(*ts):
     for t in ts:
         if t is not None and not t.is_cuda:
-            raise L.ShotVaeHipError("shot-vae_amd criteria run on an MI355X only (no CPU fallback)")
+            raise L.ShotVaeHipError("shot_vae_amd criteria run on an MI355X only (no CPU fallback)")
 
 
 class _ElboFn(torch.autograd.Function):

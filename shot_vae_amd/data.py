@@ -29,7 +29,7 @@ class DeviceDataset:
         """index: int64 device tensor [B].  Returns (images, labels): images fp32 NCHW in [0, 1] (the model's input), or,
         with nhwc_dtype ("bf16" / "fp32"), the NHWC [B][H][W][cpad] tensor the stem convolution reads."""
         if not self.images.is_cuda:
-            raise L.ShotVaeHipError("shot-vae_amd data pipeline runs on an MI355X only (no CPU fallback)")
+            raise L.ShotVaeHipError("shot_vae_amd data pipeline runs on an MI355X only (no CPU fallback)")
         index = index.to(self.images.device, torch.int64).contiguous()
         B = index.numel()
         _, H, W, Cc = self.images.shape

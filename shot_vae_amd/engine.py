@@ -285,7 +285,7 @@ class Engine:
         """Apply a torch `_apply` function (device move) to the flat buffers."""
         new = fn(self.param)
         if new.dtype != torch.float32:
-            raise TypeError("shot-vae_amd keeps fp32 master weights; choose the compute dtype with "
+            raise TypeError("shot_vae_amd keeps fp32 master weights; choose the compute dtype with "
                             "compute_dtype='bf16'|'fp32' instead of .half()/.bfloat16()")
         self.param, self.grad = new, fn(self.grad)
         self.bufs, self.nbt = fn(self.bufs), fn(self.nbt)
@@ -331,7 +331,7 @@ class Engine:
 
     def _require_gpu(self, t):
         if not t.is_cuda or not self.param.is_cuda:
-            raise L.ShotVaeHipError("shot-vae_amd runs on an MI355X only (HIP kernels, no CPU fallback): "
+            raise L.ShotVaeHipError("shot_vae_amd runs on an MI355X only (HIP kernels, no CPU fallback): "
                                     "move the model and its inputs to cuda first")
         L.lib()
 

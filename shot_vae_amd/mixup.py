@@ -21,7 +21,7 @@ def _st():
 
 def _lerp(a, index, lam, exp_space):
     if not a.is_cuda:
-        raise L.ShotVaeHipError("shot-vae_amd mixup runs on an MI355X only (no CPU fallback)")
+        raise L.ShotVaeHipError("shot_vae_amd mixup runs on an MI355X only (no CPU fallback)")
     a = a.contiguous().float()
     out = torch.empty_like(a)
     B = a.shape[0]

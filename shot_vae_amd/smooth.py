@@ -88,7 +88,7 @@ class _ConvLikeFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, master, bias, layer, relu_in, dtype):
         if not x.is_cuda:
-            raise L.ShotVaeHipError("shot-vae_amd runs on an MI355X only (no CPU fallback)")
+            raise L.ShotVaeHipError("shot_vae_amd runs on an MI355X only (no CPU fallback)")
         code, tdt = (L.SV_BF16, torch.bfloat16) if dtype == "bf16" else (L.SV_F32, torch.float32)
         x = x.contiguous()
         B, dev = x.shape[0], x.device

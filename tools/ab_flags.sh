@@ -8,5 +8,5 @@ run() {
     python3 "$R/bench.py" --steps 30 --warmup 10 --no-cpu-baseline 2>/dev/null | tail -1 | cut -c1-200
 }
 echo "== baseline build"; run
-make -C "$R/shot-vae_amd/csrc" clean > /dev/null; make -C "$R/shot-vae_amd/csrc" -j8 EXTRA="$1" 2>&1 | grep -E "error" 
+make -C "$R/shot_vae_amd/csrc" clean > /dev/null; make -C "$R/shot_vae_amd/csrc" -j8 EXTRA="$1" 2>&1 | grep -E "error" 
 echo "== with $1"; run

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Timing ablations of conv3x3p (diagnostic builds; results are numerically wrong by construction).
-cd "$(dirname "$0")/../shot-vae_amd/csrc" || exit 1
+cd "$(dirname "$0")/../shot_vae_amd/csrc" || exit 1
 FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -munsafe-fp-atomics -I../../include -Wno-unused-function"
 for v in "$@"; do
   D=""; for m in $v; do [ "$m" != "BASE" ] && D="$D -DSV_C3P_$m"; done

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Timing ablations of conv3x3w (diagnostic builds; results are numerically wrong by construction).
 # usage: tools/w3_ablate.sh "NO_MFMA" "NO_W" ...   (each argument = one build, space-separated macro suffixes inside)
-cd "$(dirname "$0")/../shot-vae_amd/csrc" || exit 1
+cd "$(dirname "$0")/../shot_vae_amd/csrc" || exit 1
 FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -munsafe-fp-atomics -I../../include -Wno-unused-function"
 for v in "$@"; do
   D=""; for m in $v; do [ "$m" != "BASE" ] && D="$D -DSV_W3_$m"; done

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Timing experiments on conv3x3x (diagnostic builds).  usage: tools/x3_ablate.sh "<flags>" "<flags>" ...
-cd "$(dirname "$0")/../shot-vae_amd/csrc" || exit 1
+cd "$(dirname "$0")/../shot_vae_amd/csrc" || exit 1
 FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -munsafe-fp-atomics -I../../include -Wno-unused-function"
 for v in "$@"; do
   [ "$v" = "BASE" ] && D="" || D="$v"
