@@ -168,6 +168,12 @@ int sv_post_fwd(const float* mu, const float* ls, const float* mu_t, const float
 int sv_post_bwd(const float* mu, const float* ls, const float* mu_t, const float* sigma_t, int B, int D,
                 const float* gout, float* dmu, float* dls, void* stream);
 
+/* ---- top-1 / top-k accuracy counts of valid() / test() (main_shot_vae.py:441-447, :493-499): for every row b the rank
+ * of class label[b] among score[b][0..K) (descending; ties: lower index first); hits[0] += #(rank < 1),
+ * hits[1] += #(rank < k).  score may be exp(disc_log_alpha) or disc_log_alpha itself (monotone).  hits: 2 floats,
+ * accumulated (+=) across calls = across the batches of an epoch.                                              */
+int sv_topk_hits(const float* score, const int64_t* label, int B, int K, int k, float* hits, void* stream);
+
 /* ---- K17 mixup / label smoothing gather-lerp (lib/utils/mixup.py:22-25,36-39) --------------------
  * out[b] = lam*f(a[b]) + (1-lam)*f(a[index[b]]), f = exp when `exp_space` else identity.           */
 int sv_mix_lerp(const float* a, const int64_t* index, float lam, const float* lam_dev, int B, int64_t row,
@@ -210,16 +216,32 @@ int sv_prof_collect(int max_tags, double* ms, int* count);
  * halo_vectors = 3 or 4 (halo 16-byte vectors per thread; 4 for 32 x 32 maps).  items = int[180][3]: for the gap behind
  * every MFMA of one tile iteration (4 phases x 45) up to three item codes, 0 = none, 1000 + 41*vector + step = one
  * single-instruction step of the halo transform (step 40 = its LDS store), 2000 + k = dy DMA instruction k,
- * 3000 + v = global load of halo vector v, 4000 + v = the vmcnt wait before vector v's first step.
- * waits = int[5]: the vmcnt of those waits (vector 0..3) and of the wait before the barrier.          */
+ * 3000 + v = global load of halo vector v (tile after next, into the second register set), 5000 + 4*v + d = the move of
+ * dword d of vector v from the second register set into the first.  The kernel has no counted vmcnt wait (one vmcnt(0)
+ * in front of its barrier, which follows gap 134): waits = int[5], [0..3] = 0, [4] = the gap of the last VMEM instruction
+ * before that barrier.                                                                                      */
 int sv_debug_wgrad_tile_program(int halo_vectors, int* items, int* waits);
 
 /* The chunk program of the wide forward / data-gradient kernel (conv3x3x.hip): items = int[180][6], the gap behind every
  * MFMA of one 32-channel chunk (9 taps x 20).  Codes: 1000 + 41*vector + step (BatchNorm pass), 2000 + 3*slice + i (weight
  * DMA instruction; slice 0..3 = this chunk's taps 5..8, 4..8 = the next chunk's taps 0..4), 3000 + v (halo load),
  * 3500 + q (coefficient load), 4000 + v / 4500 (vmcnt waits), 5000 (stage flip).  waits = int[10]: vmcnt of the waits
- * before vectors 0..5, before the coefficients, and before the barriers after taps 1, 4, 7.                          */
+ * before vectors 0..5, before the coefficients (each = the YOUNGER REGISTER LOADS only), and before the barriers after
+ * taps 1, 4, 7 (each = the younger LDS-DMA instructions only: zero).                                               */
 int sv_debug_conv_chunk_program(int* items, int* waits);
+
+/* ---- dispatcher options (process-wide; set them between launches, not concurrently with them) --------------------
+ * SV_OPT_DISABLE_MASK: OR of SV_K_* bits; a set bit routes the layers a specialised kernel would take to the next more
+ * general one (sv_igemm: conv3x3x -> conv3x3w -> conv3x3 / conv3x3p / conv3x3m -> the generic gather-GEMM; sv_wgrad:
+ * wgrad3x3w -> wgrad3x3 -> the generic weight-gradient kernel).  Default 0.  The parity tests use it to compare every
+ * specialised kernel with the general one on the same inputs (conv3x3x against conv3x3w bit for bit).
+ * SV_OPT_WIDE_MIN_BLOCKS: minimum grid (blocks) for which the 256-pixel wide-tile kernels are chosen; default 256 (one
+ * block per CU).  Tests set 1 to reach those kernels at small batch sizes.                                          */
+enum { SV_OPT_DISABLE_MASK = 0, SV_OPT_WIDE_MIN_BLOCKS = 1 };
+enum { SV_K_CONV3X3 = 1, SV_K_CONV3X3P = 2, SV_K_CONV3X3M = 4, SV_K_CONV3X3W = 8, SV_K_CONV3X3X = 16,
+       SV_K_WGRAD3X3 = 32, SV_K_WGRAD3X3W = 64, SV_K_IGEMM_KV2 = 128 };
+int sv_set_option(int key, int value);
+int sv_get_option(int key);          /* -1 for an unknown key */
 
 int sv_version(void);
 const char* sv_last_error(void);

@@ -6,7 +6,8 @@ from .criterion import VAECriterion, ClsCriterion, continuous_posterior_loss   #
 from .mixup import mixup_vae_data, label_smoothing, optimal_match_index        # noqa: F401
 from .optim import FlatSGD                        # noqa: F401
 from .train import (train_step, train_step_overlapped, GraphedTrainStep, DeviceRng, schedule,   # noqa: F401
-                    alpha_schedule, m2_train_step)
+                    alpha_schedule, m2_train_step, apply_update, inference_kl)
+from .evaluate import Evaluator, evaluate       # noqa: F401
 from .data import DeviceDataset, ssl_split      # noqa: F401
 from .smooth import (SmoothVAE, svhn_VAE, mnist_VAE, SmoothELBOLoss, smooth_train_step,      # noqa: F401
                      GraphedSmoothStep)

@@ -60,6 +60,7 @@ _PROTOS = {
     "sv_elbo_bwd": [P, P, I64, P, P, P, I, I, I, I, F, P, P, P, P, P, P],
     "sv_cls_fwd": [P, P, P, I, I, P, P],
     "sv_cls_bwd": [P, P, I, I, P, P, P],
+    "sv_topk_hits": [P, P, I, I, I, P, P],
     "sv_post_fwd": [P, P, P, P, I, I, P, P],
     "sv_post_bwd": [P, P, P, P, I, I, P, P, P, P],
     "sv_mix_lerp": [P, P, F, P, I, I64, I, P, P],
@@ -74,8 +75,13 @@ _PROTOS = {
     "sv_prof_collect": [I, C.POINTER(C.c_double), C.POINTER(C.c_int)],
     "sv_debug_wgrad_tile_program": [I, C.POINTER(C.c_int), C.POINTER(C.c_int)],
     "sv_debug_conv_chunk_program": [C.POINTER(C.c_int), C.POINTER(C.c_int)],
+    "sv_set_option": [I, I],
+    "sv_get_option": [I],
     "sv_version": [],
 }
+OPT_DISABLE_MASK, OPT_WIDE_MIN_BLOCKS = 0, 1
+K_CONV3X3, K_CONV3X3P, K_CONV3X3M, K_CONV3X3W, K_CONV3X3X, K_WGRAD3X3, K_WGRAD3X3W, K_IGEMM_KV2 = (
+    1, 2, 4, 8, 16, 32, 64, 128)
 EXPORTS = sorted(list(_PROTOS) + ["sv_last_error"])
 
 _lib = None
@@ -113,6 +119,26 @@ def lib():
         L.sv_last_error.restype = C.c_char_p
         _lib = L
     return _lib
+
+
+class options:
+    """with options(disable=K_CONV3X3X, wide_min_blocks=1): ...  -- dispatcher options for the duration of a block
+    (tests / tools: compare a specialised kernel with the general one)."""
+
+    def __init__(self, disable=None, wide_min_blocks=None):
+        self.new = {OPT_DISABLE_MASK: disable, OPT_WIDE_MIN_BLOCKS: wide_min_blocks}
+
+    def __enter__(self):
+        self.old = {k: lib().sv_get_option(k) for k in self.new}
+        for k, v in self.new.items():
+            if v is not None:
+                call("sv_set_option", k, int(v))
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self.old.items():
+            call("sv_set_option", k, v)
+        return False
 
 
 def call(name, *args):

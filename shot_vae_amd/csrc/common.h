@@ -54,6 +54,8 @@ __device__ __forceinline__ int tap_off(uint64_t p, int t) { return (int)((p >> (
 
 // host side ------------------------------------------------------------------------------------------
 void sv_set_error(const char* fmt, ...);
+bool sv_disabled(int kernel_bit);        // sv_set_option(SV_OPT_DISABLE_MASK, ...): a specialised kernel is switched off
+int sv_wide_min_blocks();                // sv_set_option(SV_OPT_WIDE_MIN_BLOCKS, ...)
 int sv_check_launch(const char* what);
 void sv_prof_begin(hipStream_t s);
 void sv_prof_end(hipStream_t s);

@@ -749,7 +749,7 @@ int launch_p(const sv_geom* g, const sv_igemm_args* a, hipStream_t s) {
     constexpr int HV = LROWS * (W + 2) * VPP, HI = (HV + 255) / 256, HPIX = (HI * 256 + VPP - 1) / VPP;
     const int nT = g->B * g->Hin / TR;
     const int nNt = g->N / 32;
-    static const int target = getenv("SV_C3P_BLOCKS") ? atoi(getenv("SV_C3P_BLOCKS")) : 512;
+    constexpr int target = 512;       // persistent blocks (two per CU): fewer / more measured slower
     int chunks = (target + nNt - 1) / nNt;
     if (chunks > nT) chunks = nT;
     const int tiles_per = (nT + chunks - 1) / chunks;
@@ -819,7 +819,7 @@ int sv_conv3x3_try(const sv_geom* g, int dtype, const sv_igemm_args* a, hipStrea
         if (g->phase[0].dy[t] < -1 || g->phase[0].dy[t] > 1 || g->phase[0].dx[t] < -1 || g->phase[0].dx[t] > 1) return 0;
     const int TR = 128 / g->Win;
     if ((g->B * g->Hin) % TR != 0) return 0;
-    static const bool no_persist = getenv("SV_NO_CONV3X3P") != nullptr;
+    const bool no_persist = sv_disabled(SV_K_CONV3X3P);
     if (!no_persist && dtype == SV_BF16 && (g->Cin == 32 || g->Cin == 64)) {
         // whole weight slab resident in LDS: persistent software-pipelined kernel
         *rc = g->Cin == 32 ? launch_pw<bf16, 1>(g, a, s) : launch_pw<bf16, 2>(g, a, s);
@@ -830,7 +830,7 @@ int sv_conv3x3_try(const sv_geom* g, int dtype, const sv_igemm_args* a, hipStrea
         return 1;
     }
     if (sv_conv3x3w_try(g, dtype, a, s, rc)) return 1;       // wide MFMA-bound layers: conv3x3w.hip
-    static const bool no_multi = getenv("SV_NO_CONV3X3M") != nullptr;
+    const bool no_multi = sv_disabled(SV_K_CONV3X3M);
     if (!no_multi && dtype == SV_BF16 && g->Cin >= 96) {
         // MFMA-bound wide layers: multi-tile kernel when the grid still fills the chip
         // (measured at B=512: 160 ch 707 vs 796 us; the 64-channel-tile variant <4,4> lost to the 128-pixel kernel

@@ -392,19 +392,13 @@ int launch_w3(const sv_geom* g, const sv_igemm_args* a, hipStream_t s) {
     using C = WCfg<NF, WLOG>;
     const int nT = g->B * g->Hin / C::TR, nNt = g->N / C::BN;
     const int grid = 8 * ((nT + 7) / 8) * nNt;
-    static const bool one_per_cu = getenv("SV_W3_ONE_BLOCK") != nullptr;      // A/B: does the second block of a CU pay?
-    const size_t lds = one_per_cu ? (size_t)100 * 1024 : (size_t)C::LDS;
+    const size_t lds = (size_t)C::LDS;
     static bool optin = false;
     if (!optin) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3w_kernel<NF, WLOG, REV>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return sv_check_launch("hipFuncSetAttribute(conv3x3w)");
         optin = true;
-        if (getenv("SV_W3_OCC")) {
-            int nb = -1;
-            hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(&conv3x3w_kernel<NF, WLOG, REV>), 256, lds);
-            fprintf(stderr, "conv3x3w<%d,%d,%d>: lds %zu B, max active blocks per CU %d (err %d)\n", NF, WLOG, (int)REV, lds, nb, (int)e);
-        }
     }
     sv_prof_begin(s);
     hipLaunchKernelGGL((conv3x3w_kernel<NF, WLOG, REV>), dim3(grid), dim3(256), lds, s, *g, *a);
@@ -426,17 +420,16 @@ int launch_w2(const sv_geom* g, const sv_igemm_args* a, hipStream_t s) {
 // Returns 1 and sets *rc when the geometry is a wide bf16 stride-1 3x3 convolution this kernel covers.
 // (The caller, sv_conv3x3_try, has already checked the generic stride-1 3x3 / square-image conditions.)
 int sv_conv3x3w_try(const sv_geom* g, int dtype, const sv_igemm_args* a, hipStream_t s, int* rc) {
-    static const bool off = getenv("SV_NO_CONV3X3W") != nullptr;
-    if (off || dtype != SV_BF16) return 0;
+    if (sv_disabled(SV_K_CONV3X3W) || dtype != SV_BF16) return 0;
     if (g->Cin < 96 || g->Cin % 32 != 0 || g->ldx % 8 != 0 || g->ldo % 8 != 0) return 0;
     if (g->N % 160 != 0 && g->N % 64 != 0) return 0;
     const int TR = 256 / g->Win;
     if ((g->B * g->Hin) % TR != 0) return 0;
     // 256-pixel x 160/128/64-channel tiles: below one block per CU the small-tile kernels of conv3x3.hip are faster
-    // (measured: WRN-28-2 stage 3 as 128 blocks of 128 channels, 38 vs 24 us); SV_W3_MIN_BLOCKS overrides (tests use 1).
+    // (measured: WRN-28-2 stage 3 as 128 blocks of 128 channels, 38 vs 24 us); sv_set_option(SV_OPT_WIDE_MIN_BLOCKS) moves
+    // the bound (tests use 1 to reach these kernels at small batch sizes).
     // Narrower channel tiles are taken only when the wider ones do not fill the chip.
-    const char* mb = getenv("SV_W3_MIN_BLOCKS");              // (read per call: the tests toggle it)
-    const int min_blocks = mb ? atoi(mb) : 256;
+    const int min_blocks = sv_wide_min_blocks();
     const int64_t nTiles = g->B * g->Hin / TR;
     int bn = 0;
     if (g->N % 160 == 0) bn = 160;
@@ -444,8 +437,6 @@ int sv_conv3x3w_try(const sv_geom* g, int dtype, const sv_igemm_args* a, hipStre
     else if (nTiles * (g->N / 64) >= min_blocks && (!a->pro_scale || min_blocks <= 1)) bn = 64;   // measured on 128 ch at
                                         // 8x8: data gradient 21.6 vs 24.7 us, forward (BatchNorm pass) 26.7 vs 25.8 us
     else if (g->N % 128 == 0 && min_blocks <= 1) bn = 128;
-    static const bool no64 = getenv("SV_W3_NO_BN64") != nullptr;
-    if (bn == 64 && no64) bn = 0;
     if (bn == 0 || nTiles * (g->N / bn) < min_blocks) return 0;
     if ((int64_t)g->B * g->Hin * g->Win * g->ldx * 2 >= ((int64_t)1 << 31)) return 0;
     if ((int64_t)g->N * 9 * g->Cin * 2 >= ((int64_t)1 << 31)) return 0;

@@ -76,10 +76,11 @@ constexpr XSched make_xsched() {
     bool ok = true;
     // weight DMA (six ring slots): slice codes 2000 + 3 s + i, s = 0..8 meaning
     //   s = 0: (this chunk, tap 5) in tap 0;  s = 1, 2: (this, 6), (this, 7) in tap 2;  s = 3: (this, 8) in tap 3;
-    //   s = 4, 5: (next, 0), (next, 1) in tap 5;  s = 6: (next, 2) in tap 6;  s = 7, 8: (next, 3), (next, 4) in tap 8
-    // -- each early in the three-step window its slot's previous fragments allow, in the read-free gaps 0, 2, 4 (10, 12, 14)
+    //   s = 4: (next, 0) in tap 5;  s = 5, 6: (next, 1), (next, 2) in tap 6;  s = 7, 8: (next, 3), (next, 4) in tap 8
+    // -- each inside the three-step window its slot's previous fragments allow, in the read-free gaps 0, 2, 4 (10, 12, 14);
+    //    the second half of tap 5 stays free for the halo re-loads that follow the barrier after tap 4 (below)
     {
-        const int tap_of[9] = {0, 2, 2, 3, 5, 5, 6, 8, 8}, first_gap[9] = {0, 0, 10, 0, 0, 10, 0, 0, 10};
+        const int tap_of[9] = {0, 2, 2, 3, 5, 6, 6, 8, 8}, first_gap[9] = {0, 0, 10, 0, 0, 10, 0, 0, 10};
         for (int sl = 0; sl < 9; ++sl)
             for (int i = 0; i < 3; ++i) {
                 const int gp = 20 * tap_of[sl] + first_gap[sl] + 2 * i;
@@ -89,20 +90,26 @@ constexpr XSched make_xsched() {
     }
     ok = put(20 * 8 + 0, 5000) && ok;          // before the first fragment read of tap 8 (gap 1)
     // the BatchNorm pass starts with tap 1 (the coefficients were requested at the end of the previous chunk's pass):
-    // two or three steps per gap next to fragment reads, four otherwise; a halo register is re-loaded in the first read-free,
-    // VMEM-free gap after its vector's store, the coefficients after the last vector
+    // two or three steps per gap next to fragment reads, four otherwise; a halo register is re-loaded in a read-free,
+    // VMEM-free gap after its vector's store, the coefficients after the last vector.
+    // Every barrier of the chunk waits with vmcnt(0) (a wait for LDS-DMA counts only the younger LDS-DMA, and there is
+    // none: see the bookkeeping below), so it also drains the register loads in flight: those are therefore issued in the
+    // windows that FOLLOW a barrier (gaps 41..62 behind tap 1's, 101..144 behind tap 4's) and have 1 000+ cycles to land
+    // before the next one; none is issued in tap 8 / tap 0, so that after the barrier behind tap 7 every register of the
+    // chunk after next has arrived (the compiler is told so there: nothing is pending across the loop's back edge)
     int m = 0, next_reload = 0, coef_q = 0;
     const int nsteps = X_HSTEPS * X_HI;
     for (int gp = 20; gp < 160; ++gp) {
         const int mm = gp % 20;
+        const bool window = (gp > 40 && gp <= 62) || (gp > 100 && gp <= 144);
         const bool fre = !x_gap_has_read(mm) && !used[gp];
-        if (fre && next_reload < X_HI && m >= X_HSTEPS * (next_reload + 1)) {
+        if (fre && window && next_reload < X_HI && m >= X_HSTEPS * (next_reload + 1)) {
             ok = put(gp, 3000 + next_reload) && ok;
             used[gp] = 1;
             ++next_reload;
             continue;
         }
-        if (fre && m >= nsteps && next_reload == X_HI && coef_q < 4) {
+        if (fre && window && m >= nsteps && next_reload == X_HI && coef_q < 4) {
             ok = put(gp, 3500 + coef_q) && ok;
             used[gp] = 1;
             ++coef_q;
@@ -132,44 +139,35 @@ constexpr XSched make_xsched() {
             for (int j = 0; j < 6; ++j) if (S.item[gp][j] == code) return gp * 8 + j;
         return -1;
     };
-    // VMEM issued after order[idx] until position p of the NEXT iteration (p < 0: until the end of this one + |p| ...)
-    auto since = [&](int idx, int p, bool wrap) {
-        int cnt = 0;
-        if (wrap) {
-            cnt = nv - 1 - idx;
-            for (int i = 0; i < nv; ++i) if (pos[i] < p) ++cnt;
-        } else {
-            for (int i = idx + 1; i < nv; ++i) if (pos[i] < p) ++cnt;
-        }
-        return cnt;
-    };
     auto index_of = [&](int code) { for (int i = 0; i < nv; ++i) if (order[i] == code) return i; return -1; };
-    // Waits for REGISTER loads count only the younger register loads: LDS-DMA instructions retire out of order with
-    // respect to older register loads (a younger weight copy may leave the counter first), so they must not be relied
-    // upon to keep it up.  (The price: such a wait also drains every DMA older than those register loads.)
-    auto since_reg = [&](int idx, int p) {
+    // A hand-counted wait counts only YOUNGER INSTRUCTIONS OF THE SAME KIND: LDS-DMA and register loads do not retire in
+    // one common order (a younger weight copy may leave the counter before an older register load and vice versa), so
+    // instructions of the other kind must not be relied upon to keep the counter up.  (The price: such a wait also
+    // drains every older instruction of the other kind.)
+    auto since_reg = [&](int idx, int p) {                 // register loads after order[idx], wrapping to position p
         int cnt = 0;
         for (int i = idx + 1; i < nv; ++i) if (order[i] >= 3000) ++cnt;
         for (int i = 0; i < nv; ++i) if (pos[i] < p && order[i] >= 3000) ++cnt;
         return cnt;
     };
-#ifdef SV_X3_COUNT_ALL_VMEM
-    for (int sl = 0; sl < X_HI; ++sl) S.vm_slot[sl] = since(index_of(3000 + sl), find_item(4000 + sl), true);
-    S.vm_coef = since(index_of(3503), find_item(4500), true);
-#else
+    auto dma_between = [&](int idx, int p) {               // LDS-DMA instructions after order[idx] and before position p
+        int cnt = 0;
+        for (int i = idx + 1; i < nv; ++i) if (pos[i] < p && order[i] < 3000) ++cnt;
+        return cnt;
+    };
+    auto last_dma_before = [&](int p) { int l = -1; for (int i = 0; i < nv; ++i) if (pos[i] < p && order[i] < 3000) l = i; return l; };
     for (int sl = 0; sl < X_HI; ++sl) S.vm_slot[sl] = since_reg(index_of(3000 + sl), find_item(4000 + sl));
     S.vm_coef = since_reg(index_of(3503), find_item(4500));
-#endif
-    // barrier after tap 1: (this, 3), (this, 4) from the previous chunk's tap 8 and (this, 5) from tap 0 have landed
-    S.vm_b1 = since(index_of(2000 + 3 * 0 + 2), 40 * 8, false);
-    // barrier after tap 4: (this, 6..8) from taps 2, 3
-    S.vm_b4 = since(index_of(2000 + 3 * 3 + 2), 100 * 8, false);
-    // barrier after tap 7: (next, 0..2) from taps 5, 6
-    S.vm_b7 = since(index_of(2000 + 3 * 6 + 2), 160 * 8, false);
-#ifdef SV_X3_SAFE_WAITS      // experiment: every hand-counted wait becomes a full drain
-    for (int sl = 0; sl < X_HI; ++sl) S.vm_slot[sl] = 0;
-    S.vm_coef = S.vm_b1 = S.vm_b4 = S.vm_b7 = 0;
-#endif
+    // barrier after tap 1: (this, 3), (this, 4) from the previous chunk's tap 8 and (this, 5) from tap 0 have landed;
+    // after tap 4: (this, 6..8) from taps 2, 3;  after tap 7: (next, 0..2) from taps 5, 6.  Each barrier needs EVERY
+    // DMA issued before it (none is issued between the last slice it needs and the barrier), so the counts are zero
+    S.vm_b1 = dma_between(last_dma_before(40 * 8), 40 * 8);
+    S.vm_b4 = dma_between(last_dma_before(100 * 8), 100 * 8);
+    S.vm_b7 = dma_between(last_dma_before(160 * 8), 160 * 8);
+    S.ok = S.ok && index_of(2000 + 3 * 0 + 2) <= last_dma_before(40 * 8) && index_of(2000 + 3 * 3 + 2) <= last_dma_before(100 * 8) &&
+           index_of(2000 + 3 * 6 + 2) <= last_dma_before(160 * 8) && index_of(2000 + 3 * 5 + 2) <= last_dma_before(160 * 8);
+    // no register load after the barrier behind tap 7 (see above)
+    for (int i = 0; i < nv; ++i) if (order[i] >= 3000 && pos[i] >= 160 * 8) S.ok = false;
     return S;
 }
 
@@ -513,7 +511,22 @@ __global__ __launch_bounds__(256, 1) void conv3x3x_kernel(const sv_geom g, const
 #ifdef SV_X3_STAMP
                 const uint64_t sb0 = __builtin_amdgcn_s_memtime();
 #endif
-                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(n) : "memory");
+                if constexpr (t == 7) {
+                    // The halo / coefficient registers of the chunk after next were requested by assembly the compiler
+                    // cannot see through: to it they are defined the moment the load is issued.  Nothing it might do with
+                    // them later -- a copy on the loop's back edge, a spill into the AGPR half across the epilogue -- may
+                    // happen before the data has arrived.  This wait (vmcnt(0): all of them are older, the chunk program
+                    // issues none behind this barrier) is where it is told that they have
+                    static_assert(n == 0, "the barrier after tap 7 drains the queue");
+                    u32x4 h0 = rh[0], h1 = rh[1], h2 = rh[2], h3 = rh[3], h4 = rh[4], h5 = rh[5];
+                    f32x4 c0 = csc[0], c1 = csc[1], c2 = csh[0], c3 = csh[1];
+                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(h0), "+v"(h1), "+v"(h2), "+v"(h3), "+v"(h4), "+v"(h5),
+                                 "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3) :: "memory");
+                    rh[0] = h0; rh[1] = h1; rh[2] = h2; rh[3] = h3; rh[4] = h4; rh[5] = h5;
+                    csc[0] = c0; csc[1] = c1; csh[0] = c2; csh[1] = c3;
+                } else {
+                    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(n) : "memory");
+                }
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
 #ifdef SV_X3_STAMP
@@ -521,18 +534,6 @@ __global__ __launch_bounds__(256, 1) void conv3x3x_kernel(const sv_geom g, const
 #endif
             }
         });
-        // The halo / coefficient registers were requested by assembly the compiler cannot see through: to it they are
-        // defined the moment the load is issued.  Nothing it might do with them later -- a copy on the loop back-edge, a
-        // spill into the AGPR half across the epilogue -- may happen before the data has arrived: make sure it has, here,
-        // where the requests are at least two taps old (only the six DMA instructions of tap 8 are younger).
-        {
-            u32x4 h0 = rh[0], h1 = rh[1], h2 = rh[2], h3 = rh[3], h4 = rh[4], h5 = rh[5];
-            f32x4 c0 = csc[0], c1 = csc[1], c2 = csh[0], c3 = csh[1];
-            asm volatile("s_waitcnt vmcnt(6)" : "+v"(h0), "+v"(h1), "+v"(h2), "+v"(h3), "+v"(h4), "+v"(h5),
-                         "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3) :: "memory");
-            rh[0] = h0; rh[1] = h1; rh[2] = h2; rh[3] = h3; rh[4] = h4; rh[5] = h5;
-            csc[0] = c0; csc[1] = c1; csh[0] = c2; csh[1] = c3;
-        }
         par ^= 1;
         if (cc + 1 < nck) { cur = nxt; nxt = nn; }
 #ifdef SV_X3_STAMP
@@ -625,8 +626,7 @@ int launch_x4(const sv_geom* g, const sv_igemm_args* a, hipStream_t s) {
 template <int WLOG, bool REV>
 int launch_x3(const sv_geom* g, const sv_igemm_args* a, hipStream_t s) {
 #ifdef SV_X3_MODES      // (measured: -0.3 % forward, -2.6 % data gradient for 2.5x the build time -- not instantiated by default)
-    static const bool generic_only = getenv("SV_X3_GENERIC_EPILOGUE") != nullptr;        // A/B
-    if (!generic_only && !a->bias) {
+    if (!a->bias) {
         if (!REV && !a->ex && a->stats) return a->residual ? launch_x4<WLOG, REV, 2>(g, a, s) : launch_x4<WLOG, REV, 1>(g, a, s);
         if (REV && a->ex && !a->residual) return launch_x4<WLOG, REV, 3>(g, a, s);
     }
@@ -648,15 +648,13 @@ int launch_x2(const sv_geom* g, const sv_igemm_args* a, hipStream_t s) {
 // Returns 1 and sets *rc when the geometry is a wide bf16 stride-1 3x3 convolution with 160-channel tiles.
 // (The caller, sv_conv3x3w_try, has already checked the stride-1 3x3 / tap-order / size conditions; fwd = canonical taps.)
 int sv_conv3x3x_try(const sv_geom* g, const sv_igemm_args* a, bool fwd, hipStream_t s, int* rc) {
-    // Default for 160-channel tiles; SV_CONV3X3X=0 (or SV_NO_CONV3X3X) falls back to conv3x3w (read per call: tests, A/B).
+    // Default for 160-channel tiles; sv_set_option(SV_OPT_DISABLE_MASK, SV_K_CONV3X3X) falls back to conv3x3w (the two
+    // accumulate in the same order: tests compare them bitwise).
     // History: the first persistent version lost ~5 % of the config-4 training runs to a non-finite loss -- its prologue
     // counted on the oldest (HBM) register loads to retire before 18 younger (L2) LDS-DMA instructions; the two kinds do not
-    // share one completion order.  With the prologue draining the queue: 140 training runs, 1 300 bitwise comparisons
-    // against conv3x3w and 900 launches under concurrent HBM load without a difference (tools/cfg4_repeat.sh,
-    // x3_stress.py, load_stress.py).  The waits inside the K loop still count across both kinds, with a whole chunk
-    // (~7 k cycles) of lead.
-    const char* on = getenv("SV_CONV3X3X");
-    if ((on && on[0] == '0') || getenv("SV_NO_CONV3X3X")) return 0;
+    // share one completion order.  Since then every hand-counted wait of this file counts younger instructions of its own
+    // kind only (make_xsched; tests/test_abi_cpu.py checks the program).
+    if (sv_disabled(SV_K_CONV3X3X)) return 0;
     if (g->N % 160 != 0 || g->Cin % 32 != 0 || g->Cin < 96) return 0;
     *rc = fwd ? launch_x2<false>(g, a, s) : launch_x2<true>(g, a, s);
     return 1;

@@ -246,8 +246,7 @@ int launch_kv(const sv_geom* g, const sv_igemm_args* a, hipStream_t s) {
 template <typename T, int NT>
 int launch(const sv_geom* g, const sv_igemm_args* a, hipStream_t s) {
     // two sub-chunks per iteration when K is deep (>= 8 chunks in the shallowest phase) -- bf16 only (LDS budget)
-    static const bool no_kv2 = getenv("SV_NO_IGEMM_KV2") != nullptr;
-    if (sizeof(T) == 2 && NT <= 5 && !no_kv2) {
+    if (sizeof(T) == 2 && NT <= 5 && !sv_disabled(SV_K_IGEMM_KV2)) {
         int kmin = 1 << 30;
         for (int p = 0; p < g->nphase; ++p) kmin = min(kmin, g->phase[p].ntap * g->Cin);
         if (kmin >= 8 * BK && kmin % (2 * BK) == 0) return launch_kv<T, NT, 2>(g, a, s);
@@ -274,10 +273,9 @@ extern "C" int sv_igemm(const sv_geom* g, int dtype, const sv_igemm_args* a, voi
     SV_REQUIRE(!(a->stats || a->ex) || (a->replicas >= 1 && (a->replicas & (a->replicas - 1)) == 0), SV_E_ARG,
                "sv_igemm: replicas=%d must be a power of two", a->replicas);
     hipStream_t s = (hipStream_t)stream;
-    {   // stride-1 3x3 convolutions take the LDS-halo kernel (conv3x3.hip); SV_NO_CONV3X3=1 disables it (A/B)
-        static const bool no_fast = getenv("SV_NO_CONV3X3") != nullptr;
+    {   // stride-1 3x3 convolutions take the LDS-halo kernels (conv3x3*.hip) unless switched off (tests: generic vs special)
         int rc = 0;
-        if (!no_fast && sv_conv3x3_try(g, dtype, a, s, &rc)) return rc;
+        if (!sv_disabled(SV_K_CONV3X3) && sv_conv3x3_try(g, dtype, a, s, &rc)) return rc;
     }
     const int64_t M = (int64_t)g->B * g->Hq * g->Wq;
     const int64_t mtiles = (M + BM - 1) / BM * g->nphase;
@@ -294,11 +292,6 @@ extern "C" int sv_igemm(const sv_geom* g, int dtype, const sv_igemm_args* a, voi
         if (c <= 2) break;
     }
     if (N % 80 == 0 && N % 64 != 0 && mtiles * (N / 80) >= 256 && dtype == SV_BF16) nt = 5;
-    {   // A/B: SV_IGEMM_NT=<8|4|2|1> forces the channel-tile width where it divides N; SV_IGEMM_MINBLK=<n> moves the
-        // block-count threshold of the choice above
-        static const int force = getenv("SV_IGEMM_NT") ? atoi(getenv("SV_IGEMM_NT")) : 0;
-        if (force && N % (16 * force) == 0 && !(dtype == SV_F32 && force > 2)) nt = force;
-    }
     if (dtype == SV_BF16) {
         switch (nt) {
             case 8: return launch<bf16, 8>(g, a, s);

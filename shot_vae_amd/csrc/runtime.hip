@@ -26,6 +26,13 @@ int sv_check_launch(const char* what) {
 }
 
 namespace {
+int g_disable_mask = 0;
+int g_wide_min_blocks = 256;
+}  // namespace
+bool sv_disabled(int kernel_bit) { return (g_disable_mask & kernel_bit) != 0; }
+int sv_wide_min_blocks() { return g_wide_min_blocks; }
+
+namespace {
 struct Rec { hipEvent_t a, b; int tag; };
 int g_prof_on = 0, g_tag = 0;
 std::vector<Rec> g_recs;
@@ -78,6 +85,26 @@ int sv_prof_collect(int max_tags, double* ms, int* count) {
     g_recs.clear();
     (void)hipGetLastError();
     return SV_OK;
+}
+
+int sv_set_option(int key, int value) {
+    switch (key) {
+        case SV_OPT_DISABLE_MASK: g_disable_mask = value; return SV_OK;
+        case SV_OPT_WIDE_MIN_BLOCKS:
+            SV_REQUIRE(value >= 1, SV_E_ARG, "sv_set_option: SV_OPT_WIDE_MIN_BLOCKS=%d", value);
+            g_wide_min_blocks = value;
+            return SV_OK;
+    }
+    sv_set_error("sv_set_option: unknown key %d", key);
+    return SV_E_ARG;
+}
+
+int sv_get_option(int key) {
+    switch (key) {
+        case SV_OPT_DISABLE_MASK: return g_disable_mask;
+        case SV_OPT_WIDE_MIN_BLOCKS: return g_wide_min_blocks;
+    }
+    return -1;
 }
 
 int sv_version(void) { return SV_ABI_VERSION; }

@@ -585,6 +585,27 @@ __global__ void cls_bwd_kernel(const float* label, const float* w, int B, int K,
     if (i < (int64_t)B * K) dp[i] = -gout[0] * label[i] * (w ? w[i / K] : 1.f) / (float)B;
 }
 
+// top-k accuracy counts (main_shot_vae.py:441-447): rank of the true class among the K scores of a row = how many
+// classes score higher (ties: the lower index first, as a stable descending sort); hits[0] += rank < 1, hits[1] += rank < k
+__global__ __launch_bounds__(256) void topk_hits_kernel(const float* score, const int64_t* label, int B, int K, int k,
+                                                        float* hits) {
+    __shared__ float red[4];
+    float h1 = 0.f, hk = 0.f;
+    for (int b = blockIdx.x * 256 + threadIdx.x; b < B; b += gridDim.x * 256) {
+        const float* row = score + (int64_t)b * K;
+        const int y = (int)label[b];
+        const float sy = row[y];
+        int rank = 0;
+        for (int c = 0; c < K; ++c) rank += (row[c] > sy || (row[c] == sy && c < y)) ? 1 : 0;
+        h1 += rank < 1 ? 1.f : 0.f;
+        hk += rank < k ? 1.f : 0.f;
+    }
+    h1 = block_sum(h1, red);
+    __syncthreads();
+    hk = block_sum(hk, red);
+    if (threadIdx.x == 0) { atomicAdd(hits, h1); atomicAdd(hits + 1, hk); }
+}
+
 __global__ __launch_bounds__(256) void post_fwd_kernel(const float* mu, const float* ls, const float* mt,
                                                        const float* st, int B, int D, float* out) {
     __shared__ float red[4];
@@ -955,6 +976,13 @@ int sv_cls_bwd(const float* label, const float* weight, int B, int K, const floa
     hipLaunchKernelGGL(cls_bwd_kernel, dim3(((int64_t)B * K + 255) / 256), dim3(256), 0, (hipStream_t)stream, label,
                        weight, B, K, gout, dpredict);
     return sv_check_launch("sv_cls_bwd");
+}
+int sv_topk_hits(const float* score, const int64_t* label, int B, int K, int k, float* hits, void* stream) {
+    SV_REQUIRE(score && label && hits && B >= 0 && K >= 1 && k >= 1, SV_E_ARG, "sv_topk_hits: bad argument");
+    if (B == 0) return SV_OK;
+    hipLaunchKernelGGL(topk_hits_kernel, dim3(nblocks(B, 256, 64)), dim3(256), 0, (hipStream_t)stream, score, label, B, K,
+                       k, hits);
+    return sv_check_launch("sv_topk_hits");
 }
 int sv_post_fwd(const float* mu, const float* ls, const float* mu_t, const float* sigma_t, int B, int D, float* out,
                 void* stream) {

@@ -295,10 +295,9 @@ extern "C" int sv_wgrad(const sv_geom* g, int dtype, const void* x, const float*
     SV_REQUIRE(!pro_scale || pro_shift, SV_E_ARG, "sv_wgrad: prologue shift missing");
     SV_REQUIRE(!pro_scale || (pro_slope >= 0.f && pro_slope <= 1.f), SV_E_ARG,
                "sv_wgrad: activation slope %g outside [0, 1]", (double)pro_slope);
-    if (dtype == SV_F32 || use_tr) {   // stride-1 3x3: LDS-halo kernel (wgrad3x3.hip); SV_NO_WGRAD3X3=1 disables (A/B)
-        static const bool no_fast = getenv("SV_NO_WGRAD3X3") != nullptr;
+    if (dtype == SV_F32 || use_tr) {   // stride-1 3x3: LDS-halo kernels (wgrad3x3.hip) unless switched off
         int rc = 0;
-        if (!no_fast && sv_wgrad3x3_try(g, dtype, x, pro_scale, pro_shift, pro_slope, dy, dw, ws, ws_elems, (hipStream_t)stream, &rc))
+        if (!sv_disabled(SV_K_WGRAD3X3) && sv_wgrad3x3_try(g, dtype, x, pro_scale, pro_shift, pro_slope, dy, dw, ws, ws_elems, (hipStream_t)stream, &rc))
             return rc;
     }
     wg_params p;

@@ -313,100 +313,63 @@ constexpr int free_before(int g) { int c = 0; for (int i = 0; i < g; ++i) c += g
 
 // The per-tile program of everything that is not an MFMA or a fragment read, packed into the gaps at compile time.
 //   items: HSTEPS * HI transform micro-steps (code 1000 + 41 slot + step); the YI = 11 dy DMA instructions (2000 + k);
-//          the HI halo loads (3000 + slot); the vmcnt waits before a slot's first step (4000 + slot, free).
-//   VMEM instructions are spread over the whole tile -- the probe: one per four MFMAs is free, one per two is not (the
-//   CU's 64 B/clk L1 path) -- and a halo register is re-loaded (for the tile after next) as soon as its vector has been
-//   transformed, a whole tile iteration ahead of its use.
+//          the HI halo loads (3000 + slot); 4 * HI single-dword register copies (5000 + 4 slot + dword).
+//   VMEM instructions are spread out -- the probe: one per four MFMAs is free, one per two is not (the CU's 64 B/clk L1
+//   path).
+//   NO HAND-COUNTED vmcnt: LDS-DMA and register loads do not retire in one common order, so a counted wait for one kind
+//   may not rely on younger instructions of the other kind -- and a wait that counts only its own kind drains the
+//   other kind's instructions in flight (13 % at 160 channels when the halo waits drained the dy copies).  Instead the
+//   halo registers are DOUBLE-BUFFERED: the loads of the tile after next go to a second register set at the top of the
+//   tile iteration (phases 0..2), everything -- they and the dy copies -- is awaited by the ONE vmcnt(0) in front of the
+//   barrier, 1 000+ cycles after the last request, and phase 3 moves the second set into the first (the transform of the
+//   next iteration reads it) while the first four dy copies of the next tile start.
 constexpr int WG_HSTEPS = 41, WG_YI = 11;
 template <int HI>
 struct WSched {
     int item[180][3];       // gap (phase * 45 + g) -> up to 3 item codes, executed in this order (0 = none)
-    int vm_wait[4];         // vmcnt for the wait before slot s: VMEM instructions issued since its load
-    int vm_barrier;         // vmcnt before the barrier: VMEM instructions issued since the last dy DMA of phases 0..2
+    int last_vmem_a;        // gap of the last VMEM instruction of phases 0..2 (it has 135 - that many MFMAs to land)
     bool ok;
 };
 template <int HI>
 constexpr WSched<HI> make_wsched() {
     WSched<HI> S{};
     for (int i = 0; i < 180; ++i) S.item[i][0] = S.item[i][1] = S.item[i][2] = 0;
-    // ---- region A (phases 0..2): forward packing from the latest start gap that still fits everything.  A read gap
-    //      hides one step, a free gap two steps or ONE VMEM instruction (at least six gaps after the previous one; a
-    //      slot's reload only after its last step); a wait is free and shares the gap of the step it precedes.
+    // ---- region A (phases 0..2).  A read gap hides one step, a free gap two steps or ONE VMEM instruction (at least
+    //      six gaps after the previous one).  The requests come first -- halo registers of the tile after next, then
+    //      D4..D10 of the next tile's dy -- the transform steps fill what is left, from the front
     const int nsteps = WG_HSTEPS * HI;
     int queue[16] = {};
     int nq = 0;
-    for (int k = 4; k < 8; ++k) queue[nq++] = 2000 + k;
-    if (HI > 1) queue[nq++] = 3000;
-    for (int k = 8; k < WG_YI; ++k) queue[nq++] = 2000 + k;
-    for (int sl = 1; sl < HI - 1; ++sl) queue[nq++] = 3000 + sl;
-    S.ok = false;
-    for (int start = 134; start >= 0 && !S.ok; --start) {
-        for (int i = 0; i < 135; ++i) S.item[i][0] = S.item[i][1] = S.item[i][2] = 0;
-        int m = 0, qh = 0, last_v = -100;
-        for (int gi = start; gi < 135; ++gi) {
-            int nt = 0;
-            const bool fre = !gap_has_read(gi % 45);
-            bool vm = false;
-            if (fre && qh < nq && gi - last_v >= 6) {
-                const int c = queue[qh];
-                if (c / 1000 == 2 || m >= WG_HSTEPS * (c % 1000 + 1)) vm = true;
-            }
-            if (vm) {
-                S.item[gi][nt++] = queue[qh++];
-                last_v = gi;
-            } else {
-                for (int c = 0; c < (fre ? 2 : 1) && m < nsteps; ++c) {
-                    if (m % WG_HSTEPS == 0) S.item[gi][nt++] = 4000 + m / WG_HSTEPS;
-                    S.item[gi][nt++] = 1000 + m;
-                    ++m;
-                }
-            }
+    for (int sl = 0; sl < HI; ++sl) queue[nq++] = 3000 + sl;
+    for (int k = 4; k < WG_YI; ++k) queue[nq++] = 2000 + k;
+    int m = 0, qh = 0, last_v = -100;
+    for (int gi = 0; gi < 135; ++gi) {
+        int nt = 0;
+        const bool fre = !gap_has_read(gi % 45);
+        if (fre && qh < nq && gi - last_v >= 6) {
+            S.item[gi][nt++] = queue[qh++];
+            last_v = gi;
+        } else {
+            for (int c = 0; c < (fre ? 2 : 1) && m < nsteps; ++c) S.item[gi][nt++] = 1000 + m++;
         }
-        S.ok = m == nsteps && qh == nq;
     }
-    // ---- region B (phase 3): the last slot's reload, then D0..D3, four free gaps apart
+    S.ok = m == nsteps && qh == nq;
+    S.last_vmem_a = last_v;
+    // ---- region B (phase 3): D0..D3 four free gaps apart; the register copies (one dword each) two per free gap / one
+    //      per read gap in between
     {
-        int f = 0, placed = 0;
-        const int lb[5] = {3000 + HI - 1, 2000, 2001, 2002, 2003};
-        for (int g = 0; g < 45 && placed < 5; ++g) {
-            if (gap_has_read(g)) continue;
-            if (f % 4 == 0) S.item[135 + g][0] = lb[placed++];
-            ++f;
+        int f = 0, placed = 0, cp = 0;
+        for (int g = 0; g < 45; ++g) {
+            const bool fre = !gap_has_read(g);
+            if (fre && f % 4 == 0 && placed < 4) {
+                S.item[135 + g][0] = 2000 + placed++;
+                ++f;
+                continue;
+            }
+            if (fre) ++f;
+            for (int c = 0; c < (fre ? 2 : 1) && cp < 4 * HI; ++c) S.item[135 + g][c] = 5000 + cp++;
         }
-        S.ok = S.ok && placed == 5;
-    }
-    // ---- vmcnt bookkeeping over the steady-state order (one iteration = items of gaps 0..179 in order)
-    int order[64] = {};
-    int pos_gap[64] = {};
-    int nv = 0;
-    for (int gi = 0; gi < 180; ++gi)
-        for (int j = 0; j < 3; ++j) {
-            const int c = S.item[gi][j];
-            if (c / 1000 == 2 || c / 1000 == 3) { order[nv] = c; pos_gap[nv] = gi * 4 + j; ++nv; }
-        }
-    for (int sl = 0; sl < 4; ++sl) S.vm_wait[sl] = 0;
-    for (int sl = 0; sl < HI; ++sl) {
-        int wpos = -1, lpos = -1;
-        for (int gi = 0; gi < 180; ++gi)
-            for (int j = 0; j < 3; ++j) if (S.item[gi][j] == 4000 + sl) wpos = gi * 4 + j;
-        for (int i = 0; i < nv; ++i) if (order[i] == 3000 + sl) lpos = i;
-#ifdef SV_WG3_COUNT_REG_ONLY     // (conv3x3x.hip's rule: count only the younger REGISTER loads; measured here: see DESIGN.md)
-        int cnt = 0;
-        for (int i = lpos + 1; i < nv; ++i) if (order[i] / 1000 == 3) ++cnt;
-        for (int i = 0; i < nv; ++i) if (pos_gap[i] < wpos && order[i] / 1000 == 3) ++cnt;
-#else
-        int cnt = nv - 1 - lpos;                                   // issued after the load, to the end of its iteration
-        for (int i = 0; i < nv; ++i) if (pos_gap[i] < wpos) ++cnt; // and from the top of this one to the wait
-#endif
-        S.vm_wait[sl] = cnt;
-        S.ok = S.ok && wpos >= 0 && lpos >= 0;
-    }
-    {
-        int last = -1;
-        for (int i = 0; i < nv; ++i) if (order[i] / 1000 == 2 && pos_gap[i] < 135 * 4) last = i;
-        int cnt = 0;
-        for (int i = last + 1; i < nv; ++i) if (pos_gap[i] < 135 * 4) ++cnt;
-        S.vm_barrier = cnt;
+        S.ok = S.ok && placed == 4 && cp == 4 * HI;
     }
     return S;
 }
@@ -532,8 +495,8 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3w_kernel(const sv_geom g, cons
     // Every VMEM instruction of the tile loop is spelled in assembly and waited for by hand (WSched::vm_*): through the
     // builtin the compiler knows that the DMA writes LDS and, unable to tell the two stages apart, waits for vmcnt(0)
     // before the next fragment read; and its own vmcnt bookkeeping cannot see the assembly.
-    bf16x8 rh[HI];
-    bool hok[HI];
+    bf16x8 rh[HI], rn[HI];             // halo vectors of the next tile (being transformed) / the tile after next (in flight)
+    bool hok[HI], hokn[HI];
     const char* ybase = nullptr;       // dy rows of the tile whose DMA is in progress
     const char* hbase = nullptr;       // x rows (from one above) of the tile whose halo is being loaded
     bool top_ok = false, bot_ok = false;
@@ -554,20 +517,26 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3w_kernel(const sv_geom g, cons
                      :: "s"(base), "n"(k * 4096), "v"(yo), "s"(yb) : "memory", "scc");   // (m0 is reserved: the
                                                                                     // compiler never allocates it)
     };
-    auto load_h = [&](auto I) {       // halo vector i of the tile halo_bases() was last called for
+    auto load_h = [&](bf16x8* dst, bool* ok, auto I) {       // halo vector i of the tile halo_bases() was last called for
         constexpr int i = decltype(I)::value;
-        hok[i] = (hkind[i] == 1) | ((hkind[i] == 2) & top_ok) | ((hkind[i] == 3) & bot_ok);      // (no short circuits)
-        const uint32_t o = hok[i] ? hoff[i] : hsafe;
+        ok[i] = (hkind[i] == 1) | ((hkind[i] == 2) & top_ok) | ((hkind[i] == 3) & bot_ok);      // (no short circuits)
+        const uint32_t o = ok[i] ? hoff[i] : hsafe;
         const char* hb = hbase;
         bf16x8 r;
         asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(r) : "v"(o), "s"(hb) : "memory");
-        rh[i] = r;
+        dst[i] = r;
     };
-    auto wait_h = [&](auto I, auto N) {       // ... and the wait that makes rh[i] usable
-        constexpr int i = decltype(I)::value, nn = decltype(N)::value;
-        bf16x8 r = rh[i];
-        asm volatile("s_waitcnt vmcnt(%1)" : "+v"(r) : "n"(nn) : "memory");
-        rh[i] = r;
+    // the full drain that makes a register set usable: to the compiler the registers are (re)defined HERE
+    auto drain_h = [&](bf16x8* set) {
+        if constexpr (HI == 4) {
+            bf16x8 r0 = set[0], r1 = set[1], r2 = set[2], r3 = set[HI - 1];
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3) :: "memory");
+            set[0] = r0; set[1] = r1; set[2] = r2; set[HI - 1] = r3;
+        } else {
+            bf16x8 r0 = set[0], r1 = set[1], r2 = set[2];
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(r0), "+v"(r1), "+v"(r2) :: "memory");
+            set[0] = r0; set[1] = r1; set[2] = r2;
+        }
     };
     // The BN + activation transform of the halo vectors, as single-instruction MICRO-STEPS.  Measured with
     // tools/probes/issue_probe.hip (one wave per SIMD): behind one 16x16x32 MFMA a wave issues two (unpacked) VALU
@@ -681,8 +650,16 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3w_kernel(const sv_geom g, cons
                 if constexpr (kind == 1)
                     hstep(std::integral_constant<int, arg / HSTEPS>{}, std::integral_constant<int, arg % HSTEPS>{}, wr);
                 if constexpr (kind == 2) dma_y(dma_stage, std::integral_constant<int, arg>{});
-                if constexpr (kind == 3) load_h(std::integral_constant<int, arg>{});
-                if constexpr (kind == 4) wait_h(std::integral_constant<int, arg>{}, std::integral_constant<int, SCHED.vm_wait[arg]>{});
+                if constexpr (kind == 3) load_h(rn, hokn, std::integral_constant<int, arg>{});
+                if constexpr (kind == 5) {          // one dword of the second register set moves into the first
+                    u32x4 d = __builtin_bit_cast(u32x4, rh[arg / 4]);
+                    const uint32_t sdw = __builtin_bit_cast(u32x4, rn[arg / 4])[arg % 4];
+                    uint32_t o;
+                    asm volatile("v_mov_b32 %0, %1" : "=v"(o) : "v"(sdw));
+                    d[arg % 4] = o;
+                    rh[arg / 4] = __builtin_bit_cast(bf16x8, d);
+                    if constexpr (arg % 4 == 0) hok[arg / 4] = hokn[arg / 4];
+                }
             });
 #endif
             __builtin_amdgcn_sched_barrier(0);
@@ -690,7 +667,7 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3w_kernel(const sv_geom g, cons
         load_fx(nkc, 8, 0);
         load_fx(nkc, 8, 1);
     };
-    static_assert(HI >= 2 && HI <= 4 && HSTEPS == WG_HSTEPS, "phase work lists");
+    static_assert(HI >= 3 && HI <= 4 && HSTEPS == WG_HSTEPS, "phase work lists");
 
 #ifdef SV_WG3_STAMP
     const uint64_t st_begin = __builtin_amdgcn_s_memtime();
@@ -701,13 +678,14 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3w_kernel(const sv_geom g, cons
     halo_bases(t_begin);
     dy_base(t_begin);
     static_for<YI>([&](auto K) { dma_y(0, K); });
-    static_for<HI>([&](auto I) { load_h(I); });
-    static_for<HI>([&](auto I) { wait_h(I, std::integral_constant<int, 0>{}); store_h(lds0, I); });
+    static_for<HI>([&](auto I) { load_h(rh, hok, I); });
+    drain_h(rh);
+    static_for<HI>([&](auto I) { store_h(lds0, I); });
     halo_bases(min(t_begin + 1, t_end - 1));
     dy_base(min(t_begin + 1, t_end - 1));
-    static_for<HI>([&](auto I) { load_h(I); });
+    static_for<HI>([&](auto I) { load_h(rh, hok, I); });
     static_for<4>([&](auto K) { dma_y(1, K); });
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    drain_h(rh);
     __syncthreads();
 #pragma unroll
     for (int a = 0; a < 5; ++a) { load_fy(0, 0, a, 0); load_fy(0, 0, a, 1); }
@@ -730,7 +708,7 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3w_kernel(const sv_geom g, cons
         WG3_STAMP(st_p1)
         phase(std::integral_constant<int, 2>{}, other, cur ^ 1);
         WG3_STAMP(st_p2)
-        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(SCHED.vm_barrier) : "memory");    // this wave's share of the dy DMA landed
+        drain_h(rn);              // this wave's share of the dy DMA has landed, and so has the halo of the tile after next
         __syncthreads();          // the other stage is complete, and nobody reads this one any more (kc3 is in registers)
         WG3_STAMP(st_bar)
         {   // from here on fragments come from the other stage
@@ -829,9 +807,7 @@ static void launch_slab_reduce(const float* ws, int splits, int64_t n, float* dw
     while (G < 32 && G * 2 * 8 <= splits && (n / 4 + 256 / G - 1) / (256 / G) < 256) G *= 2;
     const int cols = 256 / G;
     const unsigned gx = (unsigned)((n / 4 + cols - 1) / cols);
-    static const bool plain = getenv("SV_SLAB_PLAIN") != nullptr;
-    if (plain) hipLaunchKernelGGL(slab_reduce_kernel<false>, dim3(gx), dim3(256), 0, s, ws, splits, n, dw, G);
-    else hipLaunchKernelGGL(slab_reduce_kernel<true>, dim3(gx), dim3(256), 0, s, ws, splits, n, dw, G);
+    hipLaunchKernelGGL(slab_reduce_kernel<true>, dim3(gx), dim3(256), 0, s, ws, splits, n, dw, G);
 }
 
 template <typename T, int WLOG>
@@ -893,8 +869,7 @@ int sv_wgrad3x3_try(const sv_geom* g, int dtype, const void* x, const float* pro
     p.x = x; p.pro_scale = pro_scale; p.pro_shift = pro_shift; p.pro_slope = pro_slope; p.dy = dy; p.dw = dw;
     p.unit = 0;
     const int nT = g->B * g->Hin / TR;
-    static const bool no_wide = getenv("SV_NO_WGRAD3X3W") != nullptr;
-    if (!no_wide && dtype == SV_BF16 && g->N % 160 == 0 && g->Cin >= 96) {
+    if (!sv_disabled(SV_K_WGRAD3X3W) && dtype == SV_BF16 && g->N % 160 == 0 && g->Cin >= 96) {
         // wide layers: 160 x 32 slabs, one block (one wave per SIMD) per CU.  Pick the split count and the affinity unit
         // (a divisor of the chunk count) that minimise the modelled time:
         //   compute: rounds-of-32-CUs-per-XCD x (tiles per block + publishing a 160 x 32 x 9 slab, ~4 tiles) x 2.0 us
@@ -931,10 +906,6 @@ int sv_wgrad3x3_try(const sv_geom* g, int dtype, const void* x, const float* pro
         p.tiles_per = (nT + splits - 1) / splits;
         const int64_t needw = (int64_t)splits * g->N * g->T_orig * g->Cin;
         p.ws = (ws && ws_elems >= needw && splits > 1) ? ws : nullptr;
-        static const bool dbg = getenv("SV_WG3_DEBUG") != nullptr;
-        if (dbg)
-            fprintf(stderr, "wgrad3x3w: Cin %d N %d W %d tiles %d -> splits %d unit %d tiles/block %d workspace %s (%lld of %lld)\n",
-                    g->Cin, g->N, g->Win, nT, splits, unit, p.tiles_per, p.ws ? "yes" : "NO", (long long)needw, (long long)ws_elems);
         switch (g->Win) {
             case 32: *rc = launch_wide<5>(g, p, s); break;
             case 16: *rc = launch_wide<4>(g, p, s); break;
@@ -943,8 +914,8 @@ int sv_wgrad3x3_try(const sv_geom* g, int dtype, const void* x, const float* pro
         return 1;
     }
     const int nNC = (g->N / 32) * (g->Cin / 32);
-    // ~four persistent blocks per CU (SV_WG3_BLOCKS overrides); every block should still see a few tiles
-    static const int target = getenv("SV_WG3_BLOCKS") ? atoi(getenv("SV_WG3_BLOCKS")) : 512;
+    // ~two persistent blocks per CU; every block should still see a few tiles
+    constexpr int target = 512;
     int splits = (target + nNC - 1) / nNC;
     if (splits > nT) splits = nT;
     if (splits >= 8) splits = splits / 8 * 8;
@@ -968,8 +939,8 @@ extern "C" int sv_debug_wgrad_tile_program(int halo_vectors, int* items, int* wa
     auto copy = [&](const auto& S) {
         for (int i = 0; i < 180; ++i)
             for (int j = 0; j < 3; ++j) items[3 * i + j] = S.item[i][j];
-        for (int v = 0; v < 4; ++v) waits[v] = S.vm_wait[v];
-        waits[4] = S.vm_barrier;
+        for (int v = 0; v < 4; ++v) waits[v] = 0;      // no counted waits: one vmcnt(0) in front of the barrier
+        waits[4] = S.last_vmem_a;
         return S.ok ? SV_OK : SV_E_SHAPE;
     };
     static constexpr WSched<3> S3 = make_wsched<3>();

@@ -34,11 +34,15 @@ def shard(t, rank, world):
     return t[rank * per: (rank + 1) * per]
 
 
-def broadcast_parameters(flat_param, flat_bufs=None, src=0):
+def broadcast_parameters(model, src=0):
+    """Rank `src`'s parameters and BatchNorm buffers to every rank (start-up / after loading a checkpoint on one rank).
+    Takes the MODEL: the in-place c10d write does not bump any version counter, so the engine is told explicitly that
+    its packed weight shadows are stale."""
     if dist.is_initialized() and dist.get_world_size() > 1:
-        dist.broadcast(flat_param, src)
-        if flat_bufs is not None:
-            dist.broadcast(flat_bufs, src)
+        eng = model._engine
+        dist.broadcast(eng.param, src)
+        dist.broadcast(eng.bufs, src)
+        eng.mark_dirty()
 
 
 def all_reduce_gradients(flat_grad):

@@ -32,13 +32,37 @@ class FlatSGD:
         self._steps += 1
         eng.mark_dirty()
 
+    # ---- checkpoint format: torch.optim.SGD's (main_shot_vae.py:237-242 saves optimizer.state_dict(), :207 loads it), so a
+    #      checkpoint written by the reference loop resumes here and vice versa.  Parameter ids follow model.parameters().
+    def _views(self):
+        return self.model._views          # [(nn.Parameter, kind, payload)] in registration (= reference) order
+
     def state_dict(self):
         eng = self.model._engine
-        return dict(param_groups=self.param_groups, steps=self._steps,
-                    momentum=None if eng.mom is None else eng.mom.clone())
+        g = self.param_groups[0]
+        n = len(self._views())
+        group = dict(lr=g["lr"], momentum=g["momentum"], dampening=0, weight_decay=g["weight_decay"], nesterov=False,
+                     maximize=False, foreach=None, differentiable=False, fused=None, params=list(range(n)))
+        state = {}
+        if eng.mom is not None and self._steps > 0:
+            for i, (_, kind, payload) in enumerate(self._views()):
+                state[i] = dict(momentum_buffer=self.model._flat_view(eng.mom, kind, payload).clone())
+        return dict(state=state, param_groups=[group])
 
     def load_state_dict(self, sd):
-        self.param_groups = sd["param_groups"]
-        self._steps = sd["steps"]
-        if sd["momentum"] is not None:
-            self.model._engine.mom = sd["momentum"].to(self.model._engine.param.device).clone()
+        eng = self.model._engine
+        g = sd["param_groups"][0]
+        self.param_groups = [dict(lr=g["lr"], momentum=g["momentum"], weight_decay=g["weight_decay"])]
+        if g.get("nesterov") or g.get("dampening", 0) != 0:
+            raise NotImplementedError("FlatSGD implements the reference's SGD (no Nesterov, dampening 0)")
+        state = sd.get("state", {})
+        bufs = {int(k): v.get("momentum_buffer") for k, v in state.items()}
+        if not any(b is not None for b in bufs.values()):
+            eng.mom, self._steps = None, 0
+            return
+        eng.mom = torch.zeros_like(eng.param)
+        for i, (_, kind, payload) in enumerate(self._views()):
+            b = bufs.get(i)
+            if b is not None:
+                self.model._flat_view(eng.mom, kind, payload).copy_(b.to(eng.param.device))
+        self._steps = 1           # momentum buffers exist: the next step is not a "first step" (v = g)

@@ -28,6 +28,35 @@ def one_hot(label, K):
     return torch.zeros(label.shape[0], K, device=label.device).scatter_(1, label.view(-1, 1), 1)
 
 
+def inference_kl(disc_log_alpha_u, label_u):
+    """The Train/KL_Inference monitor of main_shot_vae.py:330-339: KL(q(y|x) || smoothed one-hot of the (held-back)
+    label of the unlabelled batch), mean over the batch.  A device scalar -- the reference's float() (a device-to-host
+    sync every step) is left to the caller, so that the step stays asynchronous / capturable."""
+    with torch.no_grad():
+        B, K = disc_log_alpha_u.shape
+        smooth = torch.zeros(B, K, device=disc_log_alpha_u.device).scatter_(
+            1, label_u.view(-1, 1), 1 - 0.001 - 0.001 / (K - 1))
+        smooth = smooth + 0.001 / (K - 1)
+        alpha = torch.exp(disc_log_alpha_u)
+        return (alpha * disc_log_alpha_u - alpha * torch.log(smooth)).sum() / B
+
+
+def apply_update(model, optimizer, distributed=False):
+    """Gradient exchange + optimizer step + zero_grad (main_shot_vae.py:365-366).  With N ranks the flat gradient buffer
+    holds the SUM over ranks after the all-reduce; FlatSGD folds the 1/N into its kernel, any other optimizer (a plain
+    torch.optim.SGD over model.parameters()) gets the buffer scaled first, so the effective learning rate never depends
+    on the optimizer class."""
+    grad = model.flat_parameters()[1]
+    scale = dp.all_reduce_gradients(grad) if distributed else 1.0
+    if hasattr(optimizer, "_steps"):
+        optimizer.step(scale)
+    else:
+        if scale != 1.0:
+            grad.mul_(scale)
+        optimizer.step()
+    optimizer.zero_grad()
+
+
 class DeviceRng:
     """Device-side source of the step's host-RNG draws, so that the step can be captured into a hipGraph: the two
     mixup coefficients come from tables of numpy Beta draws (the reference's distributions: Beta(eps,eps) for label
@@ -35,12 +64,20 @@ class DeviceRng:
     device-side random permutation."""
 
     def __init__(self, device, epsilon=0.1, n=4096, seed=0):
-        rs = np.random.RandomState(seed)
-        tl = rs.beta(epsilon, epsilon, size=n) if epsilon > 0 else np.ones(n)
-        self.lam_l = torch.tensor(tl, dtype=torch.float32, device=device)
-        self.lam_u = torch.tensor(rs.beta(2.0, 2.0, size=n), dtype=torch.float32, device=device)
+        self.rs = np.random.RandomState(seed)          # the SAME seed on every rank: all ranks agree on the lambdas
+        self.epsilon, self.n = epsilon, n
+        self.lam_l = torch.empty(n, dtype=torch.float32, device=device)
+        self.lam_u = torch.empty(n, dtype=torch.float32, device=device)
         self.counter = torch.zeros(1, dtype=torch.int64, device=device)
-        self.n = n
+        self.refill()
+
+    def refill(self):
+        """Fresh draws into the same device tensors (outside a graph: GraphedTrainStep calls it every n replays, so the
+        tables are never recycled)."""
+        n = self.n
+        tl = self.rs.beta(self.epsilon, self.epsilon, size=n) if self.epsilon > 0 else np.ones(n)
+        self.lam_l.copy_(torch.tensor(tl, dtype=torch.float32))
+        self.lam_u.copy_(torch.tensor(self.rs.beta(2.0, 2.0, size=n), dtype=torch.float32))
 
     def next_lams(self):
         i = torch.remainder(self.counter, self.n)
@@ -50,7 +87,7 @@ class DeviceRng:
 
 
 def train_step_overlapped(model, elbo_criterion, cls_criterion, optimizer, image_l, label_l, image_u, sch,
-                          epsilon=0.1, distributed=False, device_rng=None):
+                          epsilon=0.1, distributed=False, device_rng=None, optimal_match=False, label_u=None):
     """Same step, the labelled branch ((1),(2), backward) and the unlabelled branch ((3),(4), backward) issued on two
     HIP streams: they are independent until the optimizer step (both only read the weights and add to the flat
     gradient buffer with atomics), so the latency-bound small kernels of one branch (decoder, heads, BN
@@ -97,11 +134,14 @@ def train_step_overlapped(model, elbo_criterion, cls_criterion, optimizer, image
         recon_u, klc_u, kld_u = elbo_criterion(image_u, rec3, mu3, ls3, la3)
         elbo_u = recon_u + sch["kl_beta_c"] * torch.abs(klc_u - sch["cmi"]) + sch["kl_beta_d"] * torch.abs(kld_u - sch["dmi"])
         with torch.no_grad():
+            kl_inf = inference_kl(la3, label_u) if label_u is not None else None
             if device_rng is None:
-                mx_img, mx_mu, mx_sigma, mx_alpha, lam_u = mixup_vae_data(image_u, mu3, ls3, la3)
+                mx_img, mx_mu, mx_sigma, mx_alpha, lam_u = mixup_vae_data(image_u, mu3, ls3, la3,
+                                                                          optimal_match=optimal_match)
             else:
                 mx_img, mx_mu, mx_sigma, mx_alpha, lam_u = mixup_vae_data(
-                    image_u, mu3, ls3, la3, lam=dl_u, index=device_permutation(image_u.size(0), image_u.device))
+                    image_u, mu3, ls3, la3, optimal_match=optimal_match, lam=dl_u,
+                    index=None if optimal_match else device_permutation(image_u.size(0), image_u.device))
         eng.defer_slot = 3
         rec4, mu4, ls4, la4, *_ = model(mx_img)
     eng.defer_slot = None
@@ -118,17 +158,18 @@ def train_step_overlapped(model, elbo_criterion, cls_criterion, optimizer, image
         cur.wait_stream(s)
     eng.apply_pending()
     if optimizer is not None:
-        scale = dp.all_reduce_gradients(model.flat_parameters()[1]) if distributed else 1.0
-        optimizer.step(scale) if hasattr(optimizer, "_steps") else optimizer.step()
-        optimizer.zero_grad()
+        apply_update(model, optimizer, distributed)
+    if label_u is not None:
+        return loss_sup.detach(), loss_unsup.detach(), kl_inf
     return loss_sup.detach(), loss_unsup.detach()
 
 
 def train_step(model, elbo_criterion, cls_criterion, optimizer, image_l, label_l, image_u, sch, epsilon=0.1,
-               optimal_match=False, distributed=False, return_outputs=False):
+               optimal_match=False, distributed=False, return_outputs=False, label_u=None):
     """One step: 4 forwards, 2 backwards, (all-reduce,) SGD.  Inputs are device tensors.
-    Returns the two scalar losses (device tensors) and optionally every intermediate the parity
-    tests compare against the oracle."""
+    Returns the two scalar losses (device tensors) -- with `label_u` (the held-back labels of the unlabelled batch) also
+    the Train/KL_Inference monitor of main_shot_vae.py:330-339 -- and optionally every intermediate the parity tests
+    compare against the oracle."""
     K = model._plan.K
     Bl, Bu = image_l.size(0), image_u.size(0)
     onehot_l = one_hot(label_l, K)
@@ -150,6 +191,7 @@ def train_step(model, elbo_criterion, cls_criterion, optimizer, image_l, label_l
     loss_sup.backward()
     # (3) unlabelled forward                                                  :327-346
     rec3, mu3, ls3, la3 = model(image_u)
+    kl_inference = inference_kl(la3, label_u) if label_u is not None else None      # :330-339
     recon_u, klc_u, kld_u = elbo_criterion(image_u, rec3, mu3, ls3, la3)
     prior_u = sch["kl_beta_c"] * torch.abs(klc_u - sch["cmi"]) + sch["kl_beta_d"] * torch.abs(kld_u - sch["dmi"])
     elbo_u = recon_u + prior_u
@@ -165,15 +207,16 @@ def train_step(model, elbo_criterion, cls_criterion, optimizer, image_l, label_l
     loss_unsup.backward()
     # gradient exchange + update                                              :365-366
     if optimizer is not None:
-        scale = dp.all_reduce_gradients(model.flat_parameters()[1]) if distributed else 1.0
-        optimizer.step(scale) if hasattr(optimizer, "_steps") else optimizer.step()
-        optimizer.zero_grad()
+        apply_update(model, optimizer, distributed)
     if not return_outputs:
+        if label_u is not None:
+            return loss_sup.detach(), loss_unsup.detach(), kl_inference
         return loss_sup.detach(), loss_unsup.detach()
     loc = dict(locals())
     keys = ["recon_l", "klc_l", "kld_l", "recon_u", "klc_u", "kld_u", "disc_post_l", "cont_post_l", "disc_post_u",
             "cont_post_u", "loss_sup", "loss_unsup", "sm_img", "mx_img"] + \
-           ["%s%d" % (n, i) for i in (1, 2, 3, 4) for n in ("rec", "mu", "ls", "la")]
+           ["%s%d" % (n, i) for i in (1, 2, 3, 4) for n in ("rec", "mu", "ls", "la")] + \
+           (["kl_inference"] if label_u is not None else [])
     return {k: loc[k].detach() for k in keys}
 
 
@@ -193,19 +236,13 @@ def m2_train_step(model, elbo_criterion, cls_criterion, optimizer, image_l, labe
     loss_sup = sch["ew"] * elbo_l + disc_post_l
     loss_sup.backward()
     rec3, mu3, ls3, la3 = model(image_u)
-    with torch.no_grad():
-        smooth = torch.zeros(B, K, device=image_u.device).scatter_(1, label_u.view(-1, 1), 1 - 0.001 - 0.001 / (K - 1))
-        smooth = smooth + 0.001 / (K - 1)
-        alpha = torch.exp(la3)
-        kl_inference = (alpha * la3 - alpha * torch.log(smooth)).sum() / B
+    kl_inference = inference_kl(la3, label_u)
     recon_u, klc_u, kld_u = elbo_criterion(image_u, rec3, mu3, ls3, la3)
     elbo_u = recon_u + sch["kl_beta_c"] * torch.abs(klc_u - sch["cmi"]) + sch["kl_beta_d"] * torch.abs(kld_u - sch["dmi"])
     loss_unsup = sch["ew"] * elbo_u
     loss_unsup.backward()
     if optimizer is not None:
-        scale = dp.all_reduce_gradients(model.flat_parameters()[1]) if distributed else 1.0
-        optimizer.step(scale) if hasattr(optimizer, "_steps") else optimizer.step()
-        optimizer.zero_grad()
+        apply_update(model, optimizer, distributed)
     if not return_outputs:
         return loss_sup.detach(), loss_unsup.detach(), kl_inference
     loc = dict(locals())
@@ -222,11 +259,14 @@ class GraphedTrainStep:
     Needs rng="device".  Re-capture (build a new object) when the per-epoch schedule scalars change."""
 
     def __init__(self, model, elbo_criterion, cls_criterion, optimizer, image_l, label_l, image_u, sch, epsilon=0.1,
-                 distributed=False, seed=0, warmup=2):
+                 distributed=False, seed=0, warmup=2, optimal_match=False, label_u=None):
         assert model.rng == "device", "graph capture needs device-side noise: VariationalAutoEncoder(..., rng='device')"
         self.model, self.opt, self.distributed = model, optimizer, distributed
         self.il, self.ll, self.iu = image_l.clone(), label_l.clone(), image_u.clone()
+        self.lu = label_u.clone() if label_u is not None else None
+        self.om = optimal_match
         self.rng = DeviceRng(image_l.device, epsilon, seed=seed)
+        self.replays = 0
         self.args = (elbo_criterion, cls_criterion, sch, epsilon)
         self.stream = torch.cuda.Stream()
         cur = torch.cuda.current_stream()
@@ -253,20 +293,23 @@ class GraphedTrainStep:
         eng.wgrad_side_stream = False
         try:
             return train_step_overlapped(self.model, e, c, None, self.il, self.ll, self.iu, sch, epsilon=eps,
-                                         device_rng=self.rng)
+                                         device_rng=self.rng, optimal_match=self.om, label_u=self.lu)
         finally:
             eng.wgrad_side_stream = keep
 
     def _update(self):
-        scale = dp.all_reduce_gradients(self.model.flat_parameters()[1]) if self.distributed else 1.0
-        self.opt.step(scale) if hasattr(self.opt, "_steps") else self.opt.step()
-        self.opt.zero_grad()
+        apply_update(self.model, self.opt, self.distributed)
 
-    def __call__(self, image_l=None, label_l=None, image_u=None):
+    def __call__(self, image_l=None, label_l=None, image_u=None, label_u=None):
         if image_l is not None:
             self.il.copy_(image_l)
             self.ll.copy_(label_l)
             self.iu.copy_(image_u)
+            if label_u is not None and self.lu is not None:
+                self.lu.copy_(label_u)
+        self.replays += 1
+        if self.replays % self.rng.n == 0:          # the device counter wraps next: fresh Beta draws, not a recycled table
+            self.rng.refill()
         self.graph.replay()
         self._update()
         return self.losses

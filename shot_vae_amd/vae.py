@@ -53,6 +53,11 @@ class _VAEFunction(torch.autograd.Function):
         model, f = ctx.model, ctx.f
         if f is None:
             raise RuntimeError("backward through the same SHOT-VAE forward twice is not supported")
+        if not f.training:
+            # an eval-mode forward normalises with the running statistics and saves no batch statistics: the
+            # batch-statistics BatchNorm backward below would read uninitialised mean / rstd
+            raise NotImplementedError("backward through an eval-mode forward (BatchNorm with running statistics) is not "
+                                      "implemented; the reference never does it (main_shot_vae.py:423-424: no_grad)")
         ctx.f = None
         model._attach_grads()
         eng = model._engine

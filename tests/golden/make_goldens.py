@@ -357,11 +357,101 @@ def run_fn_cases(tag):
     print(tag, "ok")
 
 
+def run_keys_case(tag):
+    """state_dict keys + shapes of the reference model, in its order, for both data_parallel layouts (the reference wraps
+    eleven sub-modules in nn.DataParallel inside the model: wideresnet.py:78-93, vae.py:108-132, decoder.py:63-64)."""
+    import json
+    VAE, *_ = import_reference()
+    rec = {}
+    for name, K in (("wideresnet-28-2", 10), ("wideresnet-10-1", 10), ("wideresnet-28-10", 100)):
+        for dp in (False, True):
+            model = VAE(encoder_name=name, num_input_channels=3, drop_rate=0, img_size=(32, 32), data_parallel=dp,
+                        continuous_latent_dim=128, disc_latent_dim=K, sample_temperature=0.67, small_input=True)
+            rec["%s|K=%d|dp=%d" % (name, K, int(dp))] = [[k, list(v.shape)] for k, v in model.state_dict().items()]
+    with open(os.path.join(HERE, tag + ".json"), "w") as f:
+        json.dump(rec, f, indent=0)
+    print(tag, {k: len(v) for k, v in rec.items()})
+
+
+def run_monitor_valid_case(tag, name, K):
+    """(a) the Train/KL_Inference monitor of main_shot_vae.py:329-339 (KL(q(y|x) || smoothed one-hot label_u), computed on
+    the unlabelled forward in train mode); (b) the body of valid() / test() (main_shot_vae.py:409-458 = :461-510) over two
+    batches of unequal size: eval-mode forward, the three AverageMeter means, the `ELBO` scalar, top-1 / top-5."""
+    import torch.nn.functional as F
+    VAE, VAECriterion, *_ = import_reference()
+    sys.path.insert(0, os.path.join(REF, "lib", "utils"))
+    from lib.utils.avgmeter import AverageMeter
+    model = VAE(encoder_name=name, num_input_channels=3, drop_rate=0, img_size=(32, 32), data_parallel=False,
+                continuous_latent_dim=128, disc_latent_dim=K, sample_temperature=0.67, small_input=True)
+    model.load_state_dict(C.make_state(name, K=K))
+    rec = {}
+    # (a)
+    model.train()
+    il, ll, iu, lu = C.make_batch(4, 6, K)
+    nz = C.make_noise(4, 6, K)
+    kl_inferences = AverageMeter()
+    with scripted_rng(randn=[nz["eps3"]], rand=[nz["u3"]]):
+        reconstruction_u, norm_mean_u, norm_log_sigma_u, disc_log_alpha_u = model(iu)
+    batch_size_u = iu.size(0)
+    with torch.no_grad():
+        label_smooth_u = torch.zeros(batch_size_u, K).scatter_(1, lu.view(-1, 1), 1 - 0.001 - 0.001 / (K - 1))
+        label_smooth_u = label_smooth_u + torch.ones(label_smooth_u.size()) * 0.001 / (K - 1)
+        disc_alpha_u = torch.exp(disc_log_alpha_u)
+        inference_kl = disc_alpha_u * disc_log_alpha_u - disc_alpha_u * torch.log(label_smooth_u)
+    kl_inferences.update(float(torch.sum(inference_kl) / batch_size_u), batch_size_u)
+    rec["kl_inference"] = np.array(kl_inferences.avg)
+    # (b): a fresh model (the train-mode forward above moved the running statistics)
+    model.load_state_dict(C.make_state(name, K=K))
+    for bce, x_sigma in ((True, 1.0), (False, 0.5)):
+        elbo_criterion = VAECriterion(discrete_dim=K, x_sigma=x_sigma, bce_reconstruction=bce)
+        continuous_kl_losses, discrete_kl_losses = AverageMeter(), AverageMeter()
+        mse_losses, elbo_losses = AverageMeter(), AverageMeter()
+        model.eval()
+        all_score, all_label = [], []
+        for i, B in enumerate((6, 4)):
+            image, label, _, _ = C.make_batch(B, B, K, stream0=7500 + 10 * i)
+            noise = C.make_noise(B, B, K, stream0=9500 + 100 * i)
+            label_onehot = torch.zeros(label.size(0), K).scatter_(1, label.view(-1, 1), 1)
+            batch_size = image.size(0)
+            with torch.no_grad(), scripted_rng(randn=[noise["eps3"][:B]], rand=[noise["u3"][:B]]):
+                reconstruction, norm_mean, norm_log_sigma, disc_log_alpha, *_ = model(image)
+            reconstruct_loss, continuous_kl_loss, discrete_kl_loss = elbo_criterion(image, reconstruction, norm_mean,
+                                                                                    norm_log_sigma, disc_log_alpha)
+            mse_loss = F.mse_loss(torch.sigmoid(reconstruction.detach()), image.detach(), reduction="sum") / (
+                2 * image.size(0) * (x_sigma ** 2))
+            mse_losses.update(float(mse_loss), image.size(0))
+            all_score.append(torch.exp(disc_log_alpha))
+            all_label.append(label_onehot)
+            continuous_kl_losses.update(float(continuous_kl_loss.item()), batch_size)
+            discrete_kl_losses.update(float(discrete_kl_loss.item()), batch_size)
+            elbo_losses.update(float(mse_loss + 0.01 * (continuous_kl_loss + discrete_kl_loss)), image.size(0))
+        all_score = torch.cat(all_score, dim=0).detach()
+        all_label = torch.cat(all_label, dim=0).detach()
+        _, y_true = torch.topk(all_label, k=1, dim=1)
+        _, y_pred = torch.topk(all_score, k=5, dim=1)
+        top1 = float(torch.sum(y_true == y_pred[:, :1]).item()) / y_true.size(0)
+        top5 = float(torch.sum(y_true == y_pred).item()) / y_true.size(0)
+        pre = "valid_bce%d." % int(bce)
+        rec[pre + "klc"] = np.array(continuous_kl_losses.avg)
+        rec[pre + "kld"] = np.array(discrete_kl_losses.avg)
+        rec[pre + "mse"] = np.array(mse_losses.avg)
+        rec[pre + "elbo"] = np.array(elbo_losses.avg)
+        rec[pre + "top1"] = np.array(top1)
+        rec[pre + "top5"] = np.array(top5)
+        rec[pre + "score"] = all_score.numpy()
+    np.savez_compressed(os.path.join(HERE, tag + ".npz"), **rec)
+    print(tag, {k: (float(v) if v.ndim == 0 else v.shape) for k, v in rec.items()})
+
+
 if __name__ == "__main__":
     assert os.path.isdir(REF), "reference not mounted; goldens are generated in the build container"
     torch.set_num_threads(8)
     if len(sys.argv) > 1 and sys.argv[1] == "m2":          # only the M2 fixture
         run_m2_case("ref_m2_step_wrn10_1", "wideresnet-10-1", 10, 6)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "extra":       # only the round-2 fixtures (keys, monitor KL, valid() metrics)
+        run_keys_case("ref_state_keys")
+        run_monitor_valid_case("ref_monitor_valid_wrn10_1", "wideresnet-10-1", 10)
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "smooth":      # only the smooth-ELBO fixtures
         run_smooth_case("ref_smooth_svhn", "svhn", 6, 4)
@@ -377,3 +467,5 @@ if __name__ == "__main__":
     run_m2_case("ref_m2_step_wrn10_1", "wideresnet-10-1", 10, 6)
     run_smooth_case("ref_smooth_svhn", "svhn", 6, 4)
     run_smooth_case("ref_smooth_mnist", "mnist", 4, 6)
+    run_keys_case("ref_state_keys")
+    run_monitor_valid_case("ref_monitor_valid_wrn10_1", "wideresnet-10-1", 10)

@@ -42,15 +42,19 @@ def _tile_program(hv):
 
 def test_wide_wgrad_tile_program_is_consistent():
     """The compile-time schedule of wgrad3x3w_kernel (wgrad3x3.hip, make_wsched): every transform step exactly once and in
-    order, vector loads after the vector's last step, VMEM instructions only in gaps without an LDS read and >= 6 MFMAs
-    apart, and the hand-counted vmcnt values equal to the number of VMEM instructions issued in between."""
+    order before the barrier, VMEM instructions only in gaps without an LDS read and >= 6 MFMAs apart, NO counted vmcnt
+    wait (the halo registers are double-buffered; one vmcnt(0) in front of the barrier covers both kinds of VMEM
+    instruction), the loads of the second register set and D4..D10 before that barrier with >= 40 MFMAs to land, and the
+    copy of the second set into the first, dword by dword, behind it."""
     has_read = lambda g: (g % 5) < 2 or ((g % 5) == 2 and g // 5 < 8)
     for hv in (3, 4):
         gaps, waits = _tile_program(hv)
         flat = [(gi, c) for gi, items in enumerate(gaps) for c in items]
         steps = [c - 1000 for _, c in flat if c // 1000 == 1]
         assert steps == list(range(41 * hv)), "transform steps out of order / missing"
-        assert all(gi < 135 for gi, c in flat if c // 1000 in (1, 4)), "transform must finish before the barrier"
+        assert all(gi < 135 for gi, c in flat if c // 1000 == 1), "transform must finish before the barrier"
+        assert not any(c // 1000 == 4 for _, c in flat), "no hand-counted waits"
+        assert waits[:4] == [0, 0, 0, 0]
         vmem = [(gi, c) for gi, c in flat if c // 1000 in (2, 3)]
         assert sorted(c for _, c in vmem if c // 1000 == 2) == [2000 + k for k in range(11)]
         assert sorted(c for _, c in vmem if c // 1000 == 3) == [3000 + v for v in range(hv)]
@@ -58,22 +62,18 @@ def test_wide_wgrad_tile_program_is_consistent():
             assert not has_read(gi % 45) and gaps[gi] == [c], "a VMEM instruction owns a read-free gap"
         for (g0, _), (g1, _) in zip(vmem, vmem[1:]):
             assert g1 - g0 >= 4
-        # D4..D10 land in the other stage before the barrier, D0..D3 start after it
+        # D4..D10 and every register load are issued before the barrier (behind gap 134) that awaits them with vmcnt(0);
+        # D0..D3 of the tile after next start after it
         assert all((gi < 135) == (c - 2000 >= 4) for gi, c in vmem if c // 1000 == 2)
-        pos = {c: i for i, (_, c) in enumerate(flat)}
-        order = [c for _, c in vmem]
-        for v in range(hv):
-            assert pos[3000 + v] > pos[1000 + 41 * v + 40], "reload only after the vector's store"
-            assert flat[pos[4000 + v] + 1][1] == 1000 + 41 * v, "the wait directly precedes the vector's first step"
-            # steady state: VMEM issued after the load (previous iteration) + before the wait (this iteration)
-            after = len(order) - 1 - order.index(3000 + v)
-            before = sum(1 for _, c in flat[:pos[4000 + v]] if c // 1000 in (2, 3))
-            assert waits[v] == after + before, (hv, v, waits[v], after, before)
-        last_dma = max(i for i, (gi, c) in enumerate(flat) if c // 1000 == 2 and gi < 135)
-        assert waits[4] == sum(1 for gi, c in flat[last_dma + 1:] if gi < 135 and c // 1000 in (2, 3))
+        assert all(gi < 135 for gi, c in vmem if c // 1000 == 3)
+        last = max(gi for gi, c in vmem if gi < 135)
+        assert waits[4] == last and 135 - last >= 40
+        # the second register set moves into the first after the barrier: every dword once, after nothing reads the first
+        copies = [(gi, c - 5000) for gi, c in flat if c // 1000 == 5]
+        assert [c for _, c in copies] == list(range(4 * hv)) and all(gi >= 135 for gi, _ in copies)
         # per gap: one step next to an LDS read, two otherwise
-        for gi, items in enumerate(gaps[:135]):
-            n = sum(1 for c in items if c // 1000 == 1)
+        for gi, items in enumerate(gaps):
+            n = sum(1 for c in items if c // 1000 in (1, 5))
             assert n <= (1 if has_read(gi % 45) else 2)
 
 
@@ -81,8 +81,8 @@ def test_wide_conv_chunk_program_is_consistent():
     """The compile-time schedule of conv3x3x_kernel (conv3x3x.hip, make_xsched): the 246 BatchNorm steps exactly once, in
     order and finished before the barrier after tap 7; every VMEM instruction alone in a gap without fragment reads; halo
     registers re-loaded after their vector's store, the coefficients after the last step; the weight slices inside the
-    window the six-slot ring allows; and the hand-counted vmcnt values: register-load waits = the younger register loads,
-    DMA waits = every younger VMEM instruction (steady state)."""
+    window the six-slot ring allows; and the SAME-KIND rule for every hand-counted vmcnt: a wait for register loads = the
+    younger register loads only, a wait for LDS-DMA (the three barriers) = the younger LDS-DMA only."""
     items = (ctypes.c_int * (180 * 6))()
     waits = (ctypes.c_int * 10)()
     assert L.lib().sv_debug_conv_chunk_program(items, waits) == 0
@@ -106,23 +106,30 @@ def test_wide_conv_chunk_program_is_consistent():
     gap_of = {c: gi for gi, c in flat}
     # ring windows: slice s of step k = 5 + s (this chunk's taps 5..8, the next chunk's 0..4 = steps 9..13) may be written
     # after the barrier that follows the fragment reads of step k - 6 (those happen during step k - 7), and must be awaited
-    # at a barrier before step k - 1
-    barrier_after = lambda step: next(b for b in (1, 4, 7, 10, 13) if b >= step)
+    # at a barrier before the fragment reads of step k (which happen during step k - 1)
+    barriers = (1, 4, 7, 10, 13)
+    barrier_after = lambda step: next(b for b in barriers if b >= step)
     for sl in range(9):
         k = 5 + sl
         first_gap = min(gap_of[2000 + 3 * sl + i] for i in range(3))
-        assert first_gap // 20 > barrier_after(k - 7) if k - 7 >= 0 else True, (sl, first_gap)
+        last_gap = max(gap_of[2000 + 3 * sl + i] for i in range(3))
+        if k - 7 >= 0:
+            assert first_gap // 20 > barrier_after(k - 7), (sl, first_gap)
+        assert any(last_gap // 20 <= b < k - 1 for b in barriers), "awaited at a barrier before its first read"
     order = [c for _, c in vmem]
-    # waits for register loads count only the younger REGISTER loads (LDS-DMA retires out of order with respect to them)
     reg_since_wrap = lambda code, until: (sum(1 for c in order[order.index(code) + 1:] if c >= 3000) +
                                           sum(1 for gi, c in vmem if pos[c] < until and c >= 3000))
-    since = lambda code, until_gap: sum(1 for gi, c in vmem[order.index(code) + 1:] if gi < until_gap)
     for v in range(6):
         assert pos[3000 + v] > pos[1000 + 41 * v + 40], "reload only after the vector's store"
         assert waits[v] == reg_since_wrap(3000 + v, pos[4000 + v])
     assert pos[3500] > pos[1000 + 41 * 6 - 1]
     assert waits[6] == reg_since_wrap(3503, pos[4500])
-    assert waits[7] == since(2000 + 3 * 0 + 2, 40)          # (this, 5), issued in tap 0, awaited after tap 1
-    assert waits[8] == since(2000 + 3 * 3 + 2, 100)         # (this, 8), tap 3 -> barrier after tap 4
-    assert waits[9] == since(2000 + 3 * 6 + 2, 160)         # (next, 2), tap 6 -> barrier after tap 7
+    # the barriers after taps 1, 4, 7 (before gaps 40, 100, 160) need every DMA issued before them: zero younger DMAs
+    assert waits[7:10] == [0, 0, 0]
+    # ... so they drain the register loads in flight as well: none is issued less than 14 MFMAs before a barrier, and none
+    # behind the last barrier of the chunk (the compiler is told there that the registers have arrived)
+    for gi, c in vmem:
+        if c >= 3000:
+            nb = min(b for b in (40, 100, 160) if b > gi) if gi < 160 else None
+            assert nb is not None and nb - gi >= 14, (c, gi)
     assert gap_of[5000] == 160, "the stage flip precedes the first fragment read of tap 8"

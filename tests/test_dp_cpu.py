@@ -20,35 +20,51 @@ def _worker(rank, world, port, out):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank))
+    import shot_vae_amd as S
     from oracle import closed_form as C
     from oracle import shotvae_oracle as O
     from shot_vae_amd import dp
+    from shot_vae_amd.train import apply_update
     torch.set_num_threads(2)
     r, w, _ = dp.init_from_env(backend="gloo")
     assert (r, w) == (rank, world)
     name, K, B = "wideresnet-10-1", 10, 8
-    st = C.make_state(name, K=K)
+    # the product's module (host side only: flat buffers, views, optimizer plumbing -- no kernel runs on CPU)
+    model = S.VariationalAutoEncoder(name, num_input_channels=3, img_size=(32, 32), data_parallel=True,
+                                     continuous_latent_dim=128, disc_latent_dim=K, small_input=True)
+    model.load_state_dict(C.make_state(name, K=K))
+    eng = model._engine
+    if rank == 1:                       # rank 1 starts from different weights: broadcast_parameters must fix that
+        eng.param.mul_(0.5)
+    epoch0 = eng._manual_epoch
+    dp.broadcast_parameters(model)
+    assert eng._manual_epoch > epoch0, "the broadcast must invalidate the packed weight shadows"
+    flat = eng.param.clone()
+    st = {k.replace(".module.", "."): v.detach().clone() for k, v in model.state_dict().items()}
     keys = [k for k in st if O.is_param(k)]
-    # rank 1 starts from different weights: broadcast_parameters must fix that
-    flat = _flat(st, keys) * (1.0 if rank == 0 else 0.5)
-    dp.broadcast_parameters(flat)
-    off = 0
     for k in keys:
-        n = st[k].numel()
-        st[k] = flat[off:off + n].view_as(st[k]).clone().requires_grad_(True)
-        off += n
+        st[k].requires_grad_(True)
     il, ll, iu, lu = C.make_batch(B, B, K)
     nz = C.make_noise(B // world, B // world, K, stream0=9000 + 10 * rank)
     nz["lam_l"], nz["lam_u"] = 0.8, 0.4                     # every rank must use the same lambdas
     O.train_step(st, name, dp.shard(il, rank, world), dp.shard(ll, rank, world), dp.shard(iu, rank, world), nz,
                  O.schedule(10))
-    g = _flat(st, keys, grad=True)
-    local = g.clone()
-    scale = dp.all_reduce_gradients(g)
+    # this rank's gradient into the flat buffer through the p.grad views, then the product's update path with a PLAIN
+    # torch optimizer: after the all-reduce (sum) it must step on the mean, not on the sum
+    model._attach_grads()
+    for k, prm in model.named_parameters():
+        prm.grad.copy_(st[k.replace(".module.", ".")].grad)
+    local = eng.grad.clone()
     gathered = [torch.zeros_like(local) for _ in range(world)]
     dist.all_gather(gathered, local)
+    opt = torch.optim.SGD(model.parameters(), lr=0.1)
+    apply_update(model, opt, distributed=True)
+    after = eng.param.clone()
+    # and the bare collective
+    g = local.clone()
+    scale = dp.all_reduce_gradients(g)
     if rank == 0:
-        torch.save(dict(reduced=g, scale=scale, locals=gathered, params=flat), out)
+        torch.save(dict(reduced=g, scale=scale, locals=gathered, params=flat, after=after), out)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -62,6 +78,9 @@ def test_two_rank_gradient_all_reduce(tmp_path):
     assert r["scale"] == 0.5
     assert torch.allclose(r["reduced"], r["locals"][0] + r["locals"][1], rtol=1e-6, atol=1e-9)
     assert float((r["locals"][0] - r["locals"][1]).abs().max()) > 0      # the shards really differ
+    # torch.optim.SGD behind apply_update(distributed=True): p -= lr * mean over ranks (not lr * sum)
+    want = r["params"] - 0.1 * 0.5 * (r["locals"][0] + r["locals"][1])
+    assert torch.allclose(r["after"], want, rtol=1e-6, atol=1e-8)
 
 
 def test_shard_partitions_the_batch():

@@ -1,0 +1,118 @@
+"""Host-side logic of the product that needs no GPU: the per-epoch schedule (main_shot_vae.py:270-279,518-520), the
+state_dict key layout against the REFERENCE's own key list (tests/golden/ref_state_keys.json, written by
+tests/golden/make_goldens.py from the reference model for both data_parallel layouts), the checkpoint round trip in the
+reference's {epoch, args, state_dict, optimizer} layout (main_shot_vae.py:237-242,202-213), and the monitor KL formula
+(:330-339) against the reference's value."""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import shot_vae_amd as S
+from oracle import closed_form as C
+from oracle import shotvae_oracle as O
+from tests import _cases as T
+
+
+def _model(name, K, dp):
+    return S.VariationalAutoEncoder(name, num_input_channels=3, img_size=(32, 32), data_parallel=dp,
+                                    continuous_latent_dim=128, disc_latent_dim=K, small_input=True)
+
+
+def test_alpha_schedule_known_answers_and_formula():
+    # alpha_schedule(0, E, a) = a e^-5, (E, E, a) = a; flat after E
+    assert S.alpha_schedule(0, 200, 2.3) == pytest.approx(2.3 * math.exp(-5))
+    assert S.alpha_schedule(200, 200, 2.3) == pytest.approx(2.3)
+    assert S.alpha_schedule(450, 200, 2.3) == pytest.approx(2.3)
+    for e in (0, 1, 10, 77, 199, 240, 399, 599):
+        for E, a in ((200, 1e-3), (400, 1e-3), (150, 4.6), (240, 1.0)):
+            assert S.alpha_schedule(e, E, a) == pytest.approx(a * math.exp(-5 * (1 - min(1, e / E)) ** 2), rel=1e-12)
+
+
+def test_schedule_matches_reference_epoch_scalars():
+    """S.schedule = the seven scalars of main_shot_vae.py:270-279 with the script's defaults (Cifar10 branch: dmi 2.3
+    from :139; wmf 0.4 -> ucw over round(0.4 * epochs) epochs, :279); the Cifar100 branch overrides dmi / akb / apw
+    (:161-163)."""
+    for epoch in (0, 10, 150, 400, 599):
+        s = S.schedule(epoch)
+        want = dict(cmi=0.0, dmi=S.alpha_schedule(epoch, 200, 2.3), ew=S.alpha_schedule(epoch, 400, 1e-3),
+                    kl_beta_c=S.alpha_schedule(epoch, 200, 1e-3), kl_beta_d=S.alpha_schedule(epoch, 200, 1e-3),
+                    pwm=S.alpha_schedule(epoch, 200, 1.0), ucw=S.alpha_schedule(epoch, 240, 1.0))
+        assert set(s) == set(want)
+        for k in want:
+            assert s[k] == pytest.approx(want[k], rel=1e-12), (epoch, k)
+        o = O.schedule(epoch)                      # and the oracle's copy (which the GPU parity tests feed to both sides)
+        for k in want:
+            assert s[k] == pytest.approx(o[k], rel=1e-12), (epoch, k)
+    c100 = S.schedule(10, epochs=700, dmi=4.6, akb=150, apw=400)
+    assert c100["dmi"] == pytest.approx(4.6 * math.exp(-5 * (1 - 10 / 150) ** 2))
+    assert c100["pwm"] == pytest.approx(math.exp(-5 * (1 - 10 / 400) ** 2))
+    assert c100["ucw"] == pytest.approx(math.exp(-5 * (1 - 10 / 280) ** 2))
+
+
+@pytest.mark.parametrize("name,K", [("wideresnet-28-2", 10), ("wideresnet-10-1", 10), ("wideresnet-28-10", 100)])
+@pytest.mark.parametrize("dp", [False, True])
+def test_state_dict_keys_equal_the_reference_key_list(name, K, dp):
+    ref = json.load(open(os.path.join(T.GOLDEN, "ref_state_keys.json")))["%s|K=%d|dp=%d" % (name, K, int(dp))]
+    sd = _model(name, K, dp).state_dict()
+    assert [k for k, _ in ref] == list(sd.keys())
+    for k, shape in ref:
+        assert list(sd[k].shape) == shape, (k, list(sd[k].shape), shape)
+    if dp:
+        assert sum(".module." in k for k in sd) == sum(".module." in k for k, _ in ref) > 0
+
+
+def test_checkpoint_round_trip_in_the_reference_layout(tmp_path):
+    """A checkpoint as main_shot_vae.py:237-242 writes it (torch.optim.SGD state) resumes into FlatSGD, and FlatSGD's
+    state_dict loads back into torch.optim.SGD: same parameter ids, same momentum buffers; the model accepts the other
+    data_parallel key layout."""
+    name, K = "wideresnet-10-1", 10
+    m1 = _model(name, K, True)
+    m1.load_state_dict(C.make_state(name, K=K))
+    opt1 = torch.optim.SGD(m1.parameters(), lr=0.02, momentum=0.9, weight_decay=5e-4)
+    m1._attach_grads()
+    g = torch.Generator().manual_seed(3)
+    m1._engine.grad.copy_(torch.randn(m1._engine.grad.shape, generator=g) * 1e-2)
+    p0 = m1._engine.param.clone()
+    opt1.step()                                        # plain torch on CPU tensors: creates the momentum buffers
+    path = str(tmp_path / "checkpoint.pth.tar")
+    torch.save({"epoch": 7, "args": {"lr": 0.1}, "state_dict": m1.state_dict(), "optimizer": opt1.state_dict()}, path)
+
+    ck = torch.load(path, weights_only=False)
+    m2 = _model(name, K, False)                        # the other key layout
+    m2.load_state_dict(ck["state_dict"])
+    opt2 = S.FlatSGD(m2)
+    opt2.load_state_dict(ck["optimizer"])
+    assert torch.equal(m2._engine.param, m1._engine.param) and not torch.equal(m1._engine.param, p0)
+    assert opt2.param_groups[0]["lr"] == 0.02 and opt2.param_groups[0]["weight_decay"] == 5e-4
+    assert opt2._steps > 0
+    # momentum after the first step = g + wd * p0 in every real (un-padded) element; pads have no parameter and stay 0
+    want = m1._engine.grad + 5e-4 * p0
+    for prm, kind, payload in m2._views:
+        got = m2._flat_view(m2._engine.mom, kind, payload)
+        assert torch.allclose(got, m2._flat_view(want, kind, payload), rtol=1e-6, atol=1e-9)
+    # and back: FlatSGD -> torch.optim.SGD
+    sd2 = opt2.state_dict()
+    opt3 = torch.optim.SGD(m1.parameters(), lr=0.5)
+    opt3.load_state_dict(sd2)
+    assert opt3.param_groups[0]["lr"] == 0.02 and opt3.param_groups[0]["momentum"] == 0.9
+    s1, s3 = opt1.state_dict()["state"], opt3.state_dict()["state"]
+    assert s1.keys() == s3.keys() and len(s1) == len(list(m1.parameters()))
+    for i in s1:
+        assert torch.allclose(s1[i]["momentum_buffer"], s3[i]["momentum_buffer"], rtol=1e-6, atol=1e-9)
+
+
+def test_inference_kl_matches_reference_monitor():
+    """S.inference_kl (main_shot_vae.py:330-339) on the oracle's unlabelled forward = the reference's Train/KL_Inference."""
+    g = T.load("ref_monitor_valid_wrn10_1")
+    name, K = "wideresnet-10-1", 10
+    st = C.make_state(name, K=K)
+    il, ll, iu, lu = C.make_batch(4, 6, K)
+    nz = C.make_noise(4, 6, K)
+    with torch.no_grad():
+        rec, mu, ls, la = O.vae_forward(st, name, iu, nz["eps3"], u=nz["u3"])
+    assert float(S.inference_kl(la, lu)) == pytest.approx(float(g["kl_inference"]), rel=2e-5)
+    assert np.isfinite(float(g["kl_inference"]))

@@ -186,29 +186,28 @@ def test_conv3x3_wide_multitile(case):
 @pytest.mark.parametrize("case", [(4, 160, 160, 8, 3, 1, 1), (8, 128, 128, 8, 3, 1, 1), (1, 96, 128, 32, 3, 1, 1),
                                   (2, 128, 256, 16, 3, 1, 1), (3, 160, 320, 32, 3, 1, 1), (4, 640, 640, 8, 3, 1, 1),
                                   (2, 96, 192, 16, 3, 1, 1)])
-def test_conv3x3_wide_mfma(case, monkeypatch):
+def test_conv3x3_wide_mfma(case):
     """Shapes that take the 256-pixel x 160/128/64-channel LDS-DMA pipelined kernel (conv3x3w.hip): all channel-tile
     widths, the three image sizes (one / several images per tile), odd and even chunk counts, several channel tiles
     per pixel tile, a grid with idle tail blocks; forward with every fusion and the data gradient with the
     activation-backward epilogue (reversed tap order).  (The dispatcher only picks this kernel for grids of at least
-    one block per CU; SV_W3_MIN_BLOCKS lowers that bound for these small parity shapes.)"""
-    monkeypatch.setenv("SV_W3_MIN_BLOCKS", "1")
-    monkeypatch.setenv("SV_CONV3X3X", "0")          # (the 160-channel-tile shapes would otherwise take conv3x3x.hip)
-    test_conv_forward_fused("bf16", case)
-    test_conv_dgrad_with_activation_backward("bf16", case)
+    one block per CU; SV_OPT_WIDE_MIN_BLOCKS lowers that bound for these small parity shapes.)"""
+    # (the 160-channel-tile shapes would otherwise take conv3x3x.hip)
+    with L.options(wide_min_blocks=1, disable=L.K_CONV3X3X):
+        test_conv_forward_fused("bf16", case)
+        test_conv_dgrad_with_activation_backward("bf16", case)
 
 
 @pytest.mark.parametrize("case", [(4, 160, 160, 8, 3, 1, 1), (3, 160, 320, 32, 3, 1, 1), (4, 640, 640, 8, 3, 1, 1),
                                   (2, 320, 160, 16, 3, 1, 1), (72, 160, 160, 32, 3, 1, 1), (70, 96, 320, 16, 3, 1, 1)])
-def test_conv3x3_one_wave_per_simd(case, monkeypatch):
+def test_conv3x3_one_wave_per_simd(case):
     """The gap-scheduled, persistent one-block-per-CU variant of the wide kernel (conv3x3x.hip, the default for
     160-channel tiles): the three image sizes, odd / even chunk counts, one and several channel tiles, blocks with one,
     two and three items (the last two cases: 288 / 140 items on 256 blocks); forward with every fusion and the data gradient
     with the activation-backward epilogue."""
-    monkeypatch.setenv("SV_W3_MIN_BLOCKS", "1")
-    monkeypatch.setenv("SV_CONV3X3X", "1")
-    test_conv_forward_fused("bf16", case)
-    test_conv_dgrad_with_activation_backward("bf16", case)
+    with L.options(wide_min_blocks=1):
+        test_conv_forward_fused("bf16", case)
+        test_conv_dgrad_with_activation_backward("bf16", case)
 
 
 @pytest.mark.parametrize("dt", ["f32", "bf16"])

@@ -317,12 +317,17 @@ def test_step_matches_oracle_b64(dtype, tol_s, tol_t, tol_g):
             assert int(sd[k]) == int(st[k]) == 4
 
 
-def test_wrn28_10_bf16_step_through_wide_kernels_tracks_oracle(monkeypatch):
+def test_wrn28_10_bf16_step_through_wide_kernels_tracks_oracle():
     """WRN-28-10 (BASELINE config 4 family), K=100, B_l = B_u = 16, bf16: the whole step with the wide-layer kernels
-    (conv3x3w for all 21 body convs and their data gradients -- SV_W3_MIN_BLOCKS lowers the dispatcher's grid bound
-    for this small batch -- and wgrad3x3w) against the fp32 CPU oracle: loss terms, outputs, BN running statistics,
-    and the flat gradient's direction."""
-    monkeypatch.setenv("SV_W3_MIN_BLOCKS", "1")
+    (conv3x3x / conv3x3w for all 21 body convs and their data gradients -- SV_OPT_WIDE_MIN_BLOCKS lowers the dispatcher's
+    grid bound for this small batch -- and wgrad3x3w) against the fp32 CPU oracle: loss terms, outputs, BN running
+    statistics, and the flat gradient's direction."""
+    from shot_vae_amd import _lib as L
+    with L.options(wide_min_blocks=1):
+        _wrn28_10_small_batch_body()
+
+
+def _wrn28_10_small_batch_body():
     name, K, Bl, Bu = "wideresnet-28-10", 100, 16, 16
     torch.manual_seed(4)
     il, ll = torch.rand(Bl, 3, 32, 32), torch.randint(0, K, (Bl,))
@@ -489,3 +494,79 @@ def test_full_size_step_properties_bf16():
     assert float(g["feature_extractor.encoder.pre_process.conv0.bias"].abs().max()) < 0.1 * gmax
     # linearity of the accumulated gradient: a second identical backward doubles nothing it should not
     assert all(torch.isfinite(v).all() for v in g.values())
+
+
+def test_monitor_kl_and_valid_metrics_match_reference_goldens():
+    """(a) train_step(..., label_u=...) returns the Train/KL_Inference monitor of main_shot_vae.py:330-339;
+    (b) S.Evaluator = the body of valid() / test() (:409-458): eval-mode forward, AverageMeter means of KL_c, KL_d,
+    MSE(sigmoid(rec), x) / (2 B sigma^2), `ELBO`, top-1 / top-5 -- both against values recorded from the reference
+    (tests/golden/ref_monitor_valid_wrn10_1.npz), fp32-operand mode, 1e-3."""
+    g = T.load("ref_monitor_valid_wrn10_1")
+    name, K = "wideresnet-10-1", 10
+    st = C.make_state(name, K=K)
+    model = make_model(name, K, "fp32", st)
+    elbo, cls = S.VAECriterion(discrete_dim=K).cuda(), S.ClsCriterion()
+    S.FlatSGD(model).zero_grad()
+    il, ll, iu, lu = C.make_batch(4, 6, K)
+    nz = C.make_noise(4, 6, K)
+    with T.rng_for_step(nz):
+        out = S.train_step(model, elbo, cls, None, il.cuda(), ll.cuda(), iu.cuda(), O.schedule(10), label_u=lu.cuda(),
+                           return_outputs=True)
+    assert abs(float(out["kl_inference"]) - float(g["kl_inference"])) <= FP32_TOL * float(g["kl_inference"])
+    with T.rng_for_step(nz):
+        ls_, lu_, kl = S.train_step(model, elbo, cls, None, il.cuda(), ll.cuda(), iu.cuda(), O.schedule(10),
+                                    label_u=lu.cuda())
+    assert torch.is_tensor(kl) and kl.is_cuda            # no host sync inside the step
+    for bce, x_sigma in ((True, 1.0), (False, 0.5)):
+        model = make_model(name, K, "fp32", st)           # fresh running statistics, as the fixture
+        crit = S.VAECriterion(discrete_dim=K, x_sigma=x_sigma, bce_reconstruction=bce).cuda()
+        ev = S.Evaluator(model, crit)
+        for i, B in enumerate((6, 4)):
+            image, label, _, _ = C.make_batch(B, B, K, stream0=7500 + 10 * i)
+            noise = C.make_noise(B, B, K, stream0=9500 + 100 * i)
+            with T.scripted_rng(randn=[noise["eps3"][:B]], rand=[noise["u3"][:B]]):
+                ev.update(image.cuda(), label.cuda())
+        assert model.training                              # update() restores the mode it found
+        res = ev.result()
+        pre = "valid_bce%d." % int(bce)
+        for k in ("klc", "kld", "mse", "elbo"):
+            ref = float(g[pre + k])
+            assert abs(res[k] - ref) <= FP32_TOL * max(abs(ref), 1e-6), (bce, k, res[k], ref)
+        assert res["top1"] == pytest.approx(float(g[pre + "top1"]), abs=1e-6)
+        assert res["top5"] == pytest.approx(float(g[pre + "top5"]), abs=1e-6)
+
+
+def test_backward_through_eval_mode_forward_raises():
+    name, K = "wideresnet-10-1", 10
+    model = make_model(name, K, "fp32", C.make_state(name, K=K)).eval()
+    x = torch.rand(4, 3, 32, 32).cuda()
+    rec, mu, ls, la = model(x)
+    with pytest.raises(NotImplementedError):
+        (rec.sum() + mu.sum()).backward()
+
+
+def test_overlapped_step_passes_optimal_match_and_label_u_through():
+    """train_step_overlapped(optimal_match=True, label_u=...) = train_step(optimal_match=True, label_u=...): the --om
+    pairing (mixup.py:9-18) and the monitor KL are not silently dropped by the two-stream schedule."""
+    from shot_vae_amd.train import train_step_overlapped
+    name, K = "wideresnet-10-1", 10
+    st = C.make_state(name, K=K)
+    m1, m2 = make_model(name, K, "fp32", st), make_model(name, K, "fp32", st)
+    elbo, cls = S.VAECriterion(discrete_dim=K).cuda(), S.ClsCriterion()
+    S.FlatSGD(m1).zero_grad()
+    S.FlatSGD(m2).zero_grad()
+    il, ll, iu, lu = C.make_batch(4, 6, K)
+    nz = C.make_noise(4, 6, K)
+    sch = O.schedule(10)
+    with T.rng_for_step(nz, om=True):
+        a = S.train_step(m1, elbo, cls, None, il.cuda(), ll.cuda(), iu.cuda(), sch, optimal_match=True, label_u=lu.cuda())
+    with T.scripted_rng(randn=[nz["eps1"], nz["eps3"], nz["eps2"], nz["eps4"]], rand=[nz["u3"], nz["u4"]],
+                        randperm=[nz["perm_l"]], beta=[nz["lam_l"], nz["lam_u"]]):
+        b = train_step_overlapped(m2, elbo, cls, None, il.cuda(), ll.cuda(), iu.cuda(), sch, optimal_match=True,
+                                  label_u=lu.cuda())
+    torch.cuda.synchronize()
+    assert len(a) == len(b) == 3
+    for x, y in zip(a, b):
+        assert abs(float(x) - float(y)) <= 1e-4 * max(abs(float(x)), 1e-6)
+    ga, gb = m1.flat_parameters()[1], m2.flat_parameters()[1]
+    assert float((ga - gb).abs().max()) <= 2e-4 * float(ga.abs().max())

@@ -1,0 +1,197 @@
+"""Full-size checks of the hand-scheduled wide-layer kernels (conv3x3x.hip, conv3x3w.hip, wgrad3x3w in wgrad3x3.hip) on
+a real MI355X.  These kernels pipeline LDS-DMA and register loads with hand-placed waits; a wait that is one request
+short reads stale data only when the timing is unlucky, so the checks here run the DEFAULT dispatch at BASELINE
+config 4's full size (every persistent block walks several items, which small parity shapes do not do), repeatedly,
+next to a stream that keeps HBM busy.
+
+  * conv3x3x against conv3x3w BIT FOR BIT (both accumulate every output in the same order);
+  * wgrad3x3w against the narrow 32 x 32-slab kernel (different summation order: fp32 rounding only);
+  * the whole WRN-28-10 / K = 100 / B_l = B_u = 256 bf16 step (main_shot_vae.py:280-366), 20 times from the same state:
+    finite, the size-independent properties, every repeat equal to the first up to atomic-order rounding, and the loss
+    terms against the fp32 CPU oracle on the same inputs."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import shot_vae_amd as S                     # noqa: E402
+from oracle import shotvae_oracle as O       # noqa: E402
+from shot_vae_amd import _lib as L           # noqa: E402
+from shot_vae_amd import geometry as G       # noqa: E402
+from tests import _cases as T                # noqa: E402
+
+BF = torch.bfloat16
+SHAPES = [(160, 32, 160), (320, 16, 320), (640, 8, 640), (160, 32, 320), (320, 16, 160)]      # Cin, H, N
+
+
+def _st():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class _HbmLoad:
+    """A second stream that copies a 1 GiB buffer back and forth while the kernels under test run."""
+
+    def __init__(self):
+        self.stream = torch.cuda.Stream()
+        self.a = torch.empty(256 << 20, dtype=torch.float32, device="cuda")
+        self.b = torch.empty_like(self.a)
+
+    def kick(self, n=2):
+        with torch.cuda.stream(self.stream):
+            for _ in range(n):
+                self.b.copy_(self.a)
+
+
+def _conv_args(x, wp, out, sc, sh, resid=None, stats=None, ex=None):
+    a = L.SvIgemmArgs()
+    a.x, a.w, a.out = x.data_ptr(), wp.data_ptr(), out.data_ptr()
+    a.pro_scale, a.pro_shift, a.pro_slope = (sc.data_ptr(), sh.data_ptr(), 0.01) if sc is not None else (None, None, 0.0)
+    a.replicas = 8
+    if resid is not None:
+        a.residual = resid.data_ptr()
+    if stats is not None:
+        a.stats = stats.data_ptr()
+    if ex is not None:
+        raw, esc, esh, emu, ers, bsums = ex
+        a.ex, a.ex_scale, a.ex_shift, a.ex_mean, a.ex_rstd = (t.data_ptr() for t in (raw, esc, esh, emu, ers))
+        a.ex_slope, a.bsums = 0.01, bsums.data_ptr()
+    return a
+
+
+@pytest.mark.parametrize("Cin,H,N", SHAPES)
+def test_conv3x3x_equals_conv3x3w_bitwise_at_full_size(Cin, H, N):
+    """B = 512 (1 024 / 512 / 256 pixel tiles on 256 persistent blocks): forward with BatchNorm prologue + residual +
+    statistics and the data gradient with the activation-backward epilogue, 6 fresh random draws each, with a
+    bandwidth-saturating copy stream beside them."""
+    B, d = 512, torch.device("cuda:0")
+    torch.manual_seed(Cin + H)
+    load = _HbmLoad()
+    master = (torch.randn(N, 9, Cin, device=d) / (9 * Cin) ** 0.5).contiguous()
+    gf = G.conv_like(B, H, H, Cin, N, 3, 1, 1)
+    gd = G.convT_like(B, H, H, N, Cin, 3, 1, 1)              # data gradient of that layer: input dy [.., N], output [.., Cin]
+    wf = torch.zeros(G.packed_size(gf), dtype=BF, device=d)
+    wd = torch.zeros(G.packed_size(gd), dtype=BF, device=d)
+    L.call("sv_repack", L.SV_BF16, C.c_void_p(master.data_ptr()), N, 9, Cin, 0, C.byref(gf), C.c_void_p(wf.data_ptr()), _st())
+    L.call("sv_repack", L.SV_BF16, C.c_void_p(master.data_ptr()), N, 9, Cin, 1, C.byref(gd), C.c_void_p(wd.data_ptr()), _st())
+    for it in range(6):
+        x = torch.randn(B, H, H, Cin, device=d).to(BF)
+        resid = torch.randn(B, H, H, N, device=d).to(BF)
+        dy = torch.randn(B, H, H, N, device=d).to(BF)
+        sc, sh = torch.rand(Cin, device=d) + 0.5, torch.randn(Cin, device=d) * 0.3
+        emu, ers = torch.randn(Cin, device=d) * 0.1, torch.rand(Cin, device=d) + 0.5
+        res = []
+        for mask in (0, L.K_CONV3X3X):
+            with L.options(disable=mask):
+                load.kick()
+                out = torch.zeros(B, H, H, N, dtype=BF, device=d)
+                stats = torch.zeros(8 * 2 * N, device=d)
+                a = _conv_args(x, wf, out, sc, sh, resid=resid, stats=stats)
+                L.call("sv_igemm", C.byref(gf), L.SV_BF16, C.byref(a), _st())
+                dx = torch.zeros(B, H, H, Cin, dtype=BF, device=d)
+                bsums = torch.zeros(8 * 2 * Cin, device=d)
+                a2 = _conv_args(dy, wd, dx, None, None, ex=(x, sc, sh, emu, ers, bsums))
+                L.call("sv_igemm", C.byref(gd), L.SV_BF16, C.byref(a2), _st())
+                torch.cuda.synchronize()
+                res.append((out, stats.view(8, 2, N).sum(0), dx, bsums.view(8, 2, Cin).sum(0)))
+        (o1, s1, d1, b1), (o0, s0, d0, b0) = res
+        assert torch.isfinite(o1.float()).all() and torch.isfinite(d1.float()).all()
+        nf = int((o1.view(torch.int16) != o0.view(torch.int16)).sum())
+        nd = int((d1.view(torch.int16) != d0.view(torch.int16)).sum())
+        assert nf == 0 and nd == 0, "conv3x3x differs from conv3x3w: %d forward / %d dgrad outputs (draw %d)" % (nf, nd, it)
+        assert float((s1 - s0).abs().max() / s0.abs().max()) < 1e-4
+        assert float((b1 - b0).abs().max() / b0.abs().max()) < 1e-4
+
+
+@pytest.mark.parametrize("Cin,H,N", SHAPES[:3])
+def test_wgrad3x3w_equals_narrow_kernel_at_full_size(Cin, H, N):
+    """wgrad3x3w (160 x 32 slabs, one wave per SIMD, double-buffered halo registers) against wgrad3x3_kernel (32 x 32
+    slabs) on the same operands at B = 512, 4 draws, copy stream beside them.  Both sum bf16 products in fp32; only the
+    order differs."""
+    B, d = 512, torch.device("cuda:0")
+    torch.manual_seed(7 * Cin + H)
+    load = _HbmLoad()
+    g = G.conv_like(B, H, H, Cin, N, 3, 1, 1)
+    ws = torch.empty(16 * 1024 * 1024, device=d)
+    for it in range(4):
+        x = torch.randn(B, H, H, Cin, device=d).to(BF)
+        dy = (torch.randn(B, H, H, N, device=d) * 0.05).to(BF)
+        sc, sh = torch.rand(Cin, device=d) + 0.5, torch.randn(Cin, device=d) * 0.3
+        got = []
+        for mask in (0, L.K_WGRAD3X3W):
+            with L.options(disable=mask):
+                load.kick()
+                dw = torch.zeros(N, 9, Cin, device=d)
+                L.call("sv_wgrad", C.byref(g), L.SV_BF16, C.c_void_p(x.data_ptr()), C.c_void_p(sc.data_ptr()),
+                       C.c_void_p(sh.data_ptr()), 0.01, C.c_void_p(dy.data_ptr()), C.c_void_p(dw.data_ptr()), 0, 1,
+                       C.c_void_p(ws.data_ptr()), ws.numel(), _st())
+                torch.cuda.synchronize()
+                got.append(dw)
+        assert torch.isfinite(got[0]).all()
+        err = float((got[0] - got[1]).abs().max() / got[1].abs().max())
+        assert err < 2e-4, (Cin, H, N, it, err)
+
+
+def test_config4_full_size_step_default_dispatch_repeats():
+    """BASELINE config 4 at full size through the default dispatch (conv3x3x, conv3x3w, wgrad3x3w on every body layer):
+    20 steps from the same parameters, inputs and noise -- 10 sequential, 10 on the two-stream schedule the bench uses."""
+    from shot_vae_amd.train import train_step_overlapped
+    name, K, B = "wideresnet-28-10", 100, 256
+    torch.manual_seed(11)
+    il, ll, iu = torch.rand(B, 3, 32, 32), torch.randint(0, K, (B,)), torch.rand(B, 3, 32, 32)
+    nz = O.make_noise(B, B, K, seed=21)
+    nz["lam_l"] = 0.9
+    sch = O.schedule(10, dmi=4.6)
+    init = O.default_init(name, K=K, seed=5)
+    model = S.VariationalAutoEncoder(name, num_input_channels=3, img_size=(32, 32), data_parallel=True,
+                                     continuous_latent_dim=128, disc_latent_dim=K, small_input=True, compute_dtype="bf16")
+    model.load_state_dict({k: v.detach() for k, v in init.items()})
+    model = model.cuda().train()
+    elbo, cls = S.VAECriterion(discrete_dim=K, bce_reconstruction=True).cuda(), S.ClsCriterion()
+    opt = S.FlatSGD(model)
+    opt.zero_grad()
+    ilc, llc, iuc = il.cuda(), ll.cuda(), iu.cuda()
+    load = _HbmLoad()
+    first, g0 = None, None
+    for rep in range(20):
+        opt.zero_grad()
+        if rep % 4 == 3:
+            load.kick(8)
+        if rep < 10:
+            with T.rng_for_step(nz):
+                out = S.train_step(model, elbo, cls, None, ilc, llc, iuc, sch, return_outputs=True)
+            torch.cuda.synchronize()
+            vals = {k: float(out[k]) for k in T.SCALARS}
+        else:
+            with T.scripted_rng(randn=[nz["eps1"], nz["eps3"], nz["eps2"], nz["eps4"]], rand=[nz["u3"], nz["u4"]],
+                                randperm=[nz["perm_l"], nz["perm_u"]], beta=[nz["lam_l"], nz["lam_u"]]):
+                ls, lu = train_step_overlapped(model, elbo, cls, None, ilc, llc, iuc, sch)
+            torch.cuda.synchronize()
+            vals = {"loss_sup": float(ls), "loss_unsup": float(lu)}
+        grad = model.flat_parameters()[1].detach().clone()
+        assert all(np.isfinite(v) for v in vals.values()), (rep, vals)
+        assert bool(torch.isfinite(grad).all()), rep
+        if rep == 0:
+            first, g0 = vals, grad
+            for i in (1, 2, 3, 4):            # size-independent properties of the first run's outputs
+                la = out["la%d" % i].double()
+                assert float((la.exp().sum(1) - 1).abs().max()) < 1e-5
+            mu, lsg = out["mu1"].double(), out["ls1"].double()
+            klc = 0.5 * (mu * mu + torch.exp(2 * lsg) - 2 * lsg - 1).sum() / B
+            assert abs(float(klc) - vals["klc_l"]) < 1e-3 * float(klc)
+            assert 0.0 <= vals["kld_l"] <= np.log(K) + 1e-4
+        else:
+            # the same step again: only the order of float atomics (BN statistics, gradient accumulation) may differ
+            for k, v in vals.items():
+                assert abs(v - first[k]) <= 2e-3 * max(abs(first[k]), 1e-3), (rep, k, v, first[k])
+            cos = float((grad.double() @ g0.double()) / grad.double().norm() / g0.double().norm())
+            assert cos > 0.995, (rep, cos)
+    # loss terms against the fp32 CPU oracle on the same inputs (bf16 tolerance of SURVEY.md 8d, doubled for K = 100)
+    st = {k: v.clone() for k, v in init.items()}
+    with torch.no_grad():
+        ref = O.train_step(st, name, il, ll, iu, nz, sch, backward=False)
+    for k in T.SCALARS:
+        r = float(ref[k])
+        assert abs(first[k] - r) <= 1e-2 * max(abs(r), 1e-6), (k, first[k], r)
