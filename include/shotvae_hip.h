@@ -205,6 +205,17 @@ int sv_augment(int dtype, const uint8_t* data, const int64_t* index, const int32
 int sv_repack(int dtype, const float* master, int N, int T_orig, int C, int transpose,
               const sv_geom* g, void* dst, void* stream);
 
+/* All packs of a network in one launch (68 sv_repack launches per optimizer step otherwise).  jobs: DEVICE array, one
+ * entry per (layer, direction, phase) with taps, sorted by block0; a job owns ceil(size / 256) consecutive blocks from
+ * block0; total_blocks = their sum.  Offsets are in elements from master_base (fp32) / dst_base (`dtype`).             */
+typedef struct {
+    int64_t master_off, dst_off, size;      /* size = N * C * ntap elements of this phase's pack                     */
+    int32_t N, T_orig, C, transpose, ntap, block0;
+    int8_t torig[SV_MAX_TAPS];
+} sv_repack_job;
+int sv_repack_batch(int dtype, const float* master_base, const sv_repack_job* jobs, int njobs, int total_blocks,
+                    void* dst_base, void* stream);
+
 /* ---- in-situ kernel timing (HIP events around launches of sv_igemm / sv_wgrad) -------------------
  * sv_prof_enable(1) starts recording; every launch is filed under the current tag (sv_prof_tag).
  * sv_prof_collect synchronises the device and returns, per tag, total milliseconds and launches.   */

@@ -36,6 +36,12 @@ class SvIgemmArgs(C.Structure):
                 ("replicas", C.c_int32)]
 
 
+class SvRepackJob(C.Structure):
+    _fields_ = [("master_off", C.c_int64), ("dst_off", C.c_int64), ("size", C.c_int64), ("N", C.c_int32),
+                ("T_orig", C.c_int32), ("C", C.c_int32), ("transpose", C.c_int32), ("ntap", C.c_int32),
+                ("block0", C.c_int32), ("torig", C.c_int8 * MAX_TAPS)]
+
+
 class SvBnBranch(C.Structure):
     _fields_ = [("g", C.c_void_p), ("bsums", C.c_void_p), ("gamma", C.c_void_p), ("dgamma", C.c_void_p),
                 ("dbeta", C.c_void_p), ("replicas", C.c_int32)]
@@ -69,6 +75,7 @@ _PROTOS = {
     "sv_nchw_to_nhwc": [I, P, I, I, I, I, I, P, P],
     "sv_nhwc_to_nchw": [I, P, I, I, I, I, I, P, P],
     "sv_repack": [I, P, I, I, I, I, C.POINTER(SvGeom), P, P],
+    "sv_repack_batch": [I, P, P, I, I, P, P],
     "sv_augment": [I, P, P, P, I, I, I, I, I, I, P, P],
     "sv_prof_enable": [I],
     "sv_prof_tag": [I],
@@ -141,7 +148,15 @@ class options:
         return False
 
 
+# in-situ timing (bench.py): tag name -> id; every entry point is filed under its own name unless the engine filed the
+# launch under a per-layer tag first (Engine._tag, for sv_igemm / sv_wgrad)
+prof_tags = None
+_LAYER_TAGGED = ("sv_igemm", "sv_wgrad", "sv_prof_tag", "sv_prof_enable", "sv_set_option")
+
+
 def call(name, *args):
+    if prof_tags is not None and name not in _LAYER_TAGGED:
+        lib().sv_prof_tag(prof_tags.setdefault(name, len(prof_tags)))
     rc = getattr(lib(), name)(*args)
     if rc != 0:
         raise ShotVaeHipError("%s failed (%d): %s" % (name, rc, lib().sv_last_error().decode()))

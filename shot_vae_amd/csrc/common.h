@@ -59,6 +59,12 @@ int sv_wide_min_blocks();                // sv_set_option(SV_OPT_WIDE_MIN_BLOCKS
 int sv_check_launch(const char* what);
 void sv_prof_begin(hipStream_t s);
 void sv_prof_end(hipStream_t s);
+// brackets the launches of one entry point with the in-situ timing events (no-ops unless sv_prof_enable(1))
+struct SvProfScope {
+    hipStream_t s;
+    explicit SvProfScope(void* st) : s((hipStream_t)st) { sv_prof_begin(s); }
+    ~SvProfScope() { sv_prof_end(s); }
+};
 int sv_conv3x3_try(const sv_geom* g, int dtype, const sv_igemm_args* a, hipStream_t s, int* rc);
 int sv_conv3x3w_try(const sv_geom* g, int dtype, const sv_igemm_args* a, hipStream_t s, int* rc);
 int sv_conv3x3x_try(const sv_geom* g, const sv_igemm_args* a, bool fwd, hipStream_t s, int* rc);

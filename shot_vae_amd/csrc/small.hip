@@ -777,6 +777,25 @@ struct repack_params {
     int64_t w_off[SV_MAX_PHASES], size[SV_MAX_PHASES];
     int8_t torig[SV_MAX_PHASES][SV_MAX_TAPS];
 };
+// every (layer, direction, phase) of the network in ONE launch: block b serves the job with block0 <= b < next block0
+template <typename T>
+__global__ __launch_bounds__(256) void repack_batch_kernel(const float* master, const sv_repack_job* jobs, int njobs, T* dst) {
+    int lo = 0, hi = njobs - 1;
+    const int b = blockIdx.x;
+    while (lo < hi) {                       // last job whose first block is <= b (uniform: scalar loads)
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].block0 <= b) lo = mid; else hi = mid - 1;
+    }
+    const sv_repack_job& J = jobs[lo];
+    const int64_t i = (int64_t)(b - J.block0) * 256 + threadIdx.x;
+    if (i >= J.size) return;
+    const int cp = J.transpose ? J.N : J.C;
+    const int c1 = (int)(i % cp);
+    const int t = (int)((i / cp) % J.ntap);
+    const int n1 = (int)(i / ((int64_t)cp * J.ntap));
+    const int n = J.transpose ? c1 : n1, c = J.transpose ? n1 : c1;
+    dst[J.dst_off + i] = (T)master[J.master_off + ((int64_t)n * J.T_orig + J.torig[t]) * J.C + c];
+}
 template <typename T>
 __global__ void repack_kernel(const float* master, const repack_params p, T* dst) {
     // dst rows n' (= N or C when transposed), cols [ntap][c'] per phase
@@ -816,6 +835,7 @@ extern "C" {
 int sv_bn_finalize(const float* stats, int replicas, int C, float count, const float* gamma, const float* beta, float eps,
                    float momentum, float* rm, float* rv, float* scale, float* shift, float* mean,
                    float* rstd, void* stream) {
+    SvProfScope prof_scope(stream);
     SV_REQUIRE(stats && gamma && beta && scale && shift && mean && rstd && C > 0 && replicas >= 1, SV_E_ARG,
                "sv_bn_finalize: bad args");
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 7) / 8), dim3(256), 0, (hipStream_t)stream, stats, replicas, C,
@@ -825,6 +845,7 @@ int sv_bn_finalize(const float* stats, int replicas, int C, float count, const f
 
 int sv_bn_running_update(const int32_t* table, const float* counts, int nbn, const float* bnbuf, float* bufs,
                          float eps, float momentum, int align, void* stream) {
+    SvProfScope prof_scope(stream);
     SV_REQUIRE(table && counts && bnbuf && bufs && nbn > 0 && align > 0, SV_E_ARG, "sv_bn_running_update: bad args");
     hipLaunchKernelGGL(bn_running_update_kernel, dim3(nbn), dim3(256), 0, (hipStream_t)stream, table, counts, bnbuf,
                        bufs, eps, momentum, align);
@@ -833,6 +854,7 @@ int sv_bn_running_update(const int32_t* table, const float* counts, int nbn, con
 
 int sv_bn_eval_affine(int C, const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
                       float* scale, float* shift, void* stream) {
+    SvProfScope prof_scope(stream);
     SV_REQUIRE(gamma && beta && rm && rv && scale && shift && C > 0, SV_E_ARG, "sv_bn_eval_affine: null");
     hipLaunchKernelGGL(bn_eval_affine_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, C, gamma,
                        beta, rm, rv, eps, scale, shift);
@@ -842,6 +864,7 @@ int sv_bn_eval_affine(int C, const float* gamma, const float* beta, const float*
 int sv_bn_bwd_apply(int dtype, int64_t M, int C, int ld, const void* x, const float* mean, const float* rstd,
                     float count, const sv_bn_branch* br, int nbranch, const void* residual, void* dx,
                     void* stream) {
+    SvProfScope prof_scope(stream);
     SV_REQUIRE(x && mean && rstd && br && dx && nbranch >= 1 && nbranch <= 2, SV_E_ARG, "sv_bn_bwd_apply: bad args");
     SV_REQUIRE(C % 8 == 0 && ld % 8 == 0, SV_E_SHAPE, "sv_bn_bwd_apply: C=%d ld=%d must be multiples of 8", C, ld);
     bnb_params p;
@@ -865,6 +888,7 @@ int sv_bn_bwd_apply(int dtype, int64_t M, int C, int ld, const void* x, const fl
 }
 
 int sv_colsum(int dtype, const void* y, int64_t M, int N, int ld, float* out, void* stream) {
+    SvProfScope prof_scope(stream);
     SV_REQUIRE(y && out && N > 0, SV_E_ARG, "sv_colsum: null");
     const int bx = N < 64 ? N : 64;
     SV_REQUIRE(256 % bx == 0, SV_E_SHAPE, "sv_colsum: N=%d", N);
@@ -876,6 +900,7 @@ int sv_colsum(int dtype, const void* y, int64_t M, int N, int ld, float* out, vo
 
 int sv_pool_fwd(int dtype, const void* x, const float* scale, const float* shift, float slope, int B, int HW,
                 int C, int ld, float* feat, void* stream) {
+    SvProfScope prof_scope(stream);
     SV_REQUIRE(x && scale && shift && feat, SV_E_ARG, "sv_pool_fwd: null");
     SV_REQUIRE(slope >= 0.f && slope <= 1.f, SV_E_ARG, "sv_pool_fwd: activation slope %g outside [0, 1]", (double)slope);
     DISPATCH_T(dtype, hipLaunchKernelGGL((pool_fwd_kernel<T>), dim3((B * C + 255) / 256), dim3(256), 0,
@@ -886,6 +911,7 @@ int sv_pool_fwd(int dtype, const void* x, const float* scale, const float* shift
 int sv_pool_bwd(int dtype, const void* x, const float* scale, const float* shift, float slope, const float* mean,
                 const float* rstd, const float* dfeat, int B, int HW, int C, int ld, void* g, float* bsums,
                 void* stream) {
+    SvProfScope prof_scope(stream);
     SV_REQUIRE(x && scale && shift && mean && rstd && dfeat && g && bsums, SV_E_ARG, "sv_pool_bwd: null");
     DISPATCH_T(dtype, hipLaunchKernelGGL((pool_bwd_kernel<T>), dim3((B * C + 255) / 256), dim3(256), 0,
                                          (hipStream_t)stream, (const T*)x, scale, shift, slope, mean, rstd, dfeat,
@@ -895,6 +921,7 @@ int sv_pool_bwd(int dtype, const void* x, const float* scale, const float* shift
 
 int sv_head_fwd(const float* feat, int B, int C, const float* W, const float* bias, int ldc, int K, float* mu,
                 float* ls, float* la, void* stream) {
+    SvProfScope prof_scope(stream);
     SV_REQUIRE(feat && W && bias && mu && ls && la, SV_E_ARG, "sv_head_fwd: null");
     const size_t lds = (size_t)HS * (C + 2 * ldc + K) * sizeof(float);
     SV_REQUIRE(lds <= 64 * 1024, SV_E_SHAPE, "sv_head_fwd: C=%d too large", C);
@@ -906,6 +933,7 @@ int sv_head_fwd(const float* feat, int B, int C, const float* W, const float* bi
 int sv_head_bwd(const float* feat, int B, int C, const float* W, int ldc, int K, const float* la,
                    const float* dmu, const float* dls, const float* dla, float* dfeat, float* dW, float* dbias,
                    float* dout_ws, void* stream) {
+    SvProfScope prof_scope(stream);
     SV_REQUIRE(feat && W && la && dmu && dls && dla && dfeat && dW && dbias && dout_ws, SV_E_ARG, "sv_head_bwd: null");
     const int NH = 2 * ldc + K;
     const size_t lds = (size_t)HS * NH * sizeof(float);
@@ -920,6 +948,7 @@ int sv_sample_fwd(int dtype, const float* mu, const float* ls, const float* la, 
                   const int64_t* label, const int64_t* label_mix, float lam, const float* lam_dev, int mode,
                   float temperature, int B,
                   int ldc, int K, int Lpad, void* latent, float* csoft, void* stream) {
+    SvProfScope prof_scope(stream);
     SV_REQUIRE(mu && ls && la && eps && latent && csoft, SV_E_ARG, "sv_sample_fwd: null");
     SV_REQUIRE((mode == 0 && u) || (mode == 1 && label) || (mode == 2 && label && label_mix), SV_E_ARG,
                "sv_sample_fwd: mode %d inputs missing", mode);
@@ -933,6 +962,7 @@ int sv_sample_fwd(int dtype, const float* mu, const float* ls, const float* la, 
 int sv_sample_bwd(int dtype, const void* dlatent, const float* ls, const float* eps, const float* csoft, int mode,
                   float temperature, int B, int ldc, int K, int Lpad, float* dmu, float* dls, float* dla,
                   void* stream) {
+    SvProfScope prof_scope(stream);
     SV_REQUIRE(dlatent && ls && eps && csoft && dmu && dls && dla, SV_E_ARG, "sv_sample_bwd: null");
     DISPATCH_T(dtype, hipLaunchKernelGGL((sample_bwd_kernel<T>), dim3(B), dim3(128), 0, (hipStream_t)stream,
                                          (const T*)dlatent, ls, eps, csoft, mode, temperature, B, ldc, K, Lpad, dmu,
@@ -948,6 +978,7 @@ static float log_prior_f32(int K) {
 
 int sv_elbo_fwd(const float* x, const float* x_rec, int64_t n_per_img, const float* mu, const float* ls,
                 const float* la, int B, int ldc, int K, int bce, float x_sigma, float* out3, void* stream) {
+    SvProfScope prof_scope(stream);
     SV_REQUIRE(x && x_rec && mu && ls && la && out3, SV_E_ARG, "sv_elbo_fwd: null");
     const int64_t n = n_per_img * B;
     hipLaunchKernelGGL(elbo_fwd_kernel, dim3(nblocks(n / 4, 256, 1024)), dim3(256), 0, (hipStream_t)stream, x, x_rec,
@@ -958,6 +989,7 @@ int sv_elbo_fwd(const float* x, const float* x_rec, int64_t n_per_img, const flo
 int sv_elbo_bwd(const float* x, const float* x_rec, int64_t n_per_img, const float* mu, const float* ls,
                 const float* la, int B, int ldc, int K, int bce, float x_sigma, const float* gout3, float* dx_rec,
                 float* dmu, float* dls, float* dla, void* stream) {
+    SvProfScope prof_scope(stream);
     SV_REQUIRE(x && x_rec && mu && ls && la && gout3 && dx_rec && dmu && dls && dla, SV_E_ARG, "sv_elbo_bwd: null");
     const int64_t n = n_per_img * B;
     hipLaunchKernelGGL(elbo_bwd_kernel, dim3(nblocks(n, 256, 2048)), dim3(256), 0, (hipStream_t)stream, x, x_rec, n,
@@ -966,18 +998,21 @@ int sv_elbo_bwd(const float* x, const float* x_rec, int64_t n_per_img, const flo
 }
 
 int sv_cls_fwd(const float* predict, const float* label, const float* weight, int B, int K, float* out, void* stream) {
+    SvProfScope prof_scope(stream);
     SV_REQUIRE(predict && label && out, SV_E_ARG, "sv_cls_fwd: null");
     hipLaunchKernelGGL(cls_fwd_kernel, dim3(nblocks((int64_t)B * K, 256, 64)), dim3(256), 0, (hipStream_t)stream,
                        predict, label, weight, B, K, out);
     return sv_check_launch("sv_cls_fwd");
 }
 int sv_cls_bwd(const float* label, const float* weight, int B, int K, const float* gout, float* dpredict, void* stream) {
+    SvProfScope prof_scope(stream);
     SV_REQUIRE(label && gout && dpredict, SV_E_ARG, "sv_cls_bwd: null");
     hipLaunchKernelGGL(cls_bwd_kernel, dim3(((int64_t)B * K + 255) / 256), dim3(256), 0, (hipStream_t)stream, label,
                        weight, B, K, gout, dpredict);
     return sv_check_launch("sv_cls_bwd");
 }
 int sv_topk_hits(const float* score, const int64_t* label, int B, int K, int k, float* hits, void* stream) {
+    SvProfScope prof_scope(stream);
     SV_REQUIRE(score && label && hits && B >= 0 && K >= 1 && k >= 1, SV_E_ARG, "sv_topk_hits: bad argument");
     if (B == 0) return SV_OK;
     hipLaunchKernelGGL(topk_hits_kernel, dim3(nblocks(B, 256, 64)), dim3(256), 0, (hipStream_t)stream, score, label, B, K,
@@ -986,6 +1021,7 @@ int sv_topk_hits(const float* score, const int64_t* label, int B, int K, int k, 
 }
 int sv_post_fwd(const float* mu, const float* ls, const float* mu_t, const float* sigma_t, int B, int D, float* out,
                 void* stream) {
+    SvProfScope prof_scope(stream);
     SV_REQUIRE(mu && ls && mu_t && sigma_t && out, SV_E_ARG, "sv_post_fwd: null");
     hipLaunchKernelGGL(post_fwd_kernel, dim3(nblocks((int64_t)B * D, 256, 64)), dim3(256), 0, (hipStream_t)stream, mu,
                        ls, mu_t, sigma_t, B, D, out);
@@ -993,6 +1029,7 @@ int sv_post_fwd(const float* mu, const float* ls, const float* mu_t, const float
 }
 int sv_post_bwd(const float* mu, const float* ls, const float* mu_t, const float* sigma_t, int B, int D,
                 const float* gout, float* dmu, float* dls, void* stream) {
+    SvProfScope prof_scope(stream);
     SV_REQUIRE(mu && ls && mu_t && sigma_t && gout && dmu && dls, SV_E_ARG, "sv_post_bwd: null");
     hipLaunchKernelGGL(post_bwd_kernel, dim3(((int64_t)B * D + 255) / 256), dim3(256), 0, (hipStream_t)stream, mu, ls,
                        mu_t, sigma_t, B, D, gout, dmu, dls);
@@ -1001,6 +1038,7 @@ int sv_post_bwd(const float* mu, const float* ls, const float* mu_t, const float
 
 int sv_mix_lerp(const float* a, const int64_t* index, float lam, const float* lam_dev, int B, int64_t row,
                 int exp_space, float* out, void* stream) {
+    SvProfScope prof_scope(stream);
     SV_REQUIRE(a && index && out, SV_E_ARG, "sv_mix_lerp: null");
     if (B == 0 || row == 0) return SV_OK;
     hipLaunchKernelGGL(mix_lerp_kernel, dim3((unsigned)((row + 255) / 256), B), dim3(256), 0, (hipStream_t)stream, a,
@@ -1009,6 +1047,7 @@ int sv_mix_lerp(const float* a, const int64_t* index, float lam, const float* la
 }
 
 int sv_optimal_match(const float* mu, const float* ls, int B, int D, int64_t* index, void* stream) {
+    SvProfScope prof_scope(stream);
     SV_REQUIRE(mu && ls && index && B >= 2, SV_E_ARG, "sv_optimal_match: bad args");
     const size_t lds = (size_t)(2 * D + B) * sizeof(float);
     SV_REQUIRE(lds <= 64 * 1024, SV_E_SHAPE, "sv_optimal_match: B=%d D=%d too large", B, D);
@@ -1018,6 +1057,7 @@ int sv_optimal_match(const float* mu, const float* ls, int B, int D, int64_t* in
 
 int sv_sgd(float* p, const float* g, float* v, int64_t n, float lr, float momentum, float weight_decay,
            float grad_scale, int first_step, void* stream) {
+    SvProfScope prof_scope(stream);
     SV_REQUIRE(p && g && v && n >= 0, SV_E_ARG, "sv_sgd: null");
     if (n == 0) return SV_OK;
     hipLaunchKernelGGL(sgd_kernel, dim3(nblocks(n / 4, 256, 2048)), dim3(256), 0, (hipStream_t)stream, p, g, v, n, lr,
@@ -1026,6 +1066,7 @@ int sv_sgd(float* p, const float* g, float* v, int64_t n, float lr, float moment
 }
 
 int sv_nchw_to_nhwc(int dtype, const float* in, int B, int C, int H, int W, int Cpad, void* out, void* stream) {
+    SvProfScope prof_scope(stream);
     SV_REQUIRE(in && out && Cpad >= C, SV_E_ARG, "sv_nchw_to_nhwc: bad args");
     const int64_t n = (int64_t)B * H * W * Cpad;
     DISPATCH_T(dtype, hipLaunchKernelGGL((nchw_to_nhwc_kernel<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
@@ -1034,6 +1075,7 @@ int sv_nchw_to_nhwc(int dtype, const float* in, int B, int C, int H, int W, int 
 }
 int sv_augment(int dtype, const uint8_t* data, const int64_t* index, const int32_t* params, int B, int H, int W, int C,
                int pad, int nhwc_cpad, void* out, void* stream) {
+    SvProfScope prof_scope(stream);
     SV_REQUIRE(data && index && out, SV_E_ARG, "sv_augment: null");
     SV_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && pad >= 0 && pad < H && pad < W && (nhwc_cpad == 0 || nhwc_cpad >= C),
                SV_E_ARG, "sv_augment: bad shape (B=%d H=%d W=%d C=%d pad=%d cpad=%d)", B, H, W, C, pad, nhwc_cpad);
@@ -1051,6 +1093,7 @@ int sv_augment(int dtype, const uint8_t* data, const int64_t* index, const int32
 }
 
 int sv_nhwc_to_nchw(int dtype, const void* in, int B, int C, int H, int W, int ld, float* out, void* stream) {
+    SvProfScope prof_scope(stream);
     SV_REQUIRE(in && out && ld >= C, SV_E_ARG, "sv_nhwc_to_nchw: bad args");
     const int64_t n = (int64_t)B * H * W * C;
     DISPATCH_T(dtype, hipLaunchKernelGGL((nhwc_to_nchw_kernel<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
@@ -1058,8 +1101,18 @@ int sv_nhwc_to_nchw(int dtype, const void* in, int B, int C, int H, int W, int l
     return sv_check_launch("sv_nhwc_to_nchw");
 }
 
+int sv_repack_batch(int dtype, const float* master_base, const sv_repack_job* jobs, int njobs, int total_blocks,
+                    void* dst_base, void* stream) {
+    SvProfScope prof_scope(stream);
+    SV_REQUIRE(master_base && jobs && dst_base && njobs >= 0 && total_blocks >= 0, SV_E_ARG, "sv_repack_batch: bad argument");
+    if (njobs == 0 || total_blocks == 0) return SV_OK;
+    DISPATCH_T(dtype, hipLaunchKernelGGL((repack_batch_kernel<T>), dim3((unsigned)total_blocks), dim3(256), 0,
+                                         (hipStream_t)stream, master_base, jobs, njobs, (T*)dst_base));
+    return sv_check_launch("sv_repack_batch");
+}
 int sv_repack(int dtype, const float* master, int N, int T_orig, int C, int transpose, const sv_geom* g, void* dst,
               void* stream) {
+    SvProfScope prof_scope(stream);
     SV_REQUIRE(master && g && dst, SV_E_ARG, "sv_repack: null");
     repack_params p;
     p.N = N; p.T_orig = T_orig; p.C = C; p.transpose = transpose; p.nphase = g->nphase;

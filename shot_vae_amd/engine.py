@@ -268,6 +268,7 @@ class Engine:
         self.defer_slot = None        # k: this forward's running-stat update is deferred into slot k (apply_pending)
         self._pending = {}
         self._run_tables = {}
+        self._repack_tables = {}
         self.version_probe = None     # callable: summed version counters of the nn.Parameters (set by the module)
         for b in p.bns:
             self.bufs[b.rv_off: b.rv_off + b.C] = 1.0
@@ -342,7 +343,7 @@ class Engine:
             return
         t = self.prof_tags.setdefault(name, len(self.prof_tags))
         L.lib().sv_prof_tag(t)
-        if g is not None and name not in self.prof_cost:
+        if g is not None:
             es = self.packs.element_size()
             taps = sum(g.phase[p].ntap for p in range(g.nphase))
             rows = g.B * g.Hq * g.Wq
@@ -354,7 +355,14 @@ class Engine:
                 nbytes = es * (n_in + n_out) + 4 * n_w
             else:
                 nbytes = es * (n_in + n_out * (1 + extra_out_reads) + n_w)
-            self.prof_cost[name] = (float(nbytes), flops)
+            self._cost(name, nbytes, flops)
+
+    def _cost(self, name, nbytes, flops=0.0):
+        """algorithmic bytes / flops of one launch filed under `name` (summed over launches; bench.py divides)"""
+        if self.prof_tags is None:
+            return
+        b, f, n = self.prof_cost.get(name, (0.0, 0.0, 0))
+        self.prof_cost[name] = (b + float(nbytes), f + float(flops), n + 1)
 
     def ensure_packs(self):
         ver = self.param._version + (self.version_probe() if self.version_probe is not None else 0)
@@ -364,14 +372,29 @@ class Engine:
         p = self.plan
         if self.packs is None or self.packs.dtype != self.tdtype or self.packs.device != self.param.device:
             self.packs = torch.zeros(p.n_pack, dtype=self.tdtype, device=self.param.device)
-        st = self._stream()
-        base, pb, es = self.param.data_ptr(), self.packs.data_ptr(), self.packs.element_size()
-        for cv in p.convs:
-            m = _vp(base + 4 * cv.master_off)
-            L.call("sv_repack", self.code, m, cv.N, cv.T, cv.Cin, 0, C.byref(cv.geom_fwd(1)),
-                   _vp(pb + es * cv.fwd_off), st)
-            L.call("sv_repack", self.code, m, cv.N, cv.T, cv.Cin, 1, C.byref(cv.geom_dgrad(1)),
-                   _vp(pb + es * cv.dgrad_off), st)
+        # every (layer, direction, phase) pack in ONE launch (sv_repack_batch); the job table is plan-static
+        tab = self._repack_tables.get(self.param.device)
+        if tab is None:
+            jobs, b0 = [], 0
+            for cv in p.convs:
+                for tr, g, off in ((0, cv.geom_fwd(1), cv.fwd_off), (1, cv.geom_dgrad(1), cv.dgrad_off)):
+                    for ph in range(g.nphase):
+                        P = g.phase[ph]
+                        if P.ntap == 0:
+                            continue
+                        j = L.SvRepackJob()
+                        j.master_off, j.dst_off, j.size = cv.master_off, off + P.w_off, cv.N * cv.Cin * P.ntap
+                        j.N, j.T_orig, j.C, j.transpose, j.ntap, j.block0 = cv.N, cv.T, cv.Cin, tr, P.ntap, b0
+                        for t in range(L.MAX_TAPS):
+                            j.torig[t] = P.torig[t]
+                        b0 += (j.size + 255) // 256
+                        jobs.append(j)
+            arr = (L.SvRepackJob * len(jobs))(*jobs)
+            raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.param.device)
+            tab = self._repack_tables[self.param.device] = (raw, len(jobs), b0)
+        raw, njobs, nblocks = tab
+        L.call("sv_repack_batch", self.code, _vp(self.param.data_ptr()), _vp(raw.data_ptr()), njobs, nblocks,
+               _vp(self.packs.data_ptr()), self._stream())
         self._pack_key = key
 
     def _igemm(self, g, x, w_ptr, out, pro=None, bias=None, residual=None, stats=None, ex=None, tag=None):
@@ -679,6 +702,8 @@ class Engine:
             _, _, mn, rs = bnp(b0)
             dx = torch.empty_like(raw)
             cc = raw.shape[-1]
+            # reads x and one g per branch (+ the residual), writes dx
+            self._cost("sv_bn_bwd_apply", raw.numel() * raw.element_size() * (2 + len(branches) + (residual is not None)))
             L.call("sv_bn_bwd_apply", self.code, raw.numel() // cc, cc, cc, _vp(raw.data_ptr()), _vp(mn), _vp(rs),
                    float(count), arr, len(branches), _vp(residual.data_ptr()) if residual is not None else None,
                    _vp(dx.data_ptr()), st)
