@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define SV_ABI_VERSION 1
+#define SV_ABI_VERSION 2
 
 enum { SV_F32 = 0, SV_BF16 = 1 };
 enum { SV_OK = 0, SV_E_ARG = -1, SV_E_SHAPE = -2, SV_E_HIP = -3 };
@@ -75,6 +75,12 @@ typedef struct {
     float* bsums;               /* [R][2N] += (sum g, sum g*xhat)                                    */
     int32_t replicas;           /* R: power of two >= 1; spreads the per-channel atomics of the many
                                    blocks of a launch over R copies (consumers sum the copies)        */
+    int32_t groups;             /* G >= 1 (0 = 1): BATCHED launch of G independent instances of the layer that
+                                   share the weights and the bias -- the four forwards of a SHOT-VAE step
+                                   (main_shot_vae.py:288,311,329,356) each with its OWN BatchNorm statistics.
+                                   g->B is the batch of ONE group; x / out / residual / ex hold the groups back
+                                   to back ([G][B][H][W][ld]); pro_scale / pro_shift are [G][Cin], the ex_*
+                                   vectors [G][N], stats / bsums [G][R][2N].                            */
 } sv_igemm_args;
 
 int sv_igemm(const sv_geom* g, int dtype, const sv_igemm_args* a, void* stream);
@@ -84,46 +90,53 @@ int sv_igemm(const sv_geom* g, int dtype, const sv_igemm_args* a, void* stream);
  * of M ranges of the generic kernel (0 = choose).  `ws` is an optional caller-owned fp32 workspace
  * (ws_elems floats, contents irrelevant on entry): stride-1 3x3 layers publish per-block partial
  * slabs there with plain stores and reduce them in a second launch instead of contending on float
- * atomics; without it (or when it is too small) partials go to dw through float atomics.           */
+ * atomics; without it (or when it is too small) partials go to dw through float atomics.
+ * groups (0 = 1): batched launch as in sv_igemm_args -- x / dy hold G instances back to back (g->B = one group's
+ * batch), pro_scale / pro_shift are [G][Cin]; the gradient of the shared weights sums over the groups.              */
 int sv_wgrad(const sv_geom* g, int dtype, const void* x, const float* pro_scale, const float* pro_shift,
              float pro_slope, const void* dy, float* dw, int splits, int use_tr, float* ws, int64_t ws_elems,
-             void* stream);
+             int groups, void* stream);
 
 /* column sums: out[n] += sum_m y[m*ld + n]   (conv0 bias gradient)                                  */
 int sv_colsum(int dtype, const void* y, int64_t M, int N, int ld, float* out, void* stream);
 
 /* ---- K4 BatchNorm2d train-mode finalize (nn.BatchNorm2d semantics, eps/momentum explicit) -------
  * stats=[R][sum, sumsq] -> scale=gamma*rstd, shift=beta-mean*scale; saves mean/rstd; updates running
- * stats (unbiased var) unless running_mean is NULL.                                                 */
+ * stats (unbiased var) unless running_mean is NULL.  groups (0 = 1): G sets of statistics [G][R][2C] of the same
+ * BatchNorm (gamma / beta shared) -> outputs [G][C]; running_mean must then be NULL (sv_bn_running_update).   */
 int sv_bn_finalize(const float* stats, int replicas, int C, float count, const float* gamma, const float* beta,
                    float eps, float momentum, float* running_mean, float* running_var,
-                   float* scale, float* shift, float* mean, float* rstd, void* stream);
+                   float* scale, float* shift, float* mean, float* rstd, int groups, void* stream);
 /* Deferred running-statistics update of all nbn BatchNorms of ONE forward from the (mean, rstd) that
  * sv_bn_finalize saved (called with running_mean = NULL): table[bn] = {offset of the BN's
  * [scale|shift|mean|rstd] block (each `align`-padded) in bnbuf, running_mean offset, running_var offset
  * (both into bufs), C}; counts[bn] = samples per channel.  Lets the four forwards of a step run on several
- * streams while the momentum updates are still applied in the reference's order (1)(2)(3)(4).           */
+ * streams while the momentum updates are still applied in the reference's order (1)(2)(3)(4).  groups (0 = 1): each
+ * of the four arrays of a block is [groups][C] (the block padded to `align` as a whole); the groups' updates are
+ * applied in group order.                                                                                  */
 int sv_bn_running_update(const int32_t* table, const float* counts, int nbn, const float* bnbuf, float* bufs,
-                         float eps, float momentum, int align, void* stream);
+                         float eps, float momentum, int align, int groups, void* stream);
 /* eval-mode affine from running statistics (main_shot_vae.py:409-510 path)                         */
 int sv_bn_eval_affine(int C, const float* gamma, const float* beta, const float* running_mean,
                       const float* running_var, float eps, float* scale, float* shift, void* stream);
 /* BatchNorm backward, second phase: dx = sum_br gamma*rstd*(g - mean(g) - xhat*mean(g*xhat)) (+res)
- * for one or two BN branches that share the input x; dgamma/dbeta accumulate (+=).                  */
+ * for one or two BN branches that share the input x; dgamma/dbeta accumulate (+=).  groups (0 = 1): G instances,
+ * M = rows of ONE group; x / g / residual / dx [G][M][ld], mean / rstd [G][C], bsums [G][R][2C].               */
 typedef struct {
     const void* g; const float* bsums; const float* gamma; float* dgamma; float* dbeta;
     int32_t replicas;           /* bsums is [replicas][2C]                                           */
 } sv_bn_branch;
 int sv_bn_bwd_apply(int dtype, int64_t M, int C, int ld, const void* x, const float* mean,
                     const float* rstd, float count, const sv_bn_branch* br, int nbranch,
-                    const void* residual, void* dx, void* stream);
+                    const void* residual, void* dx, int groups, void* stream);
 
 /* ---- K8 global average pool fused with the transition BN+LeakyReLU (vae.py:107,143) ------------- */
+/* groups (0 = 1): B = ALL images, image b belongs to group b / (B / groups); coefficients [G][C], bsums [G][2C]     */
 int sv_pool_fwd(int dtype, const void* x, const float* scale, const float* shift, float slope,
-                int B, int HW, int C, int ld, float* feat, void* stream);
+                int B, int HW, int C, int ld, float* feat, int groups, void* stream);
 int sv_pool_bwd(int dtype, const void* x, const float* scale, const float* shift, float slope,
                 const float* mean, const float* rstd, const float* dfeat, int B, int HW, int C, int ld,
-                void* g, float* bsums, void* stream);
+                void* g, float* bsums, int groups, void* stream);
 
 /* ---- K9 the three inference heads + LogSoftmax (vae.py:10-15,144-146) ----------------------------
  * W is [2*ldc+K][C] (rows: mean, log_sigma, disc), bias [2*ldc+K].                                   */

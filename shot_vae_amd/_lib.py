@@ -33,7 +33,7 @@ class SvIgemmArgs(C.Structure):
                 ("w", C.c_void_p), ("bias", C.c_void_p), ("residual", C.c_void_p), ("out", C.c_void_p),
                 ("stats", C.c_void_p), ("ex", C.c_void_p), ("ex_scale", C.c_void_p), ("ex_shift", C.c_void_p),
                 ("ex_mean", C.c_void_p), ("ex_rstd", C.c_void_p), ("ex_slope", C.c_float), ("bsums", C.c_void_p),
-                ("replicas", C.c_int32)]
+                ("replicas", C.c_int32), ("groups", C.c_int32)]
 
 
 class SvRepackJob(C.Structure):
@@ -50,14 +50,14 @@ class SvBnBranch(C.Structure):
 P, I, I64, F = C.c_void_p, C.c_int, C.c_int64, C.c_float
 _PROTOS = {
     "sv_igemm": [C.POINTER(SvGeom), I, C.POINTER(SvIgemmArgs), P],
-    "sv_wgrad": [C.POINTER(SvGeom), I, P, P, P, F, P, P, I, I, P, I64, P],
+    "sv_wgrad": [C.POINTER(SvGeom), I, P, P, P, F, P, P, I, I, P, I64, I, P],
     "sv_colsum": [I, P, I64, I, I, P, P],
-    "sv_bn_finalize": [P, I, I, F, P, P, F, F, P, P, P, P, P, P, P],
+    "sv_bn_finalize": [P, I, I, F, P, P, F, F, P, P, P, P, P, P, I, P],
     "sv_bn_eval_affine": [I, P, P, P, P, F, P, P, P],
-    "sv_bn_running_update": [P, P, I, P, P, F, F, I, P],
-    "sv_bn_bwd_apply": [I, I64, I, I, P, P, P, F, C.POINTER(SvBnBranch), I, P, P, P],
-    "sv_pool_fwd": [I, P, P, P, F, I, I, I, I, P, P],
-    "sv_pool_bwd": [I, P, P, P, F, P, P, P, I, I, I, I, P, P, P],
+    "sv_bn_running_update": [P, P, I, P, P, F, F, I, I, P],
+    "sv_bn_bwd_apply": [I, I64, I, I, P, P, P, F, C.POINTER(SvBnBranch), I, P, P, I, P],
+    "sv_pool_fwd": [I, P, P, P, F, I, I, I, I, P, I, P],
+    "sv_pool_bwd": [I, P, P, P, F, P, P, P, I, I, I, I, P, P, I, P],
     "sv_head_fwd": [P, I, I, P, P, I, I, P, P, P, P],
     "sv_head_bwd": [P, I, I, P, I, I, P, P, P, P, P, P, P, P, P],
     "sv_sample_fwd": [I, P, P, P, P, P, P, P, F, P, I, F, I, I, I, I, P, P, P],

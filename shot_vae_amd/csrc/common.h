@@ -52,6 +52,43 @@ __device__ __forceinline__ uint64_t pack_taps(const int8_t* d) {
 }
 __device__ __forceinline__ int tap_off(uint64_t p, int t) { return (int)((p >> (4 * t)) & 15) - 8; }
 
+// Batched launch (sv_igemm_args::groups): blockIdx.y = group; a group is an independent instance of the layer whose
+// tensors / coefficient vectors / accumulators follow those of the previous group.  Returns the arguments of THIS
+// block's group; the kernel then runs on (g, a) exactly as for a single instance.
+__device__ __forceinline__ sv_igemm_args sv_group_args(const sv_geom& g, const sv_igemm_args& a, int es) {
+    sv_igemm_args r = a;
+    const int64_t grp = blockIdx.y;
+    if (grp) {
+        const int64_t xs = (int64_t)g.B * g.Hin * g.Win * g.ldx * es, os = (int64_t)g.B * g.Hout * g.Wout * g.ldo * es;
+        r.x = reinterpret_cast<const char*>(a.x) + grp * xs;
+        r.out = reinterpret_cast<char*>(a.out) + grp * os;
+        if (a.residual) r.residual = reinterpret_cast<const char*>(a.residual) + grp * os;
+        if (a.ex) r.ex = reinterpret_cast<const char*>(a.ex) + grp * os;
+        if (a.pro_scale) { r.pro_scale = a.pro_scale + grp * g.Cin; r.pro_shift = a.pro_shift + grp * g.Cin; }
+        if (a.stats) r.stats = a.stats + grp * a.replicas * 2 * g.N;
+        if (a.ex) {
+            r.ex_scale = a.ex_scale + grp * g.N; r.ex_shift = a.ex_shift + grp * g.N;
+            r.ex_mean = a.ex_mean + grp * g.N; r.ex_rstd = a.ex_rstd + grp * g.N;
+            r.bsums = a.bsums + grp * a.replicas * 2 * g.N;
+        }
+    }
+    return r;
+}
+__host__ __device__ __forceinline__ int sv_ngroups(int groups) { return groups > 0 ? groups : 1; }
+// the same for the weight-gradient parameter blocks (fields x, dy, pro_scale, pro_shift): the groups' operands follow
+// each other, the gradient of the SHARED weights sums over the groups
+template <typename P>
+__device__ __forceinline__ P sv_group_wg(const sv_geom& g, const P& p, int es) {
+    P r = p;
+    const int64_t grp = blockIdx.y;
+    if (grp) {
+        r.x = reinterpret_cast<const char*>(p.x) + grp * ((int64_t)g.B * g.Hin * g.Win * g.ldx * es);
+        r.dy = reinterpret_cast<const char*>(p.dy) + grp * ((int64_t)g.B * g.Hout * g.Wout * g.ldo * es);
+        if (p.pro_scale) { r.pro_scale = p.pro_scale + grp * g.Cin; r.pro_shift = p.pro_shift + grp * g.Cin; }
+    }
+    return r;
+}
+
 // host side ------------------------------------------------------------------------------------------
 void sv_set_error(const char* fmt, ...);
 bool sv_disabled(int kernel_bit);        // sv_set_option(SV_OPT_DISABLE_MASK, ...): a specialised kernel is switched off
@@ -69,7 +106,8 @@ int sv_conv3x3_try(const sv_geom* g, int dtype, const sv_igemm_args* a, hipStrea
 int sv_conv3x3w_try(const sv_geom* g, int dtype, const sv_igemm_args* a, hipStream_t s, int* rc);
 int sv_conv3x3x_try(const sv_geom* g, const sv_igemm_args* a, bool fwd, hipStream_t s, int* rc);
 int sv_wgrad3x3_try(const sv_geom* g, int dtype, const void* x, const float* pro_scale, const float* pro_shift,
-                    float pro_slope, const void* dy, float* dw, float* ws, int64_t ws_elems, hipStream_t s, int* rc);
+                    float pro_slope, const void* dy, float* dw, float* ws, int64_t ws_elems, int groups, hipStream_t s,
+                    int* rc);
 
 #define SV_REQUIRE(cond, code, ...)                \
     do {                                           \

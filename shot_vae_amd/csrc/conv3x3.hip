@@ -22,7 +22,8 @@ constexpr int CK = 32;          // channel chunk = one MFMA k step
 constexpr int LDC = CK + 16;    // LDS pixel / weight-row stride (elements): 96 B (bf16) keeps the b128 fragment reads conflict-free
 
 template <typename T, int NT, int WLOG>
-__global__ __launch_bounds__(256) void conv3x3_kernel(const sv_geom g, const sv_igemm_args a) {
+__global__ __launch_bounds__(256) void conv3x3_kernel(const sv_geom g, const sv_igemm_args a_in) {
+    const sv_igemm_args a = sv_group_args(g, a_in, (int)sizeof(T));
     typedef typename V8<T>::type V;
     constexpr int W = 1 << WLOG, TR = 128 / W, WP = W + 2;
     constexpr int HP = (TR + 2) * WP;           // halo pixels
@@ -179,7 +180,8 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const sv_geom g, const sv_
 // residual / raw tensor needed by tile i's epilogue are already in flight -- and the BatchNorm sums are
 // kept in registers across tiles and flushed once per block (one shuffle tree, one atomic per channel).
 template <typename T, int WLOG, int CCH>      // CCH = Cin / 32
-__global__ __launch_bounds__(256, SV_C3P_WAVES) void conv3x3p_kernel(const sv_geom g, const sv_igemm_args a, int tiles_per) {
+__global__ __launch_bounds__(256, SV_C3P_WAVES) void conv3x3p_kernel(const sv_geom g, const sv_igemm_args a_in, int tiles_per) {
+    const sv_igemm_args a = sv_group_args(g, a_in, (int)sizeof(T));
     typedef typename V8<T>::type V;
     typedef typename V4<T>::type Q;
     constexpr int NT = 2, BN = 32;
@@ -462,7 +464,8 @@ __global__ __launch_bounds__(256, SV_C3P_WAVES) void conv3x3p_kernel(const sv_ge
 // pixel tiles (the 128-pixel kernel restaged it for every tile); the halo tiles alternate between two LDS
 // buffers and are register-prefetched one step ahead, the next weight chunk a whole chunk ahead.
 template <typename T, int NT, int WLOG, int PT>
-__global__ __launch_bounds__(256) void conv3x3m_kernel(const sv_geom g, const sv_igemm_args a) {
+__global__ __launch_bounds__(256) void conv3x3m_kernel(const sv_geom g, const sv_igemm_args a_in) {
+    const sv_igemm_args a = sv_group_args(g, a_in, (int)sizeof(T));
     typedef typename V8<T>::type V;
     typedef typename V4<T>::type Q;
     static_assert(PT == 2 || PT == 4, "");
@@ -728,7 +731,7 @@ int launch_m(const sv_geom* g, const sv_igemm_args* a, hipStream_t s) {
         optin = true;
     }
     sv_prof_begin(s);
-    hipLaunchKernelGGL((conv3x3m_kernel<T, NT, WLOG, PT>), dim3(grid), dim3(256), lds, s, *g, *a);
+    hipLaunchKernelGGL((conv3x3m_kernel<T, NT, WLOG, PT>), dim3(grid, sv_ngroups(a->groups)), dim3(256), lds, s, *g, *a);
     sv_prof_end(s);
     return sv_check_launch("sv_igemm(conv3x3m)");
 }
@@ -749,7 +752,8 @@ int launch_p(const sv_geom* g, const sv_igemm_args* a, hipStream_t s) {
     constexpr int HV = LROWS * (W + 2) * VPP, HI = (HV + 255) / 256, HPIX = (HI * 256 + VPP - 1) / VPP;
     const int nT = g->B * g->Hin / TR;
     const int nNt = g->N / 32;
-    constexpr int target = 512;       // persistent blocks (two per CU): fewer / more measured slower
+    // persistent blocks (two per CU): fewer / more measured slower; a batched launch shares them among its groups
+    const int target = 512 / sv_ngroups(a->groups) > 64 ? 512 / sv_ngroups(a->groups) : 64;
     int chunks = (target + nNt - 1) / nNt;
     if (chunks > nT) chunks = nT;
     const int tiles_per = (nT + chunks - 1) / chunks;
@@ -763,7 +767,7 @@ int launch_p(const sv_geom* g, const sv_igemm_args* a, hipStream_t s) {
         optin = true;
     }
     sv_prof_begin(s);
-    hipLaunchKernelGGL((conv3x3p_kernel<T, WLOG, CCH>), dim3(chunks * nNt), dim3(256), lds, s, *g, *a, tiles_per);
+    hipLaunchKernelGGL((conv3x3p_kernel<T, WLOG, CCH>), dim3(chunks * nNt, sv_ngroups(a->groups)), dim3(256), lds, s, *g, *a, tiles_per);
     sv_prof_end(s);
     return sv_check_launch("sv_igemm(conv3x3p)");
 }
@@ -792,7 +796,7 @@ int launch(const sv_geom* g, const sv_igemm_args* a, hipStream_t s) {
         optin = true;
     }
     sv_prof_begin(s);
-    hipLaunchKernelGGL((conv3x3_kernel<T, NT, WLOG>), dim3(grid), dim3(256), lds, s, *g, *a);
+    hipLaunchKernelGGL((conv3x3_kernel<T, NT, WLOG>), dim3(grid, sv_ngroups(a->groups)), dim3(256), lds, s, *g, *a);
     sv_prof_end(s);
     return sv_check_launch("sv_igemm(conv3x3)");
 }
@@ -836,7 +840,7 @@ int sv_conv3x3_try(const sv_geom* g, int dtype, const sv_igemm_args* a, hipStrea
         // (measured at B=512: 160 ch 707 vs 796 us; the 64-channel-tile variant <4,4> lost to the 128-pixel kernel
         //  on 320 / 640 channels -- 447 vs 418 us, 469 vs 356 us -- and is not dispatched)
         const int nT = g->B * g->Hin / TR;
-        if (g->N % 80 == 0 && nT % 2 == 0 && (int64_t)(nT / 2) * (g->N / 80) >= 256) {
+        if (g->N % 80 == 0 && nT % 2 == 0 && (int64_t)(nT / 2) * (g->N / 80) * sv_ngroups(a->groups) >= 256) {
             *rc = launch_mw<bf16, 5, 2>(g, a, s);
             return 1;
         }

@@ -75,7 +75,8 @@ struct WCfg {
 };
 
 template <int NF, int WLOG, bool REV>
-__global__ __launch_bounds__(256, 2) void conv3x3w_kernel(const sv_geom g, const sv_igemm_args a) {
+__global__ __launch_bounds__(256, 2) void conv3x3w_kernel(const sv_geom g, const sv_igemm_args a_in) {
+    const sv_igemm_args a = sv_group_args(g, a_in, 2);
     using C = WCfg<NF, WLOG>;
     constexpr int BN = C::BN, W = C::W, TR = C::TR, WP = C::WP, HH = C::HH, SEG = C::SEG, HI = C::HI, WI = C::WI;
     constexpr int HS = C::HS, HB = C::HB, WS = C::WS, WBUF = C::WBUF, SWS = C::SWS;
@@ -401,7 +402,7 @@ int launch_w3(const sv_geom* g, const sv_igemm_args* a, hipStream_t s) {
         optin = true;
     }
     sv_prof_begin(s);
-    hipLaunchKernelGGL((conv3x3w_kernel<NF, WLOG, REV>), dim3(grid), dim3(256), lds, s, *g, *a);
+    hipLaunchKernelGGL((conv3x3w_kernel<NF, WLOG, REV>), dim3(grid, sv_ngroups(a->groups)), dim3(256), lds, s, *g, *a);
     sv_prof_end(s);
     return sv_check_launch("sv_igemm(conv3x3w)");
 }
@@ -430,7 +431,7 @@ int sv_conv3x3w_try(const sv_geom* g, int dtype, const sv_igemm_args* a, hipStre
     // the bound (tests use 1 to reach these kernels at small batch sizes).
     // Narrower channel tiles are taken only when the wider ones do not fill the chip.
     const int min_blocks = sv_wide_min_blocks();
-    const int64_t nTiles = g->B * g->Hin / TR;
+    const int64_t nTiles = (int64_t)g->B * g->Hin / TR * sv_ngroups(a->groups);      // of the whole (batched) launch
     int bn = 0;
     if (g->N % 160 == 0) bn = 160;
     else if (g->N % 128 == 0 && nTiles * (g->N / 128) >= min_blocks) bn = 128;

@@ -191,7 +191,8 @@ struct XCfg {
 // MODE: the epilogue's fusion flags at compile time (conv3x3w_epilogue.inc: 0 = from the arguments, 1 = statistics,
 // 2 = residual + statistics, 3 = activation-backward)
 template <int WLOG, bool REV, int MODE>
-__global__ __launch_bounds__(256, 1) void conv3x3x_kernel(const sv_geom g, const sv_igemm_args a) {
+__global__ __launch_bounds__(256, 1) void conv3x3x_kernel(const sv_geom g, const sv_igemm_args a_in) {
+    const sv_igemm_args a = sv_group_args(g, a_in, 2);
     using C = XCfg<WLOG>;
     constexpr int NF = C::NF, BN = C::BN, W = C::W, TR = C::TR, WP = C::WP, HH = C::HH, SEG = C::SEG;
     constexpr int HS = C::HS, HB = C::HB, WBUF = C::WBUF, SWS = C::SWS, HI = X_HI, HSTEPS = X_HSTEPS;
@@ -605,8 +606,10 @@ int launch_x4(const sv_geom* g, const sv_igemm_args* a, hipStream_t s) {
     using C = XCfg<WLOG>;
     const int nT = g->B * g->Hin / C::TR, nNt = g->N / C::BN;
     // persistent: one block per CU (256 = 8 XCDs x 32), fewer when there are fewer items per XCD
+    // (a batched launch shares the 256 CUs among its groups)
+    const int G = sv_ngroups(a->groups), cap = 32 / G > 1 ? 32 / G : 1;
     const int per = (nT + 7) / 8, items_xcd = per * nNt;
-    const int grid = 8 * (items_xcd < 32 ? items_xcd : 32);
+    const int grid = 8 * (items_xcd < cap ? items_xcd : cap);
     const size_t lds = (size_t)C::LDS;
     static bool optin = false;
     if (!optin) {
@@ -616,7 +619,7 @@ int launch_x4(const sv_geom* g, const sv_igemm_args* a, hipStream_t s) {
         optin = true;
     }
     sv_prof_begin(s);
-    hipLaunchKernelGGL((conv3x3x_kernel<WLOG, REV, MODE>), dim3(grid), dim3(256), lds, s, *g, *a);
+    hipLaunchKernelGGL((conv3x3x_kernel<WLOG, REV, MODE>), dim3(grid, G), dim3(256), lds, s, *g, *a);
     sv_prof_end(s);
     return sv_check_launch("sv_igemm(conv3x3x)");
 }

@@ -25,7 +25,8 @@ constexpr int BK = 32;
 // (the decoder, the stride-2 convs): those are bound by one global->LDS round trip per iteration, so twice the bytes
 // in flight and twice the MFMAs per barrier nearly halve their time.
 template <typename T, int NT, int KV>
-__global__ __launch_bounds__(256) void igemm_kernel(const sv_geom g, const sv_igemm_args a) {
+__global__ __launch_bounds__(256) void igemm_kernel(const sv_geom g, const sv_igemm_args a_in) {
+    const sv_igemm_args a = sv_group_args(g, a_in, (int)sizeof(T));
     typedef typename V8<T>::type V;
     typedef typename V4<T>::type Q;
     constexpr int BN = 16 * NT;
@@ -238,7 +239,7 @@ int launch_kv(const sv_geom* g, const sv_igemm_args* a, hipStream_t s) {
         optin = true;
     }
     sv_prof_begin(s);
-    hipLaunchKernelGGL((igemm_kernel<T, NT, KV>), dim3(grid), dim3(256), lds, s, *g, *a);
+    hipLaunchKernelGGL((igemm_kernel<T, NT, KV>), dim3(grid, sv_ngroups(a->groups)), dim3(256), lds, s, *g, *a);
     sv_prof_end(s);
     return sv_check_launch("sv_igemm");
 }

@@ -29,6 +29,11 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* stats, in
                                                           float* shift, float* mean, float* rstd) {
     const int c = blockIdx.x * 8 + (threadIdx.x >> 5);
     const int r0 = threadIdx.x & 31;
+    {   // batched launch: blockIdx.y = group, its [R][2C] statistics and [C] outputs follow the previous group's
+        const size_t grp = blockIdx.y;
+        stats += grp * R * 2 * C;
+        scale += grp * C; shift += grp * C; mean += grp * C; rstd += grp * C;
+    }
     float s1 = 0.f, s2 = 0.f;
     if (c < C)
         for (int r = r0; r < R; r += 32) {
@@ -63,18 +68,23 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* stats, in
 // table[bn] = {offset of the BN's (scale,shift,mean,rstd) block in bnbuf, running_mean offset, running_var offset, C}
 __global__ __launch_bounds__(256) void bn_running_update_kernel(const int32_t* table, const float* counts,
                                                                 const float* bnbuf, float* bufs, float eps,
-                                                                float momentum, int align) {
+                                                                float momentum, int align, int groups) {
     const int bn = blockIdx.x;
     const int boff = table[4 * bn], rmo = table[4 * bn + 1], rvo = table[4 * bn + 2], C = table[4 * bn + 3];
-    const int ca = (C + align - 1) / align * align;
+    const int ca = (groups * C + align - 1) / align * align;       // each of the four arrays is [groups][C], padded
     const float n = counts[bn];
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        const float mu = bnbuf[boff + 2 * ca + c], rs = bnbuf[boff + 3 * ca + c];
-        float var = 1.f / (rs * rs) - eps;
-        var = var > 0.f ? var : 0.f;
-        const float unb = n > 1.f ? var * n / (n - 1.f) : var;
-        bufs[rmo + c] = (1.f - momentum) * bufs[rmo + c] + momentum * mu;
-        bufs[rvo + c] = (1.f - momentum) * bufs[rvo + c] + momentum * unb;
+        float rm = bufs[rmo + c], rv = bufs[rvo + c];
+        for (int gi = 0; gi < groups; ++gi) {                        // the groups' updates in order: (1)(2)(3)(4)
+            const float mu = bnbuf[boff + 2 * ca + gi * C + c], rs = bnbuf[boff + 3 * ca + gi * C + c];
+            float var = 1.f / (rs * rs) - eps;
+            var = var > 0.f ? var : 0.f;
+            const float unb = n > 1.f ? var * n / (n - 1.f) : var;
+            rm = (1.f - momentum) * rm + momentum * mu;
+            rv = (1.f - momentum) * rv + momentum * unb;
+        }
+        bufs[rmo + c] = rm;
+        bufs[rvo + c] = rv;
     }
 }
 
@@ -102,8 +112,21 @@ struct bnb_params {
 // REG: (threads of the grid) % (C/8) == 0, so a thread always meets the same 8 channels and keeps their
 // coefficients [gamma*rstd, mean(g), mean(g*xhat)] (+ mean, rstd) in registers; otherwise they sit in LDS.
 template <typename T, bool REG>
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bnb_params p) {
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bnb_params p_in) {
     typedef typename V8<T>::type V;
+    bnb_params p = p_in;
+    if (blockIdx.y) {         // batched launch: blockIdx.y = group; tensors [G][M][ld], mean / rstd [G][C], bsums [G][R][2C]
+        const int64_t grp = blockIdx.y, ts = p.M * p.ld * (int64_t)sizeof(T);
+        p.x = reinterpret_cast<const char*>(p.x) + grp * ts;
+        p.dx = reinterpret_cast<char*>(p.dx) + grp * ts;
+        if (p.residual) p.residual = reinterpret_cast<const char*>(p.residual) + grp * ts;
+        p.mean += grp * p.C;
+        p.rstd += grp * p.C;
+        for (int k = 0; k < p.nbranch; ++k) {
+            p.br[k].g = reinterpret_cast<const char*>(p.br[k].g) + grp * ts;
+            p.br[k].bsums += grp * p.br[k].replicas * 2 * p.C;
+        }
+    }
     extern __shared__ __attribute__((aligned(16))) float coef[];
     const int cv = p.C / 8;                       // vectors per row
     const int64_t gtid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -247,11 +270,12 @@ __global__ void colsum_kernel(const T* y, int64_t M, int N, int ld, float* out) 
 // ---------------------------------------------------------------------------------------- pool
 template <typename T>
 __global__ void pool_fwd_kernel(const T* x, const float* scale, const float* shift, float slope, int B,
-                                int HW, int C, int ld, float* feat) {
+                                int HW, int C, int ld, float* feat, int Bg) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= B * C) return;
     const int b = idx / C, c = idx - b * C;
-    const float sc = scale[c], sh = shift[c];
+    const int gc = (b / Bg) * C + c;                  // batched: image b belongs to group b / Bg (coefficients [G][C])
+    const float sc = scale[gc], sh = shift[gc];
     const T* px = x + (int64_t)b * HW * ld + c;
     float s = 0.f;
     for (int p = 0; p < HW; ++p) s += act_fwd(to_f(px[(int64_t)p * ld]) * sc + sh, slope);
@@ -261,11 +285,13 @@ __global__ void pool_fwd_kernel(const T* x, const float* scale, const float* shi
 template <typename T>
 __global__ void pool_bwd_kernel(const T* x, const float* scale, const float* shift, float slope,
                                 const float* mean, const float* rstd, const float* dfeat, int B, int HW,
-                                int C, int ld, T* g, float* bsums) {
+                                int C, int ld, T* g, float* bsums, int Bg) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= B * C) return;
     const int b = idx / C, c = idx - b * C;
-    const float sc = scale[c], sh = shift[c], mu = mean[c], rs = rstd[c];
+    const int grp = b / Bg, gc = grp * C + c;
+    bsums += (size_t)grp * 2 * C;
+    const float sc = scale[gc], sh = shift[gc], mu = mean[gc], rs = rstd[gc];
     const float d = dfeat[idx] / (float)HW;
     const T* px = x + (int64_t)b * HW * ld + c;
     T* pg = g + (int64_t)b * HW * ld + c;
@@ -834,21 +860,24 @@ extern "C" {
 
 int sv_bn_finalize(const float* stats, int replicas, int C, float count, const float* gamma, const float* beta, float eps,
                    float momentum, float* rm, float* rv, float* scale, float* shift, float* mean,
-                   float* rstd, void* stream) {
+                   float* rstd, int groups, void* stream) {
     SvProfScope prof_scope(stream);
     SV_REQUIRE(stats && gamma && beta && scale && shift && mean && rstd && C > 0 && replicas >= 1, SV_E_ARG,
                "sv_bn_finalize: bad args");
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 7) / 8), dim3(256), 0, (hipStream_t)stream, stats, replicas, C,
+    groups = sv_ngroups(groups);
+    SV_REQUIRE(groups == 1 || !rm, SV_E_ARG, "sv_bn_finalize: a batched launch cannot update the running statistics in "
+               "place (the groups' momentum updates are ordered): pass NULL and call sv_bn_running_update");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 7) / 8, groups), dim3(256), 0, (hipStream_t)stream, stats, replicas, C,
                        count, gamma, beta, eps, momentum, rm, rv, scale, shift, mean, rstd);
     return sv_check_launch("sv_bn_finalize");
 }
 
 int sv_bn_running_update(const int32_t* table, const float* counts, int nbn, const float* bnbuf, float* bufs,
-                         float eps, float momentum, int align, void* stream) {
+                         float eps, float momentum, int align, int groups, void* stream) {
     SvProfScope prof_scope(stream);
     SV_REQUIRE(table && counts && bnbuf && bufs && nbn > 0 && align > 0, SV_E_ARG, "sv_bn_running_update: bad args");
     hipLaunchKernelGGL(bn_running_update_kernel, dim3(nbn), dim3(256), 0, (hipStream_t)stream, table, counts, bnbuf,
-                       bufs, eps, momentum, align);
+                       bufs, eps, momentum, align, sv_ngroups(groups));
     return sv_check_launch("sv_bn_running_update");
 }
 
@@ -863,7 +892,7 @@ int sv_bn_eval_affine(int C, const float* gamma, const float* beta, const float*
 
 int sv_bn_bwd_apply(int dtype, int64_t M, int C, int ld, const void* x, const float* mean, const float* rstd,
                     float count, const sv_bn_branch* br, int nbranch, const void* residual, void* dx,
-                    void* stream) {
+                    int groups, void* stream) {
     SvProfScope prof_scope(stream);
     SV_REQUIRE(x && mean && rstd && br && dx && nbranch >= 1 && nbranch <= 2, SV_E_ARG, "sv_bn_bwd_apply: bad args");
     SV_REQUIRE(C % 8 == 0 && ld % 8 == 0, SV_E_SHAPE, "sv_bn_bwd_apply: C=%d ld=%d must be multiples of 8", C, ld);
@@ -875,14 +904,15 @@ int sv_bn_bwd_apply(int dtype, int64_t M, int C, int ld, const void* x, const fl
         SV_REQUIRE(br[k].g && br[k].bsums && br[k].gamma && br[k].replicas >= 1, SV_E_ARG,
                    "sv_bn_bwd_apply: branch %d incomplete", k);
     }
+    groups = sv_ngroups(groups);
     const int grid = nblocks(M * (C / 8), 256);
     const size_t lds = ((size_t)(2 + 3 * nbranch) * C + (size_t)nbranch * 2 * 256) * sizeof(float);
     SV_REQUIRE(lds <= 64 * 1024, SV_E_SHAPE, "sv_bn_bwd_apply: C=%d too large", C);
     const int cv = C / 8;
     if (256 % cv == 0 && (int64_t)grid * 256 >= cv) {     // every thread keeps one 8-channel group: coefficients in registers
-        DISPATCH_T(dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<T, true>), dim3(grid), dim3(256), lds, (hipStream_t)stream, p));
+        DISPATCH_T(dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<T, true>), dim3(grid, groups), dim3(256), lds, (hipStream_t)stream, p));
     } else {
-        DISPATCH_T(dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<T, false>), dim3(grid), dim3(256), lds, (hipStream_t)stream, p));
+        DISPATCH_T(dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<T, false>), dim3(grid, groups), dim3(256), lds, (hipStream_t)stream, p));
     }
     return sv_check_launch("sv_bn_bwd_apply");
 }
@@ -899,23 +929,26 @@ int sv_colsum(int dtype, const void* y, int64_t M, int N, int ld, float* out, vo
 }
 
 int sv_pool_fwd(int dtype, const void* x, const float* scale, const float* shift, float slope, int B, int HW,
-                int C, int ld, float* feat, void* stream) {
+                int C, int ld, float* feat, int groups, void* stream) {
     SvProfScope prof_scope(stream);
     SV_REQUIRE(x && scale && shift && feat, SV_E_ARG, "sv_pool_fwd: null");
+    SV_REQUIRE(B % sv_ngroups(groups) == 0, SV_E_ARG, "sv_pool_fwd: B=%d is not a multiple of groups=%d", B, groups);
     SV_REQUIRE(slope >= 0.f && slope <= 1.f, SV_E_ARG, "sv_pool_fwd: activation slope %g outside [0, 1]", (double)slope);
     DISPATCH_T(dtype, hipLaunchKernelGGL((pool_fwd_kernel<T>), dim3((B * C + 255) / 256), dim3(256), 0,
-                                         (hipStream_t)stream, (const T*)x, scale, shift, slope, B, HW, C, ld, feat));
+                                         (hipStream_t)stream, (const T*)x, scale, shift, slope, B, HW, C, ld, feat,
+                                         B / sv_ngroups(groups)));
     return sv_check_launch("sv_pool_fwd");
 }
 
 int sv_pool_bwd(int dtype, const void* x, const float* scale, const float* shift, float slope, const float* mean,
                 const float* rstd, const float* dfeat, int B, int HW, int C, int ld, void* g, float* bsums,
-                void* stream) {
+                int groups, void* stream) {
     SvProfScope prof_scope(stream);
     SV_REQUIRE(x && scale && shift && mean && rstd && dfeat && g && bsums, SV_E_ARG, "sv_pool_bwd: null");
+    SV_REQUIRE(B % sv_ngroups(groups) == 0, SV_E_ARG, "sv_pool_bwd: B=%d is not a multiple of groups=%d", B, groups);
     DISPATCH_T(dtype, hipLaunchKernelGGL((pool_bwd_kernel<T>), dim3((B * C + 255) / 256), dim3(256), 0,
                                          (hipStream_t)stream, (const T*)x, scale, shift, slope, mean, rstd, dfeat,
-                                         B, HW, C, ld, (T*)g, bsums));
+                                         B, HW, C, ld, (T*)g, bsums, B / sv_ngroups(groups)));
     return sv_check_launch("sv_pool_bwd");
 }
 

@@ -26,6 +26,7 @@ struct wg_params {
     const void* dy;
     float* dw;
     int splits, m_per;          // m ranges
+    int groups;                 // batched launch: blockIdx.y = group (common.h)
     int wsh, hwsh;              // log2(Wq), log2(Hq*Wq) or -1
     int ntap_total;
 };
@@ -79,7 +80,8 @@ __device__ __forceinline__ f32x8 frag_t(const float* S, int ld, int col0, int la
 }
 
 template <typename T, int TN, int TC, bool USE_TR, bool FAST>
-__global__ __launch_bounds__(256) void wgrad_kernel(const sv_geom g, const wg_params p) {
+__global__ __launch_bounds__(256) void wgrad_kernel(const sv_geom g, const wg_params p_in) {
+    const wg_params p = sv_group_wg(g, p_in, (int)sizeof(T));
     typedef typename V8<T>::type V;
     constexpr int BNw = 16 * TN, BCw = 16 * TC;
     constexpr int LDN = BNw + 8, LDC = BCw + 8;           // LDS row strides (elements)
@@ -259,7 +261,7 @@ int launch2(const sv_geom* g, const wg_params& p, hipStream_t s) {
     const size_t red = (size_t)4 * BNw * BCw * sizeof(float);
     if (red > lds) lds = red;
     sv_prof_begin(s);
-    hipLaunchKernelGGL((wgrad_kernel<T, TN, TC, USE_TR, FAST>), dim3(grid), dim3(256), lds, s, *g, p);
+    hipLaunchKernelGGL((wgrad_kernel<T, TN, TC, USE_TR, FAST>), dim3(grid, p.groups), dim3(256), lds, s, *g, p);
     sv_prof_end(s);
     return sv_check_launch("sv_wgrad");
 }
@@ -287,7 +289,7 @@ int dispatch(const sv_geom* g, const wg_params& p, int tn, int tc, hipStream_t s
 
 extern "C" int sv_wgrad(const sv_geom* g, int dtype, const void* x, const float* pro_scale,
                         const float* pro_shift, float pro_slope, const void* dy, float* dw, int splits,
-                        int use_tr, float* ws, int64_t ws_elems, void* stream) {
+                        int use_tr, float* ws, int64_t ws_elems, int groups, void* stream) {
     SV_REQUIRE(g && x && dy && dw, SV_E_ARG, "sv_wgrad: null argument");
     SV_REQUIRE(dtype == SV_F32 || dtype == SV_BF16, SV_E_ARG, "sv_wgrad: bad dtype %d", dtype);
     SV_REQUIRE(g->Cin % 16 == 0 && g->N % 16 == 0 && g->ldx % 8 == 0 && g->ldo % 8 == 0, SV_E_SHAPE,
@@ -297,12 +299,13 @@ extern "C" int sv_wgrad(const sv_geom* g, int dtype, const void* x, const float*
                "sv_wgrad: activation slope %g outside [0, 1]", (double)pro_slope);
     if (dtype == SV_F32 || use_tr) {   // stride-1 3x3: LDS-halo kernels (wgrad3x3.hip) unless switched off
         int rc = 0;
-        if (!sv_disabled(SV_K_WGRAD3X3) && sv_wgrad3x3_try(g, dtype, x, pro_scale, pro_shift, pro_slope, dy, dw, ws, ws_elems, (hipStream_t)stream, &rc))
+        if (!sv_disabled(SV_K_WGRAD3X3) && sv_wgrad3x3_try(g, dtype, x, pro_scale, pro_shift, pro_slope, dy, dw, ws, ws_elems, sv_ngroups(groups), (hipStream_t)stream, &rc))
             return rc;
     }
     wg_params p;
     p.x = x; p.pro_scale = pro_scale; p.pro_shift = pro_shift; p.pro_slope = pro_slope;
     p.dy = dy; p.dw = dw;
+    p.groups = sv_ngroups(groups);
     p.wsh = ilog2_exact(g->Wq);
     p.hwsh = ilog2_exact(g->Hq * g->Wq);
     if (p.wsh < 0 || p.hwsh < 0) p.wsh = p.hwsh = -1;
@@ -319,7 +322,7 @@ extern "C" int sv_wgrad(const sv_geom* g, int dtype, const void* x, const float*
     const int tiles = ((g->N + 16 * tn - 1) / (16 * tn)) * p.ntap_total * ((g->Cin + 16 * tc - 1) / (16 * tc));
     if (splits <= 0) {
         // aim at ~4 blocks per CU, at least 512 rows per block, at most one split per 128 rows
-        int64_t want = (1024 + tiles - 1) / tiles;
+        int64_t want = (1024 / p.groups + tiles - 1) / tiles;        // (the groups of a batched launch share the chip)
         int64_t maxs = (M + 511) / 512;
         if (want > maxs) want = maxs;
         if (want < 1) want = 1;

@@ -38,6 +38,7 @@ struct wg3_params {
     float* ws;                    // [splits][N*T_orig*Cin] partial slabs (plain stores) or NULL (atomics into dw)
     int splits, tiles_per;        // 128-pixel tiles: range [split*tiles_per, ...)
     int unit;                     // wide kernel: channel chunks per XCD-affinity unit (0: plain block order)
+    int groups;                   // batched launch: blockIdx.y = group; slab index = group * splits + split
 };
 
 // 8 consecutive pixels (k = 8g + j) of one (shifted) image row, 16 channels starting at col0: k-major
@@ -57,7 +58,8 @@ __device__ __forceinline__ bf16x8 frag_tr(const bf16* S, int pix_elem_q, int col
 // nine taps (9 accumulator tiles) and reduces over ALL 128 pixels of every staged tile, so no cross-wave
 // reduction is needed (LDS float atomics are far too slow for that: 92 us of a 140 us kernel).
 template <typename T, int WLOG>
-__global__ __launch_bounds__(256) void wgrad3x3_kernel(const sv_geom g, const wg3_params p) {
+__global__ __launch_bounds__(256) void wgrad3x3_kernel(const sv_geom g, const wg3_params p_in) {
+    const wg3_params p = sv_group_wg(g, p_in, (int)sizeof(T));
     typedef typename V8<T>::type V;
 #ifdef SV_WG3_STAMP
     const uint64_t st_entry = __builtin_amdgcn_s_memtime();
@@ -274,7 +276,7 @@ __global__ __launch_bounds__(256) void wgrad3x3_kernel(const sv_geom g, const wg
 
     // ---- publish: D layout = lane holds c = 16*wj + fr, n = 16*wi + 4*fq + r ----------------------------
     const int64_t slab = (int64_t)g.N * g.T_orig * g.Cin;
-    float* dst = p.ws ? p.ws + (int64_t)split * slab : p.dw;
+    float* dst = p.ws ? p.ws + ((int64_t)blockIdx.y * p.splits + split) * slab : p.dw;
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
         const int to = P.torig[t];
@@ -396,7 +398,8 @@ __device__ __forceinline__ bf16x8 frag_tr_ld(const bf16* S, int pix_elem_q, int 
 }
 
 template <int WLOG>
-__global__ __launch_bounds__(256, 1) void wgrad3x3w_kernel(const sv_geom g, const wg3_params p) {
+__global__ __launch_bounds__(256, 1) void wgrad3x3w_kernel(const sv_geom g, const wg3_params p_in) {
+    const wg3_params p = sv_group_wg(g, p_in, 2);
     constexpr int W = 1 << WLOG, TR = 128 / W, WP = W + 2;
     // LDS halo rows: row 0 / the last row are the vertical halo, and when a tile holds several whole images (W = 8:
     // TR = 16 > H = 8) a zero spacer row separates them -- zero padding is DATA in LDS, the nine taps need no masks
@@ -734,7 +737,7 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3w_kernel(const sv_geom g, cons
 
     // ---- publish: D layout = lane holds c = c0 + 16*wj + fr, n = n0 + 80*wi + 16*a + 4*fq + r --------------------
     const int64_t slab = (int64_t)g.N * g.T_orig * g.Cin;
-    float* dst = p.ws ? p.ws + (int64_t)split * slab : p.dw;
+    float* dst = p.ws ? p.ws + ((int64_t)blockIdx.y * p.splits + split) * slab : p.dw;
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
         const int to = P.torig[t];
@@ -818,11 +821,11 @@ int launch(const sv_geom* g, const wg3_params& p, hipStream_t s) {
     constexpr int HHn = (TR < W) ? TR : W, LROWSn = TR + TR / HHn + 1;
     const size_t lds = (size_t)(128 + LROWSn * (W + 2)) * LDH * sizeof(T);
     sv_prof_begin(s);
-    hipLaunchKernelGGL((wgrad3x3_kernel<T, WLOG>), dim3(grid), dim3(256), lds, s, *g, p);
+    hipLaunchKernelGGL((wgrad3x3_kernel<T, WLOG>), dim3(grid, p.groups), dim3(256), lds, s, *g, p);
     sv_prof_end(s);               // the event bracket times the main kernel only (comparable with rocprofv3)
     if (p.ws) {
         const int64_t n = (int64_t)g->N * g->T_orig * g->Cin;      // multiple of 4 (Cin % 32 == 0)
-        launch_slab_reduce(p.ws, p.splits, n, p.dw, s);
+        launch_slab_reduce(p.ws, p.splits * p.groups, n, p.dw, s);
     }
     return sv_check_launch("sv_wgrad(3x3)");
 }
@@ -842,11 +845,11 @@ int launch_wide(const sv_geom* g, const wg3_params& p, hipStream_t s) {
         optin = true;
     }
     sv_prof_begin(s);
-    hipLaunchKernelGGL((wgrad3x3w_kernel<WLOG>), dim3(grid), dim3(256), lds, s, *g, p);
+    hipLaunchKernelGGL((wgrad3x3w_kernel<WLOG>), dim3(grid, p.groups), dim3(256), lds, s, *g, p);
     sv_prof_end(s);
     if (p.ws) {
         const int64_t n = (int64_t)g->N * g->T_orig * g->Cin;
-        launch_slab_reduce(p.ws, p.splits, n, p.dw, s);
+        launch_slab_reduce(p.ws, p.splits * p.groups, n, p.dw, s);
     }
     return sv_check_launch("sv_wgrad(3x3 wide)");
 }
@@ -855,7 +858,8 @@ int launch_wide(const sv_geom* g, const wg3_params& p, hipStream_t s) {
 
 // Returns 1 and sets *rc when the geometry is a stride-1 3x3 convolution this kernel covers.
 int sv_wgrad3x3_try(const sv_geom* g, int dtype, const void* x, const float* pro_scale, const float* pro_shift,
-                    float pro_slope, const void* dy, float* dw, float* ws, int64_t ws_elems, hipStream_t s, int* rc) {
+                    float pro_slope, const void* dy, float* dw, float* ws, int64_t ws_elems, int groups, hipStream_t s,
+                    int* rc) {
     if (g->nphase != 1 || g->phase[0].ntap != 9 || g->sy != 1 || g->sx != 1 || g->osy != 1 || g->osx != 1) return 0;
     if (g->Hq != g->Hin || g->Wq != g->Win || g->Hout != g->Hin || g->Wout != g->Win || g->Hin != g->Win) return 0;
     if (g->Win != 8 && g->Win != 16 && g->Win != 32) return 0;
@@ -868,7 +872,8 @@ int sv_wgrad3x3_try(const sv_geom* g, int dtype, const void* x, const float* pro
     wg3_params p;
     p.x = x; p.pro_scale = pro_scale; p.pro_shift = pro_shift; p.pro_slope = pro_slope; p.dy = dy; p.dw = dw;
     p.unit = 0;
-    const int nT = g->B * g->Hin / TR;
+    p.groups = groups;
+    const int nT = g->B * g->Hin / TR;          // per group
     if (!sv_disabled(SV_K_WGRAD3X3W) && dtype == SV_BF16 && g->N % 160 == 0 && g->Cin >= 96) {
         // wide layers: 160 x 32 slabs, one block (one wave per SIMD) per CU.  Pick the split count and the affinity unit
         // (a divisor of the chunk count) that minimise the modelled time:
@@ -889,14 +894,15 @@ int sv_wgrad3x3_try(const sv_geom* g, int dtype, const void* x, const float* pro
         for (int sp = 1; sp <= nT && sp <= 128; ++sp) {
             const int tp = (nT + sp - 1) / sp;
             if ((nT + tp - 1) / tp != sp) continue;               // no empty splits
-            const bool fits = sp == 1 || (ws && ws_elems >= sp * slab_elems);
+            const bool fits = sp * groups == 1 || (ws && ws_elems >= (int64_t)sp * groups * slab_elems);
             for (int u = 1; u <= nC && u <= 32; ++u) {
                 if (nC % u) continue;
-                const int units = sp * nNt * (nC / u);
+                const int units = sp * groups * nNt * (nC / u);
                 const int per_xcd = (units + 7) / 8 * u;
                 const double t_mma = (double)((per_xcd + 31) / 32) * (tp + 4.0) * 2.0e-6;
-                const double t_hbm = (dy_bytes * (nC / u) + 1.5 * x_bytes * nNt + (sp > 1 ? 2.0 * sp * slab_bytes : 0.0)) / 5.0e12;
-                double cost = (t_mma > t_hbm ? t_mma : t_hbm) + (sp > 1 ? sp * slab_bytes / 4.0e12 : 0.0) - 1e-9 * u;
+                const int nsl = sp * groups;              // slabs to publish and reduce
+                const double t_hbm = (groups * (dy_bytes * (nC / u) + 1.5 * x_bytes * nNt) + (nsl > 1 ? 2.0 * nsl * slab_bytes : 0.0)) / 5.0e12;
+                double cost = (t_mma > t_hbm ? t_mma : t_hbm) + (nsl > 1 ? nsl * slab_bytes / 4.0e12 : 0.0) - 1e-9 * u;
                 if (!fits) cost += 1.0;
                 if (best < 0 || cost < best) { best = cost; splits = sp; unit = u; }
             }
@@ -904,8 +910,8 @@ int sv_wgrad3x3_try(const sv_geom* g, int dtype, const void* x, const float* pro
         p.splits = splits;
         p.unit = unit;
         p.tiles_per = (nT + splits - 1) / splits;
-        const int64_t needw = (int64_t)splits * g->N * g->T_orig * g->Cin;
-        p.ws = (ws && ws_elems >= needw && splits > 1) ? ws : nullptr;
+        const int64_t needw = (int64_t)splits * groups * g->N * g->T_orig * g->Cin;
+        p.ws = (ws && ws_elems >= needw && splits * groups > 1) ? ws : nullptr;
         switch (g->Win) {
             case 32: *rc = launch_wide<5>(g, p, s); break;
             case 16: *rc = launch_wide<4>(g, p, s); break;
@@ -915,7 +921,7 @@ int sv_wgrad3x3_try(const sv_geom* g, int dtype, const void* x, const float* pro
     }
     const int nNC = (g->N / 32) * (g->Cin / 32);
     // ~two persistent blocks per CU; every block should still see a few tiles
-    constexpr int target = 512;
+    const int target = 512 / groups > 32 ? 512 / groups : 32;
     int splits = (target + nNC - 1) / nNC;
     if (splits > nT) splits = nT;
     if (splits >= 8) splits = splits / 8 * 8;
@@ -923,8 +929,8 @@ int sv_wgrad3x3_try(const sv_geom* g, int dtype, const void* x, const float* pro
     p.tiles_per = (nT + splits - 1) / splits;
     if (splits < 8) splits = (nT + p.tiles_per - 1) / p.tiles_per;
     p.splits = splits;
-    const int64_t need = (int64_t)splits * g->N * g->T_orig * g->Cin;
-    p.ws = (ws && ws_elems >= need && splits > 1) ? ws : nullptr;    // no workspace: atomics straight into dw
+    const int64_t need = (int64_t)splits * groups * g->N * g->T_orig * g->Cin;
+    p.ws = (ws && ws_elems >= need && splits * groups > 1) ? ws : nullptr;    // no workspace: atomics straight into dw
     switch (g->Win) {
         case 32: *rc = dtype == SV_BF16 ? launch<bf16, 5>(g, p, s) : launch<float, 5>(g, p, s); break;
         case 16: *rc = dtype == SV_BF16 ? launch<bf16, 4>(g, p, s) : launch<float, 4>(g, p, s); break;

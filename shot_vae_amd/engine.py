@@ -269,6 +269,7 @@ class Engine:
         self._pending = {}
         self._run_tables = {}
         self._repack_tables = {}
+        self._bn_layouts = {}
         self.version_probe = None     # callable: summed version counters of the nn.Parameters (set by the module)
         for b in p.bns:
             self.bufs[b.rv_off: b.rv_off + b.C] = 1.0
@@ -336,7 +337,7 @@ class Engine:
                                     "move the model and its inputs to cuda first")
         L.lib()
 
-    def _tag(self, name, g=None, extra_out_reads=0, wgrad=False):
+    def _tag(self, name, g=None, extra_out_reads=0, wgrad=False, groups=1):
         """File the next launch under `name` for sv_prof_collect and remember its algorithmic cost:
         bytes = input + output (+ fused residual / raw-tensor reads) + weights, flops = 2*M*N*K."""
         if self.prof_tags is None:
@@ -346,9 +347,9 @@ class Engine:
         if g is not None:
             es = self.packs.element_size()
             taps = sum(g.phase[p].ntap for p in range(g.nphase))
-            rows = g.B * g.Hq * g.Wq
-            n_in = g.B * g.Hin * g.Win * g.Cin
-            n_out = g.B * g.Hout * g.Wout * g.N
+            rows = groups * g.B * g.Hq * g.Wq
+            n_in = groups * g.B * g.Hin * g.Win * g.Cin
+            n_out = groups * g.B * g.Hout * g.Wout * g.N
             n_w = taps * g.Cin * g.N
             flops = 2.0 * rows * taps * g.Cin * g.N
             if wgrad:
@@ -397,8 +398,9 @@ class Engine:
                _vp(self.packs.data_ptr()), self._stream())
         self._pack_key = key
 
-    def _igemm(self, g, x, w_ptr, out, pro=None, bias=None, residual=None, stats=None, ex=None, tag=None):
+    def _igemm(self, g, x, w_ptr, out, pro=None, bias=None, residual=None, stats=None, ex=None, tag=None, groups=1):
         a = L.SvIgemmArgs()
+        a.groups = groups
         a.x, a.w, a.out = x.data_ptr(), w_ptr, out.data_ptr()
         if pro is not None:
             a.pro_scale, a.pro_shift, a.pro_slope = pro[0], pro[1], pro[2]
@@ -413,7 +415,7 @@ class Engine:
             a.ex = ex[0].data_ptr()
             a.ex_scale, a.ex_shift, a.ex_mean, a.ex_rstd, a.ex_slope, a.bsums, a.replicas = ex[1:]
         if tag:
-            self._tag(tag, g, (residual is not None) + (ex is not None))
+            self._tag(tag, g, (residual is not None) + (ex is not None), groups=groups)
         L.call("sv_igemm", C.byref(g), self.code, C.byref(a), self._stream())
 
     _ws_elems = 16 * 1024 * 1024       # 64 MiB of fp32 partial-slab workspace for sv_wgrad
@@ -442,15 +444,15 @@ class Engine:
             s = pool[cur.cuda_stream] = torch.cuda.Stream()
         return cur, s
 
-    def _wgrad_async(self, g, x, pro, dy, dw_ptr, tag=None):
+    def _wgrad_async(self, g, x, pro, dy, dw_ptr, tag=None, groups=1):
         """Enqueue the weight gradient behind everything issued so far, on the side stream: the dgrad -> BN-apply
         chain continues on the main stream without waiting for it (joined at the end of backward)."""
         if not self.wgrad_side_stream or self.prof_tags is not None:
-            return self._wgrad(g, x, pro, dy, dw_ptr, tag)
+            return self._wgrad(g, x, pro, dy, dw_ptr, tag, groups)
         cur, side = self._side()
         side.wait_stream(cur)
         with torch.cuda.stream(side):
-            self._wgrad(g, x, pro, dy, dw_ptr, tag)
+            self._wgrad(g, x, pro, dy, dw_ptr, tag, groups)
         if not torch.cuda.is_current_stream_capturing():    # (graph-private pools keep memory until the graph dies)
             x.record_stream(side)
             dy.record_stream(side)
@@ -460,20 +462,44 @@ class Engine:
             cur, side = self._side()
             cur.wait_stream(side)
 
-    def _wgrad(self, g, x, pro, dy, dw_ptr, tag=None):
+    def _wgrad(self, g, x, pro, dy, dw_ptr, tag=None, groups=1):
         if tag:
-            self._tag(tag, g, wgrad=True)
+            self._tag(tag, g, wgrad=True, groups=groups)
         ps, pt, sl = (pro[0], pro[1], pro[2]) if pro is not None else (None, None, 0.0)
         L.call("sv_wgrad", C.byref(g), self.code, _vp(x.data_ptr()), _vp(ps) if ps else None,
                _vp(pt) if pt else None, sl, _vp(dy.data_ptr()), _vp(dw_ptr), 0, self.use_tr,
-               _vp(self._wg_ws().data_ptr()), self._ws_elems, self._stream())
+               _vp(self._wg_ws().data_ptr()), self._ws_elems, groups, self._stream())
 
     # ------------------------------------------------------------------------------- forward
-    def forward(self, image, mode, label, label_mix, lam, eps, u, temperature, training, keep):
-        """image NCHW fp32 on device.  Returns (rec NCHW fp32, mu, ls, la, ctx-or-None)."""
+    def _bn_layout(self, G):
+        """Offsets (in floats) of every BatchNorm's [scale | shift | mean | rstd] block in the per-forward scratch for G
+        groups: each of the four arrays is [G][C], padded to the alignment as a whole."""
+        lay = self._bn_layouts.get(G)
+        if lay is None:
+            off, o = {}, 0
+            for b in self.plan.bns:
+                off[b.index] = o
+                o += 4 * _align(G * b.C)
+            lay = self._bn_layouts[G] = (off, o)
+        return lay
+
+    def forward(self, image, groups, eps, u, temperature, training, keep):
+        """One BATCHED forward of G = len(groups) independent instances of the network that share the weights (the
+        forwards (1)-(4) of a SHOT-VAE step, main_shot_vae.py:288,311,329,356, or a single one): every launch carries
+        the G groups (sv_igemm_args::groups), each with its OWN BatchNorm batch statistics -- the reference's
+        semantics of separate model(...) calls -- so the step costs a quarter of the launches at four times the rows.
+
+        image   NCHW fp32 on device, [G * B] images: the groups back to back, B images each
+        groups  list of (mode, label, label_mix, lam): the sampler mode of each group (vae.py:38-52): 0 Gumbel-softmax,
+                1 one-hot(label), 2 lam * onehot(label) + (1 - lam) * onehot(label_mix)
+        eps, u  [G * B, ldc] Gaussian noise, [G * B, K] uniform noise (rows of groups with mode != 0 are ignored) or None
+        Returns (rec NCHW fp32, mu, ls, la, ctx-or-None), all [G * B, ...]."""
         self._require_gpu(image)
         p = self.plan
-        B = image.shape[0]
+        G = len(groups)
+        Bt = image.shape[0]
+        assert Bt % G == 0, "the groups of a batched forward have equal batch sizes"
+        B = Bt // G
         dev = image.device
         T = self.tdtype
         st = self._stream()
@@ -482,7 +508,7 @@ class Engine:
         pbase, bbase = self.param.data_ptr(), self.bufs.data_ptr()
         pk, es = self.packs.data_ptr(), self.packs.element_size()
 
-        # per-forward scratch: BN statistics (zeroed), BN affine/mean/rstd
+        # per-forward scratch: BN statistics [G][R][2C] (zeroed), BN affine/mean/rstd [G][C]
         n_stat = 0
         stat_off, stat_rep = {}, {}
 
@@ -490,7 +516,7 @@ class Engine:
             nonlocal n_stat
             stat_off[name] = n_stat
             stat_rep[name] = _replicas(rows)
-            n_stat += _align(stat_rep[name] * 2 * c)
+            n_stat += _align(G * stat_rep[name] * 2 * c)
 
         stat_slot("t0", 16, B * p.img * p.img)
         hs = p.img
@@ -502,25 +528,28 @@ class Engine:
             stat_slot("h%d" % i, p.dec_convs[i].N, B * p.dec_convs[i].Hout ** 2)
         stats = torch.zeros(n_stat, dtype=torch.float32, device=dev)
         sbase = stats.data_ptr()
-        bnbuf = torch.empty(p.n_bnbuf, dtype=torch.float32, device=dev)
+        bn_off, n_bnbuf = self._bn_layout(G)
+        bnbuf = torch.empty(n_bnbuf, dtype=torch.float32, device=dev)
         nb = bnbuf.data_ptr()
+        defer = training and (self.defer_slot is not None or G > 1)
 
         def bn_ptrs(b):
-            a = _align(b.C)
-            o = nb + 4 * b.buf_off
-            return o, o + 4 * a, o + 8 * a, o + 12 * a       # scale, shift, mean, rstd
+            a = _align(G * b.C)
+            o = nb + 4 * bn_off[b.index]
+            return o, o + 4 * a, o + 8 * a, o + 12 * a       # scale, shift, mean, rstd: [G][C] each
 
         def finalize(b, stat_name, count):
             sc, sh, mn, rs = bn_ptrs(b)
             if training:
-                defer = self.defer_slot is not None
                 L.call("sv_bn_finalize", _vp(sbase + 4 * stat_off[stat_name]), stat_rep[stat_name], b.C, float(count),
                        _vp(pbase + 4 * b.gamma_off), _vp(pbase + 4 * b.beta_off), BN_EPS, BN_MOMENTUM,
                        None if defer else _vp(bbase + 4 * b.rm_off), None if defer else _vp(bbase + 4 * b.rv_off),
-                       _vp(sc), _vp(sh), _vp(mn), _vp(rs), st)
+                       _vp(sc), _vp(sh), _vp(mn), _vp(rs), G, st)
             else:
-                L.call("sv_bn_eval_affine", b.C, _vp(pbase + 4 * b.gamma_off), _vp(pbase + 4 * b.beta_off),
-                       _vp(bbase + 4 * b.rm_off), _vp(bbase + 4 * b.rv_off), BN_EPS, _vp(sc), _vp(sh), st)
+                for gi in range(G):       # running statistics: the same affine for every group
+                    L.call("sv_bn_eval_affine", b.C, _vp(pbase + 4 * b.gamma_off), _vp(pbase + 4 * b.beta_off),
+                           _vp(bbase + 4 * b.rm_off), _vp(bbase + 4 * b.rv_off), BN_EPS, _vp(sc + 4 * gi * b.C),
+                           _vp(sh + 4 * gi * b.C), st)
             return (sc, sh, b.slope)
 
         def sptr(name):
@@ -528,15 +557,15 @@ class Engine:
             return (sbase + 4 * stat_off[name], stat_rep[name]) if training else None
 
         f = FwdCtx()
-        f.B, f.mode, f.lam, f.temperature, f.training = B, mode, lam, temperature, training
-        f.bnbuf = bnbuf
+        f.B, f.G, f.groups, f.temperature, f.training = B, G, groups, temperature, training
+        f.bnbuf, f.bn_off = bnbuf, bn_off
         # stem (wideresnet.py:13-14): NCHW fp32 -> NHWC16, conv3x3 + bias, stats of t0
-        x16 = torch.empty(B, p.img, p.img, CPAD, dtype=T, device=dev)
-        L.call("sv_nchw_to_nhwc", self.code, _vp(image.data_ptr()), B, p.in_ch, p.img, p.img, CPAD,
+        x16 = torch.empty(Bt, p.img, p.img, CPAD, dtype=T, device=dev)
+        L.call("sv_nchw_to_nhwc", self.code, _vp(image.data_ptr()), Bt, p.in_ch, p.img, p.img, CPAD,
                _vp(x16.data_ptr()), st)
-        t = torch.empty(B, p.img, p.img, 16, dtype=T, device=dev)
+        t = torch.empty(Bt, p.img, p.img, 16, dtype=T, device=dev)
         self._igemm(p.stem.geom_fwd(B), x16, pk + es * p.stem.fwd_off, t, bias=pbase + 4 * p.stem_bias_off,
-                    stats=sptr("t0"), tag="fwd:stem")
+                    stats=sptr("t0"), tag="fwd:stem", groups=G)
         f.x16, f.t, f.c1, f.pro = x16, [t], [], []
         h = p.img
         for i, un in enumerate(p.units):
@@ -544,75 +573,80 @@ class Engine:
             tin = f.t[-1]
             pro1 = finalize(un["bn1"], "t%d" % i, cnt_in)
             ho = h // un["stride"]
-            c1 = torch.empty(B, ho, ho, un["cout"], dtype=T, device=dev)
+            c1 = torch.empty(Bt, ho, ho, un["cout"], dtype=T, device=dev)
             self._igemm(un["conv1"].geom_fwd(B), tin, pk + es * un["conv1"].fwd_off, c1, pro=pro1,
-                        stats=sptr("c1_%d" % i), tag="fwd:conv3x3_%dx%d_s%d" % (un["cin"], un["cout"], un["stride"]))
+                        stats=sptr("c1_%d" % i), tag="fwd:conv3x3_%dx%d_s%d" % (un["cin"], un["cout"], un["stride"]),
+                        groups=G)
             pro2 = finalize(un["bn2"], "c1_%d" % i, B * ho * ho)
-            tout = torch.empty(B, ho, ho, un["cout"], dtype=T, device=dev)
+            tout = torch.empty(Bt, ho, ho, un["cout"], dtype=T, device=dev)
             if "convi" in un:
                 proi = finalize(un["bni"], "t%d" % i, cnt_in)
-                sc = torch.empty(B, ho, ho, un["cout"], dtype=T, device=dev)
+                sc = torch.empty(Bt, ho, ho, un["cout"], dtype=T, device=dev)
                 self._igemm(un["convi"].geom_fwd(B), tin, pk + es * un["convi"].fwd_off, sc, pro=proi,
-                            tag="fwd:conv1x1_%dx%d" % (un["cin"], un["cout"]))
+                            tag="fwd:conv1x1_%dx%d" % (un["cin"], un["cout"]), groups=G)
                 res = sc
             else:
                 proi = None
                 res = tin
             self._igemm(un["conv2"].geom_fwd(B), c1, pk + es * un["conv2"].fwd_off, tout, pro=pro2, residual=res,
-                        stats=sptr("t%d" % (i + 1)), tag="fwd:conv3x3_%dx%d_s1" % (un["cout"], un["cout"]))
+                        stats=sptr("t%d" % (i + 1)), tag="fwd:conv3x3_%dx%d_s1" % (un["cout"], un["cout"]), groups=G)
             f.c1.append(c1)
             f.t.append(tout)
             f.pro.append((pro1, pro2, proi))
             h = ho
         # transition BN + LeakyReLU + global average pool (wideresnet.py:90-91, vae.py:143)
         prot = finalize(p.bn_t, "t%d" % len(p.units), B * h * h)
-        feat = torch.empty(B, p.cfeat, dtype=torch.float32, device=dev)
-        L.call("sv_pool_fwd", self.code, _vp(f.t[-1].data_ptr()), _vp(prot[0]), _vp(prot[1]), prot[2], B, h * h,
-               p.cfeat, p.cfeat, _vp(feat.data_ptr()), st)
-        mu = torch.empty(B, p.ldc, dtype=torch.float32, device=dev)
-        ls = torch.empty(B, p.ldc, dtype=torch.float32, device=dev)
-        la = torch.empty(B, p.K, dtype=torch.float32, device=dev)
-        L.call("sv_head_fwd", _vp(feat.data_ptr()), B, p.cfeat, _vp(pbase + 4 * p.head_w_off),
+        feat = torch.empty(Bt, p.cfeat, dtype=torch.float32, device=dev)
+        L.call("sv_pool_fwd", self.code, _vp(f.t[-1].data_ptr()), _vp(prot[0]), _vp(prot[1]), prot[2], Bt, h * h,
+               p.cfeat, p.cfeat, _vp(feat.data_ptr()), G, st)
+        mu = torch.empty(Bt, p.ldc, dtype=torch.float32, device=dev)
+        ls = torch.empty(Bt, p.ldc, dtype=torch.float32, device=dev)
+        la = torch.empty(Bt, p.K, dtype=torch.float32, device=dev)
+        L.call("sv_head_fwd", _vp(feat.data_ptr()), Bt, p.cfeat, _vp(pbase + 4 * p.head_w_off),
                _vp(pbase + 4 * p.head_b_off), p.ldc, p.K, _vp(mu.data_ptr()), _vp(ls.data_ptr()),
                _vp(la.data_ptr()), st)
-        latent = torch.empty(B, p.Lpad, dtype=T, device=dev)
-        csoft = torch.empty(B, p.K, dtype=torch.float32, device=dev)
-        L.call("sv_sample_fwd", self.code, _vp(mu.data_ptr()), _vp(ls.data_ptr()), _vp(la.data_ptr()),
-               _vp(eps.data_ptr()), _vp(u.data_ptr()) if u is not None else None,
-               _vp(label.data_ptr()) if label is not None else None,
-               _vp(label_mix.data_ptr()) if label_mix is not None else None,
-               0.0 if torch.is_tensor(lam) else float(lam), _vp(lam.data_ptr()) if torch.is_tensor(lam) else None,
-               mode, float(temperature), B, p.ldc, p.K, p.Lpad, _vp(latent.data_ptr()),
-               _vp(csoft.data_ptr()), st)
+        latent = torch.empty(Bt, p.Lpad, dtype=T, device=dev)
+        csoft = torch.empty(Bt, p.K, dtype=torch.float32, device=dev)
+        for gi, (mode, label, label_mix, lam) in enumerate(groups):      # the sampler mode differs per group (vae.py:38-52)
+            r0 = gi * B
+            L.call("sv_sample_fwd", self.code, _vp(mu[r0:].data_ptr()), _vp(ls[r0:].data_ptr()), _vp(la[r0:].data_ptr()),
+                   _vp(eps[r0:].data_ptr()), _vp(u[r0:].data_ptr()) if (u is not None and mode == 0) else None,
+                   _vp(label.data_ptr()) if label is not None else None,
+                   _vp(label_mix.data_ptr()) if label_mix is not None else None,
+                   0.0 if torch.is_tensor(lam) else float(lam), _vp(lam.data_ptr()) if torch.is_tensor(lam) else None,
+                   mode, float(temperature), B, p.ldc, p.K, p.Lpad, _vp(latent[r0:].data_ptr()),
+                   _vp(csoft[r0:].data_ptr()), st)
         # decoder (decoder.py:12-58)
         f.h = []
-        hh = 1
-        x = latent.view(B, 1, 1, p.Lpad)
+        x = latent.view(Bt, 1, 1, p.Lpad)
         pro = None
         f.dpro = []
         for i, cv in enumerate(p.dec_convs):
             ho = cv.Hout
-            out = torch.empty(B, ho, ho, cv.N, dtype=T, device=dev)
+            out = torch.empty(Bt, ho, ho, cv.N, dtype=T, device=dev)
             self._igemm(cv.geom_fwd(B), x, pk + es * cv.fwd_off, out, pro=pro,
-                        stats=sptr("h%d" % i) if i < 5 else None, tag="fwd:dec%d" % i)
+                        stats=sptr("h%d" % i) if i < 5 else None, tag="fwd:dec%d" % i, groups=G)
             f.h.append(out)
             if i < 5:
                 pro = finalize(p.dec_bns[i], "h%d" % i, B * ho * ho)
                 f.dpro.append(pro)
                 x = out
-        rec = torch.empty(B, p.in_ch, p.img, p.img, dtype=torch.float32, device=dev)
-        L.call("sv_nhwc_to_nchw", self.code, _vp(f.h[5].data_ptr()), B, p.in_ch, p.img, p.img, p.dec_convs[5].N,
+        rec = torch.empty(Bt, p.in_ch, p.img, p.img, dtype=torch.float32, device=dev)
+        L.call("sv_nhwc_to_nchw", self.code, _vp(f.h[5].data_ptr()), Bt, p.in_ch, p.img, p.img, p.dec_convs[5].N,
                _vp(rec.data_ptr()), st)
         if training:
-            if self.defer_slot is not None:
-                self._pending[self.defer_slot] = (bnbuf, B)      # running stats + counter applied by apply_pending()
+            if defer:      # running stats + counter applied by apply_pending(), in slot order (= the reference's forward order)
+                slot = self.defer_slot if self.defer_slot is not None else len(self._pending)
+                self._pending[slot] = (bnbuf, B, G)
+                if self.defer_slot is None:
+                    self.apply_pending()
             else:
                 self.nbt += 1
         if not keep:
             return rec, mu, ls, la, None
         f.prot, f.feat, f.mu, f.ls, f.la = prot, feat, mu, ls, la
         f.eps, f.csoft, f.latent = eps, csoft, latent
-        f.keep = (label, label_mix, u, stats)
+        f.keep = (groups, u, stats)
         return rec, mu, ls, la, f
 
     def _bn_counts(self, B):
@@ -622,18 +656,20 @@ class Engine:
         return [cnt[b.index] for b in self.plan.bns]
 
     def apply_pending(self):
-        """Apply the deferred running-statistic updates in slot order (= the reference's forward order) on the
-        current stream and advance num_batches_tracked."""
+        """Apply the deferred running-statistic updates in slot order, the groups of a batched forward in group order (=
+        the reference's forward order) on the current stream and advance num_batches_tracked."""
         p = self.plan
         dev = self.param.device
-        tab = self._run_tables.get(dev)
-        if tab is None:
-            rows = []
-            for b in p.bns:
-                rows += [b.buf_off, b.rm_off, b.rv_off, b.C]
-            tab = self._run_tables[dev] = torch.tensor(rows, dtype=torch.int32, device=dev)
+        total = 0
         for k in sorted(self._pending):
-            bnbuf, B = self._pending[k]
+            bnbuf, B, G = self._pending[k]
+            tab = self._run_tables.get((dev, "tab", G))
+            if tab is None:
+                bn_off, _ = self._bn_layout(G)
+                rows = []
+                for b in p.bns:
+                    rows += [bn_off[b.index], b.rm_off, b.rv_off, b.C]
+                tab = self._run_tables[(dev, "tab", G)] = torch.tensor(rows, dtype=torch.int32, device=dev)
             if not torch.cuda.is_current_stream_capturing():
                 bnbuf.record_stream(torch.cuda.current_stream())      # allocated on a branch stream, read here
             key = (dev, B)
@@ -641,12 +677,13 @@ class Engine:
             if cnt is None:
                 cnt = self._run_tables[key] = torch.tensor(self._bn_counts(B), dtype=torch.float32, device=dev)
             L.call("sv_bn_running_update", _vp(tab.data_ptr()), _vp(cnt.data_ptr()), len(p.bns), _vp(bnbuf.data_ptr()),
-                   _vp(self.bufs.data_ptr()), BN_EPS, BN_MOMENTUM, 64, self._stream())
-        self.nbt += len(self._pending)
+                   _vp(self.bufs.data_ptr()), BN_EPS, BN_MOMENTUM, 64, G, self._stream())
+            total += G
+        self.nbt += total
         self._pending = {}
 
     def _bn_rows(self, B):
-        """(BNSpec, pixels of the tensor it normalises) for every BatchNorm."""
+        """(BNSpec, pixels of the tensor it normalises, per group) for every BatchNorm."""
         p = self.plan
         out, h = [], p.img
         for un in p.units:
@@ -662,26 +699,28 @@ class Engine:
 
     # ------------------------------------------------------------------------------- backward
     def backward(self, f, d_rec, d_mu, d_ls, d_la):
-        """Gradients accumulate (+=) into self.grad; nothing is returned (inputs need no grad)."""
+        """Gradients accumulate (+=) into self.grad; nothing is returned (inputs need no grad).  Batched like the
+        forward it belongs to: every launch carries the G groups, the weight gradients sum over them."""
         p = self.plan
-        B, T = f.B, self.tdtype
+        B, G, T = f.B, f.G, self.tdtype
+        Bt = B * G
         dev = f.mu.device
         st = self._stream()
         pbase, gbase = self.param.data_ptr(), self.grad.data_ptr()
         pk, es = self.packs.data_ptr(), self.packs.element_size()
         nb = f.bnbuf.data_ptr()
-        # one zeroed scratch for every (sum g, sum g*xhat) pair of this backward
+        # one zeroed scratch for every (sum g, sum g*xhat) pair of this backward: [G][R][2C] per BatchNorm
         bs_rep, bs_rel, tot = {}, {}, 0
         for b, rows in self._bn_rows(B):
             bs_rep[b.index] = _replicas(rows)
             bs_rel[b.index] = tot
-            tot += _align(bs_rep[b.index] * 2 * b.C)
+            tot += _align(G * bs_rep[b.index] * 2 * b.C)
         bsums = torch.zeros(tot, dtype=torch.float32, device=dev)
         bs_off = {k: bsums.data_ptr() + 4 * v for k, v in bs_rel.items()}
 
         def bnp(b):
-            a = _align(b.C)
-            q = nb + 4 * b.buf_off
+            a = _align(G * b.C)
+            q = nb + 4 * f.bn_off[b.index]
             return q, q + 4 * a, q + 8 * a, q + 12 * a
 
         def ex_of(b, raw):
@@ -689,7 +728,7 @@ class Engine:
             return (raw, sc, sh, mn, rs, b.slope, bs_off[b.index], bs_rep[b.index])
 
         def bn_apply(raw, branches, residual, count):
-            """branches: [(g tensor, BNSpec)] sharing `raw`; returns dL/d(raw) (+ residual)."""
+            """branches: [(g tensor, BNSpec)] sharing `raw`; returns dL/d(raw) (+ residual).  count = rows of ONE group."""
             arr = (L.SvBnBranch * len(branches))()
             for k, (g, b) in enumerate(branches):
                 arr[k].g = g.data_ptr()
@@ -704,38 +743,42 @@ class Engine:
             cc = raw.shape[-1]
             # reads x and one g per branch (+ the residual), writes dx
             self._cost("sv_bn_bwd_apply", raw.numel() * raw.element_size() * (2 + len(branches) + (residual is not None)))
-            L.call("sv_bn_bwd_apply", self.code, raw.numel() // cc, cc, cc, _vp(raw.data_ptr()), _vp(mn), _vp(rs),
+            L.call("sv_bn_bwd_apply", self.code, raw.numel() // cc // G, cc, cc, _vp(raw.data_ptr()), _vp(mn), _vp(rs),
                    float(count), arr, len(branches), _vp(residual.data_ptr()) if residual is not None else None,
-                   _vp(dx.data_ptr()), st)
+                   _vp(dx.data_ptr()), G, st)
             return dx
 
         # ---- decoder ------------------------------------------------------------------------
         last = p.dec_convs[5]
-        D = torch.empty(B, p.img, p.img, last.N, dtype=T, device=dev)
-        L.call("sv_nchw_to_nhwc", self.code, _vp(d_rec.data_ptr()), B, p.in_ch, p.img, p.img, last.N,
+        D = torch.empty(Bt, p.img, p.img, last.N, dtype=T, device=dev)
+        L.call("sv_nchw_to_nhwc", self.code, _vp(d_rec.data_ptr()), Bt, p.in_ch, p.img, p.img, last.N,
                _vp(D.data_ptr()), st)
         for i in range(5, 0, -1):
             cv, b = p.dec_convs[i], p.dec_bns[i - 1]
             hin = f.h[i - 1]
-            self._wgrad_async(cv.geom_fwd(B), hin, f.dpro[i - 1], D, gbase + 4 * cv.master_off, tag="wgrad:dec%d" % i)
+            self._wgrad_async(cv.geom_fwd(B), hin, f.dpro[i - 1], D, gbase + 4 * cv.master_off, tag="wgrad:dec%d" % i,
+                              groups=G)
             g = torch.empty_like(hin)
-            self._igemm(cv.geom_dgrad(B), D, pk + es * cv.dgrad_off, g, ex=ex_of(b, hin), tag="dgrad:dec%d" % i)
-            D = bn_apply(hin, [(g, b)], None, hin.numel() // hin.shape[-1])
+            self._igemm(cv.geom_dgrad(B), D, pk + es * cv.dgrad_off, g, ex=ex_of(b, hin), tag="dgrad:dec%d" % i, groups=G)
+            D = bn_apply(hin, [(g, b)], None, hin.numel() // hin.shape[-1] // G)
         cv = p.dec_convs[0]
-        lat4 = f.latent.view(B, 1, 1, p.Lpad)
-        self._wgrad_async(cv.geom_fwd(B), lat4, None, D, gbase + 4 * cv.master_off, tag="wgrad:dec0")
-        dlat = torch.empty(B, 1, 1, p.Lpad, dtype=T, device=dev)
-        self._igemm(cv.geom_dgrad(B), D, pk + es * cv.dgrad_off, dlat, tag="dgrad:dec0")
+        lat4 = f.latent.view(Bt, 1, 1, p.Lpad)
+        self._wgrad_async(cv.geom_fwd(B), lat4, None, D, gbase + 4 * cv.master_off, tag="wgrad:dec0", groups=G)
+        dlat = torch.empty(Bt, 1, 1, p.Lpad, dtype=T, device=dev)
+        self._igemm(cv.geom_dgrad(B), D, pk + es * cv.dgrad_off, dlat, tag="dgrad:dec0", groups=G)
         # ---- sampler + heads + pool -----------------------------------------------------------
         dmu = d_mu.contiguous().float().clone() if d_mu is not None else torch.zeros_like(f.mu)
         dls = d_ls.contiguous().float().clone() if d_ls is not None else torch.zeros_like(f.ls)
         dla = d_la.contiguous().float().clone() if d_la is not None else torch.zeros_like(f.la)
-        L.call("sv_sample_bwd", self.code, _vp(dlat.data_ptr()), _vp(f.ls.data_ptr()), _vp(f.eps.data_ptr()),
-               _vp(f.csoft.data_ptr()), f.mode, float(f.temperature), B, p.ldc, p.K, p.Lpad, _vp(dmu.data_ptr()),
-               _vp(dls.data_ptr()), _vp(dla.data_ptr()), st)
-        dfeat = torch.empty(B, p.cfeat, dtype=torch.float32, device=dev)
-        ws = torch.empty(B, p.NH, dtype=torch.float32, device=dev)
-        L.call("sv_head_bwd", _vp(f.feat.data_ptr()), B, p.cfeat, _vp(pbase + 4 * p.head_w_off), p.ldc, p.K,
+        dl2 = dlat.view(Bt, p.Lpad)
+        for gi, (mode, _, _, _) in enumerate(f.groups):
+            r0 = gi * B
+            L.call("sv_sample_bwd", self.code, _vp(dl2[r0:].data_ptr()), _vp(f.ls[r0:].data_ptr()),
+                   _vp(f.eps[r0:].data_ptr()), _vp(f.csoft[r0:].data_ptr()), mode, float(f.temperature), B, p.ldc, p.K,
+                   p.Lpad, _vp(dmu[r0:].data_ptr()), _vp(dls[r0:].data_ptr()), _vp(dla[r0:].data_ptr()), st)
+        dfeat = torch.empty(Bt, p.cfeat, dtype=torch.float32, device=dev)
+        ws = torch.empty(Bt, p.NH, dtype=torch.float32, device=dev)
+        L.call("sv_head_bwd", _vp(f.feat.data_ptr()), Bt, p.cfeat, _vp(pbase + 4 * p.head_w_off), p.ldc, p.K,
                _vp(f.la.data_ptr()), _vp(dmu.data_ptr()), _vp(dls.data_ptr()), _vp(dla.data_ptr()),
                _vp(dfeat.data_ptr()), _vp(gbase + 4 * p.head_w_off), _vp(gbase + 4 * p.head_b_off),
                _vp(ws.data_ptr()), st)
@@ -744,7 +787,7 @@ class Engine:
         g = torch.empty_like(tl)
         sc, sh, mn, rs = bnp(p.bn_t)
         L.call("sv_pool_bwd", self.code, _vp(tl.data_ptr()), _vp(sc), _vp(sh), p.bn_t.slope, _vp(mn), _vp(rs),
-               _vp(dfeat.data_ptr()), B, hw, p.cfeat, p.cfeat, _vp(g.data_ptr()), _vp(bs_off[p.bn_t.index]), st)
+               _vp(dfeat.data_ptr()), Bt, hw, p.cfeat, p.cfeat, _vp(g.data_ptr()), _vp(bs_off[p.bn_t.index]), G, st)
         D = bn_apply(tl, [(g, p.bn_t)], None, B * hw)
         # ---- encoder units, last to first (wideresnet.py:45-49 backward) ------------------------
         for i in range(len(p.units) - 1, -1, -1):
@@ -753,29 +796,29 @@ class Engine:
             pro1, pro2, proi = f.pro[i]
             c = un["cout"]
             self._wgrad_async(un["conv2"].geom_fwd(B), c1, pro2, D, gbase + 4 * un["conv2"].master_off,
-                        tag="wgrad:conv3x3_%dx%d_s1" % (c, c))
+                              tag="wgrad:conv3x3_%dx%d_s1" % (c, c), groups=G)
             g2 = torch.empty_like(c1)
             self._igemm(un["conv2"].geom_dgrad(B), D, pk + es * un["conv2"].dgrad_off, g2, ex=ex_of(un["bn2"], c1),
-                        tag="dgrad:conv3x3_%dx%d_s1" % (c, c))
-            dc1 = bn_apply(c1, [(g2, un["bn2"])], None, c1.numel() // c)
+                        tag="dgrad:conv3x3_%dx%d_s1" % (c, c), groups=G)
+            dc1 = bn_apply(c1, [(g2, un["bn2"])], None, c1.numel() // c // G)
             del g2
             self._wgrad_async(un["conv1"].geom_fwd(B), tin, pro1, dc1, gbase + 4 * un["conv1"].master_off,
-                        tag="wgrad:conv3x3_%dx%d_s%d" % (un["cin"], c, un["stride"]))
+                              tag="wgrad:conv3x3_%dx%d_s%d" % (un["cin"], c, un["stride"]), groups=G)
             g1 = torch.empty_like(tin)
             self._igemm(un["conv1"].geom_dgrad(B), dc1, pk + es * un["conv1"].dgrad_off, g1, ex=ex_of(un["bn1"], tin),
-                        tag="dgrad:conv3x3_%dx%d_s%d" % (un["cin"], c, un["stride"]))
+                        tag="dgrad:conv3x3_%dx%d_s%d" % (un["cin"], c, un["stride"]), groups=G)
             del dc1
-            cnt = tin.numel() // tin.shape[-1]
+            cnt = tin.numel() // tin.shape[-1] // G
             if "convi" in un:
                 self._wgrad_async(un["convi"].geom_fwd(B), tin, proi, D, gbase + 4 * un["convi"].master_off,
-                            tag="wgrad:conv1x1_%dx%d" % (un["cin"], c))
-                gi = torch.empty_like(tin)
-                self._igemm(un["convi"].geom_dgrad(B), D, pk + es * un["convi"].dgrad_off, gi,
-                            ex=ex_of(un["bni"], tin), tag="dgrad:conv1x1_%dx%d" % (un["cin"], c))
-                D = bn_apply(tin, [(g1, un["bn1"]), (gi, un["bni"])], None, cnt)
+                                  tag="wgrad:conv1x1_%dx%d" % (un["cin"], c), groups=G)
+                gi_ = torch.empty_like(tin)
+                self._igemm(un["convi"].geom_dgrad(B), D, pk + es * un["convi"].dgrad_off, gi_,
+                            ex=ex_of(un["bni"], tin), tag="dgrad:conv1x1_%dx%d" % (un["cin"], c), groups=G)
+                D = bn_apply(tin, [(g1, un["bn1"]), (gi_, un["bni"])], None, cnt)
             else:
                 D = bn_apply(tin, [(g1, un["bn1"])], D, cnt)
         # ---- stem: weight + bias gradients (the image needs none) ---------------------------------
-        self._wgrad_async(p.stem.geom_fwd(B), f.x16, None, D, gbase + 4 * p.stem.master_off, tag="wgrad:stem")
+        self._wgrad_async(p.stem.geom_fwd(B), f.x16, None, D, gbase + 4 * p.stem.master_off, tag="wgrad:stem", groups=G)
         L.call("sv_colsum", self.code, _vp(D.data_ptr()), D.numel() // 16, 16, 16, _vp(gbase + 4 * p.stem_bias_off), st)
         self._join_side()

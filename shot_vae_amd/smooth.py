@@ -133,7 +133,7 @@ class _ConvLikeFn(torch.autograd.Function):
             L.call("sv_igemm", C.byref(gd), code, C.byref(a), _st())
         dw = torch.zeros_like(master)
         L.call("sv_wgrad", C.byref(gf), code, _vp(x), _vp(one) if ctx.relu_in else None,
-               _vp(zero) if ctx.relu_in else None, 0.0, _vp(dy), _vp(dw), 0, 1, None, 0, _st())
+               _vp(zero) if ctx.relu_in else None, 0.0, _vp(dy), _vp(dw), 0, 1, None, 0, 1, _st())
         db = None
         if ctx.has_bias:
             db = torch.zeros(layer.N, device=dev)

@@ -7,7 +7,7 @@ import torch
 
 from . import dp
 from .criterion import continuous_posterior_loss
-from .mixup import device_permutation, label_smoothing, mixup_vae_data
+from .mixup import _lerp, device_permutation, label_smoothing, mixup_vae_data
 
 
 def alpha_schedule(epoch, max_epoch, alpha_max):
@@ -164,6 +164,96 @@ def train_step_overlapped(model, elbo_criterion, cls_criterion, optimizer, image
     return loss_sup.detach(), loss_unsup.detach()
 
 
+def train_step_grouped(model, elbo_criterion, cls_criterion, optimizer, image_l, label_l, image_u, sch, epsilon=0.1,
+                       distributed=False, device_rng=None, label_u=None, return_outputs=False):
+    """The same step with the four forwards as ONE batched launch sequence and one backward.
+    Legal because, without --om, the INPUTS of the mixed forwards (2) and (4) depend only on the raw images, a pairing and
+    lambda (mixup.py:22,36) -- only their loss TARGETS depend on the outputs of (1) and (3) -- and all four use the same
+    weights (optimizer.step comes last, main_shot_vae.py:365).  Each forward keeps its own BatchNorm batch statistics
+    (groups of the batched launches) and the running statistics receive the four momentum updates in the reference's
+    order; `(loss_sup + loss_unsup).backward()` accumulates the same gradient sum as the reference's two backward()
+    calls.  A quarter of the launches at four times the rows per launch.
+    Needs B_l == B_u (the kernels batch equally sized groups) and no --om: otherwise use train_step.
+    Host RNG (model.rng == "host") is consumed in the reference's order, so identical seeds give identical noise."""
+    plan = model._plan
+    K, ldc = plan.K, plan.ldc
+    B = image_l.size(0)
+    if image_u.size(0) != B:
+        raise ValueError("train_step_grouped needs B_l == B_u (got %d, %d): use train_step" % (B, image_u.size(0)))
+    dev = image_l.device
+    onehot_l = one_hot(label_l, K)
+    # ---- every random draw of the step, in the reference's order (SURVEY.md 3.1) ---------------------------------
+    if device_rng is None and model.rng == "host":
+        eps1 = torch.randn(B, ldc)
+        lam_l = np.random.beta(epsilon, epsilon) if epsilon > 0 else 1
+        perm_l = torch.randperm(B).to(dev)
+        eps2, eps3, u3 = torch.randn(B, ldc), torch.randn(B, ldc), torch.rand(B, K)
+        lam_u = np.random.beta(2.0, 2.0)
+        perm_u = torch.randperm(B).to(dev)
+        eps4, u4 = torch.randn(B, ldc), torch.rand(B, K)
+        eps = torch.cat([eps1, eps2, eps3, eps4]).to(dev)
+        uz = torch.zeros(B, K)
+        u = torch.cat([uz, uz, u3, u4]).to(dev)
+        lam_l0 = lam_l
+    else:
+        eps = torch.randn(4 * B, ldc, device=dev)
+        u = torch.rand(4 * B, K, device=dev)
+        perm_l, perm_u = device_permutation(B, dev), device_permutation(B, dev)
+        if device_rng is not None:
+            lam_l, lam_u = device_rng.next_lams()          # device scalars: capturable
+            lam_l0 = lam_l.reshape(())
+        else:
+            lam_l = lam_l0 = np.random.beta(epsilon, epsilon) if epsilon > 0 else 1
+            lam_u = np.random.beta(2.0, 2.0)
+    perm_l, perm_u = perm_l.long().contiguous(), perm_u.long().contiguous()
+    with torch.no_grad():
+        sm_img = _lerp(image_l, perm_l, lam_l, False)                        # mixup.py:36
+        mx_img = _lerp(image_u, perm_u, lam_u, False)                        # mixup.py:22
+        sm_label = label_l[perm_l]
+        sm_onehot = one_hot(sm_label, K)
+    rec, mu, ls, la = model.forward_groups(
+        [image_l, sm_img, image_u, mx_img],
+        [dict(disc_label=label_l), dict(mixup=True, disc_label=label_l, disc_pseudo_label=sm_label, mixup_lam=lam_l),
+         dict(), dict()], eps=eps, u=u)
+    rec1, rec2, rec3, rec4 = rec.split(B)
+    mu1, mu2, mu3, mu4 = mu.split(B)
+    ls1, ls2, ls3, ls4 = ls.split(B)
+    la1, la2, la3, la4 = la.split(B)
+    # (1)                                                                      :289-295
+    recon_l, klc_l, kld_l = elbo_criterion(image_l, rec1, mu1, ls1, la1)
+    elbo_l = recon_l + sch["kl_beta_c"] * torch.abs(klc_l - sch["cmi"]) + sch["kl_beta_d"] * torch.abs(kld_l - sch["dmi"])
+    with torch.no_grad():                                                    # :297-310 (the targets of (2))
+        sm_mu, sm_sigma = _lerp(mu1, perm_l, lam_l, False), _lerp(ls1, perm_l, lam_l, True)
+    # (2)                                                                      :316-323
+    disc_post_l = lam_l0 * cls_criterion(la2, onehot_l) + (1 - lam_l0) * cls_criterion(la2, sm_onehot)
+    cont_post_l = continuous_posterior_loss(mu2, ls2, sm_mu, sm_sigma)
+    loss_sup = sch["ew"] * (elbo_l + sch["kl_beta_c"] * sch["pwm"] * cont_post_l) + disc_post_l
+    # (3)                                                                      :330-346
+    kl_inference = inference_kl(la3, label_u) if label_u is not None else None
+    recon_u, klc_u, kld_u = elbo_criterion(image_u, rec3, mu3, ls3, la3)
+    elbo_u = recon_u + sch["kl_beta_c"] * torch.abs(klc_u - sch["cmi"]) + sch["kl_beta_d"] * torch.abs(kld_u - sch["dmi"])
+    with torch.no_grad():                                                    # :348-355 (the targets of (4))
+        mx_mu, mx_sigma = _lerp(mu3, perm_u, lam_u, False), _lerp(ls3, perm_u, lam_u, True)
+        mx_alpha = _lerp(la3, perm_u, lam_u, True)
+    # (4)                                                                      :358-363
+    disc_post_u = cls_criterion(la4, mx_alpha)
+    cont_post_u = continuous_posterior_loss(mu4, ls4, mx_mu, mx_sigma)
+    loss_unsup = sch["ew"] * (elbo_u + sch["kl_beta_c"] * sch["pwm"] * cont_post_u) + sch["ucw"] * disc_post_u
+    (loss_sup + loss_unsup).backward()                                       # :324 + :364
+    if optimizer is not None:
+        apply_update(model, optimizer, distributed)
+    if not return_outputs:
+        if label_u is not None:
+            return loss_sup.detach(), loss_unsup.detach(), kl_inference
+        return loss_sup.detach(), loss_unsup.detach()
+    loc = dict(locals())
+    keys = ["recon_l", "klc_l", "kld_l", "recon_u", "klc_u", "kld_u", "disc_post_l", "cont_post_l", "disc_post_u",
+            "cont_post_u", "loss_sup", "loss_unsup", "sm_img", "mx_img"] + \
+           ["%s%d" % (n, i) for i in (1, 2, 3, 4) for n in ("rec", "mu", "ls", "la")] + \
+           (["kl_inference"] if label_u is not None else [])
+    return {k: loc[k].detach() for k in keys}
+
+
 def train_step(model, elbo_criterion, cls_criterion, optimizer, image_l, label_l, image_u, sch, epsilon=0.1,
                optimal_match=False, distributed=False, return_outputs=False, label_u=None):
     """One step: 4 forwards, 2 backwards, (all-reduce,) SGD.  Inputs are device tensors.
@@ -259,8 +349,13 @@ class GraphedTrainStep:
     Needs rng="device".  Re-capture (build a new object) when the per-epoch schedule scalars change."""
 
     def __init__(self, model, elbo_criterion, cls_criterion, optimizer, image_l, label_l, image_u, sch, epsilon=0.1,
-                 distributed=False, seed=0, warmup=2, optimal_match=False, label_u=None):
+                 distributed=False, seed=0, warmup=2, optimal_match=False, label_u=None, schedule="grouped"):
         assert model.rng == "device", "graph capture needs device-side noise: VariationalAutoEncoder(..., rng='device')"
+        # "grouped": the four forwards as one batched launch sequence (train_step_grouped); "two-stream": the labelled
+        # and the unlabelled branch on two HIP streams (train_step_overlapped; also the fallback for --om / B_l != B_u)
+        if optimal_match or image_l.size(0) != image_u.size(0):
+            schedule = "two-stream"
+        self.schedule = schedule
         self.model, self.opt, self.distributed = model, optimizer, distributed
         self.il, self.ll, self.iu = image_l.clone(), label_l.clone(), image_u.clone()
         self.lu = label_u.clone() if label_u is not None else None
@@ -287,6 +382,9 @@ class GraphedTrainStep:
     def _body(self):
         e, c, sch, eps = self.args
         eng = self.model._engine
+        if self.schedule == "grouped":
+            return train_step_grouped(self.model, e, c, None, self.il, self.ll, self.iu, sch, epsilon=eps,
+                                      device_rng=self.rng, label_u=self.lu)
         keep = eng.wgrad_side_stream
         # nested side streams inside the two branch streams crash hipGraph instantiation on ROCm 7.2 (and add
         # nothing to the two-stream schedule, measured), so the captured body keeps wgrads on the branch streams

@@ -38,13 +38,13 @@ def _dp_key(key):
 
 
 class _VAEFunction(torch.autograd.Function):
-    """One autograd node for the whole network: fused HIP forward, hand-written HIP backward."""
+    """One autograd node for the whole network (one or several batched instances of it): fused HIP forward,
+    hand-written HIP backward."""
 
     @staticmethod
-    def forward(ctx, anchor, model, image, mode, label, label_mix, lam, eps, u):
+    def forward(ctx, anchor, model, image, groups, eps, u):
         eng = model._engine
-        rec, mu, ls, la, f = eng.forward(image, mode, label, label_mix, lam, eps, u, model._temperature,
-                                         model.training, keep=True)
+        rec, mu, ls, la, f = eng.forward(image, groups, eps, u, model._temperature, model.training, keep=True)
         ctx.model, ctx.f = model, f
         return rec, mu, ls, la
 
@@ -62,9 +62,9 @@ class _VAEFunction(torch.autograd.Function):
         model._attach_grads()
         eng = model._engine
         if d_rec is None:
-            d_rec = torch.zeros(f.B, eng.plan.in_ch, eng.plan.img, eng.plan.img, device=f.mu.device)
+            d_rec = torch.zeros(f.B * f.G, eng.plan.in_ch, eng.plan.img, eng.plan.img, device=f.mu.device)
         eng.backward(f, d_rec.contiguous().float(), d_mu, d_ls, d_la)
-        return (None,) * 9
+        return (None,) * 6
 
 
 class VariationalAutoEncoder(nn.Module):
@@ -196,32 +196,63 @@ class VariationalAutoEncoder(nn.Module):
         """(param, grad) flat fp32 buffers: what FlatSGD updates and dp.all_reduce reduces."""
         return self._engine.param, self._engine.grad
 
-    def forward(self, input_img, mixup=False, disc_label=None, disc_pseudo_label=None, mixup_lam=None):
-        eng, plan = self._engine, self._plan
-        if not input_img.is_cuda:
-            raise L.ShotVaeHipError("VariationalAutoEncoder: input is not on an MI355X (no CPU fallback)")
-        B = input_img.size(0)
-        dev = input_img.device
-        # noise in the reference's order: randn for z (vae.py:37,82), then rand for gumbel (vae.py:52,69)
+    def _draw_noise(self, B, dev, gumbel):
+        """noise in the reference's order: randn for z (vae.py:37,82), then rand for gumbel (vae.py:52,69)"""
+        plan = self._plan
         if self.rng == "host":
             eps = torch.randn(B, plan.ldc).to(dev)
+            u = torch.rand(B, plan.K).to(dev) if gumbel else None
         else:
             eps = torch.randn(B, plan.ldc, device=dev)
-        u = None
-        if disc_label is not None:
-            label = disc_label.view(-1).long().contiguous()
-            if mixup:
-                lam = mixup_lam.reshape(1).float() if torch.is_tensor(mixup_lam) else float(mixup_lam)
-                mode, label_mix = 2, disc_pseudo_label.view(-1).long().contiguous()
-            else:
-                mode, label_mix, lam = 1, None, 0.0
-        else:
-            mode, label, label_mix, lam = 0, None, None, 0.0
-            u = torch.rand(B, plan.K).to(dev) if self.rng == "host" else torch.rand(B, plan.K, device=dev)
+            u = torch.rand(B, plan.K, device=dev) if gumbel else None
+        return eps, u
+
+    @staticmethod
+    def _group_spec(mixup, disc_label, disc_pseudo_label, mixup_lam):
+        """(mode, label, label_mix, lam) of one forward call's arguments (vae.py:38-52)"""
+        if disc_label is None:
+            return (0, None, None, 0.0)
+        label = disc_label.view(-1).long().contiguous()
+        if mixup:
+            lam = mixup_lam.reshape(1).float() if torch.is_tensor(mixup_lam) else float(mixup_lam)
+            return (2, label, disc_pseudo_label.view(-1).long().contiguous(), lam)
+        return (1, label, None, 0.0)
+
+    def forward(self, input_img, mixup=False, disc_label=None, disc_pseudo_label=None, mixup_lam=None):
+        if not input_img.is_cuda:
+            raise L.ShotVaeHipError("VariationalAutoEncoder: input is not on an MI355X (no CPU fallback)")
+        spec = self._group_spec(mixup, disc_label, disc_pseudo_label, mixup_lam)
+        eps, u = self._draw_noise(input_img.size(0), input_img.device, spec[0] == 0)
+        return self._run(input_img, [spec], eps, u)
+
+    def forward_groups(self, images, specs, eps=None, u=None):
+        """Several forward calls as ONE batched launch sequence (extension; see Engine.forward): images = list of equally
+        sized batches, specs = list of dicts with the keyword arguments of forward() (mixup, disc_label,
+        disc_pseudo_label, mixup_lam).  Equivalent to calling forward() on each batch -- every group keeps its own
+        BatchNorm batch statistics and the running statistics receive the groups' momentum updates in list order -- at a
+        fraction of the launches.  eps / u: the noise to use ([G * B, ldc] / [G * B, K]); drawn here if None, group by
+        group in the reference's order.  Returns the 4-tuple of forward() with the groups concatenated along dim 0."""
+        G = len(images)
+        B = images[0].size(0)
+        if any(im.size(0) != B for im in images):
+            raise ValueError("forward_groups: the batches must have equal sizes")
+        dev = images[0].device
+        gs = [self._group_spec(sp.get("mixup", False), sp.get("disc_label"), sp.get("disc_pseudo_label"),
+                               sp.get("mixup_lam")) for sp in specs]
+        if eps is None:
+            pairs = [self._draw_noise(B, dev, g[0] == 0) for g in gs]
+            eps = torch.cat([e for e, _ in pairs])
+            if any(uu is not None for _, uu in pairs):
+                z = torch.zeros(B, self._plan.K, device=dev)
+                u = torch.cat([uu if uu is not None else z for _, uu in pairs])
+        return self._run(torch.cat([im.float() for im in images]), gs, eps, u)
+
+    def _run(self, image, groups, eps, u):
+        eng = self._engine
+        dev = image.device
         if torch.is_grad_enabled():
             if self._anchor is None or self._anchor.device != dev:
                 self._anchor = torch.zeros(1, device=dev, requires_grad=True)
-            return _VAEFunction.apply(self._anchor, self, input_img, mode, label, label_mix, lam, eps, u)
-        rec, mu, ls, la, _ = eng.forward(input_img, mode, label, label_mix, lam, eps, u, self._temperature,
-                                         self.training, keep=False)
+            return _VAEFunction.apply(self._anchor, self, image, groups, eps, u)
+        rec, mu, ls, la, _ = eng.forward(image, groups, eps, u, self._temperature, self.training, keep=False)
         return rec, mu, ls, la

@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), "missing export " + n
     assert set(names) == set(L.EXPORTS), set(names) ^ set(L.EXPORTS)
-    assert L.lib().sv_version() == 1
+    assert L.lib().sv_version() == 2
 
 
 def test_struct_layout_matches_header():
@@ -31,6 +31,7 @@ def test_struct_layout_matches_header():
     assert ctypes.sizeof(L.SvGeom) == 72 + 4 * 72
     assert ctypes.sizeof(L.SvIgemmArgs) == 17 * 8
     assert ctypes.sizeof(L.SvBnBranch) == 48
+    assert ctypes.sizeof(L.SvRepackJob) == 64
 
 
 def _tile_program(hv):

@@ -272,7 +272,7 @@ def test_conv_wgrad(dt, use_tr, case):
     ws = torch.full((8 * 1024 * 1024,), float("nan"), device=d)      # workspace contents are irrelevant on entry
     for it in range(2):   # accumulates: two calls == 2x; once with and once without the slab workspace
         L.call("sv_wgrad", C.byref(g), code, p(xd), p(sc), p(sh), 0.01, p(dyd), p(dw), 0, use_tr,
-               p(ws) if it else None, ws.numel() if it else 0, st())
+               p(ws) if it else None, ws.numel() if it else 0, 1, st())
     torch.cuda.synchronize()
     got = dw.cpu().view(N, k, k, Cin).permute(0, 3, 1, 2) / 2
     assert rel(got, wref) < tol, rel(got, wref)
@@ -291,7 +291,7 @@ def test_convT_wgrad(dt, use_tr, H, Cin, N, B):
     d = dev()
     dw = torch.zeros(N, 16, Cin, device=d)
     L.call("sv_wgrad", C.byref(g), code, p(nhwc(x).to(d, tdt)), None, None, 0.0, p(nhwc(dy).to(d, tdt)), p(dw), 0,
-           use_tr, None, 0, st())
+           use_tr, None, 0, 1, st())
     torch.cuda.synchronize()
     got = dw.cpu().view(N, 4, 4, Cin).permute(3, 0, 1, 2)
     assert rel(got, w.grad) < tol
@@ -319,7 +319,7 @@ def test_bn_finalize_and_bwd_apply():
     outs = [torch.zeros(Cc, device=d) for _ in range(4)]
     rmd, rvd = rm.to(d), rv.to(d)
     L.call("sv_bn_finalize", p(stats), 2, Cc, float(n), p(gamma.to(d)), p(beta.to(d)), 1e-5, 0.1, p(rmd), p(rvd),
-           p(outs[0]), p(outs[1]), p(outs[2]), p(outs[3]), st())
+           p(outs[0]), p(outs[1]), p(outs[2]), p(outs[3]), 1, st())
     assert rel(rmd, rm2) < 1e-5 and rel(rvd, rv2) < 1e-5
     mean, var = x.mean((0, 2, 3)), x.var((0, 2, 3), unbiased=False)
     assert rel(outs[2], mean) < 1e-4 and rel(outs[3], torch.rsqrt(var + 1e-5)) < 1e-4
@@ -337,7 +337,7 @@ def test_bn_finalize_and_bwd_apply():
     br_[0].dgamma, br_[0].dbeta, br_[0].replicas = dgam.data_ptr(), dbet.data_ptr(), 2
     dx = torch.empty_like(xn)
     rn = nhwc(res).to(d)
-    L.call("sv_bn_bwd_apply", L.SV_F32, n, Cc, Cc, p(xn), p(outs[2]), p(outs[3]), float(n), br_, 1, p(rn), p(dx), st())
+    L.call("sv_bn_bwd_apply", L.SV_F32, n, Cc, Cc, p(xn), p(outs[2]), p(outs[3]), float(n), br_, 1, p(rn), p(dx), 1, st())
     torch.cuda.synchronize()
     assert rel(nchw(dx.cpu()), xr.grad + res) < 1e-4
     assert rel(dgam, gr.grad) < 1e-4 and rel(dbet, br.grad) < 1e-4
@@ -371,7 +371,7 @@ def test_pool_head_sample(dt):
     xd = x.to(d, tdt)
     featd = torch.empty(B, Cc, device=d)
     sc, sh, mn, rs = scale.to(d), shift.to(d), mean.to(d), rstd.to(d)
-    L.call("sv_pool_fwd", code, p(xd), p(sc), p(sh), 0.01, B, HW, Cc, Cc, p(featd), st())
+    L.call("sv_pool_fwd", code, p(xd), p(sc), p(sh), 0.01, B, HW, Cc, Cc, p(featd), 1, st())
     assert rel(featd, feat.detach()) < 1e-4
     mud, lsd, lad = torch.empty(B, ldc, device=d), torch.empty(B, ldc, device=d), torch.empty(B, K, device=d)
     Wd, bd = W.to(d), bias.to(d)
@@ -398,7 +398,7 @@ def test_pool_head_sample(dt):
     assert rel(dW, Wr.grad) < 2e-3 and rel(db, br.grad) < 2e-3
     g = torch.empty(B, HW, Cc, device=d, dtype=tdt)
     bs = torch.zeros(2 * Cc, device=d)
-    L.call("sv_pool_bwd", code, p(xd), p(sc), p(sh), 0.01, p(mn), p(rs), p(dfeat), B, HW, Cc, Cc, p(g), p(bs), st())
+    L.call("sv_pool_bwd", code, p(xd), p(sc), p(sh), 0.01, p(mn), p(rs), p(dfeat), B, HW, Cc, Cc, p(g), p(bs), 1, st())
     torch.cuda.synchronize()
     gref = xr.grad / scale     # the kernel emits dL/d(BN output); gamma*rstd is applied by sv_bn_bwd_apply
     assert rel(g.float(), gref) < max(tol, 2e-3)
@@ -566,3 +566,163 @@ def test_augment_pipeline(mode):
     # the drawn parameters stay in range
     dr = ds.draw(1000).cpu().numpy()
     assert dr[:, :2].min() >= 0 and dr[:, :2].max() <= 8 and set(np.unique(dr[:, 2])) <= {0, 1}
+
+
+# ------------------------------------------------------------------------------------------ batched launches (groups)
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("case", [(4, 16, 32, 8, 3, 1, 1), (4, 32, 32, 32, 3, 1, 1), (4, 64, 64, 16, 3, 1, 1),
+                                  (3, 32, 64, 16, 3, 2, 1), (4, 32, 64, 16, 1, 2, 0), (2, 160, 160, 8, 3, 1, 1)])
+def test_batched_groups_equal_separate_launches(dt, case):
+    """sv_igemm / sv_wgrad with groups = 3 (blockIdx.y = group: tensors back to back, coefficient vectors [G][C],
+    accumulators [G][R][2N]) against three separate launches on the slices: forward with prologue + residual + statistics,
+    data gradient with the activation-backward epilogue, weight gradient (sum over the groups)."""
+    B, Cin, N, H, k, stride, pad = case
+    code, tdt, tol = DT[dt]
+    Gn, d, R = 3, dev(), 4
+    torch.manual_seed(11)
+    Ho = (H + 2 * pad - k) // stride + 1
+    x = torch.randn(Gn * B, H, H, Cin, device=d).to(tdt)
+    sc, sh = (torch.rand(Gn, Cin, device=d) + 0.5).contiguous(), (torch.randn(Gn, Cin, device=d) * 0.3).contiguous()
+    w = bq(torch.randn(N, k * k, Cin) / (k * k * Cin) ** 0.5, dt)
+    gf = G.conv_like(B, H, H, Cin, N, k, stride, pad)
+    wf = repack(w, gf, False, dt)
+    resid = torch.randn(Gn * B, Ho, Ho, N, device=d).to(tdt)
+
+    def fwd(xs, scs, shs, rs, groups):
+        out = torch.zeros(xs.shape[0], Ho, Ho, N, dtype=tdt, device=d)
+        stats = torch.zeros(groups, R, 2 * N, device=d)
+        a = L.SvIgemmArgs()
+        a.x, a.w, a.out, a.residual = xs.data_ptr(), wf.data_ptr(), out.data_ptr(), rs.data_ptr()
+        a.pro_scale, a.pro_shift, a.pro_slope = scs.data_ptr(), shs.data_ptr(), 0.01
+        a.stats, a.replicas, a.groups = stats.data_ptr(), R, groups
+        L.call("sv_igemm", C.byref(gf), code, C.byref(a), st())
+        torch.cuda.synchronize()
+        return out, stats.sum(1)
+
+    ob, sb = fwd(x, sc, sh, resid, Gn)
+    for gi in range(Gn):
+        o1, s1 = fwd(x[gi * B:(gi + 1) * B].contiguous(), sc[gi].contiguous(), sh[gi].contiguous(),
+                     resid[gi * B:(gi + 1) * B].contiguous(), 1)
+        assert torch.equal(ob[gi * B:(gi + 1) * B], o1), "group %d of the batched forward differs" % gi
+        assert rel(sb[gi], s1[0]) < 1e-5
+    # data gradient with the activation-backward epilogue
+    gd = G.convT_like(B, Ho, Ho, N, Cin, k, stride, pad)
+    wd = repack(w, gd, True, dt)
+    dy = torch.randn(Gn * B, Ho, Ho, N, device=d).to(tdt)
+    emu, ers = (torch.randn(Gn, Cin, device=d) * 0.1).contiguous(), (torch.rand(Gn, Cin, device=d) + 0.5).contiguous()
+
+    def dgrad(dys, xs, scs, shs, mus, rss, groups):
+        dx = torch.zeros(xs.shape[0], H, H, Cin, dtype=tdt, device=d)
+        bs = torch.zeros(groups, R, 2 * Cin, device=d)
+        a = L.SvIgemmArgs()
+        a.x, a.w, a.out = dys.data_ptr(), wd.data_ptr(), dx.data_ptr()
+        a.ex, a.ex_scale, a.ex_shift, a.ex_mean, a.ex_rstd = (t.data_ptr() for t in (xs, scs, shs, mus, rss))
+        a.ex_slope, a.bsums, a.replicas, a.groups = 0.01, bs.data_ptr(), R, groups
+        L.call("sv_igemm", C.byref(gd), code, C.byref(a), st())
+        torch.cuda.synchronize()
+        return dx, bs.sum(1)
+
+    db, bb = dgrad(dy, x, sc, sh, emu, ers, Gn)
+    for gi in range(Gn):
+        sl = slice(gi * B, (gi + 1) * B)
+        d1, b1 = dgrad(dy[sl].contiguous(), x[sl].contiguous(), sc[gi].contiguous(), sh[gi].contiguous(),
+                       emu[gi].contiguous(), ers[gi].contiguous(), 1)
+        assert torch.equal(db[sl], d1), "group %d of the batched data gradient differs" % gi
+        assert rel(bb[gi], b1[0]) < 1e-5
+    # weight gradient: the batched launch sums over the groups
+    ws = torch.empty(8 * 1024 * 1024, device=d)
+    dwb = torch.zeros(N, k * k, Cin, device=d)
+    L.call("sv_wgrad", C.byref(gf), code, p(x), p(sc), p(sh), 0.01, p(dy), p(dwb), 0, int(dt == "bf16"), p(ws), ws.numel(),
+           Gn, st())
+    dws = torch.zeros(N, k * k, Cin, device=d)
+    for gi in range(Gn):
+        sl = slice(gi * B, (gi + 1) * B)
+        L.call("sv_wgrad", C.byref(gf), code, p(x[sl].contiguous()), p(sc[gi].contiguous()), p(sh[gi].contiguous()), 0.01,
+               p(dy[sl].contiguous()), p(dws), 0, int(dt == "bf16"), p(ws), ws.numel(), 1, st())
+    torch.cuda.synchronize()
+    assert rel(dwb, dws) < 1e-4, rel(dwb, dws)
+
+
+def test_batched_bn_kernels_equal_separate_launches():
+    """sv_bn_finalize / sv_bn_bwd_apply / sv_pool_fwd / sv_pool_bwd / sv_bn_running_update with groups = 3 against the
+    per-group calls; the running statistics receive the groups' momentum updates in group order."""
+    Gn, B, HW, Cc, R, d = 3, 4, 64, 32, 2, dev()
+    torch.manual_seed(3)
+    n = B * HW
+    x = torch.randn(Gn, n, Cc, device=d) * (1 + torch.arange(Gn, device=d).view(Gn, 1, 1)) + 0.3
+    gamma, beta = torch.rand(Cc, device=d) + 0.5, torch.randn(Cc, device=d)
+    stats = torch.stack([torch.stack([torch.cat([x[g].sum(0), (x[g] ** 2).sum(0)]) * f for f in (0.25, 0.75)]) for g in range(Gn)]).contiguous()
+    A = (Gn * Cc + 63) // 64 * 64
+    bnbuf = torch.zeros(4 * A, device=d)
+    o = bnbuf.data_ptr()
+    L.call("sv_bn_finalize", p(stats), R, Cc, float(n), p(gamma), p(beta), 1e-5, 0.1, None, None, C.c_void_p(o),
+           C.c_void_p(o + 4 * A), C.c_void_p(o + 8 * A), C.c_void_p(o + 12 * A), Gn, st())
+    torch.cuda.synchronize()
+    sc, sh, mn, rs = (bnbuf[i * A: i * A + Gn * Cc].view(Gn, Cc) for i in range(4))
+    for g in range(Gn):
+        mu, var = x[g].mean(0), x[g].var(0, unbiased=False)
+        assert rel(mn[g], mu) < 1e-4 and rel(rs[g], torch.rsqrt(var + 1e-5)) < 1e-4
+        assert rel(sc[g], gamma * torch.rsqrt(var + 1e-5)) < 1e-4
+    # running statistics: three ordered momentum updates from (mean, rstd)
+    bufs = torch.cat([torch.zeros(Cc), torch.ones(Cc)]).to(d)
+    tab = torch.tensor([0, 0, Cc, Cc], dtype=torch.int32, device=d)
+    cnt = torch.tensor([float(n)], device=d)
+    L.call("sv_bn_running_update", p(tab), p(cnt), 1, p(bnbuf), p(bufs), 1e-5, 0.1, 64, Gn, st())
+    rm, rv = torch.zeros(Cc, device=d), torch.ones(Cc, device=d)
+    for g in range(Gn):
+        rm = 0.9 * rm + 0.1 * x[g].mean(0)
+        rv = 0.9 * rv + 0.1 * x[g].var(0, unbiased=True)
+    torch.cuda.synchronize()
+    assert rel(bufs[:Cc], rm) < 1e-4 and rel(bufs[Cc:], rv) < 1e-3
+    # backward apply, batched against per group
+    gup = torch.randn(Gn, n, Cc, device=d)
+    res = torch.randn(Gn, n, Cc, device=d)
+    xh = (x - mn.view(Gn, 1, Cc)) * rs.view(Gn, 1, Cc)
+    bsums = torch.stack([torch.stack([torch.cat([gup[g].sum(0), (gup[g] * xh[g]).sum(0)]) * 0.5] * 2) for g in range(Gn)]).contiguous()
+
+    def apply(xs, gs, rsd, mns, rss, bss, groups):
+        dgam, dbet = torch.zeros(Cc, device=d), torch.zeros(Cc, device=d)
+        br_ = (L.SvBnBranch * 1)()
+        br_[0].g, br_[0].bsums, br_[0].gamma = gs.data_ptr(), bss.data_ptr(), gamma.data_ptr()
+        br_[0].dgamma, br_[0].dbeta, br_[0].replicas = dgam.data_ptr(), dbet.data_ptr(), 2
+        dx = torch.empty_like(xs)
+        L.call("sv_bn_bwd_apply", L.SV_F32, n, Cc, Cc, p(xs), p(mns), p(rss), float(n), br_, 1, p(rsd), p(dx), groups, st())
+        torch.cuda.synchronize()
+        return dx, dgam, dbet
+
+    dxb, dgb, dbb = apply(x.contiguous(), gup.contiguous(), res.contiguous(), mn.contiguous(), rs.contiguous(), bsums, Gn)
+    dg_sum, db_sum = torch.zeros(Cc, device=d), torch.zeros(Cc, device=d)
+    for g in range(Gn):
+        d1, dg1, db1 = apply(x[g].contiguous(), gup[g].contiguous(), res[g].contiguous(), mn[g].contiguous(),
+                             rs[g].contiguous(), bsums[g].contiguous(), 1)
+        assert torch.equal(dxb[g], d1)
+        dg_sum += dg1
+        db_sum += db1
+    assert rel(dgb, dg_sum) < 1e-5 and rel(dbb, db_sum) < 1e-5
+    # pooling with per-group coefficients
+    xp = x.view(Gn * B, HW, Cc).contiguous()
+    feat = torch.zeros(Gn * B, Cc, device=d)
+    L.call("sv_pool_fwd", L.SV_F32, p(xp), p(sc.contiguous()), p(sh.contiguous()), 0.01, Gn * B, HW, Cc, Cc, p(feat), Gn, st())
+    torch.cuda.synchronize()
+    for g in range(Gn):
+        want = F.leaky_relu(x[g].view(B, HW, Cc) * sc[g] + sh[g], 0.01).mean(1)
+        assert rel(feat[g * B:(g + 1) * B], want) < 1e-5
+
+
+def test_repack_batch_equals_per_layer_repack():
+    """sv_repack_batch (one launch for every layer / direction / phase) against sv_repack, on the WRN-10-1 plan."""
+    import shot_vae_amd as S
+    m = S.VariationalAutoEncoder("wideresnet-10-1", num_input_channels=3, img_size=(32, 32), data_parallel=False,
+                                 continuous_latent_dim=128, disc_latent_dim=10, small_input=True).cuda()
+    eng, plan = m._engine, m._plan
+    eng.ensure_packs()
+    torch.cuda.synchronize()
+    ref = torch.zeros_like(eng.packs)
+    base, pb, es = eng.param.data_ptr(), ref.data_ptr(), ref.element_size()
+    for cv in plan.convs:
+        mm = C.c_void_p(base + 4 * cv.master_off)
+        L.call("sv_repack", eng.code, mm, cv.N, cv.T, cv.Cin, 0, C.byref(cv.geom_fwd(1)), C.c_void_p(pb + es * cv.fwd_off), st())
+        L.call("sv_repack", eng.code, mm, cv.N, cv.T, cv.Cin, 1, C.byref(cv.geom_dgrad(1)), C.c_void_p(pb + es * cv.dgrad_off), st())
+    torch.cuda.synchronize()
+    assert torch.equal(ref.view(torch.int16), eng.packs.view(torch.int16))
+    assert float(eng.packs.float().abs().sum()) > 0

@@ -570,3 +570,84 @@ def test_overlapped_step_passes_optimal_match_and_label_u_through():
         assert abs(float(x) - float(y)) <= 1e-4 * max(abs(float(x)), 1e-6)
     ga, gb = m1.flat_parameters()[1], m2.flat_parameters()[1]
     assert float((ga - gb).abs().max()) <= 2e-4 * float(ga.abs().max())
+
+
+@pytest.mark.parametrize("tag", [t for t, c in T.STEP_CASES.items() if c[2] == c[3] and not c[6]])
+def test_grouped_step_matches_reference_goldens_fp32(tag):
+    """train_step_grouped -- the four forwards as ONE batched launch sequence (groups of sv_igemm_args), one backward --
+    against the REFERENCE's outputs for the same step (the fixtures with B_l == B_u): losses, all sixteen output
+    tensors, gradients, parameters after SGD, BatchNorm running statistics after the four momentum updates."""
+    name, K, Bl, Bu, bce, x_sigma, om, dmi, steps = T.STEP_CASES[tag]
+    g = T.load(tag)
+    model = make_model(name, K, "fp32", C.make_state(name, K=K))
+    elbo = S.VAECriterion(discrete_dim=K, x_sigma=x_sigma, bce_reconstruction=bce).cuda()
+    cls = S.ClsCriterion()
+    opt = S.FlatSGD(model, lr=0.1, momentum=0.9, weight_decay=5e-4)
+    opt.zero_grad()
+    sch = O.schedule(10, dmi=dmi)
+    names = [str(n) for n in g["meta.param_names"]]
+    for s in range(steps):
+        il, ll, iu, lu = C.make_batch(Bl, Bu, K, stream0=7000 + 10 * s)
+        nz = C.make_noise(Bl, Bu, K, stream0=9000 + 100 * s)
+        with T.rng_for_step(nz):                                   # the reference's host-RNG order
+            out = S.train_step_grouped(model, elbo, cls, None, il.cuda(), ll.cuda(), iu.cuda(), sch, return_outputs=True)
+        torch.cuda.synchronize()
+        for k in T.SCALARS:
+            ref = float(g["s%d.%s" % (s, k)])
+            assert abs(float(out[k]) - ref) <= FP32_TOL * max(abs(ref), 1e-6), (tag, s, k, float(out[k]), ref)
+        for k in T.TENSORS:
+            e = T.rel_err(out[k].float().cpu().numpy(), g["s%d.%s" % (s, k)])
+            assert e < FP32_TOL, (tag, s, k, e)
+        grads = param_grads(model)
+        gn = np.array([float(grads[k].double().norm()) for k in names])
+        gr = g["s%d.grad_norm" % s]
+        bad = np.abs(gn - gr) > 1e-2 * gr + 1e-4 * gr.max()
+        assert not bad.any(), (tag, s, [(names[i], gn[i], gr[i]) for i in np.nonzero(bad)[0][:5]])
+        opt.step()
+        opt.zero_grad()
+    torch.cuda.synchronize()
+    sd = {k.replace(".module.", "."): v.detach().float().cpu() for k, v in model.state_dict().items()}
+    pn = np.array([float(sd[k].double().norm()) for k in names])
+    assert np.max(np.abs(pn - g["final.param_norm"]) / g["final.param_norm"]) < 1e-3
+    for k in g.files:
+        if k.startswith("final.buf."):
+            key = k[len("final.buf."):]
+            assert T.rel_err(sd[key].numpy(), g[k]) < 1e-3, key
+
+
+@pytest.mark.parametrize("dtype,B,tol", [("fp32", 8, 2e-4), ("fp32", 128, 2e-4), ("bf16", 128, 3e-2)])
+def test_grouped_step_equals_sequential_step(dtype, B, tol):
+    """Batched (groups = 4) against per-forward launches on the same weights, inputs and noise: the grouped kernels see
+    exactly the per-group problems (blockIdx.y = group), so fp32 agrees to rounding; B = 128 is the size at which every
+    layer of the decoder fills whole 128-row tiles."""
+    name, K = "wideresnet-10-1", 10
+    st = C.make_state(name, K=K)
+    m1, m2 = make_model(name, K, dtype, st), make_model(name, K, dtype, st)
+    elbo, cls = S.VAECriterion(discrete_dim=K).cuda(), S.ClsCriterion()
+    o1, o2 = S.FlatSGD(m1), S.FlatSGD(m2)
+    o1.zero_grad()
+    o2.zero_grad()
+    il, ll, iu, lu = C.make_batch(B, B, K)
+    nz = C.make_noise(B, B, K)
+    sch = O.schedule(10)
+    with T.rng_for_step(nz):
+        a = S.train_step(m1, elbo, cls, None, il.cuda(), ll.cuda(), iu.cuda(), sch, return_outputs=True, label_u=lu.cuda())
+    with T.rng_for_step(nz):
+        b = S.train_step_grouped(m2, elbo, cls, None, il.cuda(), ll.cuda(), iu.cuda(), sch, return_outputs=True,
+                                 label_u=lu.cuda())
+    torch.cuda.synchronize()
+    for k in T.SCALARS + ["kl_inference"]:
+        assert abs(float(a[k]) - float(b[k])) <= tol * max(abs(float(a[k])), 1e-6), (k, float(a[k]), float(b[k]))
+    for k in T.TENSORS:
+        assert T.rel_err(b[k].float().cpu().numpy(), a[k].float().cpu().numpy()) < tol, k
+    ga, gb = m1.flat_parameters()[1].double(), m2.flat_parameters()[1].double()
+    if dtype == "fp32":
+        assert float((ga - gb).norm() / ga.norm()) < 2e-3
+    else:
+        assert float(ga @ gb / ga.norm() / gb.norm()) > 0.9
+    sa, sb = m1.state_dict(), m2.state_dict()
+    for k in sa:
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            assert T.rel_err(sb[k].float().cpu().numpy(), sa[k].float().cpu().numpy()) < (1e-4 if dtype == "fp32" else 2e-2), k
+        if k.endswith("num_batches_tracked"):
+            assert int(sa[k]) == int(sb[k]) == 4, k

@@ -126,7 +126,7 @@ def test_wgrad3x3w_equals_narrow_kernel_at_full_size(Cin, H, N):
                 dw = torch.zeros(N, 9, Cin, device=d)
                 L.call("sv_wgrad", C.byref(g), L.SV_BF16, C.c_void_p(x.data_ptr()), C.c_void_p(sc.data_ptr()),
                        C.c_void_p(sh.data_ptr()), 0.01, C.c_void_p(dy.data_ptr()), C.c_void_p(dw.data_ptr()), 0, 1,
-                       C.c_void_p(ws.data_ptr()), ws.numel(), _st())
+                       C.c_void_p(ws.data_ptr()), ws.numel(), 1, _st())
                 torch.cuda.synchronize()
                 got.append(dw)
         assert torch.isfinite(got[0]).all()

@@ -74,7 +74,7 @@ def bench_layer(B, Cin, H, N, what=("fwd", "dgrad", "wgrad")):
         res["wgrad"] = timed(lambda: L.call("sv_wgrad", C.byref(g), L.SV_BF16, C.c_void_p(x.data_ptr()),
                                             C.c_void_p(sc.data_ptr()), C.c_void_p(sh.data_ptr()), C.c_float(0.01),
                                             C.c_void_p(dy.data_ptr()), C.c_void_p(dw.data_ptr()), 0, 1,
-                                            C.c_void_p(ws.data_ptr()), ws.numel(), st))
+                                            C.c_void_p(ws.data_ptr()), ws.numel(), 1, st))
     for k, us in res.items():
         print(f"B={B} Cin={Cin} N={N} H={H} {k:6s} {us:9.1f} us  {flops / us / 1e6:8.1f} TFLOP/s  "
               f"{flops / us / 1e-6 / PEAK:6.3f} of bf16 MFMA peak", flush=True)
