@@ -44,8 +44,9 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--prof-steps", type=int, default=3)
     ap.add_argument("--graph", type=int, default=1, help="1 (default): replay the step from a captured hipGraph")
-    ap.add_argument("--overlap", type=int, default=1,
-                    help="1 (default): labelled / unlabelled branches of the step on two HIP streams; 0: one stream")
+    ap.add_argument("--schedule", default="grouped", choices=["grouped", "two-stream", "sequential"],
+                    help="grouped (default): the four forwards of the step as one batched launch sequence; two-stream: the "
+                         "labelled / unlabelled branches on two HIP streams; sequential: the reference's order, one stream")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher check without a GPU: the ranks rendezvous over gloo, agree on a max-reduced time and "
                          "rank 0 prints a JSON stub (tests/test_bench_launch_cpu.py)")
@@ -205,12 +206,12 @@ def main():
     iu = torch.rand(B, 3, 32, 32, device="cuda", generator=g)
     ll = torch.randint(0, K, (B,), device="cuda", generator=g)
 
-    from shot_vae_amd.train import GraphedTrainStep, train_step_overlapped
+    from shot_vae_amd.train import GraphedTrainStep, train_step_grouped, train_step_overlapped
 
     graphed, graph_note = None, "eager"
-    if a.graph and a.overlap:
+    if a.graph and a.schedule != "sequential":
         try:
-            graphed = GraphedTrainStep(model, elbo, cls, opt, il, ll, iu, sch, distributed=world > 1)
+            graphed = GraphedTrainStep(model, elbo, cls, opt, il, ll, iu, sch, distributed=world > 1, schedule=a.schedule)
             graph_note = "hipGraph replay"
         except Exception as e:        # capture unsupported on this stack: run eagerly, say so in the output
             graphed, graph_note = None, "eager (graph capture failed: %s)" % type(e).__name__
@@ -219,7 +220,9 @@ def main():
     def step():
         if graphed is not None:
             return graphed()
-        if a.overlap:
+        if a.schedule == "grouped":
+            return train_step_grouped(model, elbo, cls, opt, il, ll, iu, sch, distributed=world > 1)
+        if a.schedule == "two-stream":
             return train_step_overlapped(model, elbo, cls, opt, il, ll, iu, sch, distributed=world > 1)
         return S.train_step(model, elbo, cls, opt, il, ll, iu, sch, distributed=world > 1)
 
@@ -252,7 +255,9 @@ def main():
            "config": {"workload": "SHOT-VAE train step (4 fwd + 2 bwd + SGD) %s K=%d ldc=128, B_l=B_u=%d per GPU, "
                                   "synthetic 3x32x32 in HBM, random init" % (a.net, K, B),
                       "global_batch": 2 * B * world, "parallelism": "dp%d" % world,
-                      "schedule": "two-stream (labelled || unlabelled branch)" if a.overlap else "single stream",
+                      "schedule": {"grouped": "grouped (forwards (1)-(4) as one batched launch sequence, 4 BatchNorm groups)",
+                                   "two-stream": "two-stream (labelled || unlabelled branch)",
+                                   "sequential": "sequential (reference order)"}[a.schedule],
                       "launch": graph_note,
                       "collective": "1 RCCL all-reduce of the flat fp32 gradient buffer per step" if world > 1 else "none"},
            "loss_sup": round(float(ls), 5), "loss_unsup": round(float(lu), 5)}
@@ -263,8 +268,12 @@ def main():
         eng.prof_tags, eng.prof_cost = {}, {}
         L.prof_tags = eng.prof_tags
         L.lib().sv_prof_enable(1)
-        for _ in range(a.prof_steps):       # eager, single stream: HIP events bracket every launch
-            S.train_step(model, elbo, cls, opt, il, ll, iu, sch, distributed=world > 1)
+        eng.wgrad_side_stream = False
+        for _ in range(a.prof_steps):       # eager, single stream: HIP events bracket every launch of the timed schedule
+            if a.schedule == "grouped":
+                train_step_grouped(model, elbo, cls, opt, il, ll, iu, sch, distributed=world > 1)
+            else:
+                S.train_step(model, elbo, cls, opt, il, ll, iu, sch, distributed=world > 1)
         ntag = len(eng.prof_tags) + 1
         ms = (ctypes.c_double * ntag)()
         cnt = (ctypes.c_int * ntag)()
