@@ -53,40 +53,52 @@ __device__ __forceinline__ uint64_t pack_taps(const int8_t* d) {
 __device__ __forceinline__ int tap_off(uint64_t p, int t) { return (int)((p >> (4 * t)) & 15) - 8; }
 
 // Batched launch (sv_igemm_args::groups): blockIdx.y = group; a group is an independent instance of the layer whose
-// tensors / coefficient vectors / accumulators follow those of the previous group.  Returns the arguments of THIS
-// block's group; the kernel then runs on (g, a) exactly as for a single instance.
-__device__ __forceinline__ sv_igemm_args sv_group_args(const sv_geom& g, const sv_igemm_args& a, int es) {
-    sv_igemm_args r = a;
-    const int64_t grp = blockIdx.y;
-    if (grp) {
-        const int64_t xs = (int64_t)g.B * g.Hin * g.Win * g.ldx * es, os = (int64_t)g.B * g.Hout * g.Wout * g.ldo * es;
-        r.x = reinterpret_cast<const char*>(a.x) + grp * xs;
-        r.out = reinterpret_cast<char*>(a.out) + grp * os;
-        if (a.residual) r.residual = reinterpret_cast<const char*>(a.residual) + grp * os;
-        if (a.ex) r.ex = reinterpret_cast<const char*>(a.ex) + grp * os;
-        if (a.pro_scale) { r.pro_scale = a.pro_scale + grp * g.Cin; r.pro_shift = a.pro_shift + grp * g.Cin; }
-        if (a.stats) r.stats = a.stats + grp * a.replicas * 2 * g.N;
-        if (a.ex) {
-            r.ex_scale = a.ex_scale + grp * g.N; r.ex_shift = a.ex_shift + grp * g.N;
-            r.ex_mean = a.ex_mean + grp * g.N; r.ex_rstd = a.ex_rstd + grp * g.N;
-            r.bsums = a.bsums + grp * a.replicas * 2 * g.N;
-        }
-    }
-    return r;
-}
+// tensors / coefficient vectors / accumulators follow those of the previous group.  The HOST expands the caller's
+// arguments into one argument block per group (all of them travel as the kernel parameter); a kernel starts with
+// `const sv_igemm_args& a = A.g[blockIdx.y];` -- a reference into kernel-argument memory, so every field is still a scalar
+// load at its point of use (a modified COPY of the block would pin ~40 SGPRs for the kernel's lifetime: measured +40 % on
+// the persistent 3x3 kernel) -- and runs on (g, a) exactly as for a single instance.
+constexpr int SV_MAX_GROUPS = 4;          // the four forwards of a SHOT-VAE step
+struct sv_igemm_args_g { sv_igemm_args g[SV_MAX_GROUPS]; };
 __host__ __device__ __forceinline__ int sv_ngroups(int groups) { return groups > 0 ? groups : 1; }
+inline sv_igemm_args_g sv_expand_groups(const sv_geom& g, const sv_igemm_args& a, int es) {
+    sv_igemm_args_g A;
+    const int64_t xs = (int64_t)g.B * g.Hin * g.Win * g.ldx * es, os = (int64_t)g.B * g.Hout * g.Wout * g.ldo * es;
+    for (int64_t grp = 0; grp < SV_MAX_GROUPS; ++grp) {
+        sv_igemm_args r = a;
+        if (grp > 0 && grp < sv_ngroups(a.groups)) {
+            r.x = reinterpret_cast<const char*>(a.x) + grp * xs;
+            r.out = reinterpret_cast<char*>(a.out) + grp * os;
+            if (a.residual) r.residual = reinterpret_cast<const char*>(a.residual) + grp * os;
+            if (a.ex) r.ex = reinterpret_cast<const char*>(a.ex) + grp * os;
+            if (a.pro_scale) { r.pro_scale = a.pro_scale + grp * g.Cin; r.pro_shift = a.pro_shift + grp * g.Cin; }
+            if (a.stats) r.stats = a.stats + grp * a.replicas * 2 * g.N;
+            if (a.ex) {
+                r.ex_scale = a.ex_scale + grp * g.N; r.ex_shift = a.ex_shift + grp * g.N;
+                r.ex_mean = a.ex_mean + grp * g.N; r.ex_rstd = a.ex_rstd + grp * g.N;
+                r.bsums = a.bsums + grp * a.replicas * 2 * g.N;
+            }
+        }
+        A.g[grp] = r;
+    }
+    return A;
+}
 // the same for the weight-gradient parameter blocks (fields x, dy, pro_scale, pro_shift): the groups' operands follow
 // each other, the gradient of the SHARED weights sums over the groups
+template <typename P> struct sv_wg_g { P g[SV_MAX_GROUPS]; };
 template <typename P>
-__device__ __forceinline__ P sv_group_wg(const sv_geom& g, const P& p, int es) {
-    P r = p;
-    const int64_t grp = blockIdx.y;
-    if (grp) {
-        r.x = reinterpret_cast<const char*>(p.x) + grp * ((int64_t)g.B * g.Hin * g.Win * g.ldx * es);
-        r.dy = reinterpret_cast<const char*>(p.dy) + grp * ((int64_t)g.B * g.Hout * g.Wout * g.ldo * es);
-        if (p.pro_scale) { r.pro_scale = p.pro_scale + grp * g.Cin; r.pro_shift = p.pro_shift + grp * g.Cin; }
+inline sv_wg_g<P> sv_expand_wg(const sv_geom& g, const P& p, int groups, int es) {
+    sv_wg_g<P> A;
+    for (int64_t grp = 0; grp < SV_MAX_GROUPS; ++grp) {
+        P r = p;
+        if (grp > 0 && grp < groups) {
+            r.x = reinterpret_cast<const char*>(p.x) + grp * ((int64_t)g.B * g.Hin * g.Win * g.ldx * es);
+            r.dy = reinterpret_cast<const char*>(p.dy) + grp * ((int64_t)g.B * g.Hout * g.Wout * g.ldo * es);
+            if (p.pro_scale) { r.pro_scale = p.pro_scale + grp * g.Cin; r.pro_shift = p.pro_shift + grp * g.Cin; }
+        }
+        A.g[grp] = r;
     }
-    return r;
+    return A;
 }
 
 // host side ------------------------------------------------------------------------------------------

@@ -22,8 +22,8 @@ constexpr int CK = 32;          // channel chunk = one MFMA k step
 constexpr int LDC = CK + 16;    // LDS pixel / weight-row stride (elements): 96 B (bf16) keeps the b128 fragment reads conflict-free
 
 template <typename T, int NT, int WLOG>
-__global__ __launch_bounds__(256) void conv3x3_kernel(const sv_geom g, const sv_igemm_args a_in) {
-    const sv_igemm_args a = sv_group_args(g, a_in, (int)sizeof(T));
+__global__ __launch_bounds__(256) void conv3x3_kernel(const sv_geom g, const sv_igemm_args_g A) {
+    const sv_igemm_args& a = A.g[blockIdx.y];
     typedef typename V8<T>::type V;
     constexpr int W = 1 << WLOG, TR = 128 / W, WP = W + 2;
     constexpr int HP = (TR + 2) * WP;           // halo pixels
@@ -180,8 +180,8 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const sv_geom g, const sv_
 // residual / raw tensor needed by tile i's epilogue are already in flight -- and the BatchNorm sums are
 // kept in registers across tiles and flushed once per block (one shuffle tree, one atomic per channel).
 template <typename T, int WLOG, int CCH>      // CCH = Cin / 32
-__global__ __launch_bounds__(256, SV_C3P_WAVES) void conv3x3p_kernel(const sv_geom g, const sv_igemm_args a_in, int tiles_per) {
-    const sv_igemm_args a = sv_group_args(g, a_in, (int)sizeof(T));
+__global__ __launch_bounds__(256, SV_C3P_WAVES) void conv3x3p_kernel(const sv_geom g, const sv_igemm_args_g A, int tiles_per) {
+    const sv_igemm_args& a = A.g[blockIdx.y];
     typedef typename V8<T>::type V;
     typedef typename V4<T>::type Q;
     constexpr int NT = 2, BN = 32;
@@ -464,8 +464,8 @@ __global__ __launch_bounds__(256, SV_C3P_WAVES) void conv3x3p_kernel(const sv_ge
 // pixel tiles (the 128-pixel kernel restaged it for every tile); the halo tiles alternate between two LDS
 // buffers and are register-prefetched one step ahead, the next weight chunk a whole chunk ahead.
 template <typename T, int NT, int WLOG, int PT>
-__global__ __launch_bounds__(256) void conv3x3m_kernel(const sv_geom g, const sv_igemm_args a_in) {
-    const sv_igemm_args a = sv_group_args(g, a_in, (int)sizeof(T));
+__global__ __launch_bounds__(256) void conv3x3m_kernel(const sv_geom g, const sv_igemm_args_g A) {
+    const sv_igemm_args& a = A.g[blockIdx.y];
     typedef typename V8<T>::type V;
     typedef typename V4<T>::type Q;
     static_assert(PT == 2 || PT == 4, "");
@@ -731,7 +731,7 @@ int launch_m(const sv_geom* g, const sv_igemm_args* a, hipStream_t s) {
         optin = true;
     }
     sv_prof_begin(s);
-    hipLaunchKernelGGL((conv3x3m_kernel<T, NT, WLOG, PT>), dim3(grid, sv_ngroups(a->groups)), dim3(256), lds, s, *g, *a);
+    hipLaunchKernelGGL((conv3x3m_kernel<T, NT, WLOG, PT>), dim3(grid, sv_ngroups(a->groups)), dim3(256), lds, s, *g, sv_expand_groups(*g, *a, (int)sizeof(T)));
     sv_prof_end(s);
     return sv_check_launch("sv_igemm(conv3x3m)");
 }
@@ -767,7 +767,7 @@ int launch_p(const sv_geom* g, const sv_igemm_args* a, hipStream_t s) {
         optin = true;
     }
     sv_prof_begin(s);
-    hipLaunchKernelGGL((conv3x3p_kernel<T, WLOG, CCH>), dim3(chunks * nNt, sv_ngroups(a->groups)), dim3(256), lds, s, *g, *a, tiles_per);
+    hipLaunchKernelGGL((conv3x3p_kernel<T, WLOG, CCH>), dim3(chunks * nNt, sv_ngroups(a->groups)), dim3(256), lds, s, *g, sv_expand_groups(*g, *a, (int)sizeof(T)), tiles_per);
     sv_prof_end(s);
     return sv_check_launch("sv_igemm(conv3x3p)");
 }
@@ -796,7 +796,7 @@ int launch(const sv_geom* g, const sv_igemm_args* a, hipStream_t s) {
         optin = true;
     }
     sv_prof_begin(s);
-    hipLaunchKernelGGL((conv3x3_kernel<T, NT, WLOG>), dim3(grid, sv_ngroups(a->groups)), dim3(256), lds, s, *g, *a);
+    hipLaunchKernelGGL((conv3x3_kernel<T, NT, WLOG>), dim3(grid, sv_ngroups(a->groups)), dim3(256), lds, s, *g, sv_expand_groups(*g, *a, (int)sizeof(T)));
     sv_prof_end(s);
     return sv_check_launch("sv_igemm(conv3x3)");
 }

@@ -75,8 +75,8 @@ struct WCfg {
 };
 
 template <int NF, int WLOG, bool REV>
-__global__ __launch_bounds__(256, 2) void conv3x3w_kernel(const sv_geom g, const sv_igemm_args a_in) {
-    const sv_igemm_args a = sv_group_args(g, a_in, 2);
+__global__ __launch_bounds__(256, 2) void conv3x3w_kernel(const sv_geom g, const sv_igemm_args_g AG) {
+    const sv_igemm_args& a = AG.g[blockIdx.y];
     using C = WCfg<NF, WLOG>;
     constexpr int BN = C::BN, W = C::W, TR = C::TR, WP = C::WP, HH = C::HH, SEG = C::SEG, HI = C::HI, WI = C::WI;
     constexpr int HS = C::HS, HB = C::HB, WS = C::WS, WBUF = C::WBUF, SWS = C::SWS;
@@ -402,7 +402,7 @@ int launch_w3(const sv_geom* g, const sv_igemm_args* a, hipStream_t s) {
         optin = true;
     }
     sv_prof_begin(s);
-    hipLaunchKernelGGL((conv3x3w_kernel<NF, WLOG, REV>), dim3(grid, sv_ngroups(a->groups)), dim3(256), lds, s, *g, *a);
+    hipLaunchKernelGGL((conv3x3w_kernel<NF, WLOG, REV>), dim3(grid, sv_ngroups(a->groups)), dim3(256), lds, s, *g, sv_expand_groups(*g, *a, 2));
     sv_prof_end(s);
     return sv_check_launch("sv_igemm(conv3x3w)");
 }

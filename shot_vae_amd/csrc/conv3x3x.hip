@@ -191,8 +191,8 @@ struct XCfg {
 // MODE: the epilogue's fusion flags at compile time (conv3x3w_epilogue.inc: 0 = from the arguments, 1 = statistics,
 // 2 = residual + statistics, 3 = activation-backward)
 template <int WLOG, bool REV, int MODE>
-__global__ __launch_bounds__(256, 1) void conv3x3x_kernel(const sv_geom g, const sv_igemm_args a_in) {
-    const sv_igemm_args a = sv_group_args(g, a_in, 2);
+__global__ __launch_bounds__(256, 1) void conv3x3x_kernel(const sv_geom g, const sv_igemm_args_g AG) {
+    const sv_igemm_args& a = AG.g[blockIdx.y];
     using C = XCfg<WLOG>;
     constexpr int NF = C::NF, BN = C::BN, W = C::W, TR = C::TR, WP = C::WP, HH = C::HH, SEG = C::SEG;
     constexpr int HS = C::HS, HB = C::HB, WBUF = C::WBUF, SWS = C::SWS, HI = X_HI, HSTEPS = X_HSTEPS;
@@ -619,7 +619,7 @@ int launch_x4(const sv_geom* g, const sv_igemm_args* a, hipStream_t s) {
         optin = true;
     }
     sv_prof_begin(s);
-    hipLaunchKernelGGL((conv3x3x_kernel<WLOG, REV, MODE>), dim3(grid, G), dim3(256), lds, s, *g, *a);
+    hipLaunchKernelGGL((conv3x3x_kernel<WLOG, REV, MODE>), dim3(grid, G), dim3(256), lds, s, *g, sv_expand_groups(*g, *a, 2));
     sv_prof_end(s);
     return sv_check_launch("sv_igemm(conv3x3x)");
 }

@@ -25,8 +25,8 @@ constexpr int BK = 32;
 // (the decoder, the stride-2 convs): those are bound by one global->LDS round trip per iteration, so twice the bytes
 // in flight and twice the MFMAs per barrier nearly halve their time.
 template <typename T, int NT, int KV>
-__global__ __launch_bounds__(256) void igemm_kernel(const sv_geom g, const sv_igemm_args a_in) {
-    const sv_igemm_args a = sv_group_args(g, a_in, (int)sizeof(T));
+__global__ __launch_bounds__(256) void igemm_kernel(const sv_geom g, const sv_igemm_args_g A) {
+    const sv_igemm_args& a = A.g[blockIdx.y];
     typedef typename V8<T>::type V;
     typedef typename V4<T>::type Q;
     constexpr int BN = 16 * NT;
@@ -239,7 +239,7 @@ int launch_kv(const sv_geom* g, const sv_igemm_args* a, hipStream_t s) {
         optin = true;
     }
     sv_prof_begin(s);
-    hipLaunchKernelGGL((igemm_kernel<T, NT, KV>), dim3(grid, sv_ngroups(a->groups)), dim3(256), lds, s, *g, *a);
+    hipLaunchKernelGGL((igemm_kernel<T, NT, KV>), dim3(grid, sv_ngroups(a->groups)), dim3(256), lds, s, *g, sv_expand_groups(*g, *a, (int)sizeof(T)));
     sv_prof_end(s);
     return sv_check_launch("sv_igemm");
 }
@@ -266,6 +266,7 @@ extern "C" int sv_igemm(const sv_geom* g, int dtype, const sv_igemm_args* a, voi
     for (int p = 0; p < g->nphase; ++p)
         SV_REQUIRE(g->phase[p].ntap >= 0 && g->phase[p].ntap <= SV_MAX_TAPS, SV_E_SHAPE, "sv_igemm: ntap");
     SV_REQUIRE(!(a->stats && a->ex), SV_E_ARG, "sv_igemm: stats and ex epilogues are exclusive");
+    SV_REQUIRE(a->groups >= 0 && a->groups <= SV_MAX_GROUPS, SV_E_ARG, "sv_igemm: groups=%d (at most %d)", a->groups, SV_MAX_GROUPS);
     SV_REQUIRE(!a->ex || (a->ex_scale && a->ex_shift && a->ex_mean && a->ex_rstd && a->bsums), SV_E_ARG,
                "sv_igemm: incomplete act-backward epilogue");
     SV_REQUIRE(!a->pro_scale || a->pro_shift, SV_E_ARG, "sv_igemm: prologue shift missing");

@@ -109,24 +109,35 @@ struct bnb_params {
     void* dx;
 };
 
+struct bnb_params_g { bnb_params g[SV_MAX_GROUPS]; };
+// tensors [G][M][ld], mean / rstd [G][C], bsums [G][R][2C]
+static bnb_params_g bnb_expand(const bnb_params& p, int groups, int es) {
+    bnb_params_g A;
+    for (int64_t grp = 0; grp < SV_MAX_GROUPS; ++grp) {
+        bnb_params r = p;
+        if (grp > 0 && grp < groups) {
+            const int64_t ts = p.M * p.ld * es;
+            r.x = reinterpret_cast<const char*>(p.x) + grp * ts;
+            r.dx = reinterpret_cast<char*>(p.dx) + grp * ts;
+            if (p.residual) r.residual = reinterpret_cast<const char*>(p.residual) + grp * ts;
+            r.mean = p.mean + grp * p.C;
+            r.rstd = p.rstd + grp * p.C;
+            for (int k = 0; k < p.nbranch; ++k) {
+                r.br[k].g = reinterpret_cast<const char*>(p.br[k].g) + grp * ts;
+                r.br[k].bsums = p.br[k].bsums + grp * p.br[k].replicas * 2 * p.C;
+            }
+        }
+        A.g[grp] = r;
+    }
+    return A;
+}
+
 // REG: (threads of the grid) % (C/8) == 0, so a thread always meets the same 8 channels and keeps their
 // coefficients [gamma*rstd, mean(g), mean(g*xhat)] (+ mean, rstd) in registers; otherwise they sit in LDS.
 template <typename T, bool REG>
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bnb_params p_in) {
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bnb_params_g PG) {
     typedef typename V8<T>::type V;
-    bnb_params p = p_in;
-    if (blockIdx.y) {         // batched launch: blockIdx.y = group; tensors [G][M][ld], mean / rstd [G][C], bsums [G][R][2C]
-        const int64_t grp = blockIdx.y, ts = p.M * p.ld * (int64_t)sizeof(T);
-        p.x = reinterpret_cast<const char*>(p.x) + grp * ts;
-        p.dx = reinterpret_cast<char*>(p.dx) + grp * ts;
-        if (p.residual) p.residual = reinterpret_cast<const char*>(p.residual) + grp * ts;
-        p.mean += grp * p.C;
-        p.rstd += grp * p.C;
-        for (int k = 0; k < p.nbranch; ++k) {
-            p.br[k].g = reinterpret_cast<const char*>(p.br[k].g) + grp * ts;
-            p.br[k].bsums += grp * p.br[k].replicas * 2 * p.C;
-        }
-    }
+    const bnb_params& p = PG.g[blockIdx.y];        // batched launch: blockIdx.y = group (the host expanded the pointers)
     extern __shared__ __attribute__((aligned(16))) float coef[];
     const int cv = p.C / 8;                       // vectors per row
     const int64_t gtid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -905,14 +916,15 @@ int sv_bn_bwd_apply(int dtype, int64_t M, int C, int ld, const void* x, const fl
                    "sv_bn_bwd_apply: branch %d incomplete", k);
     }
     groups = sv_ngroups(groups);
+    SV_REQUIRE(groups <= SV_MAX_GROUPS, SV_E_ARG, "sv_bn_bwd_apply: groups=%d (at most %d)", groups, SV_MAX_GROUPS);
     const int grid = nblocks(M * (C / 8), 256);
     const size_t lds = ((size_t)(2 + 3 * nbranch) * C + (size_t)nbranch * 2 * 256) * sizeof(float);
     SV_REQUIRE(lds <= 64 * 1024, SV_E_SHAPE, "sv_bn_bwd_apply: C=%d too large", C);
     const int cv = C / 8;
     if (256 % cv == 0 && (int64_t)grid * 256 >= cv) {     // every thread keeps one 8-channel group: coefficients in registers
-        DISPATCH_T(dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<T, true>), dim3(grid, groups), dim3(256), lds, (hipStream_t)stream, p));
+        DISPATCH_T(dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<T, true>), dim3(grid, groups), dim3(256), lds, (hipStream_t)stream, bnb_expand(p, groups, (int)sizeof(T))));
     } else {
-        DISPATCH_T(dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<T, false>), dim3(grid, groups), dim3(256), lds, (hipStream_t)stream, p));
+        DISPATCH_T(dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<T, false>), dim3(grid, groups), dim3(256), lds, (hipStream_t)stream, bnb_expand(p, groups, (int)sizeof(T))));
     }
     return sv_check_launch("sv_bn_bwd_apply");
 }

@@ -80,8 +80,8 @@ __device__ __forceinline__ f32x8 frag_t(const float* S, int ld, int col0, int la
 }
 
 template <typename T, int TN, int TC, bool USE_TR, bool FAST>
-__global__ __launch_bounds__(256) void wgrad_kernel(const sv_geom g, const wg_params p_in) {
-    const wg_params p = sv_group_wg(g, p_in, (int)sizeof(T));
+__global__ __launch_bounds__(256) void wgrad_kernel(const sv_geom g, const sv_wg_g<wg_params> PG) {
+    const wg_params& p = PG.g[blockIdx.y];
     typedef typename V8<T>::type V;
     constexpr int BNw = 16 * TN, BCw = 16 * TC;
     constexpr int LDN = BNw + 8, LDC = BCw + 8;           // LDS row strides (elements)
@@ -261,7 +261,7 @@ int launch2(const sv_geom* g, const wg_params& p, hipStream_t s) {
     const size_t red = (size_t)4 * BNw * BCw * sizeof(float);
     if (red > lds) lds = red;
     sv_prof_begin(s);
-    hipLaunchKernelGGL((wgrad_kernel<T, TN, TC, USE_TR, FAST>), dim3(grid, p.groups), dim3(256), lds, s, *g, p);
+    hipLaunchKernelGGL((wgrad_kernel<T, TN, TC, USE_TR, FAST>), dim3(grid, p.groups), dim3(256), lds, s, *g, sv_expand_wg(*g, p, p.groups, (int)sizeof(T)));
     sv_prof_end(s);
     return sv_check_launch("sv_wgrad");
 }
@@ -295,6 +295,7 @@ extern "C" int sv_wgrad(const sv_geom* g, int dtype, const void* x, const float*
     SV_REQUIRE(g->Cin % 16 == 0 && g->N % 16 == 0 && g->ldx % 8 == 0 && g->ldo % 8 == 0, SV_E_SHAPE,
                "sv_wgrad: Cin=%d N=%d must be multiples of 16", g->Cin, g->N);
     SV_REQUIRE(!pro_scale || pro_shift, SV_E_ARG, "sv_wgrad: prologue shift missing");
+    SV_REQUIRE(groups >= 0 && groups <= SV_MAX_GROUPS, SV_E_ARG, "sv_wgrad: groups=%d (at most %d)", groups, SV_MAX_GROUPS);
     SV_REQUIRE(!pro_scale || (pro_slope >= 0.f && pro_slope <= 1.f), SV_E_ARG,
                "sv_wgrad: activation slope %g outside [0, 1]", (double)pro_slope);
     if (dtype == SV_F32 || use_tr) {   // stride-1 3x3: LDS-halo kernels (wgrad3x3.hip) unless switched off

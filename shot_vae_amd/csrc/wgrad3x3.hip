@@ -58,8 +58,8 @@ __device__ __forceinline__ bf16x8 frag_tr(const bf16* S, int pix_elem_q, int col
 // nine taps (9 accumulator tiles) and reduces over ALL 128 pixels of every staged tile, so no cross-wave
 // reduction is needed (LDS float atomics are far too slow for that: 92 us of a 140 us kernel).
 template <typename T, int WLOG>
-__global__ __launch_bounds__(256) void wgrad3x3_kernel(const sv_geom g, const wg3_params p_in) {
-    const wg3_params p = sv_group_wg(g, p_in, (int)sizeof(T));
+__global__ __launch_bounds__(256) void wgrad3x3_kernel(const sv_geom g, const sv_wg_g<wg3_params> PG) {
+    const wg3_params& p = PG.g[blockIdx.y];
     typedef typename V8<T>::type V;
 #ifdef SV_WG3_STAMP
     const uint64_t st_entry = __builtin_amdgcn_s_memtime();
@@ -398,8 +398,8 @@ __device__ __forceinline__ bf16x8 frag_tr_ld(const bf16* S, int pix_elem_q, int 
 }
 
 template <int WLOG>
-__global__ __launch_bounds__(256, 1) void wgrad3x3w_kernel(const sv_geom g, const wg3_params p_in) {
-    const wg3_params p = sv_group_wg(g, p_in, 2);
+__global__ __launch_bounds__(256, 1) void wgrad3x3w_kernel(const sv_geom g, const sv_wg_g<wg3_params> PG) {
+    const wg3_params& p = PG.g[blockIdx.y];
     constexpr int W = 1 << WLOG, TR = 128 / W, WP = W + 2;
     // LDS halo rows: row 0 / the last row are the vertical halo, and when a tile holds several whole images (W = 8:
     // TR = 16 > H = 8) a zero spacer row separates them -- zero padding is DATA in LDS, the nine taps need no masks
@@ -821,7 +821,7 @@ int launch(const sv_geom* g, const wg3_params& p, hipStream_t s) {
     constexpr int HHn = (TR < W) ? TR : W, LROWSn = TR + TR / HHn + 1;
     const size_t lds = (size_t)(128 + LROWSn * (W + 2)) * LDH * sizeof(T);
     sv_prof_begin(s);
-    hipLaunchKernelGGL((wgrad3x3_kernel<T, WLOG>), dim3(grid, p.groups), dim3(256), lds, s, *g, p);
+    hipLaunchKernelGGL((wgrad3x3_kernel<T, WLOG>), dim3(grid, p.groups), dim3(256), lds, s, *g, sv_expand_wg(*g, p, p.groups, (int)sizeof(T)));
     sv_prof_end(s);               // the event bracket times the main kernel only (comparable with rocprofv3)
     if (p.ws) {
         const int64_t n = (int64_t)g->N * g->T_orig * g->Cin;      // multiple of 4 (Cin % 32 == 0)
@@ -845,7 +845,7 @@ int launch_wide(const sv_geom* g, const wg3_params& p, hipStream_t s) {
         optin = true;
     }
     sv_prof_begin(s);
-    hipLaunchKernelGGL((wgrad3x3w_kernel<WLOG>), dim3(grid, p.groups), dim3(256), lds, s, *g, p);
+    hipLaunchKernelGGL((wgrad3x3w_kernel<WLOG>), dim3(grid, p.groups), dim3(256), lds, s, *g, sv_expand_wg(*g, p, p.groups, 2));
     sv_prof_end(s);
     if (p.ws) {
         const int64_t n = (int64_t)g->N * g->T_orig * g->Cin;
