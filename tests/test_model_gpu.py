@@ -418,10 +418,12 @@ def test_overlapped_two_stream_step_equals_sequential():
             assert int(sa[k]) == int(sb[k]) == 8, k
 
 
-def test_graphed_step_equals_eager_overlapped_step():
-    """GraphedTrainStep (hipGraph replay of the two-stream step) against the eager two-stream step, with the device
-    noise frozen (torch.randn / torch.rand return fixed device tensors per shape) so both are deterministic."""
-    from shot_vae_amd.train import GraphedTrainStep, DeviceRng, train_step_overlapped
+@pytest.mark.parametrize("schedule", ["grouped", "two-stream"])
+def test_graphed_step_equals_eager_step(schedule):
+    """GraphedTrainStep (hipGraph replay of the grouped / the two-stream step) against the same step issued eagerly, with
+    the device noise frozen (torch.randn / torch.rand return fixed device tensors per shape) so both are deterministic."""
+    from shot_vae_amd.train import GraphedTrainStep, DeviceRng, train_step_grouped, train_step_overlapped
+    eager = train_step_grouped if schedule == "grouped" else train_step_overlapped
     name, K, Bl, Bu = "wideresnet-10-1", 10, 8, 8
     st = C.make_state(name, K=K)
     il, ll, iu, lu = C.make_batch(Bl, Bu, K)
@@ -450,8 +452,8 @@ def test_graphed_step_equals_eager_overlapped_step():
         steps, warm = 3, 2
         rng1 = DeviceRng(il.device, seed=3)
         for _ in range(warm + steps):
-            train_step_overlapped(m1, elbo, cls, o1, il, ll, iu, sch, device_rng=rng1)
-        g = GraphedTrainStep(m2, elbo, cls, o2, il, ll, iu, sch, seed=3, warmup=warm)
+            eager(m1, elbo, cls, o1, il, ll, iu, sch, device_rng=rng1)
+        g = GraphedTrainStep(m2, elbo, cls, o2, il, ll, iu, sch, seed=3, warmup=warm, schedule=schedule)
         for _ in range(steps):
             ls, lu_ = g()
         torch.cuda.synchronize()
