@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--schedule", default="grouped", choices=["grouped", "two-stream", "sequential"],
                     help="grouped (default): the four forwards of the step as one batched launch sequence; two-stream: the "
                          "labelled / unlabelled branches on two HIP streams; sequential: the reference's order, one stream")
+    ap.add_argument("--wgrad-side", type=int, default=1, help="weight gradients on a side stream (off the critical path)")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher check without a GPU: the ranks rendezvous over gloo, agree on a max-reduced time and "
                          "rank 0 prints a JSON stub (tests/test_bench_launch_cpu.py)")
@@ -207,6 +208,7 @@ def main():
     ll = torch.randint(0, K, (B,), device="cuda", generator=g)
 
     from shot_vae_amd.train import GraphedTrainStep, train_step_grouped, train_step_overlapped
+    model._engine.wgrad_side_stream = bool(a.wgrad_side)
 
     graphed, graph_note = None, "eager"
     if a.graph and a.schedule != "sequential":

@@ -917,7 +917,9 @@ int sv_bn_bwd_apply(int dtype, int64_t M, int C, int ld, const void* x, const fl
     }
     groups = sv_ngroups(groups);
     SV_REQUIRE(groups <= SV_MAX_GROUPS, SV_E_ARG, "sv_bn_bwd_apply: groups=%d (at most %d)", groups, SV_MAX_GROUPS);
-    const int grid = nblocks(M * (C / 8), 256);
+    // every block first sums the accumulator replicas into its coefficients (a few us of latency): the groups of a batched
+    // launch share the block budget, so that this prologue stays amortised over as many rows per block
+    const int grid = nblocks(M * (C / 8), 256, 2048 / groups > 256 ? 2048 / groups : 256);
     const size_t lds = ((size_t)(2 + 3 * nbranch) * C + (size_t)nbranch * 2 * 256) * sizeof(float);
     SV_REQUIRE(lds <= 64 * 1024, SV_E_SHAPE, "sv_bn_bwd_apply: C=%d too large", C);
     const int cv = C / 8;
