@@ -270,7 +270,6 @@ class Engine:
         self._run_tables = {}
         self._repack_tables = {}
         self._bn_layouts = {}
-        self._wg_queue = []
         self.version_probe = None     # callable: summed version counters of the nn.Parameters (set by the module)
         for b in p.bns:
             self.bufs[b.rv_off: b.rv_off + b.C] = 1.0
@@ -446,31 +445,19 @@ class Engine:
         return cur, s
 
     def _wgrad_async(self, g, x, pro, dy, dw_ptr, tag=None, groups=1):
-        """Weight gradients are off the backward's critical path (nothing downstream reads them before the optimizer):
-        they are queued and issued in a few BATCHES on the side stream (_flush_wgrads at segment boundaries of the
-        backward), so that a batch runs beside the next segment of the dgrad -> BN-apply chain.  Batches, not one
-        fork per launch: a hipGraph replays a handful of cross-stream edges well and a hundred of them badly (measured:
-        per-launch forks made the captured step 0.5 ms slower than one stream, batches make it faster)."""
+        """Enqueue the weight gradient behind everything issued so far, on the side stream: the dgrad -> BN-apply
+        chain continues on the main stream without waiting for it (joined at the end of backward)."""
         if not self.wgrad_side_stream or self.prof_tags is not None:
             return self._wgrad(g, x, pro, dy, dw_ptr, tag, groups)
-        self._wg_queue.append((g, x, pro, dy, dw_ptr, tag, groups))
-
-    def _flush_wgrads(self):
-        if not self._wg_queue:
-            return
         cur, side = self._side()
         side.wait_stream(cur)
         with torch.cuda.stream(side):
-            for (g, x, pro, dy, dw_ptr, tag, groups) in self._wg_queue:
-                self._wgrad(g, x, pro, dy, dw_ptr, tag, groups)
+            self._wgrad(g, x, pro, dy, dw_ptr, tag, groups)
         if not torch.cuda.is_current_stream_capturing():    # (graph-private pools keep memory until the graph dies)
-            for (g, x, pro, dy, dw_ptr, tag, groups) in self._wg_queue:
-                x.record_stream(side)
-                dy.record_stream(side)
-        self._wg_queue = []
+            x.record_stream(side)
+            dy.record_stream(side)
 
     def _join_side(self):
-        self._flush_wgrads()
         if self.wgrad_side_stream and self.prof_tags is None:
             cur, side = self._side()
             cur.wait_stream(side)
@@ -779,7 +766,6 @@ class Engine:
         self._wgrad_async(cv.geom_fwd(B), lat4, None, D, gbase + 4 * cv.master_off, tag="wgrad:dec0", groups=G)
         dlat = torch.empty(Bt, 1, 1, p.Lpad, dtype=T, device=dev)
         self._igemm(cv.geom_dgrad(B), D, pk + es * cv.dgrad_off, dlat, tag="dgrad:dec0", groups=G)
-        self._flush_wgrads()          # the decoder's weight gradients run beside the encoder's backward chain
         # ---- sampler + heads + pool -----------------------------------------------------------
         dmu = d_mu.contiguous().float().clone() if d_mu is not None else torch.zeros_like(f.mu)
         dls = d_ls.contiguous().float().clone() if d_ls is not None else torch.zeros_like(f.ls)
@@ -832,8 +818,6 @@ class Engine:
                 D = bn_apply(tin, [(g1, un["bn1"]), (gi_, un["bni"])], None, cnt)
             else:
                 D = bn_apply(tin, [(g1, un["bn1"])], D, cnt)
-            if "convi" in un or i % 2 == 0:
-                self._flush_wgrads()          # a batch per stage boundary / every other unit
         # ---- stem: weight + bias gradients (the image needs none) ---------------------------------
         self._wgrad_async(p.stem.geom_fwd(B), f.x16, None, D, gbase + 4 * p.stem.master_off, tag="wgrad:stem", groups=G)
         L.call("sv_colsum", self.code, _vp(D.data_ptr()), D.numel() // 16, 16, 16, _vp(gbase + 4 * p.stem_bias_off), st)
