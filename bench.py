@@ -43,7 +43,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--prof-steps", type=int, default=3)
-    ap.add_argument("--graph", type=int, default=1, help="1 (default): replay the step from a captured hipGraph")
+    ap.add_argument("--graph", type=int, default=0,
+                    help="1: replay the step from a captured hipGraph (one stream); 0 (default): issue it eagerly, weight "
+                         "gradients on a side stream -- the grouped step is ~280 launches, which the host keeps ahead of")
     ap.add_argument("--schedule", default="grouped", choices=["grouped", "two-stream", "sequential"],
                     help="grouped (default): the four forwards of the step as one batched launch sequence; two-stream: the "
                          "labelled / unlabelled branches on two HIP streams; sequential: the reference's order, one stream")
@@ -210,7 +212,7 @@ def main():
     from shot_vae_amd.train import GraphedTrainStep, train_step_grouped, train_step_overlapped
     model._engine.wgrad_side_stream = bool(a.wgrad_side)
 
-    graphed, graph_note = None, "eager"
+    graphed, graph_note = None, "eager, weight gradients on a side stream"
     if a.graph and a.schedule != "sequential":
         try:
             graphed = GraphedTrainStep(model, elbo, cls, opt, il, ll, iu, sch, distributed=world > 1, schedule=a.schedule)
