@@ -1,0 +1,401 @@
+// LDS-halo gather-GEMM for the "odd" conv-like layers of the SHOT-VAE network -- everything conv-like that is not a
+// stride-1 3x3 convolution with >= 32 channels (those have conv3x3*.hip): the ConvTranspose2d(4, 2, 1) decoder stack and
+// its data gradients (decoder.py:22-58), the stride-2 3x3 convolutions and 1x1 shortcuts of the WideResNet and their data
+// gradients (wideresnet.py:29-30,41-43), the 16-channel stem / first block (wideresnet.py:13-14).  gfx950.
+//
+// The generic gather-GEMM (igemm.hip) fetches its A operand from global memory once per TAP: a ConvTranspose phase reads
+// every input pixel 4 times, the four phases 16 times, a 4x4 stride-2 convolution 16 times -- through L2, with a
+// global -> LDS round trip and a barrier per 32..64-deep k step.  Those layers ran at 0.15-1.8 TB/s of algorithmic
+// traffic (3-7x their HBM time) and made up a third of the config-2 step.  Here a block owns 128 positions of the
+// per-phase output grid (TR = 128 / Wq whole grid rows, possibly several whole images) x 16*NT output channels and
+//   * stages the input region those positions touch -- (sy (HH - 1) + dy range + 1) rows x (sx (Wq - 1) + dx range + 1)
+//     columns per image segment, zero padding as data -- ONCE per 16/32-channel chunk, the BatchNorm + LeakyReLU/ReLU
+//     prologue applied once per element on the way in;
+//   * stages the weight chunk of EVERY tap of EVERY phase ([BN][taps][CC]);
+//   * runs all phases x taps on MFMA out of LDS (a tap is an LDS address offset), one accumulator set per phase;
+//   * ends with the fused epilogue of sv_igemm (bias, residual, next-BatchNorm statistics or activation-backward +
+//     BatchNorm-backward sums), the per-channel sums kept in registers over the phases and flushed once.
+// With 16 input channels (the stem, the first block, the last decoder gradient) one 32-deep MFMA k step carries TWO taps.
+// Same sv_geom / packed weights / sv_igemm_args contract as sv_igemm: a drop-in fast path inside it (SV_K_HALO disables).
+#include <stdlib.h>
+
+#include "common.h"
+
+namespace {
+
+constexpr int HMAXV = 12;       // halo 16-byte vectors per thread (3072 per block)
+constexpr int HMAXW = 8;        // weight vectors per thread
+
+struct halo_cfg {
+    int wlog, hlog, hhlog;      // log2 of Wq, Hq, HH (HH = grid rows per image segment of a tile = min(TR, Hq))
+    int TR, SEG, SR, LW;        // grid rows per tile, image segments per tile, LDS rows per segment, LDS columns
+    int dymin, dxmin;
+    int HP;                     // LDS halo pixels
+    int tslots;                 // tap slots per weight row (phases padded to whole k steps)
+    int tap0[SV_MAX_PHASES];    // first tap slot of each phase
+    int nks[SV_MAX_PHASES];     // k steps of each phase
+};
+
+template <typename T, int NT, int CC, int NPH>
+__global__ __launch_bounds__(256) void halo_kernel(const sv_geom g, const sv_igemm_args_g AG, const halo_cfg c) {
+    typedef typename V8<T>::type V;
+    typedef typename V4<T>::type Q;
+    constexpr int BN = 16 * NT;
+    constexpr int VPP = CC / 8;                 // 8-channel vectors per pixel per chunk
+    constexpr int LDC = CC + 16;                // LDS pixel stride (elements): 96 B / 64 B rows
+    constexpr int TPK = 32 / CC;                // taps per 32-deep k step
+    const sv_igemm_args& a = AG.g[blockIdx.y];
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* halo = reinterpret_cast<T*>(smem);                       // [HP][LDC]
+    const int LDW = c.tslots * CC + 16;                         // weight row stride (elements)
+    T* wl = halo + c.HP * LDC;                                  // [BN][LDW]
+    float* ssum = reinterpret_cast<float*>(wl + BN * LDW);      // [2][BN]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int Wq = 1 << c.wlog, Hq = 1 << c.hlog, HH = 1 << c.hhlog;
+    const int BHq = g.B * Hq;                                   // rows of the (per-phase) output grid
+    const int nT = (BHq + c.TR - 1) / c.TR;
+    const int nNt = (g.N + BN - 1) / BN;
+    const int L = blockIdx.x;
+    int in_i, mt;
+    if (nT >= 64) {                                             // XCD-affine: the channel tiles of a pixel tile share an L2
+        const int xcd = L & 7, slot = L >> 3;
+        in_i = slot % nNt;
+        mt = (slot / nNt) * 8 + xcd;
+        if (mt >= nT) return;
+    } else {
+        in_i = L % nNt;
+        mt = L / nNt;
+    }
+    const int n0 = in_i * BN;
+    const int R0 = mt * c.TR;                                   // first grid row of the tile (rows run over images)
+    const T* __restrict__ X = reinterpret_cast<const T*>(a.x);
+    const T* __restrict__ Wg = reinterpret_cast<const T*>(a.w);
+    T* __restrict__ O = reinterpret_cast<T*>(a.out);
+    const T* __restrict__ R = reinterpret_cast<const T*>(a.residual);
+    const T* __restrict__ EX = reinterpret_cast<const T*>(a.ex);
+    const bool has_pro = a.pro_scale != nullptr;
+    const bool want_sums = (a.stats != nullptr) || (EX != nullptr);
+
+    if (tid < 2 * BN) ssum[tid] = 0.f;
+    V zero;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) zero[j] = (T)0.f;
+
+    // ---- halo staging slots (channel-chunk independent): vector idx -> (LDS pixel, 8-channel vector) ---------------------
+    const int HVn = c.HP * VPP;
+    int hsrc[HMAXV], hdst[HMAXV];              // element offset into x (channel chunk 0) or -1 (zero) ; LDS element offset or -1
+#pragma unroll
+    for (int i = 0; i < HMAXV; ++i) {
+        const int idx = tid + 256 * i;
+        hsrc[i] = -1;
+        hdst[i] = -1;
+        if (idx < HVn) {
+            const int pix = idx / VPP, cv = idx - pix * VPP;
+            const int lr = pix / c.LW, lc = pix - lr * c.LW;
+            const int seg = lr / c.SR, off = lr - seg * c.SR;
+            const int grow = R0 + (seg << c.hhlog);                 // first grid row of the segment
+            const int b = grow >> c.hlog, qy0 = grow & (Hq - 1);
+            const int iy = g.sy * qy0 + off + c.dymin, ix = lc + c.dxmin;
+            hdst[i] = pix * LDC + 8 * cv;
+            if (grow < BHq && (unsigned)iy < (unsigned)g.Hin && (unsigned)ix < (unsigned)g.Win)
+                hsrc[i] = ((b * g.Hin + iy) * g.Win + ix) * g.ldx + 8 * cv;
+        }
+    }
+    // ---- this lane's two output-grid positions --------------------------------------------------------------------------
+    int hbase[2], prow[2], pcol[2];
+#pragma unroll
+    for (int ms = 0; ms < 2; ++ms) {
+        const int p = 32 * wave + 16 * ms + fr;
+        prow[ms] = p >> c.wlog;
+        pcol[ms] = p & (Wq - 1);
+        const int seg = prow[ms] >> c.hhlog, rin = prow[ms] & (HH - 1);
+        hbase[ms] = ((seg * c.SR + g.sy * rin) * c.LW + g.sx * pcol[ms]) * LDC + (CC == 16 ? 8 * (fq & 1) : 8 * fq);
+    }
+
+    f32x4 acc[NPH][NT][2];
+#pragma unroll
+    for (int ph = 0; ph < NPH; ++ph)
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[ph][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nck = g.Cin / CC;
+    for (int ck = 0; ck < nck; ++ck) {
+        const int c0 = ck * CC;
+        if (ck > 0) __syncthreads();                // the previous chunk's MFMAs are done with the LDS tiles
+        // ---- halo chunk: loads first (in flight together), then transform + store ----------------------------------------
+        f32x4 s0, s1, t0, t1;
+        {
+            const int cv8 = 8 * ((tid % VPP));        // a thread's 8-channel group is the same for all of its slots (256 % VPP == 0)
+            if (has_pro) {
+                s0 = *reinterpret_cast<const f32x4*>(a.pro_scale + c0 + cv8);
+                s1 = *reinterpret_cast<const f32x4*>(a.pro_scale + c0 + cv8 + 4);
+                t0 = *reinterpret_cast<const f32x4*>(a.pro_shift + c0 + cv8);
+                t1 = *reinterpret_cast<const f32x4*>(a.pro_shift + c0 + cv8 + 4);
+            }
+        }
+#pragma unroll
+        for (int i0 = 0; i0 < HMAXV; i0 += 4) {
+            if (256 * i0 >= HVn) break;
+            V hv[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) hv[i] = hsrc[i0 + i] >= 0 ? *reinterpret_cast<const V*>(X + hsrc[i0 + i] + c0) : zero;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                V o = hv[i];
+                if (has_pro && hsrc[i0 + i] >= 0) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float u0 = to_f(hv[i][j]) * s0[j] + t0[j], u1 = to_f(hv[i][j + 4]) * s1[j] + t1[j];
+                        o[j] = (T)fmaxf(u0, u0 * a.pro_slope);
+                        o[j + 4] = (T)fmaxf(u1, u1 * a.pro_slope);
+                    }
+                }
+                if (hdst[i0 + i] >= 0) *reinterpret_cast<V*>(halo + hdst[i0 + i]) = o;
+            }
+        }
+        // ---- weight chunk of every tap slot of every phase: wl[n][(tap0[ph] + t) * CC + c] ----------------------------------
+        {
+            const int WVn = BN * c.tslots * VPP;
+#pragma unroll
+            for (int i = 0; i < HMAXW; ++i) {
+                const int idx = tid + 256 * i;
+                if (idx < WVn) {
+                    const int v = idx % VPP, r = idx / VPP;
+                    const int slot = r % c.tslots, n = r / c.tslots;
+                    int ph = 0;
+#pragma unroll
+                    for (int q = 1; q < NPH; ++q)
+                        if (q < g.nphase && slot >= c.tap0[q]) ph = q;
+                    const int t = slot - c.tap0[ph];
+                    V w = zero;
+                    if (t < g.phase[ph].ntap && n0 + n < g.N)
+                        w = *reinterpret_cast<const V*>(Wg + g.phase[ph].w_off + ((int64_t)(n0 + n) * g.phase[ph].ntap + t) * g.Cin + c0 + 8 * v);
+                    *reinterpret_cast<V*>(wl + n * LDW + slot * CC + 8 * v) = w;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- every phase x k step out of LDS ---------------------------------------------------------------------------------
+#pragma unroll
+        for (int ph = 0; ph < NPH; ++ph) {
+            if (ph >= g.nphase) break;
+            const sv_phase& P = g.phase[ph];
+            const int nks = c.nks[ph];
+            for (int ks = 0; ks < nks; ++ks) {
+                // tap(s) of this k step: the LDS address offset of the tap shift (a pad slot repeats tap 0: its weights are zero)
+                int sh;
+                {
+                    const int ta = ks * TPK < P.ntap ? ks * TPK : 0;
+                    const int sha = ((P.dy[ta] - c.dymin) * c.LW + (P.dx[ta] - c.dxmin)) * LDC;
+                    sh = sha;
+                    if (TPK == 2) {
+                        const int tb = ks * TPK + 1 < P.ntap ? ks * TPK + 1 : 0;
+                        const int shb = ((P.dy[tb] - c.dymin) * c.LW + (P.dx[tb] - c.dxmin)) * LDC;
+                        sh = (fq >> 1) ? shb : sha;
+                    }
+                }
+                const V af0 = *reinterpret_cast<const V*>(halo + hbase[0] + sh);
+                const V af1 = *reinterpret_cast<const V*>(halo + hbase[1] + sh);
+                const T* wrow = wl + (c.tap0[ph] + ks * TPK) * CC + 8 * fq;
+#pragma unroll
+                for (int i = 0; i < NT; ++i) {
+                    const V wf = *reinterpret_cast<const V*>(wrow + (16 * i + fr) * LDW);
+                    mma32(acc[ph][i][0], wf, af0);
+                    mma32(acc[ph][i][1], wf, af1);
+                }
+            }
+        }
+    }
+
+    // ---- epilogue: every phase's outputs, per-channel sums kept in registers and flushed once ------------------------------
+    float s1[NT][4], s2[NT][4];
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s1[i][r] = s2[i][r] = 0.f;
+    f32x4 bias[NT], esc[NT], esh[NT], emu[NT], ers[NT];
+    bool nval[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        const int n = n0 + 16 * i + 4 * fq;
+        nval[i] = n < g.N;
+        const int nc = nval[i] ? n : 0;
+        bias[i] = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + nc) : f32x4{0.f, 0.f, 0.f, 0.f};
+        if (EX) {
+            esc[i] = *reinterpret_cast<const f32x4*>(a.ex_scale + nc);
+            esh[i] = *reinterpret_cast<const f32x4*>(a.ex_shift + nc);
+            emu[i] = *reinterpret_cast<const f32x4*>(a.ex_mean + nc);
+            ers[i] = *reinterpret_cast<const f32x4*>(a.ex_rstd + nc);
+        }
+    }
+#pragma unroll
+    for (int ph = 0; ph < NPH; ++ph) {
+        if (ph >= g.nphase) break;
+        const sv_phase& P = g.phase[ph];
+#pragma unroll
+        for (int ms = 0; ms < 2; ++ms) {
+            const int grow = R0 + prow[ms];
+            if (grow >= BHq) continue;
+            const int b = grow >> c.hlog, qy = grow & (Hq - 1);
+            const int64_t ob = ((int64_t)(b * g.Hout + qy * g.osy + P.ooy) * g.Wout + pcol[ms] * g.osx + P.oox) * g.ldo;
+#pragma unroll
+            for (int i = 0; i < NT; ++i) {
+                if (!nval[i]) continue;
+                const int n = n0 + 16 * i + 4 * fq;
+                f32x4 vv = acc[ph][i][ms];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) vv[r] += bias[i][r];
+                if (R) {
+                    const Q rr = *reinterpret_cast<const Q*>(R + ob + n);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) vv[r] += to_f(rr[r]);
+                }
+                if (EX) {
+                    const Q xe = *reinterpret_cast<const Q*>(EX + ob + n);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float xf = to_f(xe[r]);
+                        const float gv = vv[r] * act_grad(xf * esc[i][r] + esh[i][r], a.ex_slope);
+                        vv[r] = gv;
+                        s1[i][r] += gv;
+                        s2[i][r] += gv * ((xf - emu[i][r]) * ers[i][r]);
+                    }
+                } else if (a.stats) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        s1[i][r] += vv[r];
+                        s2[i][r] += vv[r] * vv[r];
+                    }
+                }
+                Q o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = (T)vv[r];
+                *reinterpret_cast<Q*>(O + ob + n) = o;
+            }
+        }
+    }
+    if (want_sums) {
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) {
+                    s1[i][r] += __shfl_xor(s1[i][r], o);
+                    s2[i][r] += __shfl_xor(s2[i][r], o);
+                }
+                if (fr == 0 && nval[i]) {
+                    atomicAdd(&ssum[16 * i + 4 * fq + r], s1[i][r]);
+                    atomicAdd(&ssum[BN + 16 * i + 4 * fq + r], s2[i][r]);
+                }
+            }
+        }
+        __syncthreads();
+        float* dst = (EX ? a.bsums : a.stats) + (size_t)(blockIdx.x & (a.replicas - 1)) * 2 * g.N;
+        if (tid < 2 * BN) {
+            const int which = tid / BN, nl = tid - which * BN;
+            if (n0 + nl < g.N) atomicAdd(dst + which * g.N + n0 + nl, ssum[tid]);
+        }
+    }
+}
+
+int ilog2x(int v) {
+    int l = 0;
+    while ((1 << l) < v) ++l;
+    return (1 << l) == v ? l : -1;
+}
+
+template <typename T, int NT, int CC, int NPH>
+int launch_halo(const sv_geom* g, const sv_igemm_args* a, const halo_cfg& c, hipStream_t s) {
+    constexpr int BN = 16 * NT;
+    const int nT = (g->B * g->Hq + c.TR - 1) / c.TR;
+    const int nNt = (g->N + BN - 1) / BN;
+    const int grid = (nT >= 64 ? ((nT + 7) / 8) * 8 : nT) * nNt;
+    const size_t lds = ((size_t)c.HP * (CC + 16) + (size_t)BN * (c.tslots * CC + 16)) * sizeof(T) + 2 * BN * sizeof(float);
+    static bool optin = false;
+    if (lds > 64 * 1024 && !optin) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&halo_kernel<T, NT, CC, NPH>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return sv_check_launch("hipFuncSetAttribute(halo)");
+        optin = true;
+    }
+    sv_prof_begin(s);
+    hipLaunchKernelGGL((halo_kernel<T, NT, CC, NPH>), dim3(grid, sv_ngroups(a->groups)), dim3(256), lds, s, *g,
+                       sv_expand_groups(*g, *a, (int)sizeof(T)), c);
+    sv_prof_end(s);
+    return sv_check_launch("sv_igemm(halo)");
+}
+
+template <typename T, int CC, int NPH>
+int launch_halo_nt(const sv_geom* g, const sv_igemm_args* a, const halo_cfg& c, int nt, hipStream_t s) {
+    return nt == 2 ? launch_halo<T, 2, CC, NPH>(g, a, c, s) : launch_halo<T, 1, CC, NPH>(g, a, c, s);
+}
+
+}  // namespace
+
+// Returns 1 and sets *rc when the geometry is covered: square power-of-two grids, taps within a small window, the
+// tile's LDS image within budget.
+int sv_halo_try(const sv_geom* g, int dtype, const sv_igemm_args* a, hipStream_t s, int* rc) {
+    if (sv_disabled(SV_K_HALO)) return 0;
+    if (g->Hq != g->Wq || g->Hin != g->Win || g->sy != g->sx || g->osy != g->osx) return 0;
+    if (g->sy < 1 || g->sy > 2) return 0;
+    halo_cfg c;
+    c.wlog = ilog2x(g->Wq);
+    c.hlog = ilog2x(g->Hq);
+    if (c.wlog < 1 || c.wlog > 5) return 0;              // 2 .. 32 columns (1 x 1 maps are plain GEMMs: igemm.hip)
+    if (g->Cin % 16 != 0 || g->N % 16 != 0 || g->ldx != g->Cin) return 0;
+    if (g->Cin % 32 != 0 && g->Cin != 16) return 0;
+    if (g->nphase < 1 || g->nphase > SV_MAX_PHASES) return 0;
+    int dymin = 127, dymax = -127, dxmin = 127, dxmax = -127, ttot = 0;
+    for (int p = 0; p < g->nphase; ++p)
+        for (int t = 0; t < g->phase[p].ntap; ++t) {
+            const int dy = g->phase[p].dy[t], dx = g->phase[p].dx[t];
+            dymin = dy < dymin ? dy : dymin; dymax = dy > dymax ? dy : dymax;
+            dxmin = dx < dxmin ? dx : dxmin; dxmax = dx > dxmax ? dx : dxmax;
+            ++ttot;
+        }
+    if (ttot == 0) return 0;
+    if (dymax - dymin > 3 || dxmax - dxmin > 3) return 0;
+    const int CC = g->Cin == 16 ? 16 : 32, TPK = 32 / CC;
+    const int Wq = g->Wq, Hq = g->Hq;
+    c.TR = 128 / Wq;
+    const int HH = c.TR < Hq ? c.TR : Hq;
+    c.hhlog = ilog2x(HH);
+    c.SEG = c.TR / HH;
+    c.SR = g->sy * (HH - 1) + (dymax - dymin) + 1;
+    c.LW = g->sx * (Wq - 1) + (dxmax - dxmin) + 1;
+    c.dymin = dymin;
+    c.dxmin = dxmin;
+    c.HP = c.SEG * c.SR * c.LW;
+    int slots = 0;
+    for (int p = 0; p < SV_MAX_PHASES; ++p) {
+        c.tap0[p] = slots;
+        c.nks[p] = 0;
+        if (p < g->nphase) {
+            c.nks[p] = (g->phase[p].ntap + TPK - 1) / TPK;
+            slots += c.nks[p] * TPK;
+        }
+    }
+    c.tslots = slots;
+    const int es = dtype == SV_BF16 ? 2 : 4;
+    const int nt = (g->N % 32 == 0) ? 2 : 1, BN = 16 * nt;
+    if (c.HP * (CC / 8) > 256 * HMAXV) return 0;
+    if (BN * c.tslots * (CC / 8) > 256 * HMAXW) return 0;
+    const size_t lds = ((size_t)c.HP * (CC + 16) + (size_t)BN * (c.tslots * CC + 16)) * es + 2 * BN * 4;
+    if (lds > 100 * 1024) return 0;
+    if ((int64_t)g->B * g->Hin * g->Win * g->ldx >= ((int64_t)1 << 31)) return 0;
+    const bool multi = g->nphase > 1;
+    if (dtype == SV_BF16) {
+        if (CC == 16) *rc = multi ? launch_halo_nt<bf16, 16, 4>(g, a, c, nt, s) : launch_halo_nt<bf16, 16, 1>(g, a, c, nt, s);
+        else *rc = multi ? launch_halo_nt<bf16, 32, 4>(g, a, c, nt, s) : launch_halo_nt<bf16, 32, 1>(g, a, c, nt, s);
+    } else {
+        if (CC == 16) *rc = multi ? launch_halo_nt<float, 16, 4>(g, a, c, nt, s) : launch_halo_nt<float, 16, 1>(g, a, c, nt, s);
+        else *rc = multi ? launch_halo_nt<float, 32, 4>(g, a, c, nt, s) : launch_halo_nt<float, 32, 1>(g, a, c, nt, s);
+    }
+    return 1;
+}

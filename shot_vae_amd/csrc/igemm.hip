@@ -278,6 +278,8 @@ extern "C" int sv_igemm(const sv_geom* g, int dtype, const sv_igemm_args* a, voi
     {   // stride-1 3x3 convolutions take the LDS-halo kernels (conv3x3*.hip) unless switched off (tests: generic vs special)
         int rc = 0;
         if (!sv_disabled(SV_K_CONV3X3) && sv_conv3x3_try(g, dtype, a, s, &rc)) return rc;
+        // the other conv-like layers with a spatial extent: LDS-halo gather-GEMM over all phases / taps (halo.hip)
+        if (sv_halo_try(g, dtype, a, s, &rc)) return rc;
     }
     const int64_t M = (int64_t)g->B * g->Hq * g->Wq;
     const int64_t mtiles = (M + BM - 1) / BM * g->nphase;
