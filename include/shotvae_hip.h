@@ -260,8 +260,12 @@ int sv_debug_conv_chunk_program(int* items, int* waits);
  * wgrad3x3w -> wgrad3x3 -> the generic weight-gradient kernel).  Default 0.  The parity tests use it to compare every
  * specialised kernel with the general one on the same inputs (conv3x3x against conv3x3w bit for bit).
  * SV_OPT_WIDE_MIN_BLOCKS: minimum grid (blocks) for which the 256-pixel wide-tile kernels are chosen; default 256 (one
- * block per CU).  Tests set 1 to reach those kernels at small batch sizes.                                          */
-enum { SV_OPT_DISABLE_MASK = 0, SV_OPT_WIDE_MIN_BLOCKS = 1 };
+ * block per CU).  Tests set 1 to reach those kernels at small batch sizes.
+ * SV_OPT_HALO_ALL: 1 = the LDS-halo gather-GEMM (halo.hip) takes every geometry it covers, not only the layers it is
+ * faster on (tests: the kernel's whole range against the references).  Default 0.
+ * SV_OPT_PERSISTENT_BLOCKS: block budget of the persistent narrow 3x3 kernels (conv3x3p, wgrad3x3), shared among the
+ * groups of a batched launch.  Default 512 (two blocks per CU); tools/tune_blocks.py sweeps it.                       */
+enum { SV_OPT_DISABLE_MASK = 0, SV_OPT_WIDE_MIN_BLOCKS = 1, SV_OPT_HALO_ALL = 2, SV_OPT_PERSISTENT_BLOCKS = 3 };
 enum { SV_K_CONV3X3 = 1, SV_K_CONV3X3P = 2, SV_K_CONV3X3M = 4, SV_K_CONV3X3W = 8, SV_K_CONV3X3X = 16,
        SV_K_WGRAD3X3 = 32, SV_K_WGRAD3X3W = 64, SV_K_IGEMM_KV2 = 128, SV_K_HALO = 256 };
 int sv_set_option(int key, int value);

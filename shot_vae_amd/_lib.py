@@ -86,7 +86,7 @@ _PROTOS = {
     "sv_get_option": [I],
     "sv_version": [],
 }
-OPT_DISABLE_MASK, OPT_WIDE_MIN_BLOCKS = 0, 1
+OPT_DISABLE_MASK, OPT_WIDE_MIN_BLOCKS, OPT_HALO_ALL, OPT_PERSISTENT_BLOCKS = 0, 1, 2, 3
 K_CONV3X3, K_CONV3X3P, K_CONV3X3M, K_CONV3X3W, K_CONV3X3X, K_WGRAD3X3, K_WGRAD3X3W, K_IGEMM_KV2, K_HALO = (
     1, 2, 4, 8, 16, 32, 64, 128, 256)
 EXPORTS = sorted(list(_PROTOS) + ["sv_last_error"])
@@ -132,8 +132,9 @@ class options:
     """with options(disable=K_CONV3X3X, wide_min_blocks=1): ...  -- dispatcher options for the duration of a block
     (tests / tools: compare a specialised kernel with the general one)."""
 
-    def __init__(self, disable=None, wide_min_blocks=None):
-        self.new = {OPT_DISABLE_MASK: disable, OPT_WIDE_MIN_BLOCKS: wide_min_blocks}
+    def __init__(self, disable=None, wide_min_blocks=None, halo_all=None, persistent_blocks=None):
+        self.new = {OPT_DISABLE_MASK: disable, OPT_WIDE_MIN_BLOCKS: wide_min_blocks, OPT_HALO_ALL: halo_all,
+                    OPT_PERSISTENT_BLOCKS: persistent_blocks}
 
     def __enter__(self):
         self.old = {k: lib().sv_get_option(k) for k in self.new}

@@ -104,7 +104,9 @@ inline sv_wg_g<P> sv_expand_wg(const sv_geom& g, const P& p, int groups, int es)
 // host side ------------------------------------------------------------------------------------------
 void sv_set_error(const char* fmt, ...);
 bool sv_disabled(int kernel_bit);        // sv_set_option(SV_OPT_DISABLE_MASK, ...): a specialised kernel is switched off
-int sv_wide_min_blocks();                // sv_set_option(SV_OPT_WIDE_MIN_BLOCKS, ...)
+int sv_wide_min_blocks();
+bool sv_halo_all();
+int sv_persistent_blocks();            // sv_set_option(SV_OPT_PERSISTENT_BLOCKS, ...): block budget of the persistent 3x3 kernels                      // sv_set_option(SV_OPT_HALO_ALL, ...)                // sv_set_option(SV_OPT_WIDE_MIN_BLOCKS, ...)
 int sv_check_launch(const char* what);
 void sv_prof_begin(hipStream_t s);
 void sv_prof_end(hipStream_t s);

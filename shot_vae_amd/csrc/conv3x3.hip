@@ -753,7 +753,8 @@ int launch_p(const sv_geom* g, const sv_igemm_args* a, hipStream_t s) {
     const int nT = g->B * g->Hin / TR;
     const int nNt = g->N / 32;
     // persistent blocks (two per CU): fewer / more measured slower; a batched launch shares them among its groups
-    const int target = 512 / sv_ngroups(a->groups) > 64 ? 512 / sv_ngroups(a->groups) : 64;
+    const int budget = sv_persistent_blocks();
+    const int target = budget / sv_ngroups(a->groups) > 64 ? budget / sv_ngroups(a->groups) : 64;
     int chunks = (target + nNt - 1) / nNt;
     if (chunks > nT) chunks = nT;
     const int tiles_per = (nT + chunks - 1) / chunks;

@@ -342,6 +342,12 @@ int launch_halo_nt(const sv_geom* g, const sv_igemm_args* a, const halo_cfg& c, 
 // tile's LDS image within budget.
 int sv_halo_try(const sv_geom* g, int dtype, const sv_igemm_args* a, hipStream_t s, int* rc) {
     if (sv_disabled(SV_K_HALO)) return 0;
+    // Measured against the generic gather-GEMM on the WRN-28-2 / decoder shapes at 4 x 512 images (profiles/r02_*): this
+    // one-tile-per-block version wins where a phase has few output channels and the staging is small -- the last two
+    // ConvTranspose layers forward (207 -> 125 us, 181 -> 153 us) -- and loses elsewhere (two blocks per CU of 60-90 KB LDS
+    // and no overlap of staging and MFMA: 32 -> 64 stride-2 forward 112 -> 214 us).  Until it is persistent and
+    // software-pipelined like conv3x3p it only takes the former; SV_OPT_HALO_ALL = 1 takes everything it covers (tests).
+    if (!sv_halo_all() && !(g->nphase == 4 && g->sy == 1 && g->N <= 64 && g->Cin <= 128 && g->Wq >= 8)) return 0;
     if (g->Hq != g->Wq || g->Hin != g->Win || g->sy != g->sx || g->osy != g->osx) return 0;
     if (g->sy < 1 || g->sy > 2) return 0;
     halo_cfg c;

@@ -28,7 +28,11 @@ int sv_check_launch(const char* what) {
 namespace {
 int g_disable_mask = 0;
 int g_wide_min_blocks = 256;
+int g_halo_all = 0;
+int g_persistent_blocks = 512;
 }  // namespace
+int sv_persistent_blocks() { return g_persistent_blocks; }
+bool sv_halo_all() { return g_halo_all != 0; }
 bool sv_disabled(int kernel_bit) { return (g_disable_mask & kernel_bit) != 0; }
 int sv_wide_min_blocks() { return g_wide_min_blocks; }
 
@@ -94,6 +98,11 @@ int sv_set_option(int key, int value) {
             SV_REQUIRE(value >= 1, SV_E_ARG, "sv_set_option: SV_OPT_WIDE_MIN_BLOCKS=%d", value);
             g_wide_min_blocks = value;
             return SV_OK;
+        case SV_OPT_HALO_ALL: g_halo_all = value; return SV_OK;
+        case SV_OPT_PERSISTENT_BLOCKS:
+            SV_REQUIRE(value >= 8, SV_E_ARG, "sv_set_option: SV_OPT_PERSISTENT_BLOCKS=%d", value);
+            g_persistent_blocks = value;
+            return SV_OK;
     }
     sv_set_error("sv_set_option: unknown key %d", key);
     return SV_E_ARG;
@@ -103,6 +112,8 @@ int sv_get_option(int key) {
     switch (key) {
         case SV_OPT_DISABLE_MASK: return g_disable_mask;
         case SV_OPT_WIDE_MIN_BLOCKS: return g_wide_min_blocks;
+        case SV_OPT_HALO_ALL: return g_halo_all;
+        case SV_OPT_PERSISTENT_BLOCKS: return g_persistent_blocks;
     }
     return -1;
 }

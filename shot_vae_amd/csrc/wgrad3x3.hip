@@ -921,7 +921,8 @@ int sv_wgrad3x3_try(const sv_geom* g, int dtype, const void* x, const float* pro
     }
     const int nNC = (g->N / 32) * (g->Cin / 32);
     // ~two persistent blocks per CU; every block should still see a few tiles
-    const int target = 512 / groups > 32 ? 512 / groups : 32;
+    const int budget = sv_persistent_blocks();
+    const int target = budget / groups > 32 ? budget / groups : 32;
     int splits = (target + nNC - 1) / nNC;
     if (splits > nT) splits = nT;
     if (splits >= 8) splits = splits / 8 * 8;

@@ -726,3 +726,22 @@ def test_repack_batch_equals_per_layer_repack():
     torch.cuda.synchronize()
     assert torch.equal(ref.view(torch.int16), eng.packs.view(torch.int16))
     assert float(eng.packs.float().abs().sum()) > 0
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("case", [c for c in CONV_CASES if not (c[4] == 3 and c[5] == 1 and c[1] % 32 == 0 and c[2] % 32 == 0)])
+def test_halo_kernel_conv_cases(dt, case):
+    """halo.hip over its whole range (SV_OPT_HALO_ALL): stride-2 3x3, 1x1 (both strides), the 16-channel layers -- forward
+    with every fusion and the data gradient with the activation-backward epilogue, against torch."""
+    with L.options(halo_all=1):
+        test_conv_forward_fused(dt, case)
+        test_conv_dgrad_with_activation_backward(dt, case)
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("H,Cin,N,B", [(2, 512, 256, 4), (4, 256, 128, 4), (8, 128, 64, 3), (16, 64, 16, 2)])
+def test_halo_kernel_convT_cases(dt, H, Cin, N, B):
+    """... and the ConvTranspose2d(4, 2, 1) decoder layers (four sub-pixel phases in one block) with their data gradients
+    (4x4 stride-2 convolutions)."""
+    with L.options(halo_all=1):
+        test_convT_forward_and_dgrad(dt, H, Cin, N, B)
