@@ -58,7 +58,7 @@ __device__ __forceinline__ bf16x8 frag_tr(const bf16* S, int pix_elem_q, int col
 // nine taps (9 accumulator tiles) and reduces over ALL 128 pixels of every staged tile, so no cross-wave
 // reduction is needed (LDS float atomics are far too slow for that: 92 us of a 140 us kernel).
 template <typename T, int WLOG>
-__global__ __launch_bounds__(256) void wgrad3x3_kernel(const sv_geom g, const sv_wg_g<wg3_params> PG) {
+__global__ __launch_bounds__(256, 2) void wgrad3x3_kernel(const sv_geom g, const sv_wg_g<wg3_params> PG) {
     const wg3_params& p = PG.g[blockIdx.y];
     typedef typename V8<T>::type V;
 #ifdef SV_WG3_STAMP
@@ -141,35 +141,38 @@ __global__ __launch_bounds__(256) void wgrad3x3_kernel(const sv_geom g, const sv
     for (int i = 0; i < YI; ++i) yoff[i] = (uint32_t)(((tid >> 2) + 64 * i) * g.ldo + n0 + 8 * v) * (uint32_t)sizeof(T);
     const uint32_t hsafe = (uint32_t)(W * g.ldx + c0 + 8 * v) * (uint32_t)sizeof(T);
 
-    V ry[YI], rh[HI];
-    bool hok[HI];
-    auto load_tile = [&](int tile) {
+    // TWO register stages: the operands of tile i + 2 are requested while tile i is on the MFMAs, so every request has two
+    // whole tile periods to arrive (at two blocks per CU -- 208 registers -- one tile period does not cover the HBM
+    // latency: the loop was latency-bound at 2.3 TB/s of algorithmic traffic with one stage)
+    struct Stage { V ry[YI], rh[HI]; bool hok[HI]; };
+    Stage SA, SB;
+    auto load_tile = [&](Stage& S, int tile) {
         const int gr0 = tile * TR;
         const bool top_ok = (gr0 & (H - 1)) != 0, bot_ok = ((gr0 + TR) & (H - 1)) != 0;
         const char* ybase = reinterpret_cast<const char*>(DY + (int64_t)gr0 * W * g.ldo);
         const char* hbase = reinterpret_cast<const char*>(X) + ((int64_t)gr0 - 1) * W * g.ldx * (int64_t)sizeof(T);
 #pragma unroll
-        for (int i = 0; i < YI; ++i) ry[i] = *reinterpret_cast<const V*>(ybase + yoff[i]);   // tile pixel (tid>>2) + 64 i
+        for (int i = 0; i < YI; ++i) S.ry[i] = *reinterpret_cast<const V*>(ybase + yoff[i]);   // tile pixel (tid>>2) + 64 i
 #pragma unroll
         for (int i = 0; i < HI; ++i) {
-            hok[i] = hkind[i] == 1 || (hkind[i] == 2 && top_ok) || (hkind[i] == 3 && bot_ok);
-            rh[i] = *reinterpret_cast<const V*>(hbase + (hok[i] ? hoff[i] : hsafe));
+            S.hok[i] = hkind[i] == 1 || (hkind[i] == 2 && top_ok) || (hkind[i] == 3 && bot_ok);
+            S.rh[i] = *reinterpret_cast<const V*>(hbase + (S.hok[i] ? hoff[i] : hsafe));
         }
     };
-    auto store_tile = [&]() {
+    auto store_tile = [&](Stage& S) {
 #pragma unroll
         for (int i = 0; i < YI; ++i)
-            *reinterpret_cast<V*>(Ys + ((tid >> 2) + 64 * i) * LDH + 8 * v) = ry[i];
+            *reinterpret_cast<V*>(Ys + ((tid >> 2) + 64 * i) * LDH + 8 * v) = S.ry[i];
 #pragma unroll
         for (int i = 0; i < HI; ++i) {
             V o = zero;
-            if (hok[i]) {
-                o = rh[i];
+            if (S.hok[i]) {
+                o = S.rh[i];
                 if (has_pro) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        o[j] = (T)act_fwd(to_f(rh[i][j]) * s0[j] + t0[j], p.pro_slope);
-                        o[j + 4] = (T)act_fwd(to_f(rh[i][j + 4]) * s1[j] + t1[j], p.pro_slope);
+                        o[j] = (T)act_fwd(to_f(S.rh[i][j]) * s0[j] + t0[j], p.pro_slope);
+                        o[j + 4] = (T)act_fwd(to_f(S.rh[i][j + 4]) * s1[j] + t1[j], p.pro_slope);
                     }
                 }
             }
@@ -194,17 +197,19 @@ __global__ __launch_bounds__(256) void wgrad3x3_kernel(const sv_geom g, const sv
 #else
 #define WG3_STAMP(acc_)
 #endif
-    if (t_begin < t_end) load_tile(t_begin);
-    for (int tile = t_begin; tile < t_end; ++tile) {
+    if (t_begin < t_end) load_tile(SA, t_begin);
+    if (t_begin + 1 < t_end) load_tile(SB, t_begin + 1);
+    // one tile of the pipeline: CUR holds this tile (requested two tiles ago), and is re-loaded with tile + 2 once stored
+    auto do_tile = [&](int tile, Stage& CUR) {
 #ifdef SV_WG3_STAMP
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         WG3_STAMP(st_wait)
 #endif
-        store_tile();
+        store_tile(CUR);
         WG3_STAMP(st_store)
         __syncthreads();
         WG3_STAMP(st_bar)
-        if (tile + 1 < t_end) load_tile(tile + 1);        // in flight while this tile is on the MFMAs
+        if (tile + 2 < t_end) load_tile(CUR, tile + 2);   // in flight during this tile's and the next tile's MFMAs
         WG3_STAMP(st_ld)
         if (sizeof(T) == 2) {
             const bf16* Yb = reinterpret_cast<const bf16*>(Ys);
@@ -264,6 +269,10 @@ __global__ __launch_bounds__(256) void wgrad3x3_kernel(const sv_geom g, const sv
         WG3_STAMP(st_mma)
         __syncthreads();          // everyone is done reading before the next tile overwrites LDS
         WG3_STAMP(st_bar2)
+    };
+    for (int tile = t_begin; tile < t_end; tile += 2) {
+        do_tile(tile, SA);
+        if (tile + 1 < t_end) do_tile(tile + 1, SB);
     }
 #ifdef SV_WG3_STAMP
     if (tid == 0 && p.ws) {     // diagnostic build: per-block cycle shares into the tail of the caller's workspace
