@@ -57,7 +57,7 @@ __device__ __forceinline__ bf16x8 frag_tr(const bf16* S, int pix_elem_q, int col
 // Block = 32(n) x 32(c) slab of dW, all nine taps.  Wave w owns the 16x16 sub-block (w>>1, w&1) for all
 // nine taps (9 accumulator tiles) and reduces over ALL 128 pixels of every staged tile, so no cross-wave
 // reduction is needed (LDS float atomics are far too slow for that: 92 us of a 140 us kernel).
-template <typename T, int WLOG>
+template <typename T, int WLOG, int STAGES>
 __global__ __launch_bounds__(256, 2) void wgrad3x3_kernel(const sv_geom g, const sv_wg_g<wg3_params> PG) {
     const wg3_params& p = PG.g[blockIdx.y];
     typedef typename V8<T>::type V;
@@ -141,9 +141,10 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_kernel(const sv_geom g, const
     for (int i = 0; i < YI; ++i) yoff[i] = (uint32_t)(((tid >> 2) + 64 * i) * g.ldo + n0 + 8 * v) * (uint32_t)sizeof(T);
     const uint32_t hsafe = (uint32_t)(W * g.ldx + c0 + 8 * v) * (uint32_t)sizeof(T);
 
-    // TWO register stages: the operands of tile i + 2 are requested while tile i is on the MFMAs, so every request has two
-    // whole tile periods to arrive (at two blocks per CU -- 208 registers -- one tile period does not cover the HBM
-    // latency: the loop was latency-bound at 2.3 TB/s of algorithmic traffic with one stage)
+    // STAGES = 2: two register stages -- the operands of tile i + 2 are requested while tile i is on the MFMAs, so every
+    // request has two whole tile periods to arrive (at two blocks per CU one tile period does not cover the HBM latency:
+    // the 32-channel layer at 4 x 512 images 119 -> 87 us, 64 channels 91 -> 81 us).  STAGES = 1 (requests one tile ahead)
+    // for the 128-channel layer, whose operands are re-read by 16 blocks and come from L2 (74 us; 82 us with two stages)
     struct Stage { V ry[YI], rh[HI]; bool hok[HI]; };
     Stage SA, SB;
     auto load_tile = [&](Stage& S, int tile) {
@@ -198,7 +199,7 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_kernel(const sv_geom g, const
 #define WG3_STAMP(acc_)
 #endif
     if (t_begin < t_end) load_tile(SA, t_begin);
-    if (t_begin + 1 < t_end) load_tile(SB, t_begin + 1);
+    if (STAGES == 2 && t_begin + 1 < t_end) load_tile(SB, t_begin + 1);
     // one tile of the pipeline: CUR holds this tile (requested two tiles ago), and is re-loaded with tile + 2 once stored
     auto do_tile = [&](int tile, Stage& CUR) {
 #ifdef SV_WG3_STAMP
@@ -209,7 +210,7 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_kernel(const sv_geom g, const
         WG3_STAMP(st_store)
         __syncthreads();
         WG3_STAMP(st_bar)
-        if (tile + 2 < t_end) load_tile(CUR, tile + 2);   // in flight during this tile's and the next tile's MFMAs
+        if (tile + STAGES < t_end) load_tile(CUR, tile + STAGES);   // in flight during this (and the next) tile's MFMAs
         WG3_STAMP(st_ld)
         if (sizeof(T) == 2) {
             const bf16* Yb = reinterpret_cast<const bf16*>(Ys);
@@ -270,9 +271,13 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_kernel(const sv_geom g, const
         __syncthreads();          // everyone is done reading before the next tile overwrites LDS
         WG3_STAMP(st_bar2)
     };
-    for (int tile = t_begin; tile < t_end; tile += 2) {
-        do_tile(tile, SA);
-        if (tile + 1 < t_end) do_tile(tile + 1, SB);
+    if (STAGES == 2) {
+        for (int tile = t_begin; tile < t_end; tile += 2) {
+            do_tile(tile, SA);
+            if (tile + 1 < t_end) do_tile(tile + 1, SB);
+        }
+    } else {
+        for (int tile = t_begin; tile < t_end; ++tile) do_tile(tile, SA);
     }
 #ifdef SV_WG3_STAMP
     if (tid == 0 && p.ws) {     // diagnostic build: per-block cycle shares into the tail of the caller's workspace
@@ -830,7 +835,10 @@ int launch(const sv_geom* g, const wg3_params& p, hipStream_t s) {
     constexpr int HHn = (TR < W) ? TR : W, LROWSn = TR + TR / HHn + 1;
     const size_t lds = (size_t)(128 + LROWSn * (W + 2)) * LDH * sizeof(T);
     sv_prof_begin(s);
-    hipLaunchKernelGGL((wgrad3x3_kernel<T, WLOG>), dim3(grid, p.groups), dim3(256), lds, s, *g, sv_expand_wg(*g, p, p.groups, (int)sizeof(T)));
+    if (sizeof(T) == 2 && g->N * g->Cin <= 64 * 64)
+        hipLaunchKernelGGL((wgrad3x3_kernel<T, WLOG, 2>), dim3(grid, p.groups), dim3(256), lds, s, *g, sv_expand_wg(*g, p, p.groups, (int)sizeof(T)));
+    else
+        hipLaunchKernelGGL((wgrad3x3_kernel<T, WLOG, 1>), dim3(grid, p.groups), dim3(256), lds, s, *g, sv_expand_wg(*g, p, p.groups, (int)sizeof(T)));
     sv_prof_end(s);               // the event bracket times the main kernel only (comparable with rocprofv3)
     if (p.ws) {
         const int64_t n = (int64_t)g->N * g->T_orig * g->Cin;      // multiple of 4 (Cin % 32 == 0)
