@@ -413,7 +413,10 @@ __device__ __forceinline__ bf16x8 frag_tr_ld(const bf16* S, int pix_elem_q, int 
 
 template <int WLOG>
 __global__ __launch_bounds__(256, 1) void wgrad3x3w_kernel(const sv_geom g, const sv_wg_g<wg3_params> PG) {
-    const wg3_params& p = PG.g[blockIdx.y];
+    // (a batched launch: the groups are an INNER loop of every block here, not a grid dimension -- a block accumulates its
+    //  slab over its tile range of every group and publishes ONE slab: with 15-59 MB slabs a slab per (group, split) is
+    //  what the workspace and the reduction cannot afford; measured 745 us for the four groups of the 640-channel layer)
+    const wg3_params& p = PG.g[0];
     constexpr int W = 1 << WLOG, TR = 128 / W, WP = W + 2;
     // LDS halo rows: row 0 / the last row are the vertical halo, and when a tile holds several whole images (W = 8:
     // TR = 16 > H = 8) a zero spacer row separates them -- zero padding is DATA in LDS, the nine taps need no masks
@@ -457,8 +460,8 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3w_kernel(const sv_geom g, cons
     const int t_begin = split * p.tiles_per, t_end = min(nT, t_begin + p.tiles_per);
     const sv_phase& P = g.phase[0];
     const uint64_t pdy = pack_taps(P.dy), pdx = pack_taps(P.dx);
-    const bf16* __restrict__ X = reinterpret_cast<const bf16*>(p.x);
-    const bf16* __restrict__ DY = reinterpret_cast<const bf16*>(p.dy);
+    const bf16* X = reinterpret_cast<const bf16*>(p.x);            // (of the current group)
+    const bf16* DY = reinterpret_cast<const bf16*>(p.dy);
     const bool has_pro = p.pro_scale != nullptr;
 
     bf16x8 zero;
@@ -690,6 +693,29 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3w_kernel(const sv_geom g, cons
     const uint64_t st_begin = __builtin_amdgcn_s_memtime();
     uint64_t st_p0 = 0, st_p1 = 0, st_p2 = 0, st_p3 = 0, st_bar = 0, st_last = 0;
 #endif
+    int cur = 0;
+    for (int gi = 0; gi < p.groups; ++gi) {
+    if (gi > 0) {
+        // next group of a batched launch: its tensors and BatchNorm coefficients; the pipeline restarts from stage 0
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the last (redundant) requests of the previous group
+        __syncthreads();                                        // nobody reads the stages any more
+        const wg3_params& pg = PG.g[gi];
+        X = reinterpret_cast<const bf16*>(pg.x);
+        DY = reinterpret_cast<const bf16*>(pg.dy);
+        if (has_pro) {
+            s0 = *reinterpret_cast<const f32x4*>(pg.pro_scale + c0 + 8 * v);
+            s1 = *reinterpret_cast<const f32x4*>(pg.pro_scale + c0 + 8 * v + 4);
+            t0 = *reinterpret_cast<const f32x4*>(pg.pro_shift + c0 + 8 * v);
+            t1 = *reinterpret_cast<const f32x4*>(pg.pro_shift + c0 + 8 * v + 4);
+        }
+        if (cur) {                                              // fragment addresses back to stage 0
+            const uint32_t flip = (uint32_t)(-(BUF * 2));
+            yaddr += flip;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) xaddr[t] += flip;
+            cur = 0;
+        }
+    }
     // prologue: tile t_begin into stage 0; then the state the steady loop expects -- the halo of the second tile in rh,
     // D0..D3 of its dy DMA on their way into stage 1 -- and the first fragments
     halo_bases(t_begin);
@@ -711,7 +737,6 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3w_kernel(const sv_geom g, cons
 #ifdef SV_WG3_STAMP
     st_last = __builtin_amdgcn_s_memtime();
 #endif
-    int cur = 0;
     for (int tile = t_begin; tile < t_end; ++tile) {
         bf16* cur_stage = lds0 + cur * BUF;
         bf16* other = lds0 + (cur ^ 1) * BUF;
@@ -739,6 +764,7 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3w_kernel(const sv_geom g, cons
         WG3_STAMP(st_p3)
         cur ^= 1;
     }
+    }
     asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");   // the last (redundant) DMA, before the LDS goes
                                                                             // away; the last MFMAs, before acc is read
 #ifdef SV_WG3_STAMP
@@ -751,7 +777,7 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3w_kernel(const sv_geom g, cons
 
     // ---- publish: D layout = lane holds c = c0 + 16*wj + fr, n = n0 + 80*wi + 16*a + 4*fq + r --------------------
     const int64_t slab = (int64_t)g.N * g.T_orig * g.Cin;
-    float* dst = p.ws ? p.ws + ((int64_t)blockIdx.y * p.splits + split) * slab : p.dw;
+    float* dst = p.ws ? p.ws + (int64_t)split * slab : p.dw;
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
         const int to = P.torig[t];
@@ -862,11 +888,11 @@ int launch_wide(const sv_geom* g, const wg3_params& p, hipStream_t s) {
         optin = true;
     }
     sv_prof_begin(s);
-    hipLaunchKernelGGL((wgrad3x3w_kernel<WLOG>), dim3(grid, p.groups), dim3(256), lds, s, *g, sv_expand_wg(*g, p, p.groups, 2));
+    hipLaunchKernelGGL((wgrad3x3w_kernel<WLOG>), dim3(grid), dim3(256), lds, s, *g, sv_expand_wg(*g, p, p.groups, 2));
     sv_prof_end(s);
     if (p.ws) {
         const int64_t n = (int64_t)g->N * g->T_orig * g->Cin;
-        launch_slab_reduce(p.ws, p.splits * p.groups, n, p.dw, s);
+        launch_slab_reduce(p.ws, p.splits, n, p.dw, s);
     }
     return sv_check_launch("sv_wgrad(3x3 wide)");
 }
@@ -911,13 +937,14 @@ int sv_wgrad3x3_try(const sv_geom* g, int dtype, const void* x, const float* pro
         for (int sp = 1; sp <= nT && sp <= 128; ++sp) {
             const int tp = (nT + sp - 1) / sp;
             if ((nT + tp - 1) / tp != sp) continue;               // no empty splits
-            const bool fits = sp * groups == 1 || (ws && ws_elems >= (int64_t)sp * groups * slab_elems);
+            const bool fits = sp == 1 || (ws && ws_elems >= (int64_t)sp * slab_elems);
             for (int u = 1; u <= nC && u <= 32; ++u) {
                 if (nC % u) continue;
-                const int units = sp * groups * nNt * (nC / u);
+                const int units = sp * nNt * (nC / u);
                 const int per_xcd = (units + 7) / 8 * u;
-                const double t_mma = (double)((per_xcd + 31) / 32) * (tp + 4.0) * 2.0e-6;
-                const int nsl = sp * groups;              // slabs to publish and reduce
+                // (a block walks its tile range of every group: + ~1.5 tiles per group for the pipeline restart)
+                const double t_mma = (double)((per_xcd + 31) / 32) * (groups * (tp + 1.5) + 2.5) * 2.0e-6;
+                const int nsl = sp;                       // slabs to publish and reduce
                 const double t_hbm = (groups * (dy_bytes * (nC / u) + 1.5 * x_bytes * nNt) + (nsl > 1 ? 2.0 * nsl * slab_bytes : 0.0)) / 5.0e12;
                 double cost = (t_mma > t_hbm ? t_mma : t_hbm) + (nsl > 1 ? nsl * slab_bytes / 4.0e12 : 0.0) - 1e-9 * u;
                 if (!fits) cost += 1.0;
@@ -927,8 +954,8 @@ int sv_wgrad3x3_try(const sv_geom* g, int dtype, const void* x, const float* pro
         p.splits = splits;
         p.unit = unit;
         p.tiles_per = (nT + splits - 1) / splits;
-        const int64_t needw = (int64_t)splits * groups * g->N * g->T_orig * g->Cin;
-        p.ws = (ws && ws_elems >= needw && splits * groups > 1) ? ws : nullptr;
+        const int64_t needw = (int64_t)splits * g->N * g->T_orig * g->Cin;
+        p.ws = (ws && ws_elems >= needw && splits > 1) ? ws : nullptr;
         switch (g->Win) {
             case 32: *rc = launch_wide<5>(g, p, s); break;
             case 16: *rc = launch_wide<4>(g, p, s); break;
