@@ -1,0 +1,86 @@
+"""The N > 1 code path on ONE MI355X: two ranks on the same device, torch.distributed over gloo (the collective through
+host memory) -- a functional check of the data-parallel step (bench.py's own launcher: fresh rank processes, broadcast,
+per-rank noise seeds, shared lambdas, ONE all-reduce of the flat gradient buffer, 1/world folded into the SGD kernel), not a
+measurement.  RCCL itself needs one device per rank: the driver's multi-GPU run covers it."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import os, sys, json, torch
+sys.path.insert(0, %r)
+import torch.distributed as dist
+import shot_vae_amd as S
+from shot_vae_amd import dp
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+torch.cuda.set_device(0)
+dist.init_process_group("gloo", rank=rank, world_size=world)
+torch.manual_seed(1 + 7 * rank)                 # ranks start from DIFFERENT weights: the broadcast must fix that
+K, B = 10, 16
+model = S.VariationalAutoEncoder("wideresnet-10-1", num_input_channels=3, img_size=(32, 32), data_parallel=True,
+                                 continuous_latent_dim=128, disc_latent_dim=K, small_input=True, compute_dtype="fp32",
+                                 rng="device").cuda().train()
+dp.broadcast_parameters(model)
+elbo, cls = S.VAECriterion(discrete_dim=K).cuda(), S.ClsCriterion()
+opt = S.FlatSGD(model, lr=0.05)
+opt.zero_grad()
+torch.manual_seed(100 + rank); torch.cuda.manual_seed(100 + rank)       # per-rank data shard + noise
+il, iu = torch.rand(B, 3, 32, 32, device="cuda"), torch.rand(B, 3, 32, 32, device="cuda")
+ll = torch.randint(0, K, (B,), device="cuda")
+rng = S.DeviceRng("cuda", seed=0)               # same seed everywhere: all ranks agree on the mixup lambdas
+losses = []
+for step in range(3):
+    ls, lu = S.train_step_grouped(model, elbo, cls, opt, il, ll, iu, S.schedule(10), distributed=True, device_rng=rng)
+    losses.append((float(ls), float(lu)))
+p = model._engine.param.detach().cpu()
+gathered = [torch.zeros_like(p) for _ in range(world)]
+dist.all_gather(gathered, p)
+lam = [float(rng.lam_l[i]) for i in range(3)]
+if rank == 0:
+    print(json.dumps({"max_param_diff": float((gathered[0] - gathered[1]).abs().max()), "losses": losses,
+                      "finite": bool(torch.isfinite(p).all()), "param_norm": float(p.norm()), "lam": lam}))
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+@pytest.mark.timeout(600)
+def test_two_ranks_on_one_gpu_keep_identical_parameters(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % ROOT)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(29600 + os.getpid() % 300), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=560) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[1][-1500:] for o in outs]
+    line = [ln for ln in outs[0][0].splitlines() if ln.startswith("{")][-1]
+    res = json.loads(line)
+    assert res["finite"] and res["param_norm"] > 0
+    # the ranks saw different data and noise, started from different weights, and still hold the same parameters
+    assert res["max_param_diff"] == 0.0, res
+    assert all(abs(a) < 1e3 for pair in res["losses"] for a in pair)
+
+
+@pytest.mark.timeout(900)
+def test_bench_two_ranks_gloo_on_one_gpu():
+    """bench.py --gpus 2 started WITHOUT torchrun (its own launcher), both ranks on the one GPU over gloo, strong scaling."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["SV_DIST_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--batch", "64", "--scaling", "strong", "--net", "wideresnet-10-1", "--no-cpu-baseline",
+                        "--no-roofline"], capture_output=True, text=True, env=env, timeout=850)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["value"] > 0
+    assert out["config"]["global_batch"] == 128                 # 2 loaders x 64 images in total, 32 per rank and loader
