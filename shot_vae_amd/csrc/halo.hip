@@ -304,6 +304,330 @@ __global__ __launch_bounds__(256) void halo_kernel(const sv_geom g, const sv_ige
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// PERSISTENT variant for the thin layers (Cin <= 64: the stem, the 16 -> 32 block, the 32 -> 64 stride-2 convolution, the last
+// ConvTranspose, and the data gradients of all of them): the weights of every tap of every phase and ALL input channels of
+// the halo tile are LDS-resident, so a block stages its weights ONCE and walks a contiguous range of tiles with the
+// register-prefetch pipeline of conv3x3p (conv3x3.hip): while tile i is on the MFMAs the halo of tile i + 2 is already
+// requested (two register stages), the BatchNorm sums stay in registers across tiles and are flushed once per block.
+// These layers are HBM-bound (2-4.5 flop/B x C): what matters is that every input byte is fetched once and that the
+// requests never stop.
+constexpr int PMAXV = 6;        // halo vectors per thread per register stage
+
+template <typename T, int NT, int CC, int NPH>
+__global__ __launch_bounds__(256, 2) void halop_kernel(const sv_geom g, const sv_igemm_args_g AG, const halo_cfg c, int tiles_per) {
+    typedef typename V8<T>::type V;
+    typedef typename V4<T>::type Q;
+    constexpr int BN = 16 * NT;
+    constexpr int TPK = 32 / CC;
+    const sv_igemm_args& a = AG.g[blockIdx.y];
+    const int Cin = g.Cin, VPP = Cin / 8, NCK = Cin / CC;
+    const int LDC = Cin + 16;                                   // LDS pixel stride (elements)
+    const int LDW = c.tslots * Cin + 16;                        // weight row stride (elements)
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* halo = reinterpret_cast<T*>(smem);                       // [HP][LDC]
+    T* wl = halo + c.HP * LDC;                                  // [BN][LDW]
+    float* ssum = reinterpret_cast<float*>(wl + BN * LDW);      // [2][BN]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int Wq = 1 << c.wlog, Hq = 1 << c.hlog, HH = 1 << c.hhlog;
+    const int BHq = g.B * Hq;
+    const int nT = (BHq + c.TR - 1) / c.TR;
+    const int nNt = (g.N + BN - 1) / BN;
+    int in_i, chunk;
+    if (nNt > 1 && (gridDim.x / nNt) % 8 == 0) {                // the channel tiles of a pixel range on one XCD
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        in_i = slot % nNt;
+        chunk = (slot / nNt) * 8 + xcd;
+    } else {
+        in_i = blockIdx.x % nNt;
+        chunk = blockIdx.x / nNt;
+    }
+    const int n0 = in_i * BN;
+    const int t_begin = chunk * tiles_per, t_end = min(nT, t_begin + tiles_per);
+    if (t_begin >= t_end) return;
+    const T* __restrict__ X = reinterpret_cast<const T*>(a.x);
+    const T* __restrict__ Wg = reinterpret_cast<const T*>(a.w);
+    T* __restrict__ O = reinterpret_cast<T*>(a.out);
+    const T* __restrict__ R = reinterpret_cast<const T*>(a.residual);
+    const T* __restrict__ EX = reinterpret_cast<const T*>(a.ex);
+    const bool has_pro = a.pro_scale != nullptr;
+    const bool want_sums = (a.stats != nullptr) || (EX != nullptr);
+
+    if (tid < 2 * BN) ssum[tid] = 0.f;
+    V zero;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) zero[j] = (T)0.f;
+
+    // ---- weights of every tap slot of every phase, all input channels: once per block --------------------------------------
+    {
+        const int WVn = BN * c.tslots * VPP;
+        for (int idx = tid; idx < WVn; idx += 256) {
+            const int v = idx % VPP, r = idx / VPP;
+            const int slot = r % c.tslots, n = r / c.tslots;
+            int ph = 0;
+#pragma unroll
+            for (int q = 1; q < NPH; ++q)
+                if (q < g.nphase && slot >= c.tap0[q]) ph = q;
+            const int t = slot - c.tap0[ph];
+            V w = zero;
+            if (t < g.phase[ph].ntap && n0 + n < g.N)
+                w = *reinterpret_cast<const V*>(Wg + g.phase[ph].w_off + ((int64_t)(n0 + n) * g.phase[ph].ntap + t) * Cin + 8 * v);
+            *reinterpret_cast<V*>(wl + n * LDW + slot * Cin + 8 * v) = w;
+        }
+    }
+    // ---- halo staging slots: everything that does not depend on the tile ----------------------------------------------------
+    // slot -> (LDS pixel, 8-channel vector); source = tile base + hoff, where the tile base is the input pixel
+    // (image of the tile's first grid row, input row sy * qy0 + dymin, column dxmin) -- possibly outside the tensor, the
+    // offsets of valid slots bring it back inside -- and segment s of a multi-image tile is the image s further on
+    const int HVn = c.HP * VPP;
+    int hoff[PMAXV], hdst[PMAXV], hrs[PMAXV];       // element offset from the tile base; LDS element offset; row within the
+                                                    // segment | segment << 8 (or -1: never valid)
+#pragma unroll
+    for (int i = 0; i < PMAXV; ++i) {
+        const int idx = tid + 256 * i;
+        hoff[i] = 0; hdst[i] = -1; hrs[i] = -1;
+        if (idx < HVn) {
+            const int pix = idx / VPP, cv = idx - pix * VPP;
+            const int lr = pix / c.LW, lc = pix - lr * c.LW;
+            const int seg = lr / c.SR, off = lr - seg * c.SR;
+            hdst[i] = pix * LDC + 8 * cv;
+            if ((unsigned)(lc + c.dxmin) < (unsigned)g.Win) {
+                hrs[i] = off | (seg << 8);
+                hoff[i] = ((seg * g.Hin + off) * g.Win + lc) * g.ldx + 8 * cv;
+            }
+        }
+    }
+    f32x4 ps0 = {1.f, 1.f, 1.f, 1.f}, ps1 = ps0, pt0 = {0.f, 0.f, 0.f, 0.f}, pt1 = pt0;
+    if (has_pro) {                                  // a thread's 8-channel group is the same for all of its slots (256 % VPP == 0)
+        const int cv8 = 8 * (tid % VPP);
+        ps0 = *reinterpret_cast<const f32x4*>(a.pro_scale + cv8);
+        ps1 = *reinterpret_cast<const f32x4*>(a.pro_scale + cv8 + 4);
+        pt0 = *reinterpret_cast<const f32x4*>(a.pro_shift + cv8);
+        pt1 = *reinterpret_cast<const f32x4*>(a.pro_shift + cv8 + 4);
+    }
+    struct HStage { V hv[PMAXV]; bool hok[PMAXV]; };
+    HStage HA, HB;
+    auto load_halo = [&](HStage& S, int tile) {
+        const int R0 = tile * c.TR;
+        const int b0 = R0 >> c.hlog, qy0 = R0 & (Hq - 1);
+        const int iy0 = g.sy * qy0 + c.dymin;                                  // input row of LDS row 0 of a segment
+        const int64_t base = ((int64_t)(b0 * g.Hin + iy0) * g.Win + c.dxmin) * g.ldx;
+        const int64_t safe = ((int64_t)(b0 * g.Hin + g.sy * qy0) * g.Win) * g.ldx;    // the tile's first input pixel
+#pragma unroll
+        for (int i = 0; i < PMAXV; ++i) {
+            if (256 * i >= HVn) break;
+            const bool ok = hrs[i] >= 0 && (unsigned)(iy0 + (hrs[i] & 255)) < (unsigned)g.Hin &&
+                            R0 + ((hrs[i] >> 8) << c.hhlog) < BHq;
+            S.hok[i] = ok;
+            S.hv[i] = *reinterpret_cast<const V*>(X + (ok ? base + hoff[i] : safe));
+        }
+    };
+    auto store_halo = [&](HStage& S) {
+#pragma unroll
+        for (int i = 0; i < PMAXV; ++i) {
+            if (256 * i >= HVn) break;
+            V o = S.hv[i];
+            if (has_pro) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float u0 = to_f(S.hv[i][j]) * ps0[j] + pt0[j], u1 = to_f(S.hv[i][j + 4]) * ps1[j] + pt1[j];
+                    o[j] = (T)fmaxf(u0, u0 * a.pro_slope);
+                    o[j + 4] = (T)fmaxf(u1, u1 * a.pro_slope);
+                }
+            }
+            if (hdst[i] >= 0) *reinterpret_cast<V*>(halo + hdst[i]) = S.hok[i] ? o : zero;
+        }
+    };
+
+    // ---- this lane's two output-grid positions inside a tile, epilogue constants ----------------------------------------------
+    int hbase[2], prow[2], pcol[2];
+#pragma unroll
+    for (int ms = 0; ms < 2; ++ms) {
+        const int p = 32 * wave + 16 * ms + fr;
+        prow[ms] = p >> c.wlog;
+        pcol[ms] = p & (Wq - 1);
+        const int seg = prow[ms] >> c.hhlog, rin = prow[ms] & (HH - 1);
+        hbase[ms] = ((seg * c.SR + g.sy * rin) * c.LW + g.sx * pcol[ms]) * LDC + (CC == 16 ? 8 * (fq & 1) : 8 * fq);
+    }
+    f32x4 bias[NT], esc[NT], esh[NT], emu[NT], ers[NT];
+    bool nval[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        const int n = n0 + 16 * i + 4 * fq;
+        nval[i] = n < g.N;
+        const int nc = nval[i] ? n : 0;
+        bias[i] = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + nc) : f32x4{0.f, 0.f, 0.f, 0.f};
+        if (EX) {
+            esc[i] = *reinterpret_cast<const f32x4*>(a.ex_scale + nc);
+            esh[i] = *reinterpret_cast<const f32x4*>(a.ex_shift + nc);
+            emu[i] = *reinterpret_cast<const f32x4*>(a.ex_mean + nc);
+            ers[i] = *reinterpret_cast<const f32x4*>(a.ex_rstd + nc);
+        }
+    }
+    float s1[NT][4], s2[NT][4];
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s1[i][r] = s2[i][r] = 0.f;
+
+    load_halo(HA, t_begin);
+    if (t_begin + 1 < t_end) load_halo(HB, t_begin + 1);
+    store_halo(HA);
+    __syncthreads();
+    auto do_tile = [&](int tile, HStage& NEXT, HStage& FREE) {
+        const int R0 = tile * c.TR;
+        const bool more = tile + 1 < t_end;
+        if (tile + 2 < t_end) load_halo(FREE, tile + 2);              // flies during this tile's and the next tile's MFMAs
+        f32x4 acc[NPH][NT][2];
+#pragma unroll
+        for (int ph = 0; ph < NPH; ++ph)
+#pragma unroll
+            for (int i = 0; i < NT; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[ph][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ph = 0; ph < NPH; ++ph) {
+            if (ph >= g.nphase) break;
+            const sv_phase& P = g.phase[ph];
+            const int nks = c.nks[ph];
+            for (int ks = 0; ks < nks; ++ks) {
+                int sh;
+                {
+                    const int ta = ks * TPK < P.ntap ? ks * TPK : 0;
+                    const int sha = ((P.dy[ta] - c.dymin) * c.LW + (P.dx[ta] - c.dxmin)) * LDC;
+                    sh = sha;
+                    if (TPK == 2) {
+                        const int tb = ks * TPK + 1 < P.ntap ? ks * TPK + 1 : 0;
+                        const int shb = ((P.dy[tb] - c.dymin) * c.LW + (P.dx[tb] - c.dxmin)) * LDC;
+                        sh = (fq >> 1) ? shb : sha;
+                    }
+                }
+                const T* wrow = wl + (c.tap0[ph] + ks * TPK) * Cin + 8 * fq;
+                for (int ck = 0; ck < NCK; ++ck) {
+                    const V af0 = *reinterpret_cast<const V*>(halo + hbase[0] + sh + CC * ck);
+                    const V af1 = *reinterpret_cast<const V*>(halo + hbase[1] + sh + CC * ck);
+#pragma unroll
+                    for (int i = 0; i < NT; ++i) {
+                        const V wf = *reinterpret_cast<const V*>(wrow + (16 * i + fr) * LDW + CC * ck);
+                        mma32(acc[ph][i][0], wf, af0);
+                        mma32(acc[ph][i][1], wf, af1);
+                    }
+                }
+            }
+        }
+        __syncthreads();                               // every wave is done reading this tile's halo
+        if (more) store_halo(NEXT);                    // the next tile's halo -> LDS (requested a whole tile ago)
+        // ---- epilogue of this tile ------------------------------------------------------------------------------------------
+#pragma unroll
+        for (int ph = 0; ph < NPH; ++ph) {
+            if (ph >= g.nphase) break;
+            const sv_phase& P = g.phase[ph];
+#pragma unroll
+            for (int ms = 0; ms < 2; ++ms) {
+                const int grow = R0 + prow[ms];
+                if (grow >= BHq) continue;
+                const int b = grow >> c.hlog, qy = grow & (Hq - 1);
+                const int64_t ob = ((int64_t)(b * g.Hout + qy * g.osy + P.ooy) * g.Wout + pcol[ms] * g.osx + P.oox) * g.ldo;
+#pragma unroll
+                for (int i = 0; i < NT; ++i) {
+                    if (!nval[i]) continue;
+                    const int n = n0 + 16 * i + 4 * fq;
+                    f32x4 vv = acc[ph][i][ms];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) vv[r] += bias[i][r];
+                    if (R) {
+                        const Q rr = *reinterpret_cast<const Q*>(R + ob + n);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) vv[r] += to_f(rr[r]);
+                    }
+                    if (EX) {
+                        const Q xe = *reinterpret_cast<const Q*>(EX + ob + n);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float xf = to_f(xe[r]);
+                            const float gv = vv[r] * act_grad(xf * esc[i][r] + esh[i][r], a.ex_slope);
+                            vv[r] = gv;
+                            s1[i][r] += gv;
+                            s2[i][r] += gv * ((xf - emu[i][r]) * ers[i][r]);
+                        }
+                    } else if (a.stats) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            s1[i][r] += vv[r];
+                            s2[i][r] += vv[r] * vv[r];
+                        }
+                    }
+                    Q o;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = (T)vv[r];
+                    *reinterpret_cast<Q*>(O + ob + n) = o;
+                }
+            }
+        }
+        __syncthreads();                               // the next halo is visible
+    };
+    for (int tile = t_begin; tile < t_end; tile += 2) {
+        do_tile(tile, HB, HA);
+        if (tile + 1 < t_end) do_tile(tile + 1, HA, HB);
+    }
+    if (want_sums) {
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) {
+                    s1[i][r] += __shfl_xor(s1[i][r], o);
+                    s2[i][r] += __shfl_xor(s2[i][r], o);
+                }
+                if (fr == 0 && nval[i]) {
+                    atomicAdd(&ssum[16 * i + 4 * fq + r], s1[i][r]);
+                    atomicAdd(&ssum[BN + 16 * i + 4 * fq + r], s2[i][r]);
+                }
+            }
+        }
+        __syncthreads();
+        float* dst = (EX ? a.bsums : a.stats) + (size_t)(blockIdx.x & (a.replicas - 1)) * 2 * g.N;
+        if (tid < 2 * BN) {
+            const int which = tid / BN, nl = tid - which * BN;
+            if (n0 + nl < g.N) atomicAdd(dst + which * g.N + n0 + nl, ssum[tid]);
+        }
+    }
+}
+
+template <typename T, int NT, int CC, int NPH>
+int launch_halop(const sv_geom* g, const sv_igemm_args* a, const halo_cfg& c, size_t lds, hipStream_t s) {
+    constexpr int BN = 16 * NT;
+    const int nT = (g->B * g->Hq + c.TR - 1) / c.TR;
+    const int nNt = (g->N + BN - 1) / BN;
+    const int budget = sv_persistent_blocks();
+    const int target = budget / sv_ngroups(a->groups) > 64 ? budget / sv_ngroups(a->groups) : 64;
+    int chunks = (target + nNt - 1) / nNt;
+    if (chunks > nT) chunks = nT;
+    const int tiles_per = (nT + chunks - 1) / chunks;
+    chunks = (nT + tiles_per - 1) / tiles_per;
+    static bool optin = false;
+    if (lds > 64 * 1024 && !optin) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&halop_kernel<T, NT, CC, NPH>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return sv_check_launch("hipFuncSetAttribute(halop)");
+        optin = true;
+    }
+    sv_prof_begin(s);
+    hipLaunchKernelGGL((halop_kernel<T, NT, CC, NPH>), dim3(chunks * nNt, sv_ngroups(a->groups)), dim3(256), lds, s, *g,
+                       sv_expand_groups(*g, *a, (int)sizeof(T)), c, tiles_per);
+    sv_prof_end(s);
+    return sv_check_launch("sv_igemm(halop)");
+}
+
+template <typename T, int CC, int NPH>
+int launch_halop_nt(const sv_geom* g, const sv_igemm_args* a, const halo_cfg& c, int nt, size_t lds, hipStream_t s) {
+    return nt == 2 ? launch_halop<T, 2, CC, NPH>(g, a, c, lds, s) : launch_halop<T, 1, CC, NPH>(g, a, c, lds, s);
+}
+
 int ilog2x(int v) {
     int l = 0;
     while ((1 << l) < v) ++l;
@@ -347,7 +671,6 @@ int sv_halo_try(const sv_geom* g, int dtype, const sv_igemm_args* a, hipStream_t
     // ConvTranspose layers forward (207 -> 125 us, 181 -> 153 us) -- and loses elsewhere (two blocks per CU of 60-90 KB LDS
     // and no overlap of staging and MFMA: 32 -> 64 stride-2 forward 112 -> 214 us).  Until it is persistent and
     // software-pipelined like conv3x3p it only takes the former; SV_OPT_HALO_ALL = 1 takes everything it covers (tests).
-    if (!sv_halo_all() && !(g->nphase == 4 && g->sy == 1 && g->N <= 64 && g->Cin <= 128 && g->Wq >= 8)) return 0;
     if (g->Hq != g->Wq || g->Hin != g->Win || g->sy != g->sx || g->osy != g->osx) return 0;
     if (g->sy < 1 || g->sy > 2) return 0;
     halo_cfg c;
@@ -396,6 +719,24 @@ int sv_halo_try(const sv_geom* g, int dtype, const sv_igemm_args* a, hipStream_t
     if (lds > 100 * 1024) return 0;
     if ((int64_t)g->B * g->Hin * g->Win * g->ldx >= ((int64_t)1 << 31)) return 0;
     const bool multi = g->nphase > 1;
+    // thin layers: the persistent variant (all channels + all weights LDS-resident, two blocks per CU)
+    if (!sv_disabled(SV_K_HALOP) && g->Cin <= 64) {
+        const int nt = multi ? 1 : (g->N % 32 == 0 ? 2 : 1), BN = 16 * nt;     // (four accumulator sets: 16-channel tiles)
+        const size_t ldsp = ((size_t)c.HP * (g->Cin + 16) + (size_t)BN * (c.tslots * g->Cin + 16)) * es + 2 * BN * 4;
+        const int nT = (g->B * g->Hq + c.TR - 1) / c.TR;
+        if (ldsp <= 72 * 1024 && c.HP * (g->Cin / 8) <= 256 * PMAXV && 256 % (g->Cin / 8) == 0 &&
+            (sv_halo_all() || nT * sv_ngroups(a->groups) >= 1024)) {       // (a few tiles per block at least; tests: any size)
+            if (dtype == SV_BF16) {
+                if (CC == 16) *rc = multi ? launch_halop_nt<bf16, 16, 4>(g, a, c, nt, ldsp, s) : launch_halop_nt<bf16, 16, 1>(g, a, c, nt, ldsp, s);
+                else *rc = multi ? launch_halop_nt<bf16, 32, 4>(g, a, c, nt, ldsp, s) : launch_halop_nt<bf16, 32, 1>(g, a, c, nt, ldsp, s);
+            } else {
+                if (CC == 16) *rc = multi ? launch_halop_nt<float, 16, 4>(g, a, c, nt, ldsp, s) : launch_halop_nt<float, 16, 1>(g, a, c, nt, ldsp, s);
+                else *rc = multi ? launch_halop_nt<float, 32, 4>(g, a, c, nt, ldsp, s) : launch_halop_nt<float, 32, 1>(g, a, c, nt, ldsp, s);
+            }
+            return 1;
+        }
+    }
+    if (!sv_halo_all() && !(g->nphase == 4 && g->sy == 1 && g->N <= 64 && g->Cin <= 128 && g->Wq >= 8)) return 0;
     if (dtype == SV_BF16) {
         if (CC == 16) *rc = multi ? launch_halo_nt<bf16, 16, 4>(g, a, c, nt, s) : launch_halo_nt<bf16, 16, 1>(g, a, c, nt, s);
         else *rc = multi ? launch_halo_nt<bf16, 32, 4>(g, a, c, nt, s) : launch_halo_nt<bf16, 32, 1>(g, a, c, nt, s);

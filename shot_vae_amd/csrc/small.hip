@@ -414,7 +414,33 @@ __global__ __launch_bounds__(256) void head_bwd_data_kernel(int B, int C, const 
             if (b0 + s < B) dout[(int64_t)(b0 + s) * NH + (i - s * NH)] = d[i];
         }
     }
-    // blockIdx.y = 256-channel slice of the features (wide encoders: 640 channels, K = 100 -> three times the blocks)
+    // blockIdx.y = 256-channel slice of the features (wide encoders: 640 channels, K = 100 -> three times the blocks).
+    // With fewer than 256 channels the thread groups (tid / C) split the NH outputs among them and meet in LDS: 128
+    // channels left half of the block idle in a 266-step dependent loop (85 us at 2048 samples)
+    const int Cb = C < 256 ? C : 256, parts = 256 / Cb;
+    if (parts > 1 && gridDim.y == 1 && 256 % Cb == 0) {
+        float* red = d + HS * NH;                                   // [parts][HS][Cb]
+        const int c = tid % Cb, part = tid / Cb;
+        float acc[HS];
+#pragma unroll
+        for (int s = 0; s < HS; ++s) acc[s] = 0.f;
+#pragma unroll 8
+        for (int n = part; n < NH; n += parts) {
+            const float w = W[(int64_t)n * C + c];
+#pragma unroll
+            for (int s = 0; s < HS; ++s) acc[s] += w * d[s * NH + n];
+        }
+#pragma unroll
+        for (int s = 0; s < HS; ++s) red[(part * HS + s) * Cb + c] = acc[s];
+        __syncthreads();
+        for (int i = tid; i < HS * Cb; i += 256) {
+            const int s = i / Cb, cc = i - s * Cb;
+            float t = 0.f;
+            for (int q = 0; q < parts; ++q) t += red[(q * HS + s) * Cb + cc];
+            if (b0 + s < B) dfeat[(int64_t)(b0 + s) * C + cc] = t;
+        }
+        return;
+    }
     for (int c = blockIdx.y * 256 + tid; c < C; c += 256 * gridDim.y) {
         float acc[HS];
 #pragma unroll
@@ -752,14 +778,26 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* p, const float* g, floa
 }
 
 // ---------------------------------------------------------------------------------------- layout
+// one thread per pixel: C strided channel reads (coalesced across the pixels of a wave), the Cpad outputs of the pixel
+// as 16-byte stores (one 2-byte store per thread ran at 1.5 TB/s)
 template <typename T>
-__global__ void nchw_to_nhwc_kernel(const float* in, int B, int C, int HW, int Cpad, T* out) {
-    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;           // over B*HW*Cpad (< 2^32)
-    if (i >= (unsigned)B * HW * Cpad) return;
-    const unsigned c = i % Cpad;
-    const unsigned bp = i / Cpad;
-    const unsigned b = bp / HW, p = bp - b * HW;
-    out[i] = (T)(c < (unsigned)C ? in[((size_t)b * C + c) * HW + p] : 0.f);
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* in, int B, int C, int HW, int Cpad, T* out) {
+    typedef typename V8<T>::type V;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;     // over B*HW
+    if (i >= (int64_t)B * HW) return;
+    const int64_t b = i / HW, p = i - b * HW;
+    const float* src = in + b * C * HW + p;
+    T* dst = out + i * Cpad;
+    if (Cpad % 8 == 0) {
+        for (int c0 = 0; c0 < Cpad; c0 += 8) {
+            V v;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (T)(c0 + j < C ? src[(int64_t)(c0 + j) * HW] : 0.f);
+            *reinterpret_cast<V*>(dst + c0) = v;
+        }
+    } else {
+        for (int c = 0; c < Cpad; ++c) dst[c] = (T)(c < C ? src[(int64_t)c * HW] : 0.f);
+    }
 }
 template <typename T>
 __global__ void nhwc_to_nchw_kernel(const T* in, int B, int C, int HW, int ld, float* out) {
@@ -983,7 +1021,7 @@ int sv_head_bwd(const float* feat, int B, int C, const float* W, int ldc, int K,
     SvProfScope prof_scope(stream);
     SV_REQUIRE(feat && W && la && dmu && dls && dla && dfeat && dW && dbias && dout_ws, SV_E_ARG, "sv_head_bwd: null");
     const int NH = 2 * ldc + K;
-    const size_t lds = (size_t)HS * NH * sizeof(float);
+    const size_t lds = ((size_t)HS * NH + (size_t)HS * 256) * sizeof(float);       // gradients + the thread groups' partial sums
     hipLaunchKernelGGL(head_bwd_data_kernel, dim3((B + HS - 1) / HS, (C + 255) / 256), dim3(256), lds, (hipStream_t)stream, B, C, W,
                        ldc, K, la, dmu, dls, dla, dfeat, dout_ws);
     hipLaunchKernelGGL(head_bwd_weight_kernel, dim3(NH, B >= 64 ? 8 : 1), dim3(256), 0, (hipStream_t)stream, feat,
@@ -1115,7 +1153,7 @@ int sv_sgd(float* p, const float* g, float* v, int64_t n, float lr, float moment
 int sv_nchw_to_nhwc(int dtype, const float* in, int B, int C, int H, int W, int Cpad, void* out, void* stream) {
     SvProfScope prof_scope(stream);
     SV_REQUIRE(in && out && Cpad >= C, SV_E_ARG, "sv_nchw_to_nhwc: bad args");
-    const int64_t n = (int64_t)B * H * W * Cpad;
+    const int64_t n = (int64_t)B * H * W;
     DISPATCH_T(dtype, hipLaunchKernelGGL((nchw_to_nhwc_kernel<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
                                          (hipStream_t)stream, in, B, C, H * W, Cpad, (T*)out));
     return sv_check_launch("sv_nchw_to_nhwc");
