@@ -135,8 +135,8 @@ def pmc_traffic(tag, a):
     headline shapes is collected by tools/pmc_traffic.py (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes,
     gfx950 correction applied) and committed under profiles/; it is deterministic for a given kernel and shape."""
     import glob
-    if a.dtype != "bf16" or a.batch != 512:
-        return None, "no PMC profile for this batch / dtype"
+    if a.dtype != "bf16" or a.batch != 512 or a.schedule != "grouped" or a.scaling != "weak":
+        return None, "no PMC profile for this batch / dtype / schedule"
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")))
     if not files:
         return None, "profiles/*pmc_traffic.json missing"

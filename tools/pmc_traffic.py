@@ -20,19 +20,21 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-# tag (bench.py's name of the launch) -> (B, Cin, H, N, kind, substrings of the kernel names that make up one launch)
+# tag (bench.py's name of the launch) -> (B, Cin, H, N, kind, substrings of the kernel names that make up one launch).
+# B = the images ONE launch of the grouped step processes: 4 x 512 at BASELINE config 2, 4 x 256 at config 4 (a batched
+# launch of G groups of B images runs the same blocks as one group of G * B images)
 LAYERS = {
-    "wgrad:conv3x3_32x32_s1": (512, 32, 32, 32, "wgrad", ["wgrad3x3_kernel", "slab_reduce_kernel"]),
-    "fwd:conv3x3_32x32_s1": (512, 32, 32, 32, "fwd", ["conv3x3p_kernel"]),
-    "dgrad:conv3x3_32x32_s1": (512, 32, 32, 32, "dgrad", ["conv3x3p_kernel"]),
-    "wgrad:conv3x3_64x64_s1": (512, 64, 16, 64, "wgrad", ["wgrad3x3_kernel", "slab_reduce_kernel"]),
-    "fwd:conv3x3_64x64_s1": (512, 64, 16, 64, "fwd", ["conv3x3p_kernel"]),
-    "dgrad:conv3x3_64x64_s1": (512, 64, 16, 64, "dgrad", ["conv3x3p_kernel"]),
-    "wgrad:conv3x3_128x128_s1": (512, 128, 8, 128, "wgrad", ["wgrad3x3_kernel", "slab_reduce_kernel"]),
-    "fwd:conv3x3_128x128_s1": (512, 128, 8, 128, "fwd", ["conv3x3_kernel", "conv3x3w_kernel"]),
-    "dgrad:conv3x3_128x128_s1": (512, 128, 8, 128, "dgrad", ["conv3x3_kernel", "conv3x3w_kernel"]),
-    "fwd:conv3x3_160x160_s1": (512, 160, 32, 160, "fwd", ["conv3x3x_kernel", "conv3x3w_kernel"]),
-    "wgrad:conv3x3_160x160_s1": (512, 160, 32, 160, "wgrad", ["wgrad3x3w_kernel", "slab_reduce_kernel"]),
+    "wgrad:conv3x3_32x32_s1": (2048, 32, 32, 32, "wgrad", ["wgrad3x3_kernel", "slab_reduce_kernel"]),
+    "fwd:conv3x3_32x32_s1": (2048, 32, 32, 32, "fwd", ["conv3x3p_kernel"]),
+    "dgrad:conv3x3_32x32_s1": (2048, 32, 32, 32, "dgrad", ["conv3x3p_kernel"]),
+    "wgrad:conv3x3_64x64_s1": (2048, 64, 16, 64, "wgrad", ["wgrad3x3_kernel", "slab_reduce_kernel"]),
+    "fwd:conv3x3_64x64_s1": (2048, 64, 16, 64, "fwd", ["conv3x3p_kernel"]),
+    "dgrad:conv3x3_64x64_s1": (2048, 64, 16, 64, "dgrad", ["conv3x3p_kernel"]),
+    "wgrad:conv3x3_128x128_s1": (2048, 128, 8, 128, "wgrad", ["wgrad3x3_kernel", "slab_reduce_kernel"]),
+    "fwd:conv3x3_128x128_s1": (2048, 128, 8, 128, "fwd", ["conv3x3_kernel", "conv3x3w_kernel"]),
+    "dgrad:conv3x3_128x128_s1": (2048, 128, 8, 128, "dgrad", ["conv3x3_kernel", "conv3x3w_kernel"]),
+    "fwd:conv3x3_160x160_s1": (1024, 160, 32, 160, "fwd", ["conv3x3x_kernel", "conv3x3w_kernel"]),
+    "wgrad:conv3x3_160x160_s1": (1024, 160, 32, 160, "wgrad", ["wgrad3x3w_kernel", "slab_reduce_kernel"]),
 }
 ITERS, WARM = 4, 1
 
