@@ -67,11 +67,48 @@ def one_pass(tag, counter, outdir):
     return total, sorted(per)
 
 
+# kernels that have no single-layer harness: measured inside the WHOLE step (bench.py under the counter pass), mean over
+# every dispatch of the kernel.  tag -> (kernel-name substring, algorithmic bytes are taken from bench.py's own line)
+STEP_KERNELS = {"sv_bn_bwd_apply": "bn_bwd_apply_kernel"}
+
+
+def step_pass(counter, outdir):
+    d = os.path.join(outdir, "step_" + counter)
+    cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--",
+           "python3", os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-roofline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT)
+    if r.returncode != 0:
+        raise RuntimeError("rocprofv3 failed: " + r.stderr[-2000:])
+    files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+    assert files, "no counter_collection.csv under " + d
+    per = {}
+    for row in csv.DictReader(open(files[0])):
+        if row.get("Counter_Name") != counter:
+            continue
+        for tag, nm in STEP_KERNELS.items():
+            if nm in row["Kernel_Name"]:
+                per.setdefault(tag, []).append(float(row["Counter_Value"]))
+    return {tag: (sum(v) / len(v), len(v)) for tag, v in per.items()}
+
+
 def main():
     out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "pmc_traffic.json")
     outdir = os.path.join(ROOT, "gpurun_out", "pmc")
     os.makedirs(outdir, exist_ok=True)
     res = {}
+    if len(sys.argv) > 2 and sys.argv[2] == "step" and os.path.exists(out):
+        res = json.load(open(out))          # add the step-level kernels to an existing table
+    fetch, write = step_pass("FETCH_SIZE", outdir), step_pass("WRITE_SIZE", outdir)
+    for tag in STEP_KERNELS:
+        f, n = fetch[tag]
+        w, _ = write[tag]
+        res[tag] = {"FETCH_SIZE_KiB": f, "WRITE_SIZE_KiB": w, "traffic_bytes": (2 * f + w) * 1024, "kernels": [STEP_KERNELS[tag]],
+                    "shape": "every launch of the kernel in the BASELINE config-2 step (bench.py, grouped schedule)",
+                    "formula": "(2*FETCH_SIZE + WRITE_SIZE)*1024, per launch, mean of the %d launches of 3 steps" % n}
+        print(tag, json.dumps(res[tag]), flush=True)
+    if len(sys.argv) > 2 and sys.argv[2] == "step":
+        json.dump(res, open(out, "w"), indent=1)
+        return
     for tag in LAYERS:
         B, Cin, H, N, kind, _ = LAYERS[tag]
         fetch, k1 = one_pass(tag, "FETCH_SIZE", outdir)
