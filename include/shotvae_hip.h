@@ -257,7 +257,7 @@ int sv_debug_conv_chunk_program(int* items, int* waits);
 /* ---- dispatcher options (process-wide; set them between launches, not concurrently with them) --------------------
  * SV_OPT_DISABLE_MASK: OR of SV_K_* bits; a set bit routes the layers a specialised kernel would take to the next more
  * general one (sv_igemm: conv3x3x -> conv3x3w -> conv3x3 / conv3x3p / conv3x3m -> halo -> the generic gather-GEMM; sv_wgrad:
- * wgrad3x3w -> wgrad3x3 -> the generic weight-gradient kernel).  Default 0.  The parity tests use it to compare every
+ * wgrad3x3w -> wgrad3x3 -> hwgrad -> the generic weight-gradient kernel).  Default 0.  The parity tests use it to compare every
  * specialised kernel with the general one on the same inputs (conv3x3x against conv3x3w bit for bit).
  * SV_OPT_WIDE_MIN_BLOCKS: minimum grid (blocks) for which the 256-pixel wide-tile kernels are chosen; default 256 (one
  * block per CU).  Tests set 1 to reach those kernels at small batch sizes.
@@ -267,7 +267,7 @@ int sv_debug_conv_chunk_program(int* items, int* waits);
  * groups of a batched launch.  Default 512 (two blocks per CU); tools/tune_blocks.py sweeps it.                       */
 enum { SV_OPT_DISABLE_MASK = 0, SV_OPT_WIDE_MIN_BLOCKS = 1, SV_OPT_HALO_ALL = 2, SV_OPT_PERSISTENT_BLOCKS = 3 };
 enum { SV_K_CONV3X3 = 1, SV_K_CONV3X3P = 2, SV_K_CONV3X3M = 4, SV_K_CONV3X3W = 8, SV_K_CONV3X3X = 16,
-       SV_K_WGRAD3X3 = 32, SV_K_WGRAD3X3W = 64, SV_K_IGEMM_KV2 = 128, SV_K_HALO = 256, SV_K_HALOP = 512 };
+       SV_K_WGRAD3X3 = 32, SV_K_WGRAD3X3W = 64, SV_K_IGEMM_KV2 = 128, SV_K_HALO = 256, SV_K_HALOP = 512, SV_K_HWGRAD = 1024 };
 int sv_set_option(int key, int value);
 int sv_get_option(int key);          /* -1 for an unknown key */
 

@@ -302,6 +302,9 @@ extern "C" int sv_wgrad(const sv_geom* g, int dtype, const void* x, const float*
         int rc = 0;
         if (!sv_disabled(SV_K_WGRAD3X3) && sv_wgrad3x3_try(g, dtype, x, pro_scale, pro_shift, pro_slope, dy, dw, ws, ws_elems, sv_ngroups(groups), (hipStream_t)stream, &rc))
             return rc;
+        // the other layers with a spatial extent: tap-fused LDS-halo weight gradient (hwgrad.hip)
+        if (use_tr && sv_hwgrad_try(g, dtype, x, pro_scale, pro_shift, pro_slope, dy, dw, ws, ws_elems, sv_ngroups(groups), (hipStream_t)stream, &rc))
+            return rc;
     }
     wg_params p;
     p.x = x; p.pro_scale = pro_scale; p.pro_shift = pro_shift; p.pro_slope = pro_slope;

@@ -899,6 +899,8 @@ int launch_wide(const sv_geom* g, const wg3_params& p, hipStream_t s) {
 
 }  // namespace
 
+void sv_slab_reduce(const float* ws, int nslabs, int64_t n, float* dw, hipStream_t s) { launch_slab_reduce(ws, nslabs, n, dw, s); }
+
 // Returns 1 and sets *rc when the geometry is a stride-1 3x3 convolution this kernel covers.
 int sv_wgrad3x3_try(const sv_geom* g, int dtype, const void* x, const float* pro_scale, const float* pro_shift,
                     float pro_slope, const void* dy, float* dw, float* ws, int64_t ws_elems, int groups, hipStream_t s,

@@ -745,3 +745,60 @@ def test_halo_kernel_convT_cases(dt, H, Cin, N, B):
     (4x4 stride-2 convolutions)."""
     with L.options(halo_all=1):
         test_convT_forward_and_dgrad(dt, H, Cin, N, B)
+
+
+@pytest.mark.parametrize("case", [(40, 16, 16, 32, 3, 1, 1), (16, 16, 32, 32, 3, 1, 1), (8, 32, 64, 32, 3, 2, 1),
+                                  (8, 64, 128, 16, 3, 2, 1), (4, 32, 64, 16, 3, 2, 1)])
+def test_tap_fused_wgrad_conv(case):
+    """hwgrad.hip (all taps of a layer in one block, LDS-halo) on the thin / stride-2 convolutions against torch; once as a
+    plain launch (accumulating twice) and once batched over three groups."""
+    B, Cin, N, H, k, stride, pad = case
+    code, tdt, tol = DT["bf16"]
+    torch.manual_seed(5)
+    d = dev()
+    Gn = 3
+    x = bq(torch.randn(Gn * B, Cin, H, H), "bf16")
+    scale, shift = torch.rand(Gn, Cin) + 0.5, torch.randn(Gn, Cin) * 0.3
+    Ho = (H + 2 * pad - k) // stride + 1
+    dy = bq(torch.randn(Gn * B, N, Ho, Ho), "bf16")
+    wref = torch.zeros(N, Cin, k, k)
+    for gi in range(Gn):
+        sl = slice(gi * B, (gi + 1) * B)
+        a = bq(F.leaky_relu(x[sl] * scale[gi][None, :, None, None] + shift[gi][None, :, None, None], 0.01), "bf16")
+        wref += torch.nn.grad.conv2d_weight(a, (N, Cin, k, k), dy[sl], stride, pad)
+    g = G.conv_like(B, H, H, Cin, N, k, stride, pad)
+    xd, dyd = nhwc(x).to(d, tdt), nhwc(dy).to(d, tdt)
+    sc, sh = scale.to(d).contiguous(), shift.to(d).contiguous()
+    ws = torch.full((16 * 1024 * 1024,), float("nan"), device=d)
+    with L.options(halo_all=1):
+        dw = torch.zeros(N, k * k, Cin, device=d)
+        L.call("sv_wgrad", C.byref(g), code, p(xd), p(sc), p(sh), 0.01, p(dyd), p(dw), 0, 1, p(ws), ws.numel(), Gn, st())
+        dw2 = torch.zeros(N, k * k, Cin, device=d)
+        with L.options(disable=L.K_HWGRAD):
+            L.call("sv_wgrad", C.byref(g), code, p(xd), p(sc), p(sh), 0.01, p(dyd), p(dw2), 0, 1, p(ws), ws.numel(), Gn, st())
+    torch.cuda.synchronize()
+    got = dw.cpu().view(N, k, k, Cin).permute(0, 3, 1, 2)
+    assert rel(got, wref) < tol, rel(got, wref)
+    assert rel(dw, dw2) < 2e-3, rel(dw, dw2)             # against the generic kernel on the same bf16 operands
+
+
+@pytest.mark.parametrize("H,Cin,N,B", [(4, 256, 128, 32), (8, 128, 64, 16), (16, 64, 16, 8)])
+def test_tap_fused_wgrad_convT(H, Cin, N, B):
+    """... and on the ConvTranspose2d(4, 2, 1) decoder layers (four phases of dy, one input region)."""
+    code, tdt, tol = DT["bf16"]
+    torch.manual_seed(6)
+    x = bq(torch.randn(B, Cin, H, H), "bf16")
+    dy = bq(torch.randn(B, N, 2 * H, 2 * H), "bf16")
+    w = torch.zeros(Cin, N, 4, 4, requires_grad=True)
+    F.conv_transpose2d(F.relu(x), w, None, 2, 1).backward(dy)
+    g = G.convT_like(B, H, H, Cin, N, 4, 2, 1)
+    d = dev()
+    one, zero = torch.ones(Cin, device=d), torch.zeros(Cin, device=d)
+    ws = torch.full((16 * 1024 * 1024,), float("nan"), device=d)
+    dw = torch.zeros(N, 16, Cin, device=d)
+    with L.options(halo_all=1):
+        L.call("sv_wgrad", C.byref(g), code, p(nhwc(x).to(d, tdt)), p(one), p(zero), 0.0, p(nhwc(dy).to(d, tdt)), p(dw), 0, 1,
+               p(ws), ws.numel(), 1, st())
+    torch.cuda.synchronize()
+    got = dw.cpu().view(N, 4, 4, Cin).permute(3, 0, 1, 2)
+    assert rel(got, w.grad) < tol, rel(got, w.grad)
