@@ -318,6 +318,11 @@ int sv_hwgrad_try(const sv_geom* g, int dtype, const void* x, const float* pro_s
     p.tiles_per = (nT + splits - 1) / splits;
     splits = (nT + p.tiles_per - 1) / p.tiles_per;
     if (p.tiles_per < 4 && !sv_halo_all()) return 0;             // too little work per block to amortise the slab: generic kernel
+    // Measured against the generic kernel at 4 x 512 images (profiles/r02_*): it wins on the thin stride-1 layers, which are
+    // L2-bound there (16 -> 32: 189 -> 100 us, last ConvTranspose 155 -> 77 us, stem 132 -> 66 us), and is level or behind on
+    // the layers with many slabs or a stride-2 input region (128 -> 64 ConvTranspose 131 -> 139 us, 32 -> 64 stride 2
+    // 97 -> 106 us): those stay on the generic kernel (SV_OPT_HALO_ALL = 1 takes the whole range: tests)
+    if (!sv_halo_all() && !(nNC <= 2 && g->sy == 1)) return 0;
     const int64_t need = (int64_t)splits * groups * kparts * g->N * g->T_orig * g->Cin;
     if (ws_elems < need) return 0;
     p.x = x; p.pro_scale = pro_scale; p.pro_shift = pro_shift; p.pro_slope = pro_slope; p.dy = dy; p.ws = ws;
