@@ -149,8 +149,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bnb_params_g PG
         float* cmean = coef;
         float* crstd = coef + p.C;
         float* part = coef + (2 + 3 * p.nbranch) * p.C;         // [nbranch][2][G][Cg]
-        const int Cg = p.C < 256 ? p.C : 256;
-        const int G = 256 / Cg;
+        const int nthr = blockDim.x;                 // 256, or the largest multiple of C/8 below it (see the launcher)
+        const int Cg = p.C < nthr ? p.C : nthr;
+        const int G = nthr / Cg;
         const int grp = threadIdx.x / Cg, cl = threadIdx.x - grp * Cg;
         for (int cb0 = 0; cb0 < p.C; cb0 += Cg) {
             const int c = cb0 + cl;
@@ -961,8 +962,12 @@ int sv_bn_bwd_apply(int dtype, int64_t M, int C, int ld, const void* x, const fl
     const size_t lds = ((size_t)(2 + 3 * nbranch) * C + (size_t)nbranch * 2 * 256) * sizeof(float);
     SV_REQUIRE(lds <= 64 * 1024, SV_E_SHAPE, "sv_bn_bwd_apply: C=%d too large", C);
     const int cv = C / 8;
-    if (256 % cv == 0 && (int64_t)grid * 256 >= cv) {     // every thread keeps one 8-channel group: coefficients in registers
-        DISPATCH_T(dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<T, true>), dim3(grid, groups), dim3(256), lds, (hipStream_t)stream, bnb_expand(p, groups, (int)sizeof(T))));
+    // every thread keeps one 8-channel group (coefficients in registers) when the block size is a multiple of C/8: 256
+    // threads for the power-of-two widths, 240 for the 160 / 320 / 640-channel tensors of WRN-28-10 (C/8 = 20, 40, 80) -- those
+    // took the LDS-coefficient path at 3.5 TB/s
+    const int nthr = 256 % cv == 0 ? 256 : (cv <= 256 ? 256 / cv * cv : 0);
+    if (nthr >= 192 && (int64_t)grid * nthr >= cv) {
+        DISPATCH_T(dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<T, true>), dim3(grid, groups), dim3(nthr), lds, (hipStream_t)stream, bnb_expand(p, groups, (int)sizeof(T))));
     } else {
         DISPATCH_T(dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<T, false>), dim3(grid, groups), dim3(256), lds, (hipStream_t)stream, bnb_expand(p, groups, (int)sizeof(T))));
     }
