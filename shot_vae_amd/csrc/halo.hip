@@ -724,7 +724,8 @@ int sv_halo_try(const sv_geom* g, int dtype, const sv_igemm_args* a, hipStream_t
         const int nt = multi ? 1 : (g->N % 32 == 0 ? 2 : 1), BN = 16 * nt;     // (four accumulator sets: 16-channel tiles)
         const size_t ldsp = ((size_t)c.HP * (g->Cin + 16) + (size_t)BN * (c.tslots * g->Cin + 16)) * es + 2 * BN * 4;
         const int nT = (g->B * g->Hq + c.TR - 1) / c.TR;
-        if (ldsp <= 72 * 1024 && c.HP * (g->Cin / 8) <= 256 * PMAXV && 256 % (g->Cin / 8) == 0 &&
+        // (at most two channel tiles: every tile re-stages the input region -- 16 -> 160 as five tiles ran 564 us against 302)
+        if (ldsp <= 72 * 1024 && c.HP * (g->Cin / 8) <= 256 * PMAXV && 256 % (g->Cin / 8) == 0 && (g->N + BN - 1) / BN <= 2 &&
             (sv_halo_all() || nT * sv_ngroups(a->groups) >= 1024)) {       // (a few tiles per block at least; tests: any size)
             if (dtype == SV_BF16) {
                 if (CC == 16) *rc = multi ? launch_halop_nt<bf16, 16, 4>(g, a, c, nt, ldsp, s) : launch_halop_nt<bf16, 16, 1>(g, a, c, nt, ldsp, s);
