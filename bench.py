@@ -53,6 +53,8 @@ def parse():
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher check without a GPU: the ranks rendezvous over gloo, agree on a max-reduced time and "
                          "rank 0 prints a JSON stub (tests/test_bench_launch_cpu.py)")
+    ap.add_argument("--disable", type=int, default=0,
+                    help="dispatcher mask SV_OPT_DISABLE_MASK (A/B runs of the specialised kernels; 0 = all enabled)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak (default): --batch per loader PER GPU; strong: --batch per loader in total, split over the GPUs")
     return ap.parse_args()
@@ -182,6 +184,8 @@ def main():
     import shot_vae_amd as S
     from shot_vae_amd import _lib as L
     from shot_vae_amd import dp
+    if a.disable:
+        L.call("sv_set_option", L.OPT_DISABLE_MASK, a.disable)
 
     K = a.classes
     if a.scaling == "strong":

@@ -9,9 +9,9 @@
 #pragma once
 #include "common.h"
 
-template <typename T, int NT>
-__device__ __forceinline__ void gemm_epilogue(const f32x4 (&acc)[NT][2], const int64_t (&obase)[2],
-                                              const bool (&oval)[2], int n0, int N, const sv_igemm_args& a,
+template <typename T, int NT, int MS = 2>
+__device__ __forceinline__ void gemm_epilogue(const f32x4 (&acc)[NT][MS], const int64_t (&obase)[MS],
+                                              const bool (&oval)[MS], int n0, int N, const sv_igemm_args& a,
                                               float* ssum /* LDS [2][16*NT], zeroed, visible */) {
     typedef typename V4<T>::type Q;
     constexpr int BN = 16 * NT;
@@ -38,7 +38,7 @@ __device__ __forceinline__ void gemm_epilogue(const f32x4 (&acc)[NT][2], const i
                 ers = *reinterpret_cast<const f32x4*>(a.ex_rstd + n);
             }
 #pragma unroll
-            for (int ms = 0; ms < 2; ++ms) {
+            for (int ms = 0; ms < MS; ++ms) {
                 if (!oval[ms]) continue;
                 f32x4 vv = acc[i][ms];
 #pragma unroll
@@ -101,3 +101,4 @@ __device__ __forceinline__ void gemm_epilogue(const f32x4 (&acc)[NT][2], const i
         }
     }
 }
+

@@ -5,7 +5,8 @@
 //   out[b, qy*osy+ooy, qx*osx+oox, n] = sum_{t,c} A(b,qy,qx,t,c) * W[n][t][c]
 //   A = LeakyReLU(x*scale[c]+shift[c])  (BatchNorm-apply prologue, zero outside the image)
 //
-// Tile: 128 output positions x (16*NT) channels x 32-deep k; 4 waves, wave w owns rows [32w,32w+32).
+// Tile: 64*MS output positions x (16*NT) channels x 32*KV-deep k; 4 waves, wave w owns rows [16 MS w, 16 MS (w+1)).
+// MS = 2 (128 rows) by default; MS = 4 (256 rows x 160 / 128 channels, two blocks per CU) for the wide layers.
 // Weights are the MFMA A-operand (rows = n) and activations the B-operand (cols = m), so that each
 // lane ends up with 4 consecutive channels of one output pixel -> 8/16-byte epilogue accesses.
 // Epilogue: +bias, +residual, either per-channel (sum, sumsq) for the next BatchNorm or the
@@ -18,17 +19,19 @@
 
 namespace {
 
-constexpr int BM = 128;
 constexpr int BK = 32;
 
 // KV = 32-deep k sub-chunks per loop iteration (one barrier per iteration).  KV = 2 for deep-K layers with few tiles
 // (the decoder, the stride-2 convs): those are bound by one global->LDS round trip per iteration, so twice the bytes
 // in flight and twice the MFMAs per barrier nearly halve their time.
-template <typename T, int NT, int KV>
-__global__ __launch_bounds__(256) void igemm_kernel(const sv_geom g, const sv_igemm_args_g A) {
+// MS = 16-row sub-tiles per wave: block tile = 64 MS output positions (128 by default; 256 x 160/128 channels for the
+// wide layers, whose small tiles were bound by the L2 -> LDS traffic of re-gathering the input per channel tile).
+template <typename T, int NT, int KV, int MS>
+__global__ __launch_bounds__(256, MS == 4 ? 2 : 1) void igemm_kernel(const sv_geom g, const sv_igemm_args_g A) {
     const sv_igemm_args& a = A.g[blockIdx.y];
     typedef typename V8<T>::type V;
     typedef typename V4<T>::type Q;
+    constexpr int BM = 64 * MS;
     constexpr int BN = 16 * NT;
     constexpr int NBV = (BN * 4 + 255) / 256;   // weight vectors per thread per 32-deep sub-chunk
     constexpr int BKK = BK * KV;
@@ -37,7 +40,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const sv_geom g, const sv_ig
     extern __shared__ __attribute__((aligned(16))) char smem[];
     T* As = reinterpret_cast<T*>(smem);           // [2][BM][LDK]
     T* Bs = As + 2 * BM * LDK;                    // [2][BN][LDK]
-    float* ssum = reinterpret_cast<float*>(Bs + 2 * BN * LDK);   // [2][BN]
+    // [2][BN] channel sums; the 256-row tiles (two blocks per CU: <= 80 KB each) put them over the A buffers after the k loop
+    float* ssum = MS == 4 ? reinterpret_cast<float*>(smem) : reinterpret_cast<float*>(Bs + 2 * BN * LDK);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int HWq = g.Hq * g.Wq;
@@ -67,18 +71,43 @@ __global__ __launch_bounds__(256) void igemm_kernel(const sv_geom g, const sv_ig
     const int nk = (Ktot + BKK - 1) / BKK;
     const T* __restrict__ X = reinterpret_cast<const T*>(a.x);
     const T* __restrict__ W = reinterpret_cast<const T*>(a.w) + P.w_off;
+#ifdef SV_IG_NO_XF      // (timing ablations: results are wrong by construction)
+    const bool has_pro = false;
+#else
     const bool has_pro = a.pro_scale != nullptr;
+#endif
 
-    if (tid < 2 * BN) ssum[tid] = 0.f;
-    if (BN > 128 && tid + 256 < 2 * BN) ssum[tid + 256] = 0.f;
+    // A phase without taps (three of the four output parities of a stride-2 1x1 data gradient) is exactly zero, and so
+    // are its contributions to the BatchNorm sums of either epilogue: plain 16-byte zero stores, no reads, no atomics.
+    if (ntap == 0 && !a.bias && !a.residual && g.ldo % 8 == 0) {
+        constexpr int VR = BN / 8;
+        V z;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) z[j] = (T)0.f;
+        T* __restrict__ O = reinterpret_cast<T*>(a.out);
+        for (int idx = tid; idx < BM * VR; idx += 256) {
+            const int row = idx / VR, vv = idx - row * VR;
+            const int m = mt * BM + row;
+            if (m >= M || n0 + 8 * vv >= g.N) continue;
+            const int b = m / HWq, r = m - b * HWq, qy = r / g.Wq, qx = r - qy * g.Wq;
+            *reinterpret_cast<V*>(O + ((int64_t)(b * g.Hout + qy * g.osy + P.ooy) * g.Wout + qx * g.osx + P.oox) * g.ldo +
+                                  n0 + 8 * vv) = z;
+        }
+        return;
+    }
+
+    if (MS != 4) {
+        if (tid < 2 * BN) ssum[tid] = 0.f;
+        if (BN > 128 && tid + 256 < 2 * BN) ssum[tid + 256] = 0.f;
+    }
 
     // ---- loader state -------------------------------------------------------------------------
     const int v = tid & 3;                 // 8-element k vector inside the 32-deep chunk
     const int lrow = tid >> 2;             // 0..63
-    int iy0[2], ix0[2], pixb[2];
-    bool mval[2];
+    int iy0[MS], ix0[MS], pixb[MS];
+    bool mval[MS];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < MS; ++i) {
         const int m = mt * BM + lrow + 64 * i;
         mval[i] = m < M;
         const int mm = mval[i] ? m : 0;
@@ -98,8 +127,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const sv_geom g, const sv_ig
         while (c[s] >= g.Cin) { c[s] -= g.Cin; ++tap[s]; }
     }
 
-    V ra[KV][2], rb[KV][NBV];
-    bool oka[KV][2];
+    V ra[KV][MS], rb[KV][NBV];
+    bool oka[KV][MS];
     f32x4 ps0[KV], ps1[KV], pt0[KV], pt1[KV];        // BN scale / shift of the chunk in flight (fetched WITH its data)
 
     V zero;
@@ -119,13 +148,18 @@ __global__ __launch_bounds__(256) void igemm_kernel(const sv_geom g, const sv_ig
                 pt1[s] = *reinterpret_cast<const f32x4*>(a.pro_shift + cc + 4);
             }
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < MS; ++i) {
                 const int iy = iy0[i] + dy, ix = ix0[i] + dx;
                 const bool ok = mval[i] && tap[s] < ntap && (unsigned)iy < (unsigned)g.Hin &&
                                 (unsigned)ix < (unsigned)g.Win;
                 oka[s][i] = ok;
                 const int iyc = min(max(iy, 0), g.Hin - 1), ixc = min(max(ix, 0), g.Win - 1);
+#ifdef SV_IG_NO_GA
+                const V val = zero;
+                asm volatile("" ::"v"(iyc), "v"(ixc));
+#else
                 const V val = *reinterpret_cast<const V*>(X + ((int64_t)(pixb[i] + iyc * g.Win + ixc) * g.ldx + cc));
+#endif
                 ra[s][i] = ok ? val : zero;
             }
             const int k8 = kc * BKK + BK * s + 8 * v;
@@ -134,7 +168,12 @@ __global__ __launch_bounds__(256) void igemm_kernel(const sv_geom g, const sv_ig
             for (int i = 0; i < NBV; ++i) {
                 const int nb = lrow + 64 * i;
                 const bool ok = nb < BN && n0 + nb < g.N && k8 < Ktot;
+#ifdef SV_IG_NO_GB
+                const V val = zero;
+                asm volatile("" ::"v"(k8c));
+#else
                 const V val = *reinterpret_cast<const V*>(W + (int64_t)min(n0 + nb, g.N - 1) * Ktot + k8c);
+#endif
                 rb[s][i] = ok ? val : zero;
             }
             // advance (tap, c) to this sub-chunk's position in the next iteration
@@ -150,7 +189,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const sv_geom g, const sv_ig
         for (int s = 0; s < KV; ++s) {
             if (has_pro) {
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
+                for (int i = 0; i < MS; ++i) {
                     V o;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
@@ -163,7 +202,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const sv_geom g, const sv_ig
                 }
             }
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < MS; ++i)
                 *reinterpret_cast<V*>(Ab + (lrow + 64 * i) * LDK + BK * s + 8 * v) = ra[s][i];
 #pragma unroll
             for (int i = 0; i < NBV; ++i) {
@@ -173,11 +212,11 @@ __global__ __launch_bounds__(256) void igemm_kernel(const sv_geom g, const sv_ig
         }
     };
 
-    f32x4 acc[NT][2];
+    f32x4 acc[NT][MS];
 #pragma unroll
     for (int i = 0; i < NT; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < MS; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int fr = lane & 15, fq = lane >> 4;
     if (nk > 0) {
@@ -188,18 +227,22 @@ __global__ __launch_bounds__(256) void igemm_kernel(const sv_geom g, const sv_ig
     for (int kc = 0; kc < nk; ++kc) {
         const int buf = kc & 1;
         if (kc + 1 < nk) load_global(kc + 1);   // in flight while this chunk's MFMAs run
-        const T* Ab = As + buf * BM * LDK + (32 * wave + fr) * LDK + 8 * fq;
+        const T* Ab = As + buf * BM * LDK + (16 * MS * wave + fr) * LDK + 8 * fq;
         const T* Bb = Bs + buf * BN * LDK + fr * LDK + 8 * fq;
 #pragma unroll
         for (int s = 0; s < KV; ++s) {
-            V af[2];
-            af[0] = *reinterpret_cast<const V*>(Ab + BK * s);
-            af[1] = *reinterpret_cast<const V*>(Ab + 16 * LDK + BK * s);
+            V af[MS];
+#pragma unroll
+            for (int j = 0; j < MS; ++j) af[j] = *reinterpret_cast<const V*>(Ab + 16 * j * LDK + BK * s);
 #pragma unroll
             for (int i = 0; i < NT; ++i) {
                 const V wf = *reinterpret_cast<const V*>(Bb + 16 * i * LDK + BK * s);
-                mma32(acc[i][0], wf, af[0]);
-                mma32(acc[i][1], wf, af[1]);
+#ifdef SV_IG_NO_MFMA
+                asm volatile("" ::"v"(wf[0]));
+#else
+#pragma unroll
+                for (int j = 0; j < MS; ++j) mma32(acc[i][j], wf, af[j]);
+#endif
             }
         }
         if (kc + 1 < nk) store_lds(buf ^ 1);
@@ -207,11 +250,15 @@ __global__ __launch_bounds__(256) void igemm_kernel(const sv_geom g, const sv_ig
     }
 
     // ---- epilogue ------------------------------------------------------------------------------
-    int64_t obase[2];
-    bool oval[2];
+    if (MS == 4) {          // (the loop ended with a barrier: the A buffers are free)
+        for (int i = tid; i < 2 * BN; i += 256) ssum[i] = 0.f;
+        __syncthreads();
+    }
+    int64_t obase[MS];
+    bool oval[MS];
 #pragma unroll
-    for (int ms = 0; ms < 2; ++ms) {
-        const int m = mt * BM + 32 * wave + 16 * ms + fr;
+    for (int ms = 0; ms < MS; ++ms) {
+        const int m = mt * BM + 16 * MS * wave + 16 * ms + fr;
         oval[ms] = m < M;
         const int mm = oval[ms] ? m : 0;
         const int b = mm / HWq;
@@ -220,26 +267,30 @@ __global__ __launch_bounds__(256) void igemm_kernel(const sv_geom g, const sv_ig
         const int qx = r - qy * g.Wq;
         obase[ms] = ((int64_t)(b * g.Hout + qy * g.osy + P.ooy) * g.Wout + qx * g.osx + P.oox) * g.ldo;
     }
-    gemm_epilogue<T, NT>(acc, obase, oval, n0, g.N, a, ssum);
+#ifdef SV_IG_NO_EPI
+    if (obase[0] == -12345) gemm_epilogue<T, NT, MS>(acc, obase, oval, n0, g.N, a, ssum);
+#else
+    gemm_epilogue<T, NT, MS>(acc, obase, oval, n0, g.N, a, ssum);
+#endif
 }
 
-template <typename T, int NT, int KV>
+template <typename T, int NT, int KV, int MS = 2>
 int launch_kv(const sv_geom* g, const sv_igemm_args* a, hipStream_t s) {
-    constexpr int BN = 16 * NT, LDK = BK * KV + 16;
+    constexpr int BM = 64 * MS, BN = 16 * NT, LDK = BK * KV + 16;
     const int M = g->B * g->Hq * g->Wq;
     const int nMt = (M + BM - 1) / BM;
     const int nNt = (g->N + BN - 1) / BN;
     const int grid = (nMt >= 64 ? ((nMt + 7) / 8) * 8 : nMt) * nNt * g->nphase;
-    const size_t lds = (size_t)2 * (BM + BN) * LDK * sizeof(T) + 2 * BN * sizeof(float);
+    const size_t lds = (size_t)2 * (BM + BN) * LDK * sizeof(T) + (MS == 4 ? 0 : 2 * BN * sizeof(float));
     static bool optin = false;
     if (lds > 64 * 1024 && !optin) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<T, NT, KV>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<T, NT, KV, MS>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return sv_check_launch("hipFuncSetAttribute(igemm)");
         optin = true;
     }
     sv_prof_begin(s);
-    hipLaunchKernelGGL((igemm_kernel<T, NT, KV>), dim3(grid, sv_ngroups(a->groups)), dim3(256), lds, s, *g, sv_expand_groups(*g, *a, (int)sizeof(T)));
+    hipLaunchKernelGGL((igemm_kernel<T, NT, KV, MS>), dim3(grid, sv_ngroups(a->groups)), dim3(256), lds, s, *g, sv_expand_groups(*g, *a, (int)sizeof(T)));
     sv_prof_end(s);
     return sv_check_launch("sv_igemm");
 }
@@ -282,7 +333,17 @@ extern "C" int sv_igemm(const sv_geom* g, int dtype, const sv_igemm_args* a, voi
         if (sv_halo_try(g, dtype, a, s, &rc)) return rc;
     }
     const int64_t M = (int64_t)g->B * g->Hq * g->Wq;
-    const int64_t mtiles = (M + BM - 1) / BM * g->nphase;
+    // wide layers (N a multiple of 160 / 128) with enough rows: 256-row tiles at two blocks per CU -- the input is gathered
+    // and BatchNorm-transformed once per 160 / 128 channels instead of once per 64 / 80 (measured on the WRN-28-10 stride-2
+    // 3x3 layers at 4 x 256 images: forward 798 -> 517 us, data gradient 1102 -> 820 us; tools/ig_ablate.sh)
+#ifndef SV_IG_NO_BIG
+    if (dtype == SV_BF16 && !sv_disabled(SV_K_IGEMM_BIG)) {
+        const int64_t mt256 = (M + 255) / 256 * g->nphase * sv_ngroups(a->groups);
+        if (g->N % 160 == 0 && mt256 * (g->N / 160) >= sv_wide_min_blocks()) return launch_kv<bf16, 10, 1, 4>(g, a, s);
+        if (g->N % 128 == 0 && mt256 * (g->N / 128) >= sv_wide_min_blocks()) return launch_kv<bf16, 8, 1, 4>(g, a, s);
+    }
+#endif
+    const int64_t mtiles = (M + 127) / 128 * g->nphase;
     // widest channel tile that still yields >= 2 blocks per CU; never below 32 channels unless N is
     const int N = g->N;
     int nt = 1;

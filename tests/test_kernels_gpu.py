@@ -210,6 +210,20 @@ def test_conv3x3_one_wave_per_simd(case):
         test_conv_dgrad_with_activation_backward("bf16", case)
 
 
+@pytest.mark.parametrize("case", [(5, 160, 320, 32, 3, 2, 1), (3, 320, 640, 16, 3, 2, 1), (5, 160, 320, 32, 1, 2, 0),
+                                  (3, 16, 160, 32, 3, 1, 1), (7, 16, 160, 32, 1, 1, 0), (2, 320, 160, 8, 3, 2, 1),
+                                  (5, 64, 128, 16, 3, 2, 1), (3, 128, 256, 8, 1, 2, 0), (3, 128, 128, 16, 1, 2, 0)])
+def test_generic_gemm_256_row_tiles(case):
+    """The 256-row x 160 / 128-channel tiles of the generic gather-GEMM (igemm.hip, MS = 4): the stride-2 3x3 convolutions
+    and 1x1 shortcuts of WRN-28-10 and its first layers; ragged row counts (B * Hq * Wq not a multiple of 256), k tails
+    (Cin * taps not a multiple of 32), one / two / four channel tiles; forward with every fusion and the data gradient
+    (four phases for stride 2, three of them without taps for the 1x1 shortcut: the zero-store path) with the
+    activation-backward epilogue."""
+    with L.options(wide_min_blocks=1, disable=L.K_HALO | L.K_HALOP):
+        test_conv_forward_fused("bf16", case)
+        test_conv_dgrad_with_activation_backward("bf16", case)
+
+
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
 @pytest.mark.parametrize("H,Cin,N,B", [(1, 1024, 512, 6), (2, 512, 256, 4), (8, 128, 64, 3), (16, 64, 16, 2)])
 def test_convT_forward_and_dgrad(dt, H, Cin, N, B):

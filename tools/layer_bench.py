@@ -32,6 +32,9 @@ def timed(fn, iters=int(os.environ.get("SV_BENCH_ITERS", "20")), warm=int(os.env
 
 
 def bench_layer(B, Cin, H, N, what=("fwd", "dgrad", "wgrad")):
+    KS, STR = int(os.environ.get("SV_BENCH_K", "3")), int(os.environ.get("SV_BENCH_S", "1"))     # kernel size, stride
+    if KS != 3 or STR != 1:
+        return bench_odd_layer(B, Cin, H, N, KS, STR, what)
     d = torch.device("cuda:0")
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     bf = torch.bfloat16
@@ -77,6 +80,59 @@ def bench_layer(B, Cin, H, N, what=("fwd", "dgrad", "wgrad")):
                                             C.c_void_p(ws.data_ptr()), ws.numel(), 1, st))
     for k, us in res.items():
         print(f"B={B} Cin={Cin} N={N} H={H} {k:6s} {us:9.1f} us  {flops / us / 1e6:8.1f} TFLOP/s  "
+              f"{flops / us / 1e-6 / PEAK:6.3f} of bf16 MFMA peak", flush=True)
+    return res
+
+
+def bench_odd_layer(B, Cin, H, N, KS, STR, what):
+    """The other conv layers (stride 2, 1x1): SV_BENCH_K / SV_BENCH_S; H = input size."""
+    d = torch.device("cuda:0")
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    bf = torch.bfloat16
+    pad = KS // 2
+    Ho = (H + 2 * pad - KS) // STR + 1
+    T = KS * KS
+    x = torch.randn(B, H, H, Cin, device=d).to(bf)
+    dy = torch.randn(B, Ho, Ho, N, device=d).to(bf)
+    master = (torch.randn(N, T, Cin, device=d) / (T * Cin) ** 0.5).contiguous()
+    flops = 2.0 * B * Ho * Ho * T * Cin * N
+    R = int(os.environ.get("SV_BENCH_R", "8"))
+    res = {}
+    if "fwd" in what:
+        g = G.conv_like(B, H, H, Cin, N, KS, STR, pad)
+        wp = torch.zeros(G.packed_size(g), dtype=bf, device=d)
+        L.call("sv_repack", L.SV_BF16, C.c_void_p(master.data_ptr()), N, T, Cin, 0, C.byref(g), C.c_void_p(wp.data_ptr()), st)
+        out = torch.empty(B, Ho, Ho, N, dtype=bf, device=d)
+        sc, sh = torch.rand(Cin, device=d) + 0.5, torch.randn(Cin, device=d) * 0.3
+        stats = torch.zeros(R, 2 * N, device=d)
+        a = L.SvIgemmArgs()
+        a.x, a.w, a.out = x.data_ptr(), wp.data_ptr(), out.data_ptr()
+        a.pro_scale, a.pro_shift, a.pro_slope = sc.data_ptr(), sh.data_ptr(), 0.01
+        a.stats, a.replicas = stats.data_ptr(), R
+        res["fwd"] = timed(lambda: L.call("sv_igemm", C.byref(g), L.SV_BF16, C.byref(a), st))
+    if "dgrad" in what:
+        g = G.convT_like(B, Ho, Ho, N, Cin, KS, STR, pad)
+        wp = torch.zeros(G.packed_size(g), dtype=bf, device=d)
+        L.call("sv_repack", L.SV_BF16, C.c_void_p(master.data_ptr()), N, T, Cin, 1, C.byref(g), C.c_void_p(wp.data_ptr()), st)
+        out = torch.empty(B, H, H, Cin, dtype=bf, device=d)
+        vec = [torch.rand(Cin, device=d) + 0.5 for _ in range(4)]
+        bs = torch.zeros(R, 2 * Cin, device=d)
+        a = L.SvIgemmArgs()
+        a.x, a.w, a.out = dy.data_ptr(), wp.data_ptr(), out.data_ptr()
+        a.ex, a.ex_scale, a.ex_shift, a.ex_mean, a.ex_rstd = [t.data_ptr() for t in [x] + vec]
+        a.ex_slope, a.bsums, a.replicas = 0.01, bs.data_ptr(), R
+        res["dgrad"] = timed(lambda: L.call("sv_igemm", C.byref(g), L.SV_BF16, C.byref(a), st))
+    if "wgrad" in what:
+        g = G.conv_like(B, H, H, Cin, N, KS, STR, pad)
+        dw = torch.zeros(N, T, Cin, device=d)
+        sc, sh = torch.rand(Cin, device=d) + 0.5, torch.randn(Cin, device=d) * 0.3
+        ws = torch.empty(16 << 20, device=d)
+        res["wgrad"] = timed(lambda: L.call("sv_wgrad", C.byref(g), L.SV_BF16, C.c_void_p(x.data_ptr()),
+                                            C.c_void_p(sc.data_ptr()), C.c_void_p(sh.data_ptr()), C.c_float(0.01),
+                                            C.c_void_p(dy.data_ptr()), C.c_void_p(dw.data_ptr()), 0, 1,
+                                            C.c_void_p(ws.data_ptr()), ws.numel(), 1, st))
+    for k, us in res.items():
+        print(f"B={B} Cin={Cin} N={N} H={H} k={KS} s={STR} {k:6s} {us:9.1f} us  {flops / us / 1e6:8.1f} TFLOP/s  "
               f"{flops / us / 1e-6 / PEAK:6.3f} of bf16 MFMA peak", flush=True)
     return res
 
