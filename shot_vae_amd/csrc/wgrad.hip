@@ -244,6 +244,213 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const sv_geom g, const sv_wg
     }
 }
 
+// Cooperative wide variant (bf16, transposing reads): one block owns a (32*TNW) x (one tap) x (32*TCW) tile of dW -- 160 x
+// 160 for the WRN-28-10 odd layers -- and all four waves share each 32-row k chunk of dy and A (wave (wn, wc) multiplies the
+// (16 TNW) x (16 TCW) quarter).  The 64 x 64 wave-private tiles above re-read every row of dy and x once per (64 channels
+// out) x (tap) x (64 channels in): 9 GB of L2 -> LDS traffic on the 160 -> 320 stride-2 3x3 layer at 4 x 256 images, which
+// is what bounded it (1.26 ms); here the same layer moves a third of that.
+template <int TNW, int TCW, bool FAST>
+__global__ __launch_bounds__(256, 2) void wgradc_kernel(const sv_geom g, const sv_wg_g<wg_params> PG) {
+    const wg_params& p = PG.g[blockIdx.y];
+    typedef bf16 T;
+    typedef bf16x8 V;
+    constexpr int BNb = 32 * TNW, BCb = 32 * TCW;
+    constexpr int LDN = BNb + 8, LDC = BCb + 8;
+    constexpr int VRN = BNb / 8, VRC = BCb / 8;                   // 16-byte vectors per row
+    constexpr int NVY = (RW * VRN + 255) / 256, NVX = (RW * VRC + 255) / 256;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* const Ys = reinterpret_cast<T*>(smem);                     // [2][RW][LDN]
+    T* const Xs = Ys + 2 * RW * LDN;                              // [2][RW][LDC]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = wave >> 1, wc = wave & 1;
+
+    const int M = g.B * g.Hq * g.Wq;
+    const int nNt = (g.N + BNb - 1) / BNb;
+    const int nCt = (g.Cin + BCb - 1) / BCb;
+    const int tiles = nNt * p.ntap_total * nCt;
+    const int L = blockIdx.x;
+    int tile, split;
+    if (p.splits % 8 == 0) {        // blocks L and L + 8 share an XCD: all tiles of one m-range read dy / x through one L2
+        const int xcd = L & 7, slot = L >> 3;
+        tile = slot % tiles;
+        split = (slot / tiles) * 8 + xcd;
+    } else {
+        tile = L % tiles;
+        split = L / tiles;
+    }
+    const int ct = tile % nCt;
+    int tapg = (tile / nCt) % p.ntap_total;
+    const int n0 = (tile / (nCt * p.ntap_total)) * BNb;
+    const int c0 = ct * BCb;
+    int ph = 0;
+    while (tapg >= g.phase[ph].ntap) { tapg -= g.phase[ph].ntap; ++ph; }
+    const sv_phase& P = g.phase[ph];
+    const int dy = P.dy[tapg], dx = P.dx[tapg], torig = P.torig[tapg];
+    const int ooy = P.ooy, oox = P.oox;
+
+    const T* __restrict__ X = reinterpret_cast<const T*>(p.x);
+    const T* __restrict__ DY = reinterpret_cast<const T*>(p.dy);
+    const bool has_pro = p.pro_scale != nullptr;
+    const int m_begin = split * p.m_per;
+    const int m_end = min(M, m_begin + p.m_per);
+    if (m_end <= m_begin) return;
+
+    // loader slots: vector tid + 256 i of the [RW][VRN] / [RW][VRC] chunk
+    int yrow[NVY], yv[NVY], xrow[NVX], xv[NVX];
+    bool yon[NVY], xon[NVX];
+#pragma unroll
+    for (int i = 0; i < NVY; ++i) {
+        const int idx = tid + 256 * i;
+        yrow[i] = idx / VRN;
+        yv[i] = idx - yrow[i] * VRN;
+        yon[i] = idx < RW * VRN && n0 + 8 * yv[i] < g.N;
+        if (idx >= RW * VRN) yrow[i] = 0, yv[i] = 0;
+    }
+#pragma unroll
+    for (int i = 0; i < NVX; ++i) {
+        const int idx = tid + 256 * i;
+        xrow[i] = idx / VRC;
+        xv[i] = idx - xrow[i] * VRC;
+        xon[i] = idx < RW * VRC && c0 + 8 * xv[i] < g.Cin;
+        if (idx >= RW * VRC) xrow[i] = 0, xv[i] = 0;
+    }
+    // two register stages: the loads of step it + 2 are issued before the MFMAs of step it (a step's 25 MFMAs per wave are
+    // ~0.2 us, a gather round trip 1.5-2 us: one stage ahead left the block waiting on every step)
+    struct Stage { V ry[NVY], rx[NVX]; bool okx[NVX]; } SA, SB;
+    V zero;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) zero[j] = (T)0.f;
+    auto load_global = [&](Stage& S, int mbase) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NVY; ++i) {
+            const int m = mbase + yrow[i];
+            const bool ok = m < m_end && yon[i];
+            int b, qy, qx;
+            decode_m<FAST>(g, p, min(m, m_end - 1), b, qy, qx);
+            const int64_t op = (int64_t)(b * g.Hout + qy * g.osy + ooy) * g.Wout + qx * g.osx + oox;
+            const V val = *reinterpret_cast<const V*>(DY + op * g.ldo + (yon[i] ? n0 + 8 * yv[i] : 0));
+            S.ry[i] = ok ? val : zero;
+        }
+#pragma unroll
+        for (int i = 0; i < NVX; ++i) {
+            const int m = mbase + xrow[i];
+            int b, qy, qx;
+            decode_m<FAST>(g, p, min(m, m_end - 1), b, qy, qx);
+            const int iy = qy * g.sy + dy, ix = qx * g.sx + dx;
+            const bool ok = m < m_end && xon[i] && (unsigned)iy < (unsigned)g.Hin && (unsigned)ix < (unsigned)g.Win;
+            const int iyc = min(max(iy, 0), g.Hin - 1), ixc = min(max(ix, 0), g.Win - 1);
+            const V val = *reinterpret_cast<const V*>(X + ((int64_t)(b * g.Hin + iyc) * g.Win + ixc) * g.ldx +
+                                                      (xon[i] ? c0 + 8 * xv[i] : 0));
+            S.okx[i] = ok;
+            S.rx[i] = ok ? val : zero;
+        }
+    };
+    auto store_lds = [&](const Stage& S, int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NVY; ++i)
+            if (tid + 256 * i < RW * VRN) *reinterpret_cast<V*>(Ys + (buf * RW + yrow[i]) * LDN + 8 * yv[i]) = S.ry[i];
+#pragma unroll
+        for (int i = 0; i < NVX; ++i) {
+            V o = S.rx[i];
+            if (has_pro && S.okx[i]) {
+                const int cc = c0 + 8 * xv[i];
+                const f32x4 s0 = *reinterpret_cast<const f32x4*>(p.pro_scale + cc), s1 = *reinterpret_cast<const f32x4*>(p.pro_scale + cc + 4);
+                const f32x4 t0 = *reinterpret_cast<const f32x4*>(p.pro_shift + cc), t1 = *reinterpret_cast<const f32x4*>(p.pro_shift + cc + 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    o[j] = (T)act_fwd(to_f(S.rx[i][j]) * s0[j] + t0[j], p.pro_slope);
+                    o[j + 4] = (T)act_fwd(to_f(S.rx[i][j + 4]) * s1[j] + t1[j], p.pro_slope);
+                }
+            }
+            if (tid + 256 * i < RW * VRC) *reinterpret_cast<V*>(Xs + (buf * RW + xrow[i]) * LDC + 8 * xv[i]) = o;
+        }
+    };
+
+    f32x4 acc[TNW][TCW];
+#pragma unroll
+    for (int i = 0; i < TNW; ++i)
+#pragma unroll
+        for (int j = 0; j < TCW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int niter = (m_end - m_begin + RW - 1) / RW;
+    // step it: [loads of it + 2 -> the stage step it's data came from] [MFMAs on LDS buffer it & 1] [stage of it + 1 -> LDS]
+    auto step = [&](int it, Stage& Snext, Stage& Sfar) __attribute__((always_inline)) {
+        const int buf = it & 1;
+        if (it + 2 < niter) load_global(Sfar, m_begin + (it + 2) * RW);
+        V fy[TNW], fx[TCW];
+#pragma unroll
+        for (int i = 0; i < TNW; ++i) fy[i] = frag_t<true>(Ys + buf * RW * LDN, LDN, 16 * (TNW * wn + i), lane);
+#pragma unroll
+        for (int j = 0; j < TCW; ++j) fx[j] = frag_t<true>(Xs + buf * RW * LDC, LDC, 16 * (TCW * wc + j), lane);
+#pragma unroll
+        for (int i = 0; i < TNW; ++i)
+#pragma unroll
+            for (int j = 0; j < TCW; ++j) mma32(acc[i][j], fy[i], fx[j]);
+        if (it + 1 < niter) store_lds(Snext, buf ^ 1);
+        __syncthreads();
+    };
+    load_global(SA, m_begin);
+    store_lds(SA, 0);
+    if (niter > 1) load_global(SB, m_begin + RW);
+    __syncthreads();
+    for (int it = 0; it < niter; it += 2) {
+        step(it, SB, SA);                         // step it + 1 is in SB; SA (step it, already in LDS) takes step it + 2
+        if (it + 1 < niter) step(it + 1, SA, SB);
+    }
+    // every wave owns its quarter of the tile: one global atomic per element per block
+    const int fr = lane & 15, fq = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < TNW; ++i)
+#pragma unroll
+        for (int j = 0; j < TCW; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + 16 * (TNW * wn + i) + 4 * fq + r, c = c0 + 16 * (TCW * wc + j) + fr;
+                if (n < g.N && c < g.Cin) atomicAdd(p.dw + ((int64_t)n * g.T_orig + torig) * g.Cin + c, acc[i][j][r]);
+            }
+}
+
+template <int TNW, int TCW>
+int launch_c(const sv_geom* g, wg_params p, int64_t M, hipStream_t s) {
+    constexpr int BNb = 32 * TNW, BCb = 32 * TCW;
+    const int nNt = (g->N + BNb - 1) / BNb, nCt = (g->Cin + BCb - 1) / BCb;
+    const int tiles = nNt * p.ntap_total * nCt;
+    // two blocks per CU over the whole (batched) launch, at least 1024 rows per block
+    int64_t want = (512 / p.groups + tiles - 1) / tiles;
+    const int64_t maxs = (M + 1023) / 1024;
+    if (want > maxs) want = maxs;
+    if (want < 1) want = 1;
+    int splits = (int)want;
+    if (splits >= 8 || (maxs >= 8 && tiles * p.groups >= 32)) {
+        // a multiple of 8 (XCD-affine mapping): of the three from ~one block per slot upwards, the one that leaves the
+        // smallest idle tail on the 512 block slots
+        const int k0 = splits >= 8 ? splits / 8 * 8 : 8;
+        int best = k0;
+        double beste = 0.;
+        for (int k = k0; k <= k0 + 16 && (k == k0 || k <= maxs); k += 8) {
+            const int64_t blocks = (int64_t)k * tiles * p.groups;
+            if (k > k0 && blocks > 2048) break;
+            const double e = (double)blocks / (double)((blocks + 511) / 512 * 512);
+            if (e > beste + 0.02) beste = e, best = k;
+        }
+        splits = best;
+    }
+    int64_t m_per = (M + splits - 1) / splits;
+    m_per = (m_per + RW - 1) / RW * RW;
+    if (splits < 8) splits = (int)((M + m_per - 1) / m_per);
+    p.splits = splits;
+    p.m_per = (int)m_per;
+    const size_t lds = (size_t)2 * RW * (BNb + 8 + BCb + 8) * sizeof(bf16);
+    sv_prof_begin(s);
+    if (p.hwsh >= 0)
+        hipLaunchKernelGGL((wgradc_kernel<TNW, TCW, true>), dim3(splits * tiles, p.groups), dim3(256), lds, s, *g, sv_expand_wg(*g, p, p.groups, 2));
+    else
+        hipLaunchKernelGGL((wgradc_kernel<TNW, TCW, false>), dim3(splits * tiles, p.groups), dim3(256), lds, s, *g, sv_expand_wg(*g, p, p.groups, 2));
+    sv_prof_end(s);
+    return sv_check_launch("sv_wgrad(wide)");
+}
+
 int ilog2_exact(int v) {
     if (v <= 0 || (v & (v - 1))) return -1;
     int s = 0;
@@ -317,6 +524,9 @@ extern "C" int sv_wgrad(const sv_geom* g, int dtype, const void* x, const float*
     for (int i = 0; i < g->nphase; ++i) p.ntap_total += g->phase[i].ntap;
     if (p.ntap_total == 0) return SV_OK;
     const int64_t M = (int64_t)g->B * g->Hq * g->Wq;
+    if (dtype == SV_BF16 && use_tr && splits <= 0 && !sv_disabled(SV_K_WGRAD_WIDE) && g->N % 160 == 0 && g->Cin % 160 == 0 &&
+        M * p.groups >= (int64_t)256 * sv_wide_min_blocks())
+        return launch_c<5, 5>(g, p, M, (hipStream_t)stream);
     // tile: the widest of {64,32,16} that divides; fp32 is capped at 32 (LDS budget)
     auto pick = [&](int n) { int t = (n % 64 == 0) ? 4 : (n % 32 == 0 ? 2 : 1); if (n >= 64 && t == 1) t = (n % 32 == 0) ? 2 : 1; return t; };
     int tn = pick(g->N), tc = pick(g->Cin);

@@ -796,6 +796,48 @@ def test_tap_fused_wgrad_conv(case):
     assert rel(dw, dw2) < 2e-3, rel(dw, dw2)             # against the generic kernel on the same bf16 operands
 
 
+@pytest.mark.parametrize("case", [(5, 160, 320, 32, 3, 2, 1), (3, 320, 640, 16, 3, 2, 1), (7, 160, 320, 32, 1, 2, 0),
+                                  (3, 320, 160, 8, 3, 2, 1), (9, 160, 160, 8, 1, 1, 0)])
+def test_wide_cooperative_wgrad(case):
+    """The 160 x 160 cooperative tiles of the generic weight gradient (wgrad.hip, wgradc_kernel: the stride-2 3x3 layers and
+    1x1 shortcuts of WRN-28-10) against torch and against the 64 x 64 wave-private tiles; plain (accumulating twice) and
+    batched over three groups with their own BatchNorm coefficients; m-ranges that are not multiples of 32 rows."""
+    B, Cin, N, H, k, stride, pad = case
+    code, tdt, tol = DT["bf16"]
+    torch.manual_seed(6)
+    d = dev()
+    Gn = 3
+    x = bq(torch.randn(Gn * B, Cin, H, H), "bf16")
+    scale, shift = torch.rand(Gn, Cin) + 0.5, torch.randn(Gn, Cin) * 0.3
+    Ho = (H + 2 * pad - k) // stride + 1
+    dy = bq(torch.randn(Gn * B, N, Ho, Ho), "bf16")
+    wref = torch.zeros(N, Cin, k, k)
+    for gi in range(Gn):
+        sl = slice(gi * B, (gi + 1) * B)
+        a = bq(F.leaky_relu(x[sl] * scale[gi][None, :, None, None] + shift[gi][None, :, None, None], 0.01), "bf16")
+        wref += torch.nn.grad.conv2d_weight(a, (N, Cin, k, k), dy[sl], stride, pad)
+    g = G.conv_like(B, H, H, Cin, N, k, stride, pad)
+    xd, dyd = nhwc(x).to(d, tdt), nhwc(dy).to(d, tdt)
+    sc, sh = scale.to(d).contiguous(), shift.to(d).contiguous()
+    ws = torch.full((16 * 1024 * 1024,), float("nan"), device=d)
+    with L.options(wide_min_blocks=1):
+        dw = torch.zeros(N, k * k, Cin, device=d)
+        L.call("sv_wgrad", C.byref(g), code, p(xd), p(sc), p(sh), 0.01, p(dyd), p(dw), 0, 1, p(ws), ws.numel(), Gn, st())
+        dw2 = torch.zeros(N, k * k, Cin, device=d)
+        with L.options(disable=L.K_WGRAD_WIDE):
+            L.call("sv_wgrad", C.byref(g), code, p(xd), p(sc), p(sh), 0.01, p(dyd), p(dw2), 0, 1, p(ws), ws.numel(), Gn, st())
+        g1 = G.conv_like(Gn * B, H, H, Cin, N, k, stride, pad)          # one group, no prologue, two accumulating calls
+        dw3 = torch.zeros(N, k * k, Cin, device=d)
+        for _ in range(2):
+            L.call("sv_wgrad", C.byref(g1), code, p(xd), None, None, 0.01, p(dyd), p(dw3), 0, 1, None, 0, 1, st())
+    torch.cuda.synchronize()
+    got = dw.cpu().view(N, k, k, Cin).permute(0, 3, 1, 2)
+    assert rel(got, wref) < tol, rel(got, wref)
+    assert rel(dw, dw2) < 2e-3, rel(dw, dw2)
+    w3 = torch.nn.grad.conv2d_weight(x, (N, Cin, k, k), dy, stride, pad)
+    assert rel(dw3.cpu().view(N, k, k, Cin).permute(0, 3, 1, 2) / 2, w3) < tol
+
+
 @pytest.mark.parametrize("H,Cin,N,B", [(4, 256, 128, 32), (8, 128, 64, 16), (16, 64, 16, 8)])
 def test_tap_fused_wgrad_convT(H, Cin, N, B):
     """... and on the ConvTranspose2d(4, 2, 1) decoder layers (four phases of dy, one input region)."""
