@@ -219,7 +219,7 @@ int sv_repack(int dtype, const float* master, int N, int T_orig, int C, int tran
               const sv_geom* g, void* dst, void* stream);
 
 /* All packs of a network in one launch (68 sv_repack launches per optimizer step otherwise).  jobs: DEVICE array, one
- * entry per (layer, direction, phase) with taps, sorted by block0; a job owns ceil(size / 256) consecutive blocks from
+ * entry per (layer, direction, phase) with taps, sorted by block0; a job owns ceil(size / 1024) consecutive blocks from
  * block0; total_blocks = their sum.  Offsets are in elements from master_base (fp32) / dst_base (`dtype`).             */
 typedef struct {
     int64_t master_off, dst_off, size;      /* size = N * C * ntap elements of this phase's pack                     */

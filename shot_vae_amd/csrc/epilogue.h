@@ -9,6 +9,17 @@
 #pragma once
 #include "common.h"
 
+// sum over the 16 lanes of a DPP row (= the 16 pixels of an accumulator sub-tile), result in every lane: four rotate-adds on
+// the VALU (row_ror:8,4,2,1) instead of four ds_bpermute round trips per value -- the shuffles were ~10 % of the generic
+// kernels on the wide layers (tools/ig_ablate.sh)
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));
+    return v;
+}
+
 template <typename T, int NT, int MS = 2>
 __device__ __forceinline__ void gemm_epilogue(const f32x4 (&acc)[NT][MS], const int64_t (&obase)[MS],
                                               const bool (&oval)[MS], int n0, int N, const sv_igemm_args& a,
@@ -75,11 +86,8 @@ __device__ __forceinline__ void gemm_epilogue(const f32x4 (&acc)[NT][MS], const 
         if (want_sums) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) {
-                    s1[r] += __shfl_xor(s1[r], o);
-                    s2[r] += __shfl_xor(s2[r], o);
-                }
+                s1[r] = row16_sum(s1[r]);
+                s2[r] = row16_sum(s2[r]);
             }
             if (fr == 0 && nval) {
 #pragma unroll

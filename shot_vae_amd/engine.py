@@ -388,7 +388,7 @@ class Engine:
                         j.N, j.T_orig, j.C, j.transpose, j.ntap, j.block0 = cv.N, cv.T, cv.Cin, tr, P.ntap, b0
                         for t in range(L.MAX_TAPS):
                             j.torig[t] = P.torig[t]
-                        b0 += (j.size + 255) // 256
+                        b0 += (j.size + 1023) // 1024
                         jobs.append(j)
             arr = (L.SvRepackJob * len(jobs))(*jobs)
             raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.param.device)
