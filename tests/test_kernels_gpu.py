@@ -752,6 +752,15 @@ def test_halo_kernel_conv_cases(dt, case):
         test_conv_dgrad_with_activation_backward(dt, case)
 
 
+@pytest.mark.parametrize("case", [(3, 16, 160, 32, 3, 1, 1), (5, 16, 128, 16, 3, 1, 1), (2, 32, 320, 8, 3, 1, 1)])
+def test_halo_kernel_thin_output_default_dispatch(case):
+    """Default dispatch (no option): the data gradient of a 3x3 layer with 16 / 32 input and >= 128 output channels -- few
+    output channels of the gather-GEMM, many input channels (first block of WRN-28-10) -- takes the channel-chunked LDS-halo
+    kernel; the forward of the same layer is covered alongside."""
+    test_conv_dgrad_with_activation_backward("bf16", case)
+    test_conv_forward_fused("bf16", case)
+
+
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
 @pytest.mark.parametrize("H,Cin,N,B", [(2, 512, 256, 4), (4, 256, 128, 4), (8, 128, 64, 3), (16, 64, 16, 2)])
 def test_halo_kernel_convT_cases(dt, H, Cin, N, B):

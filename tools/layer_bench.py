@@ -138,6 +138,10 @@ def bench_odd_layer(B, Cin, H, N, KS, STR, what):
 
 
 if __name__ == "__main__":
+    if os.environ.get("SV_BENCH_HALO_ALL"):             # A/B: let the LDS-halo kernels take every layer they can run
+        L.call("sv_set_option", L.OPT_HALO_ALL, 1)
+    if os.environ.get("SV_BENCH_DISABLE"):
+        L.call("sv_set_option", L.OPT_DISABLE_MASK, int(os.environ["SV_BENCH_DISABLE"]))
     if len(sys.argv) >= 5:
         B, Cc, H, N = map(int, sys.argv[1:5])
         bench_layer(B, Cc, H, N, tuple(sys.argv[5:]) or ("fwd", "dgrad", "wgrad"))
