@@ -221,12 +221,13 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bnb_params_g PG
     const int c_step = (int)(gsz - m_step * cv) * 8;          // 0 in the REG case
     for (int64_t i = gtid; i < total; i += gsz) {
         const int64_t off = m * p.ld + c;
-        const V xv = *reinterpret_cast<const V*>(X + off);
+        // streamed once: non-temporal loads (5.0 -> 5.16 TB/s; a non-temporal store of dx costs its consumer as much)
+        const V xv = __builtin_nontemporal_load(reinterpret_cast<const V*>(X + off));
         V gv[2];
-        gv[0] = *reinterpret_cast<const V*>(reinterpret_cast<const T*>(p.br[0].g) + off);
-        if (p.nbranch > 1) gv[1] = *reinterpret_cast<const V*>(reinterpret_cast<const T*>(p.br[1].g) + off);
+        gv[0] = __builtin_nontemporal_load(reinterpret_cast<const V*>(reinterpret_cast<const T*>(p.br[0].g) + off));
+        if (p.nbranch > 1) gv[1] = __builtin_nontemporal_load(reinterpret_cast<const V*>(reinterpret_cast<const T*>(p.br[1].g) + off));
         V rv;
-        if (R) rv = *reinterpret_cast<const V*>(R + off);
+        if (R) rv = __builtin_nontemporal_load(reinterpret_cast<const V*>(R + off));
         float o[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
