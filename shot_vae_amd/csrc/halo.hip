@@ -16,7 +16,13 @@
 //   * ends with the fused epilogue of sv_igemm (bias, residual, next-BatchNorm statistics or activation-backward +
 //     BatchNorm-backward sums), the per-channel sums kept in registers over the phases and flushed once.
 // With 16 input channels (the stem, the first block, the last decoder gradient) one 32-deep MFMA k step carries TWO taps.
-// Same sv_geom / packed weights / sv_igemm_args contract as sv_igemm: a drop-in fast path inside it (SV_K_HALO disables).
+// Two kernels: halop_kernel (persistent blocks, ALL input channels and the weights of every tap LDS-resident, two-stage
+// register prefetch of the next tile -- the form that pays: thin layers with Cin <= 64 and at most two channel tiles) and
+// halo_kernel (one tile per block, channel-chunked; dispatched only where measured faster than igemm_kernel: the
+// ConvTranspose 128 -> 64 forward and thin-OUTPUT 3x3 layers such as the 160 -> 16 data gradient).  sv_halo_try holds the
+// rules; SV_OPT_HALO_ALL lets both take everything they can run (tests, A/B runs).
+// Same sv_geom / packed weights / sv_igemm_args contract as sv_igemm: a drop-in fast path inside it (SV_K_HALO / SV_K_HALOP
+// disable).
 #include <stdlib.h>
 
 #include "common.h"
