@@ -26,7 +26,11 @@ constexpr int BK = 32;
 // in flight and twice the MFMAs per barrier nearly halve their time.
 // MS = 16-row sub-tiles per wave: block tile = 64 MS output positions (128 by default; 256 x 160/128 channels for the
 // wide layers, whose small tiles were bound by the L2 -> LDS traffic of re-gathering the input per channel tile).
-template <typename T, int NT, int KV, int MS>
+// AL: Cin is a multiple of the k depth of an iteration, so an iteration never straddles a tap: tap and channel offset are
+// block-uniform (scalar registers), the gather addresses of a tap are computed once per tap instead of once per iteration
+// (the loop of the round-1 loader issued ~285 VALU instructions per 40 MFMAs on the wide layers -- the SQ counters showed
+// the kernel VALU-issue-bound: tools/pmc_sq.py).
+template <typename T, int NT, int KV, int MS, bool AL>
 __global__ __launch_bounds__(256, MS == 4 ? 2 : 1) void igemm_kernel(const sv_geom g, const sv_igemm_args_g A) {
     const sv_igemm_args& a = A.g[blockIdx.y];
     typedef typename V8<T>::type V;
@@ -134,8 +138,74 @@ __global__ __launch_bounds__(256, MS == 4 ? 2 : 1) void igemm_kernel(const sv_ge
     V zero;
 #pragma unroll
     for (int j = 0; j < 8; ++j) zero[j] = (T)0.f;
-    // Branch-free loader: clamped addresses, unconditional loads (all in flight together), select.
-    auto load_global = [&](int kc) {
+    // ---- aligned loader state (AL): per-row gather pointer and validity of the CURRENT tap, weight row pointers ----------
+    const T* pa[MS];
+    bool okr[MS];
+    const T* pw[NBV];
+    bool wok[NBV];
+    int tapu = 0, cu = 0;                   // block-uniform: tap and first channel of the next iteration to load
+    auto set_tap = [&](int t) {
+        const int tt = t < SV_MAX_TAPS ? t : SV_MAX_TAPS - 1;
+        const int dy = tap_off(pdy, tt), dx = tap_off(pdx, tt);
+#pragma unroll
+        for (int i = 0; i < MS; ++i) {
+            const int iy = iy0[i] + dy, ix = ix0[i] + dx;
+            okr[i] = mval[i] && t < ntap && (unsigned)iy < (unsigned)g.Hin && (unsigned)ix < (unsigned)g.Win;
+            const int iyc = min(max(iy, 0), g.Hin - 1), ixc = min(max(ix, 0), g.Win - 1);
+            pa[i] = X + ((int64_t)(pixb[i] + iyc * g.Win + ixc) * g.ldx + 8 * v);
+        }
+    };
+    if (AL) {
+        set_tap(0);
+#pragma unroll
+        for (int i = 0; i < NBV; ++i) {
+            const int nb = lrow + 64 * i;
+            wok[i] = nb < BN && n0 + nb < g.N;
+            pw[i] = W + (int64_t)min(n0 + nb, g.N - 1) * Ktot + 8 * v;
+        }
+    }
+    auto load_aligned = [&](int kc) {
+#pragma unroll
+        for (int s = 0; s < KV; ++s) {
+            const int cs = cu + BK * s;                                   // uniform
+            if (has_pro) {
+                const float* sc = a.pro_scale + cs + 8 * v;
+                const float* sh = a.pro_shift + cs + 8 * v;
+                ps0[s] = *reinterpret_cast<const f32x4*>(sc);
+                ps1[s] = *reinterpret_cast<const f32x4*>(sc + 4);
+                pt0[s] = *reinterpret_cast<const f32x4*>(sh);
+                pt1[s] = *reinterpret_cast<const f32x4*>(sh + 4);
+            }
+#pragma unroll
+            for (int i = 0; i < MS; ++i) {
+                oka[s][i] = okr[i];
+#ifdef SV_IG_NO_GA
+                const V val = zero;
+#else
+                const V val = *reinterpret_cast<const V*>(pa[i] + cs);
+#endif
+                ra[s][i] = okr[i] ? val : zero;
+            }
+            const int ks = kc * BKK + BK * s;                             // uniform; < Ktot by construction
+#pragma unroll
+            for (int i = 0; i < NBV; ++i) {
+#ifdef SV_IG_NO_GB
+                const V val = zero;
+#else
+                const V val = *reinterpret_cast<const V*>(pw[i] + ks);
+#endif
+                rb[s][i] = wok[i] ? val : zero;
+            }
+        }
+        cu += BKK;
+        if (cu >= g.Cin) {          // (uniform branch) next iteration starts the next tap
+            cu = 0;
+            ++tapu;
+            set_tap(tapu);
+        }
+    };
+    // Branch-free general loader: clamped addresses, unconditional loads (all in flight together), select.
+    auto load_general = [&](int kc) {
 #pragma unroll
         for (int s = 0; s < KV; ++s) {
             const int tt = tap[s] < SV_MAX_TAPS ? tap[s] : SV_MAX_TAPS - 1;
@@ -180,6 +250,10 @@ __global__ __launch_bounds__(256, MS == 4 ? 2 : 1) void igemm_kernel(const sv_ge
             c[s] += BKK;
             while (c[s] >= g.Cin) { c[s] -= g.Cin; ++tap[s]; }
         }
+    };
+
+    auto load_global = [&](int kc) {
+        if (AL) load_aligned(kc); else load_general(kc);
     };
 
     auto store_lds = [&](int buf) {
@@ -274,8 +348,8 @@ __global__ __launch_bounds__(256, MS == 4 ? 2 : 1) void igemm_kernel(const sv_ge
 #endif
 }
 
-template <typename T, int NT, int KV, int MS = 2>
-int launch_kv(const sv_geom* g, const sv_igemm_args* a, hipStream_t s) {
+template <typename T, int NT, int KV, int MS, bool AL>
+int launch_al(const sv_geom* g, const sv_igemm_args* a, hipStream_t s) {
     constexpr int BM = 64 * MS, BN = 16 * NT, LDK = BK * KV + 16;
     const int M = g->B * g->Hq * g->Wq;
     const int nMt = (M + BM - 1) / BM;
@@ -284,15 +358,21 @@ int launch_kv(const sv_geom* g, const sv_igemm_args* a, hipStream_t s) {
     const size_t lds = (size_t)2 * (BM + BN) * LDK * sizeof(T) + (MS == 4 ? 0 : 2 * BN * sizeof(float));
     static bool optin = false;
     if (lds > 64 * 1024 && !optin) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<T, NT, KV, MS>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<T, NT, KV, MS, AL>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return sv_check_launch("hipFuncSetAttribute(igemm)");
         optin = true;
     }
     sv_prof_begin(s);
-    hipLaunchKernelGGL((igemm_kernel<T, NT, KV, MS>), dim3(grid, sv_ngroups(a->groups)), dim3(256), lds, s, *g, sv_expand_groups(*g, *a, (int)sizeof(T)));
+    hipLaunchKernelGGL((igemm_kernel<T, NT, KV, MS, AL>), dim3(grid, sv_ngroups(a->groups)), dim3(256), lds, s, *g, sv_expand_groups(*g, *a, (int)sizeof(T)));
     sv_prof_end(s);
     return sv_check_launch("sv_igemm");
+}
+
+template <typename T, int NT, int KV, int MS = 2>
+int launch_kv(const sv_geom* g, const sv_igemm_args* a, hipStream_t s) {
+    if (sizeof(T) == 2 && g->Cin % (BK * KV) == 0 && !sv_disabled(SV_K_IGEMM_ALIGNED)) return launch_al<T, NT, KV, MS, true>(g, a, s);
+    return launch_al<T, NT, KV, MS, false>(g, a, s);
 }
 
 template <typename T, int NT>
@@ -340,7 +420,8 @@ extern "C" int sv_igemm(const sv_geom* g, int dtype, const sv_igemm_args* a, voi
     if (dtype == SV_BF16 && !sv_disabled(SV_K_IGEMM_BIG)) {
         const int64_t mt256 = (M + 255) / 256 * g->nphase * sv_ngroups(a->groups);
         if (g->N % 160 == 0 && mt256 * (g->N / 160) >= sv_wide_min_blocks()) return launch_kv<bf16, 10, 1, 4>(g, a, s);
-        if (g->N % 128 == 0 && mt256 * (g->N / 128) >= sv_wide_min_blocks()) return launch_kv<bf16, 8, 1, 4>(g, a, s);
+        // (128-channel tiles from half a block per slot: the 4x4 stride-2 data gradient of ConvT 512 -> 256, 128 tiles, 163 -> 142 us)
+        if (g->N % 128 == 0 && mt256 * (g->N / 128) >= (sv_wide_min_blocks() + 1) / 2) return launch_kv<bf16, 8, 1, 4>(g, a, s);
     }
 #endif
     const int64_t mtiles = (M + 127) / 128 * g->nphase;
