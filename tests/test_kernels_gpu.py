@@ -752,6 +752,24 @@ def test_halo_kernel_conv_cases(dt, case):
         test_conv_dgrad_with_activation_backward(dt, case)
 
 
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("M,N,ld", [(5000, 16, 16), (70001, 16, 16), (4099, 24, 32), (9000, 128, 128), (300, 16, 16), (4500, 4, 4)])
+def test_colsum(dt, M, N, ld):
+    """sv_colsum (bias gradients: column sums over all rows, accumulating into `out`): the 16-byte-load kernel (N and ld
+    multiples of 8, >= 4096 rows; ragged row counts, a channel-group count that does not divide 256, a padded row
+    stride) and the element-wise kernel."""
+    code, tdt, tol = DT[dt]
+    torch.manual_seed(11)
+    d = dev()
+    y = bq(torch.randn(M, ld), dt)
+    yd = y.to(d, tdt).contiguous()
+    out = torch.full((N,), 0.5, device=d)
+    L.call("sv_colsum", code, p(yd), M, N, ld, p(out), st())
+    torch.cuda.synchronize()
+    ref = y[:, :N].double().sum(0).float() + 0.5
+    assert (out.cpu() - ref).abs().max() < 2e-3 * (M ** 0.5), (out.cpu() - ref).abs().max()
+
+
 @pytest.mark.parametrize("case", [(3, 16, 160, 32, 3, 1, 1), (5, 16, 128, 16, 3, 1, 1), (2, 32, 320, 8, 3, 1, 1)])
 def test_halo_kernel_thin_output_default_dispatch(case):
     """Default dispatch (no option): the data gradient of a 3x3 layer with 16 / 32 input and >= 128 output channels -- few
