@@ -300,8 +300,18 @@ __global__ __launch_bounds__(256) void colsum8_kernel(const T* y, int64_t M, int
 #pragma unroll
             for (int j = 0; j < 8; ++j) s[j] += to_f(q[j]);
         }
+    if ((cv & (cv - 1)) == 0 && cv <= 32) {              // lanes l, l + cv, ... of a wave share a channel group: butterfly first
 #pragma unroll
-    for (int j = 0; j < 8; ++j) atomicAdd(&csum[8 * v + j], s[j]);
+        for (int j = 0; j < 8; ++j)
+            for (int o = cv; o < 64; o <<= 1) s[j] += __shfl_xor(s[j], o);
+        if ((threadIdx.x & 63) < cv) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) atomicAdd(&csum[8 * v + j], s[j]);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) atomicAdd(&csum[8 * v + j], s[j]);
+    }
     __syncthreads();
     for (int i = threadIdx.x; i < N; i += 256) atomicAdd(out + i, csum[i]);
 }
@@ -1042,7 +1052,7 @@ int sv_colsum(int dtype, const void* y, int64_t M, int N, int ld, float* out, vo
     SV_REQUIRE(y && out && N > 0, SV_E_ARG, "sv_colsum: null");
     if (N % 8 == 0 && ld % 8 == 0 && N <= 2048 && M >= 4096) {
         const int rpp = 256 / (N / 8);
-        DISPATCH_T(dtype, hipLaunchKernelGGL((colsum8_kernel<T>), dim3(nblocks(M, rpp * 8, 2048)), dim3(256), N * sizeof(float),
+        DISPATCH_T(dtype, hipLaunchKernelGGL((colsum8_kernel<T>), dim3(nblocks(M, rpp * 8, 512)), dim3(256), N * sizeof(float),
                                              (hipStream_t)stream, (const T*)y, M, N, ld, out));
         return sv_check_launch("sv_colsum");
     }
