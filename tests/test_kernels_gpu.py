@@ -753,6 +753,44 @@ def test_halo_kernel_conv_cases(dt, case):
 
 
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("B,Cc,HW,Gn", [(16, 128, 64, 2), (6, 640, 64, 1), (8, 64, 16, 1), (12, 128, 64, 4), (11, 64, 16, 1),
+                                        (8, 16, 4, 2)])
+def test_pool_kernels_vectorised(dt, B, Cc, HW, Gn):
+    """sv_pool_fwd / sv_pool_bwd (BatchNorm + LeakyReLU + global average pool and its backward with the BatchNorm-backward
+    sums) in the 16-byte form (images x pixel parts x 8-channel groups per block; several images per block, 640 channels =
+    one image per block with idle threads) and the element-wise fallback (B = 11), batched over groups with their own
+    coefficients."""
+    code, tdt, tol = DT[dt]
+    torch.manual_seed(12)
+    d = dev()
+    Bg = B // Gn
+    x = bq(torch.randn(B, HW, Cc), dt)
+    scale, shift = torch.rand(Gn, Cc) + 0.5, torch.randn(Gn, Cc) * 0.2
+    mean, rstd = torch.randn(Gn, Cc) * 0.1, torch.rand(Gn, Cc) + 0.5
+    dfeat = torch.randn(B, Cc)
+    gi = torch.arange(B) // Bg
+    u = x * scale[gi][:, None, :] + shift[gi][:, None, :]
+    feat = F.leaky_relu(u, 0.01).mean(1)
+    gref = (dfeat / HW)[:, None, :] * torch.where(u > 0, torch.ones_like(u), torch.full_like(u, 0.01))
+    xh = (x - mean[gi][:, None, :]) * rstd[gi][:, None, :]
+    xd = x.to(d, tdt).contiguous()
+    sc, sh, mn, rs = [t.to(d).contiguous() for t in (scale, shift, mean, rstd)]
+    featd = torch.empty(B, Cc, device=d)
+    L.call("sv_pool_fwd", code, p(xd), p(sc), p(sh), 0.01, B, HW, Cc, Cc, p(featd), Gn, st())
+    assert rel(featd, feat) < (1e-4 if dt == "f32" else 1e-3)
+    gd = torch.empty(B, HW, Cc, device=d, dtype=tdt)
+    bs = torch.zeros(Gn, 2 * Cc, device=d)
+    dfd = dfeat.to(d)
+    L.call("sv_pool_bwd", code, p(xd), p(sc), p(sh), 0.01, p(mn), p(rs), p(dfd), B, HW, Cc, Cc, p(gd), p(bs), Gn, st())
+    torch.cuda.synchronize()
+    assert rel(gd.float(), gref) < tol
+    for k in range(Gn):
+        sl = slice(k * Bg, (k + 1) * Bg)
+        assert rel(bs[k, :Cc], gref[sl].sum((0, 1))) < max(tol, 1e-3) * 3
+        assert rel(bs[k, Cc:], (gref[sl] * xh[sl]).sum((0, 1))) < max(tol, 1e-3) * 3
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
 @pytest.mark.parametrize("M,N,ld", [(5000, 16, 16), (70001, 16, 16), (4099, 24, 32), (9000, 128, 128), (300, 16, 16), (4500, 4, 4)])
 def test_colsum(dt, M, N, ld):
     """sv_colsum (bias gradients: column sums over all rows, accumulating into `out`): the 16-byte-load kernel (N and ld
