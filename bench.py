@@ -55,6 +55,8 @@ def parse():
                          "rank 0 prints a JSON stub (tests/test_bench_launch_cpu.py)")
     ap.add_argument("--disable", type=int, default=0,
                     help="dispatcher mask SV_OPT_DISABLE_MASK (A/B runs of the specialised kernels; 0 = all enabled)")
+    ap.add_argument("--persistent-blocks", type=int, default=0,
+                    help="SV_OPT_PERSISTENT_BLOCKS: block budget of the persistent narrow kernels (0 = library default, 512)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak (default): --batch per loader PER GPU; strong: --batch per loader in total, split over the GPUs")
     return ap.parse_args()
@@ -186,6 +188,8 @@ def main():
     from shot_vae_amd import dp
     if a.disable:
         L.call("sv_set_option", L.OPT_DISABLE_MASK, a.disable)
+    if a.persistent_blocks:
+        L.call("sv_set_option", L.OPT_PERSISTENT_BLOCKS, a.persistent_blocks)
 
     K = a.classes
     if a.scaling == "strong":
