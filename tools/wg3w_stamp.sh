@@ -2,7 +2,7 @@
 # Diagnostic build of wgrad3x3w_kernel (wide layers) with in-kernel stamps.  usage: wg3w_stamp.sh B C H N
 cd "$(dirname "$0")/../shot_vae_amd/csrc" || exit 1
 FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -munsafe-fp-atomics -I../../include -Wno-unused-function $SV_EXTRA_FLAGS"
-/opt/rocm/bin/hipcc $FLAGS -DSV_WG3_STAMP -c wgrad3x3.hip -o wgrad3x3.o 2>/dev/null && /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC igemm.o conv3x3.o conv3x3w.o conv3x3x.o wgrad.o wgrad3x3.o small.o runtime.o -o ../libshotvae_hip.so
+/opt/rocm/bin/hipcc $FLAGS -DSV_WG3_STAMP -c wgrad3x3.hip -o wgrad3x3.o 2>/dev/null && /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC igemm.o halo.o hwgrad.o conv3x3.o conv3x3w.o conv3x3x.o wgrad.o wgrad3x3.o small.o runtime.o -o ../libshotvae_hip.so
 cd ../.. && python - "$@" <<'PY'
 import ctypes as C, sys, torch
 sys.path.insert(0, ".")
