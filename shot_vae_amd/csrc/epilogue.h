@@ -23,7 +23,8 @@ __device__ __forceinline__ float row16_sum(float v) {
 template <typename T, int NT, int MS = 2>
 __device__ __forceinline__ void gemm_epilogue(const f32x4 (&acc)[NT][MS], const int64_t (&obase)[MS],
                                               const bool (&oval)[MS], int n0, int N, const sv_igemm_args& a,
-                                              float* ssum /* LDS [2][16*NT], zeroed, visible */) {
+                                              float* ssum /* LDS [2][16*NT], zeroed, visible */,
+                                              float* cst = nullptr /* LDS [5][16*NT] scratch or NULL */) {
     typedef typename V4<T>::type Q;
     constexpr int BN = 16 * NT;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -32,40 +33,82 @@ __device__ __forceinline__ void gemm_epilogue(const f32x4 (&acc)[NT][MS], const 
     const T* __restrict__ R = reinterpret_cast<const T*>(a.residual);
     const T* __restrict__ EX = reinterpret_cast<const T*>(a.ex);
     const bool want_sums = (a.stats != nullptr) || (EX != nullptr);
+    // per-channel constants of the block's channels: one cooperative copy into LDS (when the caller has scratch) instead
+    // of a dependent global round trip per 16-channel group
+    const bool lds_c = cst != nullptr && (a.bias || EX);
+    if (lds_c) {
+        for (int c = tid; c < BN; c += 256) {
+            const int n = min(n0 + c, N - 1);
+            cst[c] = a.bias ? a.bias[n] : 0.f;
+            if (EX) {
+                cst[BN + c] = a.ex_scale[n];
+                cst[2 * BN + c] = a.ex_shift[n];
+                cst[3 * BN + c] = a.ex_mean[n];
+                cst[4 * BN + c] = a.ex_rstd[n];
+            }
+        }
+        __syncthreads();
+    }
+    // The residual / raw-tensor operands of all MS rows of a channel group are requested together, one group AHEAD of the
+    // arithmetic (every row address is inside the tensor: invalid rows were clamped to row 0 by the caller).  Issued one
+    // by one behind an `if (valid)` each of them was an exposed round trip -- 40 per block on the 256 x 160 tiles, most
+    // of the data-gradient kernels' time (WRN-28-10 stride-2 data gradient 711 -> 567 us with the batching alone).
+    Q rr[2][MS], xe[2][MS];
+    auto fetch = [&](int i, int buf) __attribute__((always_inline)) {
+        const int n = min(n0 + 16 * i + 4 * fq, N - 4);
+        if (R) {
+#pragma unroll
+            for (int ms = 0; ms < MS; ++ms) rr[buf][ms] = *reinterpret_cast<const Q*>(R + obase[ms] + n);
+        }
+        if (EX) {
+#pragma unroll
+            for (int ms = 0; ms < MS; ++ms) xe[buf][ms] = *reinterpret_cast<const Q*>(EX + obase[ms] + n);
+        }
+    };
+    fetch(0, 0);
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
         const int nl = 16 * i + 4 * fq;      // local channel of this lane's 4-vector
         const int n = n0 + nl;
         const bool nval = n < N;
+        if (i + 1 < NT) fetch(i + 1, (i + 1) & 1);
         float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
         if (nval) {
             f32x4 bias = {0.f, 0.f, 0.f, 0.f};
-            if (a.bias) bias = *reinterpret_cast<const f32x4*>(a.bias + n);
             f32x4 esc, esh, emu, ers;
-            if (EX) {
-                esc = *reinterpret_cast<const f32x4*>(a.ex_scale + n);
-                esh = *reinterpret_cast<const f32x4*>(a.ex_shift + n);
-                emu = *reinterpret_cast<const f32x4*>(a.ex_mean + n);
-                ers = *reinterpret_cast<const f32x4*>(a.ex_rstd + n);
+            if (lds_c) {
+                bias = *reinterpret_cast<const f32x4*>(cst + nl);
+                if (EX) {
+                    esc = *reinterpret_cast<const f32x4*>(cst + BN + nl);
+                    esh = *reinterpret_cast<const f32x4*>(cst + 2 * BN + nl);
+                    emu = *reinterpret_cast<const f32x4*>(cst + 3 * BN + nl);
+                    ers = *reinterpret_cast<const f32x4*>(cst + 4 * BN + nl);
+                }
+            } else {
+                if (a.bias) bias = *reinterpret_cast<const f32x4*>(a.bias + n);
+                if (EX) {
+                    esc = *reinterpret_cast<const f32x4*>(a.ex_scale + n);
+                    esh = *reinterpret_cast<const f32x4*>(a.ex_shift + n);
+                    emu = *reinterpret_cast<const f32x4*>(a.ex_mean + n);
+                    ers = *reinterpret_cast<const f32x4*>(a.ex_rstd + n);
+                }
             }
 #pragma unroll
             for (int ms = 0; ms < MS; ++ms) {
-                if (!oval[ms]) continue;
                 f32x4 vv = acc[i][ms];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) vv[r] += bias[r];
                 if (R) {
-                    const Q rr = *reinterpret_cast<const Q*>(R + obase[ms] + n);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) vv[r] += to_f(rr[r]);
+                    for (int r = 0; r < 4; ++r) vv[r] += to_f(rr[i & 1][ms][r]);
                 }
+                const float live = oval[ms] ? 1.f : 0.f;             // rows beyond M contribute nothing to the sums
                 if (EX) {
-                    const Q xe = *reinterpret_cast<const Q*>(EX + obase[ms] + n);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float xf = to_f(xe[r]);
+                        const float xf = to_f(xe[i & 1][ms][r]);
                         const float u = xf * esc[r] + esh[r];
-                        const float gv = vv[r] * act_grad(u, a.ex_slope);
+                        const float gv = vv[r] * act_grad(u, a.ex_slope) * live;
                         vv[r] = gv;
                         s1[r] += gv;
                         s2[r] += gv * ((xf - emu[r]) * ers[r]);
@@ -73,14 +116,15 @@ __device__ __forceinline__ void gemm_epilogue(const f32x4 (&acc)[NT][MS], const 
                 } else if (a.stats) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        s1[r] += vv[r];
-                        s2[r] += vv[r] * vv[r];
+                        const float t = vv[r] * live;
+                        s1[r] += t;
+                        s2[r] += t * t;
                     }
                 }
                 Q o;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) o[r] = (T)vv[r];
-                *reinterpret_cast<Q*>(O + obase[ms] + n) = o;
+                if (oval[ms]) *reinterpret_cast<Q*>(O + obase[ms] + n) = o;
             }
         }
         if (want_sums) {

@@ -344,8 +344,226 @@ __global__ __launch_bounds__(256, MS == 4 ? 2 : 1) void igemm_kernel(const sv_ge
 #ifdef SV_IG_NO_EPI
     if (obase[0] == -12345) gemm_epilogue<T, NT, MS>(acc, obase, oval, n0, g.N, a, ssum);
 #else
-    gemm_epilogue<T, NT, MS>(acc, obase, oval, n0, g.N, a, ssum);
+    // (the k loop ended with a barrier: the operand buffers are free for the epilogue's constants)
+    gemm_epilogue<T, NT, MS>(acc, obase, oval, n0, g.N, a, ssum, reinterpret_cast<float*>(smem) + (MS == 4 ? 2 * BN : 0));
 #endif
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// LDS-DMA variant for geometries WITHOUT a load prologue (data gradients, layers that read a plain tensor), bf16, Cin a
+// multiple of 32.  The SQ counters showed the register-staged loop issue-bound on its non-MFMA instructions (9 VALU per
+// MFMA: address arithmetic, selects, LDS stores of both operands); with nothing to transform, both operands can go
+// global -> LDS directly (global_load_lds_dwordx4): one address add per 16 bytes, no staging registers, no ds_write.
+//   * LDS rows are 64 bytes (one 32-deep k chunk), lane-linear as the DMA requires; the 16-byte k-quarter of a row sits in
+//     slot q ^ ((row >> 2) & 3) -- applied on the DMA SOURCE address -- which makes the ds_read_b128 fragment reads
+//     conflict-free (rows r, r+4, r+8, r+12 share a bank group and get distinct quarters);
+//   * rows whose tap falls outside the image (and channel rows beyond N) read 16 bytes of a zero page instead;
+//   * three stages: the DMAs of chunks k+1 and k+2 are in flight during the MFMAs of chunk k; every vector-memory
+//     instruction of the loop is an LDS-DMA, so the counted `s_waitcnt vmcnt` in front of the barrier counts a single kind.
+__device__ __attribute__((aligned(256))) const unsigned char sv_zero_page[256] = {0};
+
+typedef __attribute__((address_space(3))) void* ig_lds_ptr;
+typedef const __attribute__((address_space(1))) void* ig_glb_ptr;
+
+template <int NT, int MS>
+__global__ __launch_bounds__(256, 2) void igemm_dma_kernel(const sv_geom g, const sv_igemm_args_g A) {
+    const sv_igemm_args& a = A.g[blockIdx.y];
+    typedef bf16 T;
+    typedef bf16x8 V;
+    constexpr int BM = 64 * MS, BN = 16 * NT;
+    constexpr int NBV = (BN + 63) / 64;              // 64-row passes over the weight tile
+    constexpr int STAGE = (BM + BN) * 64;            // bytes per stage: [BM][32] + [BN][32] bf16; three stages
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* ssum = reinterpret_cast<float*>(smem);    // [2][BN] over the operand buffers, after the k loop
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int HWq = g.Hq * g.Wq;
+    const int M = g.B * HWq;
+    const int nMt = (M + BM - 1) / BM;
+    const int nNt = (g.N + BN - 1) / BN;
+    const int inner = nNt * g.nphase;
+    const int L = blockIdx.x;
+    int in_i, mt;
+    if (nMt >= 64) {
+        const int xcd = L & 7, slot = L >> 3;
+        in_i = slot % inner;
+        mt = (slot / inner) * 8 + xcd;
+        if (mt >= nMt) return;
+    } else {
+        in_i = L % inner;
+        mt = L / inner;
+    }
+    const int ph = in_i / nNt;
+    const int n0 = (in_i % nNt) * BN;
+    const sv_phase& P = g.phase[ph];
+    const uint64_t pdy = pack_taps(P.dy), pdx = pack_taps(P.dx);
+    const int ntap = P.ntap;
+    const int Ktot = ntap * g.Cin;
+    const int nk = Ktot / 32;
+    const T* __restrict__ X = reinterpret_cast<const T*>(a.x);
+    const T* __restrict__ W = reinterpret_cast<const T*>(a.w) + P.w_off;
+
+    if (ntap == 0 && !a.bias && !a.residual && g.ldo % 8 == 0) {          // (see igemm_kernel)
+        constexpr int VR = BN / 8;
+        V z;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) z[j] = (T)0.f;
+        T* __restrict__ O = reinterpret_cast<T*>(a.out);
+        for (int idx = tid; idx < BM * VR; idx += 256) {
+            const int row = idx / VR, vv = idx - row * VR;
+            const int m = mt * BM + row;
+            if (m >= M || n0 + 8 * vv >= g.N) continue;
+            const int b = m / HWq, r = m - b * HWq, qy = r / g.Wq, qx = r - qy * g.Wq;
+            *reinterpret_cast<V*>(O + ((int64_t)(b * g.Hout + qy * g.osy + P.ooy) * g.Wout + qx * g.osx + P.oox) * g.ldo +
+                                  n0 + 8 * vv) = z;
+        }
+        return;
+    }
+
+    // ---- DMA slots: lane (row lrow + 64 i, k-quarter slot v) --------------------------------------------------------
+    const int v = tid & 3, lrow = tid >> 2;
+    const int vs = v ^ ((lrow >> 2) & 3);            // the k-quarter this slot holds
+    int iy0[MS], ix0[MS], pixb[MS];
+    bool mval[MS];
+#pragma unroll
+    for (int i = 0; i < MS; ++i) {
+        const int m = mt * BM + lrow + 64 * i;
+        mval[i] = m < M;
+        const int mm = mval[i] ? m : 0;
+        const int b = mm / HWq;
+        const int r = mm - b * HWq;
+        const int qy = r / g.Wq;
+        const int qx = r - qy * g.Wq;
+        iy0[i] = qy * g.sy;
+        ix0[i] = qx * g.sx;
+        pixb[i] = b * g.Hin * g.Win;
+    }
+    const T* const zp = reinterpret_cast<const T*>(sv_zero_page);
+    const T* pa[MS];            // source of this lane's 16 bytes of the current tap (channel 0), or the zero page
+    int astep[MS];              // elements to advance per 32-channel chunk (0 on the zero page)
+    const T* pw[NBV];
+    int wstep[NBV];
+    auto set_tap = [&](int t) {
+        const int tt = t < SV_MAX_TAPS ? t : SV_MAX_TAPS - 1;
+        const int dy = tap_off(pdy, tt), dx = tap_off(pdx, tt);
+#pragma unroll
+        for (int i = 0; i < MS; ++i) {
+            const int iy = iy0[i] + dy, ix = ix0[i] + dx;
+            const bool ok = mval[i] && t < ntap && (unsigned)iy < (unsigned)g.Hin && (unsigned)ix < (unsigned)g.Win;
+            pa[i] = ok ? X + ((int64_t)(pixb[i] + iy * g.Win + ix) * g.ldx + 8 * vs) : zp;
+            astep[i] = ok ? 32 : 0;
+        }
+    };
+    set_tap(0);
+#pragma unroll
+    for (int i = 0; i < NBV; ++i) {
+        const int nb = lrow + 64 * i;
+        const bool ok = nb < BN && n0 + nb < g.N;
+        pw[i] = ok ? W + (int64_t)(n0 + nb) * Ktot + 8 * vs : zp;
+        wstep[i] = ok ? 32 : 0;
+    }
+    int cu = 0, tapu = 0;       // block-uniform: first channel / tap of the next chunk to issue
+    auto issue = [&](int stage) {
+        char* const sb = smem + stage * STAGE;
+#pragma unroll
+        for (int i = 0; i < MS; ++i) {
+            __builtin_amdgcn_global_load_lds((ig_glb_ptr)pa[i], (ig_lds_ptr)(sb + (64 * i + 16 * wave) * 64), 16, 0, 0);
+            pa[i] += astep[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NBV; ++i) {
+            if (64 * i + 16 * wave < BN) {           // (wave-uniform: rows beyond the tile have no LDS)
+                __builtin_amdgcn_global_load_lds((ig_glb_ptr)pw[i], (ig_lds_ptr)(sb + BM * 64 + (64 * i + 16 * wave) * 64), 16, 0, 0);
+                pw[i] += wstep[i];
+            }
+        }
+        cu += 32;
+        if (cu >= g.Cin) {      // (uniform) the next chunk starts the next tap
+            cu = 0;
+            ++tapu;
+            set_tap(tapu);
+        }
+    };
+
+    f32x4 acc[NT][MS];
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < MS; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int fr = lane & 15, fq = lane >> 4;
+    const int qa = fq ^ ((fr >> 2) & 3);             // slot of k-quarter fq in rows fr, fr + 16, ...
+    // three stages: chunks k+1 and k+2 are in flight during the MFMAs of chunk k.  The wait in front of the barrier lets
+    // the DMAs of chunk k+2 stay outstanding: a wave issues MS + (weight passes it takes part in) of them per chunk, at
+    // least DMIN -- vmcnt(DMIN) therefore covers chunk k+1 for every wave (all of them LDS-DMA: one kind).
+    constexpr int DMIN = MS + (BN / 64);
+    if (nk > 0) issue(0);
+    if (nk > 1) issue(1);
+    if (nk > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMIN) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int st = 0;                 // stage of chunk kc
+    for (int kc = 0; kc < nk; ++kc) {
+        const int st2 = st >= 1 ? st - 1 : 2;       // (st + 2) % 3: the stage chunk kc - 1 has released
+        if (kc + 2 < nk) issue(st2);
+        const char* const sb = smem + st * STAGE;
+        const char* Ab = sb + (16 * MS * (tid >> 6) + fr) * 64 + 16 * qa;
+        const char* Bb = sb + BM * 64 + fr * 64 + 16 * qa;
+        V af[MS];
+#pragma unroll
+        for (int j = 0; j < MS; ++j) af[j] = *reinterpret_cast<const V*>(Ab + 16 * j * 64);
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            const V wf = *reinterpret_cast<const V*>(Bb + 16 * i * 64);
+#pragma unroll
+            for (int j = 0; j < MS; ++j) mma32(acc[i][j], wf, af[j]);
+        }
+        if (kc + 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMIN) : "memory");     // chunk kc + 1 has landed
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        st = st == 2 ? 0 : st + 1;
+    }
+
+    // ---- epilogue -----------------------------------------------------------------------------------------------
+    for (int i = tid; i < 2 * BN; i += 256) ssum[i] = 0.f;
+    __syncthreads();
+    int64_t obase[MS];
+    bool oval[MS];
+#pragma unroll
+    for (int ms = 0; ms < MS; ++ms) {
+        const int m = mt * BM + 16 * MS * (tid >> 6) + 16 * ms + fr;
+        oval[ms] = m < M;
+        const int mm = oval[ms] ? m : 0;
+        const int b = mm / HWq;
+        const int r = mm - b * HWq;
+        const int qy = r / g.Wq;
+        const int qx = r - qy * g.Wq;
+        obase[ms] = ((int64_t)(b * g.Hout + qy * g.osy + P.ooy) * g.Wout + qx * g.osx + P.oox) * g.ldo;
+    }
+    gemm_epilogue<T, NT, MS>(acc, obase, oval, n0, g.N, a, ssum, ssum + 2 * BN);
+}
+
+template <int NT, int MS>
+int launch_dma(const sv_geom* g, const sv_igemm_args* a, hipStream_t s) {
+    constexpr int BM = 64 * MS, BN = 16 * NT;
+    const int M = g->B * g->Hq * g->Wq;
+    const int nMt = (M + BM - 1) / BM;
+    const int nNt = (g->N + BN - 1) / BN;
+    const int grid = (nMt >= 64 ? ((nMt + 7) / 8) * 8 : nMt) * nNt * g->nphase;
+    const size_t lds = (size_t)3 * (BM + BN) * 64;
+    static bool optin = false;
+    if (lds > 64 * 1024 && !optin) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_dma_kernel<NT, MS>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return sv_check_launch("hipFuncSetAttribute(igemm_dma)");
+        optin = true;
+    }
+    sv_prof_begin(s);
+    hipLaunchKernelGGL((igemm_dma_kernel<NT, MS>), dim3(grid, sv_ngroups(a->groups)), dim3(256), lds, s, *g, sv_expand_groups(*g, *a, 2));
+    sv_prof_end(s);
+    return sv_check_launch("sv_igemm(dma)");
 }
 
 template <typename T, int NT, int KV, int MS, bool AL>
@@ -419,6 +637,10 @@ extern "C" int sv_igemm(const sv_geom* g, int dtype, const sv_igemm_args* a, voi
 #ifndef SV_IG_NO_BIG
     if (dtype == SV_BF16 && !sv_disabled(SV_K_IGEMM_BIG)) {
         const int64_t mt256 = (M + 255) / 256 * g->nphase * sv_ngroups(a->groups);
+        // no load prologue (data gradients): both operands by LDS-DMA
+        const bool dma = !a->pro_scale && g->Cin % 32 == 0 && g->ldx % 8 == 0 && !sv_disabled(SV_K_IGEMM_DMA);
+        if (dma && g->N % 160 == 0 && mt256 * (g->N / 160) >= sv_wide_min_blocks()) return launch_dma<10, 4>(g, a, s);
+        if (dma && g->N % 128 == 0 && mt256 * (g->N / 128) >= (sv_wide_min_blocks() + 1) / 2) return launch_dma<8, 4>(g, a, s);
         if (g->N % 160 == 0 && mt256 * (g->N / 160) >= sv_wide_min_blocks()) return launch_kv<bf16, 10, 1, 4>(g, a, s);
         // (128-channel tiles from half a block per slot: the 4x4 stride-2 data gradient of ConvT 512 -> 256, 128 tiles, 163 -> 142 us)
         if (g->N % 128 == 0 && mt256 * (g->N / 128) >= (sv_wide_min_blocks() + 1) / 2) return launch_kv<bf16, 8, 1, 4>(g, a, s);
