@@ -245,33 +245,40 @@ __global__ __launch_bounds__(256) void halo_kernel(const sv_geom g, const sv_ige
         const sv_phase& P = g.phase[ph];
 #pragma unroll
         for (int ms = 0; ms < 2; ++ms) {
+            // every operand of the (phase, row) pair is requested before the first is consumed (clamped addresses: rows / channel
+            // groups beyond the tensor read a valid element and are not stored) -- one exposed round trip instead of NT
             const int grow = R0 + prow[ms];
-            if (grow >= BHq) continue;
-            const int b = grow >> c.hlog, qy = grow & (Hq - 1);
+            const bool rok = grow < BHq;
+            const int growc = rok ? grow : BHq - 1;
+            const int b = growc >> c.hlog, qy = growc & (Hq - 1);
             const int64_t ob = ((int64_t)(b * g.Hout + qy * g.osy + P.ooy) * g.Wout + pcol[ms] * g.osx + P.oox) * g.ldo;
+            Q eo[NT];
+            if (R || EX) {
+                const T* __restrict__ E = R ? R : EX;
+#pragma unroll
+                for (int i = 0; i < NT; ++i) eo[i] = *reinterpret_cast<const Q*>(E + ob + (nval[i] ? n0 + 16 * i + 4 * fq : 0));
+            }
 #pragma unroll
             for (int i = 0; i < NT; ++i) {
-                if (!nval[i]) continue;
+                if (!nval[i] || !rok) continue;
                 const int n = n0 + 16 * i + 4 * fq;
                 f32x4 vv = acc[ph][i][ms];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) vv[r] += bias[i][r];
                 if (R) {
-                    const Q rr = *reinterpret_cast<const Q*>(R + ob + n);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) vv[r] += to_f(rr[r]);
-                }
-                if (EX) {
-                    const Q xe = *reinterpret_cast<const Q*>(EX + ob + n);
+                    for (int r = 0; r < 4; ++r) vv[r] += to_f(eo[i][r]);
+                } else if (EX) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float xf = to_f(xe[r]);
+                        const float xf = to_f(eo[i][r]);
                         const float gv = vv[r] * act_grad(xf * esc[i][r] + esh[i][r], a.ex_slope);
                         vv[r] = gv;
                         s1[i][r] += gv;
                         s2[i][r] += gv * ((xf - emu[i][r]) * ers[i][r]);
                     }
-                } else if (a.stats) {
+                }
+                if (!EX && a.stats) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         s1[i][r] += vv[r];
@@ -533,33 +540,40 @@ __global__ __launch_bounds__(256, 2) void halop_kernel(const sv_geom g, const sv
             const sv_phase& P = g.phase[ph];
 #pragma unroll
             for (int ms = 0; ms < 2; ++ms) {
+                // every operand of the (phase, row) pair is requested before the first is consumed (clamped addresses: rows / channel
+                // groups beyond the tensor read a valid element and are not stored) -- one exposed round trip instead of NT
                 const int grow = R0 + prow[ms];
-                if (grow >= BHq) continue;
-                const int b = grow >> c.hlog, qy = grow & (Hq - 1);
+                const bool rok = grow < BHq;
+                const int growc = rok ? grow : BHq - 1;
+                const int b = growc >> c.hlog, qy = growc & (Hq - 1);
                 const int64_t ob = ((int64_t)(b * g.Hout + qy * g.osy + P.ooy) * g.Wout + pcol[ms] * g.osx + P.oox) * g.ldo;
+                Q eo[NT];
+                if (R || EX) {
+                    const T* __restrict__ E = R ? R : EX;
+#pragma unroll
+                    for (int i = 0; i < NT; ++i) eo[i] = *reinterpret_cast<const Q*>(E + ob + (nval[i] ? n0 + 16 * i + 4 * fq : 0));
+                }
 #pragma unroll
                 for (int i = 0; i < NT; ++i) {
-                    if (!nval[i]) continue;
+                    if (!nval[i] || !rok) continue;
                     const int n = n0 + 16 * i + 4 * fq;
                     f32x4 vv = acc[ph][i][ms];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) vv[r] += bias[i][r];
                     if (R) {
-                        const Q rr = *reinterpret_cast<const Q*>(R + ob + n);
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) vv[r] += to_f(rr[r]);
-                    }
-                    if (EX) {
-                        const Q xe = *reinterpret_cast<const Q*>(EX + ob + n);
+                        for (int r = 0; r < 4; ++r) vv[r] += to_f(eo[i][r]);
+                    } else if (EX) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            const float xf = to_f(xe[r]);
+                            const float xf = to_f(eo[i][r]);
                             const float gv = vv[r] * act_grad(xf * esc[i][r] + esh[i][r], a.ex_slope);
                             vv[r] = gv;
                             s1[i][r] += gv;
                             s2[i][r] += gv * ((xf - emu[i][r]) * ers[i][r]);
                         }
-                    } else if (a.stats) {
+                    }
+                    if (!EX && a.stats) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             s1[i][r] += vv[r];
@@ -672,6 +686,7 @@ int launch_halo_nt(const sv_geom* g, const sv_igemm_args* a, const halo_cfg& c, 
 // tile's LDS image within budget.
 int sv_halo_try(const sv_geom* g, int dtype, const sv_igemm_args* a, hipStream_t s, int* rc) {
     if (sv_disabled(SV_K_HALO)) return 0;
+    if (a->residual && a->ex) return 0;          // (the epilogues here take one extra operand: residual OR raw tensor)
     // Measured against the generic gather-GEMM on the WRN-28-2 / decoder shapes at 4 x 512 images (profiles/r02_*): this
     // one-tile-per-block version wins where a phase has few output channels and the staging is small -- the last two
     // ConvTranspose layers forward (207 -> 125 us, 181 -> 153 us) -- and loses elsewhere (two blocks per CU of 60-90 KB LDS
