@@ -294,14 +294,7 @@ __global__ __launch_bounds__(256, SV_C3P_WAVES) void conv3x3p_kernel(const sv_ge
 #pragma unroll
         for (int i = 0; i < HI; ++i) {
             V o = S.hv[i];
-            if (has_pro) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float u0 = to_f(S.hv[i][j]) * ps0[j] + pt0[j], u1 = to_f(S.hv[i][j + 4]) * ps1[j] + pt1[j];
-                    o[j] = (T)fmaxf(u0, u0 * a.pro_slope);          // LeakyReLU / ReLU for slope in [0,1]
-                    o[j + 4] = (T)fmaxf(u1, u1 * a.pro_slope);
-                }
-            }
+            if (has_pro) o = bn_act8(S.hv[i], ps0, ps1, pt0, pt1, a.pro_slope);          // LeakyReLU / ReLU for slope in [0,1]
             *reinterpret_cast<V*>(halo + hlds[i]) = S.hok[i] ? o : zero;
         }
     };

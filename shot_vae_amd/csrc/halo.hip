@@ -153,14 +153,7 @@ __global__ __launch_bounds__(256) void halo_kernel(const sv_geom g, const sv_ige
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 V o = hv[i];
-                if (has_pro && hsrc[i0 + i] >= 0) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const float u0 = to_f(hv[i][j]) * s0[j] + t0[j], u1 = to_f(hv[i][j + 4]) * s1[j] + t1[j];
-                        o[j] = (T)fmaxf(u0, u0 * a.pro_slope);
-                        o[j + 4] = (T)fmaxf(u1, u1 * a.pro_slope);
-                    }
-                }
+                if (has_pro && hsrc[i0 + i] >= 0) o = bn_act8(hv[i], s0, s1, t0, t1, a.pro_slope);
                 if (hdst[i0 + i] >= 0) *reinterpret_cast<V*>(halo + hdst[i0 + i]) = o;
             }
         }
@@ -443,14 +436,7 @@ __global__ __launch_bounds__(256, 2) void halop_kernel(const sv_geom g, const sv
         for (int i = 0; i < PMAXV; ++i) {
             if (256 * i >= HVn) break;
             V o = S.hv[i];
-            if (has_pro) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float u0 = to_f(S.hv[i][j]) * ps0[j] + pt0[j], u1 = to_f(S.hv[i][j + 4]) * ps1[j] + pt1[j];
-                    o[j] = (T)fmaxf(u0, u0 * a.pro_slope);
-                    o[j + 4] = (T)fmaxf(u1, u1 * a.pro_slope);
-                }
-            }
+            if (has_pro) o = bn_act8(S.hv[i], ps0, ps1, pt0, pt1, a.pro_slope);
             if (hdst[i] >= 0) *reinterpret_cast<V*>(halo + hdst[i]) = S.hok[i] ? o : zero;
         }
     };

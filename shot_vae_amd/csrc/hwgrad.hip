@@ -151,13 +151,7 @@ __global__ __launch_bounds__(256, 2) void hwgrad_kernel(const sv_geom g, const s
             const int idx = tid + 256 * i;
             if (idx >= HVn) break;
             V o = S.rx[i];
-            if (has_pro) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    o[j] = (bf16)act_fwd(to_f(S.rx[i][j]) * s0[j] + t0[j], p.pro_slope);
-                    o[j + 4] = (bf16)act_fwd(to_f(S.rx[i][j + 4]) * s1[j] + t1[j], p.pro_slope);
-                }
-            }
+            if (has_pro) o = bn_act8(S.rx[i], s0, s1, t0, t1, p.pro_slope);
             *reinterpret_cast<V*>(Xs + (idx / VX) * LDX + 8 * (idx % VX)) = S.xok[i] ? o : zero;
         }
     };

@@ -264,14 +264,7 @@ __global__ __launch_bounds__(256, MS == 4 ? 2 : 1) void igemm_kernel(const sv_ge
             if (has_pro) {
 #pragma unroll
                 for (int i = 0; i < MS; ++i) {
-                    V o;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const float u0 = to_f(ra[s][i][j]) * ps0[s][j] + pt0[s][j];
-                        const float u1 = to_f(ra[s][i][j + 4]) * ps1[s][j] + pt1[s][j];
-                        o[j] = (T)fmaxf(u0, u0 * a.pro_slope);          // LeakyReLU / ReLU for slope in [0,1]
-                        o[j + 4] = (T)fmaxf(u1, u1 * a.pro_slope);
-                    }
+                    const V o = bn_act8(ra[s][i], ps0[s], ps1[s], pt0[s], pt1[s], a.pro_slope);     // LeakyReLU / ReLU for slope in [0,1]
                     ra[s][i] = oka[s][i] ? o : zero;
                 }
             }

@@ -183,13 +183,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const sv_geom g, const sv_wg
 #pragma unroll
         for (int i = 0; i < TC; ++i) {
             V o = rx[i];
-            if (has_pro && okx[i]) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    o[j] = (T)act_fwd(to_f(rx[i][j]) * s0[j] + t0[j], p.pro_slope);
-                    o[j + 4] = (T)act_fwd(to_f(rx[i][j + 4]) * s1[j] + t1[j], p.pro_slope);
-                }
-            }
+            if (has_pro && okx[i]) o = bn_act8(rx[i], s0, s1, t0, t1, p.pro_slope);
             *reinterpret_cast<V*>(Xs + (rc + RPC * i) * LDC + 8 * vc) = o;
         }
     };
@@ -357,11 +351,7 @@ __global__ __launch_bounds__(256, 2) void wgradc_kernel(const sv_geom g, const s
                 const int cc = c0 + 8 * xv[i];
                 const f32x4 s0 = *reinterpret_cast<const f32x4*>(p.pro_scale + cc), s1 = *reinterpret_cast<const f32x4*>(p.pro_scale + cc + 4);
                 const f32x4 t0 = *reinterpret_cast<const f32x4*>(p.pro_shift + cc), t1 = *reinterpret_cast<const f32x4*>(p.pro_shift + cc + 4);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    o[j] = (T)act_fwd(to_f(S.rx[i][j]) * s0[j] + t0[j], p.pro_slope);
-                    o[j + 4] = (T)act_fwd(to_f(S.rx[i][j + 4]) * s1[j] + t1[j], p.pro_slope);
-                }
+                o = bn_act8(S.rx[i], s0, s1, t0, t1, p.pro_slope);
             }
             if (tid + 256 * i < RW * VRC) *reinterpret_cast<V*>(Xs + (buf * RW + xrow[i]) * LDC + 8 * xv[i]) = o;
         }

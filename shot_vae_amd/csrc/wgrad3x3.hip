@@ -169,13 +169,7 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_kernel(const sv_geom g, const
             V o = zero;
             if (S.hok[i]) {
                 o = S.rh[i];
-                if (has_pro) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        o[j] = (T)act_fwd(to_f(S.rh[i][j]) * s0[j] + t0[j], p.pro_slope);
-                        o[j + 4] = (T)act_fwd(to_f(S.rh[i][j + 4]) * s1[j] + t1[j], p.pro_slope);
-                    }
-                }
+                if (has_pro) o = bn_act8(S.rh[i], s0, s1, t0, t1, p.pro_slope);
             }
             if (hlds[i] >= 0) *reinterpret_cast<V*>(halo + hlds[i]) = o;
         }
