@@ -38,31 +38,19 @@ __device__ __forceinline__ float act_fwd(float u, float slope) { return fmaxf(u,
 __device__ __forceinline__ float act_grad(float u, float slope) { return u > 0.f ? 1.f : slope; }
 
 // BatchNorm-apply + LeakyReLU / ReLU of 8 consecutive channels (the load prologue of every conv-like kernel):
-// o[j] = act(x[j] * s[j] + t[j]).  bf16: the unpack is a shift / mask of the packed words and the arithmetic runs on packed
-// fp32 pairs (v_pk_fma_f32, v_pk_mul_f32, v_cvt_pk_bf16_f32: 28 VALU instructions per vector instead of ~40 -- the generic
-// kernels are issue-bound on exactly these, tools/pmc_sq.py); bit-identical to the scalar form.
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef bf16 bf16x2 __attribute__((ext_vector_type(2)));
+// o[j] = act(x[j] * s[j] + t[j]).  (A version on packed fp32 pairs -- v_pk_fma_f32 / v_pk_mul_f32, 28 instead of ~40 VALU
+// instructions per vector -- measured SLOWER on gfx950: conv3x3p forward 90.4 vs 88.4 us, the generic stride-2 forward 532
+// vs 517 us; the packed fp32 instructions issue at half rate.)
 __device__ __forceinline__ bf16x8 bn_act8(const bf16x8& x, const f32x4& s0, const f32x4& s1, const f32x4& t0, const f32x4& t1,
                                           float slope) {
-    const uint4 u = *reinterpret_cast<const uint4*>(&x);
-    const unsigned w[4] = {u.x, u.y, u.z, u.w};
-    const float sc[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
-    const float sh[8] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
-    unsigned r[4];
+    bf16x8 o;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const f32x2 xf = {__uint_as_float(w[j] << 16), __uint_as_float(w[j] & 0xffff0000u)};
-        const f32x2 sv = {sc[2 * j], sc[2 * j + 1]}, hv = {sh[2 * j], sh[2 * j + 1]};
-        const f32x2 y = __builtin_elementwise_fma(xf, sv, hv);
-        const f32x2 m = y * slope;
-        const f32x2 z = {fmaxf(y[0], m[0]), fmaxf(y[1], m[1])};
-        const bf16x2 b = __builtin_convertvector(z, bf16x2);
-        r[j] = *reinterpret_cast<const unsigned*>(&b);
+        const float u0 = (float)x[j] * s0[j] + t0[j], u1 = (float)x[j + 4] * s1[j] + t1[j];
+        o[j] = (bf16)fmaxf(u0, u0 * slope);
+        o[j + 4] = (bf16)fmaxf(u1, u1 * slope);
     }
-    uint4 o;
-    o.x = r[0]; o.y = r[1]; o.z = r[2]; o.w = r[3];
-    return *reinterpret_cast<const bf16x8*>(&o);
+    return o;
 }
 __device__ __forceinline__ f32x8 bn_act8(const f32x8& x, const f32x4& s0, const f32x4& s1, const f32x4& t0, const f32x4& t1,
                                          float slope) {
