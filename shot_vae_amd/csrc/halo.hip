@@ -480,6 +480,31 @@ __global__ __launch_bounds__(256, 2) void halop_kernel(const sv_geom g, const sv
         const int R0 = tile * c.TR;
         const bool more = tile + 1 < t_end;
         if (tile + 2 < t_end) load_halo(FREE, tile + 2);              // flies during this tile's and the next tile's MFMAs
+        // the epilogue's extra operand (residual OR raw tensor) of every (phase, row, channel group) is requested HERE, before
+        // the MFMAs (clamped addresses: rows / channel groups beyond the tensor read a valid element and are not stored):
+        // requested inside the epilogue it was an exposed round trip per tile -- waves of the thin layers waited 70 % of
+        // their cycles (tools/pmc_sq.py)
+        Q eo[NPH][2][NT];
+        int64_t obv[NPH][2];
+        bool rokv[2];
+#pragma unroll
+        for (int ms = 0; ms < 2; ++ms) {
+            const int grow = R0 + prow[ms];
+            rokv[ms] = grow < BHq;
+            const int growc = rokv[ms] ? grow : BHq - 1;
+            const int b = growc >> c.hlog, qy = growc & (Hq - 1);
+#pragma unroll
+            for (int ph = 0; ph < NPH; ++ph) {
+                const sv_phase& P = g.phase[ph < g.nphase ? ph : 0];
+                obv[ph][ms] = ((int64_t)(b * g.Hout + qy * g.osy + P.ooy) * g.Wout + pcol[ms] * g.osx + P.oox) * g.ldo;
+                if ((R || EX) && ph < g.nphase) {
+                    const T* __restrict__ E = R ? R : EX;
+#pragma unroll
+                    for (int i = 0; i < NT; ++i)
+                        eo[ph][ms][i] = *reinterpret_cast<const Q*>(E + obv[ph][ms] + (nval[i] ? n0 + 16 * i + 4 * fq : 0));
+                }
+            }
+        }
         f32x4 acc[NPH][NT][2];
 #pragma unroll
         for (int ph = 0; ph < NPH; ++ph)
@@ -526,19 +551,8 @@ __global__ __launch_bounds__(256, 2) void halop_kernel(const sv_geom g, const sv
             const sv_phase& P = g.phase[ph];
 #pragma unroll
             for (int ms = 0; ms < 2; ++ms) {
-                // every operand of the (phase, row) pair is requested before the first is consumed (clamped addresses: rows / channel
-                // groups beyond the tensor read a valid element and are not stored) -- one exposed round trip instead of NT
-                const int grow = R0 + prow[ms];
-                const bool rok = grow < BHq;
-                const int growc = rok ? grow : BHq - 1;
-                const int b = growc >> c.hlog, qy = growc & (Hq - 1);
-                const int64_t ob = ((int64_t)(b * g.Hout + qy * g.osy + P.ooy) * g.Wout + pcol[ms] * g.osx + P.oox) * g.ldo;
-                Q eo[NT];
-                if (R || EX) {
-                    const T* __restrict__ E = R ? R : EX;
-#pragma unroll
-                    for (int i = 0; i < NT; ++i) eo[i] = *reinterpret_cast<const Q*>(E + ob + (nval[i] ? n0 + 16 * i + 4 * fq : 0));
-                }
+                const bool rok = rokv[ms];
+                const int64_t ob = obv[ph][ms];
 #pragma unroll
                 for (int i = 0; i < NT; ++i) {
                     if (!nval[i] || !rok) continue;
@@ -548,11 +562,11 @@ __global__ __launch_bounds__(256, 2) void halop_kernel(const sv_geom g, const sv
                     for (int r = 0; r < 4; ++r) vv[r] += bias[i][r];
                     if (R) {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) vv[r] += to_f(eo[i][r]);
+                        for (int r = 0; r < 4; ++r) vv[r] += to_f(eo[ph][ms][i][r]);
                     } else if (EX) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            const float xf = to_f(eo[i][r]);
+                            const float xf = to_f(eo[ph][ms][i][r]);
                             const float gv = vv[r] * act_grad(xf * esc[i][r] + esh[i][r], a.ex_slope);
                             vv[r] = gv;
                             s1[i][r] += gv;
