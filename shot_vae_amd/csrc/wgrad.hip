@@ -29,6 +29,7 @@ struct wg_params {
     int groups;                 // batched launch: blockIdx.y = group (common.h)
     int wsh, hwsh;              // log2(Wq), log2(Hq*Wq) or -1
     int ntap_total;
+    int incr;                   // incremental addressing allowed (SV_K_WGRAD_INCR)
 };
 
 template <bool FAST>
@@ -79,7 +80,7 @@ __device__ __forceinline__ f32x8 frag_t(const float* S, int ld, int col0, int la
     return f;
 }
 
-template <typename T, int TN, int TC, bool USE_TR, bool FAST>
+template <typename T, int TN, int TC, bool USE_TR, bool FAST, bool INCR>
 __global__ __launch_bounds__(256) void wgrad_kernel(const sv_geom g, const sv_wg_g<wg_params> PG) {
     const wg_params& p = PG.g[blockIdx.y];
     typedef typename V8<T>::type V;
@@ -144,15 +145,74 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const sv_geom g, const sv_wg
 
     V ry[TN], rx[TC];
     bool okx[TC];
-    // Branch-free loader: every address is clamped into the tensor, every load is issued
-    // unconditionally (so the 2*TN..2*TC loads of an iteration are in flight together), invalid
-    // rows / padding are zeroed by a select afterwards.
     const int nvo = nvec_ok ? n0 + 8 * vn : 0;
     const int cvo = cvec_ok ? c0 + 8 * vc : 0;
     V zero;
 #pragma unroll
     for (int j = 0; j < 8; ++j) zero[j] = (T)0.f;
-    auto load_global = [&](int mbase) {   // mbase = first row of this wave's 32-row slab
+    // FAST (power-of-two grid): every slot keeps (row m, grid row qy, element offset) and ADVANCES them by the 128 rows of an
+    // iteration with adds -- the decode + address arithmetic per slot per iteration (34 quarter-rate v_mul_lo_u32 and 17
+    // 64-bit multiply-adds in the ISA: ~800 issue cycles against 256 of MFMA) made the kernel VALU-bound (23 VALU per MFMA).
+    const int STEP = 4 * RW;
+    const int dimg = INCR ? (STEP >> p.hwsh) : 0;                               // whole images per step
+    const int dq = INCR ? ((STEP - (dimg << p.hwsh)) >> p.wsh) : 0;             // remaining grid rows per step (< Hq)
+    const int rs_y = g.osy * g.Wout * g.ldo, is_y = g.Hout * g.Wout * g.ldo;     // (32-bit element offsets: the incremental
+    const int rs_x = g.sy * g.Win * g.ldx, is_x = g.Hin * g.Win * g.ldx;         //  path is taken for tensors < 2^31 elements)
+    const int st_y = dimg * is_y + dq * rs_y, wr_y = is_y - g.Hq * rs_y;          // per step / extra on a wrap into the next image
+    const int st_x = dimg * is_x + dq * rs_x, wr_x = is_x - g.Hq * rs_x;
+    constexpr bool incr = INCR;       // (the host checked: power-of-two grid, Wq <= 128, tensors < 2^31 elements)
+    int my[TN], qyy[TN], mx[TC], qyx[TC];
+    int offy[TN], offx[TC];
+    bool ixok[TC];
+    if (incr) {
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+            my[i] = m_begin + RW * wave + rn + RPN * i;
+            int b, qy, qx;
+            decode_m<FAST>(g, p, my[i], b, qy, qx);
+            qyy[i] = qy;
+            offy[i] = ((b * g.Hout + qy * g.osy + ooy) * g.Wout + qx * g.osx + oox) * g.ldo + nvo;
+        }
+#pragma unroll
+        for (int i = 0; i < TC; ++i) {
+            mx[i] = m_begin + RW * wave + rc + RPC * i;
+            int b, qy, qx;
+            decode_m<FAST>(g, p, mx[i], b, qy, qx);
+            qyx[i] = qy;
+            const int ix = qx * g.sx + dx;
+            ixok[i] = cvec_ok && (unsigned)ix < (unsigned)g.Win;
+            offx[i] = ((b * g.Hin + qy * g.sy + dy) * g.Win + ix) * g.ldx + cvo;      // (may point outside: used only when valid)
+        }
+    }
+    // Branch-free loader: every address is inside the tensor (or replaced by element 0), every load is issued
+    // unconditionally (so the 2*TN..2*TC loads of an iteration are in flight together), invalid
+    // rows / padding are zeroed by a select afterwards.
+    auto load_global = [&](int mbase) {   // mbase = first row of this wave's 32-row slab (consecutive calls: + 128 rows)
+        if (incr) {
+#pragma unroll
+            for (int i = 0; i < TN; ++i) {
+                const bool ok = my[i] < m_end && nvec_ok;
+                const V val = *reinterpret_cast<const V*>(DY + (ok ? offy[i] : 0));
+                ry[i] = ok ? val : zero;
+                my[i] += STEP;
+                qyy[i] += dq;
+                offy[i] += st_y;
+                if (qyy[i] >= g.Hq) { qyy[i] -= g.Hq; offy[i] += wr_y; }
+            }
+#pragma unroll
+            for (int i = 0; i < TC; ++i) {
+                const int iy = qyx[i] * g.sy + dy;
+                const bool ok = mx[i] < m_end && ixok[i] && (unsigned)iy < (unsigned)g.Hin;
+                const V val = *reinterpret_cast<const V*>(X + (ok ? offx[i] : 0));
+                okx[i] = ok;
+                rx[i] = ok ? val : zero;
+                mx[i] += STEP;
+                qyx[i] += dq;
+                offx[i] += st_x;
+                if (qyx[i] >= g.Hq) { qyx[i] -= g.Hq; offx[i] += wr_x; }
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < TN; ++i) {
             const int m = mbase + rn + RPN * i;
@@ -448,7 +508,7 @@ int ilog2_exact(int v) {
     return s;
 }
 
-template <typename T, int TN, int TC, bool USE_TR, bool FAST>
+template <typename T, int TN, int TC, bool USE_TR, bool FAST, bool INCR>
 int launch2(const sv_geom* g, const wg_params& p, hipStream_t s) {
     constexpr int BNw = 16 * TN, BCw = 16 * TC;
     const int nNt = (g->N + BNw - 1) / BNw, nCt = (g->Cin + BCw - 1) / BCw;
@@ -458,15 +518,23 @@ int launch2(const sv_geom* g, const wg_params& p, hipStream_t s) {
     const size_t red = (size_t)4 * BNw * BCw * sizeof(float);
     if (red > lds) lds = red;
     sv_prof_begin(s);
-    hipLaunchKernelGGL((wgrad_kernel<T, TN, TC, USE_TR, FAST>), dim3(grid, p.groups), dim3(256), lds, s, *g, sv_expand_wg(*g, p, p.groups, (int)sizeof(T)));
+    hipLaunchKernelGGL((wgrad_kernel<T, TN, TC, USE_TR, FAST, INCR>), dim3(grid, p.groups), dim3(256), lds, s, *g, sv_expand_wg(*g, p, p.groups, (int)sizeof(T)));
     sv_prof_end(s);
     return sv_check_launch("sv_wgrad");
 }
 
 template <typename T, int TN, int TC, bool USE_TR>
 int launch(const sv_geom* g, const wg_params& p, hipStream_t s) {
-    if (p.hwsh >= 0) return launch2<T, TN, TC, USE_TR, true>(g, p, s);
-    return launch2<T, TN, TC, USE_TR, false>(g, p, s);
+    if (p.hwsh >= 0) {
+        // (measured: a win where a step covers whole images -- decoder layers, 8x8 grids: -10 % -- a loss on the 16x16 grid
+        //  of the 32 -> 64 stride-2 layer, 98 -> 112 us)
+        const bool incr = sizeof(T) == 2 && p.incr && (1 << p.hwsh) <= 4 * RW &&
+                          (int64_t)g->B * g->Hout * g->Wout * g->ldo < ((int64_t)1 << 31) &&
+                          (int64_t)g->B * g->Hin * g->Win * g->ldx < ((int64_t)1 << 31);
+        if (incr) return launch2<T, TN, TC, USE_TR, true, sizeof(T) == 2>(g, p, s);
+        return launch2<T, TN, TC, USE_TR, true, false>(g, p, s);
+    }
+    return launch2<T, TN, TC, USE_TR, false, false>(g, p, s);
 }
 
 template <typename T, bool USE_TR>
@@ -511,6 +579,7 @@ extern "C" int sv_wgrad(const sv_geom* g, int dtype, const void* x, const float*
     p.hwsh = ilog2_exact(g->Hq * g->Wq);
     if (p.wsh < 0 || p.hwsh < 0) p.wsh = p.hwsh = -1;
     p.ntap_total = 0;
+    p.incr = !sv_disabled(SV_K_WGRAD_INCR);
     for (int i = 0; i < g->nphase; ++i) p.ntap_total += g->phase[i].ntap;
     if (p.ntap_total == 0) return SV_OK;
     const int64_t M = (int64_t)g->B * g->Hq * g->Wq;
