@@ -35,6 +35,8 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* stats, in
         scale += grp * C; shift += grp * C; mean += grp * C; rstd += grp * C;
     }
     float s1 = 0.f, s2 = 0.f;
+    const int cc = c < C ? c : 0;
+    const float ga = gamma[cc], be = beta[cc];        // requested with the statistics (one round trip, not two)
     if (c < C)
         for (int r = r0; r < R; r += 32) {
             s1 += stats[(size_t)r * 2 * C + c];
@@ -50,9 +52,9 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* stats, in
     float var = s2 / count - mu * mu;
     var = var > 0.f ? var : 0.f;
     const float rs = rsqrtf(var + eps);
-    const float sc = gamma[c] * rs;
+    const float sc = ga * rs;
     scale[c] = sc;
-    shift[c] = beta[c] - mu * sc;
+    shift[c] = be - mu * sc;
     mean[c] = mu;
     rstd[c] = rs;
     if (rm) {
