@@ -140,6 +140,8 @@ def bench_odd_layer(B, Cin, H, N, KS, STR, what):
 if __name__ == "__main__":
     if os.environ.get("SV_BENCH_HALO_ALL"):             # A/B: let the LDS-halo kernels take every layer they can run
         L.call("sv_set_option", L.OPT_HALO_ALL, 1)
+    if os.environ.get("SV_BENCH_PERSISTENT_BLOCKS"):    # e.g. 256: the budget a body weight gradient gets in the paired backward
+        L.call("sv_set_option", L.OPT_PERSISTENT_BLOCKS, int(os.environ["SV_BENCH_PERSISTENT_BLOCKS"]))
     if os.environ.get("SV_BENCH_DISABLE"):
         L.call("sv_set_option", L.OPT_DISABLE_MASK, int(os.environ["SV_BENCH_DISABLE"]))
     if len(sys.argv) >= 5:

@@ -43,6 +43,10 @@ def one_pass(tag, counter, outdir):
     B, Cin, H, N, kind, names = LAYERS[tag]
     d = os.path.join(outdir, tag.replace(":", "_") + "_" + counter)
     env = dict(os.environ, SV_BENCH_ITERS=str(ITERS), SV_BENCH_WARM=str(WARM))
+    if kind == "wgrad" and Cin <= 128:
+        # the narrow weight gradients run with HALF the persistent-block budget in the step (paired with the data gradient on
+        # the other stream: Engine.pair_blocks) -- half the blocks publish half the partial slabs
+        env["SV_BENCH_PERSISTENT_BLOCKS"] = "256"
     cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--",
            "python3", os.path.join(ROOT, "tools", "layer_bench.py"), str(B), str(Cin), str(H), str(N), kind]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, cwd=ROOT)
@@ -122,6 +126,8 @@ def main():
                     "traffic_bytes": (2 * fetch + write) * 1024, "algorithmic_bytes": alg,
                     "kernels": k1, "shape": {"B": B, "Cin": Cin, "H": H, "N": N, "kind": kind},
                     "formula": "(2*FETCH_SIZE + WRITE_SIZE)*1024, per launch, mean of %d launches" % ITERS}
+        if kind == "wgrad" and Cin <= 128:
+            res[tag]["persistent_blocks"] = 256
         print(tag, json.dumps(res[tag]), flush=True)
     json.dump(res, open(out, "w"), indent=1)
 
