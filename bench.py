@@ -43,9 +43,20 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--prof-steps", type=int, default=3)
-    ap.add_argument("--graph", type=int, default=0,
-                    help="1: replay the step from a captured hipGraph (one stream); 0 (default): issue it eagerly, weight "
-                         "gradients on a side stream -- the grouped step is ~280 launches, which the host keeps ahead of")
+    ap.add_argument("--graph", type=int, default=None,
+                    help="1: replay the step from a captured hipGraph (one stream); 0: issue it eagerly, weight gradients on a "
+                         "side stream (the grouped step is ~280 launches, which the host keeps ahead of at B = 512); -1: time "
+                         "a few steps of both and keep the faster (both times go into the JSON line).  Default: 0 for "
+                         "--scaling weak, -1 for --scaling strong (small per-rank batches are launch-bound)")
+    ap.add_argument("--workload", default="shotvae", choices=["shotvae", "svhn"],
+                    help="shotvae (default): the SHOT-VAE step of main_shot_vae.py:280-366 (BASELINE configs 2-4); svhn: one "
+                         "smooth-ELBO iteration of svhn_VAE, main_smooth_ELBO_svhn.py:152-176 (config 5; --batch 1024)")
+    ap.add_argument("--allreduce", default="bucketed", choices=["bucketed", "single"],
+                    help="N > 1: bucketed (default) = the decoder's 88 %% of the gradient bytes are all-reduced on a communication "
+                         "stream while the encoder's backward runs, the encoder bucket after it (dp.DecoderFirstAllReduce); "
+                         "single = one blocking all-reduce of the flat buffer after the backward")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the extra keys of the headline line (config-4 step, WRN-28-10 layer table)")
     ap.add_argument("--schedule", default="grouped", choices=["grouped", "two-stream", "sequential"],
                     help="grouped (default): the four forwards of the step as one batched launch sequence; two-stream: the "
                          "labelled / unlabelled branches on two HIP streams; sequential: the reference's order, one stream")
@@ -63,24 +74,44 @@ def parse():
 
 
 def spawn_ranks(n):
-    """`python bench.py --gpus N` outside torchrun: start N fresh rank processes (before this process touches the GPU),
-    one per device, torchrun-style environment, rank 0's JSON line passed through; non-zero exit if any rank fails."""
+    """`python bench.py --gpus N` outside torchrun: start N fresh rank processes (before this process touches the GPU; never
+    a re-exec of a GPU-initialised process), one per device, torchrun-style environment, rank 0's JSON line passed through.
+    Watchdog: every child is polled; as soon as one exits non-zero the others (by PID -- they may be sitting in the RCCL
+    rendezvous waiting for it) are terminated and the launcher exits 1."""
+    import tempfile
     with socket.socket() as so:
         so.bind(("127.0.0.1", 0))
         port = so.getsockname()[1]
     procs = []
+    out0 = tempfile.TemporaryFile()
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0 = procs[0].communicate()[0]
-    rcs = [p.wait() for p in procs]
-    sys.stdout.write(out0.decode())
-    sys.stdout.flush()
-    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+                                      stdout=out0 if r == 0 else subprocess.DEVNULL))
+    bad = []
+    while True:
+        rcs = [p.poll() for p in procs]
+        bad = [(r, rc) for r, rc in enumerate(rcs) if rc not in (None, 0)]
+        if bad or all(rc is not None for rc in rcs):
+            break
+        time.sleep(0.2)
     if bad:
-        sys.stderr.write("bench.py: ranks failed (rank, exit code): %s\n" % bad)
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        deadline = time.time() + 10
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.1, deadline - time.time()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+    out0.seek(0)
+    sys.stdout.write(out0.read().decode())
+    sys.stdout.flush()
+    if bad:
+        sys.stderr.write("bench.py: ranks failed (rank, exit code): %s; the remaining ranks were terminated\n" % bad)
         sys.exit(1)
     sys.exit(0)
 
@@ -150,6 +181,60 @@ def pmc_traffic(tag, a):
     return tab[tag]["traffic_bytes"], "profiles/%s: %s" % (os.path.basename(files[-1]), tab[tag]["formula"])
 
 
+def extras(S):
+    """Extra keys of the headline line (same JSON object, the headline fields are untouched): the BASELINE config-4 step and
+    the per-kernel table behind the north-star bar ">= 40 % of the bf16 MFMA roofline on the WRN-28-10 encoder conv at batch
+    512" (every body convolution is 0.2416 TFLOP per launch at B = 512, <= 242 us to pass), so that both are
+    in the driver-written record and not only under profiles/."""
+    import contextlib
+    from shot_vae_amd.train import train_step_grouped
+    res = {}
+    net, K, B = "wideresnet-28-10", 100, 256
+    torch.manual_seed(1)
+    model = S.VariationalAutoEncoder(net, num_input_channels=3, img_size=(32, 32), data_parallel=True,
+                                     continuous_latent_dim=128, disc_latent_dim=K, small_input=True,
+                                     compute_dtype="bf16", rng="device").cuda().train()
+    elbo, cls = S.VAECriterion(discrete_dim=K, bce_reconstruction=True).cuda(), S.ClsCriterion()
+    opt = S.FlatSGD(model, lr=0.02, momentum=0.9, weight_decay=5e-4)
+    opt.zero_grad()
+    sch = S.schedule(10, dmi=4.6)
+    g = torch.Generator(device="cuda").manual_seed(4321)
+    il = torch.rand(B, 3, 32, 32, device="cuda", generator=g)
+    iu = torch.rand(B, 3, 32, 32, device="cuda", generator=g)
+    ll = torch.randint(0, K, (B,), device="cuda", generator=g)
+    warm, steps = 3, 8
+    for _ in range(warm):
+        train_step_grouped(model, elbo, cls, opt, il, ll, iu, sch)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ls, lu = train_step_grouped(model, elbo, cls, opt, il, ll, iu, sch)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    tflop_step = 32.43                     # SURVEY.md 8d: 63.34 GFLOP per dataloader image x 512
+    res["config4"] = {"workload": "SHOT-VAE train step %s K=%d B_l=B_u=%d bf16 (BASELINE configs[3]), grouped, eager" % (net, K, B),
+                      "ms_per_step": round(ms, 3), "images_per_s": round(2 * B / ms * 1e3, 1), "steps": steps, "warmup": warm,
+                      "TFLOPs": round(tflop_step / ms * 1e3, 1),
+                      "frac_of_bf16_mfma_peak": round(tflop_step / ms * 1e3 / MFMA_PEAK_TFLOPS["bf16"], 4),
+                      "finite": bool(torch.isfinite(ls).all() and torch.isfinite(lu).all())}
+    del model, opt
+    torch.cuda.empty_cache()
+    from tools import layer_bench as LB
+    rows = []
+    with contextlib.redirect_stdout(sys.stderr):          # (the tool prints its own table: keep stdout to the one JSON line)
+        for Cc, H in ((160, 32), (320, 16), (640, 8)):
+            r = LB.bench_layer(512, Cc, H, Cc)
+            row = {"layer": "conv3x3 s1 %d->%d @%dx%d, B=512, 0.2416 TFLOP" % (Cc, Cc, H, H)}
+            for k, us in r.items():
+                row[k + "_us"] = round(us, 1)
+                row[k + "_frac"] = round(0.2416e12 / (us * 1e-6) / (MFMA_PEAK_TFLOPS["bf16"] * 1e12), 4)
+            rows.append(row)
+    res["wrn28_10_layer_table"] = {"bar": "frac >= 0.40 (<= 242 us)", "peak_TFLOPs": MFMA_PEAK_TFLOPS["bf16"], "rows": rows,
+                                   "passing": sum(1 for r in rows for k in ("fwd", "dgrad", "wgrad") if r[k + "_frac"] >= 0.40),
+                                   "of": 3 * len(rows)}
+    return res
+
+
 def main():
     a = parse()
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
@@ -161,6 +246,8 @@ def main():
         sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with --nproc-per-node %d, or without torchrun)"
                  % (a.gpus, world, a.gpus))
     if a.dry_run:
+        if os.environ.get("SV_BENCH_FAIL_RANK") == str(rank):      # launcher test: this rank dies before the rendezvous
+            sys.exit(3)
         if world > 1:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         t = torch.tensor([float(rank + 1)], dtype=torch.float64)
@@ -204,8 +291,12 @@ def main():
                                      compute_dtype=a.dtype, rng="device").cuda().train()
     if world > 1:
         dp.broadcast_parameters(model)
-    # per-rank noise streams (eps, Gumbel u, pairings): seed + rank; the mixup coefficients come from DeviceRng tables
-    # seeded identically on every rank, so all ranks agree on lambda
+    # per-rank noise streams (eps, Gumbel u, pairings): torch seeds = seed + rank.  The mixup coefficients are the lambda
+    # contract of SURVEY.md 5.2 -- every rank must use the SAME lambda_l / lambda_u in a step: the eager step draws them
+    # from numpy's global generator, seeded IDENTICALLY on every rank here (and consumed in lockstep: two draws per step);
+    # the captured step reads DeviceRng tables built from the same seed on every rank.
+    import numpy as np
+    np.random.seed(20240 + 1)
     torch.manual_seed(1 + rank)
     torch.cuda.manual_seed(1 + rank)
     elbo, cls = S.VAECriterion(discrete_dim=K, bce_reconstruction=True).cuda(), S.ClsCriterion()
@@ -219,29 +310,53 @@ def main():
 
     from shot_vae_amd.train import GraphedTrainStep, train_step_grouped, train_step_overlapped
     model._engine.wgrad_side_stream = bool(a.wgrad_side)
+    dmode = False if world == 1 else ("bucketed" if a.allreduce == "bucketed" else True)
 
-    graphed, graph_note = None, "eager, weight gradients on a side stream"
-    if a.graph and a.schedule != "sequential":
+    mode = a.graph if a.graph is not None else (-1 if a.scaling == "strong" else 0)
+    graphed, graph_note, probe = None, "eager, weight gradients on a side stream", None
+    if mode and a.schedule != "sequential":
         try:
-            graphed = GraphedTrainStep(model, elbo, cls, opt, il, ll, iu, sch, distributed=world > 1, schedule=a.schedule)
+            graphed = GraphedTrainStep(model, elbo, cls, opt, il, ll, iu, sch, distributed=dmode, schedule=a.schedule)
             graph_note = "hipGraph replay"
         except Exception as e:        # capture unsupported on this stack: run eagerly, say so in the output
             graphed, graph_note = None, "eager (graph capture failed: %s)" % type(e).__name__
             torch.cuda.synchronize()
 
-    def step():
-        if graphed is not None:
-            return graphed()
+    def eager_step():
         if a.schedule == "grouped":
-            return train_step_grouped(model, elbo, cls, opt, il, ll, iu, sch, distributed=world > 1)
+            return train_step_grouped(model, elbo, cls, opt, il, ll, iu, sch, distributed=dmode)
         if a.schedule == "two-stream":
-            return train_step_overlapped(model, elbo, cls, opt, il, ll, iu, sch, distributed=world > 1)
-        return S.train_step(model, elbo, cls, opt, il, ll, iu, sch, distributed=world > 1)
+            return train_step_overlapped(model, elbo, cls, opt, il, ll, iu, sch, distributed=dmode)
+        return S.train_step(model, elbo, cls, opt, il, ll, iu, sch, distributed=dmode)
 
     def sync():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+
+    if mode < 0 and graphed is not None:
+        # launch-mode probe: a few steps of each mode (every rank runs the same sequence: the collectives stay matched),
+        # the slower rank's time decides, every rank takes the same decision
+        def probe_ms(fn, n=6):
+            for _ in range(2):
+                fn()
+            sync()
+            t = time.perf_counter()
+            for _ in range(n):
+                fn()
+            sync()
+            v = torch.tensor([(time.perf_counter() - t) / n * 1e3], device="cuda", dtype=torch.float64)
+            if world > 1:
+                dist.all_reduce(v, op=dist.ReduceOp.MAX)
+            return float(v)
+        probe = {"eager_ms": round(probe_ms(eager_step), 3), "graph_ms": round(probe_ms(graphed), 3)}
+        if probe["eager_ms"] <= probe["graph_ms"]:
+            graphed, graph_note = None, "eager, weight gradients on a side stream (faster than hipGraph replay in the probe)"
+        else:
+            graph_note = "hipGraph replay (faster than eager issue in the probe)"
+
+    def step():
+        return graphed() if graphed is not None else eager_step()
 
     for _ in range(a.warmup):
         step()
@@ -256,6 +371,16 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t)
     assert torch.isfinite(ls).all() and torch.isfinite(lu).all(), "non-finite loss"
+    # the lambda contract: every rank used the same mixup coefficients in the last step
+    lam_equal = None
+    lams = getattr(model, "_last_lams", None)
+    if world > 1 and lams is not None:
+        hi = torch.tensor([float(v) for v in lams], device="cuda", dtype=torch.float64)
+        lo = hi.clone()
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        lam_equal = bool(torch.equal(hi, lo))
+        assert lam_equal, "ranks disagree on the mixup coefficients: max %s, min %s" % (hi.tolist(), lo.tolist())
     images = 2 * B * world * a.steps
     headline = a.net == "wideresnet-28-2" and K == 10 and a.batch == 512
     metric = "images/sec/step WRN-28-2 SHOT-VAE CIFAR-10 bs512" if headline else \
@@ -271,8 +396,16 @@ def main():
                                    "two-stream": "two-stream (labelled || unlabelled branch)",
                                    "sequential": "sequential (reference order)"}[a.schedule],
                       "launch": graph_note,
-                      "collective": "1 RCCL all-reduce of the flat fp32 gradient buffer per step" if world > 1 else "none"},
+                      "collective": "none" if world == 1 else (
+                          "RCCL all-reduce of the flat fp32 gradient buffer in two buckets per step: decoder tail (88 % of the "
+                          "bytes) on a communication stream under the encoder's backward, encoder + heads after it"
+                          if dmode == "bucketed" and graphed is None and a.schedule != "two-stream" else
+                          "1 RCCL all-reduce of the flat fp32 gradient buffer per step")},
            "loss_sup": round(float(ls), 5), "loss_unsup": round(float(lu), 5)}
+    if probe is not None:
+        out["config"]["launch_probe"] = probe
+    if lam_equal is not None:
+        out["config"]["lambda_equal_across_ranks"] = lam_equal
 
     # ---- roofline of the dominant kernel: HIP events around EVERY launch of the library (separate pass) ----
     if not a.no_roofline:
@@ -283,9 +416,9 @@ def main():
         eng.wgrad_side_stream = False
         for _ in range(a.prof_steps):       # eager, single stream: HIP events bracket every launch of the timed schedule
             if a.schedule == "grouped":
-                train_step_grouped(model, elbo, cls, opt, il, ll, iu, sch, distributed=world > 1)
+                train_step_grouped(model, elbo, cls, opt, il, ll, iu, sch, distributed=dmode)
             else:
-                S.train_step(model, elbo, cls, opt, il, ll, iu, sch, distributed=world > 1)
+                S.train_step(model, elbo, cls, opt, il, ll, iu, sch, distributed=dmode)
         ntag = len(eng.prof_tags) + 1
         ms = (ctypes.c_double * ntag)()
         cnt = (ctypes.c_int * ntag)()
@@ -333,6 +466,10 @@ def main():
                         r["name"], r["launches"] // a.prof_steps, r["avg_us"], r["total_ms"] / a.prof_steps,
                         "%.1f" % (r["bytes"] / r["avg_us"] / 1e3) if r["bytes"] else "-",
                         "%.2f" % (r["flops"] / r["avg_us"] / 1e6) if r["flops"] else "-"), file=sys.stderr)
+    if rank == 0 and world == 1 and headline and a.dtype == "bf16" and not a.no_extras:
+        del model, opt, graphed
+        torch.cuda.empty_cache()
+        out.update(extras(S))
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(a.net, K)
     if world > 1:

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define SV_ABI_VERSION 2
+#define SV_ABI_VERSION 3
 
 enum { SV_F32 = 0, SV_BF16 = 1 };
 enum { SV_OK = 0, SV_E_ARG = -1, SV_E_SHAPE = -2, SV_E_HIP = -3 };
@@ -81,6 +81,9 @@ typedef struct {
                                    g->B is the batch of ONE group; x / out / residual / ex hold the groups back
                                    to back ([G][B][H][W][ld]); pro_scale / pro_shift are [G][Cin], the ex_*
                                    vectors [G][N], stats / bsums [G][R][2N].                            */
+    int32_t block_budget;       /* > 0: block budget of THIS launch if it takes a persistent kernel (conv3x3p, halop),
+                                   overriding SV_OPT_PERSISTENT_BLOCKS -- the paired backward gives a layer's weight and
+                                   data gradient half the chip each without touching process-wide state; 0 = the option */
 } sv_igemm_args;
 
 int sv_igemm(const sv_geom* g, int dtype, const sv_igemm_args* a, void* stream);
@@ -96,6 +99,24 @@ int sv_igemm(const sv_geom* g, int dtype, const sv_igemm_args* a, void* stream);
 int sv_wgrad(const sv_geom* g, int dtype, const void* x, const float* pro_scale, const float* pro_shift,
              float pro_slope, const void* dy, float* dw, int splits, int use_tr, float* ws, int64_t ws_elems,
              int groups, void* stream);
+
+/* The same launch with its arguments in a struct (ABI 3): adds the per-launch block budget of the persistent weight-gradient
+ * kernels (0 = SV_OPT_PERSISTENT_BLOCKS).  sv_wgrad(...) == sv_wgrad_ex with block_budget = 0.                          */
+typedef struct {
+    const void* x;
+    const float* pro_scale;
+    const float* pro_shift;
+    float pro_slope;
+    const void* dy;
+    float* dw;
+    int32_t splits;
+    int32_t use_tr;
+    float* ws;
+    int64_t ws_elems;
+    int32_t groups;
+    int32_t block_budget;
+} sv_wgrad_args;
+int sv_wgrad_ex(const sv_geom* g, int dtype, const sv_wgrad_args* a, void* stream);
 
 /* column sums: out[n] += sum_m y[m*ld + n]   (conv0 bias gradient)                                  */
 int sv_colsum(int dtype, const void* y, int64_t M, int N, int ld, float* out, void* stream);

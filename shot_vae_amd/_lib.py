@@ -33,7 +33,13 @@ class SvIgemmArgs(C.Structure):
                 ("w", C.c_void_p), ("bias", C.c_void_p), ("residual", C.c_void_p), ("out", C.c_void_p),
                 ("stats", C.c_void_p), ("ex", C.c_void_p), ("ex_scale", C.c_void_p), ("ex_shift", C.c_void_p),
                 ("ex_mean", C.c_void_p), ("ex_rstd", C.c_void_p), ("ex_slope", C.c_float), ("bsums", C.c_void_p),
-                ("replicas", C.c_int32), ("groups", C.c_int32)]
+                ("replicas", C.c_int32), ("groups", C.c_int32), ("block_budget", C.c_int32)]
+
+
+class SvWgradArgs(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("pro_scale", C.c_void_p), ("pro_shift", C.c_void_p), ("pro_slope", C.c_float),
+                ("dy", C.c_void_p), ("dw", C.c_void_p), ("splits", C.c_int32), ("use_tr", C.c_int32), ("ws", C.c_void_p),
+                ("ws_elems", C.c_int64), ("groups", C.c_int32), ("block_budget", C.c_int32)]
 
 
 class SvRepackJob(C.Structure):
@@ -51,6 +57,7 @@ P, I, I64, F = C.c_void_p, C.c_int, C.c_int64, C.c_float
 _PROTOS = {
     "sv_igemm": [C.POINTER(SvGeom), I, C.POINTER(SvIgemmArgs), P],
     "sv_wgrad": [C.POINTER(SvGeom), I, P, P, P, F, P, P, I, I, P, I64, I, P],
+    "sv_wgrad_ex": [C.POINTER(SvGeom), I, C.POINTER(SvWgradArgs), P],
     "sv_colsum": [I, P, I64, I, I, P, P],
     "sv_bn_finalize": [P, I, I, F, P, P, F, F, P, P, P, P, P, P, I, P],
     "sv_bn_eval_affine": [I, P, P, P, P, F, P, P, P],

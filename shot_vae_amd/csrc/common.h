@@ -133,7 +133,14 @@ void sv_set_error(const char* fmt, ...);
 bool sv_disabled(int kernel_bit);        // sv_set_option(SV_OPT_DISABLE_MASK, ...): a specialised kernel is switched off
 int sv_wide_min_blocks();
 bool sv_halo_all();
-int sv_persistent_blocks();            // sv_set_option(SV_OPT_PERSISTENT_BLOCKS, ...): block budget of the persistent 3x3 kernels                      // sv_set_option(SV_OPT_HALO_ALL, ...)                // sv_set_option(SV_OPT_WIDE_MIN_BLOCKS, ...)
+int sv_persistent_blocks();            // block budget of the persistent kernels: the launch's own (sv_igemm_args::block_budget,
+                                       // sv_wgrad_args::block_budget) if it has one, else sv_set_option(SV_OPT_PERSISTENT_BLOCKS, ...)
+// scope of one entry-point call on the calling thread: its launches see `budget` (> 0) as their block budget
+struct SvBudgetScope {
+    int old;
+    explicit SvBudgetScope(int budget);
+    ~SvBudgetScope();
+};
 int sv_check_launch(const char* what);
 void sv_prof_begin(hipStream_t s);
 void sv_prof_end(hipStream_t s);

@@ -616,7 +616,9 @@ extern "C" int sv_igemm(const sv_geom* g, int dtype, const sv_igemm_args* a, voi
                "sv_igemm: activation slope %g outside [0, 1]", (double)a->pro_slope);
     SV_REQUIRE(!(a->stats || a->ex) || (a->replicas >= 1 && (a->replicas & (a->replicas - 1)) == 0), SV_E_ARG,
                "sv_igemm: replicas=%d must be a power of two", a->replicas);
+    SV_REQUIRE(a->block_budget == 0 || a->block_budget >= 8, SV_E_ARG, "sv_igemm: block_budget=%d", a->block_budget);
     hipStream_t s = (hipStream_t)stream;
+    SvBudgetScope budget_scope(a->block_budget);
     {   // stride-1 3x3 convolutions take the LDS-halo kernels (conv3x3*.hip) unless switched off (tests: generic vs special)
         int rc = 0;
         if (!sv_disabled(SV_K_CONV3X3) && sv_conv3x3_try(g, dtype, a, s, &rc)) return rc;

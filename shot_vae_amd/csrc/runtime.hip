@@ -31,7 +31,10 @@ int g_wide_min_blocks = 256;
 int g_halo_all = 0;
 int g_persistent_blocks = 512;
 }  // namespace
-int sv_persistent_blocks() { return g_persistent_blocks; }
+static thread_local int tl_block_budget = 0;      // per-launch override, set for the duration of one entry-point call
+SvBudgetScope::SvBudgetScope(int budget) : old(tl_block_budget) { tl_block_budget = budget > 0 ? budget : 0; }
+SvBudgetScope::~SvBudgetScope() { tl_block_budget = old; }
+int sv_persistent_blocks() { return tl_block_budget > 0 ? tl_block_budget : g_persistent_blocks; }
 bool sv_halo_all() { return g_halo_all != 0; }
 bool sv_disabled(int kernel_bit) { return (g_disable_mask & kernel_bit) != 0; }
 int sv_wide_min_blocks() { return g_wide_min_blocks; }

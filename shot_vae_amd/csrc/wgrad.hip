@@ -552,6 +552,16 @@ int dispatch(const sv_geom* g, const wg_params& p, int tn, int tc, hipStream_t s
 
 }  // namespace
 
+static_assert(sizeof(sv_wgrad_args) == 80 && sizeof(sv_igemm_args) == 144, "ABI 3 struct layout (tests/test_abi_cpu.py)");
+
+extern "C" int sv_wgrad_ex(const sv_geom* g, int dtype, const sv_wgrad_args* a, void* stream) {
+    SV_REQUIRE(g && a, SV_E_ARG, "sv_wgrad_ex: null argument");
+    SV_REQUIRE(a->block_budget == 0 || a->block_budget >= 8, SV_E_ARG, "sv_wgrad_ex: block_budget=%d", a->block_budget);
+    SvBudgetScope budget_scope(a->block_budget);
+    return sv_wgrad(g, dtype, a->x, a->pro_scale, a->pro_shift, a->pro_slope, a->dy, a->dw, a->splits, a->use_tr, a->ws,
+                    a->ws_elems, a->groups, stream);
+}
+
 extern "C" int sv_wgrad(const sv_geom* g, int dtype, const void* x, const float* pro_scale,
                         const float* pro_shift, float pro_slope, const void* dy, float* dw, int splits,
                         int use_tr, float* ws, int64_t ws_elems, int groups, void* stream) {

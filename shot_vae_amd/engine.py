@@ -189,6 +189,7 @@ class Plan:
                                                     n_real=(chans[i + 1] if i < 4 else in_ch))))
             hh *= 2
         self.n_param = off[0]
+        self.dec_off = self.dec_convs[0].master_off     # the decoder's parameters are the tail [dec_off, n_param) of the flat buffer
         # BN running statistics and per-forward scratch
         o = 0
         for b in self.bns:
@@ -273,9 +274,13 @@ class Engine:
         # same dY and x and start together; with HALF the persistent-block budget each, one block of either kernel sits on
         # every CU, the two walk the same pixel ranges on the same XCDs and the follower finds the operands in L2
         # (config 2: 9.26 -> 9.09 ms; 192 / 128 blocks are slower).  0 = both kernels with the full budget, one after the other.
+        # A pair budget above SV_OPT_PERSISTENT_BLOCKS would not be "half": it is clamped there at launch time.
         self.pair_blocks = 256
         self._bn_layouts = {}
         self.version_probe = None     # callable: summed version counters of the nn.Parameters (set by the module)
+        # one-shot callback fired by backward() as soon as every decoder gradient has been ISSUED (main + side stream): the
+        # data-parallel step starts the all-reduce of the decoder's 88 % of the gradient bytes there (dp.DecoderFirstAllReduce)
+        self.bucket_hook = None
         for b in p.bns:
             self.bufs[b.rv_off: b.rv_off + b.C] = 1.0
 
@@ -403,9 +408,11 @@ class Engine:
                _vp(self.packs.data_ptr()), self._stream())
         self._pack_key = key
 
-    def _igemm(self, g, x, w_ptr, out, pro=None, bias=None, residual=None, stats=None, ex=None, tag=None, groups=1):
+    def _igemm(self, g, x, w_ptr, out, pro=None, bias=None, residual=None, stats=None, ex=None, tag=None, groups=1,
+               budget=0):
         a = L.SvIgemmArgs()
         a.groups = groups
+        a.block_budget = budget
         a.x, a.w, a.out = x.data_ptr(), w_ptr, out.data_ptr()
         if pro is not None:
             a.pro_scale, a.pro_shift, a.pro_slope = pro[0], pro[1], pro[2]
@@ -449,17 +456,17 @@ class Engine:
             s = pool[cur.cuda_stream] = torch.cuda.Stream()
         return cur, s
 
-    def _wgrad_async(self, g, x, pro, dy, dw_ptr, tag=None, groups=1):
+    def _wgrad_async(self, g, x, pro, dy, dw_ptr, tag=None, groups=1, budget=0):
         """Enqueue the weight gradient behind everything issued so far, on the side stream: the dgrad -> BN-apply
         chain continues on the main stream without waiting for it (joined at the end of backward)."""
         # (not under hipGraph capture: a captured step replays a hundred cross-stream edges slower than one stream --
         #  11.6 against 11.05 ms, measured -- and tensors freed during capture would need to outlive the side stream)
         if not self.wgrad_side_stream or self.prof_tags is not None or torch.cuda.is_current_stream_capturing():
-            return self._wgrad(g, x, pro, dy, dw_ptr, tag, groups)
+            return self._wgrad(g, x, pro, dy, dw_ptr, tag, groups, budget)
         cur, side = self._side()
         side.wait_stream(cur)
         with torch.cuda.stream(side):
-            self._wgrad(g, x, pro, dy, dw_ptr, tag, groups)
+            self._wgrad(g, x, pro, dy, dw_ptr, tag, groups, budget)
         if not torch.cuda.is_current_stream_capturing():    # (graph-private pools keep memory until the graph dies)
             x.record_stream(side)
             dy.record_stream(side)
@@ -469,13 +476,16 @@ class Engine:
             cur, side = self._side()
             cur.wait_stream(side)
 
-    def _wgrad(self, g, x, pro, dy, dw_ptr, tag=None, groups=1):
+    def _wgrad(self, g, x, pro, dy, dw_ptr, tag=None, groups=1, budget=0):
         if tag:
             self._tag(tag, g, wgrad=True, groups=groups)
-        ps, pt, sl = (pro[0], pro[1], pro[2]) if pro is not None else (None, None, 0.0)
-        L.call("sv_wgrad", C.byref(g), self.code, _vp(x.data_ptr()), _vp(ps) if ps else None,
-               _vp(pt) if pt else None, sl, _vp(dy.data_ptr()), _vp(dw_ptr), 0, self.use_tr,
-               _vp(self._wg_ws().data_ptr()), self._ws_elems, groups, self._stream())
+        a = L.SvWgradArgs()
+        a.x, a.dy, a.dw = x.data_ptr(), dy.data_ptr(), dw_ptr
+        if pro is not None:
+            a.pro_scale, a.pro_shift, a.pro_slope = pro[0], pro[1], pro[2]
+        a.splits, a.use_tr, a.ws, a.ws_elems = 0, self.use_tr, self._wg_ws().data_ptr(), self._ws_elems
+        a.groups, a.block_budget = groups, budget          # the budget is an argument of THIS launch, not process state
+        L.call("sv_wgrad_ex", C.byref(g), self.code, C.byref(a), self._stream())
 
     # ------------------------------------------------------------------------------- forward
     def _bn_layout(self, G):
@@ -773,6 +783,9 @@ class Engine:
         self._wgrad_async(cv.geom_fwd(B), lat4, None, D, gbase + 4 * cv.master_off, tag="wgrad:dec0", groups=G)
         dlat = torch.empty(Bt, 1, 1, p.Lpad, dtype=T, device=dev)
         self._igemm(cv.geom_dgrad(B), D, pk + es * cv.dgrad_off, dlat, tag="dgrad:dec0", groups=G)
+        if self.bucket_hook is not None:          # grad[dec_off:] is complete once the launches issued so far have run
+            hook, self.bucket_hook = self.bucket_hook, None
+            hook()
         # ---- sampler + heads + pool -----------------------------------------------------------
         dmu = d_mu.contiguous().float().clone() if d_mu is not None else torch.zeros_like(f.mu)
         dls = d_ls.contiguous().float().clone() if d_ls is not None else torch.zeros_like(f.ls)
@@ -802,31 +815,24 @@ class Engine:
             tin, c1 = f.t[i], f.c1[i]
             pro1, pro2, proi = f.pro[i]
             c = un["cout"]
+            # paired launches: the weight gradient (side stream) and the data gradient (main stream) of a body convolution
+            # each get `pair` persistent blocks as a per-launch argument (sv_igemm_args / sv_wgrad_args::block_budget)
             pair = self.pair_blocks if (self.wgrad_side_stream and self.prof_tags is None and
                                         not torch.cuda.is_current_stream_capturing()) else 0
-            budget = L.lib().sv_get_option(L.OPT_PERSISTENT_BLOCKS) if pair else 0
-            pair = min(pair, budget)
-            if pair:
-                L.call("sv_set_option", L.OPT_PERSISTENT_BLOCKS, pair)
+            pair = min(pair, L.lib().sv_get_option(L.OPT_PERSISTENT_BLOCKS))
             self._wgrad_async(un["conv2"].geom_fwd(B), c1, pro2, D, gbase + 4 * un["conv2"].master_off,
-                              tag="wgrad:conv3x3_%dx%d_s1" % (c, c), groups=G)
+                              tag="wgrad:conv3x3_%dx%d_s1" % (c, c), groups=G, budget=pair)
             g2 = torch.empty_like(c1)
             self._igemm(un["conv2"].geom_dgrad(B), D, pk + es * un["conv2"].dgrad_off, g2, ex=ex_of(un["bn2"], c1),
-                        tag="dgrad:conv3x3_%dx%d_s1" % (c, c), groups=G)
-            if pair:
-                L.call("sv_set_option", L.OPT_PERSISTENT_BLOCKS, budget)
+                        tag="dgrad:conv3x3_%dx%d_s1" % (c, c), groups=G, budget=pair)
             dc1 = bn_apply(c1, [(g2, un["bn2"])], None, c1.numel() // c // G)
             del g2
             pair1 = pair if (un["stride"] == 1 and un["cin"] == c) else 0
-            if pair1:
-                L.call("sv_set_option", L.OPT_PERSISTENT_BLOCKS, pair1)
             self._wgrad_async(un["conv1"].geom_fwd(B), tin, pro1, dc1, gbase + 4 * un["conv1"].master_off,
-                              tag="wgrad:conv3x3_%dx%d_s%d" % (un["cin"], c, un["stride"]), groups=G)
+                              tag="wgrad:conv3x3_%dx%d_s%d" % (un["cin"], c, un["stride"]), groups=G, budget=pair1)
             g1 = torch.empty_like(tin)
             self._igemm(un["conv1"].geom_dgrad(B), dc1, pk + es * un["conv1"].dgrad_off, g1, ex=ex_of(un["bn1"], tin),
-                        tag="dgrad:conv3x3_%dx%d_s%d" % (un["cin"], c, un["stride"]), groups=G)
-            if pair1:
-                L.call("sv_set_option", L.OPT_PERSISTENT_BLOCKS, budget)
+                        tag="dgrad:conv3x3_%dx%d_s%d" % (un["cin"], c, un["stride"]), groups=G, budget=pair1)
             del dc1
             cnt = tin.numel() // tin.shape[-1] // G
             if "convi" in un:

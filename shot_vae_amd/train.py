@@ -41,13 +41,28 @@ def inference_kl(disc_log_alpha_u, label_u):
         return (alpha * disc_log_alpha_u - alpha * torch.log(smooth)).sum() / B
 
 
+def _bucketed(model, distributed):
+    """distributed = "bucketed": the decoder-first two-bucket exchange (dp.DecoderFirstAllReduce); True: one all-reduce"""
+    if distributed != "bucketed":
+        return None
+    ar = getattr(model, "_bucket_allreduce", None)
+    if ar is None:
+        ar = model._bucket_allreduce = dp.DecoderFirstAllReduce(model)
+    return ar
+
+
 def apply_update(model, optimizer, distributed=False):
     """Gradient exchange + optimizer step + zero_grad (main_shot_vae.py:365-366).  With N ranks the flat gradient buffer
     holds the SUM over ranks after the all-reduce; FlatSGD folds the 1/N into its kernel, any other optimizer (a plain
     torch.optim.SGD over model.parameters()) gets the buffer scaled first, so the effective learning rate never depends
-    on the optimizer class."""
+    on the optimizer class.  distributed: False | True (one all-reduce of the flat buffer) | "bucketed" (decoder bucket
+    started during the backward by the step, encoder bucket here)."""
     grad = model.flat_parameters()[1]
-    scale = dp.all_reduce_gradients(grad) if distributed else 1.0
+    ar = _bucketed(model, distributed)
+    if ar is not None:
+        scale = ar.finish()
+    else:
+        scale = dp.all_reduce_gradients(grad) if distributed else 1.0
     if hasattr(optimizer, "_steps"):
         optimizer.step(scale)
     else:
@@ -145,6 +160,7 @@ def train_step_overlapped(model, elbo_criterion, cls_criterion, optimizer, image
         eng.defer_slot = 3
         rec4, mu4, ls4, la4, *_ = model(mx_img)
     eng.defer_slot = None
+    model._last_lams = (lam_l0, lam_u)
     with torch.cuda.stream(st[0]):
         disc_post_l = lam_l0 * cls_criterion(la2, onehot_l) + (1 - lam_l0) * cls_criterion(la2, sm_onehot)
         elbo_l = elbo_l + sch["kl_beta_c"] * sch["pwm"] * continuous_posterior_loss(mu2, ls2, sm_mu, sm_sigma)
@@ -206,6 +222,7 @@ def train_step_grouped(model, elbo_criterion, cls_criterion, optimizer, image_l,
             lam_l = lam_l0 = np.random.beta(epsilon, epsilon) if epsilon > 0 else 1
             lam_u = np.random.beta(2.0, 2.0)
     perm_l, perm_u = perm_l.long().contiguous(), perm_u.long().contiguous()
+    model._last_lams = (lam_l, lam_u)          # (data-parallel runs check that every rank used the same pair)
     with torch.no_grad():
         sm_img = _lerp(image_l, perm_l, lam_l, False)                        # mixup.py:36
         mx_img = _lerp(image_u, perm_u, lam_u, False)                        # mixup.py:22
@@ -239,6 +256,8 @@ def train_step_grouped(model, elbo_criterion, cls_criterion, optimizer, image_l,
     disc_post_u = cls_criterion(la4, mx_alpha)
     cont_post_u = continuous_posterior_loss(mu4, ls4, mx_mu, mx_sigma)
     loss_unsup = sch["ew"] * (elbo_u + sch["kl_beta_c"] * sch["pwm"] * cont_post_u) + sch["ucw"] * disc_post_u
+    if optimizer is not None and _bucketed(model, distributed) is not None:
+        _bucketed(model, distributed).arm()                                  # the step's only backward: decoder bucket overlaps it
     (loss_sup + loss_unsup).backward()                                       # :324 + :364
     if optimizer is not None:
         apply_update(model, optimizer, distributed)
@@ -288,12 +307,15 @@ def train_step(model, elbo_criterion, cls_criterion, optimizer, image_l, label_l
     with torch.no_grad():                                                    # :348-355
         mx_img, mx_mu, mx_sigma, mx_alpha, lam_u = mixup_vae_data(image_u, mu3, ls3, la3,
                                                                   optimal_match=optimal_match)
+    model._last_lams = (lam_l, lam_u)
     # (4) mixed unlabelled forward                                            :356-364
     rec4, mu4, ls4, la4, *_ = model(mx_img)
     disc_post_u = cls_criterion(la4, mx_alpha)
     cont_post_u = continuous_posterior_loss(mu4, ls4, mx_mu, mx_sigma)
     elbo_u = elbo_u + sch["kl_beta_c"] * sch["pwm"] * cont_post_u
     loss_unsup = sch["ew"] * elbo_u + sch["ucw"] * disc_post_u
+    if optimizer is not None and _bucketed(model, distributed) is not None:
+        _bucketed(model, distributed).arm()               # the LAST backward of the step (the first one's gradients are in)
     loss_unsup.backward()
     # gradient exchange + update                                              :365-366
     if optimizer is not None:
@@ -346,7 +368,11 @@ class GraphedTrainStep:
     ~12 ms of host time (measured: the eager step is host-bound below that).  The graph holds the weight re-packing,
     the four forwards, both backwards and the deferred BN running-stat updates; the gradient all-reduce and the SGD
     kernel stay outside (eager), so the collective is an ordinary RCCL call and lr can change without re-capturing.
-    Needs rng="device".  Re-capture (build a new object) when the per-epoch schedule scalars change."""
+    Needs rng="device".  Re-capture (build a new object) when the per-epoch schedule scalars change.
+    The `warmup` eager steps of the constructor are REAL training steps on the construction batch (parameter, momentum and
+    BatchNorm running-statistic updates): pass the first batch of the epoch, or warmup=1 with a throw-away learning rate.
+    After them the lambda tables are redrawn and the device counter is reset, so replay k reads entry (k - 1) mod n and a
+    refill happens exactly when the counter wraps (no entry is used twice)."""
 
     def __init__(self, model, elbo_criterion, cls_criterion, optimizer, image_l, label_l, image_u, sch, epsilon=0.1,
                  distributed=False, seed=0, warmup=2, optimal_match=False, label_u=None, schedule="grouped"):
@@ -372,6 +398,8 @@ class GraphedTrainStep:
                 self._update()
         cur.wait_stream(self.stream)
         torch.cuda.synchronize()
+        self.rng.refill()                           # the warm-up steps consumed entries 0 .. warmup-1: fresh tables,
+        self.rng.counter.zero_()                    # and replay k reads entry (k - 1) mod n
         model._engine.mark_dirty()                  # the captured sequence must start with the weight re-packing
         self.graph = torch.cuda.CUDAGraph()
         # thread_local: other threads (RCCL's watchdog polling its events at N > 1, the autograd worker's allocator
@@ -405,9 +433,9 @@ class GraphedTrainStep:
             self.iu.copy_(image_u)
             if label_u is not None and self.lu is not None:
                 self.lu.copy_(label_u)
+        if self.replays and self.replays % self.rng.n == 0:      # the device counter wrapped: this replay reads entry 0 again
+            self.rng.refill()                                   # -> fresh Beta draws first (stream-ordered before the replay)
         self.replays += 1
-        if self.replays % self.rng.n == 0:          # the device counter wraps next: fresh Beta draws, not a recycled table
-            self.rng.refill()
         self.graph.replay()
         self._update()
         return self.losses

@@ -23,13 +23,14 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), "missing export " + n
     assert set(names) == set(L.EXPORTS), set(names) ^ set(L.EXPORTS)
-    assert L.lib().sv_version() == 2
+    assert L.lib().sv_version() == 3
 
 
 def test_struct_layout_matches_header():
     assert ctypes.sizeof(L.SvPhase) == 72
     assert ctypes.sizeof(L.SvGeom) == 72 + 4 * 72
-    assert ctypes.sizeof(L.SvIgemmArgs) == 17 * 8
+    assert ctypes.sizeof(L.SvIgemmArgs) == 18 * 8
+    assert ctypes.sizeof(L.SvWgradArgs) == 10 * 8
     assert ctypes.sizeof(L.SvBnBranch) == 48
     assert ctypes.sizeof(L.SvRepackJob) == 64
 

@@ -30,6 +30,16 @@ def test_bench_fails_when_a_rank_fails():
     assert r.returncode != 0
 
 
+def test_bench_watchdog_ends_the_ranks_left_in_the_rendezvous():
+    """Rank 1 dies before the rendezvous: rank 0 would sit in it until the store times out (minutes); the launcher's
+    watchdog ends it and reports the failure within seconds."""
+    import time
+    t0 = time.time()
+    r = _run("--gpus", "2", "--dry-run", env=dict(SV_BENCH_FAIL_RANK="1"))
+    assert r.returncode == 1 and "ranks failed" in r.stderr and "(1, 3)" in r.stderr, r.stderr[-500:]
+    assert time.time() - t0 < 60
+
+
 def test_bench_rejects_mismatched_world_size():
     r = _run("--gpus", "4", "--dry-run", env=dict(WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
                                                   MASTER_PORT="29999"))

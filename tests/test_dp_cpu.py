@@ -122,3 +122,84 @@ def test_two_rank_module_gradient_bucket(tmp_path):
     assert r["n"] == 5 * 7 + 7 + 7 * 3 + 3
     for red, per_rank in zip(r["reduced"], r["locals"]):
         assert torch.allclose(red, (per_rank[0] + per_rank[1]) / 2, rtol=1e-6, atol=1e-7)
+
+
+def _worker_buckets(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    import shot_vae_amd as S
+    from shot_vae_amd import dp
+    from shot_vae_amd.train import apply_update
+    torch.set_num_threads(2)
+    dp.init_from_env(backend="gloo")
+    name, K = "wideresnet-10-1", 10
+    model = S.VariationalAutoEncoder(name, num_input_channels=3, img_size=(32, 32), data_parallel=True,
+                                     continuous_latent_dim=128, disc_latent_dim=K, small_input=True)
+    eng = model._engine
+    model._attach_grads()
+    g = torch.Generator().manual_seed(100 + rank)
+    local = torch.randn(eng.grad.numel(), generator=g)
+    # (a) one all-reduce of the flat buffer
+    eng.grad.copy_(local)
+    scale_a = dp.all_reduce_gradients(eng.grad)
+    single = eng.grad.clone()
+    # (b) decoder-first buckets: the hook fires where Engine.backward fires it (after `dgrad:dec0` has been issued), the
+    #     encoder bucket follows in finish()
+    eng.grad.copy_(local)
+    ar = dp.DecoderFirstAllReduce(model)
+    ar.arm()
+    assert eng.bucket_hook is not None
+    hook, eng.bucket_hook = eng.bucket_hook, None
+    hook()                                         # what Engine.backward does
+    head_untouched = bool(torch.equal(eng.grad[:eng.plan.dec_off], local[:eng.plan.dec_off]))
+    scale_b = ar.finish()
+    bucketed = eng.grad.clone()
+    # (c) finish() without the hook having fired = the single all-reduce
+    eng.grad.copy_(local)
+    ar2 = dp.DecoderFirstAllReduce(model)
+    scale_c = ar2.finish()
+    fallback = eng.grad.clone()
+    # (d) through apply_update(distributed="bucketed") with a plain torch optimizer: mean, not sum
+    eng.grad.copy_(local)
+    before = eng.param.clone()
+    opt = torch.optim.SGD(model.parameters(), lr=0.1)
+    apply_update(model, opt, distributed="bucketed")
+    after = eng.param.clone()
+    mask = torch.zeros_like(eng.param)            # the flat buffer also holds alignment gaps / padded channels: not parameters
+    for _, kind, payload in model._views:
+        model._flat_view(mask, kind, payload).fill_(1.0)
+    # (e) checkpoint resumed on rank 0 only: counters, momentum and the first-step flag travel with the parameters
+    sgd = S.FlatSGD(model, lr=0.1)
+    if rank == 0:
+        eng.nbt += 7
+        eng.mom = torch.full_like(eng.param, 0.25)
+        sgd._steps = 3
+        sgd.param_groups[0]["lr"] = 0.03
+    dp.broadcast_parameters(model, optimizer=sgd)
+    state = (int(eng.nbt[0]), sgd._steps, sgd.param_groups[0]["lr"], float(eng.mom.mean()) if eng.mom is not None else None)
+    states = [None] * world
+    dist.all_gather_object(states, state)
+    if rank == 0:
+        torch.save(dict(single=single, bucketed=bucketed, fallback=fallback, scales=(scale_a, scale_b, scale_c),
+                        head_untouched=head_untouched, dec_off=eng.plan.dec_off, n=eng.grad.numel(),
+                        before=before, after=after, mask=mask, states=states), out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_decoder_first_buckets_equal_the_single_all_reduce(tmp_path):
+    """dp.DecoderFirstAllReduce (decoder bucket issued during the backward, encoder bucket after it) is bit-equal to the
+    one all-reduce of the flat gradient buffer at world size 2; its fallback and apply_update(distributed="bucketed");
+    dp.broadcast_parameters(model, optimizer=...) carries num_batches_tracked and the FlatSGD state."""
+    out = str(tmp_path / "dpb.pt")
+    port = 33500 + os.getpid() % 2000
+    mp.spawn(_worker_buckets, args=(2, port, out), nprocs=2, join=True)
+    r = torch.load(out, weights_only=False)
+    assert r["scales"] == (0.5, 0.5, 0.5)
+    assert r["head_untouched"], "the decoder bucket must not touch the encoder's range"
+    assert 0.8 < 1 - r["dec_off"] / r["n"] < 1.0             # the decoder is the bulk of the bytes (99 % on WRN-10-1)
+    assert torch.equal(r["bucketed"], r["single"]) and torch.equal(r["fallback"], r["single"])
+    assert torch.allclose(r["after"], r["before"] - 0.1 * 0.5 * r["single"] * r["mask"], rtol=1e-6, atol=1e-8)
+    assert r["states"][0] == r["states"][1] == (7, 3, 0.03, 0.25)

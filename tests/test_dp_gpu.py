@@ -38,7 +38,8 @@ ll = torch.randint(0, K, (B,), device="cuda")
 rng = S.DeviceRng("cuda", seed=0)               # same seed everywhere: all ranks agree on the mixup lambdas
 losses = []
 for step in range(3):
-    ls, lu = S.train_step_grouped(model, elbo, cls, opt, il, ll, iu, S.schedule(10), distributed=True, device_rng=rng)
+    ls, lu = S.train_step_grouped(model, elbo, cls, opt, il, ll, iu, S.schedule(10), distributed="bucketed" if step else True,
+                                  device_rng=rng)      # step 0: one all-reduce; then the decoder-first buckets
     losses.append((float(ls), float(lu)))
 p = model._engine.param.detach().cpu()
 gathered = [torch.zeros_like(p) for _ in range(world)]
@@ -84,3 +85,7 @@ def test_bench_two_ranks_gloo_on_one_gpu():
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["value"] > 0
     assert out["config"]["global_batch"] == 128                 # 2 loaders x 64 images in total, 32 per rank and loader
+    # the lambda contract through the BENCH path: both ranks used the same mixup coefficients
+    assert out["config"]["lambda_equal_across_ranks"] is True
+    # --scaling strong probes both launch modes and reports both
+    assert set(out["config"]["launch_probe"]) == {"eager_ms", "graph_ms"}

@@ -136,7 +136,9 @@ def test_wgrad3x3w_equals_narrow_kernel_at_full_size(Cin, H, N):
 
 def test_config4_full_size_step_default_dispatch_repeats():
     """BASELINE config 4 at full size through the default dispatch (conv3x3x, conv3x3w, wgrad3x3w on every body layer):
-    20 steps from the same parameters, inputs and noise -- 10 sequential, 10 on the two-stream schedule the bench uses."""
+    20 steps from the same parameters, inputs and noise -- 10 on the sequential schedule (the reference's order), 10 on the
+    two-stream schedule (train_step_overlapped).  The grouped schedule that bench.py times is held to the same checks, at
+    this size and at config 2's, by tests/test_timed_path_gpu.py."""
     from shot_vae_amd.train import train_step_overlapped
     name, K, B = "wideresnet-28-10", 100, 256
     torch.manual_seed(11)

@@ -33,7 +33,9 @@ def timed(fn, iters=int(os.environ.get("SV_BENCH_ITERS", "20")), warm=int(os.env
 
 def bench_layer(B, Cin, H, N, what=("fwd", "dgrad", "wgrad")):
     KS, STR = int(os.environ.get("SV_BENCH_K", "3")), int(os.environ.get("SV_BENCH_S", "1"))     # kernel size, stride
-    if KS != 3 or STR != 1:
+    if os.environ.get("SV_BENCH_T"):
+        return bench_convT_layer(B, Cin, H, N, what)
+    if KS != 3 or STR != 1 or os.environ.get("SV_BENCH_NOPRO"):
         return bench_odd_layer(B, Cin, H, N, KS, STR, what)
     d = torch.device("cuda:0")
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -107,7 +109,11 @@ def bench_odd_layer(B, Cin, H, N, KS, STR, what):
         stats = torch.zeros(R, 2 * N, device=d)
         a = L.SvIgemmArgs()
         a.x, a.w, a.out = x.data_ptr(), wp.data_ptr(), out.data_ptr()
-        a.pro_scale, a.pro_shift, a.pro_slope = sc.data_ptr(), sh.data_ptr(), 0.01
+        if os.environ.get("SV_BENCH_NOPRO"):            # the stem: bias, no BatchNorm prologue
+            bias = torch.randn(N, device=d)
+            a.bias = bias.data_ptr()
+        else:
+            a.pro_scale, a.pro_shift, a.pro_slope = sc.data_ptr(), sh.data_ptr(), 0.01
         a.stats, a.replicas = stats.data_ptr(), R
         res["fwd"] = timed(lambda: L.call("sv_igemm", C.byref(g), L.SV_BF16, C.byref(a), st))
     if "dgrad" in what:
@@ -134,6 +140,61 @@ def bench_odd_layer(B, Cin, H, N, KS, STR, what):
     for k, us in res.items():
         print(f"B={B} Cin={Cin} N={N} H={H} k={KS} s={STR} {k:6s} {us:9.1f} us  {flops / us / 1e6:8.1f} TFLOP/s  "
               f"{flops / us / 1e-6 / PEAK:6.3f} of bf16 MFMA peak", flush=True)
+    return res
+
+
+def bench_convT_layer(B, Cin, H, N, what):
+    """The decoder's ConvTranspose2d(4, 2, 1) layers (SV_BENCH_T=1): H = INPUT size, output 2H; forward with the BatchNorm +
+    ReLU prologue and the next BatchNorm's statistics, data gradient (a 4x4 stride-2 convolution of dy) with the
+    activation-backward epilogue, weight gradient."""
+    d = torch.device("cuda:0")
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    bf = torch.bfloat16
+    Ho = 2 * H
+    x = torch.randn(B, H, H, Cin, device=d).to(bf)
+    dy = torch.randn(B, Ho, Ho, N, device=d).to(bf)
+    master = (torch.randn(N, 16, Cin, device=d) / (4 * Cin) ** 0.5).contiguous()
+    flops = 2.0 * B * H * H * 16 * Cin * N          # the PyTorch count (SURVEY.md appendix A)
+    R = int(os.environ.get("SV_BENCH_R", "8"))
+    res = {}
+    gf = G.convT_like(B, H, H, Cin, N, 4, 2, 1)
+    if "fwd" in what:
+        wp = torch.zeros(G.packed_size(gf), dtype=bf, device=d)
+        L.call("sv_repack", L.SV_BF16, C.c_void_p(master.data_ptr()), N, 16, Cin, 0, C.byref(gf), C.c_void_p(wp.data_ptr()), st)
+        out = torch.empty(B, Ho, Ho, N, dtype=bf, device=d)
+        sc, sh = torch.rand(Cin, device=d) + 0.5, torch.randn(Cin, device=d) * 0.3
+        stats = torch.zeros(R, 2 * N, device=d)
+        a = L.SvIgemmArgs()
+        a.x, a.w, a.out = x.data_ptr(), wp.data_ptr(), out.data_ptr()
+        a.pro_scale, a.pro_shift, a.pro_slope = sc.data_ptr(), sh.data_ptr(), 0.0
+        a.stats, a.replicas = stats.data_ptr(), R
+        res["fwd"] = timed(lambda: L.call("sv_igemm", C.byref(gf), L.SV_BF16, C.byref(a), st))
+    if "dgrad" in what:
+        g = G.conv_like(B, Ho, Ho, N, Cin, 4, 2, 1)
+        wp2 = torch.zeros(G.packed_size(g), dtype=bf, device=d)
+        L.call("sv_repack", L.SV_BF16, C.c_void_p(master.data_ptr()), N, 16, Cin, 1, C.byref(g), C.c_void_p(wp2.data_ptr()), st)
+        out2 = torch.empty(B, H, H, Cin, dtype=bf, device=d)
+        vec = [torch.rand(Cin, device=d) + 0.5 for _ in range(4)]
+        bs = torch.zeros(R, 2 * Cin, device=d)
+        a2 = L.SvIgemmArgs()
+        a2.x, a2.w, a2.out = dy.data_ptr(), wp2.data_ptr(), out2.data_ptr()
+        a2.ex, a2.ex_scale, a2.ex_shift, a2.ex_mean, a2.ex_rstd = [t.data_ptr() for t in [x] + vec]
+        a2.ex_slope, a2.bsums, a2.replicas = 0.0, bs.data_ptr(), R
+        res["dgrad"] = timed(lambda: L.call("sv_igemm", C.byref(g), L.SV_BF16, C.byref(a2), st))
+    if "wgrad" in what:
+        dw = torch.zeros(N, 16, Cin, device=d)
+        sc2, sh2 = torch.rand(Cin, device=d) + 0.5, torch.randn(Cin, device=d) * 0.3
+        ws = torch.empty(16 << 20, device=d)
+        res["wgrad"] = timed(lambda: L.call("sv_wgrad", C.byref(gf), L.SV_BF16, C.c_void_p(x.data_ptr()),
+                                            C.c_void_p(sc2.data_ptr()), C.c_void_p(sh2.data_ptr()), C.c_float(0.0),
+                                            C.c_void_p(dy.data_ptr()), C.c_void_p(dw.data_ptr()), 0, 1,
+                                            C.c_void_p(ws.data_ptr()), ws.numel(), 1, st))
+    es = 2
+    nb = es * (B * H * H * Cin + B * Ho * Ho * N)
+    for k, us in res.items():
+        by = nb + (4 if k == "wgrad" else es) * 16 * Cin * N + (es * B * H * H * Cin if k == "dgrad" else 0)
+        print(f"B={B} Cin={Cin} N={N} H={H} convT4x4s2 {k:6s} {us:9.1f} us  {flops / us / 1e6:8.1f} TFLOP/s  "
+              f"{flops / us / 1e-6 / PEAK:6.3f} of bf16 MFMA peak  {by / us / 1e3:7.1f} GB/s", flush=True)
     return res
 
 
