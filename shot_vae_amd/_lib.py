@@ -159,7 +159,7 @@ class options:
 # in-situ timing (bench.py): tag name -> id; every entry point is filed under its own name unless the engine filed the
 # launch under a per-layer tag first (Engine._tag, for sv_igemm / sv_wgrad)
 prof_tags = None
-_LAYER_TAGGED = ("sv_igemm", "sv_wgrad", "sv_prof_tag", "sv_prof_enable", "sv_set_option")
+_LAYER_TAGGED = ("sv_igemm", "sv_wgrad", "sv_wgrad_ex", "sv_prof_tag", "sv_prof_enable", "sv_set_option")
 
 
 def call(name, *args):

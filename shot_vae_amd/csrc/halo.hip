@@ -40,7 +40,59 @@ struct halo_cfg {
     int tslots;                 // tap slots per weight row (phases padded to whole k steps)
     int tap0[SV_MAX_PHASES];    // first tap slot of each phase
     int nks[SV_MAX_PHASES];     // k steps of each phase
+    // LDS pixel shift of every tap slot: shift[16 * phase + slot] = (dy - dymin) * LW + (dx - dxmin); a pad slot repeats
+    // tap 0 of its phase (its weights are zero).  Lane l of every wave keeps entry l in a register and the k loop reads
+    // it with v_readlane: no memory access in the loop.  (Indexing sv_phase::dy[] / dx[] in the loop compiled to FOUR
+    // global_load_sbyte from the kernel-argument segment per k step, each followed by s_waitcnt vmcnt(0) -- which also
+    // drained the prefetches of the next tiles: the thin layers ran at 1.4 - 2 TB/s with their waves waiting 55 - 63 %
+    // of the time, profiles/r03_pmc_odd.txt.)
+    int shift[SV_MAX_PHASES * 16];
 };
+
+// The k loop of both kernels: all (tap slot, channel chunk) steps of one phase out of LDS, software-pipelined by hand -- the
+// fragments of step i + 1 are requested before the MFMAs of step i (two register sets, ping-pong), the tap shift comes from
+// the lane-held table.  hb0 / hb1: the lane's two activation fragment bases (elements), wrow0: the lane's weight fragment
+// base of the phase (element pointer incl. the 16-row stride term fr * LDW is added here).
+template <typename T, int NT, int CC>
+__device__ __forceinline__ void halo_phase_mma(f32x4 (&acc)[NT][2], const T* halo, int hb0, int hb1, const T* wph, int fr, int fq,
+                                               int LDC, int LDW, int kstride /* elements between k steps of the weights */,
+                                               int nks, int nck, int ncklog, int mytab, int tab0) {
+    typedef typename V8<T>::type V;
+    constexpr int TPK = 32 / CC;
+    const int nst = nks << ncklog;
+    V a0[2], a1[2], w[2][NT];
+    auto load = [&](int st, int buf) __attribute__((always_inline)) {
+        const int ks = st >> ncklog, ck = st & (nck - 1);
+        int sh = __builtin_amdgcn_readlane(mytab, tab0 + ks * TPK);
+        if (TPK == 2) {
+            const int shb = __builtin_amdgcn_readlane(mytab, tab0 + ks * TPK + 1);
+            sh = (fq >> 1) ? shb : sh;
+        }
+        const int off = sh * LDC + CC * ck;
+        a0[buf] = *reinterpret_cast<const V*>(halo + hb0 + off);
+        a1[buf] = *reinterpret_cast<const V*>(halo + hb1 + off);
+        const T* wrow = wph + ks * kstride + CC * ck;
+#pragma unroll
+        for (int i = 0; i < NT; ++i) w[buf][i] = *reinterpret_cast<const V*>(wrow + (16 * i + fr) * LDW);
+    };
+    auto mma = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            mma32(acc[i][0], w[buf][i], a0[buf]);
+            mma32(acc[i][1], w[buf][i], a1[buf]);
+        }
+    };
+    load(0, 0);
+    int st = 0;
+    while (true) {
+        if (st + 1 < nst) load(st + 1, 1);
+        mma(0);
+        if (++st >= nst) break;
+        if (st + 1 < nst) load(st + 1, 0);
+        mma(1);
+        if (++st >= nst) break;
+    }
+}
 
 template <typename T, int NT, int CC, int NPH>
 __global__ __launch_bounds__(256) void halo_kernel(const sv_geom g, const sv_igemm_args_g AG, const halo_cfg c) {
@@ -60,6 +112,10 @@ __global__ __launch_bounds__(256) void halo_kernel(const sv_geom g, const sv_ige
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fq = lane >> 4;
+    int mytab = c.shift[lane];                                  // tap-shift table: entry l in lane l (halo_phase_mma)
+    // (the load is waited for HERE, once: a register that is still "in flight" at the head of the tile loop makes the
+    //  compiler put s_waitcnt vmcnt(0) in front of its first use in EVERY iteration, draining the tile prefetches)
+    asm volatile("v_mov_b32 %0, %0" : "+v"(mytab));
     const int Wq = 1 << c.wlog, Hq = 1 << c.hlog, HH = 1 << c.hhlog;
     const int BHq = g.B * Hq;                                   // rows of the (per-phase) output grid
     const int nT = (BHq + c.TR - 1) / c.TR;
@@ -183,31 +239,9 @@ __global__ __launch_bounds__(256) void halo_kernel(const sv_geom g, const sv_ige
 #pragma unroll
         for (int ph = 0; ph < NPH; ++ph) {
             if (ph >= g.nphase) break;
-            const sv_phase& P = g.phase[ph];
-            const int nks = c.nks[ph];
-            for (int ks = 0; ks < nks; ++ks) {
-                // tap(s) of this k step: the LDS address offset of the tap shift (a pad slot repeats tap 0: its weights are zero)
-                int sh;
-                {
-                    const int ta = ks * TPK < P.ntap ? ks * TPK : 0;
-                    const int sha = ((P.dy[ta] - c.dymin) * c.LW + (P.dx[ta] - c.dxmin)) * LDC;
-                    sh = sha;
-                    if (TPK == 2) {
-                        const int tb = ks * TPK + 1 < P.ntap ? ks * TPK + 1 : 0;
-                        const int shb = ((P.dy[tb] - c.dymin) * c.LW + (P.dx[tb] - c.dxmin)) * LDC;
-                        sh = (fq >> 1) ? shb : sha;
-                    }
-                }
-                const V af0 = *reinterpret_cast<const V*>(halo + hbase[0] + sh);
-                const V af1 = *reinterpret_cast<const V*>(halo + hbase[1] + sh);
-                const T* wrow = wl + (c.tap0[ph] + ks * TPK) * CC + 8 * fq;
-#pragma unroll
-                for (int i = 0; i < NT; ++i) {
-                    const V wf = *reinterpret_cast<const V*>(wrow + (16 * i + fr) * LDW);
-                    mma32(acc[ph][i][0], wf, af0);
-                    mma32(acc[ph][i][1], wf, af1);
-                }
-            }
+            if (c.nks[ph] > 0)
+                halo_phase_mma<T, NT, CC>(acc[ph], halo, hbase[0], hbase[1], wl + c.tap0[ph] * CC + 8 * fq, fr, fq, LDC, LDW,
+                                          TPK * CC, c.nks[ph], 1, 0, mytab, 16 * ph);
         }
     }
 
@@ -327,7 +361,8 @@ __global__ __launch_bounds__(256, 2) void halop_kernel(const sv_geom g, const sv
     constexpr int BN = 16 * NT;
     constexpr int TPK = 32 / CC;
     const sv_igemm_args& a = AG.g[blockIdx.y];
-    const int Cin = g.Cin, VPP = Cin / 8, NCK = Cin / CC;
+    const int Cin = g.Cin, VPP = Cin / 8, NCK = Cin / CC;       // NCK = 1 or 2 (Cin <= 64)
+    const int ncklog = NCK > 1 ? 1 : 0;
     const int LDC = Cin + 16;                                   // LDS pixel stride (elements)
     const int LDW = c.tslots * Cin + 16;                        // weight row stride (elements)
 
@@ -338,6 +373,10 @@ __global__ __launch_bounds__(256, 2) void halop_kernel(const sv_geom g, const sv
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fq = lane >> 4;
+    int mytab = c.shift[lane];                                  // tap-shift table: entry l in lane l (halo_phase_mma)
+    // (the load is waited for HERE, once: a register that is still "in flight" at the head of the tile loop makes the
+    //  compiler put s_waitcnt vmcnt(0) in front of its first use in EVERY iteration, draining the tile prefetches)
+    asm volatile("v_mov_b32 %0, %0" : "+v"(mytab));
     const int Wq = 1 << c.wlog, Hq = 1 << c.hlog, HH = 1 << c.hhlog;
     const int BHq = g.B * Hq;
     const int nT = (BHq + c.TR - 1) / c.TR;
@@ -515,32 +554,9 @@ __global__ __launch_bounds__(256, 2) void halop_kernel(const sv_geom g, const sv
 #pragma unroll
         for (int ph = 0; ph < NPH; ++ph) {
             if (ph >= g.nphase) break;
-            const sv_phase& P = g.phase[ph];
-            const int nks = c.nks[ph];
-            for (int ks = 0; ks < nks; ++ks) {
-                int sh;
-                {
-                    const int ta = ks * TPK < P.ntap ? ks * TPK : 0;
-                    const int sha = ((P.dy[ta] - c.dymin) * c.LW + (P.dx[ta] - c.dxmin)) * LDC;
-                    sh = sha;
-                    if (TPK == 2) {
-                        const int tb = ks * TPK + 1 < P.ntap ? ks * TPK + 1 : 0;
-                        const int shb = ((P.dy[tb] - c.dymin) * c.LW + (P.dx[tb] - c.dxmin)) * LDC;
-                        sh = (fq >> 1) ? shb : sha;
-                    }
-                }
-                const T* wrow = wl + (c.tap0[ph] + ks * TPK) * Cin + 8 * fq;
-                for (int ck = 0; ck < NCK; ++ck) {
-                    const V af0 = *reinterpret_cast<const V*>(halo + hbase[0] + sh + CC * ck);
-                    const V af1 = *reinterpret_cast<const V*>(halo + hbase[1] + sh + CC * ck);
-#pragma unroll
-                    for (int i = 0; i < NT; ++i) {
-                        const V wf = *reinterpret_cast<const V*>(wrow + (16 * i + fr) * LDW + CC * ck);
-                        mma32(acc[ph][i][0], wf, af0);
-                        mma32(acc[ph][i][1], wf, af1);
-                    }
-                }
-            }
+            if (c.nks[ph] > 0)
+                halo_phase_mma<T, NT, CC>(acc[ph], halo, hbase[0], hbase[1], wl + c.tap0[ph] * Cin + 8 * fq, fr, fq, LDC, LDW,
+                                          TPK * Cin, c.nks[ph], NCK, ncklog, mytab, 16 * ph);
         }
         __syncthreads();                               // every wave is done reading this tile's halo
         if (more) store_halo(NEXT);                    // the next tile's halo -> LDS (requested a whole tile ago)
@@ -732,6 +748,15 @@ int sv_halo_try(const sv_geom* g, int dtype, const sv_igemm_args* a, hipStream_t
         }
     }
     c.tslots = slots;
+    for (int p = 0; p < SV_MAX_PHASES; ++p)
+        for (int sl = 0; sl < 16; ++sl) {
+            int v = 0;
+            if (p < g->nphase && g->phase[p].ntap > 0) {
+                const int t = sl < g->phase[p].ntap ? sl : 0;
+                v = (g->phase[p].dy[t] - dymin) * c.LW + (g->phase[p].dx[t] - dxmin);
+            }
+            c.shift[16 * p + sl] = v;
+        }
     const int es = dtype == SV_BF16 ? 2 : 4;
     const int nt = (g->N % 32 == 0) ? 2 : 1, BN = 16 * nt;
     if (c.HP * (CC / 8) > 256 * HMAXV) return 0;
