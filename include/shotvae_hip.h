@@ -84,9 +84,14 @@ typedef struct {
     int32_t block_budget;       /* > 0: block budget of THIS launch if it takes a persistent kernel (conv3x3p, halop),
                                    overriding SV_OPT_PERSISTENT_BLOCKS -- the paired backward gives a layer's weight and
                                    data gradient half the chip each without touching process-wide state; 0 = the option */
+    int32_t flags;              /* reserved: written by the library (bit 0 = deterministic accumulation of this launch) */
 } sv_igemm_args;
 
 int sv_igemm(const sv_geom* g, int dtype, const sv_igemm_args* a, void* stream);
+/* The grid (blocks in x) sv_igemm WOULD launch for these arguments under the current options; nothing is launched.  With
+ * SV_OPT_DETERMINISTIC the per-channel accumulators (`stats` / `bsums`) need replicas >= 4 * blocks (next power of two):
+ * every wave of every block then adds to a replica of its own.                                                        */
+int sv_igemm_query_blocks(const sv_geom* g, int dtype, const sv_igemm_args* a, int* blocks);
 
 /* ---- K19 weight gradient: dW[n][torig][c] += sum_m dy[m][n] * act(x[m,t][c]) --------------------
  * Replaces autograd's convolution_backward (weight part) for the same layers.  `splits` = number
@@ -285,8 +290,22 @@ int sv_debug_conv_chunk_program(int* items, int* waits);
  * SV_OPT_HALO_ALL: 1 = the LDS-halo gather-GEMM (halo.hip) takes every geometry it covers, not only the layers it is
  * faster on (tests: the kernel's whole range against the references).  Default 0.
  * SV_OPT_PERSISTENT_BLOCKS: block budget of the persistent narrow 3x3 kernels (conv3x3p, wgrad3x3), shared among the
- * groups of a batched launch.  Default 512 (two blocks per CU); tools/tune_blocks.py sweeps it.                       */
-enum { SV_OPT_DISABLE_MASK = 0, SV_OPT_WIDE_MIN_BLOCKS = 1, SV_OPT_HALO_ALL = 2, SV_OPT_PERSISTENT_BLOCKS = 3 };
+ * groups of a batched launch.  Default 512 (two blocks per CU); tools/tune_blocks.py sweeps it.
+ * SV_OPT_DETERMINISTIC: 1 = every floating-point accumulation of the library has a FIXED summation order, so that two runs
+ * on the same inputs agree bit for bit (parity tests; slower, and the accumulator replicas grow with the grid):
+ *   - BatchNorm statistics / BatchNorm-backward sums of the conv-like kernels: no LDS float atomics, every wave of every
+ *     block adds its partial sums to a replica of its own (ONE adder per address; needs replicas >= 4 * blocks, see
+ *     sv_igemm_query_blocks; sv_igemm fails with SV_E_ARG otherwise); the consumers sum the replicas in index order;
+ *   - weight gradients: per-block partial slabs + the ordered slab reduction where the kernel has them (3x3 stride 1, the
+ *     tap-fused thin layers -- they need the workspace), otherwise ONE M range and the groups of a batched launch one after
+ *     the other (a single adder per weight); the cooperative wide kernel (float atomics over splits) is not taken;
+ *   - the wide 3x3 kernels conv3x3w / conv3x3x (cross-wave LDS atomics in their epilogue) are not taken: their layers run on
+ *     the general LDS-halo kernel (each is tested against it separately);
+ *   - the small reduction kernels (pool backward, head weight gradient, column sums, loss terms, BatchNorm dgamma / dbeta
+ *     of a batched launch) run their fixed-order variants.
+ * Default 0.                                                                                                          */
+enum { SV_OPT_DISABLE_MASK = 0, SV_OPT_WIDE_MIN_BLOCKS = 1, SV_OPT_HALO_ALL = 2, SV_OPT_PERSISTENT_BLOCKS = 3,
+       SV_OPT_DETERMINISTIC = 4 };
 enum { SV_K_CONV3X3 = 1, SV_K_CONV3X3P = 2, SV_K_CONV3X3M = 4, SV_K_CONV3X3W = 8, SV_K_CONV3X3X = 16,
        SV_K_WGRAD3X3 = 32, SV_K_WGRAD3X3W = 64, SV_K_IGEMM_KV2 = 128, SV_K_HALO = 256, SV_K_HALOP = 512, SV_K_HWGRAD = 1024, SV_K_IGEMM_BIG = 2048, SV_K_WGRAD_WIDE = 4096, SV_K_IGEMM_ALIGNED = 8192, SV_K_IGEMM_DMA = 16384, SV_K_WGRAD_INCR = 32768 };
 int sv_set_option(int key, int value);

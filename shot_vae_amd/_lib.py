@@ -33,7 +33,7 @@ class SvIgemmArgs(C.Structure):
                 ("w", C.c_void_p), ("bias", C.c_void_p), ("residual", C.c_void_p), ("out", C.c_void_p),
                 ("stats", C.c_void_p), ("ex", C.c_void_p), ("ex_scale", C.c_void_p), ("ex_shift", C.c_void_p),
                 ("ex_mean", C.c_void_p), ("ex_rstd", C.c_void_p), ("ex_slope", C.c_float), ("bsums", C.c_void_p),
-                ("replicas", C.c_int32), ("groups", C.c_int32), ("block_budget", C.c_int32)]
+                ("replicas", C.c_int32), ("groups", C.c_int32), ("block_budget", C.c_int32), ("flags", C.c_int32)]
 
 
 class SvWgradArgs(C.Structure):
@@ -56,6 +56,7 @@ class SvBnBranch(C.Structure):
 P, I, I64, F = C.c_void_p, C.c_int, C.c_int64, C.c_float
 _PROTOS = {
     "sv_igemm": [C.POINTER(SvGeom), I, C.POINTER(SvIgemmArgs), P],
+    "sv_igemm_query_blocks": [C.POINTER(SvGeom), I, C.POINTER(SvIgemmArgs), C.POINTER(C.c_int)],
     "sv_wgrad": [C.POINTER(SvGeom), I, P, P, P, F, P, P, I, I, P, I64, I, P],
     "sv_wgrad_ex": [C.POINTER(SvGeom), I, C.POINTER(SvWgradArgs), P],
     "sv_colsum": [I, P, I64, I, I, P, P],
@@ -93,7 +94,7 @@ _PROTOS = {
     "sv_get_option": [I],
     "sv_version": [],
 }
-OPT_DISABLE_MASK, OPT_WIDE_MIN_BLOCKS, OPT_HALO_ALL, OPT_PERSISTENT_BLOCKS = 0, 1, 2, 3
+OPT_DISABLE_MASK, OPT_WIDE_MIN_BLOCKS, OPT_HALO_ALL, OPT_PERSISTENT_BLOCKS, OPT_DETERMINISTIC = 0, 1, 2, 3, 4
 K_CONV3X3, K_CONV3X3P, K_CONV3X3M, K_CONV3X3W, K_CONV3X3X, K_WGRAD3X3, K_WGRAD3X3W, K_IGEMM_KV2, K_HALO, K_HALOP, K_HWGRAD, K_IGEMM_BIG, K_WGRAD_WIDE, K_IGEMM_ALIGNED, K_IGEMM_DMA, K_WGRAD_INCR = (
     1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384, 32768)
 EXPORTS = sorted(list(_PROTOS) + ["sv_last_error"])
@@ -139,9 +140,9 @@ class options:
     """with options(disable=K_CONV3X3X, wide_min_blocks=1): ...  -- dispatcher options for the duration of a block
     (tests / tools: compare a specialised kernel with the general one)."""
 
-    def __init__(self, disable=None, wide_min_blocks=None, halo_all=None, persistent_blocks=None):
+    def __init__(self, disable=None, wide_min_blocks=None, halo_all=None, persistent_blocks=None, deterministic=None):
         self.new = {OPT_DISABLE_MASK: disable, OPT_WIDE_MIN_BLOCKS: wide_min_blocks, OPT_HALO_ALL: halo_all,
-                    OPT_PERSISTENT_BLOCKS: persistent_blocks}
+                    OPT_PERSISTENT_BLOCKS: persistent_blocks, OPT_DETERMINISTIC: deterministic}
 
     def __enter__(self):
         self.old = {k: lib().sv_get_option(k) for k in self.new}
@@ -159,7 +160,22 @@ class options:
 # in-situ timing (bench.py): tag name -> id; every entry point is filed under its own name unless the engine filed the
 # launch under a per-layer tag first (Engine._tag, for sv_igemm / sv_wgrad)
 prof_tags = None
-_LAYER_TAGGED = ("sv_igemm", "sv_wgrad", "sv_wgrad_ex", "sv_prof_tag", "sv_prof_enable", "sv_set_option")
+_LAYER_TAGGED = ("sv_igemm", "sv_igemm_query_blocks", "sv_wgrad", "sv_wgrad_ex", "sv_prof_tag", "sv_prof_enable", "sv_set_option")
+
+
+def deterministic():
+    """SV_OPT_DETERMINISTIC is set: fixed summation order everywhere (include/shotvae_hip.h)"""
+    return lib().sv_get_option(OPT_DETERMINISTIC) == 1
+
+
+def det_replicas(g, code, a):
+    """replica count sv_igemm needs for `stats` / `bsums` in deterministic mode: next power of two >= 4 * blocks"""
+    blocks = C.c_int(0)
+    call("sv_igemm_query_blocks", C.byref(g), code, C.byref(a), C.byref(blocks))
+    r = 1
+    while r < 4 * blocks.value:
+        r *= 2
+    return r
 
 
 def call(name, *args):

@@ -99,11 +99,11 @@ inline sv_igemm_args_g sv_expand_groups(const sv_geom& g, const sv_igemm_args& a
             if (a.residual) r.residual = reinterpret_cast<const char*>(a.residual) + grp * os;
             if (a.ex) r.ex = reinterpret_cast<const char*>(a.ex) + grp * os;
             if (a.pro_scale) { r.pro_scale = a.pro_scale + grp * g.Cin; r.pro_shift = a.pro_shift + grp * g.Cin; }
-            if (a.stats) r.stats = a.stats + grp * a.replicas * 2 * g.N;
+            if (a.stats) r.stats = a.stats + grp * (int64_t)a.replicas * 2 * g.N;
             if (a.ex) {
                 r.ex_scale = a.ex_scale + grp * g.N; r.ex_shift = a.ex_shift + grp * g.N;
                 r.ex_mean = a.ex_mean + grp * g.N; r.ex_rstd = a.ex_rstd + grp * g.N;
-                r.bsums = a.bsums + grp * a.replicas * 2 * g.N;
+                r.bsums = a.bsums + grp * (int64_t)a.replicas * 2 * g.N;
             }
         }
         A.g[grp] = r;
@@ -141,6 +141,17 @@ struct SvBudgetScope {
     explicit SvBudgetScope(int budget);
     ~SvBudgetScope();
 };
+bool sv_deterministic();               // sv_set_option(SV_OPT_DETERMINISTIC, 1)
+enum { SV_FLAG_DET = 1 };              // sv_igemm_args::flags
+// sv_igemm_query_blocks: the launch functions call sv_dry_run(grid) right before their launch; it returns true (and records
+// the grid) when the calling thread is inside a query -- the caller then returns SV_OK without launching.  In deterministic
+// mode it also checks the replica count of a real launch (returns true with *rc < 0 when it is too small).
+bool sv_dry_run(int grid_x, const sv_igemm_args* a, int* rc);
+#define SV_LAUNCH_GATE(grid_x, a)                                \
+    do {                                                         \
+        int gate_rc_ = SV_OK;                                    \
+        if (sv_dry_run((grid_x), (a), &gate_rc_)) return gate_rc_; \
+    } while (0)
 int sv_check_launch(const char* what);
 void sv_prof_begin(hipStream_t s);
 void sv_prof_end(hipStream_t s);

@@ -425,27 +425,10 @@ __global__ __launch_bounds__(256, SV_C3P_WAVES) void conv3x3p_kernel(const sv_ge
     }
     // ---- flush the per-channel sums once per block ---------------------------------------------------------
     if (want_sums) {
+        bool allv[NT];
 #pragma unroll
-        for (int i = 0; i < NT; ++i) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) {
-                    s1[i][r] += __shfl_xor(s1[i][r], o);
-                    s2[i][r] += __shfl_xor(s2[i][r], o);
-                }
-                if (fr == 0) {
-                    atomicAdd(&ssum[16 * i + 4 * fq + r], s1[i][r]);
-                    atomicAdd(&ssum[BN + 16 * i + 4 * fq + r], s2[i][r]);
-                }
-            }
-        }
-        __syncthreads();
-        float* dst = (EX ? a.bsums : a.stats) + (size_t)(blockIdx.x & (a.replicas - 1)) * 2 * g.N;
-        if (tid < 2 * BN) {
-            const int which = tid / BN, nl = tid - which * BN;
-            atomicAdd(dst + which * g.N + n0 + nl, ssum[tid]);
-        }
+        for (int i = 0; i < NT; ++i) allv[i] = true;
+        flush_channel_sums<NT>(s1, s2, allv, ssum, EX ? a.bsums : a.stats, n0, g.N, a.replicas, a.flags);
     }
 }
 
@@ -682,27 +665,10 @@ __global__ __launch_bounds__(256) void conv3x3m_kernel(const sv_geom g, const sv
         }
     }
     if (want_sums) {
+        bool allv[NT];
 #pragma unroll
-        for (int i = 0; i < NT; ++i) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) {
-                    s1[i][r] += __shfl_xor(s1[i][r], o);
-                    s2[i][r] += __shfl_xor(s2[i][r], o);
-                }
-                if (fr == 0) {
-                    atomicAdd(&ssum[16 * i + 4 * fq + r], s1[i][r]);
-                    atomicAdd(&ssum[BN + 16 * i + 4 * fq + r], s2[i][r]);
-                }
-            }
-        }
-        __syncthreads();
-        float* dst = (EX ? a.bsums : a.stats) + (size_t)(blockIdx.x & (a.replicas - 1)) * 2 * g.N;
-        if (tid < 2 * BN) {
-            const int which = tid / BN, nl = tid - which * BN;
-            atomicAdd(dst + which * g.N + n0 + nl, ssum[tid]);
-        }
+        for (int i = 0; i < NT; ++i) allv[i] = true;
+        flush_channel_sums<NT>(s1, s2, allv, ssum, EX ? a.bsums : a.stats, n0, g.N, a.replicas, a.flags);
     }
 }
 
@@ -723,6 +689,7 @@ int launch_m(const sv_geom* g, const sv_igemm_args* a, hipStream_t s) {
             return sv_check_launch("hipFuncSetAttribute(conv3x3m)");
         optin = true;
     }
+    SV_LAUNCH_GATE(grid, a);
     sv_prof_begin(s);
     hipLaunchKernelGGL((conv3x3m_kernel<T, NT, WLOG, PT>), dim3(grid, sv_ngroups(a->groups)), dim3(256), lds, s, *g, sv_expand_groups(*g, *a, (int)sizeof(T)));
     sv_prof_end(s);
@@ -760,6 +727,7 @@ int launch_p(const sv_geom* g, const sv_igemm_args* a, hipStream_t s) {
             return sv_check_launch("hipFuncSetAttribute(conv3x3p)");
         optin = true;
     }
+    SV_LAUNCH_GATE(chunks * nNt, a);
     sv_prof_begin(s);
     hipLaunchKernelGGL((conv3x3p_kernel<T, WLOG, CCH>), dim3(chunks * nNt, sv_ngroups(a->groups)), dim3(256), lds, s, *g, sv_expand_groups(*g, *a, (int)sizeof(T)), tiles_per);
     sv_prof_end(s);
@@ -789,6 +757,7 @@ int launch(const sv_geom* g, const sv_igemm_args* a, hipStream_t s) {
             return sv_check_launch("hipFuncSetAttribute(conv3x3)");
         optin = true;
     }
+    SV_LAUNCH_GATE(grid, a);
     sv_prof_begin(s);
     hipLaunchKernelGGL((conv3x3_kernel<T, NT, WLOG>), dim3(grid, sv_ngroups(a->groups)), dim3(256), lds, s, *g, sv_expand_groups(*g, *a, (int)sizeof(T)));
     sv_prof_end(s);

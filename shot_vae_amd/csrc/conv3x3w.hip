@@ -401,6 +401,7 @@ int launch_w3(const sv_geom* g, const sv_igemm_args* a, hipStream_t s) {
             return sv_check_launch("hipFuncSetAttribute(conv3x3w)");
         optin = true;
     }
+    SV_LAUNCH_GATE(grid, a);          // (query only: these kernels are not dispatched in deterministic mode)
     sv_prof_begin(s);
     hipLaunchKernelGGL((conv3x3w_kernel<NF, WLOG, REV>), dim3(grid, sv_ngroups(a->groups)), dim3(256), lds, s, *g, sv_expand_groups(*g, *a, 2));
     sv_prof_end(s);

@@ -20,6 +20,60 @@ __device__ __forceinline__ float row16_sum(float v) {
     return v;
 }
 
+// Flush of the per-channel sums a block kept in registers (s1 / s2: lane l holds the partial sums of channels
+// 16*i + 4*(l >> 4) + r over ITS pixels) into the accumulator replica -- shared by the persistent kernels (conv3x3p,
+// conv3x3m, halo, halop).  Default: 16-lane shuffle reduction, LDS float atomics across the waves, one global atomic per
+// channel and block into replica blockIdx.x % R.  Deterministic (SV_FLAG_DET): no LDS stage, every wave adds its own sums to
+// replica (4 * blockIdx.x + wave) % R -- with R >= 4 * gridDim.x there is ONE adder per address and the consumers sum the
+// replicas in index order, so the result does not depend on timing.
+template <int NT>
+__device__ __forceinline__ void flush_channel_sums(float (&s1)[NT][4], float (&s2)[NT][4], const bool (&nval)[NT],
+                                                   float* ssum /* LDS [2][16*NT], zeroed */, float* gsum /* stats | bsums */,
+                                                   int n0, int N, int replicas, int flags) {
+    constexpr int BN = 16 * NT;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fq = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            s1[i][r] = row16_sum(s1[i][r]);
+            s2[i][r] = row16_sum(s2[i][r]);
+        }
+    if (flags & SV_FLAG_DET) {
+        float* dst = gsum + (size_t)((blockIdx.x * 4 + wave) & (replicas - 1)) * 2 * N;
+        if (fr == 0) {
+#pragma unroll
+            for (int i = 0; i < NT; ++i)
+                if (nval[i]) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        atomicAdd(dst + n0 + 16 * i + 4 * fq + r, s1[i][r]);
+                        atomicAdd(dst + N + n0 + 16 * i + 4 * fq + r, s2[i][r]);
+                    }
+                }
+        }
+        return;
+    }
+    if (fr == 0) {
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+            if (nval[i]) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    atomicAdd(&ssum[16 * i + 4 * fq + r], s1[i][r]);
+                    atomicAdd(&ssum[BN + 16 * i + 4 * fq + r], s2[i][r]);
+                }
+            }
+    }
+    __syncthreads();
+    float* dst = gsum + (size_t)(blockIdx.x & (replicas - 1)) * 2 * N;
+    if (tid < 2 * BN) {
+        const int which = tid / BN, nl = tid - which * BN;
+        if (n0 + nl < N) atomicAdd(dst + which * N + n0 + nl, ssum[tid]);
+    }
+}
+
 template <typename T, int NT, int MS = 2>
 __device__ __forceinline__ void gemm_epilogue(const f32x4 (&acc)[NT][MS], const int64_t (&obase)[MS],
                                               const bool (&oval)[MS], int n0, int N, const sv_igemm_args& a,
@@ -134,15 +188,24 @@ __device__ __forceinline__ void gemm_epilogue(const f32x4 (&acc)[NT][MS], const 
                 s2[r] = row16_sum(s2[r]);
             }
             if (fr == 0 && nval) {
+                if (a.flags & SV_FLAG_DET) {      // one adder per address: this wave's replica (see flush_channel_sums)
+                    float* dw_ = (EX ? a.bsums : a.stats) + (size_t)((blockIdx.x * 4 + (tid >> 6)) & (a.replicas - 1)) * 2 * N;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    atomicAdd(&ssum[nl + r], s1[r]);
-                    atomicAdd(&ssum[BN + nl + r], s2[r]);
+                    for (int r = 0; r < 4; ++r) {
+                        atomicAdd(dw_ + n + r, s1[r]);
+                        atomicAdd(dw_ + N + n + r, s2[r]);
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        atomicAdd(&ssum[nl + r], s1[r]);
+                        atomicAdd(&ssum[BN + nl + r], s2[r]);
+                    }
                 }
             }
         }
     }
-    if (want_sums) {
+    if (want_sums && !(a.flags & SV_FLAG_DET)) {
         __syncthreads();
         // replica chosen by block index: keeps the number of adders per address low (contended float
         // atomics on a handful of addresses were 2/3 of the kernel time before)

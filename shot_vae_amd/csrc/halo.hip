@@ -26,6 +26,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "epilogue.h"
 
 namespace {
 
@@ -319,29 +320,7 @@ __global__ __launch_bounds__(256) void halo_kernel(const sv_geom g, const sv_ige
             }
         }
     }
-    if (want_sums) {
-#pragma unroll
-        for (int i = 0; i < NT; ++i) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) {
-                    s1[i][r] += __shfl_xor(s1[i][r], o);
-                    s2[i][r] += __shfl_xor(s2[i][r], o);
-                }
-                if (fr == 0 && nval[i]) {
-                    atomicAdd(&ssum[16 * i + 4 * fq + r], s1[i][r]);
-                    atomicAdd(&ssum[BN + 16 * i + 4 * fq + r], s2[i][r]);
-                }
-            }
-        }
-        __syncthreads();
-        float* dst = (EX ? a.bsums : a.stats) + (size_t)(blockIdx.x & (a.replicas - 1)) * 2 * g.N;
-        if (tid < 2 * BN) {
-            const int which = tid / BN, nl = tid - which * BN;
-            if (n0 + nl < g.N) atomicAdd(dst + which * g.N + n0 + nl, ssum[tid]);
-        }
-    }
+    if (want_sums) flush_channel_sums<NT>(s1, s2, nval, ssum, EX ? a.bsums : a.stats, n0, g.N, a.replicas, a.flags);
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
@@ -609,29 +588,7 @@ __global__ __launch_bounds__(256, 2) void halop_kernel(const sv_geom g, const sv
         do_tile(tile, HB, HA);
         if (tile + 1 < t_end) do_tile(tile + 1, HA, HB);
     }
-    if (want_sums) {
-#pragma unroll
-        for (int i = 0; i < NT; ++i) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) {
-                    s1[i][r] += __shfl_xor(s1[i][r], o);
-                    s2[i][r] += __shfl_xor(s2[i][r], o);
-                }
-                if (fr == 0 && nval[i]) {
-                    atomicAdd(&ssum[16 * i + 4 * fq + r], s1[i][r]);
-                    atomicAdd(&ssum[BN + 16 * i + 4 * fq + r], s2[i][r]);
-                }
-            }
-        }
-        __syncthreads();
-        float* dst = (EX ? a.bsums : a.stats) + (size_t)(blockIdx.x & (a.replicas - 1)) * 2 * g.N;
-        if (tid < 2 * BN) {
-            const int which = tid / BN, nl = tid - which * BN;
-            if (n0 + nl < g.N) atomicAdd(dst + which * g.N + n0 + nl, ssum[tid]);
-        }
-    }
+    if (want_sums) flush_channel_sums<NT>(s1, s2, nval, ssum, EX ? a.bsums : a.stats, n0, g.N, a.replicas, a.flags);
 }
 
 template <typename T, int NT, int CC, int NPH>
@@ -652,6 +609,7 @@ int launch_halop(const sv_geom* g, const sv_igemm_args* a, const halo_cfg& c, si
             return sv_check_launch("hipFuncSetAttribute(halop)");
         optin = true;
     }
+    SV_LAUNCH_GATE(chunks * nNt, a);
     sv_prof_begin(s);
     hipLaunchKernelGGL((halop_kernel<T, NT, CC, NPH>), dim3(chunks * nNt, sv_ngroups(a->groups)), dim3(256), lds, s, *g,
                        sv_expand_groups(*g, *a, (int)sizeof(T)), c, tiles_per);
@@ -684,6 +642,7 @@ int launch_halo(const sv_geom* g, const sv_igemm_args* a, const halo_cfg& c, hip
             return sv_check_launch("hipFuncSetAttribute(halo)");
         optin = true;
     }
+    SV_LAUNCH_GATE(grid, a);
     sv_prof_begin(s);
     hipLaunchKernelGGL((halo_kernel<T, NT, CC, NPH>), dim3(grid, sv_ngroups(a->groups)), dim3(256), lds, s, *g,
                        sv_expand_groups(*g, *a, (int)sizeof(T)), c);

@@ -553,6 +553,7 @@ int launch_dma(const sv_geom* g, const sv_igemm_args* a, hipStream_t s) {
             return sv_check_launch("hipFuncSetAttribute(igemm_dma)");
         optin = true;
     }
+    SV_LAUNCH_GATE(grid, a);
     sv_prof_begin(s);
     hipLaunchKernelGGL((igemm_dma_kernel<NT, MS>), dim3(grid, sv_ngroups(a->groups)), dim3(256), lds, s, *g, sv_expand_groups(*g, *a, 2));
     sv_prof_end(s);
@@ -574,6 +575,7 @@ int launch_al(const sv_geom* g, const sv_igemm_args* a, hipStream_t s) {
             return sv_check_launch("hipFuncSetAttribute(igemm)");
         optin = true;
     }
+    SV_LAUNCH_GATE(grid, a);
     sv_prof_begin(s);
     hipLaunchKernelGGL((igemm_kernel<T, NT, KV, MS, AL>), dim3(grid, sv_ngroups(a->groups)), dim3(256), lds, s, *g, sv_expand_groups(*g, *a, (int)sizeof(T)));
     sv_prof_end(s);
@@ -599,8 +601,11 @@ int launch(const sv_geom* g, const sv_igemm_args* a, hipStream_t s) {
 
 }  // namespace
 
-extern "C" int sv_igemm(const sv_geom* g, int dtype, const sv_igemm_args* a, void* stream) {
-    SV_REQUIRE(g && a && a->x && a->w && a->out, SV_E_ARG, "sv_igemm: null argument");
+extern "C" int sv_igemm(const sv_geom* g, int dtype, const sv_igemm_args* a_in, void* stream) {
+    SV_REQUIRE(g && a_in && a_in->x && a_in->w && a_in->out, SV_E_ARG, "sv_igemm: null argument");
+    sv_igemm_args a_loc = *a_in;                       // `flags` belongs to the library
+    a_loc.flags = sv_deterministic() ? SV_FLAG_DET : 0;
+    const sv_igemm_args* a = &a_loc;
     SV_REQUIRE(dtype == SV_F32 || dtype == SV_BF16, SV_E_ARG, "sv_igemm: bad dtype %d", dtype);
     SV_REQUIRE(g->Cin % 16 == 0 && g->N % 16 == 0 && g->ldx % 8 == 0 && g->ldo % 4 == 0, SV_E_SHAPE,
                "sv_igemm: Cin=%d N=%d must be multiples of 16 (ldx=%d ldo=%d)", g->Cin, g->N, g->ldx, g->ldo);

@@ -30,13 +30,44 @@ int g_disable_mask = 0;
 int g_wide_min_blocks = 256;
 int g_halo_all = 0;
 int g_persistent_blocks = 512;
+int g_deterministic = 0;
+thread_local int* tl_query_blocks = nullptr;
 }  // namespace
+bool sv_deterministic() { return g_deterministic != 0; }
+bool sv_dry_run(int grid_x, const sv_igemm_args* a, int* rc) {
+    if (tl_query_blocks) {
+        *tl_query_blocks = grid_x;
+        *rc = SV_OK;
+        return true;
+    }
+    if (a && (a->flags & SV_FLAG_DET) && (a->stats || a->ex) && (int64_t)a->replicas < 4 * (int64_t)grid_x) {
+        sv_set_error("sv_igemm: deterministic mode needs replicas >= 4 * blocks = %d (got %d): size the accumulators with "
+                     "sv_igemm_query_blocks", 4 * grid_x, a->replicas);
+        *rc = SV_E_ARG;
+        return true;
+    }
+    return false;
+}
+struct SvQueryScope {
+    explicit SvQueryScope(int* out) { tl_query_blocks = out; }
+    ~SvQueryScope() { tl_query_blocks = nullptr; }
+};
+extern "C" int sv_igemm_query_blocks(const sv_geom* g, int dtype, const sv_igemm_args* a, int* blocks) {
+    SV_REQUIRE(blocks, SV_E_ARG, "sv_igemm_query_blocks: null argument");
+    *blocks = 0;
+    SvQueryScope scope(blocks);
+    return sv_igemm(g, dtype, a, nullptr);
+}
 static thread_local int tl_block_budget = 0;      // per-launch override, set for the duration of one entry-point call
 SvBudgetScope::SvBudgetScope(int budget) : old(tl_block_budget) { tl_block_budget = budget > 0 ? budget : 0; }
 SvBudgetScope::~SvBudgetScope() { tl_block_budget = old; }
 int sv_persistent_blocks() { return tl_block_budget > 0 ? tl_block_budget : g_persistent_blocks; }
 bool sv_halo_all() { return g_halo_all != 0; }
-bool sv_disabled(int kernel_bit) { return (g_disable_mask & kernel_bit) != 0; }
+bool sv_disabled(int kernel_bit) {
+    // deterministic mode: no kernel with cross-wave LDS float atomics / float atomics over splits (see shotvae_hip.h)
+    if (g_deterministic && (kernel_bit & (SV_K_CONV3X3W | SV_K_CONV3X3X | SV_K_WGRAD_WIDE))) return true;
+    return (g_disable_mask & kernel_bit) != 0;
+}
 int sv_wide_min_blocks() { return g_wide_min_blocks; }
 
 namespace {
@@ -106,6 +137,7 @@ int sv_set_option(int key, int value) {
             SV_REQUIRE(value >= 8, SV_E_ARG, "sv_set_option: SV_OPT_PERSISTENT_BLOCKS=%d", value);
             g_persistent_blocks = value;
             return SV_OK;
+        case SV_OPT_DETERMINISTIC: g_deterministic = value ? 1 : 0; return SV_OK;
     }
     sv_set_error("sv_set_option: unknown key %d", key);
     return SV_E_ARG;
@@ -117,6 +149,7 @@ int sv_get_option(int key) {
         case SV_OPT_WIDE_MIN_BLOCKS: return g_wide_min_blocks;
         case SV_OPT_HALO_ALL: return g_halo_all;
         case SV_OPT_PERSISTENT_BLOCKS: return g_persistent_blocks;
+        case SV_OPT_DETERMINISTIC: return g_deterministic;
     }
     return -1;
 }

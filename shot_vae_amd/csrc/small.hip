@@ -441,6 +441,60 @@ __global__ __launch_bounds__(256) void pool_bwd8_kernel(const T* x, const float*
     for (int i = threadIdx.x; i < 2 * C; i += 256) atomicAdd(dst + i, psum[i]);
 }
 
+// SV_OPT_DETERMINISTIC: ONE block per group walks the group's images; every thread sums its (image lane, 8-channel group)
+// in a fixed order, the image lanes meet in LDS slots and are added in index order, one add per channel leaves the block.
+template <typename T>
+__global__ __launch_bounds__(256) void pool_bwd_det_kernel(const T* x, const float* scale, const float* shift, float slope,
+                                                           const float* mean, const float* rstd, const float* dfeat, int Bg, int HW,
+                                                           int C, int ld, T* g, float* bsums) {
+    typedef typename V8<T>::type V;
+    extern __shared__ float psum[];                   // [lanes][2C]
+    const int cv = C / 8, lanes = 256 / cv;
+    const int v = threadIdx.x % cv, im = threadIdx.x / cv;
+    const int grp = blockIdx.x;
+    float s1[8], s2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s1[j] = s2[j] = 0.f;
+    if (im < lanes) {
+        const int gc = grp * C + 8 * v;
+        float sc[8], sh[8], mu[8], rs[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sc[j] = scale[gc + j], sh[j] = shift[gc + j], mu[j] = mean[gc + j], rs[j] = rstd[gc + j];
+        for (int bi = im; bi < Bg; bi += lanes) {
+            const int64_t b = (int64_t)grp * Bg + bi;
+            float d[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) d[j] = dfeat[b * C + 8 * v + j] / (float)HW;
+            const T* px = x + b * HW * ld + 8 * v;
+            T* pg = g + b * HW * ld + 8 * v;
+            for (int p = 0; p < HW; ++p) {
+                const V q = *reinterpret_cast<const V*>(px + (int64_t)p * ld);
+                V o;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float xf = to_f(q[j]);
+                    const float gv = d[j] * act_grad(xf * sc[j] + sh[j], slope);
+                    o[j] = (T)gv;
+                    s1[j] += gv;
+                    s2[j] += gv * ((xf - mu[j]) * rs[j]);
+                }
+                *reinterpret_cast<V*>(pg + (int64_t)p * ld) = o;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            psum[im * 2 * C + 8 * v + j] = s1[j];
+            psum[im * 2 * C + C + 8 * v + j] = s2[j];
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * C; i += 256) {
+        float t = 0.f;
+        for (int q = 0; q < lanes; ++q) t += psum[q * 2 * C + i];
+        atomicAdd(bsums + (size_t)grp * 2 * C + i, t);
+    }
+}
+
 // ---------------------------------------------------------------------------------------- heads
 constexpr int HS = 4;   // samples per block
 
@@ -1124,7 +1178,20 @@ int sv_bn_bwd_apply(int dtype, int64_t M, int C, int ld, const void* x, const fl
     // threads for the power-of-two widths, 240 for the 160 / 320 / 640-channel tensors of WRN-28-10 (C/8 = 20, 40, 80) -- those
     // took the LDS-coefficient path at 3.5 TB/s
     const int nthr = 256 % cv == 0 ? 256 : (cv <= 256 ? 256 / cv * cv : 0);
-    if (nthr >= 192 && (int64_t)grid * nthr >= cv) {
+    const bool reg = nthr >= 192 && (int64_t)grid * nthr >= cv;
+    if (sv_deterministic() && groups > 1) {
+        // dgamma / dbeta receive ONE add per launch (block 0): the groups one after the other, in stream order
+        bnb_params_g A;
+        DISPATCH_T(dtype, A = bnb_expand(p, groups, (int)sizeof(T)));
+        for (int grp = 0; grp < groups; ++grp) {
+            bnb_params_g one = A;
+            one.g[0] = A.g[grp];
+            if (reg) DISPATCH_T(dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<T, true>), dim3(grid, 1), dim3(nthr), lds, (hipStream_t)stream, one));
+            else DISPATCH_T(dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<T, false>), dim3(grid, 1), dim3(256), lds, (hipStream_t)stream, one));
+        }
+        return sv_check_launch("sv_bn_bwd_apply");
+    }
+    if (reg) {
         DISPATCH_T(dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<T, true>), dim3(grid, groups), dim3(nthr), lds, (hipStream_t)stream, bnb_expand(p, groups, (int)sizeof(T))));
     } else {
         DISPATCH_T(dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<T, false>), dim3(grid, groups), dim3(256), lds, (hipStream_t)stream, bnb_expand(p, groups, (int)sizeof(T))));
@@ -1135,6 +1202,13 @@ int sv_bn_bwd_apply(int dtype, int64_t M, int C, int ld, const void* x, const fl
 int sv_colsum(int dtype, const void* y, int64_t M, int N, int ld, float* out, void* stream) {
     SvProfScope prof_scope(stream);
     SV_REQUIRE(y && out && N > 0, SV_E_ARG, "sv_colsum: null");
+    if (sv_deterministic()) {       // one block per channel slice, fixed order inside it: one add per output
+        const int bx = N < 64 ? N : 64;
+        SV_REQUIRE(256 % bx == 0, SV_E_SHAPE, "sv_colsum: N=%d", N);
+        DISPATCH_T(dtype, hipLaunchKernelGGL((colsum_kernel<T>), dim3(1, (N + bx - 1) / bx), dim3(bx, 256 / bx), 0, (hipStream_t)stream,
+                                             (const T*)y, M, N, ld, out));
+        return sv_check_launch("sv_colsum");
+    }
     if (N % 8 == 0 && ld % 8 == 0 && N <= 2048 && M >= 4096) {
         const int rpp = 256 / (N / 8);
         DISPATCH_T(dtype, hipLaunchKernelGGL((colsum8_kernel<T>), dim3(nblocks(M, rpp * 8, 512)), dim3(256), N * sizeof(float),
@@ -1179,6 +1253,13 @@ int sv_pool_bwd(int dtype, const void* x, const float* scale, const float* shift
     SvProfScope prof_scope(stream);
     SV_REQUIRE(x && scale && shift && mean && rstd && dfeat && g && bsums, SV_E_ARG, "sv_pool_bwd: null");
     SV_REQUIRE(B % sv_ngroups(groups) == 0, SV_E_ARG, "sv_pool_bwd: B=%d is not a multiple of groups=%d", B, groups);
+    if (sv_deterministic() && C % 8 == 0 && ld % 8 == 0 && C / 8 <= 256) {
+        const int cv = C / 8, lanes = 256 / cv;
+        DISPATCH_T(dtype, hipLaunchKernelGGL((pool_bwd_det_kernel<T>), dim3(sv_ngroups(groups)), dim3(256), (size_t)lanes * 2 * C * sizeof(float),
+                                             (hipStream_t)stream, (const T*)x, scale, shift, slope, mean, rstd, dfeat, B / sv_ngroups(groups),
+                                             HW, C, ld, (T*)g, bsums));
+        return sv_check_launch("sv_pool_bwd");
+    }
     {
         const int Bg = B / sv_ngroups(groups), cv = C / 8;
         int P = POOL_PARTS;
@@ -1217,7 +1298,7 @@ int sv_head_bwd(const float* feat, int B, int C, const float* W, int ldc, int K,
     const size_t lds = ((size_t)HS * NH + (size_t)HS * 256) * sizeof(float);       // gradients + the thread groups' partial sums
     hipLaunchKernelGGL(head_bwd_data_kernel, dim3((B + HS - 1) / HS, (C + 255) / 256), dim3(256), lds, (hipStream_t)stream, B, C, W,
                        ldc, K, la, dmu, dls, dla, dfeat, dout_ws);
-    hipLaunchKernelGGL(head_bwd_weight_kernel, dim3(NH, B >= 64 ? 8 : 1), dim3(256), 0, (hipStream_t)stream, feat,
+    hipLaunchKernelGGL(head_bwd_weight_kernel, dim3(NH, (B >= 64 && !sv_deterministic()) ? 8 : 1), dim3(256), 0, (hipStream_t)stream, feat,
                        dout_ws, B, C, NH, dW, dbias);
     return sv_check_launch("sv_head_bwd");
 }
@@ -1259,7 +1340,7 @@ int sv_elbo_fwd(const float* x, const float* x_rec, int64_t n_per_img, const flo
     SvProfScope prof_scope(stream);
     SV_REQUIRE(x && x_rec && mu && ls && la && out3, SV_E_ARG, "sv_elbo_fwd: null");
     const int64_t n = n_per_img * B;
-    hipLaunchKernelGGL(elbo_fwd_kernel, dim3(nblocks(n / 4, 256, 1024)), dim3(256), 0, (hipStream_t)stream, x, x_rec,
+    hipLaunchKernelGGL(elbo_fwd_kernel, dim3(sv_deterministic() ? 1 : nblocks(n / 4, 256, 1024)), dim3(256), 0, (hipStream_t)stream, x, x_rec,
                        n, mu, ls, la, B, ldc, K, bce, x_sigma, log_prior_f32(K), out3);
     return sv_check_launch("sv_elbo_fwd");
 }
@@ -1278,7 +1359,7 @@ int sv_elbo_bwd(const float* x, const float* x_rec, int64_t n_per_img, const flo
 int sv_cls_fwd(const float* predict, const float* label, const float* weight, int B, int K, float* out, void* stream) {
     SvProfScope prof_scope(stream);
     SV_REQUIRE(predict && label && out, SV_E_ARG, "sv_cls_fwd: null");
-    hipLaunchKernelGGL(cls_fwd_kernel, dim3(nblocks((int64_t)B * K, 256, 64)), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(cls_fwd_kernel, dim3(sv_deterministic() ? 1 : nblocks((int64_t)B * K, 256, 64)), dim3(256), 0, (hipStream_t)stream,
                        predict, label, weight, B, K, out);
     return sv_check_launch("sv_cls_fwd");
 }
@@ -1301,7 +1382,7 @@ int sv_post_fwd(const float* mu, const float* ls, const float* mu_t, const float
                 void* stream) {
     SvProfScope prof_scope(stream);
     SV_REQUIRE(mu && ls && mu_t && sigma_t && out, SV_E_ARG, "sv_post_fwd: null");
-    hipLaunchKernelGGL(post_fwd_kernel, dim3(nblocks((int64_t)B * D, 256, 64)), dim3(256), 0, (hipStream_t)stream, mu,
+    hipLaunchKernelGGL(post_fwd_kernel, dim3(sv_deterministic() ? 1 : nblocks((int64_t)B * D, 256, 64)), dim3(256), 0, (hipStream_t)stream, mu,
                        ls, mu_t, sigma_t, B, D, out);
     return sv_check_launch("sv_post_fwd");
 }

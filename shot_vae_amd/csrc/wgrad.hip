@@ -573,6 +573,20 @@ extern "C" int sv_wgrad(const sv_geom* g, int dtype, const void* x, const float*
     SV_REQUIRE(groups >= 0 && groups <= SV_MAX_GROUPS, SV_E_ARG, "sv_wgrad: groups=%d (at most %d)", groups, SV_MAX_GROUPS);
     SV_REQUIRE(!pro_scale || (pro_slope >= 0.f && pro_slope <= 1.f), SV_E_ARG,
                "sv_wgrad: activation slope %g outside [0, 1]", (double)pro_slope);
+    if (sv_deterministic() && sv_ngroups(groups) > 1) {
+        // fixed summation order: the groups of a batched launch one after the other (stream order), each a launch whose
+        // blocks add ONCE per weight (partial slabs + ordered reduction, or a single M range of the generic kernel)
+        const int es = dtype == SV_BF16 ? 2 : 4;
+        const int64_t xs = (int64_t)g->B * g->Hin * g->Win * g->ldx * es, ys = (int64_t)g->B * g->Hout * g->Wout * g->ldo * es;
+        for (int grp = 0; grp < groups; ++grp) {
+            const int rc = sv_wgrad(g, dtype, reinterpret_cast<const char*>(x) + grp * xs, pro_scale ? pro_scale + grp * g->Cin : nullptr,
+                                    pro_shift ? pro_shift + grp * g->Cin : nullptr, pro_slope,
+                                    reinterpret_cast<const char*>(dy) + grp * ys, dw, splits, use_tr, ws, ws_elems, 1, stream);
+            if (rc != SV_OK) return rc;
+        }
+        return SV_OK;
+    }
+    if (sv_deterministic()) splits = 1;          // (generic kernel: one M range = one adder per weight)
     if (dtype == SV_F32 || use_tr) {   // stride-1 3x3: LDS-halo kernels (wgrad3x3.hip) unless switched off
         int rc = 0;
         if (!sv_disabled(SV_K_WGRAD3X3) && sv_wgrad3x3_try(g, dtype, x, pro_scale, pro_shift, pro_slope, dy, dw, ws, ws_elems, sv_ngroups(groups), (hipStream_t)stream, &rc))

@@ -952,6 +952,7 @@ int sv_wgrad3x3_try(const sv_geom* g, int dtype, const void* x, const float* pro
         p.tiles_per = (nT + splits - 1) / splits;
         const int64_t needw = (int64_t)splits * g->N * g->T_orig * g->Cin;
         p.ws = (ws && ws_elems >= needw && splits > 1) ? ws : nullptr;
+        if (!p.ws && splits > 1 && sv_deterministic()) return 0;      // (the splits would meet in dw through float atomics)
         switch (g->Win) {
             case 32: *rc = launch_wide<5>(g, p, s); break;
             case 16: *rc = launch_wide<4>(g, p, s); break;
@@ -972,6 +973,7 @@ int sv_wgrad3x3_try(const sv_geom* g, int dtype, const void* x, const float* pro
     p.splits = splits;
     const int64_t need = (int64_t)splits * groups * g->N * g->T_orig * g->Cin;
     p.ws = (ws && ws_elems >= need && splits * groups > 1) ? ws : nullptr;    // no workspace: atomics straight into dw
+    if (!p.ws && splits * groups > 1 && sv_deterministic()) return 0;
     switch (g->Win) {
         case 32: *rc = dtype == SV_BF16 ? launch<bf16, 5>(g, p, s) : launch<float, 5>(g, p, s); break;
         case 16: *rc = dtype == SV_BF16 ? launch<bf16, 4>(g, p, s) : launch<float, 4>(g, p, s); break;

@@ -421,11 +421,25 @@ class Engine:
         if residual is not None:
             a.residual = residual.data_ptr()
         a.replicas = 1
+        # deterministic mode (SV_OPT_DETERMINISTIC): the accumulator needs one replica per wave of the launch's grid, which
+        # only the dispatcher knows -- `stats` / the bsums slot of `ex` is then a callable(replicas) -> pointer that
+        # allocates it once the grid has been queried
         if stats is not None:
-            a.stats, a.replicas = stats
+            if callable(stats):
+                a.stats = x.data_ptr()           # (placeholder for the query: the dispatch does not depend on it)
+                a.replicas = L.det_replicas(g, self.code, a)
+                a.stats = stats(a.replicas)
+            else:
+                a.stats, a.replicas = stats
         if ex is not None:
             a.ex = ex[0].data_ptr()
-            a.ex_scale, a.ex_shift, a.ex_mean, a.ex_rstd, a.ex_slope, a.bsums, a.replicas = ex[1:]
+            a.ex_scale, a.ex_shift, a.ex_mean, a.ex_rstd, a.ex_slope = ex[1:6]
+            if callable(ex[6]):
+                a.bsums = x.data_ptr()
+                a.replicas = L.det_replicas(g, self.code, a)
+                a.bsums = ex[6](a.replicas)
+            else:
+                a.bsums, a.replicas = ex[6:]
         if tag:
             self._tag(tag, g, (residual is not None) + (ex is not None), groups=groups)
         L.call("sv_igemm", C.byref(g), self.code, C.byref(a), self._stream())
@@ -527,10 +541,11 @@ class Engine:
 
         # per-forward scratch: BN statistics [G][R][2C] (zeroed), BN affine/mean/rstd [G][C]
         n_stat = 0
-        stat_off, stat_rep = {}, {}
+        stat_off, stat_rep, stat_c = {}, {}, {}
 
         def stat_slot(name, c, rows):
             nonlocal n_stat
+            stat_c[name] = c
             stat_off[name] = n_stat
             stat_rep[name] = _replicas(rows)
             n_stat += _align(G * stat_rep[name] * 2 * c)
@@ -545,6 +560,8 @@ class Engine:
             stat_slot("h%d" % i, p.dec_convs[i].N, B * p.dec_convs[i].Hout ** 2)
         stats = torch.zeros(n_stat, dtype=torch.float32, device=dev)
         sbase = stats.data_ptr()
+        det = training and L.deterministic()
+        det_stats = {}                 # deterministic mode: name -> (tensor [G][R][2C], R), sized by the launch's grid
         bn_off, n_bnbuf = self._bn_layout(G)
         bnbuf = torch.empty(n_bnbuf, dtype=torch.float32, device=dev)
         nb = bnbuf.data_ptr()
@@ -558,7 +575,11 @@ class Engine:
         def finalize(b, stat_name, count):
             sc, sh, mn, rs = bn_ptrs(b)
             if training:
-                L.call("sv_bn_finalize", _vp(sbase + 4 * stat_off[stat_name]), stat_rep[stat_name], b.C, float(count),
+                if det:
+                    sp, sr = det_stats[stat_name][0].data_ptr(), det_stats[stat_name][1]
+                else:
+                    sp, sr = sbase + 4 * stat_off[stat_name], stat_rep[stat_name]
+                L.call("sv_bn_finalize", _vp(sp), sr, b.C, float(count),
                        _vp(pbase + 4 * b.gamma_off), _vp(pbase + 4 * b.beta_off), BN_EPS, BN_MOMENTUM,
                        None if defer else _vp(bbase + 4 * b.rm_off), None if defer else _vp(bbase + 4 * b.rv_off),
                        _vp(sc), _vp(sh), _vp(mn), _vp(rs), G, st)
@@ -571,7 +592,15 @@ class Engine:
 
         def sptr(name):
             # in eval mode BN uses running statistics; batch statistics are not accumulated
-            return (sbase + 4 * stat_off[name], stat_rep[name]) if training else None
+            if not training:
+                return None
+            if det:
+                def alloc(replicas, name=name):
+                    t = torch.zeros(G * replicas * 2 * stat_c[name], dtype=torch.float32, device=dev)
+                    det_stats[name] = (t, replicas)
+                    return t.data_ptr()
+                return alloc
+            return (sbase + 4 * stat_off[name], stat_rep[name])
 
         f = FwdCtx()
         f.B, f.G, f.groups, f.temperature, f.training = B, G, groups, temperature, training
@@ -734,6 +763,8 @@ class Engine:
             tot += _align(G * bs_rep[b.index] * 2 * b.C)
         bsums = torch.zeros(tot, dtype=torch.float32, device=dev)
         bs_off = {k: bsums.data_ptr() + 4 * v for k, v in bs_rel.items()}
+        det = L.deterministic()
+        det_keep = []                  # deterministic mode: per-BatchNorm accumulators sized by the producing launch's grid
 
         def bnp(b):
             a = _align(G * b.C)
@@ -742,6 +773,13 @@ class Engine:
 
         def ex_of(b, raw):
             sc, sh, mn, rs = bnp(b)
+            if det:
+                def alloc(replicas, b=b):
+                    t = torch.zeros(G * replicas * 2 * b.C, dtype=torch.float32, device=dev)
+                    det_keep.append(t)
+                    bs_off[b.index], bs_rep[b.index] = t.data_ptr(), replicas
+                    return t.data_ptr()
+                return (raw, sc, sh, mn, rs, b.slope, alloc, None)
             return (raw, sc, sh, mn, rs, b.slope, bs_off[b.index], bs_rep[b.index])
 
         def bn_apply(raw, branches, residual, count):

@@ -923,3 +923,69 @@ def test_tap_fused_wgrad_convT(H, Cin, N, B):
     torch.cuda.synchronize()
     got = dw.cpu().view(N, 4, 4, Cin).permute(3, 0, 1, 2)
     assert rel(got, w.grad) < tol, rel(got, w.grad)
+
+
+# ------------------------------------------------------------------------------------------ deterministic accumulation
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("case", [(8, 32, 32, 16, 3, 1, 1), (6, 64, 64, 16, 3, 1, 1), (5, 64, 128, 8, 3, 2, 1), (8, 16, 32, 32, 3, 1, 1),
+                                  (4, 32, 64, 16, 1, 2, 0), (4, 160, 160, 8, 3, 1, 1), (16, 128, 128, 8, 3, 1, 1)])
+def test_deterministic_mode_reproduces_bit_for_bit(dt, case):
+    """SV_OPT_DETERMINISTIC: the BatchNorm statistics of a forward, the BatchNorm-backward sums of a data gradient (groups =
+    2) and the weight gradient are IDENTICAL over repeated launches (one adder per accumulator address: replicas sized by
+    sv_igemm_query_blocks; ordered slab reduction / a single M range for the weights), agree with the atomic path to
+    rounding, and a replica count below 4 x blocks is refused."""
+    B, Cin, N, H, k, stride, pad = case
+    code, tdt, tol = DT[dt]
+    Gn, d = 2, dev()
+    torch.manual_seed(5)
+    Ho = (H + 2 * pad - k) // stride + 1
+    x = torch.randn(Gn * B, H, H, Cin, device=d).to(tdt)
+    sc, sh = (torch.rand(Gn, Cin, device=d) + 0.5).contiguous(), (torch.randn(Gn, Cin, device=d) * 0.3).contiguous()
+    emu, ers = (torch.randn(Gn, Cin, device=d) * 0.1).contiguous(), (torch.rand(Gn, Cin, device=d) + 0.5).contiguous()
+    w = bq(torch.randn(N, k * k, Cin) / (k * k * Cin) ** 0.5, dt)
+    gf = G.conv_like(B, H, H, Cin, N, k, stride, pad)
+    gd = G.convT_like(B, Ho, Ho, N, Cin, k, stride, pad)
+    wf, wd = repack(w, gf, False, dt), repack(w, gd, True, dt)
+    dy = torch.randn(Gn * B, Ho, Ho, N, device=d).to(tdt)
+    ws = torch.empty(8 * 1024 * 1024, device=d)
+
+    def run(det, replicas=None):
+        with L.options(deterministic=int(det), wide_min_blocks=1):
+            a = L.SvIgemmArgs()
+            out = torch.zeros(Gn * B, Ho, Ho, N, dtype=tdt, device=d)
+            a.x, a.w, a.out = x.data_ptr(), wf.data_ptr(), out.data_ptr()
+            a.pro_scale, a.pro_shift, a.pro_slope, a.groups = sc.data_ptr(), sh.data_ptr(), 0.01, Gn
+            a.stats = x.data_ptr()
+            R = replicas or (L.det_replicas(gf, code, a) if det else 4)
+            stats = torch.zeros(Gn, R, 2 * N, device=d)
+            a.stats, a.replicas = stats.data_ptr(), R
+            L.call("sv_igemm", C.byref(gf), code, C.byref(a), st())
+            a2 = L.SvIgemmArgs()
+            dx = torch.zeros(Gn * B, H, H, Cin, dtype=tdt, device=d)
+            a2.x, a2.w, a2.out, a2.groups = dy.data_ptr(), wd.data_ptr(), dx.data_ptr(), Gn
+            a2.ex, a2.ex_scale, a2.ex_shift, a2.ex_mean, a2.ex_rstd = (t.data_ptr() for t in (x, sc, sh, emu, ers))
+            a2.ex_slope, a2.bsums = 0.01, x.data_ptr()
+            R2 = replicas or (L.det_replicas(gd, code, a2) if det else 4)
+            bs = torch.zeros(Gn, R2, 2 * Cin, device=d)
+            a2.bsums, a2.replicas = bs.data_ptr(), R2
+            L.call("sv_igemm", C.byref(gd), code, C.byref(a2), st())
+            dw = torch.zeros(N, k * k, Cin, device=d)
+            L.call("sv_wgrad", C.byref(gf), code, p(x), p(sc), p(sh), 0.01, p(dy), p(dw), 0, int(dt == "bf16"), p(ws), ws.numel(),
+                   Gn, st())
+            torch.cuda.synchronize()
+            # the consumers' order: replicas in index order
+            return out, stats.double().sum(1).float(), stats, dx, bs, dw
+
+    ref = run(False)
+    first = run(True)
+    for _ in range(3):
+        again = run(True)
+        assert torch.equal(again[2], first[2]), "statistics differ between two deterministic launches"
+        assert torch.equal(again[4], first[4]), "BatchNorm-backward sums differ between two deterministic launches"
+        assert torch.equal(again[5], first[5]), "weight gradient differs between two deterministic launches"
+        assert torch.equal(again[0], first[0]) and torch.equal(again[3], first[3])
+    # every replica address received at most one add: a replica row is either untouched or one wave's sums
+    assert rel(first[1], ref[1]) < 1e-4 and rel(first[4].sum(1), ref[4].sum(1)) < 1e-4
+    assert rel(first[5], ref[5]) < 2e-4 and torch.equal(first[0], ref[0]) and torch.equal(first[3], ref[3])
+    with pytest.raises(L.ShotVaeHipError, match="replicas"):
+        run(True, replicas=2)

@@ -31,8 +31,9 @@ def param_grads(model):
     return {k.replace(".module.", "."): p.grad.detach().float().cpu().clone() for k, p in model.named_parameters()}
 
 
-@pytest.mark.parametrize("tag", list(T.STEP_CASES))
-def test_step_matches_reference_goldens_fp32(tag):
+def _golden_case(tag, gate_grad_sample):
+    """One run of a reference fixture through the sequential step; asserts everything but the strided gradient sample,
+    whose worst relative error over the steps is returned (asserted here only when gate_grad_sample is given)."""
     name, K, Bl, Bu, bce, x_sigma, om, dmi, steps = T.STEP_CASES[tag]
     g = T.load(tag)
     model = make_model(name, K, "fp32", C.make_state(name, K=K))
@@ -42,6 +43,7 @@ def test_step_matches_reference_goldens_fp32(tag):
     opt.zero_grad()
     sch = O.schedule(10, dmi=dmi)
     names = [str(n) for n in g["meta.param_names"]]
+    worst_gs, flat = 0.0, None
     for s in range(steps):
         il, ll, iu, lu = C.make_batch(Bl, Bu, K, stream0=7000 + 10 * s)
         nz = C.make_noise(Bl, Bu, K, stream0=9000 + 100 * s)
@@ -64,8 +66,12 @@ def test_step_matches_reference_goldens_fp32(tag):
         assert not bad.any(), (tag, s, [(names[i], gn[i], gr[i]) for i in np.nonzero(bad)[0][:5]])
         gs = np.concatenate([grads[k].reshape(-1)[torch.from_numpy(T.sample_idx(grads[k].numel()))].numpy()
                              for k in names])
-        # (2e-2: at B = 2 the order of the float atomics alone moves this between 0.9e-2 and 1.1e-2 on WRN-28-10)
-        assert T.rel_err(gs, g["s%d.grad_sample" % s]) < 2e-2, (tag, s, "grad_sample")
+        e_gs = T.rel_err(gs, g["s%d.grad_sample" % s])
+        worst_gs = max(worst_gs, e_gs)
+        if gate_grad_sample is not None:
+            assert e_gs < gate_grad_sample, (tag, s, "grad_sample", e_gs)
+        if s == 0:
+            flat = model.flat_parameters()[1].detach().clone()
         opt.step()
         opt.zero_grad()
     torch.cuda.synchronize()
@@ -78,6 +84,28 @@ def test_step_matches_reference_goldens_fp32(tag):
         if k.startswith("final.buf."):
             key = k[len("final.buf."):]
             assert T.rel_err(sd[key].numpy(), g[k]) < 1e-3, key
+    return worst_gs, flat
+
+
+@pytest.mark.parametrize("tag", list(T.STEP_CASES))
+def test_step_matches_reference_goldens_fp32(tag):
+    """The reference's own outputs, through the DETERMINISTIC accumulation mode (SV_OPT_DETERMINISTIC: fixed summation
+    order of the BatchNorm statistics / backward sums and of the weight-gradient merges): the round-1 gates hold -- 1e-3 on
+    losses, logits and reconstructions, 1e-2 on the strided gradient sample -- and a second run agrees BIT FOR BIT."""
+    from shot_vae_amd import _lib as L
+    with L.options(deterministic=1):
+        gs1, flat1 = _golden_case(tag, 1e-2)
+        gs2, flat2 = _golden_case(tag, 1e-2)
+    assert gs1 == gs2 and torch.equal(flat1, flat2), "deterministic mode: two runs differ (%g vs %g)" % (gs1, gs2)
+
+
+def test_step_matches_reference_goldens_fp32_atomic_path_median():
+    """The production accumulation (float atomics: the order of the adders varies from run to run) on the fixture with the
+    largest spread (WRN-28-10, B = 2: 0.9e-2 ... 1.1e-2 on the gradient sample): the MEDIAN of five runs meets the same
+    1e-2 gate, every single run a sanity bound of 2e-2."""
+    vals = [_golden_case("ref_step_wrn28_10_k100", 2e-2)[0] for _ in range(5)]
+    print("\n[atomic path] gradient-sample errors of five runs: %s" % ["%.3e" % v for v in sorted(vals)])
+    assert sorted(vals)[2] < 1.05e-2, vals
 
 
 def test_m2_baseline_step_matches_reference_golden_fp32():
@@ -260,38 +288,43 @@ def _oracle_run(name, K, il, ll, iu, nz, sch, dt):
     return st, out
 
 
-@pytest.mark.parametrize("dtype,tol_s,tol_t,tol_g", [("fp32", 1e-3, 1e-3, 1.5e-2), ("bf16", 5e-3, 3e-2, 0.25)])
-def test_step_matches_oracle_b64(dtype, tol_s, tol_t, tol_g):
-    """WRN-28-2, B_l=64 / B_u=48 (ragged), default init, random noise: HIP path vs the CPU oracle.
-    Loss terms / outputs against the fp32 oracle; gradients against an fp64 run of the oracle, because
-    the fp32 oracle itself sits ~5e-3 (per-tensor relative L2) away from fp64 on this network."""
-    name, K, Bl, Bu = "wideresnet-28-2", 10, 64, 48
-    torch.manual_seed(3)
-    il, ll = torch.rand(Bl, 3, 32, 32), torch.randint(0, K, (Bl,))
-    iu = torch.rand(Bu, 3, 32, 32)
-    nz = O.make_noise(Bl, Bu, K, seed=11)
-    nz["lam_l"] = 0.85            # Beta(0.1,0.1) draws are ~0 or ~1: keep the mixed forward non-degenerate
-    sch = O.schedule(10)
-    st, ref = _oracle_run(name, K, il, ll, iu, nz, sch, torch.float32)
-    st64, _ = _oracle_run(name, K, il, ll, iu, nz, sch, torch.float64)
-    init = O.default_init(name, K=K, seed=5)
-    model = make_model(name, K, dtype, init, dp=True)
-    elbo, cls = S.VAECriterion(discrete_dim=K, bce_reconstruction=True).cuda(), S.ClsCriterion()
+_B64 = {}
+
+
+def _b64_setup():
+    """inputs, noise and the CPU oracle's fp32 / fp64 runs of the B_l=64 / B_u=48 WRN-28-2 step (computed once per session)"""
+    if not _B64:
+        name, K, Bl, Bu = "wideresnet-28-2", 10, 64, 48
+        torch.manual_seed(3)
+        il, ll = torch.rand(Bl, 3, 32, 32), torch.randint(0, K, (Bl,))
+        iu = torch.rand(Bu, 3, 32, 32)
+        nz = O.make_noise(Bl, Bu, K, seed=11)
+        nz["lam_l"] = 0.85            # Beta(0.1,0.1) draws are ~0 or ~1: keep the mixed forward non-degenerate
+        sch = O.schedule(10)
+        st, ref = _oracle_run(name, K, il, ll, iu, nz, sch, torch.float32)
+        st64, _ = _oracle_run(name, K, il, ll, iu, nz, sch, torch.float64)
+        _B64.update(name=name, K=K, il=il, ll=ll, iu=iu, nz=nz, sch=sch, st=st, ref=ref, st64=st64,
+                    init=O.default_init(name, K=K, seed=5))
+    return _B64
+
+
+def _b64_run(dtype):
+    """One HIP run of that step; returns its deviations from the oracle."""
+    d = _b64_setup()
+    model = make_model(d["name"], d["K"], dtype, d["init"], dp=True)
+    elbo, cls = S.VAECriterion(discrete_dim=d["K"], bce_reconstruction=True).cuda(), S.ClsCriterion()
     S.FlatSGD(model).zero_grad()
-    with T.rng_for_step(nz):
-        out = S.train_step(model, elbo, cls, None, il.cuda(), ll.cuda(), iu.cuda(), sch, return_outputs=True)
+    with T.rng_for_step(d["nz"]):
+        out = S.train_step(model, elbo, cls, None, d["il"].cuda(), d["ll"].cuda(), d["iu"].cuda(), d["sch"], return_outputs=True)
     torch.cuda.synchronize()
+    m = {"scalar": {}, "tensor": {}, "tensor_grad": {}}
     for k in T.SCALARS:
-        r = float(ref[k])
-        # the posterior terms are differences between the outputs of TWO forwards (mixed input vs mixed outputs): their bf16
-        # rounding noise is twice that of the ELBO terms and run-to-run spread (float-atomic order of the BatchNorm sums)
-        # reaches 5.3e-3 about once in ten runs -- gate them at 1e-2, the ELBO terms and the two totals at 5e-3
-        tol_k = 2 * tol_s if (dtype == "bf16" and "_post_" in k) else tol_s
-        assert abs(float(out[k]) - r) <= tol_k * max(abs(r), 1e-6), (dtype, k, float(out[k]), r)
+        r = float(d["ref"][k])
+        m["scalar"][k] = abs(float(out[k]) - r) / max(abs(r), 1e-6)
     for k in T.TENSORS:
-        e = T.rel_err(out[k].float().cpu().numpy(), ref[k].numpy())
-        assert e < tol_t, (dtype, k, e)
+        m["tensor"][k] = T.rel_err(out[k].float().cpu().numpy(), d["ref"][k].numpy())
     grads = param_grads(model)
+    st64 = d["st64"]
     gmax = max(float(st64[k].grad.norm()) for k in st64 if O.is_param(k))
     fa, fb, worst = [], [], (0.0, "")
     for k in st64:
@@ -302,26 +335,64 @@ def test_step_matches_oracle_b64(dtype, tol_s, tol_t, tol_g):
         fb.append(b.flatten())
         err = float((a - b).norm()) / max(float(b.norm()), 1e-4 * gmax)
         worst = max(worst, (err, k))
-        if dtype == "fp32":
-            assert err < tol_g, (dtype, k, err)
+        m["tensor_grad"][k] = err
     fa, fb = torch.cat(fa), torch.cat(fb)
-    cos = float(fa @ fb / fa.norm() / fb.norm())
-    grel = float((fa - fb).norm() / fb.norm())
-    print("\n[%s] flat-gradient cosine %.5f, relative L2 error %.4f, worst tensor %.3f (%s)" % (dtype, cos, grel, *worst))
-    if dtype == "bf16":
-        # This step is ill-conditioned in bf16: torch's own bf16 autocast of the oracle (CPU, same inputs)
-        # gives cosine 0.914 / relative error 0.416 / worst tensor 0.74 against the fp64 gradient
-        # (measured in the build container).  The HIP bf16 path must be at least that good.  Its own
-        # run-to-run spread (the order of the float atomics in the BatchNorm sums decides a few bf16 roundings) is
-        # typically 0.930-0.940 / 0.36-0.375, with about one run in ten outside it -- the gate sits at torch's own figures.
-        assert cos > 0.914 and grel < 0.416 and worst[0] < 0.74, (cos, grel, worst)
-    # BN running statistics after the four forwards
+    m["cos"] = float(fa @ fb / fa.norm() / fb.norm())
+    m["grel"] = float((fa - fb).norm() / fb.norm())
+    m["worst"] = worst
+    m["flat"] = model.flat_parameters()[1].detach().clone()
+    m["loss"] = (float(out["loss_sup"]), float(out["loss_unsup"]))
     sd = {k.replace(".module.", "."): v for k, v in model.state_dict().items()}
-    for k in st:
-        if k.endswith("running_mean") or k.endswith("running_var"):
-            assert T.rel_err(sd[k].float().cpu().numpy(), st[k].numpy()) < (1e-3 if dtype == "fp32" else 2e-2), k
-        if k.endswith("num_batches_tracked"):
-            assert int(sd[k]) == int(st[k]) == 4
+    st = d["st"]
+    m["running"] = max(T.rel_err(sd[k].float().cpu().numpy(), st[k].numpy()) for k in st
+                       if k.endswith("running_mean") or k.endswith("running_var"))
+    m["nbt"] = {int(sd[k]) for k in st if k.endswith("num_batches_tracked")}
+    return m
+
+
+@pytest.mark.parametrize("dtype,tol_s,tol_t,tol_g", [("fp32", 1e-3, 1e-3, 1.5e-2), ("bf16", 5e-3, 3e-2, 0.25)])
+def test_step_matches_oracle_b64(dtype, tol_s, tol_t, tol_g):
+    """WRN-28-2, B_l=64 / B_u=48 (ragged), default init, random noise: HIP path vs the CPU oracle, in the DETERMINISTIC
+    accumulation mode (SV_OPT_DETERMINISTIC) so that the gates can sit at the values SURVEY.md 8d derives instead of
+    following float-atomic noise.  Loss terms / outputs against the fp32 oracle (bf16: ALL twelve loss scalars at 5e-3);
+    gradients against an fp64 run of the oracle, because the fp32 oracle itself sits ~5e-3 (per-tensor relative L2) away
+    from fp64 on this network.  A second run must agree bit for bit."""
+    from shot_vae_amd import _lib as L
+    with L.options(deterministic=1):
+        m = _b64_run(dtype)
+        m2 = _b64_run(dtype)
+    assert m["loss"] == m2["loss"] and torch.equal(m["flat"], m2["flat"]), "deterministic mode: two runs differ"
+    for k, e in m["scalar"].items():
+        assert e <= tol_s, (dtype, k, e)
+    for k, e in m["tensor"].items():
+        assert e < tol_t, (dtype, k, e)
+    if dtype == "fp32":
+        for k, e in m["tensor_grad"].items():
+            assert e < tol_g, (dtype, k, e)
+    print("\n[%s, deterministic] flat-gradient cosine %.5f, relative L2 error %.4f, worst tensor %.3f (%s)"
+          % (dtype, m["cos"], m["grel"], *m["worst"]))
+    if dtype == "bf16":
+        # This step is ill-conditioned in bf16: torch's own bf16 autocast of the oracle (CPU, same inputs) gives cosine
+        # 0.914 / relative error 0.416 / worst tensor 0.74 against the fp64 gradient (measured in the build container, see
+        # DESIGN.md).  The HIP bf16 path must BEAT that: the round-1 gates.
+        assert m["cos"] > 0.93 and m["grel"] < 0.40 and m["worst"][0] < 0.74, (m["cos"], m["grel"], m["worst"])
+    assert m["running"] < (1e-3 if dtype == "fp32" else 2e-2)
+    assert m["nbt"] == {4}
+
+
+def test_step_matches_oracle_b64_bf16_atomic_path_median():
+    """The same step through the production accumulation (float atomics; which bf16 roundings flip depends on the order of
+    the adders): the MEDIAN of five runs meets the same gates as the deterministic run, every single run torch-autocast's
+    own figures (the sanity bound the round-2 gate had drifted to)."""
+    runs = [_b64_run("bf16") for _ in range(5)]
+    med = lambda xs: sorted(xs)[len(xs) // 2]
+    print("\n[bf16, atomic path] cosines %s" % ["%.4f" % r["cos"] for r in runs])
+    for k in T.SCALARS:
+        assert med([r["scalar"][k] for r in runs]) <= 5e-3, (k, [r["scalar"][k] for r in runs])
+        assert max(r["scalar"][k] for r in runs) <= 1e-2, k
+    assert med([r["cos"] for r in runs]) > 0.93 and med([r["grel"] for r in runs]) < 0.40
+    for r in runs:
+        assert r["cos"] > 0.914 and r["grel"] < 0.416 and r["worst"][0] < 0.74, (r["cos"], r["grel"], r["worst"])
 
 
 def test_wrn28_10_bf16_step_through_wide_kernels_tracks_oracle():
