@@ -171,6 +171,8 @@ def deterministic():
 def det_replicas(g, code, a):
     """replica count sv_igemm needs for `stats` / `bsums` in deterministic mode: next power of two >= 4 * blocks"""
     blocks = C.c_int(0)
+    if a.replicas < 1:
+        a.replicas = 1                 # (the argument check wants a power of two; the query does not use it)
     call("sv_igemm_query_blocks", C.byref(g), code, C.byref(a), C.byref(blocks))
     r = 1
     while r < 4 * blocks.value:
