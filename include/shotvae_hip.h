@@ -142,6 +142,12 @@ int sv_bn_finalize(const float* stats, int replicas, int C, float count, const f
  * applied in group order.                                                                                  */
 int sv_bn_running_update(const int32_t* table, const float* counts, int nbn, const float* bnbuf, float* bufs,
                          float eps, float momentum, int align, int groups, void* stream);
+/* The same with an explicit order of the momentum updates: order[k] = the group whose statistics the k-th forward of the
+ * reference left (HOST array of `groups` ints, a permutation; NULL = group order).  A batched launch may hold the forwards
+ * in any order -- e.g. (1)(3)(2)(4), so that the two forwards whose reconstruction enters the loss are adjacent -- and the
+ * running statistics still receive the updates as the reference applies them.                                         */
+int sv_bn_running_update_ex(const int32_t* table, const float* counts, int nbn, const float* bnbuf, float* bufs,
+                            float eps, float momentum, int align, int groups, const int32_t* order, void* stream);
 /* eval-mode affine from running statistics (main_shot_vae.py:409-510 path)                         */
 int sv_bn_eval_affine(int C, const float* gamma, const float* beta, const float* running_mean,
                       const float* running_var, float eps, float* scale, float* shift, void* stream);
@@ -217,6 +223,30 @@ int sv_topk_hits(const float* score, const int64_t* label, int B, int K, int k, 
  * out[b] = lam*f(a[b]) + (1-lam)*f(a[index[b]]), f = exp when `exp_space` else identity.           */
 int sv_mix_lerp(const float* a, const int64_t* index, float lam, const float* lam_dev, int B, int64_t row,
                 int exp_space, float* out, void* stream);
+
+/* random permutations from uniform keys (the device-side replacement of torch.randperm, mixup.py:20,34): perm[rank of
+ * key i] = i within each of `batches` key vectors of length n (<= 16384); ties: the lower index first.                */
+int sv_rank_permutation(const float* keys, int n, int batches, int64_t* perm, void* stream);
+
+/* ---- fused loss stage of the SHOT-VAE step (main_shot_vae.py:289-323,340-363) ---------------------------------------
+ * sv_shot_targets: the targets of the mixed forwards (2) and (4) in one launch -- label_smoothing / mixup_vae_data
+ * (lib/utils/mixup.py:22-25,36-39) applied to the outputs of forwards (1) [mu_l, ls_l] and (3) [mu_u, ls_u, la_u]:
+ *   sm_mu = lerp(mu_l, perm_l, lam_l), sm_sigma = lerp(exp(ls_l), ...), mx_mu / mx_sigma / mx_alpha likewise with
+ *   (perm_u, lam_u), lab_mix = lam_l * onehot(label_l) + (1 - lam_l) * onehot(label_l[perm_l]) -- the ONE soft label
+ *   that replaces the two ClsCriterion terms of :316-318 (the criterion is linear in its label).  lam_*_dev (optional
+ *   device scalars) override lam_* (hipGraph capture).  All outputs fp32 [B][D] / [B][K].
+ * sv_shot_compose: terms[0..9] = recon_l, KLc_l, KLd_l, recon_u, KLc_u, KLd_u, disc_post_l, cont_post_l, disc_post_u,
+ *   cont_post_u (as written by sv_elbo_fwd / sv_cls_fwd / sv_post_fwd) -> terms[10] = loss_supervised, terms[11] =
+ *   loss_unsupervised; coef[i] = d loss / d terms[i] (10 floats).
+ * sv_shot_scale: gvec[i] = coef[i] * (upstream gradient of the loss term i belongs to): the `gout` operands of
+ *   sv_elbo_bwd (gvec, gvec + 3), sv_cls_bwd (gvec + 6, gvec + 8) and sv_post_bwd (gvec + 7, gvec + 9).              */
+typedef struct { float ew, kl_beta_c, kl_beta_d, cmi, dmi, pwm, ucw; } sv_shot_schedule;
+int sv_shot_targets(const float* mu_l, const float* ls_l, const float* mu_u, const float* ls_u, const float* la_u,
+                    const int64_t* label_l, const int64_t* perm_l, const int64_t* perm_u, float lam_l, const float* lam_l_dev,
+                    float lam_u, const float* lam_u_dev, int B, int D, int K, float* sm_mu, float* sm_sigma, float* lab_mix,
+                    float* mx_mu, float* mx_sigma, float* mx_alpha, void* stream);
+int sv_shot_compose(float* terms, const sv_shot_schedule* sch, float* coef, void* stream);
+int sv_shot_scale(const float* coef, const float* g_sup, const float* g_unsup, float* gvec, void* stream);
 
 /* ---- K18 optimal-match pairing (lib/utils/mixup.py:9-18,93-99): index[i] = argmin_{j!=rank0} ----
  * second-smallest entry of row i of the pairwise Gaussian-KL matrix.                               */

@@ -48,6 +48,10 @@ class SvRepackJob(C.Structure):
                 ("block0", C.c_int32), ("torig", C.c_int8 * MAX_TAPS)]
 
 
+class SvShotSchedule(C.Structure):
+    _fields_ = [(n, C.c_float) for n in ("ew", "kl_beta_c", "kl_beta_d", "cmi", "dmi", "pwm", "ucw")]
+
+
 class SvBnBranch(C.Structure):
     _fields_ = [("g", C.c_void_p), ("bsums", C.c_void_p), ("gamma", C.c_void_p), ("dgamma", C.c_void_p),
                 ("dbeta", C.c_void_p), ("replicas", C.c_int32)]
@@ -63,6 +67,7 @@ _PROTOS = {
     "sv_bn_finalize": [P, I, I, F, P, P, F, F, P, P, P, P, P, P, I, P],
     "sv_bn_eval_affine": [I, P, P, P, P, F, P, P, P],
     "sv_bn_running_update": [P, P, I, P, P, F, F, I, I, P],
+    "sv_bn_running_update_ex": [P, P, I, P, P, F, F, I, I, C.POINTER(C.c_int32), P],
     "sv_bn_bwd_apply": [I, I64, I, I, P, P, P, F, C.POINTER(SvBnBranch), I, P, P, I, P],
     "sv_pool_fwd": [I, P, P, P, F, I, I, I, I, P, I, P],
     "sv_pool_bwd": [I, P, P, P, F, P, P, P, I, I, I, I, P, P, I, P],
@@ -79,6 +84,10 @@ _PROTOS = {
     "sv_post_bwd": [P, P, P, P, I, I, P, P, P, P],
     "sv_mix_lerp": [P, P, F, P, I, I64, I, P, P],
     "sv_optimal_match": [P, P, I, I, P, P],
+    "sv_rank_permutation": [P, I, I, P, P],
+    "sv_shot_targets": [P, P, P, P, P, P, P, P, F, P, F, P, I, I, I, P, P, P, P, P, P, P],
+    "sv_shot_compose": [P, C.POINTER(SvShotSchedule), P, P],
+    "sv_shot_scale": [P, P, P, P, P],
     "sv_sgd": [P, P, P, I64, F, F, F, F, I, P],
     "sv_nchw_to_nhwc": [I, P, I, I, I, I, I, P, P],
     "sv_nhwc_to_nchw": [I, P, I, I, I, I, I, P, P],

@@ -70,14 +70,15 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* stats, in
 // table[bn] = {offset of the BN's (scale,shift,mean,rstd) block in bnbuf, running_mean offset, running_var offset, C}
 __global__ __launch_bounds__(256) void bn_running_update_kernel(const int32_t* table, const float* counts,
                                                                 const float* bnbuf, float* bufs, float eps,
-                                                                float momentum, int align, int groups) {
+                                                                float momentum, int align, int groups, int order) {
     const int bn = blockIdx.x;
     const int boff = table[4 * bn], rmo = table[4 * bn + 1], rvo = table[4 * bn + 2], C = table[4 * bn + 3];
     const int ca = (groups * C + align - 1) / align * align;       // each of the four arrays is [groups][C], padded
     const float n = counts[bn];
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
         float rm = bufs[rmo + c], rv = bufs[rvo + c];
-        for (int gi = 0; gi < groups; ++gi) {                        // the groups' updates in order: (1)(2)(3)(4)
+        for (int k = 0; k < groups; ++k) {                           // the updates in the reference's forward order
+            const int gi = (order >> (4 * k)) & 15;                    // (nibble k = the group of the k-th forward)
             const float mu = bnbuf[boff + 2 * ca + gi * C + c], rs = bnbuf[boff + 3 * ca + gi * C + c];
             float var = 1.f / (rs * rs) - eps;
             var = var > 0.f ? var : 0.f;
@@ -867,6 +868,85 @@ __global__ void post_bwd_kernel(const float* mu, const float* ls, const float* m
     dls[i] = g * (e - st[i]) * e;
 }
 
+// random permutations from uniform keys: perm[r] = i where r = rank of key i among the n keys of its batch (ties: the lower
+// index first) -- blockIdx.y = batch; n is a minibatch size (<= a few thousand), so the O(n^2) counting pass in LDS beats a
+// device-wide radix sort (torch.rand(n).argsort(): ~5 launches) by an order of magnitude
+__global__ __launch_bounds__(256) void rank_perm_kernel(const float* keys, int n, int64_t* perm) {
+    extern __shared__ float kk[];
+    const float* k = keys + (size_t)blockIdx.y * n;
+    int64_t* p = perm + (size_t)blockIdx.y * n;
+    for (int i = threadIdx.x; i < n; i += 256) kk[i] = k[i];
+    __syncthreads();
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const float v = kk[i];
+        int r = 0;
+        for (int j = 0; j < n; ++j) r += (kk[j] < v || (kk[j] == v && j < i)) ? 1 : 0;
+        p[r] = i;
+    }
+}
+
+// ---------------------------------------------------------------------------------------- fused loss stage of the step
+// Targets of the mixed forwards in ONE launch: label_smoothing / mixup_vae_data (lib/utils/mixup.py:22-25,36-39) applied to
+// the OUTPUTS of forwards (1) and (3) -- gather-lerps of mu, exp(log_sigma), exp(log_alpha) and of the one-hot labels
+// (onehot(label[perm]) = onehot(label)[perm], and ClsCriterion is linear in its label argument, so the two label terms of
+// main_shot_vae.py:316-318 are one soft label lam * onehot(y) + (1 - lam) * onehot(y[perm])).
+__global__ __launch_bounds__(256) void shot_targets_kernel(const float* mu_l, const float* ls_l, const float* mu_u, const float* ls_u,
+                                                           const float* la_u, const int64_t* label_l, const int64_t* perm_l,
+                                                           const int64_t* perm_u, float lam_l, const float* lam_l_dev, float lam_u,
+                                                           const float* lam_u_dev, int B, int D, int K, float* sm_mu,
+                                                           float* sm_sigma, float* lab_mix, float* mx_mu, float* mx_sigma,
+                                                           float* mx_alpha) {
+    if (lam_l_dev) lam_l = lam_l_dev[0];
+    if (lam_u_dev) lam_u = lam_u_dev[0];
+    const int b = blockIdx.x;
+    const int64_t pl = perm_l[b], pu = perm_u[b];
+    for (int j = threadIdx.x; j < D; j += blockDim.x) {
+        const int64_t i = (int64_t)b * D + j;
+        sm_mu[i] = lam_l * mu_l[i] + (1.f - lam_l) * mu_l[pl * D + j];
+        sm_sigma[i] = lam_l * expf(ls_l[i]) + (1.f - lam_l) * expf(ls_l[pl * D + j]);
+        mx_mu[i] = lam_u * mu_u[i] + (1.f - lam_u) * mu_u[pu * D + j];
+        mx_sigma[i] = lam_u * expf(ls_u[i]) + (1.f - lam_u) * expf(ls_u[pu * D + j]);
+    }
+    const int ya = (int)label_l[b], yb = (int)label_l[pl];
+    for (int k = threadIdx.x; k < K; k += blockDim.x) {
+        const int64_t i = (int64_t)b * K + k;
+        lab_mix[i] = lam_l * (k == ya ? 1.f : 0.f) + (1.f - lam_l) * (k == yb ? 1.f : 0.f);
+        mx_alpha[i] = lam_u * expf(la_u[i]) + (1.f - lam_u) * expf(la_u[pu * K + k]);
+    }
+}
+
+// terms[0..9] = recon_l, KLc_l, KLd_l, recon_u, KLc_u, KLd_u, disc_post_l, cont_post_l, disc_post_u, cont_post_u ->
+// terms[10] = loss_supervised, terms[11] = loss_unsupervised (main_shot_vae.py:293-296,316-323,343-346,358-363) and
+// coef[i] = d(loss that contains term i) / d(term i)   (|.| has gradient sign(.), 0 at 0 like torch.abs)
+__global__ void shot_compose_kernel(float* terms, sv_shot_schedule s, float* coef) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    auto sgn = [](float v) { return v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f); };
+    const float cp = s.kl_beta_c * s.pwm;
+    const float elbo_l = terms[0] + s.kl_beta_c * fabsf(terms[1] - s.cmi) + s.kl_beta_d * fabsf(terms[2] - s.dmi) + cp * terms[7];
+    const float elbo_u = terms[3] + s.kl_beta_c * fabsf(terms[4] - s.cmi) + s.kl_beta_d * fabsf(terms[5] - s.dmi) + cp * terms[9];
+    terms[10] = s.ew * elbo_l + terms[6];
+    terms[11] = s.ew * elbo_u + s.ucw * terms[8];
+    coef[0] = s.ew;
+    coef[1] = s.ew * s.kl_beta_c * sgn(terms[1] - s.cmi);
+    coef[2] = s.ew * s.kl_beta_d * sgn(terms[2] - s.dmi);
+    coef[3] = s.ew;
+    coef[4] = s.ew * s.kl_beta_c * sgn(terms[4] - s.cmi);
+    coef[5] = s.ew * s.kl_beta_d * sgn(terms[5] - s.dmi);
+    coef[6] = 1.f;
+    coef[7] = s.ew * cp;
+    coef[8] = s.ucw;
+    coef[9] = s.ew * cp;
+}
+
+// upstream gradients of the two losses times the per-term coefficients -> the `gout` operands of the backward kernels
+__global__ void shot_scale_kernel(const float* coef, const float* g_sup, const float* g_unsup, float* gvec) {
+    const int i = threadIdx.x;
+    if (i >= 10) return;
+    const bool sup = i < 3 || i == 6 || i == 7;
+    const float g = sup ? (g_sup ? g_sup[0] : 0.f) : (g_unsup ? g_unsup[0] : 0.f);
+    gvec[i] = coef[i] * g;
+}
+
 // ---------------------------------------------------------------------------------------- mixup
 __global__ void mix_lerp_kernel(const float* a, const int64_t* index, float lam, const float* lam_dev, int B,
                                 int64_t row, int exp_space, float* out) {
@@ -1134,13 +1214,27 @@ int sv_bn_finalize(const float* stats, int replicas, int C, float count, const f
     return sv_check_launch("sv_bn_finalize");
 }
 
-int sv_bn_running_update(const int32_t* table, const float* counts, int nbn, const float* bnbuf, float* bufs,
-                         float eps, float momentum, int align, int groups, void* stream) {
+int sv_bn_running_update_ex(const int32_t* table, const float* counts, int nbn, const float* bnbuf, float* bufs,
+                            float eps, float momentum, int align, int groups, const int32_t* order, void* stream) {
     SvProfScope prof_scope(stream);
     SV_REQUIRE(table && counts && bnbuf && bufs && nbn > 0 && align > 0, SV_E_ARG, "sv_bn_running_update: bad args");
+    groups = sv_ngroups(groups);
+    SV_REQUIRE(groups <= 8, SV_E_ARG, "sv_bn_running_update: groups=%d (at most 8)", groups);
+    int packed = 0, seen = 0;
+    for (int k = 0; k < groups; ++k) {
+        const int gi = order ? order[k] : k;
+        SV_REQUIRE(gi >= 0 && gi < groups && !(seen & (1 << gi)), SV_E_ARG, "sv_bn_running_update: order is not a permutation");
+        seen |= 1 << gi;
+        packed |= gi << (4 * k);
+    }
     hipLaunchKernelGGL(bn_running_update_kernel, dim3(nbn), dim3(256), 0, (hipStream_t)stream, table, counts, bnbuf,
-                       bufs, eps, momentum, align, sv_ngroups(groups));
+                       bufs, eps, momentum, align, groups, packed);
     return sv_check_launch("sv_bn_running_update");
+}
+
+int sv_bn_running_update(const int32_t* table, const float* counts, int nbn, const float* bnbuf, float* bufs,
+                         float eps, float momentum, int align, int groups, void* stream) {
+    return sv_bn_running_update_ex(table, counts, nbn, bnbuf, bufs, eps, momentum, align, groups, nullptr, stream);
 }
 
 int sv_bn_eval_affine(int C, const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
@@ -1393,6 +1487,41 @@ int sv_post_bwd(const float* mu, const float* ls, const float* mu_t, const float
     hipLaunchKernelGGL(post_bwd_kernel, dim3(((int64_t)B * D + 255) / 256), dim3(256), 0, (hipStream_t)stream, mu, ls,
                        mu_t, sigma_t, B, D, gout, dmu, dls);
     return sv_check_launch("sv_post_bwd");
+}
+
+int sv_rank_permutation(const float* keys, int n, int batches, int64_t* perm, void* stream) {
+    SvProfScope prof_scope(stream);
+    SV_REQUIRE(keys && perm && n > 0 && batches > 0, SV_E_ARG, "sv_rank_permutation: bad argument");
+    SV_REQUIRE(n <= 16384, SV_E_SHAPE, "sv_rank_permutation: n=%d (at most 16384 keys per permutation)", n);
+    hipLaunchKernelGGL(rank_perm_kernel, dim3((n + 255) / 256, batches), dim3(256), n * sizeof(float), (hipStream_t)stream, keys, n, perm);
+    return sv_check_launch("sv_rank_permutation");
+}
+
+int sv_shot_targets(const float* mu_l, const float* ls_l, const float* mu_u, const float* ls_u, const float* la_u,
+                    const int64_t* label_l, const int64_t* perm_l, const int64_t* perm_u, float lam_l, const float* lam_l_dev,
+                    float lam_u, const float* lam_u_dev, int B, int D, int K, float* sm_mu, float* sm_sigma, float* lab_mix,
+                    float* mx_mu, float* mx_sigma, float* mx_alpha, void* stream) {
+    SvProfScope prof_scope(stream);
+    SV_REQUIRE(mu_l && ls_l && mu_u && ls_u && la_u && label_l && perm_l && perm_u && sm_mu && sm_sigma && lab_mix && mx_mu &&
+               mx_sigma && mx_alpha && B > 0 && D > 0 && K > 0, SV_E_ARG, "sv_shot_targets: bad argument");
+    hipLaunchKernelGGL(shot_targets_kernel, dim3(B), dim3(128), 0, (hipStream_t)stream, mu_l, ls_l, mu_u, ls_u, la_u, label_l,
+                       perm_l, perm_u, lam_l, lam_l_dev, lam_u, lam_u_dev, B, D, K, sm_mu, sm_sigma, lab_mix, mx_mu, mx_sigma,
+                       mx_alpha);
+    return sv_check_launch("sv_shot_targets");
+}
+
+int sv_shot_compose(float* terms, const sv_shot_schedule* sch, float* coef, void* stream) {
+    SvProfScope prof_scope(stream);
+    SV_REQUIRE(terms && sch && coef, SV_E_ARG, "sv_shot_compose: null");
+    hipLaunchKernelGGL(shot_compose_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, terms, *sch, coef);
+    return sv_check_launch("sv_shot_compose");
+}
+
+int sv_shot_scale(const float* coef, const float* g_sup, const float* g_unsup, float* gvec, void* stream) {
+    SvProfScope prof_scope(stream);
+    SV_REQUIRE(coef && gvec, SV_E_ARG, "sv_shot_scale: null");
+    hipLaunchKernelGGL(shot_scale_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, coef, g_sup, g_unsup, gvec);
+    return sv_check_launch("sv_shot_scale");
 }
 
 int sv_mix_lerp(const float* a, const int64_t* index, float lam, const float* lam_dev, int B, int64_t row,

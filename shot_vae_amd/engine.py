@@ -514,7 +514,7 @@ class Engine:
             lay = self._bn_layouts[G] = (off, o)
         return lay
 
-    def forward(self, image, groups, eps, u, temperature, training, keep):
+    def forward(self, image, groups, eps, u, temperature, training, keep, rec_groups=None, update_order=None):
         """One BATCHED forward of G = len(groups) independent instances of the network that share the weights (the
         forwards (1)-(4) of a SHOT-VAE step, main_shot_vae.py:288,311,329,356, or a single one): every launch carries
         the G groups (sv_igemm_args::groups), each with its OWN BatchNorm batch statistics -- the reference's
@@ -524,6 +524,12 @@ class Engine:
         groups  list of (mode, label, label_mix, lam): the sampler mode of each group (vae.py:38-52): 0 Gumbel-softmax,
                 1 one-hot(label), 2 lam * onehot(label) + (1 - lam) * onehot(label_mix)
         eps, u  [G * B, ldc] Gaussian noise, [G * B, K] uniform noise (rows of groups with mode != 0 are ignored) or None
+        rec_groups  Gd <= G: only the first Gd groups' reconstructions are produced (and their decoder differentiated).  The
+                reconstructions of the mixed forwards (2) and (4) enter no loss term (main_shot_vae.py:311,356: `*_`), so the
+                step puts (1) and (3) first and skips the last ConvTranspose of the other two and their whole decoder
+                backward -- the decoder up to its last BatchNorm still runs for every group: its running statistics are
+                updated by every train-mode forward.  rec is then [Gd * B, ...].
+        update_order  order[k] = the group of the reference's k-th forward (running-statistic updates; default group order)
         Returns (rec NCHW fp32, mu, ls, la, ctx-or-None), all [G * B, ...]."""
         self._require_gpu(image)
         p = self.plan
@@ -531,6 +537,8 @@ class Engine:
         Bt = image.shape[0]
         assert Bt % G == 0, "the groups of a batched forward have equal batch sizes"
         B = Bt // G
+        Gd = G if rec_groups is None else int(rec_groups)
+        assert 1 <= Gd <= G
         dev = image.device
         T = self.tdtype
         st = self._stream()
@@ -604,6 +612,7 @@ class Engine:
 
         f = FwdCtx()
         f.B, f.G, f.groups, f.temperature, f.training = B, G, groups, temperature, training
+        f.Gd = Gd
         f.bnbuf, f.bn_off = bnbuf, bn_off
         # stem (wideresnet.py:13-14): NCHW fp32 -> NHWC16, conv3x3 + bias, stats of t0
         x16 = torch.empty(Bt, p.img, p.img, CPAD, dtype=T, device=dev)
@@ -669,21 +678,22 @@ class Engine:
         f.dpro = []
         for i, cv in enumerate(p.dec_convs):
             ho = cv.Hout
-            out = torch.empty(Bt, ho, ho, cv.N, dtype=T, device=dev)
+            gl = G if i < 5 else Gd        # the last ConvTranspose (no BatchNorm behind it): only where rec is needed
+            out = torch.empty(gl * B, ho, ho, cv.N, dtype=T, device=dev)
             self._igemm(cv.geom_fwd(B), x, pk + es * cv.fwd_off, out, pro=pro,
-                        stats=sptr("h%d" % i) if i < 5 else None, tag="fwd:dec%d" % i, groups=G)
+                        stats=sptr("h%d" % i) if i < 5 else None, tag="fwd:dec%d" % i, groups=gl)
             f.h.append(out)
             if i < 5:
                 pro = finalize(p.dec_bns[i], "h%d" % i, B * ho * ho)
                 f.dpro.append(pro)
                 x = out
-        rec = torch.empty(Bt, p.in_ch, p.img, p.img, dtype=torch.float32, device=dev)
-        L.call("sv_nhwc_to_nchw", self.code, _vp(f.h[5].data_ptr()), Bt, p.in_ch, p.img, p.img, p.dec_convs[5].N,
+        rec = torch.empty(Gd * B, p.in_ch, p.img, p.img, dtype=torch.float32, device=dev)
+        L.call("sv_nhwc_to_nchw", self.code, _vp(f.h[5].data_ptr()), Gd * B, p.in_ch, p.img, p.img, p.dec_convs[5].N,
                _vp(rec.data_ptr()), st)
         if training:
             if defer:      # running stats + counter applied by apply_pending(), in slot order (= the reference's forward order)
                 slot = self.defer_slot if self.defer_slot is not None else len(self._pending)
-                self._pending[slot] = (bnbuf, B, G)
+                self._pending[slot] = (bnbuf, B, G, update_order)
                 if self.defer_slot is None:
                     self.apply_pending()
             else:
@@ -708,7 +718,7 @@ class Engine:
         dev = self.param.device
         total = 0
         for k in sorted(self._pending):
-            bnbuf, B, G = self._pending[k]
+            bnbuf, B, G, order = self._pending[k]
             tab = self._run_tables.get((dev, "tab", G))
             if tab is None:
                 bn_off, _ = self._bn_layout(G)
@@ -722,8 +732,9 @@ class Engine:
             cnt = self._run_tables.get(key)
             if cnt is None:
                 cnt = self._run_tables[key] = torch.tensor(self._bn_counts(B), dtype=torch.float32, device=dev)
-            L.call("sv_bn_running_update", _vp(tab.data_ptr()), _vp(cnt.data_ptr()), len(p.bns), _vp(bnbuf.data_ptr()),
-                   _vp(self.bufs.data_ptr()), BN_EPS, BN_MOMENTUM, 64, G, self._stream())
+            oarr = (C.c_int32 * G)(*order) if order is not None else None
+            L.call("sv_bn_running_update_ex", _vp(tab.data_ptr()), _vp(cnt.data_ptr()), len(p.bns), _vp(bnbuf.data_ptr()),
+                   _vp(self.bufs.data_ptr()), BN_EPS, BN_MOMENTUM, 64, G, oarr, self._stream())
             total += G
         self.nbt += total
         self._pending = {}
@@ -771,19 +782,21 @@ class Engine:
             q = nb + 4 * f.bn_off[b.index]
             return q, q + 4 * a, q + 8 * a, q + 12 * a
 
-        def ex_of(b, raw):
+        def ex_of(b, raw, Gx=None):
+            Gx = Gx or G
             sc, sh, mn, rs = bnp(b)
             if det:
                 def alloc(replicas, b=b):
-                    t = torch.zeros(G * replicas * 2 * b.C, dtype=torch.float32, device=dev)
+                    t = torch.zeros(Gx * replicas * 2 * b.C, dtype=torch.float32, device=dev)
                     det_keep.append(t)
                     bs_off[b.index], bs_rep[b.index] = t.data_ptr(), replicas
                     return t.data_ptr()
                 return (raw, sc, sh, mn, rs, b.slope, alloc, None)
             return (raw, sc, sh, mn, rs, b.slope, bs_off[b.index], bs_rep[b.index])
 
-        def bn_apply(raw, branches, residual, count):
+        def bn_apply(raw, branches, residual, count, Gx=None):
             """branches: [(g tensor, BNSpec)] sharing `raw`; returns dL/d(raw) (+ residual).  count = rows of ONE group."""
+            Gx = Gx or G
             arr = (L.SvBnBranch * len(branches))()
             for k, (g, b) in enumerate(branches):
                 arr[k].g = g.data_ptr()
@@ -798,42 +811,48 @@ class Engine:
             cc = raw.shape[-1]
             # reads x and one g per branch (+ the residual), writes dx
             self._cost("sv_bn_bwd_apply", raw.numel() * raw.element_size() * (2 + len(branches) + (residual is not None)))
-            L.call("sv_bn_bwd_apply", self.code, raw.numel() // cc // G, cc, cc, _vp(raw.data_ptr()), _vp(mn), _vp(rs),
+            L.call("sv_bn_bwd_apply", self.code, raw.numel() // cc // Gx, cc, cc, _vp(raw.data_ptr()), _vp(mn), _vp(rs),
                    float(count), arr, len(branches), _vp(residual.data_ptr()) if residual is not None else None,
-                   _vp(dx.data_ptr()), G, st)
+                   _vp(dx.data_ptr()), Gx, st)
             return dx
 
-        # ---- decoder ------------------------------------------------------------------------
-        last = p.dec_convs[5]
-        D = torch.empty(Bt, p.img, p.img, last.N, dtype=T, device=dev)
-        L.call("sv_nchw_to_nhwc", self.code, _vp(d_rec.data_ptr()), Bt, p.in_ch, p.img, p.img, last.N,
-               _vp(D.data_ptr()), st)
-        for i in range(5, 0, -1):
-            cv, b = p.dec_convs[i], p.dec_bns[i - 1]
-            hin = f.h[i - 1]
-            self._wgrad_async(cv.geom_fwd(B), hin, f.dpro[i - 1], D, gbase + 4 * cv.master_off, tag="wgrad:dec%d" % i,
-                              groups=G)
-            g = torch.empty_like(hin)
-            self._igemm(cv.geom_dgrad(B), D, pk + es * cv.dgrad_off, g, ex=ex_of(b, hin), tag="dgrad:dec%d" % i, groups=G)
-            D = bn_apply(hin, [(g, b)], None, hin.numel() // hin.shape[-1] // G)
-        cv = p.dec_convs[0]
-        lat4 = f.latent.view(Bt, 1, 1, p.Lpad)
-        self._wgrad_async(cv.geom_fwd(B), lat4, None, D, gbase + 4 * cv.master_off, tag="wgrad:dec0", groups=G)
-        dlat = torch.empty(Bt, 1, 1, p.Lpad, dtype=T, device=dev)
-        self._igemm(cv.geom_dgrad(B), D, pk + es * cv.dgrad_off, dlat, tag="dgrad:dec0", groups=G)
-        if self.bucket_hook is not None:          # grad[dec_off:] is complete once the launches issued so far have run
-            hook, self.bucket_hook = self.bucket_hook, None
-            hook()
-        # ---- sampler + heads + pool -----------------------------------------------------------
+        # ---- decoder: only the first Gd groups carry a reconstruction gradient (forward(..., rec_groups)); none at all when
+        #      the caller's loss does not use the reconstruction (d_rec is None: the mixed forwards of the sequential step) --
+        Gd = f.Gd if d_rec is not None else 0
+        Bd = B * Gd
         dmu = d_mu.contiguous().float().clone() if d_mu is not None else torch.zeros_like(f.mu)
         dls = d_ls.contiguous().float().clone() if d_ls is not None else torch.zeros_like(f.ls)
         dla = d_la.contiguous().float().clone() if d_la is not None else torch.zeros_like(f.la)
-        dl2 = dlat.view(Bt, p.Lpad)
-        for gi, (mode, _, _, _) in enumerate(f.groups):
-            r0 = gi * B
-            L.call("sv_sample_bwd", self.code, _vp(dl2[r0:].data_ptr()), _vp(f.ls[r0:].data_ptr()),
-                   _vp(f.eps[r0:].data_ptr()), _vp(f.csoft[r0:].data_ptr()), mode, float(f.temperature), B, p.ldc, p.K,
-                   p.Lpad, _vp(dmu[r0:].data_ptr()), _vp(dls[r0:].data_ptr()), _vp(dla[r0:].data_ptr()), st)
+        if Gd > 0:
+            last = p.dec_convs[5]
+            D = torch.empty(Bd, p.img, p.img, last.N, dtype=T, device=dev)
+            L.call("sv_nchw_to_nhwc", self.code, _vp(d_rec.data_ptr()), Bd, p.in_ch, p.img, p.img, last.N,
+                   _vp(D.data_ptr()), st)
+            for i in range(5, 0, -1):
+                cv, b = p.dec_convs[i], p.dec_bns[i - 1]
+                hin = f.h[i - 1][:Bd]                     # the groups are back to back: the first Gd are a prefix
+                self._wgrad_async(cv.geom_fwd(B), hin, f.dpro[i - 1], D, gbase + 4 * cv.master_off, tag="wgrad:dec%d" % i,
+                                  groups=Gd)
+                g = torch.empty_like(hin)
+                self._igemm(cv.geom_dgrad(B), D, pk + es * cv.dgrad_off, g, ex=ex_of(b, hin, Gd), tag="dgrad:dec%d" % i,
+                            groups=Gd)
+                D = bn_apply(hin, [(g, b)], None, hin.numel() // hin.shape[-1] // Gd, Gd)
+            cv = p.dec_convs[0]
+            lat4 = f.latent.view(Bt, 1, 1, p.Lpad)[:Bd]
+            self._wgrad_async(cv.geom_fwd(B), lat4, None, D, gbase + 4 * cv.master_off, tag="wgrad:dec0", groups=Gd)
+            dlat = torch.empty(Bd, 1, 1, p.Lpad, dtype=T, device=dev)
+            self._igemm(cv.geom_dgrad(B), D, pk + es * cv.dgrad_off, dlat, tag="dgrad:dec0", groups=Gd)
+            # ---- sampler (the latent's gradient reaches mu / log_sigma / log_alpha) -------------------------------
+            dl2 = dlat.view(Bd, p.Lpad)
+            for gi, (mode, _, _, _) in enumerate(f.groups[:Gd]):
+                r0 = gi * B
+                L.call("sv_sample_bwd", self.code, _vp(dl2[r0:].data_ptr()), _vp(f.ls[r0:].data_ptr()),
+                       _vp(f.eps[r0:].data_ptr()), _vp(f.csoft[r0:].data_ptr()), mode, float(f.temperature), B, p.ldc, p.K,
+                       p.Lpad, _vp(dmu[r0:].data_ptr()), _vp(dls[r0:].data_ptr()), _vp(dla[r0:].data_ptr()), st)
+        if self.bucket_hook is not None:          # grad[dec_off:] is complete once the launches issued so far have run
+            hook, self.bucket_hook = self.bucket_hook, None
+            hook()
+        # ---- heads + pool ---------------------------------------------------------------------------------------
         dfeat = torch.empty(Bt, p.cfeat, dtype=torch.float32, device=dev)
         ws = torch.empty(Bt, p.NH, dtype=torch.float32, device=dev)
         L.call("sv_head_bwd", _vp(f.feat.data_ptr()), Bt, p.cfeat, _vp(pbase + 4 * p.head_w_off), p.ldc, p.K,

@@ -41,9 +41,13 @@ def optimal_match_index(z_mean, z_log_sigma):
     return idx
 
 
-def device_permutation(n, device):
-    """random permutation drawn on the device (capturable into a hipGraph, unlike a CPU randperm + copy)"""
-    return torch.rand(n, device=device).argsort()
+def device_permutation(n, device, count=1):
+    """`count` random permutations of n drawn on the device (capturable into a hipGraph, unlike a CPU randperm + copy):
+    uniform keys + one rank-counting launch (sv_rank_permutation).  Returns int64 [n] (count == 1) or [count, n]."""
+    keys = torch.rand(count * n, device=device)
+    perm = torch.empty(count, n, dtype=torch.int64, device=device)
+    L.call("sv_rank_permutation", _p(keys), n, count, _p(perm), _st())
+    return perm[0] if count == 1 else perm
 
 
 def mixup_vae_data(image, z_mean, z_log_sigma, disc_log_alpha, optimal_match=False, lam=None, index=None):

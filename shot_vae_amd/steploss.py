@@ -1,0 +1,117 @@
+"""The loss stage of the SHOT-VAE step (main_shot_vae.py:289-323,340-363) as ONE autograd node over the C ABI.
+
+The reference composes its two objectives from ~40 small tensor operations (criteria, abs, scalar products, the mixed
+targets, two one-hot scatters) and autograd walks them again backwards: on the MI355X path that was ~65 micro-kernels per
+step with the GPU idle between them (tools/step_timeline.py: 1.4 ms of gaps).  Here the stage is 9 launches forward (the
+two ELBO reductions, one launch for every target of the mixed forwards, two ClsCriterion and two posterior reductions, the
+scalar composition) and 7 backward (upstream scaling + the seven gradient kernels, each writing its slice of the network's
+output gradients directly) -- the same kernels VAECriterion / ClsCriterion / continuous_posterior_loss use, the same
+formulas; only the two label terms of :316-318 are merged into one soft label (ClsCriterion is linear in it)."""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+
+TERMS = ["recon_l", "klc_l", "kld_l", "recon_u", "klc_u", "kld_u", "disc_post_l", "cont_post_l", "disc_post_u", "cont_post_u",
+         "loss_sup", "loss_unsup"]
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _st():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _lam(v):
+    """(host float, device pointer or None) of a mixing coefficient given as a float or as a device scalar"""
+    if torch.is_tensor(v):
+        return 0.0, _p(v)
+    return float(v), None
+
+
+class _ShotLossFn(torch.autograd.Function):
+    """rec [2B] = reconstructions of forwards (1), (3); mu / ls / la [4B] in the group order (1) (3) (2) (4)."""
+
+    @staticmethod
+    def forward(ctx, rec, mu, ls, la, image_l, image_u, label_l, perm_l, perm_u, lam_l, lam_u, sch, bce, x_sigma):
+        for t in (rec, mu, ls, la, image_l, image_u):
+            if not t.is_cuda:
+                raise L.ShotVaeHipError("shot_vae_amd losses run on an MI355X only (no CPU fallback)")
+        B = image_l.shape[0]
+        D, K = mu.shape[1], la.shape[1]
+        dev = mu.device
+        rec, mu, ls, la = rec.contiguous(), mu.contiguous(), ls.contiguous(), la.contiguous()
+        image_l, image_u = image_l.contiguous().float(), image_u.contiguous().float()
+        npi = image_l[0].numel()
+        f32 = dict(dtype=torch.float32, device=dev)
+        terms = torch.zeros(12, **f32)
+        coef = torch.empty(10, **f32)
+        tgt = torch.empty(4 * B * D + 2 * B * K, **f32)           # sm_mu | sm_sigma | mx_mu | mx_sigma | lab_mix | mx_alpha
+        sm_mu, sm_sigma, mx_mu, mx_sigma = (tgt[i * B * D:(i + 1) * B * D].view(B, D) for i in range(4))
+        lab_mix = tgt[4 * B * D: 4 * B * D + B * K].view(B, K)
+        mx_alpha = tgt[4 * B * D + B * K:].view(B, K)
+        g = lambda t, i: t[i * B:(i + 1) * B]                      # group i of a [4B] / [2B] tensor (contiguous rows)
+        st = _st()
+        tp = terms.data_ptr()
+        fp = lambda i: C.c_void_p(tp + 4 * i)
+        # (1), (3): the ELBO terms                                                                   :289-295, :340-346
+        L.call("sv_elbo_fwd", _p(image_l), _p(g(rec, 0)), npi, _p(g(mu, 0)), _p(g(ls, 0)), _p(g(la, 0)), B, D, K, int(bce),
+               float(x_sigma), fp(0), st)
+        L.call("sv_elbo_fwd", _p(image_u), _p(g(rec, 1)), npi, _p(g(mu, 1)), _p(g(ls, 1)), _p(g(la, 1)), B, D, K, int(bce),
+               float(x_sigma), fp(3), st)
+        # the targets of (2) and (4), detached                                                      :297-310, :348-355
+        ll, ld = _lam(lam_l)
+        lu, lud = _lam(lam_u)
+        L.call("sv_shot_targets", _p(g(mu, 0)), _p(g(ls, 0)), _p(g(mu, 1)), _p(g(ls, 1)), _p(g(la, 1)), _p(label_l), _p(perm_l),
+               _p(perm_u), ll, ld, lu, lud, B, D, K, _p(sm_mu), _p(sm_sigma), _p(lab_mix), _p(mx_mu), _p(mx_sigma), _p(mx_alpha),
+               st)
+        # (2): posterior terms of the smoothed labelled forward                                      :316-321
+        L.call("sv_cls_fwd", _p(g(la, 2)), _p(lab_mix), None, B, K, fp(6), st)
+        L.call("sv_post_fwd", _p(g(mu, 2)), _p(g(ls, 2)), _p(sm_mu), _p(sm_sigma), B, D, fp(7), st)
+        # (4): posterior terms of the mixed unlabelled forward                                       :358-361
+        L.call("sv_cls_fwd", _p(g(la, 3)), _p(mx_alpha), None, B, K, fp(8), st)
+        L.call("sv_post_fwd", _p(g(mu, 3)), _p(g(ls, 3)), _p(mx_mu), _p(mx_sigma), B, D, fp(9), st)
+        s = L.SvShotSchedule(*[float(sch[k]) for k in ("ew", "kl_beta_c", "kl_beta_d", "cmi", "dmi", "pwm", "ucw")])
+        L.call("sv_shot_compose", _p(terms), C.byref(s), _p(coef), st)
+        ctx.save_for_backward(rec, mu, ls, la, image_l, image_u, tgt, coef)
+        ctx.cfg = (B, D, K, npi, bce, x_sigma)
+        ctx.mark_non_differentiable(terms)
+        return terms[10], terms[11], terms
+
+    @staticmethod
+    def backward(ctx, g_sup, g_unsup, _g_terms):
+        rec, mu, ls, la, image_l, image_u, tgt, coef = ctx.saved_tensors
+        B, D, K, npi, bce, x_sigma = ctx.cfg
+        dev = mu.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        sm_mu, sm_sigma, mx_mu, mx_sigma = (tgt[i * B * D:(i + 1) * B * D] for i in range(4))
+        lab_mix = tgt[4 * B * D: 4 * B * D + B * K]
+        mx_alpha = tgt[4 * B * D + B * K:]
+        g = lambda t, i: t[i * B:(i + 1) * B]
+        st = _st()
+        gvec = torch.empty(10, **f32)
+        gs = g_sup.contiguous().float().view(1) if g_sup is not None else None
+        gu = g_unsup.contiguous().float().view(1) if g_unsup is not None else None
+        L.call("sv_shot_scale", _p(coef), _p(gs), _p(gu), _p(gvec), st)
+        gp = gvec.data_ptr()
+        fp = lambda i: C.c_void_p(gp + 4 * i)
+        # every slice of the four gradients is written by exactly one kernel (=, not +=)
+        d_rec, d_mu, d_ls, d_la = torch.empty_like(rec), torch.empty_like(mu), torch.empty_like(ls), torch.empty_like(la)
+        for i, img in ((0, image_l), (1, image_u)):
+            L.call("sv_elbo_bwd", _p(img), _p(g(rec, i)), npi, _p(g(mu, i)), _p(g(ls, i)), _p(g(la, i)), B, D, K, int(bce),
+                   float(x_sigma), fp(3 * i), _p(g(d_rec, i)), _p(g(d_mu, i)), _p(g(d_ls, i)), _p(g(d_la, i)), st)
+        L.call("sv_cls_bwd", _p(lab_mix), None, B, K, fp(6), _p(g(d_la, 2)), st)
+        L.call("sv_post_bwd", _p(g(mu, 2)), _p(g(ls, 2)), _p(sm_mu), _p(sm_sigma), B, D, fp(7), _p(g(d_mu, 2)), _p(g(d_ls, 2)), st)
+        L.call("sv_cls_bwd", _p(mx_alpha), None, B, K, fp(8), _p(g(d_la, 3)), st)
+        L.call("sv_post_bwd", _p(g(mu, 3)), _p(g(ls, 3)), _p(mx_mu), _p(mx_sigma), B, D, fp(9), _p(g(d_mu, 3)), _p(g(d_ls, 3)), st)
+        return (d_rec, d_mu, d_ls, d_la) + (None,) * 10
+
+
+def shot_losses(rec, mu, ls, la, image_l, image_u, label_l, perm_l, perm_u, lam_l, lam_u, sch, bce=True, x_sigma=1.0):
+    """(loss_supervised, loss_unsupervised, terms[12]) of one step from the batched outputs of the four forwards in the
+    group order (1) (3) (2) (4) (rec: groups (1), (3) only); terms in the order of steploss.TERMS, detached."""
+    return _ShotLossFn.apply(rec, mu, ls, la, image_l, image_u, label_l.long().contiguous(), perm_l, perm_u, lam_l, lam_u,
+                             sch, bce, x_sigma)

@@ -8,6 +8,7 @@ import torch
 from . import dp
 from .criterion import continuous_posterior_loss
 from .mixup import _lerp, device_permutation, label_smoothing, mixup_vae_data
+from .steploss import TERMS, shot_losses
 
 
 def alpha_schedule(epoch, max_epoch, alpha_max):
@@ -197,8 +198,11 @@ def train_step_grouped(model, elbo_criterion, cls_criterion, optimizer, image_l,
     if image_u.size(0) != B:
         raise ValueError("train_step_grouped needs B_l == B_u (got %d, %d): use train_step" % (B, image_u.size(0)))
     dev = image_l.device
-    onehot_l = one_hot(label_l, K)
     # ---- every random draw of the step, in the reference's order ---------------------------------
+    # group order of the batched launches: (1) (3) (2) (4) -- the two forwards whose RECONSTRUCTION enters the loss first.
+    # The reconstructions of the mixed forwards are dead values in the reference (main_shot_vae.py:311,356: `*_`): their last
+    # ConvTranspose and their whole decoder backward are skipped (forward_groups(rec_groups=2)); BatchNorm running
+    # statistics still receive the four updates in the reference's order (update_order).
     if device_rng is None and model.rng == "host":
         eps1 = torch.randn(B, ldc)
         lam_l = np.random.beta(epsilon, epsilon) if epsilon > 0 else 1
@@ -207,19 +211,17 @@ def train_step_grouped(model, elbo_criterion, cls_criterion, optimizer, image_l,
         lam_u = np.random.beta(2.0, 2.0)
         perm_u = torch.randperm(B).to(dev)
         eps4, u4 = torch.randn(B, ldc), torch.rand(B, K)
-        eps = torch.cat([eps1, eps2, eps3, eps4]).to(dev)
+        eps = torch.cat([eps1, eps3, eps2, eps4]).to(dev)
         uz = torch.zeros(B, K)
-        u = torch.cat([uz, uz, u3, u4]).to(dev)
-        lam_l0 = lam_l
+        u = torch.cat([uz, u3, uz, u4]).to(dev)
     else:
         eps = torch.randn(4 * B, ldc, device=dev)
         u = torch.rand(4 * B, K, device=dev)
-        perm_l, perm_u = device_permutation(B, dev), device_permutation(B, dev)
+        perm_l, perm_u = device_permutation(B, dev, 2)      # both pairings: one key draw, one launch
         if device_rng is not None:
             lam_l, lam_u = device_rng.next_lams()          # device scalars: capturable
-            lam_l0 = lam_l.reshape(())
         else:
-            lam_l = lam_l0 = np.random.beta(epsilon, epsilon) if epsilon > 0 else 1
+            lam_l = np.random.beta(epsilon, epsilon) if epsilon > 0 else 1
             lam_u = np.random.beta(2.0, 2.0)
     perm_l, perm_u = perm_l.long().contiguous(), perm_u.long().contiguous()
     model._last_lams = (lam_l, lam_u)          # (data-parallel runs check that every rank used the same pair)
@@ -227,35 +229,19 @@ def train_step_grouped(model, elbo_criterion, cls_criterion, optimizer, image_l,
         sm_img = _lerp(image_l, perm_l, lam_l, False)                        # mixup.py:36
         mx_img = _lerp(image_u, perm_u, lam_u, False)                        # mixup.py:22
         sm_label = label_l[perm_l]
-        sm_onehot = one_hot(sm_label, K)
     rec, mu, ls, la = model.forward_groups(
-        [image_l, sm_img, image_u, mx_img],
-        [dict(disc_label=label_l), dict(mixup=True, disc_label=label_l, disc_pseudo_label=sm_label, mixup_lam=lam_l),
-         dict(), dict()], eps=eps, u=u)
-    rec1, rec2, rec3, rec4 = rec.split(B)
-    mu1, mu2, mu3, mu4 = mu.split(B)
-    ls1, ls2, ls3, ls4 = ls.split(B)
-    la1, la2, la3, la4 = la.split(B)
-    # (1)                                                                      :289-295
-    recon_l, klc_l, kld_l = elbo_criterion(image_l, rec1, mu1, ls1, la1)
-    elbo_l = recon_l + sch["kl_beta_c"] * torch.abs(klc_l - sch["cmi"]) + sch["kl_beta_d"] * torch.abs(kld_l - sch["dmi"])
-    with torch.no_grad():                                                    # :297-310 (the targets of (2))
-        sm_mu, sm_sigma = _lerp(mu1, perm_l, lam_l, False), _lerp(ls1, perm_l, lam_l, True)
-    # (2)                                                                      :316-323
-    disc_post_l = lam_l0 * cls_criterion(la2, onehot_l) + (1 - lam_l0) * cls_criterion(la2, sm_onehot)
-    cont_post_l = continuous_posterior_loss(mu2, ls2, sm_mu, sm_sigma)
-    loss_sup = sch["ew"] * (elbo_l + sch["kl_beta_c"] * sch["pwm"] * cont_post_l) + disc_post_l
-    # (3)                                                                      :330-346
-    kl_inference = inference_kl(la3, label_u) if label_u is not None else None
-    recon_u, klc_u, kld_u = elbo_criterion(image_u, rec3, mu3, ls3, la3)
-    elbo_u = recon_u + sch["kl_beta_c"] * torch.abs(klc_u - sch["cmi"]) + sch["kl_beta_d"] * torch.abs(kld_u - sch["dmi"])
-    with torch.no_grad():                                                    # :348-355 (the targets of (4))
-        mx_mu, mx_sigma = _lerp(mu3, perm_u, lam_u, False), _lerp(ls3, perm_u, lam_u, True)
-        mx_alpha = _lerp(la3, perm_u, lam_u, True)
-    # (4)                                                                      :358-363
-    disc_post_u = cls_criterion(la4, mx_alpha)
-    cont_post_u = continuous_posterior_loss(mu4, ls4, mx_mu, mx_sigma)
-    loss_unsup = sch["ew"] * (elbo_u + sch["kl_beta_c"] * sch["pwm"] * cont_post_u) + sch["ucw"] * disc_post_u
+        [image_l, image_u, sm_img, mx_img],
+        [dict(disc_label=label_l), dict(),
+         dict(mixup=True, disc_label=label_l, disc_pseudo_label=sm_label, mixup_lam=lam_l), dict()],
+        eps=eps, u=u, rec_groups=2, update_order=[0, 2, 1, 3])
+    rec1, rec3 = rec.split(B)
+    mu1, mu3, mu2, mu4 = mu.split(B)
+    ls1, ls3, ls2, ls4 = ls.split(B)
+    la1, la3, la2, la4 = la.split(B)
+    # the loss stage as ONE autograd node (steploss.py): 9 launches forward, 7 backward, no tensor algebra in between
+    kl_inference = inference_kl(la3, label_u) if label_u is not None else None            # :330-339 (monitor)
+    loss_sup, loss_unsup, terms = shot_losses(rec, mu, ls, la, image_l, image_u, label_l, perm_l, perm_u, lam_l, lam_u, sch,
+                                              bce=elbo_criterion.bce_reconstruction, x_sigma=elbo_criterion.x_sigma)
     if optimizer is not None and _bucketed(model, distributed) is not None:
         _bucketed(model, distributed).arm()                                  # the step's only backward: decoder bucket overlaps it
     (loss_sup + loss_unsup).backward()                                       # :324 + :364
@@ -266,11 +252,10 @@ def train_step_grouped(model, elbo_criterion, cls_criterion, optimizer, image_l,
             return loss_sup.detach(), loss_unsup.detach(), kl_inference
         return loss_sup.detach(), loss_unsup.detach()
     loc = dict(locals())
-    keys = ["recon_l", "klc_l", "kld_l", "recon_u", "klc_u", "kld_u", "disc_post_l", "cont_post_l", "disc_post_u",
-            "cont_post_u", "loss_sup", "loss_unsup", "sm_img", "mx_img"] + \
-           ["%s%d" % (n, i) for i in (1, 2, 3, 4) for n in ("rec", "mu", "ls", "la")] + \
-           (["kl_inference"] if label_u is not None else [])
-    return {k: loc[k].detach() for k in keys}
+    loc.update({k: terms[i] for i, k in enumerate(TERMS)})
+    keys = TERMS + ["sm_img", "mx_img"] + ["%s%d" % (n, i) for i in (1, 2, 3, 4) for n in ("mu", "ls", "la")] + \
+        ["rec1", "rec3"] + (["kl_inference"] if label_u is not None else [])
+    return {k: loc[k].detach() for k in keys}        # (rec2 / rec4 are not computed: dead values of the reference step)
 
 
 def train_step(model, elbo_criterion, cls_criterion, optimizer, image_l, label_l, image_u, sch, epsilon=0.1,

@@ -42,10 +42,15 @@ class _VAEFunction(torch.autograd.Function):
     hand-written HIP backward."""
 
     @staticmethod
-    def forward(ctx, anchor, model, image, groups, eps, u):
+    def forward(ctx, anchor, model, image, groups, eps, u, rec_groups=None, update_order=None):
         eng = model._engine
-        rec, mu, ls, la, f = eng.forward(image, groups, eps, u, model._temperature, model.training, keep=True)
+        rec, mu, ls, la, f = eng.forward(image, groups, eps, u, model._temperature, model.training, keep=True,
+                                         rec_groups=rec_groups, update_order=update_order)
         ctx.model, ctx.f = model, f
+        # an output that enters no loss term arrives as None in backward (not as a zero tensor): the reconstruction of
+        # the mixed forwards (main_shot_vae.py:311,356) -- their decoder backward is then skipped, as autograd does in the
+        # reference
+        ctx.set_materialize_grads(False)
         return rec, mu, ls, la
 
     @staticmethod
@@ -61,10 +66,8 @@ class _VAEFunction(torch.autograd.Function):
         ctx.f = None
         model._attach_grads()
         eng = model._engine
-        if d_rec is None:
-            d_rec = torch.zeros(f.B * f.G, eng.plan.in_ch, eng.plan.img, eng.plan.img, device=f.mu.device)
-        eng.backward(f, d_rec.contiguous().float(), d_mu, d_ls, d_la)
-        return (None,) * 6
+        eng.backward(f, d_rec.contiguous().float() if d_rec is not None else None, d_mu, d_ls, d_la)
+        return (None,) * 8
 
 
 class VariationalAutoEncoder(nn.Module):
@@ -225,13 +228,16 @@ class VariationalAutoEncoder(nn.Module):
         eps, u = self._draw_noise(input_img.size(0), input_img.device, spec[0] == 0)
         return self._run(input_img, [spec], eps, u)
 
-    def forward_groups(self, images, specs, eps=None, u=None):
+    def forward_groups(self, images, specs, eps=None, u=None, rec_groups=None, update_order=None):
         """Several forward calls as ONE batched launch sequence (extension; see Engine.forward): images = list of equally
         sized batches, specs = list of dicts with the keyword arguments of forward() (mixup, disc_label,
         disc_pseudo_label, mixup_lam).  Equivalent to calling forward() on each batch -- every group keeps its own
         BatchNorm batch statistics and the running statistics receive the groups' momentum updates in list order -- at a
         fraction of the launches.  eps / u: the noise to use ([G * B, ldc] / [G * B, K]); drawn here if None, group by
-        group in the reference's order.  Returns the 4-tuple of forward() with the groups concatenated along dim 0."""
+        group in the reference's order.  rec_groups = Gd: only the first Gd batches' reconstructions are produced and
+        differentiated (the others' last ConvTranspose and decoder backward are skipped; reconstruction is [Gd * B, ...]);
+        update_order[k] = the list position of the reference's k-th forward (order of the BatchNorm running-statistic
+        updates; default list order).  Returns the 4-tuple of forward() with the groups concatenated along dim 0."""
         G = len(images)
         B = images[0].size(0)
         if any(im.size(0) != B for im in images):
@@ -245,14 +251,15 @@ class VariationalAutoEncoder(nn.Module):
             if any(uu is not None for _, uu in pairs):
                 z = torch.zeros(B, self._plan.K, device=dev)
                 u = torch.cat([uu if uu is not None else z for _, uu in pairs])
-        return self._run(torch.cat([im.float() for im in images]), gs, eps, u)
+        return self._run(torch.cat([im.float() for im in images]), gs, eps, u, rec_groups, update_order)
 
-    def _run(self, image, groups, eps, u):
+    def _run(self, image, groups, eps, u, rec_groups=None, update_order=None):
         eng = self._engine
         dev = image.device
         if torch.is_grad_enabled():
             if self._anchor is None or self._anchor.device != dev:
                 self._anchor = torch.zeros(1, device=dev, requires_grad=True)
-            return _VAEFunction.apply(self._anchor, self, image, groups, eps, u)
-        rec, mu, ls, la, _ = eng.forward(image, groups, eps, u, self._temperature, self.training, keep=False)
+            return _VAEFunction.apply(self._anchor, self, image, groups, eps, u, rec_groups, update_order)
+        rec, mu, ls, la, _ = eng.forward(image, groups, eps, u, self._temperature, self.training, keep=False,
+                                         rec_groups=rec_groups, update_order=update_order)
         return rec, mu, ls, la

@@ -989,3 +989,19 @@ def test_deterministic_mode_reproduces_bit_for_bit(dt, case):
     assert rel(first[5], ref[5]) < 2e-4 and torch.equal(first[0], ref[0]) and torch.equal(first[3], ref[3])
     with pytest.raises(L.ShotVaeHipError, match="replicas"):
         run(True, replicas=2)
+
+
+def test_rank_permutation():
+    """sv_rank_permutation: perm = argsort of the keys (ties: the lower index first), several batches per launch, sizes up
+    to a full minibatch."""
+    d = dev()
+    torch.manual_seed(2)
+    for n, nb in ((1, 1), (7, 3), (512, 2), (1000, 1), (4096, 2)):
+        keys = torch.rand(nb, n, device=d)
+        if n > 4:
+            keys[:, 3] = keys[:, 1]                     # a tie
+        perm = torch.full((nb, n), -1, dtype=torch.int64, device=d)
+        L.call("sv_rank_permutation", p(keys), n, nb, p(perm), st())
+        torch.cuda.synchronize()
+        ref = torch.argsort(keys, dim=1, stable=True)
+        assert torch.equal(perm, ref), (n, nb)

@@ -676,6 +676,9 @@ def test_grouped_step_matches_reference_goldens_fp32(tag):
             ref = float(g["s%d.%s" % (s, k)])
             assert abs(float(out[k]) - ref) <= FP32_TOL * max(abs(ref), 1e-6), (tag, s, k, float(out[k]), ref)
         for k in T.TENSORS:
+            if k in ("rec2", "rec4"):            # dead values of the step (main_shot_vae.py:311,356): not computed
+                assert k not in out
+                continue
             e = T.rel_err(out[k].float().cpu().numpy(), g["s%d.%s" % (s, k)])
             assert e < FP32_TOL, (tag, s, k, e)
         grads = param_grads(model)
@@ -719,6 +722,8 @@ def test_grouped_step_equals_sequential_step(dtype, B, tol):
     for k in T.SCALARS + ["kl_inference"]:
         assert abs(float(a[k]) - float(b[k])) <= tol * max(abs(float(a[k])), 1e-6), (k, float(a[k]), float(b[k]))
     for k in T.TENSORS:
+        if k in ("rec2", "rec4"):                # (the grouped step does not compute the unused reconstructions)
+            continue
         assert T.rel_err(b[k].float().cpu().numpy(), a[k].float().cpu().numpy()) < tol, k
     ga, gb = m1.flat_parameters()[1].double(), m2.flat_parameters()[1].double()
     if dtype == "fp32":
@@ -731,3 +736,64 @@ def test_grouped_step_equals_sequential_step(dtype, B, tol):
             assert T.rel_err(sb[k].float().cpu().numpy(), sa[k].float().cpu().numpy()) < (1e-4 if dtype == "fp32" else 2e-2), k
         if k.endswith("num_batches_tracked"):
             assert int(sa[k]) == int(sb[k]) == 4, k
+
+
+@pytest.mark.parametrize("bce,x_sigma,dev_lam", [(True, 1.0, False), (False, 0.5, True)])
+def test_fused_loss_node_equals_modular_criteria(bce, x_sigma, dev_lam):
+    """steploss.shot_losses (the loss stage of the grouped step as one autograd node: 9 + 7 launches) against the same stage
+    composed from VAECriterion / ClsCriterion / continuous_posterior_loss / the mixup helpers as train_step does
+    (main_shot_vae.py:289-323,340-363): the twelve scalars and the gradients w.r.t. the network outputs."""
+    from shot_vae_amd.criterion import continuous_posterior_loss
+    from shot_vae_amd.mixup import _lerp
+    from shot_vae_amd.steploss import TERMS, shot_losses
+    from shot_vae_amd.train import one_hot
+    B, D, K = 24, 128, 10
+    torch.manual_seed(9)
+    d = torch.device("cuda:0")
+    il, iu = torch.rand(B, 3, 32, 32, device=d), torch.rand(B, 3, 32, 32, device=d)
+    label = torch.randint(0, K, (B,), device=d)
+    perm_l, perm_u = torch.randperm(B, device=d), torch.randperm(B, device=d)
+    lam_l, lam_u = 0.83, 0.37
+    sch = O.schedule(37, dmi=2.3)
+    base = dict(rec=torch.randn(2 * B, 3, 32, 32, device=d), mu=torch.randn(4 * B, D, device=d) * 0.5,
+                ls=torch.randn(4 * B, D, device=d) * 0.3, la=torch.log_softmax(torch.randn(4 * B, K, device=d), 1))
+
+    def leaves():
+        return {k: v.clone().requires_grad_(True) for k, v in base.items()}
+
+    # fused
+    a = leaves()
+    ll = torch.tensor([lam_l], device=d) if dev_lam else lam_l
+    lu = torch.tensor([lam_u], device=d) if dev_lam else lam_u
+    ls_, lu_, terms = shot_losses(a["rec"], a["mu"], a["ls"], a["la"], il, iu, label, perm_l, perm_u, ll, lu, sch, bce=bce,
+                                  x_sigma=x_sigma)
+    (1.5 * ls_ + 0.5 * lu_).backward()
+    # modular (group order (1) (3) (2) (4))
+    b = leaves()
+    elbo, cls = S.VAECriterion(discrete_dim=K, x_sigma=x_sigma, bce_reconstruction=bce).cuda(), S.ClsCriterion()
+    rec1, rec3 = b["rec"].split(B)
+    mu1, mu3, mu2, mu4 = b["mu"].split(B)
+    ls1, ls3, ls2, ls4 = b["ls"].split(B)
+    la1, la3, la2, la4 = b["la"].split(B)
+    r_l, kc_l, kd_l = elbo(il, rec1, mu1, ls1, la1)
+    r_u, kc_u, kd_u = elbo(iu, rec3, mu3, ls3, la3)
+    with torch.no_grad():
+        sm_mu, sm_sigma = _lerp(mu1, perm_l, lam_l, False), _lerp(ls1, perm_l, lam_l, True)
+        mx_mu, mx_sigma, mx_alpha = _lerp(mu3, perm_u, lam_u, False), _lerp(ls3, perm_u, lam_u, True), _lerp(la3, perm_u, lam_u, True)
+    dp_l = lam_l * cls(la2, one_hot(label, K)) + (1 - lam_l) * cls(la2, one_hot(label[perm_l], K))
+    cp_l = continuous_posterior_loss(mu2, ls2, sm_mu, sm_sigma)
+    dp_u = cls(la4, mx_alpha)
+    cp_u = continuous_posterior_loss(mu4, ls4, mx_mu, mx_sigma)
+    e_l = r_l + sch["kl_beta_c"] * torch.abs(kc_l - sch["cmi"]) + sch["kl_beta_d"] * torch.abs(kd_l - sch["dmi"]) + \
+        sch["kl_beta_c"] * sch["pwm"] * cp_l
+    e_u = r_u + sch["kl_beta_c"] * torch.abs(kc_u - sch["cmi"]) + sch["kl_beta_d"] * torch.abs(kd_u - sch["dmi"]) + \
+        sch["kl_beta_c"] * sch["pwm"] * cp_u
+    sup, unsup = sch["ew"] * e_l + dp_l, sch["ew"] * e_u + sch["ucw"] * dp_u
+    (1.5 * sup + 0.5 * unsup).backward()
+    torch.cuda.synchronize()
+    want = dict(zip(TERMS, (r_l, kc_l, kd_l, r_u, kc_u, kd_u, dp_l, cp_l, dp_u, cp_u, sup, unsup)))
+    for i, k in enumerate(TERMS):
+        assert abs(float(terms[i]) - float(want[k])) <= 2e-6 * max(abs(float(want[k])), 1e-3), (k, float(terms[i]), float(want[k]))
+    assert abs(float(ls_) - float(sup)) <= 2e-6 * abs(float(sup))
+    for k in base:
+        assert T.rel_err(a[k].grad.cpu().numpy(), b[k].grad.cpu().numpy()) < 2e-6, k
