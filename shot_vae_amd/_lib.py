@@ -7,7 +7,9 @@ import os
 import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libshotvae_hip.so")
+# SV_LIB_PATH: a diagnostic / A-B build of the library (tools/ab.sh builds variants into scratch paths and selects them
+# here; the shipped library is never overwritten by a tool)
+LIB_PATH = os.environ.get("SV_LIB_PATH") or os.path.join(HERE, "libshotvae_hip.so")
 CSRC = os.path.join(HERE, "csrc")
 
 SV_F32, SV_BF16 = 0, 1

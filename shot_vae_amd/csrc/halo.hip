@@ -30,6 +30,21 @@
 
 namespace {
 
+// Blocks per CU of the small-stage persistent variants (measured at 4 x 512 images, tools/thin_ab.sh: three blocks of the
+// 2-vector / 16-channel-tile variant: stem 66 -> 55 us, 1x1 16 -> 32 data gradient 54 -> 46 us; four blocks or any of the
+// 32-channel-tile variants spill -- 16 -> 32 forward 115 -> 176 / 290 us -- and stay at two)
+#ifndef SV_HALOP_OCC2
+#define SV_HALOP_OCC2 3         // 2-vector stage, 16-channel tiles (NT = 1)
+#endif
+#ifndef SV_HALOP_OCC2B
+#define SV_HALOP_OCC2B 2        // ... 32-channel tiles (NT = 2)
+#endif
+#ifndef SV_HALOP_OCC4
+#define SV_HALOP_OCC4 2         // 4-vector stage, NT = 1
+#endif
+#ifndef SV_HALOP_OCC4B
+#define SV_HALOP_OCC4B 2        // ... NT = 2
+#endif
 constexpr int HMAXV = 12;       // halo 16-byte vectors per thread (3072 per block)
 constexpr int HMAXW = 8;        // weight vectors per thread
 
@@ -331,10 +346,15 @@ __global__ __launch_bounds__(256) void halo_kernel(const sv_geom g, const sv_ige
 // requested (two register stages), the BatchNorm sums stay in registers across tiles and are flushed once per block.
 // These layers are HBM-bound (2-4.5 flop/B x C): what matters is that every input byte is fetched once and that the
 // requests never stop.
-constexpr int PMAXV = 6;        // halo vectors per thread per register stage
+constexpr int PMAXV = 6;        // halo vectors per thread per register stage (upper bound; the kernel is compiled for PV <= PMAXV)
 
-template <typename T, int NT, int CC, int NPH>
-__global__ __launch_bounds__(256, 2) void halop_kernel(const sv_geom g, const sv_igemm_args_g AG, const halo_cfg c, int tiles_per) {
+// PV = halo vectors per thread per register stage (2 for the 16-channel layers, 4, or 6).  The small variants fit more blocks
+// per CU (OCC = blocks per CU the register budget is held to): the compiler waits for register prefetches with
+// s_waitcnt vmcnt(0), so a block never has more than ~one tile of loads in flight -- bytes in flight per CU, i.e. the
+// achievable bandwidth of these HBM-bound layers, scale with the number of resident blocks.
+template <typename T, int NT, int CC, int NPH, int PV, int OCC>
+__global__ __launch_bounds__(256, OCC) void halop_kernel(const sv_geom g, const sv_igemm_args_g AG, const halo_cfg c, int tiles_per) {
+    constexpr int PMAXV = PV;
     typedef typename V8<T>::type V;
     typedef typename V4<T>::type Q;
     constexpr int BN = 16 * NT;
@@ -591,12 +611,12 @@ __global__ __launch_bounds__(256, 2) void halop_kernel(const sv_geom g, const sv
     if (want_sums) flush_channel_sums<NT>(s1, s2, nval, ssum, EX ? a.bsums : a.stats, n0, g.N, a.replicas, a.flags);
 }
 
-template <typename T, int NT, int CC, int NPH>
-int launch_halop(const sv_geom* g, const sv_igemm_args* a, const halo_cfg& c, size_t lds, hipStream_t s) {
+template <typename T, int NT, int CC, int NPH, int PV, int OCC>
+int launch_halop_pv(const sv_geom* g, const sv_igemm_args* a, const halo_cfg& c, size_t lds, hipStream_t s) {
     constexpr int BN = 16 * NT;
     const int nT = (g->B * g->Hq + c.TR - 1) / c.TR;
     const int nNt = (g->N + BN - 1) / BN;
-    const int budget = sv_persistent_blocks();
+    const int budget = sv_persistent_blocks() * OCC / 2;
     const int target = budget / sv_ngroups(a->groups) > 64 ? budget / sv_ngroups(a->groups) : 64;
     int chunks = (target + nNt - 1) / nNt;
     if (chunks > nT) chunks = nT;
@@ -604,17 +624,29 @@ int launch_halop(const sv_geom* g, const sv_igemm_args* a, const halo_cfg& c, si
     chunks = (nT + tiles_per - 1) / tiles_per;
     static bool optin = false;
     if (lds > 64 * 1024 && !optin) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&halop_kernel<T, NT, CC, NPH>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&halop_kernel<T, NT, CC, NPH, PV, OCC>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return sv_check_launch("hipFuncSetAttribute(halop)");
         optin = true;
     }
     SV_LAUNCH_GATE(chunks * nNt, a);
     sv_prof_begin(s);
-    hipLaunchKernelGGL((halop_kernel<T, NT, CC, NPH>), dim3(chunks * nNt, sv_ngroups(a->groups)), dim3(256), lds, s, *g,
+    hipLaunchKernelGGL((halop_kernel<T, NT, CC, NPH, PV, OCC>), dim3(chunks * nNt, sv_ngroups(a->groups)), dim3(256), lds, s, *g,
                        sv_expand_groups(*g, *a, (int)sizeof(T)), c, tiles_per);
     sv_prof_end(s);
     return sv_check_launch("sv_igemm(halop)");
+}
+
+template <typename T, int NT, int CC, int NPH>
+int launch_halop(const sv_geom* g, const sv_igemm_args* a, const halo_cfg& c, size_t lds, hipStream_t s) {
+    // register stage size from the tile's halo; the small stages go with more resident blocks (their LDS image permitting)
+    const int hvn = c.HP * (g->Cin / 8);
+    if constexpr (sizeof(T) == 2 && NPH == 1) {
+        constexpr int O2 = NT == 1 ? SV_HALOP_OCC2 : SV_HALOP_OCC2B, O4 = NT == 1 ? SV_HALOP_OCC4 : SV_HALOP_OCC4B;
+        if (O2 > 2 && hvn <= 256 * 2 && lds * O2 <= 150 * 1024) return launch_halop_pv<T, NT, CC, NPH, 2, O2>(g, a, c, lds, s);
+        if (O4 > 2 && hvn <= 256 * 4 && lds * O4 <= 150 * 1024) return launch_halop_pv<T, NT, CC, NPH, 4, O4>(g, a, c, lds, s);
+    }
+    return launch_halop_pv<T, NT, CC, NPH, 6, 2>(g, a, c, lds, s);
 }
 
 template <typename T, int CC, int NPH>
