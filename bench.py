@@ -235,6 +235,89 @@ def extras(S):
     return res
 
 
+def svhn_workload(a, rank, world):
+    """--workload svhn: one smooth-ELBO iteration of svhn_VAE (BASELINE configs[4]; main_smooth_ELBO_svhn.py:152-176: unlabelled
+    forward + loss, labelled forward + loss, one backward, Adam) on --batch images per loader per GPU.  The iteration is ~130
+    launches of tens of microseconds: launch-bound, so the single-GPU run probes eager issue against a hipGraph replay and keeps
+    the faster (both in the JSON); N > 1 is eager with ONE all-reduce of FlatAdam's flat gradient buffer per iteration."""
+    import shot_vae_amd as S
+    B = a.batch if a.scaling == "weak" else a.batch // world
+    torch.manual_seed(1)
+    model = S.SmoothVAE((3, 32, 32), {"cont": 32, "disc": [10]}, temperature=0.67, compute_dtype=a.dtype).cuda().train()
+    if world > 1:
+        for p_ in model.parameters():
+            dist.broadcast(p_.data, 0)
+    loss_fn = S.SmoothELBOLoss()
+    opt = S.FlatAdam(model.parameters(), lr=1e-3, capturable=True)
+    torch.manual_seed(1 + rank)
+    torch.cuda.manual_seed(1 + rank)
+    g = torch.Generator(device="cuda").manual_seed(1234 + rank)
+    u = torch.rand(B, 3, 32, 32, device="cuda", generator=g) * 2 - 1
+    l = torch.rand(B, 3, 32, 32, device="cuda", generator=g) * 2 - 1
+    y = torch.randint(0, 10, (B,), device="cuda", generator=g)
+
+    def eager():
+        return S.smooth_train_step(model, loss_fn, opt, u, l, y, distributed=world > 1)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def timed(fn, n):
+        sync()
+        t = time.perf_counter()
+        for _ in range(n):
+            out = fn()
+        sync()
+        return (time.perf_counter() - t) / n * 1e3, out
+
+    for _ in range(max(a.warmup, 2)):
+        eager()
+    mode, probe, graphed = "eager", None, None
+    want = a.graph if a.graph is not None else -1
+    if world == 1 and want != 0:
+        try:
+            graphed = S.GraphedSmoothStep(model, loss_fn, opt, u, l, y, warmup=2)
+        except Exception as e:
+            mode = "eager (graph capture failed: %s)" % type(e).__name__
+            torch.cuda.synchronize()
+    if graphed is not None:
+        if want < 0:
+            probe = {"eager_ms": round(timed(eager, 10)[0], 3), "graph_ms": round(timed(graphed, 10)[0], 3)}
+            if probe["graph_ms"] < probe["eager_ms"]:
+                mode = "hipGraph replay (faster than eager issue in the probe)"
+            else:
+                graphed, mode = None, "eager (faster than hipGraph replay in the probe)"
+        else:
+            mode = "hipGraph replay"
+    step = graphed if graphed is not None else eager
+    ms, loss = timed(step, a.steps)
+    dt = torch.tensor([ms], device="cuda", dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    ms = float(dt)
+    assert bool(torch.isfinite(loss).all()), "non-finite loss"
+    # algorithmic work (SURVEY.md 8d): 1.1332e7 MACs per forwarded image, x3 for forward + both gradients, x2 flop per MAC
+    flops = 2 * B * 1.1332e7 * 2 * 3
+    out = {"metric": "images/sec/step svhn_VAE smooth-ELBO bs%d (BASELINE configs[4])" % a.batch, "value": round(2 * B * world / ms * 1e3, 1),
+           "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3),
+           "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+           "config": {"workload": "svhn_VAE smooth-ELBO iteration (2 fwd + 1 bwd + Adam), B_u=B_l=%d per GPU, synthetic 3x32x32 in "
+                                  "[-1,1] in HBM, random init" % B, "global_batch": 2 * B * world, "parallelism": "dp%d" % world,
+                      "launch": mode, "optimizer": "FlatAdam (one sv_adam launch on a flat buffer)",
+                      "collective": "1 RCCL all-reduce of the flat gradient buffer (2.49 M floats) per iteration" if world > 1 else "none"},
+           "loss": round(float(loss), 4), "TFLOPs": round(flops / ms / 1e9, 2),
+           "note": "launch-bound workload (SURVEY.md 8d): 0.07 TFLOP and 0.43 GB per iteration"}
+    if probe is not None:
+        out["config"]["launch_probe"] = probe
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
 def main():
     a = parse()
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
@@ -270,6 +353,8 @@ def main():
         # ranks on the same device, the collective through host memory): a functional check, not a measurement.
         dist.init_process_group(os.environ.get("SV_DIST_BACKEND", "nccl"), rank=rank, world_size=world)
 
+    if a.workload == "svhn":
+        return svhn_workload(a, rank, world)
     import shot_vae_amd as S
     from shot_vae_amd import _lib as L
     from shot_vae_amd import dp

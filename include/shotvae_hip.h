@@ -252,6 +252,47 @@ int sv_shot_scale(const float* coef, const float* g_sup, const float* g_unsup, f
  * second-smallest entry of row i of the pairwise Gaussian-KL matrix.                               */
 int sv_optimal_match(const float* mu, const float* ls, int B, int D, int64_t* index, void* stream);
 
+/* ---- the one-stage smooth-ELBO conv-VAEs (BASELINE configs 1 / 5: smooth_vae_model/svhn_vae.py, mnist_vae.py) -----
+ * sv_smooth_latent_fwd: everything between the fused head GEMM and the decoder (svhn_vae.py:137-208).  o [B][ldo] =
+ *   [mean (Dc) | log-variance (Dc) | logits (Dd) | pad] of `dtype`; alpha = softmax(logits); z = mean + exp(logvar / 2) *
+ *   eps in training mode, else mean; gs = Gumbel-softmax sample softmax((log(alpha + 1e-12) + g) / T), g = -log(-log(u +
+ *   1e-12) + 1e-12) in training mode, else one-hot(argmax alpha); c = one-hot(label) when label != NULL, else gs.
+ *   Outputs: mean, logvar [B][Dc], alpha, gs [B][Dd] (fp32), latent [B][Lpad] = [z | c | 0] of `dtype` (the decoder's
+ *   input), latent32 [B][Dc + Dd] fp32 (the API's latent_sample).
+ * sv_smooth_latent_bwd: d_o [B][ldo] from the latent's gradient dlat [B][Lpad] (`dtype`) and the loss' gradients
+ *   dmean / dlogvar / dalpha (fp32, NULL = none); sample_path = 1 when c was the Gumbel-softmax sample.               */
+int sv_smooth_latent_fwd(int dtype, const void* o, int ldo, const float* eps, const float* u, const int64_t* label,
+                         float temperature, int training, int B, int Dc, int Dd, int Lpad, float* mean, float* logvar,
+                         float* alpha, float* gs, void* latent, float* latent32, void* stream);
+int sv_smooth_latent_bwd(int dtype, const void* dlat, int Lpad, const float* dmean, const float* dlogvar, const float* dalpha,
+                         const float* logvar, const float* eps, const float* alpha, const float* gs, float temperature,
+                         int training, int sample_path, int B, int Dc, int Dd, void* d_o, int ldo, void* stream);
+/* reconstruction = tanh(f[..., :C]) of the decoder's NHWC output f [B][H][W][ld] as NCHW fp32 (svhn_vae.py:118-120), and
+ * the backward d_f = d_out * (1 - out^2) in NHWC (channels >= C zero)                                                  */
+int sv_tanh_to_nchw(int dtype, const void* f, int B, int C, int H, int W, int ld, float* out, void* stream);
+int sv_tanh_to_nchw_bwd(int dtype, const float* d_out, const float* out, int B, int C, int H, int W, int ld, void* d_f, void* stream);
+/* Trainer._loss_function (main_smooth_ELBO_svhn.py:228-310,312-335,368-388) in two launches: the raw reductions and the
+ * composition.  terms [9] (zeroed by the caller): [0] num_pixels * MSE, [1] KL_c, [2] sum alpha log(alpha + 1e-12) / B
+ * (KL_d = log D + [2]), [3] BCE(alpha, one-hot(label)) (label may be NULL), [4] the loss, [5..8] its four parts
+ * (reconstruction, gamma_c |C_c - KL_c|, gamma_d |C_d - KL_d|, alpha_cls * BCE); coef [4] = d loss / d terms[0..3].
+ * Capacities C = min((max - min) * steps / iters + min, max) (C_d also <= log D); steps_dev (optional device scalar)
+ * replaces sch->steps (hipGraph replay).                                                                               */
+typedef struct {
+    float cont_min, cont_max, cont_iters, cont_gamma, disc_min, disc_max, disc_iters, disc_gamma, alpha_cls, steps;
+} sv_smooth_schedule;
+int sv_smooth_elbo_fwd(const float* data, const float* rec, int64_t n_per_img, const float* mean, const float* logvar,
+                       const float* alpha, const int64_t* label, int B, int Dc, int Dd, const sv_smooth_schedule* sch,
+                       const float* steps_dev, float* terms, float* coef, void* stream);
+/* gradients of the loss (times the upstream gradient gout[0]) w.r.t. rec, mean, logvar, alpha (=, not +=)            */
+int sv_smooth_elbo_bwd(const float* data, const float* rec, int64_t n_per_img, const float* mean, const float* logvar,
+                       const float* alpha, const int64_t* label, int B, int Dc, int Dd, const float* coef, const float* gout,
+                       float* d_rec, float* d_mean, float* d_logvar, float* d_alpha, void* stream);
+/* torch.optim.Adam (no weight decay / amsgrad; main_smooth_ELBO_svhn.py:428) on a flat buffer: m, v = first / second
+ * moments; step = 1-based update count (host) or step_dev (device scalar, hipGraph replay); g is scaled by grad_scale
+ * first (1 / world after the gradient all-reduce).                                                                    */
+int sv_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, float step,
+            const float* step_dev, float grad_scale, void* stream);
+
 /* ---- K20 SGD(momentum, weight decay) on the flat parameter buffer (torch.optim.SGD semantics) ---- */
 int sv_sgd(float* p, const float* g, float* v, int64_t n, float lr, float momentum, float weight_decay,
            float grad_scale, int first_step, void* stream);

@@ -4,7 +4,7 @@ lib/utils/mixup.py, the step of main_shot_vae.py)."""
 from .vae import VariationalAutoEncoder          # noqa: F401
 from .criterion import VAECriterion, ClsCriterion, continuous_posterior_loss   # noqa: F401
 from .mixup import mixup_vae_data, label_smoothing, optimal_match_index        # noqa: F401
-from .optim import FlatSGD                        # noqa: F401
+from .optim import FlatSGD, FlatAdam              # noqa: F401
 from .train import (train_step, train_step_overlapped, train_step_grouped, GraphedTrainStep, DeviceRng, schedule,   # noqa: F401
                     alpha_schedule, m2_train_step, apply_update, inference_kl)
 from .evaluate import Evaluator, evaluate       # noqa: F401

@@ -54,6 +54,11 @@ class SvShotSchedule(C.Structure):
     _fields_ = [(n, C.c_float) for n in ("ew", "kl_beta_c", "kl_beta_d", "cmi", "dmi", "pwm", "ucw")]
 
 
+class SvSmoothSchedule(C.Structure):
+    _fields_ = [(n, C.c_float) for n in ("cont_min", "cont_max", "cont_iters", "cont_gamma", "disc_min", "disc_max",
+                                         "disc_iters", "disc_gamma", "alpha_cls", "steps")]
+
+
 class SvBnBranch(C.Structure):
     _fields_ = [("g", C.c_void_p), ("bsums", C.c_void_p), ("gamma", C.c_void_p), ("dgamma", C.c_void_p),
                 ("dbeta", C.c_void_p), ("replicas", C.c_int32)]
@@ -91,6 +96,13 @@ _PROTOS = {
     "sv_shot_compose": [P, C.POINTER(SvShotSchedule), P, P],
     "sv_shot_scale": [P, P, P, P, P],
     "sv_sgd": [P, P, P, I64, F, F, F, F, I, P],
+    "sv_adam": [P, P, P, P, I64, F, F, F, F, F, P, F, P],
+    "sv_smooth_latent_fwd": [I, P, I, P, P, P, F, I, I, I, I, I, P, P, P, P, P, P, P],
+    "sv_smooth_latent_bwd": [I, P, I, P, P, P, P, P, P, P, F, I, I, I, I, I, P, I, P],
+    "sv_tanh_to_nchw": [I, P, I, I, I, I, I, P, P],
+    "sv_tanh_to_nchw_bwd": [I, P, P, I, I, I, I, I, P, P],
+    "sv_smooth_elbo_fwd": [P, P, I64, P, P, P, P, I, I, I, C.POINTER(SvSmoothSchedule), P, P, P, P],
+    "sv_smooth_elbo_bwd": [P, P, I64, P, P, P, P, I, I, I, P, P, P, P, P, P, P],
     "sv_nchw_to_nhwc": [I, P, I, I, I, I, I, P, P],
     "sv_nhwc_to_nchw": [I, P, I, I, I, I, I, P, P],
     "sv_repack": [I, P, I, I, I, I, C.POINTER(SvGeom), P, P],

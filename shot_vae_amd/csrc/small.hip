@@ -1008,6 +1008,246 @@ __global__ __launch_bounds__(256) void optimal_match_kernel(const float* mu, con
     }
 }
 
+// ---------------------------------------------------------------------------------------- smooth-ELBO conv-VAE (config 5)
+// Heads of svhn_VAE / mnist_VAE (smooth_vae_model/svhn_vae.py:137-208) behind the fused head GEMM: o[b] = [mean | logvar |
+// logits | pad] -> alpha = softmax(logits), z = mean + exp(logvar / 2) * eps (training) or mean, the Gumbel-softmax sample
+// gs = softmax((log(alpha + EPS) + g) / T), g = -log(-log(u + EPS) + EPS) (training) or one-hot(argmax alpha), the
+// discrete code c = one-hot(label) for labelled data, else gs; latent = [z | c | 0] in the compute dtype (the decoder's
+// first GEMM reads it) and in fp32 (API).  One block per sample.
+constexpr float SM_EPS = 1e-12f;
+template <typename T>
+__global__ __launch_bounds__(64) void smooth_latent_fwd_kernel(const T* o, int ldo, const float* eps, const float* u,
+                                                                const int64_t* label, float temperature, int training, int Dc,
+                                                                int Dd, int Lpad, float* mean, float* logvar, float* alpha,
+                                                                float* gs, T* latent, float* latent32) {
+    const int b = blockIdx.x, l = threadIdx.x;
+    const T* ob = o + (int64_t)b * ldo;
+    T* lat = latent + (int64_t)b * Lpad;
+    float* l32 = latent32 + (int64_t)b * (Dc + Dd);
+    for (int j = l; j < Dc; j += 64) {
+        const float m = to_f(ob[j]), lv = to_f(ob[Dc + j]);
+        mean[(int64_t)b * Dc + j] = m;
+        logvar[(int64_t)b * Dc + j] = lv;
+        const float z = training ? m + expf(0.5f * lv) * eps[(int64_t)b * Dc + j] : m;
+        lat[j] = (T)z;
+        l32[j] = z;
+    }
+    // softmax over the Dd logits (Dd <= 64 per pass; strided loops cover more)
+    float mx = -INFINITY;
+    for (int k = l; k < Dd; k += 64) mx = fmaxf(mx, to_f(ob[2 * Dc + k]));
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+    float se = 0.f;
+    for (int k = l; k < Dd; k += 64) se += expf(to_f(ob[2 * Dc + k]) - mx);
+    se = wave_sum(se);
+    // second pass: alpha and the Gumbel-softmax sample
+    float ymx = -INFINITY;
+    int amax = 0x7fffffff;
+    float abest = -INFINITY;
+    for (int k = l; k < Dd; k += 64) {
+        const float a = expf(to_f(ob[2 * Dc + k]) - mx) / se;
+        alpha[(int64_t)b * Dd + k] = a;
+        if (a > abest) { abest = a; amax = k; }
+        if (training) {
+            const float g = -logf(-logf(u[(int64_t)b * Dd + k] + SM_EPS) + SM_EPS);
+            ymx = fmaxf(ymx, (logf(a + SM_EPS) + g) / temperature);
+        }
+    }
+    if (training) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) ymx = fmaxf(ymx, __shfl_xor(ymx, off));
+        float ys = 0.f;
+        for (int k = l; k < Dd; k += 64) {
+            const float a = alpha[(int64_t)b * Dd + k];
+            const float g = -logf(-logf(u[(int64_t)b * Dd + k] + SM_EPS) + SM_EPS);
+            ys += expf((logf(a + SM_EPS) + g) / temperature - ymx);
+        }
+        ys = wave_sum(ys);
+        for (int k = l; k < Dd; k += 64) {
+            const float a = alpha[(int64_t)b * Dd + k];
+            const float g = -logf(-logf(u[(int64_t)b * Dd + k] + SM_EPS) + SM_EPS);
+            gs[(int64_t)b * Dd + k] = expf((logf(a + SM_EPS) + g) / temperature - ymx) / ys;
+        }
+    } else {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {       // argmax (first maximum)
+            const float ov = __shfl_xor(abest, off);
+            const int oi = __shfl_xor(amax, off);
+            if (ov > abest || (ov == abest && oi < amax)) { abest = ov; amax = oi; }
+        }
+        for (int k = l; k < Dd; k += 64) gs[(int64_t)b * Dd + k] = k == amax ? 1.f : 0.f;
+    }
+    const int y = label ? (int)label[b] : -1;
+    for (int k = l; k < Dd; k += 64) {
+        const float c = label ? (k == y ? 1.f : 0.f) : gs[(int64_t)b * Dd + k];
+        lat[Dc + k] = (T)c;
+        l32[Dc + k] = c;
+    }
+    for (int k = Dc + Dd + l; k < Lpad; k += 64) lat[k] = (T)0.f;
+}
+
+// backward of the above: d_o = gradient w.r.t. the head GEMM's output row.  dlat: gradient of the (compute-dtype) latent
+// from the decoder, dmean / dlogvar / dalpha: gradients from the loss (may be NULL), sample_path = 1 when c was the
+// Gumbel-softmax sample (unlabelled data in training mode)
+template <typename T>
+__global__ __launch_bounds__(64) void smooth_latent_bwd_kernel(const T* dlat, int Lpad, const float* dmean, const float* dlogvar,
+                                                                const float* dalpha, const float* logvar, const float* eps,
+                                                                const float* alpha, const float* gs, float temperature,
+                                                                int training, int sample_path, int Dc, int Dd, T* d_o, int ldo) {
+    const int b = blockIdx.x, l = threadIdx.x;
+    const T* dl = dlat + (int64_t)b * Lpad;
+    T* out = d_o + (int64_t)b * ldo;
+    for (int j = l; j < Dc; j += 64) {
+        const int64_t i = (int64_t)b * Dc + j;
+        const float dz = to_f(dl[j]);
+        float dm = dz + (dmean ? dmean[i] : 0.f);
+        float dv = dlogvar ? dlogvar[i] : 0.f;
+        if (training) dv += dz * eps[i] * 0.5f * expf(0.5f * logvar[i]);
+        out[j] = (T)dm;
+        out[Dc + j] = (T)dv;
+    }
+    // d alpha: from the loss and, on the sample path, through the Gumbel-softmax
+    float sdc = 0.f;
+    if (sample_path && training)
+        for (int k = l; k < Dd; k += 64) sdc += to_f(dl[Dc + k]) * gs[(int64_t)b * Dd + k];
+    sdc = wave_sum(sdc);
+    float sda = 0.f;
+    for (int k = l; k < Dd; k += 64) {
+        const int64_t i = (int64_t)b * Dd + k;
+        const float a = alpha[i];
+        float da = dalpha ? dalpha[i] : 0.f;
+        if (sample_path && training) da += gs[i] * (to_f(dl[Dc + k]) - sdc) / temperature / (a + SM_EPS);
+        sda += da * a;
+    }
+    sda = wave_sum(sda);
+    for (int k = l; k < Dd; k += 64) {
+        const int64_t i = (int64_t)b * Dd + k;
+        const float a = alpha[i];
+        float da = dalpha ? dalpha[i] : 0.f;
+        if (sample_path && training) da += gs[i] * (to_f(dl[Dc + k]) - sdc) / temperature / (a + SM_EPS);
+        out[2 * Dc + k] = (T)(a * (da - sda));
+    }
+    for (int k = 2 * Dc + Dd + l; k < ldo; k += 64) out[k] = (T)0.f;
+}
+
+// decoder output f [B][HW][ld] (compute dtype) -> reconstruction tanh(f[..., :C]) as NCHW fp32 (svhn_vae.py:118-120), and
+// its backward d_f = d_rec * (1 - rec^2) in NHWC (pad channels zero)
+template <typename T>
+__global__ void tanh_to_nchw_kernel(const T* f, int B, int Cc, int HW, int ld, float* out) {
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (unsigned)B * Cc * HW) return;
+    const unsigned p = i % HW, bc = i / HW, b = bc / Cc, c = bc - b * Cc;
+    out[i] = tanhf(to_f(f[((size_t)b * HW + p) * ld + c]));
+}
+template <typename T>
+__global__ void tanh_to_nchw_bwd_kernel(const float* d_out, const float* out, int B, int Cc, int HW, int ld, T* d_f) {
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;          // over B*HW*ld
+    if (i >= (unsigned)B * HW * ld) return;
+    const unsigned c = i % ld, bp = i / ld, b = bp / HW, p = bp - b * HW;
+    float v = 0.f;
+    if (c < (unsigned)Cc) {
+        const size_t j = ((size_t)b * Cc + c) * HW + p;
+        v = d_out[j] * (1.f - out[j] * out[j]);
+    }
+    d_f[i] = (T)v;
+}
+
+// Trainer._loss_function (main_smooth_ELBO_svhn.py:228-310) raw terms: t[0] = num_pixels * MSE = sum (rec - x)^2 / B,
+// t[1] = KL_c (:312-335), t[2] = sum alpha log(alpha + EPS) / B (KL_d = log D + t[2], :368-388), t[3] = BCE(alpha, one-hot)
+// (mean over B * D; 0 without labels).  t must be zeroed by the caller.
+__global__ __launch_bounds__(256) void smooth_elbo_fwd_kernel(const float* data, const float* rec, int64_t n, const float* mean,
+                                                              const float* logvar, const float* alpha, const int64_t* label,
+                                                              int B, int Dc, int Dd, float* t) {
+    __shared__ float red[4];
+    const int64_t stride = (int64_t)gridDim.x * 256, t0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    float s = 0.f;
+    for (int64_t i = t0; i < n; i += stride) { const float d = rec[i] - data[i]; s += d * d; }
+    float kc = 0.f;
+    for (int64_t i = t0; i < (int64_t)B * Dc; i += stride) { const float m = mean[i], lv = logvar[i]; kc += -0.5f * (1.f + lv - m * m - expf(lv)); }
+    float kd = 0.f, bc = 0.f;
+    for (int64_t i = t0; i < (int64_t)B * Dd; i += stride) {
+        const float a = alpha[i];
+        kd += a * logf(a + SM_EPS);
+        if (label) {
+            const bool y = (int)label[i / Dd] == (int)(i % Dd);
+            bc += -(y ? fmaxf(logf(a), -100.f) : fmaxf(log1pf(-a), -100.f));        // F.binary_cross_entropy clamps the logs at -100
+        }
+    }
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) atomicAdd(t, s / (float)B);
+    kc = block_sum(kc, red);
+    if (threadIdx.x == 0) atomicAdd(t + 1, kc / (float)B);
+    kd = block_sum(kd, red);
+    if (threadIdx.x == 0) atomicAdd(t + 2, kd / (float)B);
+    bc = block_sum(bc, red);
+    if (threadIdx.x == 0 && label) atomicAdd(t + 3, bc / ((float)B * (float)Dd));
+}
+
+// loss = t0 + gamma_c |C_c - KL_c| + gamma_d |C_d - KL_d| + alpha_cls * t3 with the linearly growing capacities
+// C = min((max - min) * steps / iters + min, max) (C_d also capped at log D); steps from the host or from a device counter
+// (hipGraph replay).  Writes t[4] = loss, t[5..8] = the four weighted parts (reconstruction, continuous capacity, discrete
+// capacity, classification) and coef[i] = d loss / d t[i].
+struct smooth_caps { float cmin, cmax, citers, cgamma, dmin, dmax, diters, dgamma, alpha_cls, steps; };
+__global__ void smooth_compose_kernel(float* t, smooth_caps c, const float* steps_dev, int Dd, int has_label, float* coef) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const float steps = steps_dev ? steps_dev[0] : c.steps;
+    const float cc = fminf((c.cmax - c.cmin) * steps / c.citers + c.cmin, c.cmax);
+    const float logD = logf((float)Dd);
+    const float cd = fminf(fminf((c.dmax - c.dmin) * steps / c.diters + c.dmin, c.dmax), logD);
+    const float klc = t[1], kld = logD + t[2];
+    auto sgn = [](float v) { return v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f); };
+    t[5] = t[0];
+    t[6] = c.cgamma * fabsf(cc - klc);
+    t[7] = c.dgamma * fabsf(cd - kld);
+    t[8] = has_label ? c.alpha_cls * t[3] : 0.f;
+    t[4] = t[5] + t[6] + t[7] + t[8];
+    coef[0] = 1.f;
+    coef[1] = c.cgamma * sgn(klc - cc);
+    coef[2] = c.dgamma * sgn(kld - cd);
+    coef[3] = has_label ? c.alpha_cls : 0.f;
+}
+
+__global__ __launch_bounds__(256) void smooth_elbo_bwd_kernel(const float* data, const float* rec, int64_t n, const float* mean,
+                                                              const float* logvar, const float* alpha, const int64_t* label,
+                                                              int B, int Dc, int Dd, const float* coef, const float* gout,
+                                                              float* d_rec, float* d_mean, float* d_logvar, float* d_alpha) {
+    const int64_t stride = (int64_t)gridDim.x * 256, t0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const float g = gout[0], ib = 1.f / (float)B;
+    const float c0 = g * coef[0] * 2.f * ib, c1 = g * coef[1] * ib, c2 = g * coef[2] * ib, c3 = g * coef[3] * ib / (float)Dd;
+    for (int64_t i = t0; i < n; i += stride) d_rec[i] = c0 * (rec[i] - data[i]);
+    for (int64_t i = t0; i < (int64_t)B * Dc; i += stride) {
+        d_mean[i] = c1 * mean[i];
+        d_logvar[i] = c1 * (-0.5f) * (1.f - expf(logvar[i]));
+    }
+    for (int64_t i = t0; i < (int64_t)B * Dd; i += stride) {
+        const float a = alpha[i];
+        float d = c2 * (logf(a + SM_EPS) + a / (a + SM_EPS));
+        if (label) {
+            const float y = (int)label[i / Dd] == (int)(i % Dd) ? 1.f : 0.f;
+            d += c3 * (a - y) / fmaxf((1.f - a) * a, 1e-12f);          // torch's binary_cross_entropy backward
+        }
+        d_alpha[i] = d;
+    }
+}
+
+// ---------------------------------------------------------------------------------------- Adam
+// torch.optim.Adam (no weight decay, no amsgrad; main_smooth_ELBO_svhn.py:428) on a flat parameter buffer: one launch
+// instead of one per tensor.  step = the 1-based count of this update, from the host or from a device counter (hipGraph).
+__global__ __launch_bounds__(256) void adam_kernel(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1,
+                                                   float b2, float eps, float step, const float* step_dev, float gscale) {
+    const float t = step_dev ? step_dev[0] : step;
+    const float bc1 = 1.f - powf(b1, t), bc2 = 1.f - powf(b2, t);
+    const float step_size = lr / bc1, inv_sq_bc2 = rsqrtf(bc2);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float gi = g[i] * gscale;
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        p[i] -= step_size * mi / (sqrtf(vi) * inv_sq_bc2 + eps);
+    }
+}
+
 // ---------------------------------------------------------------------------------------- SGD
 __global__ __launch_bounds__(256) void sgd_kernel(float* p, const float* g, float* v, int64_t n, float lr,
                                                   float momentum, float wd, float gscale, int first) {
@@ -1541,6 +1781,89 @@ int sv_optimal_match(const float* mu, const float* ls, int B, int D, int64_t* in
     SV_REQUIRE(lds <= 64 * 1024, SV_E_SHAPE, "sv_optimal_match: B=%d D=%d too large", B, D);
     hipLaunchKernelGGL(optimal_match_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, mu, ls, B, D, index);
     return sv_check_launch("sv_optimal_match");
+}
+
+int sv_smooth_latent_fwd(int dtype, const void* o, int ldo, const float* eps, const float* u, const int64_t* label,
+                         float temperature, int training, int B, int Dc, int Dd, int Lpad, float* mean, float* logvar,
+                         float* alpha, float* gs, void* latent, float* latent32, void* stream) {
+    SvProfScope prof_scope(stream);
+    SV_REQUIRE(o && mean && logvar && alpha && gs && latent && latent32 && B > 0 && Dc > 0 && Dd > 0, SV_E_ARG, "sv_smooth_latent_fwd: bad argument");
+    SV_REQUIRE(!training || (eps && u), SV_E_ARG, "sv_smooth_latent_fwd: training mode needs the noise");
+    SV_REQUIRE(ldo >= 2 * Dc + Dd && Lpad >= Dc + Dd && temperature > 0.f, SV_E_SHAPE, "sv_smooth_latent_fwd: ldo=%d Lpad=%d", ldo, Lpad);
+    DISPATCH_T(dtype, hipLaunchKernelGGL((smooth_latent_fwd_kernel<T>), dim3(B), dim3(64), 0, (hipStream_t)stream, (const T*)o, ldo, eps, u,
+                                         label, temperature, training, Dc, Dd, Lpad, mean, logvar, alpha, gs, (T*)latent, latent32));
+    return sv_check_launch("sv_smooth_latent_fwd");
+}
+
+int sv_smooth_latent_bwd(int dtype, const void* dlat, int Lpad, const float* dmean, const float* dlogvar, const float* dalpha,
+                         const float* logvar, const float* eps, const float* alpha, const float* gs, float temperature,
+                         int training, int sample_path, int B, int Dc, int Dd, void* d_o, int ldo, void* stream) {
+    SvProfScope prof_scope(stream);
+    SV_REQUIRE(dlat && logvar && alpha && gs && d_o && B > 0, SV_E_ARG, "sv_smooth_latent_bwd: bad argument");
+    SV_REQUIRE(!training || eps, SV_E_ARG, "sv_smooth_latent_bwd: training mode needs eps");
+    DISPATCH_T(dtype, hipLaunchKernelGGL((smooth_latent_bwd_kernel<T>), dim3(B), dim3(64), 0, (hipStream_t)stream, (const T*)dlat, Lpad,
+                                         dmean, dlogvar, dalpha, logvar, eps, alpha, gs, temperature, training, sample_path, Dc, Dd,
+                                         (T*)d_o, ldo));
+    return sv_check_launch("sv_smooth_latent_bwd");
+}
+
+int sv_tanh_to_nchw(int dtype, const void* f, int B, int C, int H, int W, int ld, float* out, void* stream) {
+    SvProfScope prof_scope(stream);
+    SV_REQUIRE(f && out, SV_E_ARG, "sv_tanh_to_nchw: null");
+    const int64_t n = (int64_t)B * C * H * W;
+    SV_REQUIRE(n < ((int64_t)1 << 32), SV_E_SHAPE, "sv_tanh_to_nchw: tensor too large");
+    DISPATCH_T(dtype, hipLaunchKernelGGL((tanh_to_nchw_kernel<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                                         (const T*)f, B, C, H * W, ld, out));
+    return sv_check_launch("sv_tanh_to_nchw");
+}
+
+int sv_tanh_to_nchw_bwd(int dtype, const float* d_out, const float* out, int B, int C, int H, int W, int ld, void* d_f, void* stream) {
+    SvProfScope prof_scope(stream);
+    SV_REQUIRE(d_out && out && d_f, SV_E_ARG, "sv_tanh_to_nchw_bwd: null");
+    const int64_t n = (int64_t)B * H * W * ld;
+    SV_REQUIRE(n < ((int64_t)1 << 32), SV_E_SHAPE, "sv_tanh_to_nchw_bwd: tensor too large");
+    DISPATCH_T(dtype, hipLaunchKernelGGL((tanh_to_nchw_bwd_kernel<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                                         d_out, out, B, C, H * W, ld, (T*)d_f));
+    return sv_check_launch("sv_tanh_to_nchw_bwd");
+}
+
+int sv_smooth_elbo_fwd(const float* data, const float* rec, int64_t n_per_img, const float* mean, const float* logvar,
+                       const float* alpha, const int64_t* label, int B, int Dc, int Dd, const sv_smooth_schedule* sch,
+                       const float* steps_dev, float* terms, float* coef, void* stream) {
+    SvProfScope prof_scope(stream);
+    SV_REQUIRE(data && rec && mean && logvar && alpha && sch && terms && coef && B > 0, SV_E_ARG, "sv_smooth_elbo_fwd: bad argument");
+    const int64_t n = n_per_img * B;
+    hipLaunchKernelGGL(smooth_elbo_fwd_kernel, dim3(sv_deterministic() ? 1 : nblocks(n, 1024, 1024)), dim3(256), 0, (hipStream_t)stream,
+                       data, rec, n, mean, logvar, alpha, label, B, Dc, Dd, terms);
+    smooth_caps c;
+    c.cmin = sch->cont_min; c.cmax = sch->cont_max; c.citers = sch->cont_iters; c.cgamma = sch->cont_gamma;
+    c.dmin = sch->disc_min; c.dmax = sch->disc_max; c.diters = sch->disc_iters; c.dgamma = sch->disc_gamma;
+    c.alpha_cls = sch->alpha_cls; c.steps = sch->steps;
+    hipLaunchKernelGGL(smooth_compose_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, terms, c, steps_dev, Dd, label ? 1 : 0, coef);
+    return sv_check_launch("sv_smooth_elbo_fwd");
+}
+
+int sv_smooth_elbo_bwd(const float* data, const float* rec, int64_t n_per_img, const float* mean, const float* logvar,
+                       const float* alpha, const int64_t* label, int B, int Dc, int Dd, const float* coef, const float* gout,
+                       float* d_rec, float* d_mean, float* d_logvar, float* d_alpha, void* stream) {
+    SvProfScope prof_scope(stream);
+    SV_REQUIRE(data && rec && mean && logvar && alpha && coef && gout && d_rec && d_mean && d_logvar && d_alpha, SV_E_ARG,
+               "sv_smooth_elbo_bwd: null");
+    const int64_t n = n_per_img * B;
+    hipLaunchKernelGGL(smooth_elbo_bwd_kernel, dim3(nblocks(n, 1024, 2048)), dim3(256), 0, (hipStream_t)stream, data, rec, n, mean,
+                       logvar, alpha, label, B, Dc, Dd, coef, gout, d_rec, d_mean, d_logvar, d_alpha);
+    return sv_check_launch("sv_smooth_elbo_bwd");
+}
+
+int sv_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, float step,
+            const float* step_dev, float grad_scale, void* stream) {
+    SvProfScope prof_scope(stream);
+    SV_REQUIRE(p && g && m && v && n >= 0, SV_E_ARG, "sv_adam: null");
+    SV_REQUIRE(step_dev || step >= 1.f, SV_E_ARG, "sv_adam: step=%g (1-based)", (double)step);
+    if (n == 0) return SV_OK;
+    hipLaunchKernelGGL(adam_kernel, dim3(nblocks(n, 256, 2048)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2,
+                       eps, step, step_dev, grad_scale);
+    return sv_check_launch("sv_adam");
 }
 
 int sv_sgd(float* p, const float* g, float* v, int64_t n, float lr, float momentum, float weight_decay,

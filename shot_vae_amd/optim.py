@@ -66,3 +66,82 @@ class FlatSGD:
             if b is not None:
                 self.model._flat_view(eng.mom, kind, payload).copy_(b.to(eng.param.device))
         self._steps = 1           # momentum buffers exist: the next step is not a "first step" (v = g)
+
+
+class FlatAdam:
+    """torch.optim.Adam(params, lr, betas, eps) -- no weight decay, no amsgrad: the optimizer of the smooth-ELBO trainers
+    (main_smooth_ELBO_svhn.py:428) -- on ONE flat fp32 buffer: the parameters are re-pointed to views of it (as are their
+    .grad), so a step is one sv_adam launch instead of ~60 small kernels per tensor list, and a data-parallel step reduces
+    one buffer.  Construct it AFTER moving the module to the GPU.  capturable=True keeps the step count on the device, so
+    that step() can be captured into a hipGraph.  state_dict() / load_state_dict() use torch.optim.Adam's format."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, capturable=False):
+        self.params = [p for p in params]
+        assert self.params and all(p.is_cuda and p.dtype == torch.float32 for p in self.params), \
+            "FlatAdam: fp32 parameters on an MI355X (move the module to the GPU first)"
+        dev = self.params[0].device
+        self.offsets, n = [], 0
+        for p in self.params:
+            self.offsets.append(n)
+            n += (p.numel() + 63) // 64 * 64
+        self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.flat_grad = torch.zeros_like(self.flat)
+        self.m, self.v = torch.zeros_like(self.flat), torch.zeros_like(self.flat)
+        for p, o in zip(self.params, self.offsets):
+            self.flat[o:o + p.numel()].copy_(p.data.reshape(-1))
+            p.data = self.flat[o:o + p.numel()].view(p.shape)
+        self._attach()
+        self.param_groups = [dict(lr=lr, betas=tuple(betas), eps=eps)]
+        self.steps = 0
+        self.step_dev = torch.zeros((), dtype=torch.float32, device=dev) if capturable else None
+
+    def _attach(self):
+        for p, o in zip(self.params, self.offsets):
+            g = p.grad
+            if g is None or g.data_ptr() != self.flat_grad.data_ptr() + 4 * o:
+                p.grad = self.flat_grad[o:o + p.numel()].view(p.shape)
+
+    def zero_grad(self, set_to_none=False):
+        self.flat_grad.zero_()
+        self._attach()
+
+    def step(self, grad_scale=1.0):
+        g = self.param_groups[0]
+        self.steps += 1
+        if self.step_dev is not None:
+            self.step_dev += 1
+        self._attach()
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        L.call("sv_adam", C.c_void_p(self.flat.data_ptr()), C.c_void_p(self.flat_grad.data_ptr()), C.c_void_p(self.m.data_ptr()),
+               C.c_void_p(self.v.data_ptr()), self.flat.numel(), float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]),
+               float(g["eps"]), float(self.steps), C.c_void_p(self.step_dev.data_ptr()) if self.step_dev is not None else None,
+               float(grad_scale), st)
+
+    def state_dict(self):
+        g = self.param_groups[0]
+        group = dict(lr=g["lr"], betas=g["betas"], eps=g["eps"], weight_decay=0, amsgrad=False, maximize=False, foreach=None,
+                     capturable=self.step_dev is not None, differentiable=False, fused=None, decoupled_weight_decay=False,
+                     params=list(range(len(self.params))))
+        state = {}
+        if self.steps > 0:
+            for i, (p, o) in enumerate(zip(self.params, self.offsets)):
+                state[i] = dict(step=torch.tensor(float(self.steps)), exp_avg=self.m[o:o + p.numel()].view(p.shape).clone(),
+                                exp_avg_sq=self.v[o:o + p.numel()].view(p.shape).clone())
+        return dict(state=state, param_groups=[group])
+
+    def load_state_dict(self, sd):
+        g = sd["param_groups"][0]
+        if g.get("weight_decay", 0) != 0 or g.get("amsgrad", False):
+            raise NotImplementedError("FlatAdam implements the reference's Adam (no weight decay, no amsgrad)")
+        self.param_groups = [dict(lr=g["lr"], betas=tuple(g["betas"]), eps=g["eps"])]
+        self.m.zero_()
+        self.v.zero_()
+        self.steps = 0
+        for k, st in sd.get("state", {}).items():
+            i = int(k)
+            p, o = self.params[i], self.offsets[i]
+            self.m[o:o + p.numel()].copy_(st["exp_avg"].reshape(-1).to(self.m.device))
+            self.v[o:o + p.numel()].copy_(st["exp_avg_sq"].reshape(-1).to(self.v.device))
+            self.steps = max(self.steps, int(float(st["step"])))
+        if self.step_dev is not None:
+            self.step_dev.fill_(float(self.steps))

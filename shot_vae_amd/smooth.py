@@ -8,8 +8,10 @@ convs as `convT_like` (four sub-pixel phases), the Linear layers as 1x1 GEMMs (t
 with their weights permuted between the reference's (c, y, x) flattening and the NHWC one); the ReLU between two layers is
 the consumer's load prologue (scale 1, shift 0, slope 0) and, in the backward, the producer's activation-backward
 epilogue, so no activation tensor is ever materialised.  Each layer is one torch.autograd.Function over those calls;
-the heads' softmax, the samplers and the scalar loss terms on [B, 32] / [B, 10] tensors are torch ops (plumbing), as is
-torch.optim.Adam on the parameters.  Parameters keep the reference's names and shapes (state_dict compatible).
+the heads' softmax, both samplers and the decoder input are one launch each way (sv_smooth_latent_fwd / _bwd), the Tanh +
+layout change of the reconstruction another (sv_tanh_to_nchw), the trainer's loss two launches forward and one backward
+(sv_smooth_elbo_fwd / _bwd), and Adam one launch on a flat parameter buffer (optim.FlatAdam over sv_adam;
+torch.optim.Adam also works).  Parameters keep the reference's names and shapes (state_dict compatible).
 
 There is no CPU fallback: the layers raise when the HIP library or a GPU is missing."""
 import ctypes as C
@@ -141,6 +143,100 @@ class _ConvLikeFn(torch.autograd.Function):
         return dx, dw, db, None, None, None
 
 
+class _LatentFn(torch.autograd.Function):
+    """Everything between the head GEMM and the decoder (svhn_vae.py:137-208) as one launch each way: softmax of the
+    discrete logits, the reparameterised normal sample, the Gumbel-softmax sample, one-hot of the label, the decoder's
+    padded input (sv_smooth_latent_fwd / _bwd)."""
+
+    @staticmethod
+    def forward(ctx, o, eps, u, label, temperature, training, Dc, Dd, Lpad, code):
+        B, ldo, dev = o.shape[0], o.shape[-1], o.device
+        o = o.contiguous()
+        f32 = dict(dtype=torch.float32, device=dev)
+        mean, logvar = torch.empty(B, Dc, **f32), torch.empty(B, Dc, **f32)
+        alpha, gs = torch.empty(B, Dd, **f32), torch.empty(B, Dd, **f32)
+        latent = torch.empty(B, 1, 1, Lpad, dtype=o.dtype, device=dev)
+        lat32 = torch.empty(B, Dc + Dd, **f32)
+        L.call("sv_smooth_latent_fwd", code, _vp(o), ldo, _vp(eps), _vp(u), _vp(label), float(temperature), int(training), B, Dc,
+               Dd, Lpad, _vp(mean), _vp(logvar), _vp(alpha), _vp(gs), _vp(latent), _vp(lat32), _st())
+        ctx.save_for_backward(logvar, eps, alpha, gs)
+        ctx.cfg = (temperature, training, label is None, Dc, Dd, Lpad, ldo, code, o.dtype)
+        ctx.set_materialize_grads(False)
+        ctx.mark_non_differentiable(gs, lat32)
+        return mean, logvar, alpha, gs, latent, lat32
+
+    @staticmethod
+    def backward(ctx, d_mean, d_logvar, d_alpha, _d_gs, d_latent, _d_lat32):
+        logvar, eps, alpha, gs = ctx.saved_tensors
+        temperature, training, sample_path, Dc, Dd, Lpad, ldo, code, tdt = ctx.cfg
+        B, dev = logvar.shape[0], logvar.device
+        if d_latent is None:
+            d_latent = torch.zeros(B, Lpad, dtype=tdt, device=dev)
+        c = lambda t: t.contiguous().float() if t is not None else None
+        d_mean, d_logvar, d_alpha = c(d_mean), c(d_logvar), c(d_alpha)
+        d_latent = d_latent.contiguous()
+        d_o = torch.empty(B, 1, 1, ldo, dtype=tdt, device=dev)
+        L.call("sv_smooth_latent_bwd", code, _vp(d_latent), Lpad, _vp(d_mean), _vp(d_logvar), _vp(d_alpha), _vp(logvar), _vp(eps),
+               _vp(alpha), _vp(gs), float(temperature), int(training), int(sample_path), B, Dc, Dd, _vp(d_o), ldo, _st())
+        return (d_o,) + (None,) * 9
+
+
+class _TanhNchwFn(torch.autograd.Function):
+    """reconstruction = tanh(decoder output[..., :C]) as NCHW fp32 (svhn_vae.py:118-120): one launch each way"""
+
+    @staticmethod
+    def forward(ctx, f, C_, code):
+        f = f.contiguous()
+        B, H, W, ld = f.shape
+        out = torch.empty(B, C_, H, W, dtype=torch.float32, device=f.device)
+        L.call("sv_tanh_to_nchw", code, _vp(f), B, C_, H, W, ld, _vp(out), _st())
+        ctx.save_for_backward(out)
+        ctx.cfg = (ld, code, f.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        out, = ctx.saved_tensors
+        ld, code, tdt = ctx.cfg
+        B, C_, H, W = out.shape
+        d_f = torch.empty(B, H, W, ld, dtype=tdt, device=out.device)
+        L.call("sv_tanh_to_nchw_bwd", code, _vp(d_out.contiguous().float()), _vp(out), B, C_, H, W, ld, _vp(d_f), _st())
+        return d_f, None, None
+
+
+class _SmoothLossFn(torch.autograd.Function):
+    """Trainer._loss_function (main_smooth_ELBO_svhn.py:228-310) in two launches forward (reductions, composition) and one
+    backward (sv_smooth_elbo_fwd / _bwd)."""
+
+    @staticmethod
+    def forward(ctx, data, recon, mean, logvar, alpha, label, sched, steps_dev):
+        for t in (data, recon, mean, logvar, alpha):
+            if not t.is_cuda:
+                raise L.ShotVaeHipError("shot_vae_amd runs on an MI355X only (no CPU fallback)")
+        data, recon = data.contiguous().float(), recon.contiguous().float()
+        mean, logvar, alpha = mean.contiguous().float(), logvar.contiguous().float(), alpha.contiguous().float()
+        label = label.contiguous().long() if label is not None else None
+        B, Dc, Dd = data.shape[0], mean.shape[1], alpha.shape[1]
+        terms = torch.zeros(9, dtype=torch.float32, device=data.device)
+        coef = torch.empty(4, dtype=torch.float32, device=data.device)
+        L.call("sv_smooth_elbo_fwd", _vp(data), _vp(recon), data[0].numel(), _vp(mean), _vp(logvar), _vp(alpha), _vp(label), B, Dc,
+               Dd, C.byref(sched), _vp(steps_dev), _vp(terms), _vp(coef), _st())
+        ctx.save_for_backward(data, recon, mean, logvar, alpha, coef)
+        ctx.label = label
+        ctx.mark_non_differentiable(terms)
+        return terms[4], terms
+
+    @staticmethod
+    def backward(ctx, g, _g_terms):
+        data, recon, mean, logvar, alpha, coef = ctx.saved_tensors
+        B, Dc, Dd = data.shape[0], mean.shape[1], alpha.shape[1]
+        d_rec, d_mean, d_logvar, d_alpha = (torch.empty_like(t) for t in (recon, mean, logvar, alpha))
+        g = g.contiguous().float().view(1)
+        L.call("sv_smooth_elbo_bwd", _vp(data), _vp(recon), data[0].numel(), _vp(mean), _vp(logvar), _vp(alpha), _vp(ctx.label), B,
+               Dc, Dd, _vp(coef), _vp(g), _vp(d_rec), _vp(d_mean), _vp(d_logvar), _vp(d_alpha), _st())
+        return None, d_rec, d_mean, d_logvar, d_alpha, None, None, None
+
+
 class SmoothVAE(nn.Module):
     """svhn_VAE / mnist_VAE (smooth_vae_model/svhn_vae.py:8-300): same constructor arguments, parameter names and
     forward contract -- forward(x, label=None) -> (reconstruction after Tanh, {'cont': [mean, logvar], 'disc': [alpha]},
@@ -192,10 +288,14 @@ class SmoothVAE(nn.Module):
         return _ConvLikeFn.apply(x, layer.master(w), b.float().contiguous() if b is not None else None, layer, relu_in,
                                  self.compute_dtype)
 
-    def encode(self, x):
-        """-> (mean, logvar, alpha) (svhn_vae.py:137-166)"""
+    def _code(self):
+        return L.SV_BF16 if self.compute_dtype == "bf16" else L.SV_F32
+
+    def _heads(self, x):
+        """image -> raw head outputs [B,1,1,pad16(2*cont + disc)] = [mean | logvar | logits | pad] (svhn_vae.py:137-160)"""
         B = x.shape[0]
-        x16 = F.pad(x.permute(0, 2, 3, 1), (0, 16 - x.shape[1])).to(self._tdt).contiguous()     # NHWC16 (layout edge)
+        x16 = torch.empty(B, 32, 32, 16, dtype=self._tdt, device=x.device)                       # NHWC16 (layout edge)
+        L.call("sv_nchw_to_nhwc", self._code(), _vp(x.contiguous().float()), B, x.shape[1], 32, 32, 16, _vp(x16), _st())
         e = self.img_to_features
         y = self._run("c1", x16, e[0].weight, e[0].bias, False)
         y = self._run("c2", y, e[2].weight, e[2].bias, True)
@@ -208,7 +308,23 @@ class SmoothVAE(nn.Module):
         hid = self._run("f1", y.view(B, 1, 1, w3 * 16), wf, fh.bias, True)                       # [B,1,1,hidden] raw
         wh = torch.cat([self.fc_mean.weight, self.fc_log_var.weight, self.fc_alphas[0].weight], 0)
         bh = torch.cat([self.fc_mean.bias, self.fc_log_var.bias, self.fc_alphas[0].bias], 0)
-        o = self._run("heads", hid, wh.view(wh.shape[0], self.hidden_dim, 1, 1), bh, True).view(B, -1).float()
+        return self._run("heads", hid, wh.view(wh.shape[0], self.hidden_dim, 1, 1), bh, True)
+
+    def _latent(self, o, label):
+        """head outputs -> (mean, logvar, alpha, Gumbel-softmax sample, decoder input, latent_sample): one launch
+        (sv_smooth_latent_fwd).  Host RNG order of the reference: randn for z (svhn_vae.py:176), then rand for the Gumbel
+        noise (:192) -- drawn in training mode for labelled data too (:205-207)."""
+        B, dev = o.shape[0], o.device
+        eps = u = None
+        if self.training:
+            eps = torch.randn((B, self.latent_cont_dim), device=dev).to(dev).float().contiguous()
+            u = torch.rand((B, self.latent_disc_dim), device=dev).to(dev).float().contiguous()
+        return _LatentFn.apply(o, eps, u, label.long().contiguous() if label is not None else None, self.temperature,
+                               self.training, self.latent_cont_dim, self.latent_disc_dim, self._L["g1"].Cin, self._code())
+
+    def encode(self, x):
+        """-> (mean, logvar, alpha) (svhn_vae.py:137-166)"""
+        o = self._heads(x).view(x.shape[0], -1).float()
         c = self.latent_cont_dim
         return o[:, :c], o[:, c:2 * c], F.softmax(o[:, 2 * c:2 * c + self.latent_disc_dim], dim=1)
 
@@ -224,10 +340,9 @@ class SmoothVAE(nn.Module):
             return F.softmax((torch.log(alpha + EPS) + gumbel) / self.temperature, dim=1)
         return F.one_hot(alpha.argmax(1), alpha.shape[1]).float()
 
-    def decode(self, latent_sample):
-        B = latent_sample.shape[0]
-        lat = self._L["g1"].Cin
-        z = F.pad(latent_sample, (0, lat - latent_sample.shape[1])).to(self._tdt).view(B, 1, 1, lat)
+    def _decode_padded(self, z):
+        """z: [B,1,1,pad16(latent)] in the compute dtype -> reconstruction NCHW fp32 after Tanh"""
+        B = z.shape[0]
         lf = self.latent_to_features
         f = self._run("g1", z, lf[0].weight.view(self.hidden_dim, self.latent_dim, 1, 1), lf[0].bias, False)
         w3 = self.reshape[0]
@@ -239,20 +354,19 @@ class SmoothVAE(nn.Module):
         f = self._run("t1", f, d[0].weight, d[0].bias, True)
         f = self._run("t2", f, d[2].weight, d[2].bias, True)
         f = self._run("t3", f, d[4].weight, d[4].bias, True)                                              # [B,32,32,16]
-        return torch.tanh(f[..., :self.img_size[0]].permute(0, 3, 1, 2).float())
+        return _TanhNchwFn.apply(f, self.img_size[0], self._code())
+
+    def decode(self, latent_sample):
+        B = latent_sample.shape[0]
+        lat = self._L["g1"].Cin
+        z = F.pad(latent_sample, (0, lat - latent_sample.shape[1])).to(self._tdt).view(B, 1, 1, lat)
+        return self._decode_padded(z)
 
     def forward(self, x, label=None):
-        mean, logvar, alpha = self.encode(x)
+        mean, logvar, alpha, gs, latent, latent_sample = self._latent(self._heads(x), label)
         latent_dist = {"cont": [mean, logvar], "disc": [alpha]}
-        z = self.sample_normal(mean, logvar)
-        disc_sample = []
-        if label is None:
-            c = self.sample_gumbel_softmax(alpha)
-        else:
-            c = F.one_hot(label, self.latent_disc_dim).float()
-            disc_sample.append(self.sample_gumbel_softmax(alpha))       # drawn (and unused) as in svhn_vae.py:205-207
-        latent_sample = torch.cat([z, c], 1)
-        return self.decode(latent_sample), latent_dist, latent_sample, disc_sample
+        disc_sample = [gs] if label is not None else []      # drawn (and unused) for labelled data, as svhn_vae.py:205-207
+        return self._decode_padded(latent), latent_dist, latent_sample, disc_sample
 
 
 svhn_VAE = mnist_VAE = SmoothVAE
@@ -266,28 +380,16 @@ class SmoothELBOLoss:
         self.cont_capacity, self.disc_capacity, self.alpha, self.num_steps = cont_capacity, disc_capacity, alpha, 0
         self.steps_dev = None       # optional device scalar used instead of num_steps (hipGraph replay)
 
-    def _cap(self, cap, t, tmax=None):
-        if self.steps_dev is not None:          # same formula on a device scalar: the captured graph follows the counter
-            c = torch.clamp((cap[1] - cap[0]) * self.steps_dev / float(cap[2]) + cap[0], max=float(cap[1]))
-            return c if tmax is None else torch.clamp(c, max=float(tmax))
-        c = min((cap[1] - cap[0]) * t / float(cap[2]) + cap[0], cap[1])
-        return c if tmax is None else min(c, tmax)
+    def _schedule(self):
+        cc, dc = self.cont_capacity, self.disc_capacity
+        return L.SvSmoothSchedule(float(cc[0]), float(cc[1]), float(cc[2]), float(cc[3]), float(dc[0]), float(dc[1]), float(dc[2]),
+                                  float(dc[3]), float(self.alpha), float(self.num_steps))
 
     def __call__(self, data, recon_data, latent_dist, label=None):
-        B = data.shape[0]
-        npix = data[0].numel()
-        recon_loss = F.mse_loss(recon_data.reshape(B, npix), data.reshape(B, npix)) * npix
         mean, logvar = latent_dist["cont"]
-        kl_c = (-0.5 * (1 + logvar - mean.pow(2) - logvar.exp())).mean(0).sum()
-        cont_loss = self.cont_capacity[3] * torch.abs(self._cap(self.cont_capacity, self.num_steps) - kl_c)
-        alpha = latent_dist["disc"][0]
-        D = alpha.shape[1]
-        kl_d = math.log(D) + (alpha * torch.log(alpha + EPS)).sum(1).mean(0)
-        disc_loss = self.disc_capacity[3] * torch.abs(self._cap(self.disc_capacity, self.num_steps, math.log(D)) - kl_d)
-        cls = torch.zeros((), device=data.device)
-        if label is not None:
-            cls = self.alpha * F.binary_cross_entropy(alpha, F.one_hot(label, D).float())
-        return recon_loss + cont_loss + disc_loss + cls, (recon_loss, cont_loss, disc_loss, cls)
+        loss, terms = _SmoothLossFn.apply(data, recon_data, mean, logvar, latent_dist["disc"][0], label, self._schedule(),
+                                          self.steps_dev)
+        return loss, (terms[5], terms[6], terms[7], terms[8])
 
 
 def smooth_train_step(model, loss_fn, optimizer, unlabeled_data, labeled_data, label, return_outputs=False,
@@ -303,11 +405,18 @@ def smooth_train_step(model, loss_fn, optimizer, unlabeled_data, labeled_data, l
     loss_l, split_l = loss_fn(labeled_data, rec_l, dist_l, label)
     loss = loss_u + loss_l
     loss.backward()
+    scale = None
     if distributed:
         from . import dp
-        dp.all_reduce_module_gradients(model)
+        if hasattr(optimizer, "flat_grad"):        # FlatAdam: the gradients ARE one flat buffer -> one all-reduce, 1/world in the kernel
+            scale = dp.all_reduce_gradients(optimizer.flat_grad)
+        else:
+            dp.all_reduce_module_gradients(model)
     if optimizer is not None:
-        optimizer.step()
+        if scale is not None:
+            optimizer.step(grad_scale=scale)
+        else:
+            optimizer.step()
     if not return_outputs:
         return loss.detach()
     out = dict(loss=loss, loss_u=loss_u, loss_l=loss_l, recon_u=split_u[0], cont_u=split_u[1], disc_u=split_u[2],

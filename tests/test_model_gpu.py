@@ -800,3 +800,45 @@ def test_fused_loss_node_equals_modular_criteria(bce, x_sigma, dev_lam):
     assert abs(float(ls_) - float(sup)) <= 2e-6 * abs(float(sup))
     for k in base:
         assert T.rel_err(a[k].grad.cpu().numpy(), b[k].grad.cpu().numpy()) < 2e-6, k
+
+
+def test_flat_adam_equals_torch_adam_and_shares_its_checkpoints():
+    """optim.FlatAdam (ONE sv_adam launch on a flat buffer whose views are the module's parameters / gradients) against
+    torch.optim.Adam on the same svhn_VAE iterations (main_smooth_ELBO_svhn.py:428): parameters after three iterations, and a
+    state_dict written by either loads into the other (resume), incl. the capturable variant with its device step counter."""
+    from oracle import smooth_oracle as SO
+    unl, lab, label, nz = SO.make_inputs("svhn", 16, 8)
+    unl, lab, label = unl.cuda(), lab.cuda(), label.cuda()
+
+    def run(make_opt, steps=3, resume=None):
+        model = S.SmoothVAE((3, 32, 32), {"cont": 32, "disc": [10]}, compute_dtype="fp32").cuda().train()
+        model.load_state_dict(SO.make_state("svhn"))
+        opt = make_opt(model)
+        if resume is not None:
+            model.load_state_dict(resume[0])
+            opt.load_state_dict(resume[1])
+        lf = S.SmoothELBOLoss()
+        lf.num_steps = 0 if resume is None else 3
+        with L_.options(deterministic=1):
+            for _ in range(steps):
+                with T.scripted_rng(randn=[nz["eps_u"], nz["eps_l"]], rand=[nz["u_u"], nz["u_l"]]):
+                    S.smooth_train_step(model, lf, opt, unl, lab, label)
+        torch.cuda.synchronize()
+        return model, opt
+
+    from shot_vae_amd import _lib as L_
+    m_t, o_t = run(lambda m: torch.optim.Adam(m.parameters(), lr=1e-3))
+    m_f, o_f = run(lambda m: S.FlatAdam(m.parameters(), lr=1e-3))
+    m_c, o_c = run(lambda m: S.FlatAdam(m.parameters(), lr=1e-3, capturable=True))
+    sd_t = m_t.state_dict()
+    for other in (m_f, m_c):
+        for k, v in other.state_dict().items():
+            assert T.rel_err(v.cpu().numpy(), sd_t[k].cpu().numpy()) < 2e-5, k
+    # checkpoints cross over: torch -> flat and flat -> torch, then two more iterations agree
+    ck_t = ({k: v.clone() for k, v in m_t.state_dict().items()}, o_t.state_dict())
+    ck_f = ({k: v.clone() for k, v in m_f.state_dict().items()}, o_f.state_dict())
+    a, _ = run(lambda m: S.FlatAdam(m.parameters(), lr=1e-3), steps=2, resume=ck_t)
+    b, _ = run(lambda m: torch.optim.Adam(m.parameters(), lr=1e-3), steps=2, resume=ck_f)
+    sb = b.state_dict()
+    for k, v in a.state_dict().items():
+        assert T.rel_err(v.cpu().numpy(), sb[k].cpu().numpy()) < 5e-5, k
