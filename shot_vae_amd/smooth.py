@@ -129,9 +129,12 @@ class _ConvLikeFn(torch.autograd.Function):
             a = L.SvIgemmArgs()
             a.x, a.w, a.out, a.replicas = dy.data_ptr(), wpd.data_ptr(), dx.data_ptr(), 1
             if ctx.relu_in:     # ReLU backward fused as the activation-backward epilogue (BN part: identity statistics)
-                bs = torch.zeros(2 * layer.Cin, device=dev)
                 a.ex, a.ex_scale, a.ex_shift = x.data_ptr(), one.data_ptr(), zero.data_ptr()
-                a.ex_mean, a.ex_rstd, a.ex_slope, a.bsums = zero.data_ptr(), one.data_ptr(), 0.0, bs.data_ptr()
+                a.ex_mean, a.ex_rstd, a.ex_slope, a.bsums = zero.data_ptr(), one.data_ptr(), 0.0, x.data_ptr()
+                if L.deterministic():        # (the sums are not used here, but the launch wants one replica per wave)
+                    a.replicas = L.det_replicas(gd, code, a)
+                bs = torch.zeros(a.replicas * 2 * layer.Cin, device=dev)
+                a.bsums = bs.data_ptr()
             L.call("sv_igemm", C.byref(gd), code, C.byref(a), _st())
         dw = torch.zeros_like(master)
         L.call("sv_wgrad", C.byref(gf), code, _vp(x), _vp(one) if ctx.relu_in else None,
