@@ -335,9 +335,7 @@ __global__ __launch_bounds__(256, SV_C3P_WAVES) void conv3x3p_kernel(const sv_ge
         const int gr0 = tile * TR;
         // ---- request the halo two tiles ahead + this tile's epilogue operands; they fly during the MFMAs ----
         const bool more = tile + 1 < t_end;
-#ifndef SV_C3P_NO_HALO
         if (tile + 2 < t_end) load_halo(FREE, tile + 2);
-#endif
         int64_t obase[2];
         Q eop[NT][2];
 #pragma unroll
@@ -346,12 +344,8 @@ __global__ __launch_bounds__(256, SV_C3P_WAVES) void conv3x3p_kernel(const sv_ge
 #pragma unroll
             for (int i = 0; i < NT; ++i) {
                 const int n = n0 + 16 * i + 4 * fq;
-#ifndef SV_C3P_NO_EOP
                 if (R) eop[i][ms] = *reinterpret_cast<const Q*>(R + obase[ms] + n);
                 else if (EX) eop[i][ms] = *reinterpret_cast<const Q*>(EX + obase[ms] + n);
-#else
-                eop[i][ms] = Q{};
-#endif
             }
         }
         // ---- nine taps x CCH channel chunks out of LDS (padding is data: no masks) ---------------------------
@@ -376,9 +370,7 @@ __global__ __launch_bounds__(256, SV_C3P_WAVES) void conv3x3p_kernel(const sv_ge
             }
         }
         __syncthreads();                               // all waves are done reading this tile's halo
-#ifndef SV_C3P_NO_XF
         if (more) store_halo(NEXT);                    // next tile's halo -> LDS (requested a whole tile ago)
-#endif
         // ---- epilogue of this tile (operands already in registers) -----------------------------------------
 #pragma unroll
         for (int i = 0; i < NT; ++i) {
@@ -411,9 +403,6 @@ __global__ __launch_bounds__(256, SV_C3P_WAVES) void conv3x3p_kernel(const sv_ge
                 Q o;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) o[r] = (T)vv[r];
-#ifdef SV_C3P_NO_STORE
-                if (vv[0] == 1234.5f)
-#endif
                 *reinterpret_cast<Q*>(O + obase[ms] + n) = o;
             }
         }

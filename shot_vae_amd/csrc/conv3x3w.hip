@@ -115,10 +115,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3w_kernel(const sv_geom g, const
     const uint32_t costep = has_pro ? 128u : 0u;
 
     for (int c = tid; c < 2 * BN; c += 256) ssum[c] = 0.f;
-#ifdef SV_W3_STAMP
-    const uint64_t st0 = __builtin_amdgcn_s_memtime();
-    const uint64_t rt0 = __builtin_amdgcn_s_memrealtime();
-#endif
 
     // ---- DMA slots (uniform instruction count per wave: the last, partial wave-instruction is shifted back so that it
     //      ends at the end of the image and re-copies a few slots -- same source, same destination) -----------------
@@ -289,9 +285,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3w_kernel(const sv_geom g, const
     wait_lds();
     barrier();
 
-#ifdef SV_W3_STAMP
-    const uint64_t st1 = __builtin_amdgcn_s_memtime();
-#endif
     // ---- one (chunk, tap) step: weights of step k live in ring slot k % 3 = t % 3 ---------------------------------------
     auto step = [&](int c, auto tc, auto parc) __attribute__((always_inline)) {
         constexpr int t = decltype(tc)::value, par = decltype(parc)::value;
@@ -300,23 +293,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3w_kernel(const sv_geom g, const
         const bool w_issue = k + 2 < KT;
         // (1) asynchronous copies: weights two steps ahead (into the slot step k-1 released), the next chunk's raw halo
         //     and BatchNorm coefficients at the chunk's first step
-#ifndef SV_W3_NO_W
         if (w_issue) issue_w(c + (t + 2) / 9, (t + 2) % 9, (t + 2) % 3);
-#endif
-#ifndef SV_W3_NO_H
         if (t == 0 && more_c) issue_h(c + 1, par ^ 1);
-#endif
         // (2) this step's fragments
-#ifndef SV_W3_NO_FRAG
         load_frags(tc, parc);
-#endif
         // (3) BatchNorm-apply + LeakyReLU + padding of the next chunk's halo, in place, spread over steps 3..7
         //     (unconditional: after the last chunk it rewrites an unused buffer)
-#ifndef SV_W3_NO_XF
         if (t >= 3 && t <= 7) {
-#else
-        if (false) {
-#endif
             const int cn = min(c + 1, nck - 1);
             if (t == 3) {
                 transform(cn, I0{}, par ^ 1);
@@ -326,7 +309,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3w_kernel(const sv_geom g, const
             }
         }
         // (4) this step's 4 NF MFMAs
-#ifndef SV_W3_NO_MFMA
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -334,12 +316,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3w_kernel(const sv_geom g, const
 #pragma unroll
                 for (int i = 0; i < NF; ++i)
                     acc[f][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[ks][i], Bf[ks][f], acc[f][i], 0, 0, 0);
-#else       // timing ablation: keep the fragment reads alive without the matrix work
-#pragma unroll
-        for (int i = 0; i < NF; ++i) asm volatile("" ::"v"(A[0][i]), "v"(A[1][i]));
-#pragma unroll
-        for (int f = 0; f < 2; ++f) asm volatile("" ::"v"(Bf[0][f]), "v"(Bf[1][f]));
-#endif
         // (5) the weights of step k+1 must have landed; everything issued after them may stay in flight: this step's
         //     weights, and the raw halo (+ coefficients) for two more steps
         const bool h_fly = t <= 1 && more_c;
@@ -349,9 +325,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3w_kernel(const sv_geom g, const
             if (h_fly) wait_vm<HI + 1>(); else wait_vm<0>();
         }
         wait_lds();
-#ifndef SV_W3_NO_BAR       // (timing ablation: races)
         barrier();
-#endif
     };
     auto chunk = [&](int c, auto parc) __attribute__((always_inline)) {
         step(c, std::integral_constant<int, 0>{}, parc);
@@ -369,11 +343,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3w_kernel(const sv_geom g, const
         if (c + 1 < nck) chunk(c + 1, I1{});
     }
 
-#ifdef SV_W3_STAMP
-    const uint64_t st2 = __builtin_amdgcn_s_memtime();
-#endif
     constexpr int SV_EPD = SV_W3_EPD;
-#define SV_EPI_STAMP(k)
 #define SV_EPI_NSCR 1
 #define SV_EPI_BASE 0
 #define SV_EPI_ALIAS 0
@@ -385,7 +355,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3w_kernel(const sv_geom g, const
 #undef SV_EPI_NSCR
 #undef SV_EPI_BASE
 #undef SV_EPI_ALIAS
-#undef SV_EPI_STAMP
 }
 
 template <int NF, int WLOG, bool REV>

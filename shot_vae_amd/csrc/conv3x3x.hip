@@ -255,9 +255,6 @@ __global__ __launch_bounds__(256, 1) void conv3x3x_kernel(const sv_geom g, const
         return p;
     };
 
-#ifdef SV_X3_STAMP
-    const uint64_t st0 = __builtin_amdgcn_s_memtime();
-#endif
 
     // ---- halo vectors of this thread: vector s = 256 j + tid = (halo pixel s >> 2, logical 8-channel quarter tid & 3),
     //      stored at the swizzled quarter; kind: 0 zero (padding column / spacer / dummy), 1 row of the tile, 2 the row
@@ -435,11 +432,6 @@ __global__ __launch_bounds__(256, 1) void conv3x3x_kernel(const sv_geom g, const
         static_for<NF>([&](auto I) { read_w(0, decltype(KS)::value, decltype(I)::value); });
         static_for<2>([&](auto F) { read_p(0, decltype(KS)::value, decltype(F)::value); });
     });
-#ifdef SV_X3_STAMP
-    const uint64_t st1 = __builtin_amdgcn_s_memtime();
-    uint64_t stb = 0, st_loop = 0, st_epi = 0, ste[8] = {}, sti[2] = {}, st_first = 0, st_mid = 0, st_last = 0;
-    uint64_t st_mark = st1;
-#endif
 
     // ---- the K loop over all positions of the block: one 32-channel chunk = nine taps = 180 MFMAs -------------------------
     int par = 0;                       // halo stage and ring parity of the current chunk
@@ -454,9 +446,6 @@ __global__ __launch_bounds__(256, 1) void conv3x3x_kernel(const sv_geom g, const
 #pragma unroll
               for (int e = 0; e < 16; ++e) acc[f][i][e] = 0.f;
       for (int cc = 0; cc < nck; ++cc) {
-#ifdef SV_X3_STAMP
-        const uint64_t sc0 = __builtin_amdgcn_s_memtime();
-#endif
         const Pos nn = next_pos(nxt);
         const uint32_t other = (uint32_t)((par ^ 1) * HB);
         static_for<9>([&](auto T) {
@@ -500,18 +489,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3x_kernel(const sv_geom g, const
                 if constexpr (i == 4) read_p(tn, ks, f);
                 __builtin_amdgcn_sched_barrier(0);
             });
-#ifdef SV_X3_BARRIER_EVERY_TAP      // experiment
-            if constexpr (t != 1 && t != 4 && t != 7) {
-                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-                asm volatile("" ::: "memory");
-            }
-#endif
             if constexpr (t == 1 || t == 4 || t == 7) {
                 constexpr int n = t == 1 ? SCHED.vm_b1 : t == 4 ? SCHED.vm_b4 : SCHED.vm_b7;
-#ifdef SV_X3_STAMP
-                const uint64_t sb0 = __builtin_amdgcn_s_memtime();
-#endif
                 if constexpr (t == 7) {
                     // The halo / coefficient registers of the chunk after next were requested by assembly the compiler
                     // cannot see through: to it they are defined the moment the load is issued.  Nothing it might do with
@@ -530,18 +509,10 @@ __global__ __launch_bounds__(256, 1) void conv3x3x_kernel(const sv_geom g, const
                 }
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
-#ifdef SV_X3_STAMP
-                stb += __builtin_amdgcn_s_memtime() - sb0;
-#endif
             }
         });
         par ^= 1;
         if (cc + 1 < nck) { cur = nxt; nxt = nn; }
-#ifdef SV_X3_STAMP
-#ifdef SV_X3_STAMP_CHUNK    // (opt-in: with these three counters the 160-channel diagnostic build faults -- register pressure; unresolved)
-        { const uint64_t d = __builtin_amdgcn_s_memtime() - sc0; if (cc == 0) st_first += d; else if (cc + 1 == nck) st_last += d; else st_mid += d; }
-#endif
-#endif
       }
       {
             // ---- the item is complete: epilogue (its scratch lies apart from the stages and the ring, which already hold
@@ -550,18 +521,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3x_kernel(const sv_geom g, const
             // (the per-wave sums need no clearing: every address is written once per item; the flush of item i and the
             //  writes of item i + 1 are separated by the chunk loop's barriers)
             asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
-#ifdef SV_X3_SYNC_AROUND_EPILOGUE      // experiment
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            __syncthreads();
-#endif
             const int n0 = cur.n0, gr0 = cur.gr0;
-#ifdef SV_X3_STAMP
-            { const uint64_t now = __builtin_amdgcn_s_memtime(); st_loop += now - st_mark; st_mark = now; }
-#define SV_EPI_STAMP(k) ste[k] = __builtin_amdgcn_s_memtime();
-#define SV_EPI_STAMP_IN(k) sti[k] = __builtin_amdgcn_s_memtime();
-#else
-#define SV_EPI_STAMP(k)
-#endif
             {
                 constexpr int SV_EPD = SV_X3_EPD;
 #define SV_EPI_NSCR 1
@@ -575,16 +535,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3x_kernel(const sv_geom g, const
 #undef SV_EPI_NSCR
 #undef SV_EPI_BASE
 #undef SV_EPI_ALIAS
-#undef SV_EPI_STAMP
-#undef SV_EPI_STAMP_IN
             }
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-#ifdef SV_X3_SYNC_AROUND_EPILOGUE
-            __syncthreads();
-#endif
-#ifdef SV_X3_STAMP
-            { const uint64_t now = __builtin_amdgcn_s_memtime(); st_epi += now - st_mark; st_mark = now; }
-#endif
       }
       {   // step to the next item's first chunk (staged during this item's last one)
           const Pos nn2 = next_pos(nxt);
@@ -592,13 +544,6 @@ __global__ __launch_bounds__(256, 1) void conv3x3x_kernel(const sv_geom g, const
           nxt = nn2;
       }
     }
-#ifdef SV_X3_STAMP
-    if (tid == 0 && blockIdx.x < 2048) {      // (diagnostic build: behind the eight statistics replicas)
-        float* d = a.stats + 8 * 2 * g.N + 8 * blockIdx.x;
-        d[0] = (float)(st1 - st0); d[1] = (float)st_loop; d[2] = (float)st_epi; d[3] = (float)stb;
-        d[4] = (float)cnt; d[5] = (float)(sti[0] - ste[1]); d[6] = (float)(sti[1] - sti[0]); d[7] = (float)(ste[2] - sti[1]);
-    }
-#endif
 }
 
 template <int WLOG, bool REV, int MODE>
@@ -629,12 +574,6 @@ int launch_x4(const sv_geom* g, const sv_igemm_args* a, hipStream_t s) {
 // (bias, no statistics, ...) takes the binary that reads the flags at run time
 template <int WLOG, bool REV>
 int launch_x3(const sv_geom* g, const sv_igemm_args* a, hipStream_t s) {
-#ifdef SV_X3_MODES      // (measured: -0.3 % forward, -2.6 % data gradient for 2.5x the build time -- not instantiated by default)
-    if (!a->bias) {
-        if (!REV && !a->ex && a->stats) return a->residual ? launch_x4<WLOG, REV, 2>(g, a, s) : launch_x4<WLOG, REV, 1>(g, a, s);
-        if (REV && a->ex && !a->residual) return launch_x4<WLOG, REV, 3>(g, a, s);
-    }
-#endif
     return launch_x4<WLOG, REV, 0>(g, a, s);
 }
 

@@ -75,11 +75,7 @@ __global__ __launch_bounds__(256, MS == 4 ? 2 : 1) void igemm_kernel(const sv_ge
     const int nk = (Ktot + BKK - 1) / BKK;
     const T* __restrict__ X = reinterpret_cast<const T*>(a.x);
     const T* __restrict__ W = reinterpret_cast<const T*>(a.w) + P.w_off;
-#ifdef SV_IG_NO_XF      // (timing ablations: results are wrong by construction)
-    const bool has_pro = false;
-#else
     const bool has_pro = a.pro_scale != nullptr;
-#endif
 
     // A phase without taps (three of the four output parities of a stride-2 1x1 data gradient) is exactly zero, and so
     // are its contributions to the BatchNorm sums of either epilogue: plain 16-byte zero stores, no reads, no atomics.
@@ -179,21 +175,13 @@ __global__ __launch_bounds__(256, MS == 4 ? 2 : 1) void igemm_kernel(const sv_ge
 #pragma unroll
             for (int i = 0; i < MS; ++i) {
                 oka[s][i] = okr[i];
-#ifdef SV_IG_NO_GA
-                const V val = zero;
-#else
                 const V val = *reinterpret_cast<const V*>(pa[i] + cs);
-#endif
                 ra[s][i] = okr[i] ? val : zero;
             }
             const int ks = kc * BKK + BK * s;                             // uniform; < Ktot by construction
 #pragma unroll
             for (int i = 0; i < NBV; ++i) {
-#ifdef SV_IG_NO_GB
-                const V val = zero;
-#else
                 const V val = *reinterpret_cast<const V*>(pw[i] + ks);
-#endif
                 rb[s][i] = wok[i] ? val : zero;
             }
         }
@@ -224,12 +212,7 @@ __global__ __launch_bounds__(256, MS == 4 ? 2 : 1) void igemm_kernel(const sv_ge
                                 (unsigned)ix < (unsigned)g.Win;
                 oka[s][i] = ok;
                 const int iyc = min(max(iy, 0), g.Hin - 1), ixc = min(max(ix, 0), g.Win - 1);
-#ifdef SV_IG_NO_GA
-                const V val = zero;
-                asm volatile("" ::"v"(iyc), "v"(ixc));
-#else
                 const V val = *reinterpret_cast<const V*>(X + ((int64_t)(pixb[i] + iyc * g.Win + ixc) * g.ldx + cc));
-#endif
                 ra[s][i] = ok ? val : zero;
             }
             const int k8 = kc * BKK + BK * s + 8 * v;
@@ -238,12 +221,7 @@ __global__ __launch_bounds__(256, MS == 4 ? 2 : 1) void igemm_kernel(const sv_ge
             for (int i = 0; i < NBV; ++i) {
                 const int nb = lrow + 64 * i;
                 const bool ok = nb < BN && n0 + nb < g.N && k8 < Ktot;
-#ifdef SV_IG_NO_GB
-                const V val = zero;
-                asm volatile("" ::"v"(k8c));
-#else
                 const V val = *reinterpret_cast<const V*>(W + (int64_t)min(n0 + nb, g.N - 1) * Ktot + k8c);
-#endif
                 rb[s][i] = ok ? val : zero;
             }
             // advance (tap, c) to this sub-chunk's position in the next iteration
@@ -304,12 +282,8 @@ __global__ __launch_bounds__(256, MS == 4 ? 2 : 1) void igemm_kernel(const sv_ge
 #pragma unroll
             for (int i = 0; i < NT; ++i) {
                 const V wf = *reinterpret_cast<const V*>(Bb + 16 * i * LDK + BK * s);
-#ifdef SV_IG_NO_MFMA
-                asm volatile("" ::"v"(wf[0]));
-#else
 #pragma unroll
                 for (int j = 0; j < MS; ++j) mma32(acc[i][j], wf, af[j]);
-#endif
             }
         }
         if (kc + 1 < nk) store_lds(buf ^ 1);
@@ -334,12 +308,8 @@ __global__ __launch_bounds__(256, MS == 4 ? 2 : 1) void igemm_kernel(const sv_ge
         const int qx = r - qy * g.Wq;
         obase[ms] = ((int64_t)(b * g.Hout + qy * g.osy + P.ooy) * g.Wout + qx * g.osx + P.oox) * g.ldo;
     }
-#ifdef SV_IG_NO_EPI
-    if (obase[0] == -12345) gemm_epilogue<T, NT, MS>(acc, obase, oval, n0, g.N, a, ssum);
-#else
     // (the k loop ended with a barrier: the operand buffers are free for the epilogue's constants)
     gemm_epilogue<T, NT, MS>(acc, obase, oval, n0, g.N, a, ssum, reinterpret_cast<float*>(smem) + (MS == 4 ? 2 * BN : 0));
-#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -634,7 +604,6 @@ extern "C" int sv_igemm(const sv_geom* g, int dtype, const sv_igemm_args* a_in, 
     // wide layers (N a multiple of 160 / 128) with enough rows: 256-row tiles at two blocks per CU -- the input is gathered
     // and BatchNorm-transformed once per 160 / 128 channels instead of once per 64 / 80 (measured on the WRN-28-10 stride-2
     // 3x3 layers at 4 x 256 images: forward 798 -> 517 us, data gradient 1102 -> 820 us; tools/ig_ablate.sh)
-#ifndef SV_IG_NO_BIG
     if (dtype == SV_BF16 && !sv_disabled(SV_K_IGEMM_BIG)) {
         const int64_t mt256 = (M + 255) / 256 * g->nphase * sv_ngroups(a->groups);
         // no load prologue (data gradients): both operands by LDS-DMA
@@ -645,7 +614,6 @@ extern "C" int sv_igemm(const sv_geom* g, int dtype, const sv_igemm_args* a_in, 
         // (128-channel tiles from half a block per slot: the 4x4 stride-2 data gradient of ConvT 512 -> 256, 128 tiles, 163 -> 142 us)
         if (g->N % 128 == 0 && mt256 * (g->N / 128) >= (sv_wide_min_blocks() + 1) / 2) return launch_kv<bf16, 8, 1, 4>(g, a, s);
     }
-#endif
     const int64_t mtiles = (M + 127) / 128 * g->nphase;
     // widest channel tile that still yields >= 2 blocks per CU; never below 32 channels unless N is
     const int N = g->N;

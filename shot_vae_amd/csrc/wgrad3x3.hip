@@ -61,9 +61,6 @@ template <typename T, int WLOG, int STAGES>
 __global__ __launch_bounds__(256, 2) void wgrad3x3_kernel(const sv_geom g, const sv_wg_g<wg3_params> PG) {
     const wg3_params& p = PG.g[blockIdx.y];
     typedef typename V8<T>::type V;
-#ifdef SV_WG3_STAMP
-    const uint64_t st_entry = __builtin_amdgcn_s_memtime();
-#endif
     constexpr int W = 1 << WLOG, TR = 128 / W, WP = W + 2;
     // LDS halo rows: row 0 / the last row are the vertical halo, and when a tile holds several whole images (W = 8:
     // TR = 16 > H = 8) a zero spacer row separates them -- zero padding is DATA in LDS, the nine taps need no masks
@@ -179,33 +176,13 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_kernel(const sv_geom g, const
 #pragma unroll
     for (int t = 0; t < 9; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-#ifdef SV_WG3_STAMP
-    uint64_t st_store = 0, st_bar = 0, st_mma = 0, st_bar2 = 0, st_ld = 0, st_wait = 0;
-    const uint64_t st_begin = __builtin_amdgcn_s_memtime();
-#define WG3_STAMP(acc_)                                         \
-    {                                                           \
-        const uint64_t now_ = __builtin_amdgcn_s_memtime();     \
-        acc_ += now_ - st_last;                                 \
-        st_last = now_;                                         \
-    }
-    uint64_t st_last = st_begin;
-#else
-#define WG3_STAMP(acc_)
-#endif
     if (t_begin < t_end) load_tile(SA, t_begin);
     if (STAGES == 2 && t_begin + 1 < t_end) load_tile(SB, t_begin + 1);
     // one tile of the pipeline: CUR holds this tile (requested two tiles ago), and is re-loaded with tile + 2 once stored
     auto do_tile = [&](int tile, Stage& CUR) {
-#ifdef SV_WG3_STAMP
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        WG3_STAMP(st_wait)
-#endif
         store_tile(CUR);
-        WG3_STAMP(st_store)
         __syncthreads();
-        WG3_STAMP(st_bar)
         if (tile + STAGES < t_end) load_tile(CUR, tile + STAGES);   // in flight during this (and the next) tile's MFMAs
-        WG3_STAMP(st_ld)
         if (sizeof(T) == 2) {
             const bf16* Yb = reinterpret_cast<const bf16*>(Ys);
             const bf16* Hb = reinterpret_cast<const bf16*>(halo);
@@ -236,7 +213,6 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_kernel(const sv_geom g, const
             load_frags(FB, 3);
             mma_frags(FA);
             mma_frags(FB);
-#ifndef SV_WG3_NO_SCHED
             // keep the order written above (the scheduler otherwise re-serialises to two fragments in flight)
             __builtin_amdgcn_sched_group_barrier(0x100, 40, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, 9, 0);
@@ -244,7 +220,6 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_kernel(const sv_geom g, const
             __builtin_amdgcn_sched_group_barrier(0x008, 9, 0);
             __builtin_amdgcn_sched_group_barrier(0x100, 20, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, 18, 0);
-#endif
         } else {
             // fp32 (parity mode): v_mfma_f32_16x16x4_f32 step j uses pixel 4*j + fq of each 32-pixel chunk
             const float* Yf = reinterpret_cast<const float*>(Ys);
@@ -261,9 +236,7 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_kernel(const sv_geom g, const
                 }
             }
         }
-        WG3_STAMP(st_mma)
         __syncthreads();          // everyone is done reading before the next tile overwrites LDS
-        WG3_STAMP(st_bar2)
     };
     if (STAGES == 2) {
         for (int tile = t_begin; tile < t_end; tile += 2) {
@@ -273,14 +246,6 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_kernel(const sv_geom g, const
     } else {
         for (int tile = t_begin; tile < t_end; ++tile) do_tile(tile, SA);
     }
-#ifdef SV_WG3_STAMP
-    if (tid == 0 && p.ws) {     // diagnostic build: per-block cycle shares into the tail of the caller's workspace
-        float* d = p.ws + (8u << 20) + 8 * blockIdx.x;
-        d[0] = (float)st_store; d[1] = (float)st_bar; d[2] = (float)st_mma; d[3] = (float)st_bar2;
-        d[4] = (float)(__builtin_amdgcn_s_memtime() - st_begin); d[5] = (float)(t_end - t_begin); d[6] = (float)st_ld; d[7] = (float)st_wait;
-    }
-    const uint64_t st_loop_end = __builtin_amdgcn_s_memtime();
-#endif
 
     // ---- publish: D layout = lane holds c = 16*wj + fr, n = 16*wi + 4*fq + r ----------------------------
     const int64_t slab = (int64_t)g.N * g.T_orig * g.Cin;
@@ -295,15 +260,6 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_kernel(const sv_geom g, const
             else atomicAdd(q, acc[t][r]);
         }
     }
-#ifdef SV_WG3_STAMP
-    if (tid == 0 && p.ws) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        float* d = p.ws + (9u << 20) + 8 * blockIdx.x;
-        d[0] = (float)(st_begin - st_entry);
-        d[1] = (float)(__builtin_amdgcn_s_memtime() - st_loop_end);
-        d[2] = (float)(__builtin_amdgcn_s_memtime() - st_entry);
-    }
-#endif
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -651,14 +607,11 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3w_kernel(const sv_geom g, cons
             // in-place accumulation in the AGPR half, spelled out: left to itself the register allocator rotates the
             // 180 accumulators through copies
             asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[a][t]) : "v"(fy[set][a]), "v"(fx[t]));
-#ifndef SV_WG3_NO_FRAG       // (timing ablations only: the results are wrong)
             if constexpr (a < 2) {
                 if constexpr (t >= 1) load_fx(nkc, t - 1, a);
                 else load_fy(set ^ 1, nkc, 0, a);
             }
             if constexpr (a == 2 && t < 8) load_fy(set ^ 1, nkc, 1 + t / 2, t & 1);
-#endif
-#ifndef SV_WG3_NO_SIDE
             static_for<3>([&](auto J) {
                 constexpr int code = SCHED.item[ph * 45 + g][decltype(J)::value], kind = code / 1000, arg = code % 1000;
                 if constexpr (kind == 1)
@@ -675,7 +628,6 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3w_kernel(const sv_geom g, cons
                     if constexpr (arg % 4 == 0) hok[arg / 4] = hokn[arg / 4];
                 }
             });
-#endif
             __builtin_amdgcn_sched_barrier(0);
         });
         load_fx(nkc, 8, 0);
@@ -683,10 +635,6 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3w_kernel(const sv_geom g, cons
     };
     static_assert(HI >= 3 && HI <= 4 && HSTEPS == WG_HSTEPS, "phase work lists");
 
-#ifdef SV_WG3_STAMP
-    const uint64_t st_begin = __builtin_amdgcn_s_memtime();
-    uint64_t st_p0 = 0, st_p1 = 0, st_p2 = 0, st_p3 = 0, st_bar = 0, st_last = 0;
-#endif
     int cur = 0;
     for (int gi = 0; gi < p.groups; ++gi) {
     if (gi > 0) {
@@ -728,9 +676,6 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3w_kernel(const sv_geom g, cons
     for (int a = 0; a < 5; ++a) { load_fy(0, 0, a, 0); load_fy(0, 0, a, 1); }
 #pragma unroll
     for (int t = 0; t < 9; ++t) { load_fx(0, t, 0); load_fx(0, t, 1); }
-#ifdef SV_WG3_STAMP
-    st_last = __builtin_amdgcn_s_memtime();
-#endif
     for (int tile = t_begin; tile < t_end; ++tile) {
         bf16* cur_stage = lds0 + cur * BUF;
         bf16* other = lds0 + (cur ^ 1) * BUF;
@@ -739,14 +684,10 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3w_kernel(const sv_geom g, cons
         // harmless re-load of the last tile), and after the barrier D0..D3 of tile + 2 start into this stage
         halo_bases(min(tile + 2, t_end - 1));
         phase(std::integral_constant<int, 0>{}, other, cur ^ 1);
-        WG3_STAMP(st_p0)
         phase(std::integral_constant<int, 1>{}, other, cur ^ 1);
-        WG3_STAMP(st_p1)
         phase(std::integral_constant<int, 2>{}, other, cur ^ 1);
-        WG3_STAMP(st_p2)
         drain_h(rn);              // this wave's share of the dy DMA has landed, and so has the halo of the tile after next
         __syncthreads();          // the other stage is complete, and nobody reads this one any more (kc3 is in registers)
-        WG3_STAMP(st_bar)
         {   // from here on fragments come from the other stage
             const uint32_t flip = cur ? (uint32_t)(-(BUF * 2)) : (uint32_t)(BUF * 2);
             yaddr += flip;
@@ -755,19 +696,11 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3w_kernel(const sv_geom g, cons
         }
         dy_base(min(tile + 2, t_end - 1));
         phase(std::integral_constant<int, 3>{}, cur_stage, cur);
-        WG3_STAMP(st_p3)
         cur ^= 1;
     }
     }
     asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");   // the last (redundant) DMA, before the LDS goes
                                                                             // away; the last MFMAs, before acc is read
-#ifdef SV_WG3_STAMP
-    if (tid == 0 && p.ws) {
-        float* d = p.ws + (24u << 20) + 8 * blockIdx.x;
-        d[4] = (float)(__builtin_amdgcn_s_memtime() - st_begin); d[5] = (float)(t_end - t_begin);
-        d[0] = (float)st_p0; d[1] = (float)st_p1; d[2] = (float)st_p2; d[3] = (float)st_p3; d[6] = (float)st_bar;
-    }
-#endif
 
     // ---- publish: D layout = lane holds c = c0 + 16*wj + fr, n = n0 + 80*wi + 16*a + 4*fq + r --------------------
     const int64_t slab = (int64_t)g.N * g.T_orig * g.Cin;

@@ -135,3 +135,67 @@ def test_wide_conv_chunk_program_is_consistent():
             nb = min(b for b in (40, 100, 160) if b > gi) if gi < 160 else None
             assert nb is not None and nb - gi >= 14, (c, gi)
     assert gap_of[5000] == 160, "the stage flip precedes the first fragment read of tap 8"
+
+
+def test_host_dispatchers_under_asan(tmp_path):
+    """`make asan` builds the library with the HOST side under AddressSanitizer (GPU ASan is not available on this pool); a
+    child process preloads the sanitizer runtime and drives what runs without a GPU: the dispatcher's dry run
+    (sv_igemm_query_blocks: geometry checks, halo / tile configuration, tap tables, grid arithmetic) over every conv-like
+    layer of WRN-28-2 and WRN-28-10 forward and backward with 1 and 4 groups, the compile-time tile programs, the option
+    setters and the argument-error paths.  Any heap / stack / global overflow in that host code aborts the child."""
+    import glob
+    import subprocess
+    import sys
+    rt = sorted(glob.glob("/opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so"))
+    if not rt:
+        import pytest
+        pytest.skip("no AddressSanitizer runtime in this image")
+    csrc = os.path.join(ROOT, "shot_vae_amd", "csrc")
+    r = subprocess.run(["make", "-C", csrc, "-j8", "asan"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    script = tmp_path / "drive.py"
+    script.write_text(r'''
+import ctypes as C, sys
+sys.path.insert(0, %r)
+from shot_vae_amd import _lib as L
+from shot_vae_amd.engine import Plan
+lib = L.lib()
+assert lib.sv_version() == 3
+n_ok = n_err = 0
+for net, K in (("wideresnet-28-2", 10), ("wideresnet-28-10", 100), ("wideresnet-10-1", 10)):
+    plan = Plan(net, K=K)
+    for B in (1, 8):
+        for cv in plan.convs:
+            for g in (cv.geom_fwd(B), cv.geom_dgrad(B)):
+                for groups in (1, 4):
+                    for dtype in (L.SV_F32, L.SV_BF16):
+                        a = L.SvIgemmArgs()
+                        a.x = a.w = a.out = 4096                 # never dereferenced: nothing is launched
+                        a.groups, a.replicas = groups, 1
+                        blocks = C.c_int(-1)
+                        rc = lib.sv_igemm_query_blocks(C.byref(g), dtype, C.byref(a), C.byref(blocks))
+                        # (kernels that need the >64 KiB LDS opt-in ask the HIP runtime first: an error without a GPU)
+                        if rc == 0:
+                            assert blocks.value > 0
+                            n_ok += 1
+                        else:
+                            n_err += 1
+items, waits = (C.c_int * (180 * 6))(), (C.c_int * 10)()
+assert lib.sv_debug_conv_chunk_program(items, waits) == 0
+for hv in (3, 4):
+    it3, w5 = (C.c_int * (180 * 3))(), (C.c_int * 5)()
+    assert lib.sv_debug_wgrad_tile_program(hv, it3, w5) == 0
+for key, val in ((0, 5), (1, 7), (2, 1), (3, 64), (4, 1)):
+    assert lib.sv_set_option(key, val) == 0 and lib.sv_get_option(key) == val
+assert lib.sv_set_option(99, 1) != 0 and lib.sv_set_option(3, 1) != 0
+order = (C.c_int32 * 4)(0, 2, 2, 3)            # not a permutation: refused before any launch
+assert lib.sv_bn_running_update_ex(4096, 4096, 1, 4096, 4096, 1e-5, 0.1, 64, 4, order, None) != 0
+assert lib.sv_igemm(None, 1, None, None) != 0 and b"null" in lib.sv_last_error()
+print("ASAN_DRIVE_OK", n_ok, n_err)
+''' % ROOT)
+    env = dict(os.environ, LD_PRELOAD=rt[-1], ASAN_OPTIONS="detect_leaks=0:abort_on_error=0:exitcode=66",
+               SV_LIB_PATH=os.path.join(ROOT, "shot_vae_amd", "libshotvae_hip_asan.so"))
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0 and "ASAN_DRIVE_OK" in r.stdout, (r.returncode, r.stdout[-500:], r.stderr[-3000:])
+    n_ok = int(r.stdout.split("ASAN_DRIVE_OK")[1].split()[0])
+    assert n_ok >= 100, r.stdout
