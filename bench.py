@@ -223,13 +223,20 @@ def extras(S):
     rows = []
     with contextlib.redirect_stdout(sys.stderr):          # (the tool prints its own table: keep stdout to the one JSON line)
         for Cc, H in ((160, 32), (320, 16), (640, 8)):
-            r = LB.bench_layer(512, Cc, H, Cc)
+            # best of three short measurements per kernel: a 20-launch window is 4-6 ms, and one driver / clock hiccup inside
+            # it doubles the average (seen once: 640-channel forward 439 us in one window, 198 us in every other)
+            r = {}
+            for _ in range(3):
+                for k, us in LB.bench_layer(512, Cc, H, Cc).items():
+                    r[k] = min(us, r.get(k, us))
             row = {"layer": "conv3x3 s1 %d->%d @%dx%d, B=512, 0.2416 TFLOP" % (Cc, Cc, H, H)}
             for k, us in r.items():
                 row[k + "_us"] = round(us, 1)
                 row[k + "_frac"] = round(0.2416e12 / (us * 1e-6) / (MFMA_PEAK_TFLOPS["bf16"] * 1e12), 4)
             rows.append(row)
-    res["wrn28_10_layer_table"] = {"bar": "frac >= 0.40 (<= 242 us)", "peak_TFLOPs": MFMA_PEAK_TFLOPS["bf16"], "rows": rows,
+    res["wrn28_10_layer_table"] = {"bar": "frac >= 0.40 (<= 242 us)", "peak_TFLOPs": MFMA_PEAK_TFLOPS["bf16"],
+                                   "method": "tools/layer_bench.py in-process: 3 warm-up + 20 launches per window, best of 3 windows",
+                                   "rows": rows,
                                    "passing": sum(1 for r in rows for k in ("fwd", "dgrad", "wgrad") if r[k + "_frac"] >= 0.40),
                                    "of": 3 * len(rows)}
     return res
