@@ -245,8 +245,9 @@ def extras(S):
 def svhn_workload(a, rank, world):
     """--workload svhn: one smooth-ELBO iteration of svhn_VAE (BASELINE configs[4]; main_smooth_ELBO_svhn.py:152-176: unlabelled
     forward + loss, labelled forward + loss, one backward, Adam) on --batch images per loader per GPU.  The iteration is ~130
-    launches of tens of microseconds: launch-bound, so the single-GPU run probes eager issue against a hipGraph replay and keeps
-    the faster (both in the JSON); N > 1 is eager with ONE all-reduce of FlatAdam's flat gradient buffer per iteration."""
+    launches of tens of microseconds: launch-bound, so the run probes eager issue against a hipGraph replay and keeps the faster
+    (both in the JSON); at N > 1 the graph holds forward + backward and ONE all-reduce of FlatAdam's flat gradient buffer +
+    the sv_adam launch follow it eagerly."""
     import shot_vae_amd as S
     B = a.batch if a.scaling == "weak" else a.batch // world
     torch.manual_seed(1)
@@ -283,15 +284,20 @@ def svhn_workload(a, rank, world):
         eager()
     mode, probe, graphed = "eager", None, None
     want = a.graph if a.graph is not None else -1
-    if world == 1 and want != 0:
+    if want != 0:
         try:
-            graphed = S.GraphedSmoothStep(model, loss_fn, opt, u, l, y, warmup=2)
+            graphed = S.GraphedSmoothStep(model, loss_fn, opt, u, l, y, warmup=2, distributed=world > 1)
         except Exception as e:
             mode = "eager (graph capture failed: %s)" % type(e).__name__
             torch.cuda.synchronize()
     if graphed is not None:
         if want < 0:
-            probe = {"eager_ms": round(timed(eager, 10)[0], 3), "graph_ms": round(timed(graphed, 10)[0], 3)}
+            pe, pg = timed(eager, 10)[0], timed(graphed, 10)[0]
+            if world > 1:                   # the slower rank decides, every rank decides the same
+                pv = torch.tensor([pe, pg], device="cuda", dtype=torch.float64)
+                dist.all_reduce(pv, op=dist.ReduceOp.MAX)
+                pe, pg = float(pv[0]), float(pv[1])
+            probe = {"eager_ms": round(pe, 3), "graph_ms": round(pg, 3)}
             if probe["graph_ms"] < probe["eager_ms"]:
                 mode = "hipGraph replay (faster than eager issue in the probe)"
             else:

@@ -436,8 +436,10 @@ class GraphedSmoothStep:
     follows a device-side step counter; noise comes from torch's graph-safe Philox generator."""
 
     def __init__(self, model, loss_fn, optimizer, unlabeled_data, labeled_data, label, warmup=3, distributed=False):
-        assert not distributed, "the captured iteration is single-GPU; use smooth_train_step(distributed=True) for DP"
-        self.model, self.loss_fn, self.opt = model, loss_fn, optimizer
+        # distributed=True (one process per GPU): the graph holds both forwards, the loss and the backward; the ONE gradient
+        # all-reduce (FlatAdam's flat buffer, or the bucketed module gradients) and the optimizer step follow eagerly, so
+        # the collective is an ordinary RCCL call
+        self.model, self.loss_fn, self.opt, self.distributed = model, loss_fn, optimizer, distributed
         self.u, self.l, self.y = unlabeled_data.clone(), labeled_data.clone(), label.clone()
         loss_fn.steps_dev = torch.full((), float(loss_fn.num_steps), device=self.u.device)
         self.stream = torch.cuda.Stream()
@@ -446,6 +448,8 @@ class GraphedSmoothStep:
         with torch.cuda.stream(self.stream):
             for _ in range(warmup):
                 self._body()
+                if distributed:
+                    self._update()
         cur.wait_stream(self.stream)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
@@ -462,8 +466,17 @@ class GraphedSmoothStep:
         loss_l, _ = lf(self.l, rec_l, dist_l, self.y)
         loss = loss_u + loss_l
         loss.backward()
-        self.opt.step()
+        if not self.distributed:
+            self.opt.step()
         return loss.detach()
+
+    def _update(self):
+        from . import dp
+        if hasattr(self.opt, "flat_grad"):
+            self.opt.step(grad_scale=dp.all_reduce_gradients(self.opt.flat_grad))
+        else:
+            dp.all_reduce_module_gradients(self.model)
+            self.opt.step()
 
     def __call__(self, unlabeled_data=None, labeled_data=None, label=None):
         if unlabeled_data is not None:
@@ -471,5 +484,7 @@ class GraphedSmoothStep:
             self.l.copy_(labeled_data)
             self.y.copy_(label)
         self.graph.replay()
+        if self.distributed:
+            self._update()
         self.loss_fn.num_steps += 1
         return self.loss
