@@ -89,3 +89,17 @@ def test_bench_two_ranks_gloo_on_one_gpu():
     assert out["config"]["lambda_equal_across_ranks"] is True
     # --scaling strong probes both launch modes and reports both
     assert set(out["config"]["launch_probe"]) == {"eager_ms", "graph_ms"}
+
+
+@pytest.mark.timeout(900)
+def test_bench_svhn_workload_two_ranks_gloo_on_one_gpu():
+    """bench.py --workload svhn --gpus 2 (BASELINE config 5's data-parallel iteration: per-rank shard, graph of forwards +
+    backward, ONE all-reduce of FlatAdam's flat gradient buffer, sv_adam with 1/world) on one GPU over gloo."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["SV_DIST_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "svhn", "--gpus", "2", "--steps", "3",
+                        "--warmup", "2", "--batch", "64"], capture_output=True, text=True, env=env, timeout=850)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["n_gpus"] == 2 and out["value"] > 0 and "svhn_VAE" in out["metric"]
+    assert out["config"]["global_batch"] == 256 and set(out["config"]["launch_probe"]) == {"eager_ms", "graph_ms"}

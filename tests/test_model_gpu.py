@@ -827,18 +827,34 @@ def test_flat_adam_equals_torch_adam_and_shares_its_checkpoints():
         return model, opt
 
     from shot_vae_amd import _lib as L_
+    # ONE iteration from identical gradients: the two optimizers differ by arithmetic rounding only
+    a1, _ = run(lambda m: torch.optim.Adam(m.parameters(), lr=1e-3), steps=1)
+    b1, _ = run(lambda m: S.FlatAdam(m.parameters(), lr=1e-3), steps=1)
+    sb1 = b1.state_dict()
+    for k, v in a1.state_dict().items():
+        assert T.rel_err(sb1[k].cpu().numpy(), v.cpu().numpy()) < 1e-6, k
+    # three iterations: Adam moves every weight by ~lr whatever its gradient's size, so the fp32 rounding differences of
+    # small gradients come back as O(1e-3 lr) parameter differences -- 2e-3 of the tensor's scale
     m_t, o_t = run(lambda m: torch.optim.Adam(m.parameters(), lr=1e-3))
     m_f, o_f = run(lambda m: S.FlatAdam(m.parameters(), lr=1e-3))
     m_c, o_c = run(lambda m: S.FlatAdam(m.parameters(), lr=1e-3, capturable=True))
     sd_t = m_t.state_dict()
     for other in (m_f, m_c):
         for k, v in other.state_dict().items():
-            assert T.rel_err(v.cpu().numpy(), sd_t[k].cpu().numpy()) < 2e-5, k
+            assert T.rel_err(v.cpu().numpy(), sd_t[k].cpu().numpy()) < 2e-3, k
+    sd_c = m_c.state_dict()
+    for k, v in m_f.state_dict().items():          # host step count = device step count: identical arithmetic
+        assert T.rel_err(sd_c[k].cpu().numpy(), v.cpu().numpy()) < 1e-6, k
     # checkpoints cross over: torch -> flat and flat -> torch, then two more iterations agree
     ck_t = ({k: v.clone() for k, v in m_t.state_dict().items()}, o_t.state_dict())
-    ck_f = ({k: v.clone() for k, v in m_f.state_dict().items()}, o_f.state_dict())
-    a, _ = run(lambda m: S.FlatAdam(m.parameters(), lr=1e-3), steps=2, resume=ck_t)
-    b, _ = run(lambda m: torch.optim.Adam(m.parameters(), lr=1e-3), steps=2, resume=ck_f)
+    a, _ = run(lambda m: S.FlatAdam(m.parameters(), lr=1e-3), steps=1, resume=ck_t)
+    b, _ = run(lambda m: torch.optim.Adam(m.parameters(), lr=1e-3), steps=1, resume=ck_t)
     sb = b.state_dict()
     for k, v in a.state_dict().items():
-        assert T.rel_err(v.cpu().numpy(), sb[k].cpu().numpy()) < 5e-5, k
+        assert T.rel_err(v.cpu().numpy(), sb[k].cpu().numpy()) < 1e-6, k
+    ck_f = ({k: v.clone() for k, v in m_f.state_dict().items()}, o_f.state_dict())
+    a, _ = run(lambda m: S.FlatAdam(m.parameters(), lr=1e-3), steps=1, resume=ck_f)
+    b, _ = run(lambda m: torch.optim.Adam(m.parameters(), lr=1e-3), steps=1, resume=ck_f)
+    sb = b.state_dict()
+    for k, v in a.state_dict().items():
+        assert T.rel_err(v.cpu().numpy(), sb[k].cpu().numpy()) < 1e-6, k
