@@ -1674,7 +1674,9 @@ int sv_elbo_fwd(const float* x, const float* x_rec, int64_t n_per_img, const flo
     SvProfScope prof_scope(stream);
     SV_REQUIRE(x && x_rec && mu && ls && la && out3, SV_E_ARG, "sv_elbo_fwd: null");
     const int64_t n = n_per_img * B;
-    hipLaunchKernelGGL(elbo_fwd_kernel, dim3(sv_deterministic() ? 1 : nblocks(n / 4, 256, 1024)), dim3(256), 0, (hipStream_t)stream, x, x_rec,
+    // (three float atomics per block on the same three addresses: 256 blocks, not 1 024 -- the tail of serialised atomics
+    //  was most of this kernel's 26 us)
+    hipLaunchKernelGGL(elbo_fwd_kernel, dim3(sv_deterministic() ? 1 : nblocks(n / 4, 1024, 256)), dim3(256), 0, (hipStream_t)stream, x, x_rec,
                        n, mu, ls, la, B, ldc, K, bce, x_sigma, log_prior_f32(K), out3);
     return sv_check_launch("sv_elbo_fwd");
 }

@@ -281,6 +281,7 @@ class Engine:
         # one-shot callback fired by backward() as soon as every decoder gradient has been ISSUED (main + side stream): the
         # data-parallel step starts the all-reduce of the decoder's 88 % of the gradient bytes there (dp.DecoderFirstAllReduce)
         self.bucket_hook = None
+        self._side_keep = {}          # main stream -> operands of the weight gradients in flight on its side stream
         for b in p.bns:
             self.bufs[b.rv_off: b.rv_off + b.C] = 1.0
 
@@ -470,25 +471,37 @@ class Engine:
             s = pool[cur.cuda_stream] = torch.cuda.Stream()
         return cur, s
 
-    def _wgrad_async(self, g, x, pro, dy, dw_ptr, tag=None, groups=1, budget=0):
+    def _wgrad_async(self, g, x, pro, dy, dw_ptr, tag=None, groups=1, budget=0, then=None):
         """Enqueue the weight gradient behind everything issued so far, on the side stream: the dgrad -> BN-apply
-        chain continues on the main stream without waiting for it (joined at the end of backward)."""
+        chain continues on the main stream without waiting for it (joined at the end of backward).
+        `then`: a callable that issues the main-stream launch paired with this weight gradient (the layer's data gradient).
+        It is issued FIRST -- the fork point is an event recorded before it -- so that the main stream, the critical path,
+        never waits for the host to finish the side stream's bookkeeping (tools/step_timeline.py showed ~8 us of idle main
+        stream per pair); the weight gradient still depends only on what preceded the pair."""
         # (not under hipGraph capture: a captured step replays a hundred cross-stream edges slower than one stream --
         #  11.6 against 11.05 ms, measured -- and tensors freed during capture would need to outlive the side stream)
         if not self.wgrad_side_stream or self.prof_tags is not None or torch.cuda.is_current_stream_capturing():
-            return self._wgrad(g, x, pro, dy, dw_ptr, tag, groups, budget)
+            self._wgrad(g, x, pro, dy, dw_ptr, tag, groups, budget)
+            return then() if then is not None else None
         cur, side = self._side()
-        side.wait_stream(cur)
+        ev = torch.cuda.Event()
+        ev.record(cur)
+        out = then() if then is not None else None
+        side.wait_event(ev)
         with torch.cuda.stream(side):
             self._wgrad(g, x, pro, dy, dw_ptr, tag, groups, budget)
-        if not torch.cuda.is_current_stream_capturing():    # (graph-private pools keep memory until the graph dies)
-            x.record_stream(side)
-            dy.record_stream(side)
+        # the operands stay referenced until the streams are joined at the end of backward (no record_stream bookkeeping
+        # per tensor: two allocator calls per weight gradient on the host's critical path)
+        self._side_keep.setdefault(cur.cuda_stream, []).append((x, dy))
+        return out
 
     def _join_side(self):
         if self.wgrad_side_stream and self.prof_tags is None and not torch.cuda.is_current_stream_capturing():
             cur, side = self._side()
             cur.wait_stream(side)
+            # the side stream's operands may be released now: the main stream, on which the allocator will hand their
+            # memory out again, is ordered behind everything the side stream did
+            self._side_keep.pop(cur.cuda_stream, None)
 
     def _wgrad(self, g, x, pro, dy, dw_ptr, tag=None, groups=1, budget=0):
         if tag:
@@ -831,17 +844,17 @@ class Engine:
             for i in range(5, 0, -1):
                 cv, b = p.dec_convs[i], p.dec_bns[i - 1]
                 hin = f.h[i - 1][:Bd]                     # the groups are back to back: the first Gd are a prefix
-                self._wgrad_async(cv.geom_fwd(B), hin, f.dpro[i - 1], D, gbase + 4 * cv.master_off, tag="wgrad:dec%d" % i,
-                                  groups=Gd)
                 g = torch.empty_like(hin)
-                self._igemm(cv.geom_dgrad(B), D, pk + es * cv.dgrad_off, g, ex=ex_of(b, hin, Gd), tag="dgrad:dec%d" % i,
-                            groups=Gd)
+                self._wgrad_async(cv.geom_fwd(B), hin, f.dpro[i - 1], D, gbase + 4 * cv.master_off, tag="wgrad:dec%d" % i,
+                                  groups=Gd, then=lambda: self._igemm(cv.geom_dgrad(B), D, pk + es * cv.dgrad_off, g,
+                                                                      ex=ex_of(b, hin, Gd), tag="dgrad:dec%d" % i, groups=Gd))
                 D = bn_apply(hin, [(g, b)], None, hin.numel() // hin.shape[-1] // Gd, Gd)
             cv = p.dec_convs[0]
             lat4 = f.latent.view(Bt, 1, 1, p.Lpad)[:Bd]
-            self._wgrad_async(cv.geom_fwd(B), lat4, None, D, gbase + 4 * cv.master_off, tag="wgrad:dec0", groups=Gd)
             dlat = torch.empty(Bd, 1, 1, p.Lpad, dtype=T, device=dev)
-            self._igemm(cv.geom_dgrad(B), D, pk + es * cv.dgrad_off, dlat, tag="dgrad:dec0", groups=Gd)
+            self._wgrad_async(cv.geom_fwd(B), lat4, None, D, gbase + 4 * cv.master_off, tag="wgrad:dec0", groups=Gd,
+                              then=lambda: self._igemm(cv.geom_dgrad(B), D, pk + es * cv.dgrad_off, dlat, tag="dgrad:dec0",
+                                                       groups=Gd))
             # ---- sampler (the latent's gradient reaches mu / log_sigma / log_alpha) -------------------------------
             dl2 = dlat.view(Bd, p.Lpad)
             for gi, (mode, _, _, _) in enumerate(f.groups[:Gd]):
@@ -877,27 +890,31 @@ class Engine:
             pair = self.pair_blocks if (self.wgrad_side_stream and self.prof_tags is None and
                                         not torch.cuda.is_current_stream_capturing()) else 0
             pair = min(pair, L.lib().sv_get_option(L.OPT_PERSISTENT_BLOCKS))
-            self._wgrad_async(un["conv2"].geom_fwd(B), c1, pro2, D, gbase + 4 * un["conv2"].master_off,
-                              tag="wgrad:conv3x3_%dx%d_s1" % (c, c), groups=G, budget=pair)
             g2 = torch.empty_like(c1)
-            self._igemm(un["conv2"].geom_dgrad(B), D, pk + es * un["conv2"].dgrad_off, g2, ex=ex_of(un["bn2"], c1),
-                        tag="dgrad:conv3x3_%dx%d_s1" % (c, c), groups=G, budget=pair)
+            self._wgrad_async(un["conv2"].geom_fwd(B), c1, pro2, D, gbase + 4 * un["conv2"].master_off,
+                              tag="wgrad:conv3x3_%dx%d_s1" % (c, c), groups=G, budget=pair,
+                              then=lambda: self._igemm(un["conv2"].geom_dgrad(B), D, pk + es * un["conv2"].dgrad_off, g2,
+                                                       ex=ex_of(un["bn2"], c1), tag="dgrad:conv3x3_%dx%d_s1" % (c, c),
+                                                       groups=G, budget=pair))
             dc1 = bn_apply(c1, [(g2, un["bn2"])], None, c1.numel() // c // G)
             del g2
             pair1 = pair if (un["stride"] == 1 and un["cin"] == c) else 0
-            self._wgrad_async(un["conv1"].geom_fwd(B), tin, pro1, dc1, gbase + 4 * un["conv1"].master_off,
-                              tag="wgrad:conv3x3_%dx%d_s%d" % (un["cin"], c, un["stride"]), groups=G, budget=pair1)
             g1 = torch.empty_like(tin)
-            self._igemm(un["conv1"].geom_dgrad(B), dc1, pk + es * un["conv1"].dgrad_off, g1, ex=ex_of(un["bn1"], tin),
-                        tag="dgrad:conv3x3_%dx%d_s%d" % (un["cin"], c, un["stride"]), groups=G, budget=pair1)
+            self._wgrad_async(un["conv1"].geom_fwd(B), tin, pro1, dc1, gbase + 4 * un["conv1"].master_off,
+                              tag="wgrad:conv3x3_%dx%d_s%d" % (un["cin"], c, un["stride"]), groups=G, budget=pair1,
+                              then=lambda: self._igemm(un["conv1"].geom_dgrad(B), dc1, pk + es * un["conv1"].dgrad_off, g1,
+                                                       ex=ex_of(un["bn1"], tin),
+                                                       tag="dgrad:conv3x3_%dx%d_s%d" % (un["cin"], c, un["stride"]),
+                                                       groups=G, budget=pair1))
             del dc1
             cnt = tin.numel() // tin.shape[-1] // G
             if "convi" in un:
-                self._wgrad_async(un["convi"].geom_fwd(B), tin, proi, D, gbase + 4 * un["convi"].master_off,
-                                  tag="wgrad:conv1x1_%dx%d" % (un["cin"], c), groups=G)
                 gi_ = torch.empty_like(tin)
-                self._igemm(un["convi"].geom_dgrad(B), D, pk + es * un["convi"].dgrad_off, gi_,
-                            ex=ex_of(un["bni"], tin), tag="dgrad:conv1x1_%dx%d" % (un["cin"], c), groups=G)
+                self._wgrad_async(un["convi"].geom_fwd(B), tin, proi, D, gbase + 4 * un["convi"].master_off,
+                                  tag="wgrad:conv1x1_%dx%d" % (un["cin"], c), groups=G,
+                                  then=lambda: self._igemm(un["convi"].geom_dgrad(B), D, pk + es * un["convi"].dgrad_off, gi_,
+                                                           ex=ex_of(un["bni"], tin),
+                                                           tag="dgrad:conv1x1_%dx%d" % (un["cin"], c), groups=G))
                 D = bn_apply(tin, [(g1, un["bn1"]), (gi_, un["bni"])], None, cnt)
             else:
                 D = bn_apply(tin, [(g1, un["bn1"])], D, cnt)
