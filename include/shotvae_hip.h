@@ -151,6 +151,13 @@ int sv_bn_running_update_ex(const int32_t* table, const float* counts, int nbn, 
 /* eval-mode affine from running statistics (main_shot_vae.py:409-510 path)                         */
 int sv_bn_eval_affine(int C, const float* gamma, const float* beta, const float* running_mean,
                       const float* running_var, float eps, float* scale, float* shift, void* stream);
+/* BatchNorm-apply + LeakyReLU / ReLU as a pass of its own: out = act(x * scale[c] + shift[c]), x / out [groups][M][C]
+ * (contiguous channels, C % 8 == 0), scale / shift [groups][C].  The conv-like kernels fuse this into their load prologue;
+ * for weight-heavy layers (the first ConvTranspose layers of the decoder: a few MB of activations against MBs of weights)
+ * the prologue is re-applied once per output-channel tile and bounds the GEMM (VALU), so the step materialises it once and
+ * the GEMM runs prologue-free.                                                                                        */
+int sv_bn_act(int dtype, const void* x, const float* scale, const float* shift, float slope, int64_t M, int C, void* out,
+              int groups, void* stream);
 /* BatchNorm backward, second phase: dx = sum_br gamma*rstd*(g - mean(g) - xhat*mean(g*xhat)) (+res)
  * for one or two BN branches that share the input x; dgamma/dbeta accumulate (+=).  groups (0 = 1): G instances,
  * M = rows of ONE group; x / g / residual / dx [G][M][ld], mean / rstd [G][C], bsums [G][R][2C].               */

@@ -73,6 +73,7 @@ _PROTOS = {
     "sv_colsum": [I, P, I64, I, I, P, P],
     "sv_bn_finalize": [P, I, I, F, P, P, F, F, P, P, P, P, P, P, I, P],
     "sv_bn_eval_affine": [I, P, P, P, P, F, P, P, P],
+    "sv_bn_act": [I, P, P, P, F, I64, I, P, I, P],
     "sv_bn_running_update": [P, P, I, P, P, F, F, I, I, P],
     "sv_bn_running_update_ex": [P, P, I, P, P, F, F, I, I, C.POINTER(C.c_int32), P],
     "sv_bn_bwd_apply": [I, I64, I, I, P, P, P, F, C.POINTER(SvBnBranch), I, P, P, I, P],

@@ -263,6 +263,28 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bnb_params_g PG
     }
 }
 
+// out = act(x * scale[c] + shift[c]) (BatchNorm-apply + LeakyReLU / ReLU as a pass of its own): for the weight-heavy decoder
+// layers the consumer GEMM re-applied this prologue once per output-channel tile and was VALU-bound by it
+// (9 VALU instructions per MFMA); materialised once, the GEMM takes the prologue-free LDS-DMA loader.
+template <typename T>
+__global__ __launch_bounds__(256) void bn_act_kernel(const T* x, const float* scale, const float* shift, float slope, int64_t M,
+                                                     int C, T* out) {
+    typedef typename V8<T>::type V;
+    const int grp = blockIdx.y;
+    x += (int64_t)grp * M * C;
+    out += (int64_t)grp * M * C;
+    scale += (int64_t)grp * C;
+    shift += (int64_t)grp * C;
+    const int64_t nv = M * C / 8;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nv; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)((i * 8) % C);
+        const V v = *reinterpret_cast<const V*>(x + i * 8);
+        const f32x4 s0 = *reinterpret_cast<const f32x4*>(scale + c), s1 = *reinterpret_cast<const f32x4*>(scale + c + 4);
+        const f32x4 t0 = *reinterpret_cast<const f32x4*>(shift + c), t1 = *reinterpret_cast<const f32x4*>(shift + c + 4);
+        *reinterpret_cast<V*>(out + i * 8) = bn_act8(v, s0, s1, t0, t1, slope);
+    }
+}
+
 template <typename T>
 __global__ void colsum_kernel(const T* y, int64_t M, int N, int ld, float* out) {
     // thread (n, slice): blockDim = (N<=64 ? N : 64, 256/that)
@@ -1531,6 +1553,18 @@ int sv_bn_bwd_apply(int dtype, int64_t M, int C, int ld, const void* x, const fl
         DISPATCH_T(dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<T, false>), dim3(grid, groups), dim3(256), lds, (hipStream_t)stream, bnb_expand(p, groups, (int)sizeof(T))));
     }
     return sv_check_launch("sv_bn_bwd_apply");
+}
+
+int sv_bn_act(int dtype, const void* x, const float* scale, const float* shift, float slope, int64_t M, int C, void* out,
+              int groups, void* stream) {
+    SvProfScope prof_scope(stream);
+    SV_REQUIRE(x && scale && shift && out && M > 0 && C > 0, SV_E_ARG, "sv_bn_act: bad argument");
+    SV_REQUIRE(C % 8 == 0, SV_E_SHAPE, "sv_bn_act: C=%d must be a multiple of 8", C);
+    SV_REQUIRE(slope >= 0.f && slope <= 1.f, SV_E_ARG, "sv_bn_act: activation slope %g outside [0, 1]", (double)slope);
+    groups = sv_ngroups(groups);
+    DISPATCH_T(dtype, hipLaunchKernelGGL((bn_act_kernel<T>), dim3(nblocks(M * C / 8, 256, 1024), groups), dim3(256), 0, (hipStream_t)stream,
+                                         (const T*)x, scale, shift, slope, M, C, (T*)out));
+    return sv_check_launch("sv_bn_act");
 }
 
 int sv_colsum(int dtype, const void* y, int64_t M, int N, int ld, float* out, void* stream) {

@@ -459,6 +459,7 @@ class Engine:
         return ws
 
     wgrad_side_stream = True      # weight gradients on a side stream (they are off the backward's critical path)
+    materialize_decoder_act = True   # BatchNorm + ReLU of the first decoder layers' inputs as a pass of its own (see forward)
 
     def _side(self):
         """side stream paired with the current stream"""
@@ -689,12 +690,22 @@ class Engine:
         x = latent.view(Bt, 1, 1, p.Lpad)
         pro = None
         f.dpro = []
+        f.ha = {}
         for i, cv in enumerate(p.dec_convs):
             ho = cv.Hout
             gl = G if i < 5 else Gd        # the last ConvTranspose (no BatchNorm behind it): only where rec is needed
             out = torch.empty(gl * B, ho, ho, cv.N, dtype=T, device=dev)
-            self._igemm(cv.geom_fwd(B), x, pk + es * cv.fwd_off, out, pro=pro,
-                        stats=sptr("h%d" % i) if i < 5 else None, tag="fwd:dec%d" % i, groups=gl)
+            if pro is not None and self.materialize_decoder_act and cv.Hin <= 4:
+                # weight-heavy layers (1x1 ... 4x4 maps, 1024 ... 256 channels): BatchNorm + ReLU once, as a pass over a few
+                # MB, and a prologue-free GEMM (the LDS-DMA loader) -- fused, the transform was redone per channel tile
+                xa = torch.empty_like(x)
+                L.call("sv_bn_act", self.code, _vp(x.data_ptr()), _vp(pro[0]), _vp(pro[1]), pro[2], B * cv.Hin * cv.Hin, cv.Cin,
+                       _vp(xa.data_ptr()), G, st)
+                f.ha[i] = xa
+                self._igemm(cv.geom_fwd(B), xa, pk + es * cv.fwd_off, out, stats=sptr("h%d" % i), tag="fwd:dec%d" % i, groups=gl)
+            else:
+                self._igemm(cv.geom_fwd(B), x, pk + es * cv.fwd_off, out, pro=pro,
+                            stats=sptr("h%d" % i) if i < 5 else None, tag="fwd:dec%d" % i, groups=gl)
             f.h.append(out)
             if i < 5:
                 pro = finalize(p.dec_bns[i], "h%d" % i, B * ho * ho)
@@ -845,7 +856,9 @@ class Engine:
                 cv, b = p.dec_convs[i], p.dec_bns[i - 1]
                 hin = f.h[i - 1][:Bd]                     # the groups are back to back: the first Gd are a prefix
                 g = torch.empty_like(hin)
-                self._wgrad_async(cv.geom_fwd(B), hin, f.dpro[i - 1], D, gbase + 4 * cv.master_off, tag="wgrad:dec%d" % i,
+                # (where the forward materialised BatchNorm + ReLU of this layer's input, the weight gradient reads that)
+                wx, wpro = (f.ha[i][:Bd], None) if i in f.ha else (hin, f.dpro[i - 1])
+                self._wgrad_async(cv.geom_fwd(B), wx, wpro, D, gbase + 4 * cv.master_off, tag="wgrad:dec%d" % i,
                                   groups=Gd, then=lambda: self._igemm(cv.geom_dgrad(B), D, pk + es * cv.dgrad_off, g,
                                                                       ex=ex_of(b, hin, Gd), tag="dgrad:dec%d" % i, groups=Gd))
                 D = bn_apply(hin, [(g, b)], None, hin.numel() // hin.shape[-1] // Gd, Gd)
