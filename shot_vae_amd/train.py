@@ -8,7 +8,7 @@ import torch
 from . import dp
 from .criterion import continuous_posterior_loss
 from .mixup import _lerp, device_permutation, label_smoothing, mixup_vae_data
-from .steploss import TERMS, shot_losses
+from .steploss import TERMS, shot_loss_step
 
 
 def alpha_schedule(epoch, max_epoch, alpha_max):
@@ -229,7 +229,10 @@ def train_step_grouped(model, elbo_criterion, cls_criterion, optimizer, image_l,
         sm_img = _lerp(image_l, perm_l, lam_l, False)                        # mixup.py:36
         mx_img = _lerp(image_u, perm_u, lam_u, False)                        # mixup.py:22
         sm_label = label_l[perm_l]
-    rec, mu, ls, la = model.forward_groups(
+    # forward, loss stage and backward are driven from THIS thread, without an autograd graph: the step's structure is
+    # fixed ((loss_sup + loss_unsup).backward() = upstream gradients 1), and the autograd engine's worker-thread hand-over
+    # left the GPU idle between the loss kernels and the network's backward
+    rec, mu, ls, la, fctx = model.forward_groups_direct(
         [image_l, image_u, sm_img, mx_img],
         [dict(disc_label=label_l), dict(),
          dict(mixup=True, disc_label=label_l, disc_pseudo_label=sm_label, mixup_lam=lam_l), dict()],
@@ -238,13 +241,15 @@ def train_step_grouped(model, elbo_criterion, cls_criterion, optimizer, image_l,
     mu1, mu3, mu2, mu4 = mu.split(B)
     ls1, ls3, ls2, ls4 = ls.split(B)
     la1, la3, la2, la4 = la.split(B)
-    # the loss stage as ONE autograd node (steploss.py): 9 launches forward, 7 backward, no tensor algebra in between
     kl_inference = inference_kl(la3, label_u) if label_u is not None else None            # :330-339 (monitor)
-    loss_sup, loss_unsup, terms = shot_losses(rec, mu, ls, la, image_l, image_u, label_l, perm_l, perm_u, lam_l, lam_u, sch,
-                                              bce=elbo_criterion.bce_reconstruction, x_sigma=elbo_criterion.x_sigma)
+    # the loss stage (steploss.py): 9 launches forward, 6 backward, no tensor algebra in between        :289-323, :340-363
+    terms, d_rec, d_mu, d_ls, d_la = shot_loss_step(rec, mu, ls, la, image_l, image_u, label_l, perm_l, perm_u, lam_l, lam_u,
+                                                    sch, bce=elbo_criterion.bce_reconstruction,
+                                                    x_sigma=elbo_criterion.x_sigma)
+    loss_sup, loss_unsup = terms[10], terms[11]
     if optimizer is not None and _bucketed(model, distributed) is not None:
         _bucketed(model, distributed).arm()                                  # the step's only backward: decoder bucket overlaps it
-    (loss_sup + loss_unsup).backward()                                       # :324 + :364
+    model.backward_direct(fctx, d_rec, d_mu, d_ls, d_la)                     # :324 + :364
     if optimizer is not None:
         apply_update(model, optimizer, distributed)
     if not return_outputs:

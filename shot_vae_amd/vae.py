@@ -253,6 +253,23 @@ class VariationalAutoEncoder(nn.Module):
                 u = torch.cat([uu if uu is not None else z for _, uu in pairs])
         return self._run(torch.cat([im.float() for im in images]), gs, eps, u, rec_groups, update_order)
 
+    def forward_groups_direct(self, images, specs, eps, u, rec_groups=None, update_order=None):
+        """forward_groups for a caller that runs the backward itself (no autograd node): returns (rec, mu, ls, la, ctx); pass
+        ctx and the gradients w.r.t. the four outputs to backward_direct()."""
+        gs = [self._group_spec(sp.get("mixup", False), sp.get("disc_label"), sp.get("disc_pseudo_label"),
+                               sp.get("mixup_lam")) for sp in specs]
+        with torch.no_grad():
+            return self._engine.forward(torch.cat([im.float() for im in images]), gs, eps, u, self._temperature,
+                                        self.training, keep=True, rec_groups=rec_groups, update_order=update_order)
+
+    def backward_direct(self, ctx, d_rec, d_mu, d_ls, d_la):
+        """accumulates the parameter gradients of a forward_groups_direct() call into the flat gradient buffer (p.grad)"""
+        if not ctx.training:
+            raise NotImplementedError("backward through an eval-mode forward (BatchNorm with running statistics) is not implemented")
+        self._attach_grads()
+        with torch.no_grad():
+            self._engine.backward(ctx, d_rec, d_mu, d_ls, d_la)
+
     def _run(self, image, groups, eps, u, rec_groups=None, update_order=None):
         eng = self._engine
         dev = image.device

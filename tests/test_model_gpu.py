@@ -800,6 +800,17 @@ def test_fused_loss_node_equals_modular_criteria(bce, x_sigma, dev_lam):
     assert abs(float(ls_) - float(sup)) <= 2e-6 * abs(float(sup))
     for k in base:
         assert T.rel_err(a[k].grad.cpu().numpy(), b[k].grad.cpu().numpy()) < 2e-6, k
+    # the autograd-free form the grouped step uses (upstream gradients 1 + 1) = the node under (loss_sup + loss_unsup).backward()
+    from shot_vae_amd.steploss import shot_loss_step
+    c = leaves()
+    s1, s2, t1 = shot_losses(c["rec"], c["mu"], c["ls"], c["la"], il, iu, label, perm_l, perm_u, ll, lu, sch, bce=bce, x_sigma=x_sigma)
+    (s1 + s2).backward()
+    t2, d_rec, d_mu, d_ls, d_la = shot_loss_step(base["rec"], base["mu"], base["ls"], base["la"], il, iu, label, perm_l, perm_u, ll,
+                                                 lu, sch, bce=bce, x_sigma=x_sigma)
+    torch.cuda.synchronize()
+    assert torch.equal(t1, t2)
+    for k, d in (("rec", d_rec), ("mu", d_mu), ("ls", d_ls), ("la", d_la)):
+        assert torch.equal(c[k].grad, d), k
 
 
 def test_flat_adam_equals_torch_adam_and_shares_its_checkpoints():
