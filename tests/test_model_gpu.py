@@ -518,6 +518,9 @@ def test_graphed_step_equals_eager_step(schedule):
         return f
 
     torch.randn, torch.rand = fixed("n", real_randn), fixed("u", real_rand)
+    from shot_vae_amd import _lib as L_
+    det = L_.options(deterministic=1)        # fixed summation order: the two issue modes must then agree to rounding of
+    det.__enter__()                          # nothing -- B = 8 through BatchNorm amplifies any float-atomic reordering
     try:
         sch = O.schedule(10)
         elbo, cls = S.VAECriterion(discrete_dim=K).cuda(), S.ClsCriterion()
@@ -541,10 +544,11 @@ def test_graphed_step_equals_eager_step(schedule):
         sa, sb = m1.state_dict(), m2.state_dict()
         for k in sa:
             if sa[k].dtype.is_floating_point:
-                assert T.rel_err(sb[k].cpu().numpy(), sa[k].cpu().numpy()) < 5e-4, k
+                assert T.rel_err(sb[k].cpu().numpy(), sa[k].cpu().numpy()) < 2e-6, k
             else:
                 assert int(sa[k]) == int(sb[k]) == 4 * (warm + steps), k
     finally:
+        det.__exit__(None, None, None)
         torch.randn, torch.rand = real_randn, real_rand
 
 
