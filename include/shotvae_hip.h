@@ -85,6 +85,11 @@ typedef struct {
                                    overriding SV_OPT_PERSISTENT_BLOCKS -- the paired backward gives a layer's weight and
                                    data gradient half the chip each without touching process-wide state; 0 = the option */
     int32_t flags;              /* reserved: written by the library (bit 0 = deterministic accumulation of this launch) */
+    int32_t sparse_out;         /* 1: output positions of phases WITHOUT taps are left unwritten (and their epilogue operands
+                                   unread) instead of zero-filled -- the data gradient of a stride-2 1x1 convolution is zero at
+                                   three of four positions; its only consumer, sv_bn_bwd_apply with sv_bn_branch::sparse = 1,
+                                   does not read them.  0: every output position is written.                              */
+    int32_t reserved0;
 } sv_igemm_args;
 
 int sv_igemm(const sv_geom* g, int dtype, const sv_igemm_args* a, void* stream);
@@ -164,6 +169,9 @@ int sv_bn_act(int dtype, const void* x, const float* scale, const float* shift, 
 typedef struct {
     const void* g; const float* bsums; const float* gamma; float* dgamma; float* dbeta;
     int32_t replicas;           /* bsums is [replicas][2C]                                           */
+    int32_t sparse;             /* wlog + 1 > 0: g is the data gradient of a STRIDE-2 layer written with sv_igemm_args::
+                                   sparse_out -- defined at the even (row, column) positions of the 2^wlog-wide, 2^wlog-high
+                                   maps only and taken as zero elsewhere (not read there); 0: dense                    */
 } sv_bn_branch;
 int sv_bn_bwd_apply(int dtype, int64_t M, int C, int ld, const void* x, const float* mean,
                     const float* rstd, float count, const sv_bn_branch* br, int nbranch,

@@ -35,7 +35,7 @@ class SvIgemmArgs(C.Structure):
                 ("w", C.c_void_p), ("bias", C.c_void_p), ("residual", C.c_void_p), ("out", C.c_void_p),
                 ("stats", C.c_void_p), ("ex", C.c_void_p), ("ex_scale", C.c_void_p), ("ex_shift", C.c_void_p),
                 ("ex_mean", C.c_void_p), ("ex_rstd", C.c_void_p), ("ex_slope", C.c_float), ("bsums", C.c_void_p),
-                ("replicas", C.c_int32), ("groups", C.c_int32), ("block_budget", C.c_int32), ("flags", C.c_int32)]
+                ("replicas", C.c_int32), ("groups", C.c_int32), ("block_budget", C.c_int32), ("flags", C.c_int32), ("sparse_out", C.c_int32), ("reserved0", C.c_int32)]
 
 
 class SvWgradArgs(C.Structure):
@@ -61,7 +61,7 @@ class SvSmoothSchedule(C.Structure):
 
 class SvBnBranch(C.Structure):
     _fields_ = [("g", C.c_void_p), ("bsums", C.c_void_p), ("gamma", C.c_void_p), ("dgamma", C.c_void_p),
-                ("dbeta", C.c_void_p), ("replicas", C.c_int32)]
+                ("dbeta", C.c_void_p), ("replicas", C.c_int32), ("sparse", C.c_int32)]
 
 
 P, I, I64, F = C.c_void_p, C.c_int, C.c_int64, C.c_float

@@ -285,6 +285,7 @@ __global__ __launch_bounds__(256) void halo_kernel(const sv_geom g, const sv_ige
 #pragma unroll
     for (int ph = 0; ph < NPH; ++ph) {
         if (ph >= g.nphase) break;
+        if (a.sparse_out && c.nks[ph] == 0) continue;       // tapless phase: exactly zero, left unwritten (sv_bn_branch::sparse)
         const sv_phase& P = g.phase[ph];
 #pragma unroll
         for (int ms = 0; ms < 2; ++ms) {
@@ -535,7 +536,7 @@ __global__ __launch_bounds__(256, OCC) void halop_kernel(const sv_geom g, const 
             for (int ph = 0; ph < NPH; ++ph) {
                 const sv_phase& P = g.phase[ph < g.nphase ? ph : 0];
                 obv[ph][ms] = ((int64_t)(b * g.Hout + qy * g.osy + P.ooy) * g.Wout + pcol[ms] * g.osx + P.oox) * g.ldo;
-                if ((R || EX) && ph < g.nphase) {
+                if ((R || EX) && ph < g.nphase && !(a.sparse_out && c.nks[ph] == 0)) {
                     const T* __restrict__ E = R ? R : EX;
 #pragma unroll
                     for (int i = 0; i < NT; ++i)
@@ -563,6 +564,7 @@ __global__ __launch_bounds__(256, OCC) void halop_kernel(const sv_geom g, const 
 #pragma unroll
         for (int ph = 0; ph < NPH; ++ph) {
             if (ph >= g.nphase) break;
+            if (a.sparse_out && c.nks[ph] == 0) continue;   // tapless phase: left unwritten
             const sv_phase& P = g.phase[ph];
 #pragma unroll
             for (int ms = 0; ms < 2; ++ms) {

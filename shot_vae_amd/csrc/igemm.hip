@@ -79,6 +79,7 @@ __global__ __launch_bounds__(256, MS == 4 ? 2 : 1) void igemm_kernel(const sv_ge
 
     // A phase without taps (three of the four output parities of a stride-2 1x1 data gradient) is exactly zero, and so
     // are its contributions to the BatchNorm sums of either epilogue: plain 16-byte zero stores, no reads, no atomics.
+    if (ntap == 0 && a.sparse_out) return;          // (the consumer does not read these positions: sv_bn_branch::sparse)
     if (ntap == 0 && !a.bias && !a.residual && g.ldo % 8 == 0) {
         constexpr int VR = BN / 8;
         V z;
@@ -368,6 +369,7 @@ __global__ __launch_bounds__(256, 2) void igemm_dma_kernel(const sv_geom g, cons
     const T* __restrict__ X = reinterpret_cast<const T*>(a.x);
     const T* __restrict__ W = reinterpret_cast<const T*>(a.w) + P.w_off;
 
+    if (ntap == 0 && a.sparse_out) return;
     if (ntap == 0 && !a.bias && !a.residual && g.ldo % 8 == 0) {          // (see igemm_kernel)
         constexpr int VR = BN / 8;
         V z;
@@ -592,6 +594,7 @@ extern "C" int sv_igemm(const sv_geom* g, int dtype, const sv_igemm_args* a_in, 
     SV_REQUIRE(!(a->stats || a->ex) || (a->replicas >= 1 && (a->replicas & (a->replicas - 1)) == 0), SV_E_ARG,
                "sv_igemm: replicas=%d must be a power of two", a->replicas);
     SV_REQUIRE(a->block_budget == 0 || a->block_budget >= 8, SV_E_ARG, "sv_igemm: block_budget=%d", a->block_budget);
+    SV_REQUIRE(!a->sparse_out || (!a->bias && !a->residual), SV_E_ARG, "sv_igemm: sparse_out with a bias / residual (the skipped positions would not be zero)");
     hipStream_t s = (hipStream_t)stream;
     SvBudgetScope budget_scope(a->block_budget);
     {   // stride-1 3x3 convolutions take the LDS-halo kernels (conv3x3*.hip) unless switched off (tests: generic vs special)

@@ -227,8 +227,18 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bnb_params_g PG
         // streamed once: non-temporal loads (5.0 -> 5.16 TB/s; a non-temporal store of dx costs its consumer as much)
         const V xv = __builtin_nontemporal_load(reinterpret_cast<const V*>(X + off));
         V gv[2];
-        gv[0] = __builtin_nontemporal_load(reinterpret_cast<const V*>(reinterpret_cast<const T*>(p.br[0].g) + off));
-        if (p.nbranch > 1) gv[1] = __builtin_nontemporal_load(reinterpret_cast<const V*>(reinterpret_cast<const T*>(p.br[1].g) + off));
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            if (k >= p.nbranch) break;
+            // a sparse branch (stride-2 data gradient written with sv_igemm_args::sparse_out) exists at even (row, column) only
+            const int sp = p.br[k].sparse;
+            if (sp > 0 && ((((int)(m >> (sp - 1))) | (int)m) & 1)) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) gv[k][j] = (T)0.f;
+            } else {
+                gv[k] = __builtin_nontemporal_load(reinterpret_cast<const V*>(reinterpret_cast<const T*>(p.br[k].g) + off));
+            }
+        }
         V rv;
         if (R) rv = __builtin_nontemporal_load(reinterpret_cast<const V*>(R + off));
         float o[8];
@@ -1521,6 +1531,8 @@ int sv_bn_bwd_apply(int dtype, int64_t M, int C, int ld, const void* x, const fl
         p.br[k] = br[k];
         SV_REQUIRE(br[k].g && br[k].bsums && br[k].gamma && br[k].replicas >= 1, SV_E_ARG,
                    "sv_bn_bwd_apply: branch %d incomplete", k);
+        SV_REQUIRE(br[k].sparse >= 0 && br[k].sparse <= 16 && (br[k].sparse == 0 || M % ((int64_t)1 << (2 * (br[k].sparse - 1))) == 0),
+                   SV_E_ARG, "sv_bn_bwd_apply: branch %d sparse=%d does not match M", k, br[k].sparse);
     }
     groups = sv_ngroups(groups);
     SV_REQUIRE(groups <= SV_MAX_GROUPS, SV_E_ARG, "sv_bn_bwd_apply: groups=%d (at most %d)", groups, SV_MAX_GROUPS);

@@ -410,10 +410,11 @@ class Engine:
         self._pack_key = key
 
     def _igemm(self, g, x, w_ptr, out, pro=None, bias=None, residual=None, stats=None, ex=None, tag=None, groups=1,
-               budget=0):
+               budget=0, sparse_out=False):
         a = L.SvIgemmArgs()
         a.groups = groups
         a.block_budget = budget
+        a.sparse_out = int(bool(sparse_out))
         a.x, a.w, a.out = x.data_ptr(), w_ptr, out.data_ptr()
         if pro is not None:
             a.pro_scale, a.pro_shift, a.pro_slope = pro[0], pro[1], pro[2]
@@ -459,6 +460,7 @@ class Engine:
         return ws
 
     wgrad_side_stream = True      # weight gradients on a side stream (they are off the backward's critical path)
+    sparse_shortcut_grad = True      # stride-2 1x1 shortcuts: data gradient written / read at the even positions only
     materialize_decoder_act = True   # BatchNorm + ReLU of the first decoder layers' inputs as a pass of its own (see forward)
 
     def _side(self):
@@ -818,12 +820,14 @@ class Engine:
                 return (raw, sc, sh, mn, rs, b.slope, alloc, None)
             return (raw, sc, sh, mn, rs, b.slope, bs_off[b.index], bs_rep[b.index])
 
-        def bn_apply(raw, branches, residual, count, Gx=None):
-            """branches: [(g tensor, BNSpec)] sharing `raw`; returns dL/d(raw) (+ residual).  count = rows of ONE group."""
+        def bn_apply(raw, branches, residual, count, Gx=None, sparse=()):
+            """branches: [(g tensor, BNSpec)] sharing `raw`; returns dL/d(raw) (+ residual).  count = rows of ONE group.
+            sparse: indices of branches whose g was written with sparse_out (defined at even positions only)."""
             Gx = Gx or G
             arr = (L.SvBnBranch * len(branches))()
             for k, (g, b) in enumerate(branches):
                 arr[k].g = g.data_ptr()
+                arr[k].sparse = (int(raw.shape[2]).bit_length()) if k in sparse else 0     # log2(W) + 1
                 arr[k].bsums = bs_off[b.index]
                 arr[k].gamma = pbase + 4 * b.gamma_off
                 arr[k].dgamma = gbase + 4 * b.gamma_off
@@ -923,12 +927,14 @@ class Engine:
             cnt = tin.numel() // tin.shape[-1] // G
             if "convi" in un:
                 gi_ = torch.empty_like(tin)
+                # a stride-2 shortcut's data gradient is zero at three of four positions: those are neither written nor read
+                sp = un["stride"] == 2 and self.sparse_shortcut_grad
                 self._wgrad_async(un["convi"].geom_fwd(B), tin, proi, D, gbase + 4 * un["convi"].master_off,
                                   tag="wgrad:conv1x1_%dx%d" % (un["cin"], c), groups=G,
                                   then=lambda: self._igemm(un["convi"].geom_dgrad(B), D, pk + es * un["convi"].dgrad_off, gi_,
-                                                           ex=ex_of(un["bni"], tin),
+                                                           ex=ex_of(un["bni"], tin), sparse_out=sp,
                                                            tag="dgrad:conv1x1_%dx%d" % (un["cin"], c), groups=G))
-                D = bn_apply(tin, [(g1, un["bn1"]), (gi_, un["bni"])], None, cnt)
+                D = bn_apply(tin, [(g1, un["bn1"]), (gi_, un["bni"])], None, cnt, sparse=(1,) if sp else ())
             else:
                 D = bn_apply(tin, [(g1, un["bn1"])], D, cnt)
         # ---- stem: weight + bias gradients (the image needs none) ---------------------------------

@@ -1005,3 +1005,56 @@ def test_rank_permutation():
         torch.cuda.synchronize()
         ref = torch.argsort(keys, dim=1, stable=True)
         assert torch.equal(perm, ref), (n, nb)
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("case", [(6, 32, 64, 32), (4, 64, 128, 16), (3, 160, 320, 16)])
+def test_sparse_stride2_shortcut_gradient(dt, case):
+    """Data gradient of a stride-2 1x1 shortcut with sv_igemm_args::sparse_out (the three tapless output parities are left
+    unwritten) + sv_bn_bwd_apply with sv_bn_branch::sparse (they are not read): the same dx, BatchNorm sums and dgamma /
+    dbeta as the dense pair, with the skipped positions of the gradient tensor poisoned."""
+    B, Cin, N, H = case
+    code, tdt, tol = DT[dt]
+    d = dev()
+    torch.manual_seed(13)
+    Ho = H // 2
+    x = torch.randn(B, H, H, Cin, device=d).to(tdt)                 # the shortcut's input (raw, pre-BatchNorm)
+    dy = torch.randn(B, Ho, Ho, N, device=d).to(tdt)
+    g1 = torch.randn(B, H, H, Cin, device=d).to(tdt)                # the other branch's gradient (dense)
+    w = bq(torch.randn(N, 1, Cin) / Cin ** 0.5, dt)
+    gd = G.convT_like(B, Ho, Ho, N, Cin, 1, 2, 0)
+    wd = repack(w, gd, True, dt)
+    sc, sh = torch.rand(Cin, device=d) + 0.5, torch.randn(Cin, device=d) * 0.3
+    mean, rstd = torch.randn(Cin, device=d) * 0.1, torch.rand(Cin, device=d) + 0.5
+    gamma = torch.rand(Cin, device=d) + 0.5
+    R = 4
+    res = []
+    with L.options(wide_min_blocks=1):
+        for sparse in (0, 1):
+            gi = torch.full((B, H, H, Cin), float("nan"), dtype=tdt, device=d)
+            bs = torch.zeros(R, 2 * Cin, device=d)
+            a = L.SvIgemmArgs()
+            a.x, a.w, a.out, a.replicas, a.sparse_out = dy.data_ptr(), wd.data_ptr(), gi.data_ptr(), R, sparse
+            a.ex, a.ex_scale, a.ex_shift, a.ex_mean, a.ex_rstd = (t.data_ptr() for t in (x, sc, sh, mean, rstd))
+            a.ex_slope, a.bsums = 0.01, bs.data_ptr()
+            L.call("sv_igemm", C.byref(gd), code, C.byref(a), st())
+            bs1 = torch.zeros(R, 2 * Cin, device=d)
+            bs1[0, :Cin] = g1.float().sum((0, 1, 2))
+            bs1[0, Cin:] = (g1.float() * ((x.float() - mean) * rstd)).sum((0, 1, 2))
+            dgam, dbet = torch.zeros(2, Cin, device=d), torch.zeros(2, Cin, device=d)
+            br = (L.SvBnBranch * 2)()
+            for k, (gt, bt) in enumerate(((g1, bs1), (gi, bs))):
+                br[k].g, br[k].bsums, br[k].gamma = gt.data_ptr(), bt.data_ptr(), gamma.data_ptr()
+                br[k].dgamma, br[k].dbeta, br[k].replicas = dgam[k].data_ptr(), dbet[k].data_ptr(), R
+            br[1].sparse = (H.bit_length()) if sparse else 0
+            dx = torch.empty(B, H, H, Cin, dtype=tdt, device=d)
+            L.call("sv_bn_bwd_apply", code, B * H * H, Cin, Cin, p(x), p(mean), p(rstd), float(B * H * H), br, 2, None, p(dx), 1, st())
+            torch.cuda.synchronize()
+            res.append((gi, bs.sum(0), dx, dgam.clone(), dbet.clone()))
+    (gi0, b0, dx0, dg0, db0), (gi1, b1, dx1, dg1, db1) = res
+    assert bool(torch.isfinite(gi0.float()).all())                                  # dense: every position written
+    even = gi1[:, ::2, ::2]
+    assert torch.equal(even, gi0[:, ::2, ::2]) and bool(torch.isnan(gi1[:, 1::2].float()).all())   # sparse: odd rows untouched
+    assert float(gi0[:, 1::2].float().abs().max()) == 0.0 and float(gi0[:, :, 1::2].float().abs().max()) == 0.0
+    assert bool(torch.isfinite(dx1.float()).all()) and torch.equal(dx0, dx1)
+    assert rel(b1, b0) < 1e-5 and rel(dg1, dg0) < 1e-5 and rel(db1, db0) < 1e-5

@@ -2,7 +2,7 @@
 # Regenerates the artifacts of profiles/ on the GPU box into gpurun_out/profiles_new/ (copy what should be judged into
 # profiles/ afterwards).  usage: bash tools/refresh_profiles.sh rNN [pmc]
 R="$(cd "$(dirname "$0")/.." && pwd)"
-TAG=${1:-r02}
+TAG=${1:-r03}
 PMC=$2
 OUT="$R/gpurun_out/profiles_new"
 mkdir -p "$OUT"
@@ -25,5 +25,12 @@ rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_c -o c -- pyth
 F=$(find /tmp/prof_c -name "*kernel_stats.csv" | head -1)
 cp "$F" "$OUT/${TAG}_cfg4_wrn28_10_kernel_stats.csv"
 python3 "$R/tools/kernel_stats_digest.py" "$F" 8 "rocprofv3 --kernel-trace --stats -- python3 bench.py --net wideresnet-28-10 --batch 256 --classes 100 --steps 6 --warmup 2 --no-cpu-baseline --no-roofline --wgrad-side 0   (BASELINE config 4; grouped schedule, eager, one stream)" > "$OUT/${TAG}_cfg4_wrn28_10_kernel_stats.txt"
-if [ "$PMC" = "pmc" ]; then python3 "$R/tools/pmc_traffic.py" "$OUT/${TAG}_pmc_traffic.json" > /tmp/pmc.log 2>&1 || tail -5 /tmp/pmc.log; fi
+# round 3: the odd layers of config 2 one by one, the step's timeline (idle gaps), config 5
+bash "$R/tools/odd_layers.sh" > "$OUT/${TAG}_layer_bench_odd_cfg2.txt" 2>&1
+(cd "$R" && python3 tools/step_timeline.py) > "$OUT/${TAG}_step_timeline.txt" 2>&1
+python3 "$R/bench.py" --workload svhn --batch 1024 --steps 30 --warmup 5 2>/dev/null | tail -1 > "$OUT/${TAG}_svhn_bench.json"
+if [ "$PMC" = "pmc" ]; then
+  python3 "$R/tools/pmc_traffic.py" "$OUT/${TAG}_pmc_traffic.json" > /tmp/pmc.log 2>&1 || tail -5 /tmp/pmc.log
+  (cd "$R" && bash tools/pmc_odd.sh) > "$OUT/${TAG}_pmc_odd.txt" 2>&1
+fi
 ls -la "$OUT"
