@@ -61,6 +61,9 @@ def parse():
                     help="grouped (default): the four forwards of the step as one batched launch sequence; two-stream: the "
                          "labelled / unlabelled branches on two HIP streams; sequential: the reference's order, one stream")
     ap.add_argument("--wgrad-side", type=int, default=1, help="weight gradients on a side stream (off the critical path)")
+    ap.add_argument("--pair-blocks", type=int, default=-1,
+                    help="Engine.pair_blocks: block budget of each kernel of a paired weight / data gradient launch (-1 = the "
+                         "engine's default, 256; 0 = both with the full budget)")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher check without a GPU: the ranks rendezvous over gloo, agree on a max-reduced time and "
                          "rank 0 prints a JSON stub (tests/test_bench_launch_cpu.py)")
@@ -408,6 +411,8 @@ def main():
 
     from shot_vae_amd.train import GraphedTrainStep, train_step_grouped, train_step_overlapped
     model._engine.wgrad_side_stream = bool(a.wgrad_side)
+    if a.pair_blocks >= 0:
+        model._engine.pair_blocks = a.pair_blocks
     dmode = False if world == 1 else ("bucketed" if a.allreduce == "bucketed" else True)
 
     mode = a.graph if a.graph is not None else (-1 if a.scaling == "strong" else 0)

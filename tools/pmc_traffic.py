@@ -79,7 +79,8 @@ STEP_KERNELS = {"sv_bn_bwd_apply": "bn_bwd_apply_kernel"}
 def step_pass(counter, outdir):
     d = os.path.join(outdir, "step_" + counter)
     cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--",
-           "python3", os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-roofline"]
+           "python3", os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-roofline",
+           "--no-extras"]
     r = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT)
     if r.returncode != 0:
         raise RuntimeError("rocprofv3 failed: " + r.stderr[-2000:])
@@ -108,7 +109,8 @@ def main():
         w, _ = write[tag]
         res[tag] = {"FETCH_SIZE_KiB": f, "WRITE_SIZE_KiB": w, "traffic_bytes": (2 * f + w) * 1024, "kernels": [STEP_KERNELS[tag]],
                     "shape": "every launch of the kernel in the BASELINE config-2 step (bench.py, grouped schedule)",
-                    "formula": "(2*FETCH_SIZE + WRITE_SIZE)*1024, per launch, mean of the %d launches of 3 steps" % n}
+                    "formula": "(2*FETCH_SIZE + WRITE_SIZE)*1024, per launch, mean of the %d launches of 3 steps (2 timed + 1 warm-up) of "
+                               "bench.py --no-extras" % n}
         print(tag, json.dumps(res[tag]), flush=True)
     if len(sys.argv) > 2 and sys.argv[2] == "step":
         json.dump(res, open(out, "w"), indent=1)
