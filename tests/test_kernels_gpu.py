@@ -1056,5 +1056,6 @@ def test_sparse_stride2_shortcut_gradient(dt, case):
     even = gi1[:, ::2, ::2]
     assert torch.equal(even, gi0[:, ::2, ::2]) and bool(torch.isnan(gi1[:, 1::2].float()).all())   # sparse: odd rows untouched
     assert float(gi0[:, 1::2].float().abs().max()) == 0.0 and float(gi0[:, :, 1::2].float().abs().max()) == 0.0
-    assert bool(torch.isfinite(dx1.float()).all()) and torch.equal(dx0, dx1)
+    # (the two runs accumulate the shortcut branch's sums with float atomics in their own order: equal to rounding)
+    assert bool(torch.isfinite(dx1.float()).all()) and rel(dx1, dx0) < (1e-5 if dt == "f32" else 1e-2)
     assert rel(b1, b0) < 1e-5 and rel(dg1, dg0) < 1e-5 and rel(db1, db0) < 1e-5
