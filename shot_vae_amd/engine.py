@@ -838,7 +838,9 @@ class Engine:
             dx = torch.empty_like(raw)
             cc = raw.shape[-1]
             # reads x and one g per branch (+ the residual), writes dx
-            self._cost("sv_bn_bwd_apply", raw.numel() * raw.element_size() * (2 + len(branches) + (residual is not None)))
+            # (a sparse branch is read at one position in four)
+            self._cost("sv_bn_bwd_apply", raw.numel() * raw.element_size() *
+                       (2 + len(branches) - 0.75 * len(sparse) + (residual is not None)))
             L.call("sv_bn_bwd_apply", self.code, raw.numel() // cc // Gx, cc, cc, _vp(raw.data_ptr()), _vp(mn), _vp(rs),
                    float(count), arr, len(branches), _vp(residual.data_ptr()) if residual is not None else None,
                    _vp(dx.data_ptr()), Gx, st)
