@@ -812,7 +812,7 @@ def test_fused_loss_node_equals_modular_criteria(bce, x_sigma, dev_lam):
     t2, d_rec, d_mu, d_ls, d_la = shot_loss_step(base["rec"], base["mu"], base["ls"], base["la"], il, iu, label, perm_l, perm_u, ll,
                                                  lu, sch, bce=bce, x_sigma=x_sigma)
     torch.cuda.synchronize()
-    assert torch.equal(t1, t2)
+    assert T.rel_err(t2.cpu().numpy(), t1.cpu().numpy()) < 1e-6        # (block sums meet through float atomics: last-bit order effects)
     for k, d in (("rec", d_rec), ("mu", d_mu), ("ls", d_ls), ("la", d_la)):
         assert torch.equal(c[k].grad, d), k
 
