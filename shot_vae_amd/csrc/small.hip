@@ -1538,7 +1538,23 @@ int sv_bn_bwd_apply(int dtype, int64_t M, int C, int ld, const void* x, const fl
     SV_REQUIRE(groups <= SV_MAX_GROUPS, SV_E_ARG, "sv_bn_bwd_apply: groups=%d (at most %d)", groups, SV_MAX_GROUPS);
     // every block first sums the accumulator replicas into its coefficients (a few us of latency): the groups of a batched
     // launch share the block budget, so that this prologue stays amortised over as many rows per block
-    const int grid = nblocks(M * (C / 8), 256, 2048 / groups > 256 ? 2048 / groups : 256);
+    // One resident wave of blocks over the whole (batched) launch: the register-coefficient variant holds 93 registers = 5 blocks
+    // of 256 threads per CU (the 2 048 blocks of round 2 were 1.6 waves: the second one ran 60 % full), the LDS-coefficient
+    // variant 8.  The occupancy is asked once per variant.
+    static int occ_reg = 0, occ_lds = 0;
+    if (!occ_reg) {
+        int o = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, bn_bwd_apply_kernel<bf16, true>, 256, 16 * 1024) != hipSuccess || o < 1) o = 5;
+        occ_reg = o;
+        o = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, bn_bwd_apply_kernel<bf16, false>, 256, 16 * 1024) != hipSuccess || o < 1) o = 8;
+        occ_lds = o;
+        (void)hipGetLastError();
+    }
+    const int cv_ = C / 8;
+    const bool reg_ = (256 % cv_ == 0 ? 256 : (cv_ <= 256 ? 256 / cv_ * cv_ : 0)) >= 192;
+    const int resident = 256 * (reg_ ? occ_reg : occ_lds);
+    const int grid = nblocks(M * (C / 8), 256, resident / groups > 64 ? resident / groups : 64);
     const size_t lds = ((size_t)(2 + 3 * nbranch) * C + (size_t)nbranch * 2 * 256) * sizeof(float);
     SV_REQUIRE(lds <= 64 * 1024, SV_E_SHAPE, "sv_bn_bwd_apply: C=%d too large", C);
     const int cv = C / 8;
