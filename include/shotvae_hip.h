@@ -263,6 +263,23 @@ int sv_shot_targets(const float* mu_l, const float* ls_l, const float* mu_u, con
 int sv_shot_compose(float* terms, const sv_shot_schedule* sch, float* coef, void* stream);
 int sv_shot_scale(const float* coef, const float* g_sup, const float* g_unsup, float* gvec, void* stream);
 
+/* The whole loss stage of one grouped step in ONE call (the nine forward and six backward launches above, issued back to back
+ * by the library: at ~5 us per kernel the stage is bound by the caller's per-launch host time otherwise).  Outputs of the four
+ * batched forwards in the group order (1)(3)(2)(4): rec [2B][n_per_img] (groups (1), (3) only), mu / ls [4B][D], la [4B][K].
+ * Upstream gradients 1 for both objectives (`(loss_supervised + loss_unsupervised).backward()`).
+ * terms [12] must be ZEROED by the caller; coef [10], tgt [4BD + 2BK] and the four gradient tensors are plain outputs.    */
+typedef struct {
+    const float* rec; const float* mu; const float* ls; const float* la;
+    const float* image_l; const float* image_u;
+    const int64_t* label_l; const int64_t* perm_l; const int64_t* perm_u;
+    float lam_l; const float* lam_l_dev; float lam_u; const float* lam_u_dev;
+    int32_t B, D, K, bce; int64_t n_per_img; float x_sigma;
+    sv_shot_schedule sch;
+    float* terms; float* coef; float* tgt;
+    float* d_rec; float* d_mu; float* d_ls; float* d_la;
+} sv_shot_loss_args;
+int sv_shot_loss_step(const sv_shot_loss_args* a, void* stream);
+
 /* ---- K18 optimal-match pairing (lib/utils/mixup.py:9-18,93-99): index[i] = argmin_{j!=rank0} ----
  * second-smallest entry of row i of the pairwise Gaussian-KL matrix.                               */
 int sv_optimal_match(const float* mu, const float* ls, int B, int D, int64_t* index, void* stream);

@@ -1828,6 +1828,45 @@ int sv_shot_scale(const float* coef, const float* g_sup, const float* g_unsup, f
     return sv_check_launch("sv_shot_scale");
 }
 
+int sv_shot_loss_step(const sv_shot_loss_args* a, void* stream) {
+    SV_REQUIRE(a && a->rec && a->mu && a->ls && a->la && a->image_l && a->image_u && a->label_l && a->perm_l && a->perm_u && a->terms &&
+               a->coef && a->tgt && a->d_rec && a->d_mu && a->d_ls && a->d_la && a->B > 0 && a->D > 0 && a->K > 0, SV_E_ARG,
+               "sv_shot_loss_step: bad argument");
+    const int B = a->B, D = a->D, K = a->K;
+    const int64_t n = a->n_per_img;
+    auto g = [&](const float* t, int grp, int64_t row) { return t + (int64_t)grp * B * row; };
+    auto gm = [&](float* t, int grp, int64_t row) { return t + (int64_t)grp * B * row; };
+    float* sm_mu = a->tgt;
+    float* sm_sigma = sm_mu + (int64_t)B * D;
+    float* mx_mu = sm_sigma + (int64_t)B * D;
+    float* mx_sigma = mx_mu + (int64_t)B * D;
+    float* lab_mix = mx_sigma + (int64_t)B * D;
+    float* mx_alpha = lab_mix + (int64_t)B * K;
+    int rc;
+#define SV_TRY(call) do { rc = (call); if (rc != SV_OK) return rc; } while (0)
+    // forward: ELBO terms of (1), (3); the targets of (2), (4); their posterior terms; the composition
+    SV_TRY(sv_elbo_fwd(a->image_l, g(a->rec, 0, n), n, g(a->mu, 0, D), g(a->ls, 0, D), g(a->la, 0, K), B, D, K, a->bce, a->x_sigma, a->terms, stream));
+    SV_TRY(sv_elbo_fwd(a->image_u, g(a->rec, 1, n), n, g(a->mu, 1, D), g(a->ls, 1, D), g(a->la, 1, K), B, D, K, a->bce, a->x_sigma, a->terms + 3, stream));
+    SV_TRY(sv_shot_targets(g(a->mu, 0, D), g(a->ls, 0, D), g(a->mu, 1, D), g(a->ls, 1, D), g(a->la, 1, K), a->label_l, a->perm_l, a->perm_u,
+                           a->lam_l, a->lam_l_dev, a->lam_u, a->lam_u_dev, B, D, K, sm_mu, sm_sigma, lab_mix, mx_mu, mx_sigma, mx_alpha, stream));
+    SV_TRY(sv_cls_fwd(g(a->la, 2, K), lab_mix, nullptr, B, K, a->terms + 6, stream));
+    SV_TRY(sv_post_fwd(g(a->mu, 2, D), g(a->ls, 2, D), sm_mu, sm_sigma, B, D, a->terms + 7, stream));
+    SV_TRY(sv_cls_fwd(g(a->la, 3, K), mx_alpha, nullptr, B, K, a->terms + 8, stream));
+    SV_TRY(sv_post_fwd(g(a->mu, 3, D), g(a->ls, 3, D), mx_mu, mx_sigma, B, D, a->terms + 9, stream));
+    SV_TRY(sv_shot_compose(a->terms, &a->sch, a->coef, stream));
+    // backward with upstream gradients 1: the coefficients are the `gout` operands; every slice is written once
+    SV_TRY(sv_elbo_bwd(a->image_l, g(a->rec, 0, n), n, g(a->mu, 0, D), g(a->ls, 0, D), g(a->la, 0, K), B, D, K, a->bce, a->x_sigma, a->coef,
+                       gm(a->d_rec, 0, n), gm(a->d_mu, 0, D), gm(a->d_ls, 0, D), gm(a->d_la, 0, K), stream));
+    SV_TRY(sv_elbo_bwd(a->image_u, g(a->rec, 1, n), n, g(a->mu, 1, D), g(a->ls, 1, D), g(a->la, 1, K), B, D, K, a->bce, a->x_sigma, a->coef + 3,
+                       gm(a->d_rec, 1, n), gm(a->d_mu, 1, D), gm(a->d_ls, 1, D), gm(a->d_la, 1, K), stream));
+    SV_TRY(sv_cls_bwd(lab_mix, nullptr, B, K, a->coef + 6, gm(a->d_la, 2, K), stream));
+    SV_TRY(sv_post_bwd(g(a->mu, 2, D), g(a->ls, 2, D), sm_mu, sm_sigma, B, D, a->coef + 7, gm(a->d_mu, 2, D), gm(a->d_ls, 2, D), stream));
+    SV_TRY(sv_cls_bwd(mx_alpha, nullptr, B, K, a->coef + 8, gm(a->d_la, 3, K), stream));
+    SV_TRY(sv_post_bwd(g(a->mu, 3, D), g(a->ls, 3, D), mx_mu, mx_sigma, B, D, a->coef + 9, gm(a->d_mu, 3, D), gm(a->d_ls, 3, D), stream));
+#undef SV_TRY
+    return SV_OK;
+}
+
 int sv_mix_lerp(const float* a, const int64_t* index, float lam, const float* lam_dev, int B, int64_t row,
                 int exp_space, float* out, void* stream) {
     SvProfScope prof_scope(stream);

@@ -116,15 +116,37 @@ class _ShotLossFn(torch.autograd.Function):
 def shot_loss_step(rec, mu, ls, la, image_l, image_u, label_l, perm_l, perm_u, lam_l, lam_u, sch, bce=True, x_sigma=1.0):
     """The same stage WITHOUT autograd, for a step that drives the network's backward itself (train_step_grouped): the
     forward reductions and, with upstream gradients 1 for both objectives (`(loss_sup + loss_unsup).backward()`), the
-    gradients w.r.t. the network outputs -- 9 + 6 launches issued back to back from the calling thread (the autograd
-    engine's worker-thread hand-over alone left the GPU idle for ~0.15 ms per step).
+    gradients w.r.t. the network outputs -- 9 + 6 launches issued back to back by ONE call into the library
+    (sv_shot_loss_step: at ~5 us per kernel the stage is bound by the per-launch host time of a Python caller).
     Returns (terms[12], d_rec [2B], d_mu, d_ls, d_la [4B])."""
-    with torch.no_grad():
-        ctx = _Ctx()
-        _, _, terms = _ShotLossFn.forward(ctx, rec, mu, ls, la, image_l, image_u, label_l.long().contiguous(), perm_l, perm_u,
-                                          lam_l, lam_u, sch, bce, x_sigma)
-        grads = _ShotLossFn.backward(ctx, None, None, None, unit_upstream=True)
-    return (terms,) + tuple(grads[:4])
+    for t in (rec, mu, ls, la, image_l, image_u):
+        if not t.is_cuda:
+            raise L.ShotVaeHipError("shot_vae_amd losses run on an MI355X only (no CPU fallback)")
+    B, D, K = image_l.shape[0], mu.shape[1], la.shape[1]
+    f32 = dict(dtype=torch.float32, device=mu.device)
+    rec, mu, ls, la = rec.contiguous(), mu.contiguous(), ls.contiguous(), la.contiguous()
+    image_l, image_u = image_l.contiguous().float(), image_u.contiguous().float()
+    label_l = label_l.long().contiguous()
+    terms = torch.zeros(12, **f32)
+    scratch = torch.empty(10 + 4 * B * D + 2 * B * K, **f32)          # coef | the targets
+    d_rec, d_mu, d_ls, d_la = torch.empty_like(rec), torch.empty_like(mu), torch.empty_like(ls), torch.empty_like(la)
+    a = L.SvShotLossArgs()
+    a.rec, a.mu, a.ls, a.la = rec.data_ptr(), mu.data_ptr(), ls.data_ptr(), la.data_ptr()
+    a.image_l, a.image_u, a.label_l = image_l.data_ptr(), image_u.data_ptr(), label_l.data_ptr()
+    a.perm_l, a.perm_u = perm_l.data_ptr(), perm_u.data_ptr()
+    keep = []
+    for name, v in (("lam_l", lam_l), ("lam_u", lam_u)):
+        if torch.is_tensor(v):
+            keep.append(v)
+            setattr(a, name + "_dev", v.data_ptr())
+        else:
+            setattr(a, name, float(v))
+    a.B, a.D, a.K, a.bce, a.n_per_img, a.x_sigma = B, D, K, int(bce), image_l[0].numel(), float(x_sigma)
+    a.sch = L.SvShotSchedule(*[float(sch[k]) for k in ("ew", "kl_beta_c", "kl_beta_d", "cmi", "dmi", "pwm", "ucw")])
+    a.terms, a.coef, a.tgt = terms.data_ptr(), scratch.data_ptr(), scratch.data_ptr() + 40
+    a.d_rec, a.d_mu, a.d_ls, a.d_la = d_rec.data_ptr(), d_mu.data_ptr(), d_ls.data_ptr(), d_la.data_ptr()
+    L.call("sv_shot_loss_step", C.byref(a), _st())
+    return terms, d_rec, d_mu, d_ls, d_la
 
 
 class _Ctx:
