@@ -106,7 +106,9 @@ def test_grouped_step_default_engine_state_at_full_size(name, K, B, dmi, tol):
         else:
             # the same step again: only the order of the float atomics may differ
             for k, v in vals.items():
-                assert abs(v - first[k]) <= 2e-3 * max(abs(first[k]), 1e-3), (rep, k, v, first[k])
+                # (the posterior terms are differences between the outputs of two forwards: twice the spread, as everywhere)
+                tk = 4e-3 if "_post_" in k else 2e-3
+                assert abs(v - first[k]) <= tk * max(abs(first[k]), 1e-3), (rep, k, v, first[k])
             cos = float(grad @ g0 / grad.norm() / g0.norm())
             worst_cos = min(worst_cos, cos)
             assert cos > 0.9, (rep, cos)
