@@ -518,19 +518,6 @@ def main():
                                   "tensor_passes_per_residual_unit_backward": 17,
                                   "note": "17 algorithmic passes per unit (dgrad 3, bn-backward 3 / 4, wgrad 2, twice); the paired "
                                           "weight gradients find dY / x in L2 (PMC 1.07-1.28x their own bytes)"}
-    if headline and a.dtype == "bf16":
-        # the whole step against SURVEY.md 8d's MINIMUM model (BatchNorm / activation fully fused into the convolutions: every
-        # conv reads X, W and writes Y; dgrad reads dY, W, writes dX; wgrad reads X, dY): 14.26 GB and 3.058 TFLOP per step.
-        # The real pass structure moves about three times that, so this fraction is the step-level measure of
-        # wasted traffic, next to the per-kernel `roofline` below.
-        t_s = dt / a.steps
-        out["step_vs_minimum"] = {"min_hbm_bytes": 14.26e9, "GBps": round(14.26e9 / t_s / 1e9, 1),
-                                  "frac_of_hbm_peak": round(14.26e9 / t_s / (HBM_PEAK_GBS * 1e9), 4),
-                                  "flops": 3.058e12, "TFLOPs": round(3.058e12 / t_s / 1e12, 1),
-                                  "frac_of_mfma_peak": round(3.058e12 / t_s / (MFMA_PEAK_TFLOPS["bf16"] * 1e12), 4),
-                                  "tensor_passes_per_residual_unit_backward": 17,
-                                  "note": "17 algorithmic passes per unit (dgrad 3, bn-backward 3 / 4, wgrad 2, twice); the paired "
-                                          "weight gradients find dY / x in L2 (PMC 1.07-1.28x their own bytes)"}
     if probe is not None:
         out["config"]["launch_probe"] = probe
     if lam_equal is not None:

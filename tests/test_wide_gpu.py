@@ -186,8 +186,11 @@ def test_config4_full_size_step_default_dispatch_repeats():
             assert 0.0 <= vals["kld_l"] <= np.log(K) + 1e-4
         else:
             # the same step again: only the order of float atomics (BN statistics, gradient accumulation) may differ
+            # (the posterior terms are a difference of two KLs on a bf16 forward: twice the spread, measured 2.4e-3 once in
+            #  30 full-size repeats)
             for k, v in vals.items():
-                assert abs(v - first[k]) <= 2e-3 * max(abs(first[k]), 1e-3), (rep, k, v, first[k])
+                tk = 4e-3 if "_post_" in k else 2e-3
+                assert abs(v - first[k]) <= tk * max(abs(first[k]), 1e-3), (rep, k, v, first[k])
             # (bf16 rounding makes this step's gradient ill-conditioned -- DESIGN.md: cosine 0.91-0.97 against fp64 -- and
             #  a 1e-7 change of a BatchNorm statistic re-draws that rounding noise: two runs agree to ~0.97, measured)
             cos = float((grad.double() @ g0.double()) / grad.double().norm() / g0.double().norm())
