@@ -245,6 +245,12 @@ def extras(S):
     return res
 
 
+def _multi(world):
+    """The collectives run with more than one rank -- or with ONE rank under SV_DP_SINGLE_RANK=1 (shot_vae_amd/dp.py: the same
+    RCCL calls through the hardware of a one-GPU box; a functional check)."""
+    return world > 1 or os.environ.get("SV_DP_SINGLE_RANK") == "1"
+
+
 def svhn_workload(a, rank, world):
     """--workload svhn: one smooth-ELBO iteration of svhn_VAE (BASELINE configs[4]; main_smooth_ELBO_svhn.py:152-176: unlabelled
     forward + loss, labelled forward + loss, one backward, Adam) on --batch images per loader per GPU.  The iteration is ~130
@@ -252,10 +258,11 @@ def svhn_workload(a, rank, world):
     (both in the JSON); at N > 1 the graph holds forward + backward and ONE all-reduce of FlatAdam's flat gradient buffer +
     the sv_adam launch follow it eagerly."""
     import shot_vae_amd as S
+    multi = _multi(world)
     B = a.batch if a.scaling == "weak" else a.batch // world
     torch.manual_seed(1)
     model = S.SmoothVAE((3, 32, 32), {"cont": 32, "disc": [10]}, temperature=0.67, compute_dtype=a.dtype).cuda().train()
-    if world > 1:
+    if multi:
         for p_ in model.parameters():
             dist.broadcast(p_.data, 0)
     loss_fn = S.SmoothELBOLoss()
@@ -268,10 +275,10 @@ def svhn_workload(a, rank, world):
     y = torch.randint(0, 10, (B,), device="cuda", generator=g)
 
     def eager():
-        return S.smooth_train_step(model, loss_fn, opt, u, l, y, distributed=world > 1)
+        return S.smooth_train_step(model, loss_fn, opt, u, l, y, distributed=multi)
 
     def sync():
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -289,14 +296,14 @@ def svhn_workload(a, rank, world):
     want = a.graph if a.graph is not None else -1
     if want != 0:
         try:
-            graphed = S.GraphedSmoothStep(model, loss_fn, opt, u, l, y, warmup=2, distributed=world > 1)
+            graphed = S.GraphedSmoothStep(model, loss_fn, opt, u, l, y, warmup=2, distributed=multi)
         except Exception as e:
             mode = "eager (graph capture failed: %s)" % type(e).__name__
             torch.cuda.synchronize()
     if graphed is not None:
         if want < 0:
             pe, pg = timed(eager, 10)[0], timed(graphed, 10)[0]
-            if world > 1:                   # the slower rank decides, every rank decides the same
+            if multi:                   # the slower rank decides, every rank decides the same
                 pv = torch.tensor([pe, pg], device="cuda", dtype=torch.float64)
                 dist.all_reduce(pv, op=dist.ReduceOp.MAX)
                 pe, pg = float(pv[0]), float(pv[1])
@@ -310,7 +317,7 @@ def svhn_workload(a, rank, world):
     step = graphed if graphed is not None else eager
     ms, loss = timed(step, a.steps)
     dt = torch.tensor([ms], device="cuda", dtype=torch.float64)
-    if world > 1:
+    if multi:
         dist.all_reduce(dt, op=dist.ReduceOp.MAX)
     ms = float(dt)
     assert bool(torch.isfinite(loss).all()), "non-finite loss"
@@ -322,12 +329,12 @@ def svhn_workload(a, rank, world):
            "config": {"workload": "svhn_VAE smooth-ELBO iteration (2 fwd + 1 bwd + Adam), B_u=B_l=%d per GPU, synthetic 3x32x32 in "
                                   "[-1,1] in HBM, random init" % B, "global_batch": 2 * B * world, "parallelism": "dp%d" % world,
                       "launch": mode, "optimizer": "FlatAdam (one sv_adam launch on a flat buffer)",
-                      "collective": "1 RCCL all-reduce of the flat gradient buffer (2.49 M floats) per iteration" if world > 1 else "none"},
+                      "collective": "1 RCCL all-reduce of the flat gradient buffer (2.49 M floats) per iteration" if multi else "none"},
            "loss": round(float(loss), 4), "TFLOPs": round(flops / ms / 1e9, 2),
            "note": "launch-bound workload (SURVEY.md 8d): 0.07 TFLOP and 0.43 GB per iteration"}
     if probe is not None:
         out["config"]["launch_probe"] = probe
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
@@ -364,10 +371,14 @@ def main():
     if world > ndev and os.environ.get("SV_DIST_BACKEND", "nccl") == "nccl":
         sys.exit("bench.py: %d ranks but %d visible GPUs (RCCL needs one device per rank)" % (world, ndev))
     torch.cuda.set_device(local % max(ndev, 1))
-    if world > 1:
+    multi = _multi(world)
+    if multi:
         # "nccl" is RCCL on ROCm.  SV_DIST_BACKEND=gloo lets the N > 1 code path be exercised on a one-GPU box (both
         # ranks on the same device, the collective through host memory): a functional check, not a measurement.
-        dist.init_process_group(os.environ.get("SV_DIST_BACKEND", "nccl"), rank=rank, world_size=world)
+        backend = os.environ.get("SV_DIST_BACKEND", "nccl")
+        # (device_id binds the communicator -- and every barrier -- to this rank's GPU instead of a guess from the rank)
+        kw = {"device_id": torch.device("cuda", local % max(ndev, 1))} if backend == "nccl" else {}
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
 
     if a.workload == "svhn":
         return svhn_workload(a, rank, world)
@@ -390,7 +401,7 @@ def main():
     model = S.VariationalAutoEncoder(a.net, num_input_channels=3, img_size=(32, 32), data_parallel=True,
                                      continuous_latent_dim=128, disc_latent_dim=K, small_input=True,
                                      compute_dtype=a.dtype, rng="device").cuda().train()
-    if world > 1:
+    if multi:
         dp.broadcast_parameters(model)
     # per-rank noise streams (eps, Gumbel u, pairings): torch seeds = seed + rank.  The mixup coefficients are the lambda
     # contract of SURVEY.md 5.2 -- every rank must use the SAME lambda_l / lambda_u in a step: the eager step draws them
@@ -413,7 +424,7 @@ def main():
     model._engine.wgrad_side_stream = bool(a.wgrad_side)
     if a.pair_blocks >= 0:
         model._engine.pair_blocks = a.pair_blocks
-    dmode = False if world == 1 else ("bucketed" if a.allreduce == "bucketed" else True)
+    dmode = False if not multi else ("bucketed" if a.allreduce == "bucketed" else True)
 
     mode = a.graph if a.graph is not None else (-1 if a.scaling == "strong" else 0)
     graphed, graph_note, probe = None, "eager, weight gradients on a side stream", None
@@ -433,7 +444,7 @@ def main():
         return S.train_step(model, elbo, cls, opt, il, ll, iu, sch, distributed=dmode)
 
     def sync():
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -449,7 +460,7 @@ def main():
                 fn()
             sync()
             v = torch.tensor([(time.perf_counter() - t) / n * 1e3], device="cuda", dtype=torch.float64)
-            if world > 1:
+            if multi:
                 dist.all_reduce(v, op=dist.ReduceOp.MAX)
             return float(v)
         probe = {"eager_ms": round(probe_ms(eager_step), 3), "graph_ms": round(probe_ms(graphed), 3)}
@@ -469,7 +480,7 @@ def main():
         ls, lu = step()
     sync()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if multi:
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t)
@@ -477,7 +488,7 @@ def main():
     # the lambda contract: every rank used the same mixup coefficients in the last step
     lam_equal = None
     lams = getattr(model, "_last_lams", None)
-    if world > 1 and lams is not None:
+    if multi and lams is not None:
         hi = torch.tensor([float(v) for v in lams], device="cuda", dtype=torch.float64)
         lo = hi.clone()
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
@@ -499,7 +510,7 @@ def main():
                                    "two-stream": "two-stream (labelled || unlabelled branch)",
                                    "sequential": "sequential (reference order)"}[a.schedule],
                       "launch": graph_note,
-                      "collective": "none" if world == 1 else (
+                      "collective": "none" if not multi else (
                           "RCCL all-reduce of the flat fp32 gradient buffer in two buckets per step: decoder tail (88 % of the "
                           "bytes) on a communication stream under the encoder's backward, encoder + heads after it"
                           if dmode == "bucketed" and graphed is None and a.schedule != "two-stream" else
@@ -588,7 +599,7 @@ def main():
         out.update(extras(S))
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(a.net, K)
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:

@@ -18,13 +18,22 @@ def init_from_env(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or os.environ.get("SV_DP_SINGLE_RANK") == "1") and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"      # "nccl" is RCCL on ROCm
+        kw = {}
         if backend == "nccl":
             torch.cuda.set_device(local)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+            kw["device_id"] = torch.device("cuda", local)       # the communicator and every barrier on this rank's GPU
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     return rank, world, local
+
+
+def active():
+    """True when a step must run its collectives: a process group of more than one rank -- or of ONE rank with
+    SV_DP_SINGLE_RANK=1, which sends the same RCCL calls (communication stream, async work handles, bucket order) through
+    the hardware on a one-GPU box (tests/test_dp_gpu.py; a functional check, the sums are the identity)."""
+    return dist.is_initialized() and (dist.get_world_size() > 1 or os.environ.get("SV_DP_SINGLE_RANK") == "1")
 
 
 def shard(t, rank, world):
@@ -40,7 +49,7 @@ def broadcast_parameters(model, src=0, optimizer=None):
     broadcast too -- otherwise the ranks would apply different momentum to the same all-reduced gradient and the replicas
     would drift apart from the first step.  Takes the MODEL: the in-place c10d write does not bump any version counter, so
     the engine is told explicitly that its packed weight shadows are stale."""
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if active():
         eng = model._engine
         dist.broadcast(eng.param, src)
         dist.broadcast(eng.bufs, src)
@@ -52,7 +61,7 @@ def broadcast_parameters(model, src=0, optimizer=None):
 
 def broadcast_optimizer(optimizer, src=0):
     """Rank `src`'s FlatSGD state (momentum buffer, number of steps taken, hyper-parameters) to every rank."""
-    if not (dist.is_initialized() and dist.get_world_size() > 1):
+    if not active():
         return
     eng = optimizer.model._engine
     g = optimizer.param_groups[0]
@@ -73,7 +82,7 @@ def broadcast_optimizer(optimizer, src=0):
 
 def all_reduce_gradients(flat_grad):
     """The single collective of a step.  Returns the scale the optimizer must apply (1/world)."""
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if active():
         dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM)
         return 1.0 / dist.get_world_size()
     return 1.0
@@ -100,7 +109,7 @@ class DecoderFirstAllReduce:
         self.comm = None
 
     def arm(self):
-        if dist.is_initialized() and dist.get_world_size() > 1:
+        if active():
             self.work = None
             self.model._engine.bucket_hook = self._decoder_done
 
@@ -123,7 +132,7 @@ class DecoderFirstAllReduce:
     def finish(self):
         eng = self.model._engine
         eng.bucket_hook = None
-        if not (dist.is_initialized() and dist.get_world_size() > 1):
+        if not active():
             return 1.0
         if self.work is None:
             dist.all_reduce(eng.grad, op=dist.ReduceOp.SUM)
@@ -143,7 +152,7 @@ def all_reduce_module_gradients(module, average=True):
     grads = [p.grad for p in module.parameters() if p.grad is not None]
     if not grads:
         return 0
-    if not (dist.is_initialized() and dist.get_world_size() > 1):
+    if not active():
         return sum(g.numel() for g in grads)
     flat = torch.cat([g.reshape(-1) for g in grads])
     dist.all_reduce(flat, op=dist.ReduceOp.SUM)

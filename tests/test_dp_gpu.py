@@ -103,3 +103,45 @@ def test_bench_svhn_workload_two_ranks_gloo_on_one_gpu():
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert out["n_gpus"] == 2 and out["value"] > 0 and "svhn_VAE" in out["metric"]
     assert out["config"]["global_batch"] == 256 and set(out["config"]["launch_probe"]) == {"eager_ms", "graph_ms"}
+
+
+def _single_rank_rccl_env():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "SV_DIST_BACKEND")}
+    env.update({"SV_DP_SINGLE_RANK": "1", "RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1",
+                "MASTER_PORT": str(29500 + os.getpid() % 2000), "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    return env
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("allreduce", ["bucketed", "single"])
+def test_bench_headline_step_through_rccl_single_rank(allreduce):
+    """The data-parallel step of BASELINE config 2 at FULL size with its collectives sent through RCCL on the hardware: one
+    rank (a one-GPU box cannot hold two RCCL ranks), backend "nccl", the decoder-first bucket on the communication stream
+    under the encoder's backward + the encoder bucket after it (or the single all-reduce).  With one rank the sums are the
+    identity, so the step must give finite losses of the usual size at (nearly) the usual speed: what is checked is that
+    process-group start-up, the stream / event edges around the asynchronous work handle and the 1/world path of the
+    optimizer run on a real device."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "10", "--warmup", "3",
+                        "--no-cpu-baseline", "--no-roofline", "--no-extras", "--allreduce", allreduce],
+                       capture_output=True, text=True, env=_single_rank_rccl_env(), timeout=850)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["n_gpus"] == 1 and out["value"] > 0
+    assert "RCCL" in out["config"]["collective"]
+    assert ("two buckets" in out["config"]["collective"]) == (allreduce == "bucketed")
+    assert out["config"]["lambda_equal_across_ranks"] is True
+    assert 0 < out["loss_sup"] < 1e4 and 0 < abs(out["loss_unsup"]) < 1e4
+    assert out["ms_per_step"] < 14.0, out["ms_per_step"]       # 8.0 ms without the collectives
+
+
+@pytest.mark.timeout(900)
+def test_bench_svhn_through_rccl_single_rank():
+    """BASELINE config 5's data-parallel iteration (graph of forwards + backward, one all-reduce of FlatAdam's flat gradient
+    buffer, sv_adam with 1/world) with the all-reduce sent through RCCL: one rank, backend "nccl", B = 1024."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "svhn", "--gpus", "1", "--steps", "10",
+                        "--warmup", "3", "--batch", "1024"], capture_output=True, text=True, env=_single_rank_rccl_env(),
+                       timeout=850)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["n_gpus"] == 1 and out["value"] > 0 and "RCCL" in out["config"]["collective"]
+    assert out["loss"] == out["loss"] and abs(out["loss"]) < 1e7
