@@ -63,6 +63,9 @@ struct halo_cfg {
     // drained the prefetches of the next tiles: the thin layers ran at 1.4 - 2 TB/s with their waves waiting 55 - 63 %
     // of the time, profiles/r03_pmc_odd.txt.)
     int shift[SV_MAX_PHASES * 16];
+    // weight source of every tap slot (halo_kernel's staging): wbase[slot] = w_off + tap * Cin of the slot's phase (elements; -1:
+    // pad slot), wnst[slot] = ntap * Cin = elements between two output channels in that phase.  Lane-held like `shift`.
+    int wbase[SV_MAX_PHASES * 16], wnst[SV_MAX_PHASES * 16];
 };
 
 // The k loop of both kernels: all (tap slot, channel chunk) steps of one phase out of LDS, software-pipelined by hand -- the
@@ -162,24 +165,60 @@ __global__ __launch_bounds__(256) void halo_kernel(const sv_geom g, const sv_ige
 #pragma unroll
     for (int j = 0; j < 8; ++j) zero[j] = (T)0.f;
 
-    // ---- halo staging slots (channel-chunk independent): vector idx -> (LDS pixel, 8-channel vector) ---------------------
+    // ---- staging slots (channel-chunk independent).  Halo: vector idx -> (LDS pixel, 8-channel vector); weights: vector idx
+    //      -> (output channel, tap slot, 8-channel vector).  Everything a chunk's staging needs is computed HERE, once per
+    //      block, and the staging itself is branch-free: a source that does not exist (padding, rows beyond the tensor, pad
+    //      slots of a phase) reads a valid address and is replaced by zero, a slot beyond the tile's image is stored into a
+    //      per-thread dummy vector behind the sums.  (The straightforward form -- `valid ? load : zero` per slot, the
+    //      phase of a weight slot looked up from the kernel arguments inside the chunk loop -- compiled to one basic block
+    //      per slot, each ending in s_waitcnt vmcnt(0): the requests of a chunk went out one by one, and the ConvTranspose
+    //      128 -> 64 forward ran at 0.7 TB/s with its waves waiting 60 % of the time, profiles/r03_pmc_odd.txt.)
     const int HVn = c.HP * VPP;
-    int hsrc[HMAXV], hdst[HMAXV];              // element offset into x (channel chunk 0) or -1 (zero) ; LDS element offset or -1
-#pragma unroll
-    for (int i = 0; i < HMAXV; ++i) {
+    T* const dummy = reinterpret_cast<T*>(ssum + 2 * BN) + tid * 8;
+    const int ddst = (int)(dummy - halo);
+    constexpr int PFV = 4;                     // halo vectors per thread that are prefetched (every dispatched shape: <= 4)
+    // weight vectors per thread: 16 * NT rows x tslots x CC / 8 vectors <= 256 * PFW (one phase: at most 16 tap slots)
+    constexpr int PFW = (NPH == 1 && NT == 1) ? 4 : HMAXW;
+    auto halo_slot = [&](int i, int& src, int& dst) __attribute__((always_inline)) {      // returns: the slot has a source
         const int idx = tid + 256 * i;
-        hsrc[i] = -1;
-        hdst[i] = -1;
-        if (idx < HVn) {
-            const int pix = idx / VPP, cv = idx - pix * VPP;
-            const int lr = pix / c.LW, lc = pix - lr * c.LW;
-            const int seg = lr / c.SR, off = lr - seg * c.SR;
-            const int grow = R0 + (seg << c.hhlog);                 // first grid row of the segment
-            const int b = grow >> c.hlog, qy0 = grow & (Hq - 1);
-            const int iy = g.sy * qy0 + off + c.dymin, ix = lc + c.dxmin;
-            hdst[i] = pix * LDC + 8 * cv;
-            if (grow < BHq && (unsigned)iy < (unsigned)g.Hin && (unsigned)ix < (unsigned)g.Win)
-                hsrc[i] = ((b * g.Hin + iy) * g.Win + ix) * g.ldx + 8 * cv;
+        src = 0;
+        dst = ddst;
+        if (idx >= HVn) return false;
+        const int pix = idx / VPP, cv = idx - pix * VPP;
+        const int lr = pix / c.LW, lc = pix - lr * c.LW;
+        const int seg = lr / c.SR, off = lr - seg * c.SR;
+        const int grow = R0 + (seg << c.hhlog);                 // first grid row of the segment
+        const int b = grow >> c.hlog, qy0 = grow & (Hq - 1);
+        const int iy = g.sy * qy0 + off + c.dymin, ix = lc + c.dxmin;
+        dst = pix * LDC + 8 * cv;
+        if (!(grow < BHq && (unsigned)iy < (unsigned)g.Hin && (unsigned)ix < (unsigned)g.Win)) return false;
+        src = ((b * g.Hin + iy) * g.Win + ix) * g.ldx + 8 * cv;
+        return true;
+    };
+    int hsrc[PFV], hdst[PFV];                  // element offset into x (channel chunk 0, clamped) ; LDS element offset
+    unsigned hok = 0;                          // bit i: slot i has a source
+#pragma unroll
+    for (int i = 0; i < PFV; ++i)
+        if (halo_slot(i, hsrc[i], hdst[i])) hok |= 1u << i;
+    const int WVn = BN * c.tslots * VPP;
+    const int mywb = c.wbase[lane], myws = c.wnst[lane];      // (tslots <= 64: slot s lives in lane s)
+    int wsrc[PFW], wdst[PFW];                  // element offset into the packed weights (channel chunk 0) ; LDS element offset
+    unsigned wok = 0;
+    const int wl0 = c.HP * LDC;                // wl - halo
+#pragma unroll
+    for (int i = 0; i < PFW; ++i) {
+        const int idx = tid + 256 * i;
+        wsrc[i] = 0;
+        wdst[i] = ddst;
+        if (idx < WVn) {
+            const int v = idx % VPP, r = idx / VPP;
+            const int slot = r % c.tslots, n = r / c.tslots;
+            wdst[i] = wl0 + n * LDW + slot * CC + 8 * v;
+            const int wb = __shfl(mywb, slot), ws = __shfl(myws, slot);
+            if (wb >= 0 && n0 + n < g.N) {
+                wsrc[i] = wb + (n0 + n) * ws + 8 * v;
+                wok |= 1u << i;
+            }
         }
     }
     // ---- this lane's two output-grid positions --------------------------------------------------------------------------
@@ -201,56 +240,53 @@ __global__ __launch_bounds__(256) void halo_kernel(const sv_geom g, const sv_ige
 #pragma unroll
             for (int j = 0; j < 2; ++j) acc[ph][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // ---- the chunk loop, register-prefetched: the requests of chunk i + 1 (PFV halo vectors + every weight vector + the
+    //      BatchNorm coefficients per thread) go out right after chunk i has been published in LDS and fly during its MFMAs
     const int nck = g.Cin / CC;
+    const int cv8 = 8 * (tid % VPP);            // a thread's 8-channel group is the same for all of its slots (256 % VPP == 0)
+    V hv[PFV], wv[PFW];
+    f32x4 ps0, ps1, pt0, pt1;
+    // (without a prologue the coefficient requests read the head of the weights -- Cin floats are always there -- and their
+    //  values are not used: an unconditional request needs no copy, hence no wait, at the join behind a branch)
+    const float* const psc = has_pro ? a.pro_scale : reinterpret_cast<const float*>(Wg);
+    const float* const psh = has_pro ? a.pro_shift : reinterpret_cast<const float*>(Wg);
+    auto request = [&](int c0) __attribute__((always_inline)) {
+        ps0 = *reinterpret_cast<const f32x4*>(psc + c0 + cv8);
+        ps1 = *reinterpret_cast<const f32x4*>(psc + c0 + cv8 + 4);
+        pt0 = *reinterpret_cast<const f32x4*>(psh + c0 + cv8);
+        pt1 = *reinterpret_cast<const f32x4*>(psh + c0 + cv8 + 4);
+#pragma unroll
+        for (int i = 0; i < PFV; ++i) hv[i] = *reinterpret_cast<const V*>(X + hsrc[i] + c0);
+#pragma unroll
+        for (int i = 0; i < PFW; ++i) wv[i] = *reinterpret_cast<const V*>(Wg + wsrc[i] + c0);
+    };
+    auto publish = [&](int c0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < PFV; ++i) {
+            V o = hv[i];
+            if (has_pro) o = bn_act8(hv[i], ps0, ps1, pt0, pt1, a.pro_slope);
+            *reinterpret_cast<V*>(halo + hdst[i]) = ((hok >> i) & 1u) ? o : zero;
+        }
+        // (larger halo images -- none of the dispatched shapes, SV_OPT_HALO_ALL only -- stage the rest here, unprefetched)
+#pragma unroll
+        for (int i = PFV; i < HMAXV; ++i) {
+            if (256 * i >= HVn) break;
+            int src, dst;
+            const bool ok = halo_slot(i, src, dst);
+            const V x = *reinterpret_cast<const V*>(X + src + c0);
+            V o = x;
+            if (has_pro) o = bn_act8(x, ps0, ps1, pt0, pt1, a.pro_slope);
+            *reinterpret_cast<V*>(halo + dst) = ok ? o : zero;
+        }
+#pragma unroll
+        for (int i = 0; i < PFW; ++i) *reinterpret_cast<V*>(halo + wdst[i]) = ((wok >> i) & 1u) ? wv[i] : zero;
+    };
+    request(0);
     for (int ck = 0; ck < nck; ++ck) {
-        const int c0 = ck * CC;
         if (ck > 0) __syncthreads();                // the previous chunk's MFMAs are done with the LDS tiles
-        // ---- halo chunk: loads first (in flight together), then transform + store ----------------------------------------
-        f32x4 s0, s1, t0, t1;
-        {
-            const int cv8 = 8 * ((tid % VPP));        // a thread's 8-channel group is the same for all of its slots (256 % VPP == 0)
-            if (has_pro) {
-                s0 = *reinterpret_cast<const f32x4*>(a.pro_scale + c0 + cv8);
-                s1 = *reinterpret_cast<const f32x4*>(a.pro_scale + c0 + cv8 + 4);
-                t0 = *reinterpret_cast<const f32x4*>(a.pro_shift + c0 + cv8);
-                t1 = *reinterpret_cast<const f32x4*>(a.pro_shift + c0 + cv8 + 4);
-            }
-        }
-#pragma unroll
-        for (int i0 = 0; i0 < HMAXV; i0 += 4) {
-            if (256 * i0 >= HVn) break;
-            V hv[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) hv[i] = hsrc[i0 + i] >= 0 ? *reinterpret_cast<const V*>(X + hsrc[i0 + i] + c0) : zero;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                V o = hv[i];
-                if (has_pro && hsrc[i0 + i] >= 0) o = bn_act8(hv[i], s0, s1, t0, t1, a.pro_slope);
-                if (hdst[i0 + i] >= 0) *reinterpret_cast<V*>(halo + hdst[i0 + i]) = o;
-            }
-        }
-        // ---- weight chunk of every tap slot of every phase: wl[n][(tap0[ph] + t) * CC + c] ----------------------------------
-        {
-            const int WVn = BN * c.tslots * VPP;
-#pragma unroll
-            for (int i = 0; i < HMAXW; ++i) {
-                const int idx = tid + 256 * i;
-                if (idx < WVn) {
-                    const int v = idx % VPP, r = idx / VPP;
-                    const int slot = r % c.tslots, n = r / c.tslots;
-                    int ph = 0;
-#pragma unroll
-                    for (int q = 1; q < NPH; ++q)
-                        if (q < g.nphase && slot >= c.tap0[q]) ph = q;
-                    const int t = slot - c.tap0[ph];
-                    V w = zero;
-                    if (t < g.phase[ph].ntap && n0 + n < g.N)
-                        w = *reinterpret_cast<const V*>(Wg + g.phase[ph].w_off + ((int64_t)(n0 + n) * g.phase[ph].ntap + t) * g.Cin + c0 + 8 * v);
-                    *reinterpret_cast<V*>(wl + n * LDW + slot * CC + 8 * v) = w;
-                }
-            }
-        }
+        publish(ck * CC);
         __syncthreads();
+        if (ck + 1 < nck) request((ck + 1) * CC);
         // ---- every phase x k step out of LDS ---------------------------------------------------------------------------------
 #pragma unroll
         for (int ph = 0; ph < NPH; ++ph) {
@@ -668,7 +704,8 @@ int launch_halo(const sv_geom* g, const sv_igemm_args* a, const halo_cfg& c, hip
     const int nT = (g->B * g->Hq + c.TR - 1) / c.TR;
     const int nNt = (g->N + BN - 1) / BN;
     const int grid = (nT >= 64 ? ((nT + 7) / 8) * 8 : nT) * nNt;
-    const size_t lds = ((size_t)c.HP * (CC + 16) + (size_t)BN * (c.tslots * CC + 16)) * sizeof(T) + 2 * BN * sizeof(float);
+    const size_t lds = ((size_t)c.HP * (CC + 16) + (size_t)BN * (c.tslots * CC + 16)) * sizeof(T) + 2 * BN * sizeof(float) +
+                       256 * 8 * sizeof(T);       // + the per-thread dummy vectors of the branch-free staging
     static bool optin = false;
     if (lds > 64 * 1024 && !optin) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&halo_kernel<T, NT, CC, NPH>),
@@ -750,11 +787,22 @@ int sv_halo_try(const sv_geom* g, int dtype, const sv_igemm_args* a, hipStream_t
             }
             c.shift[16 * p + sl] = v;
         }
+    for (int sl = 0; sl < SV_MAX_PHASES * 16; ++sl) { c.wbase[sl] = -1; c.wnst[sl] = 0; }
+    if (slots > SV_MAX_PHASES * 16) return 0;
+    for (int p = 0; p < g->nphase; ++p)          // (weight offsets are 32-bit in the kernels)
+        if (g->phase[p].w_off + (int64_t)g->N * g->phase[p].ntap * g->Cin >= ((int64_t)1 << 31)) return 0;
+    {
+        for (int p = 0; p < g->nphase; ++p)
+            for (int t = 0; t < g->phase[p].ntap; ++t) {
+                c.wbase[c.tap0[p] + t] = (int)(g->phase[p].w_off + (int64_t)t * g->Cin);
+                c.wnst[c.tap0[p] + t] = g->phase[p].ntap * g->Cin;
+            }
+    }
     const int es = dtype == SV_BF16 ? 2 : 4;
     const int nt = (g->N % 32 == 0) ? 2 : 1, BN = 16 * nt;
     if (c.HP * (CC / 8) > 256 * HMAXV) return 0;
     if (BN * c.tslots * (CC / 8) > 256 * HMAXW) return 0;
-    const size_t lds = ((size_t)c.HP * (CC + 16) + (size_t)BN * (c.tslots * CC + 16)) * es + 2 * BN * 4;
+    const size_t lds = ((size_t)c.HP * (CC + 16) + (size_t)BN * (c.tslots * CC + 16)) * es + 2 * BN * 4 + 256 * 8 * es;
     if (lds > 100 * 1024) return 0;
     if ((int64_t)g->B * g->Hin * g->Win * g->ldx >= ((int64_t)1 << 31)) return 0;
     const bool multi = g->nphase > 1;
