@@ -221,6 +221,10 @@ __global__ __launch_bounds__(256, 1) void conv3x3x_kernel(const sv_geom g, const
     const char* const Wp = reinterpret_cast<const char*>(reinterpret_cast<const bf16*>(a.w) + P.w_off);
     const bool has_pro = a.pro_scale != nullptr;
     const float slope = has_pro ? a.pro_slope : 1.f;
+    // (held in registers: the inline assembly of the K loop clobbers memory, so every `a.pro_scale` inside it is a scalar load
+    //  from the argument segment followed by s_waitcnt lgkmcnt(0) -- four per chunk, each also draining the fragment reads)
+    const char* const pscale_b = reinterpret_cast<const char*>(a.pro_scale);
+    const char* const pshift_b = reinterpret_cast<const char*>(a.pro_shift);
     const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_ptr)smem;
 
     // ---- a K-loop position: (item, chunk) and what staging needs to know about it -------------------------------------------
@@ -327,7 +331,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3x_kernel(const sv_geom g, const
     auto load_coef = [&](f32x4* csc, f32x4* csh, const Pos& p, auto Q) {     // q: 0,1 = scale lo/hi, 2,3 = shift lo/hi
         constexpr int q = decltype(Q)::value;
         if (!has_pro) return;
-        const char* src = reinterpret_cast<const char*>(q < 2 ? a.pro_scale : a.pro_shift) + (int64_t)p.c * 128;
+        const char* src = (q < 2 ? pscale_b : pshift_b) + (int64_t)p.c * 128;
         const uint32_t off = (uint32_t)(8 * lq + 4 * (q & 1)) * 4u;
         f32x4 v;
         asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(v) : "v"(off), "s"(src) : "memory");

@@ -159,6 +159,11 @@ __global__ __launch_bounds__(256) void halo_kernel(const sv_geom g, const sv_ige
     const T* __restrict__ EX = reinterpret_cast<const T*>(a.ex);
     const bool has_pro = a.pro_scale != nullptr;
     const bool want_sums = (a.stats != nullptr) || (EX != nullptr);
+    // (per-launch scalars of the loops, pinned in vector registers: see conv3x3p_kernel -- a uniform value from the argument
+    //  segment is otherwise re-loaded where it is used, s_load + s_waitcnt lgkmcnt(0), up to 40 times per tile here)
+    float pslope = a.pro_slope, eslope = a.ex_slope;
+    int emode = EX ? 2 : (a.stats ? 1 : 0), sparse = a.sparse_out;
+    // (halo_kernel: plain locals -- its chunk loop has no such re-loads, and four more vector registers cost it a wave)
 
     if (tid < 2 * BN) ssum[tid] = 0.f;
     V zero;
@@ -264,7 +269,7 @@ __global__ __launch_bounds__(256) void halo_kernel(const sv_geom g, const sv_ige
 #pragma unroll
         for (int i = 0; i < PFV; ++i) {
             V o = hv[i];
-            if (has_pro) o = bn_act8(hv[i], ps0, ps1, pt0, pt1, a.pro_slope);
+            if (has_pro) o = bn_act8(hv[i], ps0, ps1, pt0, pt1, pslope);
             *reinterpret_cast<V*>(halo + hdst[i]) = ((hok >> i) & 1u) ? o : zero;
         }
         // (larger halo images -- none of the dispatched shapes, SV_OPT_HALO_ALL only -- stage the rest here, unprefetched)
@@ -275,7 +280,7 @@ __global__ __launch_bounds__(256) void halo_kernel(const sv_geom g, const sv_ige
             const bool ok = halo_slot(i, src, dst);
             const V x = *reinterpret_cast<const V*>(X + src + c0);
             V o = x;
-            if (has_pro) o = bn_act8(x, ps0, ps1, pt0, pt1, a.pro_slope);
+            if (has_pro) o = bn_act8(x, ps0, ps1, pt0, pt1, pslope);
             *reinterpret_cast<V*>(halo + dst) = ok ? o : zero;
         }
 #pragma unroll
@@ -321,7 +326,7 @@ __global__ __launch_bounds__(256) void halo_kernel(const sv_geom g, const sv_ige
 #pragma unroll
     for (int ph = 0; ph < NPH; ++ph) {
         if (ph >= g.nphase) break;
-        if (a.sparse_out && c.nks[ph] == 0) continue;       // tapless phase: exactly zero, left unwritten (sv_bn_branch::sparse)
+        if (sparse && c.nks[ph] == 0) continue;       // tapless phase: exactly zero, left unwritten (sv_bn_branch::sparse)
         const sv_phase& P = g.phase[ph];
 #pragma unroll
         for (int ms = 0; ms < 2; ++ms) {
@@ -352,13 +357,13 @@ __global__ __launch_bounds__(256) void halo_kernel(const sv_geom g, const sv_ige
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const float xf = to_f(eo[i][r]);
-                        const float gv = vv[r] * act_grad(xf * esc[i][r] + esh[i][r], a.ex_slope);
+                        const float gv = vv[r] * act_grad(xf * esc[i][r] + esh[i][r], eslope);
                         vv[r] = gv;
                         s1[i][r] += gv;
                         s2[i][r] += gv * ((xf - emu[i][r]) * ers[i][r]);
                     }
                 }
-                if (!EX && a.stats) {
+                if (emode == 1) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         s1[i][r] += vv[r];
@@ -436,6 +441,11 @@ __global__ __launch_bounds__(256, OCC) void halop_kernel(const sv_geom g, const 
     const T* __restrict__ EX = reinterpret_cast<const T*>(a.ex);
     const bool has_pro = a.pro_scale != nullptr;
     const bool want_sums = (a.stats != nullptr) || (EX != nullptr);
+    // (per-launch scalars of the loops, pinned in vector registers: see conv3x3p_kernel -- a uniform value from the argument
+    //  segment is otherwise re-loaded where it is used, s_load + s_waitcnt lgkmcnt(0), up to 40 times per tile here)
+    float pslope = a.pro_slope, eslope = a.ex_slope;
+    int emode = EX ? 2 : (a.stats ? 1 : 0), sparse = a.sparse_out;
+    asm volatile("v_mov_b32 %0, %0\n\tv_mov_b32 %1, %1\n\tv_mov_b32 %2, %2\n\tv_mov_b32 %3, %3" : "+v"(pslope), "+v"(eslope), "+v"(emode), "+v"(sparse));
 
     if (tid < 2 * BN) ssum[tid] = 0.f;
     V zero;
@@ -511,7 +521,7 @@ __global__ __launch_bounds__(256, OCC) void halop_kernel(const sv_geom g, const 
         for (int i = 0; i < PMAXV; ++i) {
             if (256 * i >= HVn) break;
             V o = S.hv[i];
-            if (has_pro) o = bn_act8(S.hv[i], ps0, ps1, pt0, pt1, a.pro_slope);
+            if (has_pro) o = bn_act8(S.hv[i], ps0, ps1, pt0, pt1, pslope);
             if (hdst[i] >= 0) *reinterpret_cast<V*>(halo + hdst[i]) = S.hok[i] ? o : zero;
         }
     };
@@ -572,7 +582,7 @@ __global__ __launch_bounds__(256, OCC) void halop_kernel(const sv_geom g, const 
             for (int ph = 0; ph < NPH; ++ph) {
                 const sv_phase& P = g.phase[ph < g.nphase ? ph : 0];
                 obv[ph][ms] = ((int64_t)(b * g.Hout + qy * g.osy + P.ooy) * g.Wout + pcol[ms] * g.osx + P.oox) * g.ldo;
-                if ((R || EX) && ph < g.nphase && !(a.sparse_out && c.nks[ph] == 0)) {
+                if ((R || EX) && ph < g.nphase && !(sparse && c.nks[ph] == 0)) {
                     const T* __restrict__ E = R ? R : EX;
 #pragma unroll
                     for (int i = 0; i < NT; ++i)
@@ -600,7 +610,7 @@ __global__ __launch_bounds__(256, OCC) void halop_kernel(const sv_geom g, const 
 #pragma unroll
         for (int ph = 0; ph < NPH; ++ph) {
             if (ph >= g.nphase) break;
-            if (a.sparse_out && c.nks[ph] == 0) continue;   // tapless phase: left unwritten
+            if (sparse && c.nks[ph] == 0) continue;   // tapless phase: left unwritten
             const sv_phase& P = g.phase[ph];
 #pragma unroll
             for (int ms = 0; ms < 2; ++ms) {
@@ -620,13 +630,13 @@ __global__ __launch_bounds__(256, OCC) void halop_kernel(const sv_geom g, const 
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const float xf = to_f(eo[ph][ms][i][r]);
-                            const float gv = vv[r] * act_grad(xf * esc[i][r] + esh[i][r], a.ex_slope);
+                            const float gv = vv[r] * act_grad(xf * esc[i][r] + esh[i][r], eslope);
                             vv[r] = gv;
                             s1[i][r] += gv;
                             s2[i][r] += gv * ((xf - emu[i][r]) * ers[i][r]);
                         }
                     }
-                    if (!EX && a.stats) {
+                    if (emode == 1) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             s1[i][r] += vv[r];

@@ -79,6 +79,8 @@ __global__ __launch_bounds__(256, 2) void hwgrad_kernel(const sv_geom g, const s
     const bf16* __restrict__ X = reinterpret_cast<const bf16*>(p.x);
     const bf16* __restrict__ DY = reinterpret_cast<const bf16*>(p.dy);
     const bool has_pro = p.pro_scale != nullptr;
+    float pslope = p.pro_slope;               // pinned in a vector register (conv3x3p_kernel: no re-load from the argument segment)
+    asm volatile("v_mov_b32 %0, %0" : "+v"(pslope));
     const int os = g.osy;
 
     V zero;
@@ -151,7 +153,7 @@ __global__ __launch_bounds__(256, 2) void hwgrad_kernel(const sv_geom g, const s
             const int idx = tid + 256 * i;
             if (idx >= HVn) break;
             V o = S.rx[i];
-            if (has_pro) o = bn_act8(S.rx[i], s0, s1, t0, t1, p.pro_slope);
+            if (has_pro) o = bn_act8(S.rx[i], s0, s1, t0, t1, pslope);
             *reinterpret_cast<V*>(Xs + (idx / VX) * LDX + 8 * (idx % VX)) = S.xok[i] ? o : zero;
         }
     };

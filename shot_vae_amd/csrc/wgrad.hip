@@ -123,6 +123,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const sv_geom g, const sv_wg
     const T* __restrict__ X = reinterpret_cast<const T*>(p.x);
     const T* __restrict__ DY = reinterpret_cast<const T*>(p.dy);
     const bool has_pro = p.pro_scale != nullptr;
+    float pslope = p.pro_slope;               // pinned in a vector register (conv3x3p_kernel: no re-load from the argument segment)
+    asm volatile("v_mov_b32 %0, %0" : "+v"(pslope));
 
     const int m_begin = split * p.m_per;
     const int m_end = min(M, m_begin + p.m_per);
@@ -243,7 +245,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const sv_geom g, const sv_wg
 #pragma unroll
         for (int i = 0; i < TC; ++i) {
             V o = rx[i];
-            if (has_pro && okx[i]) o = bn_act8(rx[i], s0, s1, t0, t1, p.pro_slope);
+            if (has_pro && okx[i]) o = bn_act8(rx[i], s0, s1, t0, t1, pslope);
             *reinterpret_cast<V*>(Xs + (rc + RPC * i) * LDC + 8 * vc) = o;
         }
     };
@@ -346,6 +348,8 @@ __global__ __launch_bounds__(256, 2) void wgradc_kernel(const sv_geom g, const s
     const T* __restrict__ X = reinterpret_cast<const T*>(p.x);
     const T* __restrict__ DY = reinterpret_cast<const T*>(p.dy);
     const bool has_pro = p.pro_scale != nullptr;
+    float pslope = p.pro_slope;               // pinned in a vector register (conv3x3p_kernel: no re-load from the argument segment)
+    asm volatile("v_mov_b32 %0, %0" : "+v"(pslope));
     const int m_begin = split * p.m_per;
     const int m_end = min(M, m_begin + p.m_per);
     if (m_end <= m_begin) return;
@@ -411,7 +415,7 @@ __global__ __launch_bounds__(256, 2) void wgradc_kernel(const sv_geom g, const s
                 const int cc = c0 + 8 * xv[i];
                 const f32x4 s0 = *reinterpret_cast<const f32x4*>(p.pro_scale + cc), s1 = *reinterpret_cast<const f32x4*>(p.pro_scale + cc + 4);
                 const f32x4 t0 = *reinterpret_cast<const f32x4*>(p.pro_shift + cc), t1 = *reinterpret_cast<const f32x4*>(p.pro_shift + cc + 4);
-                o = bn_act8(S.rx[i], s0, s1, t0, t1, p.pro_slope);
+                o = bn_act8(S.rx[i], s0, s1, t0, t1, pslope);
             }
             if (tid + 256 * i < RW * VRC) *reinterpret_cast<V*>(Xs + (buf * RW + xrow[i]) * LDC + 8 * xv[i]) = o;
         }

@@ -95,6 +95,8 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_kernel(const sv_geom g, const
     const T* __restrict__ X = reinterpret_cast<const T*>(p.x);
     const T* __restrict__ DY = reinterpret_cast<const T*>(p.dy);
     const bool has_pro = p.pro_scale != nullptr;
+    float pslope = p.pro_slope;               // pinned in a vector register (conv3x3p_kernel: no re-load from the argument segment)
+    asm volatile("v_mov_b32 %0, %0" : "+v"(pslope));
 
     V zero;
 #pragma unroll
@@ -166,7 +168,7 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_kernel(const sv_geom g, const
             V o = zero;
             if (S.hok[i]) {
                 o = S.rh[i];
-                if (has_pro) o = bn_act8(S.rh[i], s0, s1, t0, t1, p.pro_slope);
+                if (has_pro) o = bn_act8(S.rh[i], s0, s1, t0, t1, pslope);
             }
             if (hlds[i] >= 0) *reinterpret_cast<V*>(halo + hlds[i]) = o;
         }

@@ -166,7 +166,8 @@ def bench_convT_layer(B, Cin, H, N, what):
         stats = torch.zeros(R, 2 * N, device=d)
         a = L.SvIgemmArgs()
         a.x, a.w, a.out = x.data_ptr(), wp.data_ptr(), out.data_ptr()
-        a.pro_scale, a.pro_shift, a.pro_slope = sc.data_ptr(), sh.data_ptr(), 0.0
+        if not os.environ.get("SV_BENCH_NOPRO"):      # (set: the materialised activations of the small decoder layers)
+            a.pro_scale, a.pro_shift, a.pro_slope = sc.data_ptr(), sh.data_ptr(), 0.0
         a.stats, a.replicas = stats.data_ptr(), R
         res["fwd"] = timed(lambda: L.call("sv_igemm", C.byref(gf), L.SV_BF16, C.byref(a), st))
     if "dgrad" in what:
@@ -203,6 +204,8 @@ if __name__ == "__main__":
         L.call("sv_set_option", L.OPT_HALO_ALL, 1)
     if os.environ.get("SV_BENCH_PERSISTENT_BLOCKS"):    # e.g. 256: the budget a body weight gradient gets in the paired backward
         L.call("sv_set_option", L.OPT_PERSISTENT_BLOCKS, int(os.environ["SV_BENCH_PERSISTENT_BLOCKS"]))
+    if os.environ.get("SV_BENCH_WIDE_MIN_BLOCKS"):      # threshold of the 256-row tiles of igemm.hip (default 256)
+        L.call("sv_set_option", L.OPT_WIDE_MIN_BLOCKS, int(os.environ["SV_BENCH_WIDE_MIN_BLOCKS"]))
     if os.environ.get("SV_BENCH_DISABLE"):
         L.call("sv_set_option", L.OPT_DISABLE_MASK, int(os.environ["SV_BENCH_DISABLE"]))
     if len(sys.argv) >= 5:

@@ -9,10 +9,10 @@ mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 python3 "$R/bench.py" --steps 30 --warmup 10 2>/dev/null | tail -1 > "$OUT/${TAG}_bench.json"
 rm -rf /tmp/prof_b
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_b -o b -- python3 "$R/bench.py" --steps 10 --warmup 3 --no-cpu-baseline --no-roofline --wgrad-side 0 > /tmp/prof_b.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_b -o b -- python3 "$R/bench.py" --steps 10 --warmup 3 --no-cpu-baseline --no-roofline --no-extras --wgrad-side 0 > /tmp/prof_b.log 2>&1
 F=$(find /tmp/prof_b -name "*kernel_stats.csv" | head -1)
 cp "$F" "$OUT/${TAG}_bench_kernel_stats.csv"
-python3 "$R/tools/kernel_stats_digest.py" "$F" 13 "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline --wgrad-side 0   (WRN-28-2, K=10, B_l=B_u=512, bf16; grouped schedule, eager, ONE stream so that per-kernel durations are not inflated by the side stream's concurrent weight gradients; $(grep "^{.metric" /tmp/prof_b.log | tail -1 | python3 -c 'import sys,json; print("wall %.2f ms/step under the profiler" % json.loads(sys.stdin.read())["ms_per_step"])'))" > "$OUT/${TAG}_bench_kernel_stats.txt"
+python3 "$R/tools/kernel_stats_digest.py" "$F" 13 "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline --no-extras --wgrad-side 0   (WRN-28-2, K=10, B_l=B_u=512, bf16; grouped schedule, eager, ONE stream so that per-kernel durations are not inflated by the side stream's concurrent weight gradients; $(grep "^{.metric" /tmp/prof_b.log | tail -1 | python3 -c 'import sys,json; print("wall %.2f ms/step under the profiler" % json.loads(sys.stdin.read())["ms_per_step"])'))" > "$OUT/${TAG}_bench_kernel_stats.txt"
 { python3 "$R/tools/layer_bench.py"; for s in "2048 32 32 32" "2048 64 16 64" "2048 128 8 128"; do python3 "$R/tools/layer_bench.py" $s; done; } 2>/dev/null | grep "of bf16" > "$OUT/${TAG}_layer_bench_wrn28_10.txt"
 # the WRN-28-10 odd layers (stride-2 3x3, 1x1 shortcuts, first block) at 4 x 256 images: SV_BENCH_K / SV_BENCH_S
 { for s in "3 2 1024 160 32 320" "3 2 1024 320 16 640" "1 2 1024 160 32 320" "1 2 1024 320 16 640" "3 1 1024 16 32 160" "1 1 1024 16 32 160"; do
