@@ -586,6 +586,24 @@ def main():
             roof["top5"] = [{"kernel": r["name"], "ms_per_step": round(r["total_ms"] / a.prof_steps, 3),
                              "launches_per_step": r["launches"] // a.prof_steps, "avg_us": round(r["avg_us"], 2),
                              "GBps": round(r["bytes"] / r["avg_us"] / 1e3, 1) if r["bytes"] else None} for r in top]
+            # every costed launch against ITS roofline, by family (the verdict's own arithmetic: floor = max(bytes / HBM peak,
+            # flops / MFMA peak) per launch): the body 3x3 layers, BatchNorm backward, and the odd layers (decoder, stride-2,
+            # 1x1 shortcuts, 16-channel layers)
+            def family(n):
+                if n.startswith("sv_"):
+                    return n
+                body = any(n.endswith("conv3x3_%dx%d_s1" % (c, c)) for c in (32, 64, 128, 160, 320, 640))
+                return "body_conv3x3_" + n.split(":")[0] if body else "odd_layers_" + n.split(":")[0]
+            fam = {}
+            for r in costed:
+                f = fam.setdefault(family(r["name"]), {"ms": 0.0, "floor_ms": 0.0, "launches": 0})
+                floor_us = max(r["bytes"] / (HBM_PEAK_GBS * 1e3), r["flops"] / (peak_t * 1e6))
+                f["ms"] += r["total_ms"] / a.prof_steps
+                f["floor_ms"] += floor_us * r["launches"] / a.prof_steps / 1e3
+                f["launches"] += r["launches"] // a.prof_steps
+            roof["families"] = {k: {"ms_per_step": round(v["ms"], 3), "floor_ms": round(v["floor_ms"], 3),
+                                    "frac_of_roofline": round(v["floor_ms"] / v["ms"], 3), "launches_per_step": v["launches"]}
+                                for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])}
             out["roofline"] = roof
             if rank == 0 and os.environ.get("SV_BENCH_TABLE"):
                 for r in sorted(rows, key=lambda r: -r["total_ms"]):

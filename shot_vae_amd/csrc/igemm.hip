@@ -17,6 +17,10 @@
 #include "common.h"
 #include "epilogue.h"
 
+#ifndef SV_IG_MIN_TILES
+#define SV_IG_MIN_TILES 512        // blocks a channel-tile width must yield to be taken (two per CU)
+#endif
+
 namespace {
 
 constexpr int BK = 32;
@@ -627,7 +631,7 @@ extern "C" int sv_igemm(const sv_geom* g, int dtype, const sv_igemm_args* a_in, 
         if (N % (16 * c) != 0) continue;
         if (dtype == SV_F32 && c > 2) continue;     // LDS budget (<= 64 KiB without opt-in)
         nt = c;
-        if (mtiles * (N / (16 * c)) >= 512) break;
+        if (mtiles * (N / (16 * c)) >= SV_IG_MIN_TILES) break;
         if (c <= 2) break;
     }
     if (N % 80 == 0 && N % 64 != 0 && mtiles * (N / 80) >= 256 && dtype == SV_BF16) nt = 5;
