@@ -32,6 +32,9 @@
 #ifndef SV_X3_EPD
 #define SV_X3_EPD 1
 #endif
+#ifndef SV_X3_MODES
+#define SV_X3_MODES 0      // 1: epilogue fusion flags at compile time for the forward launch kinds, 2: and the data gradient (A/B: tools/ab.sh)
+#endif
 
 namespace {
 
@@ -578,6 +581,18 @@ int launch_x4(const sv_geom* g, const sv_igemm_args* a, hipStream_t s) {
 // (bias, no statistics, ...) takes the binary that reads the flags at run time
 template <int WLOG, bool REV>
 int launch_x3(const sv_geom* g, const sv_igemm_args* a, hipStream_t s) {
+#if SV_X3_MODES
+    if (!a->bias) {
+        if constexpr (REV) {
+#if SV_X3_MODES > 1
+            if (a->ex && !a->residual) return launch_x4<WLOG, REV, 3>(g, a, s);
+#endif
+        } else {
+            if (a->stats && a->residual && !a->ex) return launch_x4<WLOG, REV, 2>(g, a, s);
+            if (a->stats && !a->residual && !a->ex) return launch_x4<WLOG, REV, 1>(g, a, s);
+        }
+    }
+#endif
     return launch_x4<WLOG, REV, 0>(g, a, s);
 }
 

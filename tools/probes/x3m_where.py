@@ -1,0 +1,38 @@
+"""Where does a conv3x3x variant (SV_LIB_PATH) differ from conv3x3w on the 160-channel data gradient?"""
+import ctypes as C, os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from shot_vae_amd import _lib as L, geometry as G
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests"))
+from test_wide_gpu import _conv_args, _st, BF
+B, H, Cin, N = 64, 32, 160, 160
+d = torch.device("cuda:0")
+torch.manual_seed(3)
+master = (torch.randn(N, 9, Cin, device=d) / (9 * Cin) ** 0.5).contiguous()
+gd = G.convT_like(B, H, H, N, Cin, 3, 1, 1)
+wd = torch.zeros(G.packed_size(gd), dtype=BF, device=d)
+L.call("sv_repack", L.SV_BF16, C.c_void_p(master.data_ptr()), N, 9, Cin, 1, C.byref(gd), C.c_void_p(wd.data_ptr()), _st())
+x = torch.randn(B, H, H, Cin, device=d).to(BF)
+dy = torch.randn(B, H, H, N, device=d).to(BF)
+sc, sh = torch.rand(Cin, device=d) + 0.5, torch.randn(Cin, device=d) * 0.3
+emu, ers = torch.randn(Cin, device=d) * 0.1, torch.rand(Cin, device=d) + 0.5
+res = []
+for mask in (0, L.K_CONV3X3X):
+    with L.options(disable=mask):
+        dx = torch.zeros(B, H, H, Cin, dtype=BF, device=d)
+        bsums = torch.zeros(8 * 2 * Cin, device=d)
+        a2 = _conv_args(dy, wd, dx, None, None, ex=(x, sc, sh, emu, ers, bsums))
+        L.call("sv_igemm", C.byref(gd), L.SV_BF16, C.byref(a2), _st())
+        torch.cuda.synchronize()
+        res.append((dx.float(), bsums.view(8, 2, Cin).sum(0)))
+(d1, b1), (d0, b0) = res
+bad = ~torch.isfinite(d1)
+print("non-finite:", int(bad.sum()), "of", d1.numel())
+diff = (d1 != d0) | bad
+print("differing elements:", int(diff.sum()))
+print("by channel group of 32:", [int(diff[..., 32 * i:32 * i + 32].sum()) for i in range(5)])
+print("by channel mod 8:", [int(diff[..., j::8].sum()) for j in range(8)])
+print("by row mod 8:", [int(diff[:, j::8].sum()) for j in range(8)])
+print("by image:", [int(diff[b].sum()) for b in range(0, B, 8)])
+idx = diff.nonzero()[:10]
+for i in idx: print(tuple(int(v) for v in i), float(d1[tuple(i)]), float(d0[tuple(i)]))
+print("sums equal:", bool(torch.equal(b1, b0)), float((b1 - b0).abs().max()))
