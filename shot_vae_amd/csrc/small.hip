@@ -667,24 +667,57 @@ __global__ __launch_bounds__(256) void head_bwd_data_kernel(int B, int C, const 
     }
 }
 
-// dW[n][c] += sum_b dout[b][n]*feat[b][c];  dbias[n] += sum_b dout[b][n].  grid = (NH, batch slices);
-// the slices meet through float atomics (dW / dbias accumulate anyway).
-__global__ __launch_bounds__(256) void head_bwd_weight_kernel(const float* feat, const float* dout, int B,
-                                                              int C, int NH, float* dW, float* dbias) {
-    const int n = blockIdx.x;
-    const int tid = threadIdx.x;
-    const int per = (B + gridDim.y - 1) / gridDim.y;
-    const int b0 = blockIdx.y * per, b1 = min(B, b0 + per);
-    __shared__ float red[4];
+// dW[n][c] += sum_b dout[b][n]*feat[b][c];  dbias[n] += sum_b dout[b][n]: a [NH x B] x [B x C] product in fp32 on the matrix
+// cores (v_mfma_f32_32x32x2_f32: full fp32 multiply-add).  One WAVE per (32 outputs, 32 channels, batch slice): both operands
+// are loaded from global memory straight into the MFMA layout -- lane (m, k) = (lane % 32, lane / 32) holds dout[b + k][n0 + m]
+// and feat[b + k][c0 + m], 128 contiguous bytes per half-wave -- so there is no LDS stage and no re-read: every wave reads its
+// slice of the two matrices once (the one-output-per-block version re-read feat 266 times: 33 us; this one 4 us).
+// grid = (ceil(NH / 32) * ceil(C / 32), slices of 128 samples); the slices meet through float atomics (dW / dbias accumulate
+// anyway).  Deterministic mode: the slices are launched one after the other (one adder per address at any time).
+typedef float f32x16s __attribute__((ext_vector_type(16)));
+constexpr int HWS = 128;          // samples per wave
+__global__ __launch_bounds__(64) void head_bwd_weight_kernel(const float* feat, const float* dout, int B,
+                                                             int C, int NH, float* dW, float* dbias, int slice0) {
+    const int nct = (C + 31) / 32;
+    const int n0 = (blockIdx.x / nct) * 32, c0 = (blockIdx.x % nct) * 32;
+    const int lane = threadIdx.x, m = lane & 31, k = lane >> 5;
+    // a wave owns HWS = 128 consecutive samples: ALL of its 2 x 64 loads are requested before the first MFMA (128 registers:
+    // the memory latency is paid once per wave, not once per unrolled group of steps)
+    const int b0 = (blockIdx.y + slice0) * HWS, b1 = min(B, b0 + HWS);
+    const bool nok = n0 + m < NH, cok = c0 + m < C;
+    const float* pd = dout + (nok ? n0 + m : 0);
+    const float* pf = feat + (cok ? c0 + m : 0);
+    float dv[HWS / 2], fv[HWS / 2];
+#pragma unroll
+    for (int u = 0; u < HWS / 2; ++u) {
+        const int bb = min(b0 + 2 * u + k, B - 1);          // (clamped: rows beyond the slice are zeroed below)
+        dv[u] = pd[(int64_t)bb * NH];
+        fv[u] = pf[(int64_t)bb * C];
+    }
+    f32x16s acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
     float sb = 0.f;
-    for (int b = b0 + tid; b < b1; b += 256) sb += dout[(int64_t)b * NH + n];
-    sb = block_sum(sb, red);
-    if (tid == 0) atomicAdd(dbias + n, sb);
-    for (int c = tid; c < C; c += 256) {
-        float acc = 0.f;
-#pragma unroll 8
-        for (int b = b0; b < b1; ++b) acc += dout[(int64_t)b * NH + n] * feat[(int64_t)b * C + c];
-        atomicAdd(dW + (int64_t)n * C + c, acc);
+#pragma unroll
+    for (int u = 0; u < HWS / 2; ++u) {
+        const bool bok = b0 + 2 * u + k < b1;
+        const float d_ = nok && bok ? dv[u] : 0.f, f_ = cok && bok ? fv[u] : 0.f;
+        sb += d_;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(d_, f_, acc, 0, 0, 0);
+    }
+    // D layout of the 32x32 tile: lane (r, h) = (lane % 32, lane / 32) holds column r, rows 8 g + 4 h + e in acc[4 g + e]
+    if (cok) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int n = n0 + 8 * g + 4 * k + e;
+                if (n < NH) atomicAdd(dW + (int64_t)n * C + c0 + m, acc[4 * g + e]);
+            }
+    }
+    if (c0 == 0) {                                      // bias: the two sample halves of a row meet by shuffle
+        sb += __shfl_xor(sb, 32);
+        if (k == 0 && nok) atomicAdd(dbias + n0 + m, sb);
     }
 }
 
@@ -1694,8 +1727,18 @@ int sv_head_bwd(const float* feat, int B, int C, const float* W, int ldc, int K,
     const size_t lds = ((size_t)HS * NH + (size_t)HS * 256) * sizeof(float);       // gradients + the thread groups' partial sums
     hipLaunchKernelGGL(head_bwd_data_kernel, dim3((B + HS - 1) / HS, (C + 255) / 256), dim3(256), lds, (hipStream_t)stream, B, C, W,
                        ldc, K, la, dmu, dls, dla, dfeat, dout_ws);
-    hipLaunchKernelGGL(head_bwd_weight_kernel, dim3(NH, (B >= 64 && !sv_deterministic()) ? 8 : 1), dim3(256), 0, (hipStream_t)stream, feat,
-                       dout_ws, B, C, NH, dW, dbias);
+    {
+        const int tiles = ((NH + 31) / 32) * ((C + 31) / 32);
+        const int slices = (B + HWS - 1) / HWS;
+        if (sv_deterministic()) {
+            for (int sl = 0; sl < slices; ++sl)
+                hipLaunchKernelGGL(head_bwd_weight_kernel, dim3(tiles, 1), dim3(64), 0, (hipStream_t)stream, feat, dout_ws, B, C,
+                                   NH, dW, dbias, sl);
+        } else {
+            hipLaunchKernelGGL(head_bwd_weight_kernel, dim3(tiles, slices), dim3(64), 0, (hipStream_t)stream, feat, dout_ws, B, C,
+                               NH, dW, dbias, 0);
+        }
+    }
     return sv_check_launch("sv_head_bwd");
 }
 
