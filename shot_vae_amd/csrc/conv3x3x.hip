@@ -32,8 +32,26 @@
 #ifndef SV_X3_EPD
 #define SV_X3_EPD 1
 #endif
+// An MFMA spelled in inline assembly is invisible to the compiler's hazard recognizer.  The hardware needs two wait states
+// between a VALU write of a register and an MFMA that reads it; in front of its own MFMAs the compiler inserts them, in front of
+// this assembly it does not -- and the VALU write may be its own: a spill re-load (v_accvgpr_read) or a copy of a fragment
+// register that the allocator placed right before the statement.  Found with the compile-time epilogue modes below: at
+// 506-512 registers the data-gradient variant re-loaded the first tap's fragments of a new item from their spill slots
+// directly in front of MFMAs 0, 2, ... and produced wrong even rows; the run-time-flag binary had the same exposure and was
+// right by luck of its allocation.  Every MFMA therefore carries its own `s_nop 1` (measured: not slower -- 320 / 299 us
+// against 337 / 308 at 160 channels).
+#ifndef SV_X3_NOP
+#define SV_X3_NOP 1
+#endif
+#if SV_X3_NOP == 1
+#define SV_X3_PRE "s_nop 1\n\t"
+#elif SV_X3_NOP == 3
+#define SV_X3_PRE "s_nop 3\n\t"
+#else
+#define SV_X3_PRE
+#endif
 #ifndef SV_X3_MODES
-#define SV_X3_MODES 0      // 1: epilogue fusion flags at compile time for the forward launch kinds, 2: and the data gradient (A/B: tools/ab.sh)
+#define SV_X3_MODES 2      // epilogue fusion flags at compile time: 1 = for the forward launch kinds, 2 = and the data gradient; 0 = run-time flags only
 #endif
 
 namespace {
@@ -459,7 +477,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3x_kernel(const sv_geom g, const
             constexpr int t = decltype(T)::value, tn = (t + 1) % 9;
             static_for<20>([&](auto M) {
                 constexpr int m = decltype(M)::value, ks = m / 10, i = (m % 10) / 2, f = m & 1;
-                asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc[f][i]) : "v"(A[ks][i]), "v"(Bf[ks][f]));
+                asm volatile(SV_X3_PRE "v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc[f][i]) : "v"(A[ks][i]), "v"(Bf[ks][f]));
                 static_for<6>([&](auto JJ) {
                     constexpr int code = SCHED.item[20 * t + m][decltype(JJ)::value];
                     if constexpr (code >= 1000 && code < 2000)

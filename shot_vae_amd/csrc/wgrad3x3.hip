@@ -15,6 +15,21 @@
 #include "common.h"
 #include <type_traits>
 
+// An MFMA spelled in inline assembly is invisible to the compiler's hazard recognizer: if the instruction in front of it is a
+// VALU write of one of its operands (a spill re-load, a register copy -- whatever the allocator decided), the two wait states
+// the hardware requires between them are NOT inserted and the MFMA reads the old register (conv3x3x.hip: how this was found).
+// conv3x3x gives every MFMA its own `s_nop 1` (free there); here that costs 13 % (16-cycle MFMAs in a tight gap program:
+// 228 -> 254 us at 160 channels), so this file relies on the CHECK instead: tools/asm_mfma_lint.py compiles it to ISA and fails
+// on any VALU write of an MFMA operand less than two wait states ahead (tests/test_abi_cpu.py runs it on every change).
+#ifndef SV_WG3_NOP
+#define SV_WG3_NOP 0
+#endif
+#if SV_WG3_NOP
+#define SV_WG3_PRE "s_nop 1\n\t"
+#else
+#define SV_WG3_PRE
+#endif
+
 namespace {
 
 constexpr int TC32 = 32;
@@ -608,7 +623,7 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3w_kernel(const sv_geom g, cons
             constexpr int g = decltype(GP)::value, t = g / 5, a = g % 5;
             // in-place accumulation in the AGPR half, spelled out: left to itself the register allocator rotates the
             // 180 accumulators through copies
-            asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[a][t]) : "v"(fy[set][a]), "v"(fx[t]));
+            asm volatile(SV_WG3_PRE "v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[a][t]) : "v"(fy[set][a]), "v"(fx[t]));
             if constexpr (a < 2) {
                 if constexpr (t >= 1) load_fx(nkc, t - 1, a);
                 else load_fy(set ^ 1, nkc, 0, a);

@@ -2,6 +2,9 @@
 import ctypes
 import os
 import re
+import sys
+
+import pytest
 
 from shot_vae_amd import _lib as L
 
@@ -199,3 +202,39 @@ print("ASAN_DRIVE_OK", n_ok, n_err)
     assert r.returncode == 0 and "ASAN_DRIVE_OK" in r.stdout, (r.returncode, r.stdout[-500:], r.stderr[-3000:])
     n_ok = int(r.stdout.split("ASAN_DRIVE_OK")[1].split()[0])
     assert n_ok >= 100, r.stdout
+
+
+def test_asm_mfma_lint_parser():
+    """tools/asm_mfma_lint.py on synthetic ISA: a VALU write of an MFMA operand with fewer than two wait states in between is
+    reported, the same write followed by `s_nop 1` (or by two other instructions) is not; register RANGES count."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import asm_mfma_lint as lint
+    head = "_Zkernel:\n"
+    mf = "\t;;#ASMSTART\n\tv_mfma_f32_32x32x16_bf16 a[0:15], v[46:49], v[78:81], a[0:15]\n\t;;#ASMEND\n"
+    n, bad = lint.lint_isa(head + "\tv_accvgpr_read_b32 v49, a253\n" + mf)
+    assert n == 1 and len(bad) == 1
+    n, bad = lint.lint_isa(head + "\tv_accvgpr_read_b32 v49, a253\n\ts_nop 1\n" + mf)
+    assert n == 1 and not bad
+    n, bad = lint.lint_isa(head + "\tv_mov_b32_e32 v80, v3\n\tds_read_b128 v[10:13], v5\n" + mf)
+    assert len(bad) == 1                                   # one instruction in between is one wait state: not enough
+    n, bad = lint.lint_isa(head + "\tv_mov_b32_e32 v80, v3\n\tds_read_b128 v[10:13], v5\n\ts_add_u32 s1, s2, s3\n" + mf)
+    assert not bad
+    n, bad = lint.lint_isa(head + "\tv_mov_b32_e32 v50, v3\n" + mf)           # not an operand
+    assert not bad
+    n, bad = lint.lint_isa(head + "\tv_accvgpr_write_b32 a7, v3\n" + mf)      # SrcC lives in the AGPR half
+    assert len(bad) == 1
+
+
+@pytest.mark.timeout(900)
+def test_inline_asm_mfmas_have_no_valu_hazard():
+    """The two kernel files that spell MFMAs in inline assembly (invisible to the compiler's hazard recognizer).  wgrad3x3.hip
+    carries no s_nop in front of them (13 % slower with it): its ISA is checked here.  conv3x3x.hip gives every MFMA its own
+    `s_nop 1` -- checked at source level (compiling its 15 variants takes minutes; `python tools/asm_mfma_lint.py
+    shot_vae_amd/csrc/conv3x3x.hip` is the full check)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import asm_mfma_lint as lint
+    n, bad = lint.lint_file(os.path.join(ROOT, "shot_vae_amd", "csrc", "wgrad3x3.hip"))
+    assert n > 0 and not bad, bad[:3]
+    src = open(os.path.join(ROOT, "shot_vae_amd", "csrc", "conv3x3x.hip")).read()
+    assert "#define SV_X3_NOP 1\n" in src and 'asm volatile(SV_X3_PRE "v_mfma' in src
+    assert src.count('"v_mfma') == 1                     # every assembly MFMA of the file goes through the prefixed statement
