@@ -12,6 +12,9 @@
 #include "common.h"
 #include "epilogue.h"
 
+#ifndef SV_C3P_MODES
+#define SV_C3P_MODES 1         // fusion flags of conv3x3p at compile time for the step's three launch kinds (0: run-time flags only)
+#endif
 #ifndef SV_C3P_WAVES
 #define SV_C3P_WAVES 2          // waves per SIMD the persistent kernel is compiled for (3 => spills, measured slower)
 #endif
@@ -179,7 +182,9 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const sv_geom g, const sv_
 // register-prefetch software pipeline -- while tile i is on the MFMAs, the halo of tile i+1 and the
 // residual / raw tensor needed by tile i's epilogue are already in flight -- and the BatchNorm sums are
 // kept in registers across tiles and flushed once per block (one shuffle tree, one atomic per channel).
-template <typename T, int WLOG, int CCH>      // CCH = Cin / 32
+// MODE: the fusion flags at compile time (0 = read from the arguments; 1 = prologue + statistics, 2 = prologue + residual +
+// statistics, 3 = activation-backward epilogue, no prologue -- the three launch kinds of the training step; no bias in 1..3)
+template <typename T, int WLOG, int CCH, int MODE>      // CCH = Cin / 32
 __global__ __launch_bounds__(256, SV_C3P_WAVES) void conv3x3p_kernel(const sv_geom g, const sv_igemm_args_g A, int tiles_per) {
     const sv_igemm_args& a = A.g[blockIdx.y];
     typedef typename V8<T>::type V;
@@ -227,10 +232,12 @@ __global__ __launch_bounds__(256, SV_C3P_WAVES) void conv3x3p_kernel(const sv_ge
     const T* __restrict__ X = reinterpret_cast<const T*>(a.x);
     const T* __restrict__ Wp = reinterpret_cast<const T*>(a.w) + P.w_off + (int64_t)n0 * 9 * CIN;
     T* __restrict__ O = reinterpret_cast<T*>(a.out);
-    const T* __restrict__ R = reinterpret_cast<const T*>(a.residual);
-    const T* __restrict__ EX = reinterpret_cast<const T*>(a.ex);
-    const bool has_pro = a.pro_scale != nullptr;
-    const bool want_sums = (a.stats != nullptr) || (EX != nullptr);
+    const T* __restrict__ R = MODE == 0 || MODE == 2 ? reinterpret_cast<const T*>(a.residual) : nullptr;
+    const T* __restrict__ EX = MODE == 0 || MODE == 3 ? reinterpret_cast<const T*>(a.ex) : nullptr;
+    const bool hasR = MODE == 0 ? R != nullptr : MODE == 2, hasEX = MODE == 0 ? EX != nullptr : MODE == 3;
+    const bool has_stats = MODE == 0 ? a.stats != nullptr : (MODE == 1 || MODE == 2);
+    const bool has_pro = MODE == 0 ? a.pro_scale != nullptr : MODE != 3;
+    const bool want_sums = has_stats || hasEX;
 
     if (tid < 2 * BN) ssum[tid] = 0.f;
     V zero;
@@ -312,8 +319,8 @@ __global__ __launch_bounds__(256, SV_C3P_WAVES) void conv3x3p_kernel(const sv_ge
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
         const int n = n0 + 16 * i + 4 * fq;
-        bias[i] = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
-        if (EX) {
+        bias[i] = (MODE == 0 && a.bias) ? *reinterpret_cast<const f32x4*>(a.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+        if (hasEX) {
             esc[i] = *reinterpret_cast<const f32x4*>(a.ex_scale + n);
             esh[i] = *reinterpret_cast<const f32x4*>(a.ex_shift + n);
             emu[i] = *reinterpret_cast<const f32x4*>(a.ex_mean + n);
@@ -344,8 +351,8 @@ __global__ __launch_bounds__(256, SV_C3P_WAVES) void conv3x3p_kernel(const sv_ge
 #pragma unroll
             for (int i = 0; i < NT; ++i) {
                 const int n = n0 + 16 * i + 4 * fq;
-                if (R) eop[i][ms] = *reinterpret_cast<const Q*>(R + obase[ms] + n);
-                else if (EX) eop[i][ms] = *reinterpret_cast<const Q*>(EX + obase[ms] + n);
+                if (hasR) eop[i][ms] = *reinterpret_cast<const Q*>(R + obase[ms] + n);
+                else if (hasEX) eop[i][ms] = *reinterpret_cast<const Q*>(EX + obase[ms] + n);
             }
         }
         // ---- nine taps x CCH channel chunks out of LDS (padding is data: no masks) ---------------------------
@@ -378,13 +385,15 @@ __global__ __launch_bounds__(256, SV_C3P_WAVES) void conv3x3p_kernel(const sv_ge
 #pragma unroll
             for (int ms = 0; ms < 2; ++ms) {
                 f32x4 vv = acc[i][ms];
+                if (MODE == 0) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) vv[r] += bias[i][r];
-                if (R) {
+                    for (int r = 0; r < 4; ++r) vv[r] += bias[i][r];
+                }
+                if (hasR) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) vv[r] += to_f(eop[i][ms][r]);
                 }
-                if (EX) {
+                if (hasEX) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const float xf = to_f(eop[i][ms][r]);
@@ -393,7 +402,7 @@ __global__ __launch_bounds__(256, SV_C3P_WAVES) void conv3x3p_kernel(const sv_ge
                         s1[i][r] += gv;
                         s2[i][r] += gv * ((xf - emu[i][r]) * ers[i][r]);
                     }
-                } else if (a.stats) {
+                } else if (has_stats) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         s1[i][r] += vv[r];
@@ -417,7 +426,7 @@ __global__ __launch_bounds__(256, SV_C3P_WAVES) void conv3x3p_kernel(const sv_ge
         bool allv[NT];
 #pragma unroll
         for (int i = 0; i < NT; ++i) allv[i] = true;
-        flush_channel_sums<NT>(s1, s2, allv, ssum, EX ? a.bsums : a.stats, n0, g.N, a.replicas, a.flags);
+        flush_channel_sums<NT>(s1, s2, allv, ssum, hasEX ? a.bsums : a.stats, n0, g.N, a.replicas, a.flags);
     }
 }
 
@@ -694,8 +703,8 @@ int launch_mw(const sv_geom* g, const sv_igemm_args* a, hipStream_t s) {
     }
 }
 
-template <typename T, int WLOG, int CCH>
-int launch_p(const sv_geom* g, const sv_igemm_args* a, hipStream_t s) {
+template <typename T, int WLOG, int CCH, int MODE>
+int launch_pm(const sv_geom* g, const sv_igemm_args* a, hipStream_t s) {
     constexpr int W = 1 << WLOG, TR = 128 / W, CIN = 32 * CCH, LDW = CIN + 16, VPP = CIN / 8;
     constexpr int HH = (TR < W) ? TR : W, SEG = TR / HH, LROWS = TR + SEG + 1;
     constexpr int HV = LROWS * (W + 2) * VPP, HI = (HV + 255) / 256, HPIX = (HI * 256 + VPP - 1) / VPP;
@@ -711,16 +720,30 @@ int launch_p(const sv_geom* g, const sv_igemm_args* a, hipStream_t s) {
     const size_t lds = (size_t)(HPIX + 32 * 9) * LDW * sizeof(T) + 2 * 32 * sizeof(float);
     static bool optin = false;
     if (lds > 64 * 1024 && !optin) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3p_kernel<T, WLOG, CCH>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3p_kernel<T, WLOG, CCH, MODE>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return sv_check_launch("hipFuncSetAttribute(conv3x3p)");
         optin = true;
     }
     SV_LAUNCH_GATE(chunks * nNt, a);
     sv_prof_begin(s);
-    hipLaunchKernelGGL((conv3x3p_kernel<T, WLOG, CCH>), dim3(chunks * nNt, sv_ngroups(a->groups)), dim3(256), lds, s, *g, sv_expand_groups(*g, *a, (int)sizeof(T)), tiles_per);
+    hipLaunchKernelGGL((conv3x3p_kernel<T, WLOG, CCH, MODE>), dim3(chunks * nNt, sv_ngroups(a->groups)), dim3(256), lds, s, *g, sv_expand_groups(*g, *a, (int)sizeof(T)), tiles_per);
     sv_prof_end(s);
     return sv_check_launch("sv_igemm(conv3x3p)");
+}
+
+// the three launch kinds of the training step take the binaries with their fusion flags at compile time (bf16 only)
+template <typename T, int WLOG, int CCH>
+int launch_p(const sv_geom* g, const sv_igemm_args* a, hipStream_t s) {
+#if SV_C3P_MODES
+    if constexpr (sizeof(T) == 2) {
+        if (!a->bias) {
+            if (a->pro_scale && a->stats && !a->ex) return a->residual ? launch_pm<T, WLOG, CCH, 2>(g, a, s) : launch_pm<T, WLOG, CCH, 1>(g, a, s);
+            if (!a->pro_scale && a->ex && !a->residual && !a->stats) return launch_pm<T, WLOG, CCH, 3>(g, a, s);
+        }
+    }
+#endif
+    return launch_pm<T, WLOG, CCH, 0>(g, a, s);
 }
 
 template <typename T, int CCH>
