@@ -33,6 +33,9 @@ namespace {
 // Blocks per CU of the small-stage persistent variants (measured at 4 x 512 images, tools/thin_ab.sh: three blocks of the
 // 2-vector / 16-channel-tile variant: stem 66 -> 55 us, 1x1 16 -> 32 data gradient 54 -> 46 us; four blocks or any of the
 // 32-channel-tile variants spill -- 16 -> 32 forward 115 -> 176 / 290 us -- and stay at two)
+#ifndef SV_HALOP_MODES
+#define SV_HALOP_MODES 1
+#endif
 #ifndef SV_HALOP_OCC2
 #define SV_HALOP_OCC2 3         // 2-vector stage, 16-channel tiles (NT = 1)
 #endif
@@ -44,6 +47,21 @@ namespace {
 #endif
 #ifndef SV_HALOP_OCC4B
 #define SV_HALOP_OCC4B 2        // ... NT = 2
+#endif
+#ifndef SV_HALOP_OCC2_M
+#define SV_HALOP_OCC2_M 4       // the same with compile-time fusion flags (MODE 1 / 3)
+#endif
+#ifndef SV_HALOP_OCC2B_M
+#define SV_HALOP_OCC2B_M 3
+#endif
+#ifndef SV_HALOP_OCC4_M
+#define SV_HALOP_OCC4_M 3
+#endif
+#ifndef SV_HALOP_OCC4B_M
+#define SV_HALOP_OCC4B_M 2
+#endif
+#ifndef SV_HALOP_OCC6_M
+#define SV_HALOP_OCC6_M 3       // 6-vector stage, NT = 1
 #endif
 constexpr int HMAXV = 12;       // halo 16-byte vectors per thread (3072 per block)
 constexpr int HMAXW = 8;        // weight vectors per thread
@@ -394,7 +412,9 @@ constexpr int PMAXV = 6;        // halo vectors per thread per register stage (u
 // per CU (OCC = blocks per CU the register budget is held to): the compiler waits for register prefetches with
 // s_waitcnt vmcnt(0), so a block never has more than ~one tile of loads in flight -- bytes in flight per CU, i.e. the
 // achievable bandwidth of these HBM-bound layers, scale with the number of resident blocks.
-template <typename T, int NT, int CC, int NPH, int PV, int OCC>
+// MODE: fusion flags at compile time (0 = from the arguments; 1 = prologue + statistics; 2 = prologue only (the 1x1 shortcuts);
+// 3 = activation-backward epilogue, no prologue; no bias / residual in 1..3) -- straight-line epilogue, 40-50 registers fewer (conv3x3p_kernel)
+template <typename T, int NT, int CC, int NPH, int PV, int OCC, int MODE>
 __global__ __launch_bounds__(256, OCC) void halop_kernel(const sv_geom g, const sv_igemm_args_g AG, const halo_cfg c, int tiles_per) {
     constexpr int PMAXV = PV;
     typedef typename V8<T>::type V;
@@ -437,14 +457,15 @@ __global__ __launch_bounds__(256, OCC) void halop_kernel(const sv_geom g, const 
     const T* __restrict__ X = reinterpret_cast<const T*>(a.x);
     const T* __restrict__ Wg = reinterpret_cast<const T*>(a.w);
     T* __restrict__ O = reinterpret_cast<T*>(a.out);
-    const T* __restrict__ R = reinterpret_cast<const T*>(a.residual);
-    const T* __restrict__ EX = reinterpret_cast<const T*>(a.ex);
-    const bool has_pro = a.pro_scale != nullptr;
-    const bool want_sums = (a.stats != nullptr) || (EX != nullptr);
+    const T* __restrict__ R = MODE == 0 ? reinterpret_cast<const T*>(a.residual) : nullptr;
+    const T* __restrict__ EX = MODE == 0 || MODE == 3 ? reinterpret_cast<const T*>(a.ex) : nullptr;
+    const bool hasR = MODE == 0 ? R != nullptr : false, hasEX = MODE == 0 ? EX != nullptr : MODE == 3;
+    const bool has_pro = MODE == 0 ? a.pro_scale != nullptr : (MODE == 1 || MODE == 2);
+    const bool want_sums = MODE == 0 ? ((a.stats != nullptr) || (EX != nullptr)) : MODE != 2;
     // (per-launch scalars of the loops, pinned in vector registers: see conv3x3p_kernel -- a uniform value from the argument
     //  segment is otherwise re-loaded where it is used, s_load + s_waitcnt lgkmcnt(0), up to 40 times per tile here)
     float pslope = a.pro_slope, eslope = a.ex_slope;
-    int emode = EX ? 2 : (a.stats ? 1 : 0), sparse = a.sparse_out;
+    int emode = MODE == 0 ? (EX ? 2 : (a.stats ? 1 : 0)) : (MODE == 3 ? 2 : MODE == 1 ? 1 : 0), sparse = a.sparse_out;
     asm volatile("v_mov_b32 %0, %0\n\tv_mov_b32 %1, %1\n\tv_mov_b32 %2, %2\n\tv_mov_b32 %3, %3" : "+v"(pslope), "+v"(eslope), "+v"(emode), "+v"(sparse));
 
     if (tid < 2 * BN) ssum[tid] = 0.f;
@@ -543,8 +564,8 @@ __global__ __launch_bounds__(256, OCC) void halop_kernel(const sv_geom g, const 
         const int n = n0 + 16 * i + 4 * fq;
         nval[i] = n < g.N;
         const int nc = nval[i] ? n : 0;
-        bias[i] = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + nc) : f32x4{0.f, 0.f, 0.f, 0.f};
-        if (EX) {
+        bias[i] = (MODE == 0 && a.bias) ? *reinterpret_cast<const f32x4*>(a.bias + nc) : f32x4{0.f, 0.f, 0.f, 0.f};
+        if (hasEX) {
             esc[i] = *reinterpret_cast<const f32x4*>(a.ex_scale + nc);
             esh[i] = *reinterpret_cast<const f32x4*>(a.ex_shift + nc);
             emu[i] = *reinterpret_cast<const f32x4*>(a.ex_mean + nc);
@@ -582,7 +603,7 @@ __global__ __launch_bounds__(256, OCC) void halop_kernel(const sv_geom g, const 
             for (int ph = 0; ph < NPH; ++ph) {
                 const sv_phase& P = g.phase[ph < g.nphase ? ph : 0];
                 obv[ph][ms] = ((int64_t)(b * g.Hout + qy * g.osy + P.ooy) * g.Wout + pcol[ms] * g.osx + P.oox) * g.ldo;
-                if ((R || EX) && ph < g.nphase && !(sparse && c.nks[ph] == 0)) {
+                if ((hasR || hasEX) && ph < g.nphase && !(sparse && c.nks[ph] == 0)) {
                     const T* __restrict__ E = R ? R : EX;
 #pragma unroll
                     for (int i = 0; i < NT; ++i)
@@ -623,10 +644,10 @@ __global__ __launch_bounds__(256, OCC) void halop_kernel(const sv_geom g, const 
                     f32x4 vv = acc[ph][i][ms];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) vv[r] += bias[i][r];
-                    if (R) {
+                    if (hasR) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) vv[r] += to_f(eo[ph][ms][i][r]);
-                    } else if (EX) {
+                    } else if (hasEX) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const float xf = to_f(eo[ph][ms][i][r]);
@@ -636,7 +657,7 @@ __global__ __launch_bounds__(256, OCC) void halop_kernel(const sv_geom g, const 
                             s2[i][r] += gv * ((xf - emu[i][r]) * ers[i][r]);
                         }
                     }
-                    if (emode == 1) {
+                    if (MODE == 0 ? emode == 1 : MODE == 1) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             s1[i][r] += vv[r];
@@ -656,10 +677,10 @@ __global__ __launch_bounds__(256, OCC) void halop_kernel(const sv_geom g, const 
         do_tile(tile, HB, HA);
         if (tile + 1 < t_end) do_tile(tile + 1, HA, HB);
     }
-    if (want_sums) flush_channel_sums<NT>(s1, s2, nval, ssum, EX ? a.bsums : a.stats, n0, g.N, a.replicas, a.flags);
+    if (want_sums) flush_channel_sums<NT>(s1, s2, nval, ssum, hasEX ? a.bsums : a.stats, n0, g.N, a.replicas, a.flags);
 }
 
-template <typename T, int NT, int CC, int NPH, int PV, int OCC>
+template <typename T, int NT, int CC, int NPH, int PV, int OCC, int MODE>
 int launch_halop_pv(const sv_geom* g, const sv_igemm_args* a, const halo_cfg& c, size_t lds, hipStream_t s) {
     constexpr int BN = 16 * NT;
     const int nT = (g->B * g->Hq + c.TR - 1) / c.TR;
@@ -672,29 +693,51 @@ int launch_halop_pv(const sv_geom* g, const sv_igemm_args* a, const halo_cfg& c,
     chunks = (nT + tiles_per - 1) / tiles_per;
     static bool optin = false;
     if (lds > 64 * 1024 && !optin) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&halop_kernel<T, NT, CC, NPH, PV, OCC>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&halop_kernel<T, NT, CC, NPH, PV, OCC, MODE>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return sv_check_launch("hipFuncSetAttribute(halop)");
         optin = true;
     }
     SV_LAUNCH_GATE(chunks * nNt, a);
     sv_prof_begin(s);
-    hipLaunchKernelGGL((halop_kernel<T, NT, CC, NPH, PV, OCC>), dim3(chunks * nNt, sv_ngroups(a->groups)), dim3(256), lds, s, *g,
+    hipLaunchKernelGGL((halop_kernel<T, NT, CC, NPH, PV, OCC, MODE>), dim3(chunks * nNt, sv_ngroups(a->groups)), dim3(256), lds, s, *g,
                        sv_expand_groups(*g, *a, (int)sizeof(T)), c, tiles_per);
     sv_prof_end(s);
     return sv_check_launch("sv_igemm(halop)");
 }
 
-template <typename T, int NT, int CC, int NPH>
-int launch_halop(const sv_geom* g, const sv_igemm_args* a, const halo_cfg& c, size_t lds, hipStream_t s) {
+template <typename T, int NT, int CC, int NPH, int MODE>
+int launch_halop_m(const sv_geom* g, const sv_igemm_args* a, const halo_cfg& c, size_t lds, hipStream_t s) {
     // register stage size from the tile's halo; the small stages go with more resident blocks (their LDS image permitting)
     const int hvn = c.HP * (g->Cin / 8);
     if constexpr (sizeof(T) == 2 && NPH == 1) {
-        constexpr int O2 = NT == 1 ? SV_HALOP_OCC2 : SV_HALOP_OCC2B, O4 = NT == 1 ? SV_HALOP_OCC4 : SV_HALOP_OCC4B;
-        if (O2 > 2 && hvn <= 256 * 2 && lds * O2 <= 150 * 1024) return launch_halop_pv<T, NT, CC, NPH, 2, O2>(g, a, c, lds, s);
-        if (O4 > 2 && hvn <= 256 * 4 && lds * O4 <= 150 * 1024) return launch_halop_pv<T, NT, CC, NPH, 4, O4>(g, a, c, lds, s);
+        // (with the flags at compile time the variants need 20-35 registers fewer: one more resident block each)
+        constexpr int O2 = NT == 1 ? (MODE ? SV_HALOP_OCC2_M : SV_HALOP_OCC2) : (MODE ? SV_HALOP_OCC2B_M : SV_HALOP_OCC2B);
+        constexpr int O4 = NT == 1 ? (MODE ? SV_HALOP_OCC4_M : SV_HALOP_OCC4) : (MODE ? SV_HALOP_OCC4B_M : SV_HALOP_OCC4B);
+        constexpr int O6 = (NT == 1 && MODE) ? SV_HALOP_OCC6_M : 2;
+        if constexpr (O2 > 2)
+            if (hvn <= 256 * 2 && lds * O2 <= 150 * 1024) return launch_halop_pv<T, NT, CC, NPH, 2, O2, MODE>(g, a, c, lds, s);
+        if constexpr (O4 > 2)
+            if (hvn <= 256 * 4 && lds * O4 <= 150 * 1024) return launch_halop_pv<T, NT, CC, NPH, 4, O4, MODE>(g, a, c, lds, s);
+        if constexpr (O6 > 2)
+            if (lds * O6 <= 150 * 1024) return launch_halop_pv<T, NT, CC, NPH, 6, O6, MODE>(g, a, c, lds, s);
     }
-    return launch_halop_pv<T, NT, CC, NPH, 6, 2>(g, a, c, lds, s);
+    return launch_halop_pv<T, NT, CC, NPH, 6, 2, MODE>(g, a, c, lds, s);
+}
+
+// the two launch kinds the step issues most take the binaries with their fusion flags at compile time (bf16)
+template <typename T, int NT, int CC, int NPH>
+int launch_halop(const sv_geom* g, const sv_igemm_args* a, const halo_cfg& c, size_t lds, hipStream_t s) {
+#if SV_HALOP_MODES
+    if constexpr (sizeof(T) == 2) {
+        if (!a->bias && !a->residual) {
+            if (a->pro_scale && a->stats && !a->ex) return launch_halop_m<T, NT, CC, NPH, 1>(g, a, c, lds, s);
+            if (a->pro_scale && !a->stats && !a->ex) return launch_halop_m<T, NT, CC, NPH, 2>(g, a, c, lds, s);
+            if (!a->pro_scale && a->ex && !a->stats) return launch_halop_m<T, NT, CC, NPH, 3>(g, a, c, lds, s);
+        }
+    }
+#endif
+    return launch_halop_m<T, NT, CC, NPH, 0>(g, a, c, lds, s);
 }
 
 template <typename T, int CC, int NPH>
