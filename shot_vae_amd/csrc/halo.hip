@@ -406,7 +406,7 @@ __global__ __launch_bounds__(256) void halo_kernel(const sv_geom g, const sv_ige
 // requested (two register stages), the BatchNorm sums stay in registers across tiles and are flushed once per block.
 // These layers are HBM-bound (2-4.5 flop/B x C): what matters is that every input byte is fetched once and that the
 // requests never stop.
-constexpr int PMAXV = 6;        // halo vectors per thread per register stage (upper bound; the kernel is compiled for PV <= PMAXV)
+constexpr int PMAXV = 10;       // halo vectors per thread per register stage (upper bound; the kernel is compiled for PV <= PMAXV)
 
 // PV = halo vectors per thread per register stage (2 for the 16-channel layers, 4, or 6).  The small variants fit more blocks
 // per CU (OCC = blocks per CU the register budget is held to): the compiler waits for register prefetches with
@@ -722,6 +722,9 @@ int launch_halop_m(const sv_geom* g, const sv_igemm_args* a, const halo_cfg& c, 
         if constexpr (O6 > 2)
             if (lds * O6 <= 150 * 1024) return launch_halop_pv<T, NT, CC, NPH, 6, O6, MODE>(g, a, c, lds, s);
     }
+    // (the 10-vector stage: the stride-2 3x3 forward 32 -> 64, whose 128 outputs read a 17 x 33 pixel region)
+    if constexpr (NPH == 1 && sizeof(T) == 2)
+        if (hvn > 256 * 6) return launch_halop_pv<T, NT, CC, NPH, 10, 2, MODE>(g, a, c, lds, s);
     return launch_halop_pv<T, NT, CC, NPH, 6, 2, MODE>(g, a, c, lds, s);
 }
 
@@ -865,7 +868,7 @@ int sv_halo_try(const sv_geom* g, int dtype, const sv_igemm_args* a, hipStream_t
         const size_t ldsp = ((size_t)c.HP * (g->Cin + 16) + (size_t)BN * (c.tslots * g->Cin + 16)) * es + 2 * BN * 4;
         const int nT = (g->B * g->Hq + c.TR - 1) / c.TR;
         // (at most two channel tiles: every tile re-stages the input region -- 16 -> 160 as five tiles ran 564 us against 302)
-        if (ldsp <= 72 * 1024 && c.HP * (g->Cin / 8) <= 256 * PMAXV && 256 % (g->Cin / 8) == 0 && (g->N + BN - 1) / BN <= 2 &&
+        if (ldsp <= 76 * 1024 && c.HP * (g->Cin / 8) <= 256 * ((multi || dtype != SV_BF16) ? 6 : PMAXV) && 256 % (g->Cin / 8) == 0 && (g->N + BN - 1) / BN <= 2 &&
             (sv_halo_all() || nT * sv_ngroups(a->groups) >= 1024)) {       // (a few tiles per block at least; tests: any size)
             if (dtype == SV_BF16) {
                 if (CC == 16) *rc = multi ? launch_halop_nt<bf16, 16, 4>(g, a, c, nt, ldsp, s) : launch_halop_nt<bf16, 16, 1>(g, a, c, nt, ldsp, s);
