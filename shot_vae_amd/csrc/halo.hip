@@ -722,7 +722,8 @@ int launch_halop_m(const sv_geom* g, const sv_igemm_args* a, const halo_cfg& c, 
         if constexpr (O6 > 2)
             if (lds * O6 <= 150 * 1024) return launch_halop_pv<T, NT, CC, NPH, 6, O6, MODE>(g, a, c, lds, s);
     }
-    // (the 10-vector stage: the stride-2 3x3 forward 32 -> 64, whose 128 outputs read a 17 x 33 pixel region)
+    // (the 10-vector stage: the stride-2 3x3 forward 32 -> 64, whose 128 outputs read a 17 x 33 pixel region; the stride-2 1x1
+    //  shortcut of the same shape stays with the gather-GEMM -- it needs a quarter of that region: 40 us against 62)
     if constexpr (NPH == 1 && sizeof(T) == 2)
         if (hvn > 256 * 6) return launch_halop_pv<T, NT, CC, NPH, 10, 2, MODE>(g, a, c, lds, s);
     return launch_halop_pv<T, NT, CC, NPH, 6, 2, MODE>(g, a, c, lds, s);
@@ -868,7 +869,7 @@ int sv_halo_try(const sv_geom* g, int dtype, const sv_igemm_args* a, hipStream_t
         const size_t ldsp = ((size_t)c.HP * (g->Cin + 16) + (size_t)BN * (c.tslots * g->Cin + 16)) * es + 2 * BN * 4;
         const int nT = (g->B * g->Hq + c.TR - 1) / c.TR;
         // (at most two channel tiles: every tile re-stages the input region -- 16 -> 160 as five tiles ran 564 us against 302)
-        if (ldsp <= 76 * 1024 && c.HP * (g->Cin / 8) <= 256 * ((multi || dtype != SV_BF16) ? 6 : PMAXV) && 256 % (g->Cin / 8) == 0 && (g->N + BN - 1) / BN <= 2 &&
+        if (ldsp <= 76 * 1024 && c.HP * (g->Cin / 8) <= 256 * ((multi || dtype != SV_BF16 || ttot < 4) ? 6 : PMAXV) && 256 % (g->Cin / 8) == 0 && (g->N + BN - 1) / BN <= 2 &&
             (sv_halo_all() || nT * sv_ngroups(a->groups) >= 1024)) {       // (a few tiles per block at least; tests: any size)
             if (dtype == SV_BF16) {
                 if (CC == 16) *rc = multi ? launch_halop_nt<bf16, 16, 4>(g, a, c, nt, ldsp, s) : launch_halop_nt<bf16, 16, 1>(g, a, c, nt, ldsp, s);
