@@ -31,6 +31,10 @@
 #define SV_W3_EPD 1
 #endif
 
+#ifndef SV_W3_MODES
+#define SV_W3_MODES 1
+#endif
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -74,7 +78,9 @@ struct WCfg {
     static_assert(2 * LDS <= 160 * 1024, "two blocks per CU");
 };
 
-template <int NF, int WLOG, bool REV>
+// MODE: the epilogue's fusion flags at compile time (conv3x3w_epilogue.inc: 0 = from the arguments, 1 = statistics,
+// 2 = residual + statistics, 3 = activation-backward)
+template <int NF, int WLOG, bool REV, int MODE>
 __global__ __launch_bounds__(256, 2) void conv3x3w_kernel(const sv_geom g, const sv_igemm_args_g AG) {
     const sv_igemm_args& a = AG.g[blockIdx.y];
     using C = WCfg<NF, WLOG>;
@@ -347,7 +353,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3w_kernel(const sv_geom g, const
 #define SV_EPI_NSCR 1
 #define SV_EPI_BASE 0
 #define SV_EPI_ALIAS 0
-#define SV_EPI_MODE 0
+#define SV_EPI_MODE MODE
 #define SV_EPI_WAVE_SUMS 0
 #include "conv3x3w_epilogue.inc"
 #undef SV_EPI_MODE
@@ -357,24 +363,43 @@ __global__ __launch_bounds__(256, 2) void conv3x3w_kernel(const sv_geom g, const
 #undef SV_EPI_ALIAS
 }
 
-template <int NF, int WLOG, bool REV>
-int launch_w3(const sv_geom* g, const sv_igemm_args* a, hipStream_t s) {
+template <int NF, int WLOG, bool REV, int MODE>
+int launch_w4(const sv_geom* g, const sv_igemm_args* a, hipStream_t s) {
     using C = WCfg<NF, WLOG>;
     const int nT = g->B * g->Hin / C::TR, nNt = g->N / C::BN;
     const int grid = 8 * ((nT + 7) / 8) * nNt;
     const size_t lds = (size_t)C::LDS;
     static bool optin = false;
     if (!optin) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3w_kernel<NF, WLOG, REV>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3w_kernel<NF, WLOG, REV, MODE>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return sv_check_launch("hipFuncSetAttribute(conv3x3w)");
         optin = true;
     }
     SV_LAUNCH_GATE(grid, a);          // (query only: these kernels are not dispatched in deterministic mode)
     sv_prof_begin(s);
-    hipLaunchKernelGGL((conv3x3w_kernel<NF, WLOG, REV>), dim3(grid, sv_ngroups(a->groups)), dim3(256), lds, s, *g, sv_expand_groups(*g, *a, 2));
+    hipLaunchKernelGGL((conv3x3w_kernel<NF, WLOG, REV, MODE>), dim3(grid, sv_ngroups(a->groups)), dim3(256), lds, s, *g, sv_expand_groups(*g, *a, 2));
     sv_prof_end(s);
     return sv_check_launch("sv_igemm(conv3x3w)");
+}
+
+// the 128-channel tiles at 8 x 8 (the last stage of WRN-28-2, 14 launches per step) take the binaries with their fusion flags
+// at compile time; every other shape / flag combination the run-time-flag binary
+template <int NF, int WLOG, bool REV>
+int launch_w3(const sv_geom* g, const sv_igemm_args* a, hipStream_t s) {
+#if SV_W3_MODES
+    if constexpr (NF == 4 && WLOG == 3) {
+        if (!a->bias) {
+            if constexpr (REV) {
+                if (a->ex && !a->residual) return launch_w4<NF, WLOG, REV, 3>(g, a, s);
+            } else {
+                if (a->stats && a->residual && !a->ex) return launch_w4<NF, WLOG, REV, 2>(g, a, s);
+                if (a->stats && !a->residual && !a->ex) return launch_w4<NF, WLOG, REV, 1>(g, a, s);
+            }
+        }
+    }
+#endif
+    return launch_w4<NF, WLOG, REV, 0>(g, a, s);
 }
 
 template <int NF, bool REV>
