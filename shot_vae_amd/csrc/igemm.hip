@@ -17,6 +17,9 @@
 #include "common.h"
 #include "epilogue.h"
 
+#ifndef SV_IG_DMA2
+#define SV_IG_DMA2 1
+#endif
 #ifndef SV_IG_MIN_TILES
 #define SV_IG_MIN_TILES 512        // blocks a channel-tile width must yield to be taken (two per CU)
 #endif
@@ -616,6 +619,14 @@ extern "C" int sv_igemm(const sv_geom* g, int dtype, const sv_igemm_args* a_in, 
         // no load prologue (data gradients): both operands by LDS-DMA
         const bool dma = !a->pro_scale && g->Cin % 32 == 0 && g->ldx % 8 == 0 && !sv_disabled(SV_K_IGEMM_DMA);
         if (dma && g->N % 160 == 0 && mt256 * (g->N / 160) >= sv_wide_min_blocks()) return launch_dma<10, 4>(g, a, s);
+#if SV_IG_DMA2
+        // small products (under one 256-row block per CU): 128-row tiles, twice the blocks
+        {
+            const int64_t mt128 = (M + 127) / 128 * g->nphase * sv_ngroups(a->groups);
+            if (dma && g->N % 128 == 0 && mt256 * (g->N / 128) < sv_wide_min_blocks() && mt128 * (g->N / 128) >= (sv_wide_min_blocks() + 1) / 2)
+                return launch_dma<8, 2>(g, a, s);
+        }
+#endif
         if (dma && g->N % 128 == 0 && mt256 * (g->N / 128) >= (sv_wide_min_blocks() + 1) / 2) return launch_dma<8, 4>(g, a, s);
         if (g->N % 160 == 0 && mt256 * (g->N / 160) >= sv_wide_min_blocks()) return launch_kv<bf16, 10, 1, 4>(g, a, s);
         // (128-channel tiles from half a block per slot: the 4x4 stride-2 data gradient of ConvT 512 -> 256, 128 tiles, 163 -> 142 us)
