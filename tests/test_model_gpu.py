@@ -415,15 +415,23 @@ def _wrn28_10_small_batch_body():
     sch = O.schedule(10, dmi=4.6)
     st, ref = _oracle_run(name, K, il, ll, iu, nz, sch, torch.float32)
     init = O.default_init(name, K=K, seed=5)
-    model = make_model(name, K, "bf16", init, dp=True)
+    # the wide kernels accumulate BatchNorm statistics through float atomics (they are not dispatched in deterministic mode):
+    # the loss scalars of one run carry that order noise -- cont_post_l, a difference of two KL terms on a bf16 forward at
+    # B = 16, was seen at 1.03e-2 once in ~15 runs.  As for the other atomic-path gates: the MEDIAN of five runs at 1e-2,
+    # every single run at 2e-2; everything else is checked on the last run
     elbo, cls = S.VAECriterion(discrete_dim=K, bce_reconstruction=True).cuda(), S.ClsCriterion()
-    S.FlatSGD(model).zero_grad()
-    with T.rng_for_step(nz):
-        out = S.train_step(model, elbo, cls, None, il.cuda(), ll.cuda(), iu.cuda(), sch, return_outputs=True)
-    torch.cuda.synchronize()
+    runs = []
+    for rep in range(5):
+        model = make_model(name, K, "bf16", init, dp=True)
+        S.FlatSGD(model).zero_grad()
+        with T.rng_for_step(nz):
+            out = S.train_step(model, elbo, cls, None, il.cuda(), ll.cuda(), iu.cuda(), sch, return_outputs=True)
+        torch.cuda.synchronize()
+        runs.append({k: float(out[k]) for k in T.SCALARS})
     for k in T.SCALARS:
         r = float(ref[k])
-        assert abs(float(out[k]) - r) <= 1e-2 * max(abs(r), 1e-6), (k, float(out[k]), r)
+        errs = sorted(abs(v[k] - r) / max(abs(r), 1e-6) for v in runs)
+        assert errs[2] <= 1e-2 and errs[-1] <= 2e-2, (k, errs, r)
     for k in T.TENSORS:
         e = T.rel_err(out[k].float().cpu().numpy(), ref[k].numpy())
         assert e < 5e-2, (k, e)
