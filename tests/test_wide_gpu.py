@@ -156,7 +156,7 @@ def test_config4_full_size_step_default_dispatch_repeats():
     opt.zero_grad()
     ilc, llc, iuc = il.cuda(), ll.cuda(), iu.cuda()
     load = _HbmLoad()
-    first, g0, worst_cos = None, None, 1.0
+    first, g0, worst_cos, full_runs = None, None, 1.0, []
     for rep in range(20):
         opt.zero_grad()
         if rep % 4 == 3:
@@ -175,6 +175,8 @@ def test_config4_full_size_step_default_dispatch_repeats():
         grad = model.flat_parameters()[1].detach().clone()
         assert all(np.isfinite(v) for v in vals.values()), (rep, vals)
         assert bool(torch.isfinite(grad).all()), rep
+        if rep < 10:
+            full_runs.append(vals)
         if rep == 0:
             first, g0 = vals, grad
             for i in (1, 2, 3, 4):            # size-independent properties of the first run's outputs
@@ -201,6 +203,8 @@ def test_config4_full_size_step_default_dispatch_repeats():
     st = {k: v.clone() for k, v in init.items()}
     with torch.no_grad():
         ref = O.train_step(st, name, il, ll, iu, nz, sch, backward=False)
+    # (atomic accumulation: the median of the ten sequential runs at the gate, every single run at twice the gate)
     for k in T.SCALARS:
         r = float(ref[k])
-        assert abs(first[k] - r) <= 1e-2 * max(abs(r), 1e-6), (k, first[k], r)
+        errs = sorted(abs(v[k] - r) / max(abs(r), 1e-6) for v in full_runs)
+        assert errs[len(errs) // 2] <= 1e-2 and errs[-1] <= 2e-2, (k, errs, r)
