@@ -67,7 +67,7 @@ def test_grouped_step_default_engine_state_at_full_size(name, K, B, dmi, tol):
     opt = S.FlatSGD(model)
     state0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
     load = _HbmLoad()
-    first, g0, worst_cos = None, None, 1.0
+    first, g0, worst_cos, all_vals = None, None, 1.0, []
     for rep in range(10):
         model.load_state_dict(state0)          # same parameters AND running statistics every repeat
         opt.zero_grad()
@@ -77,6 +77,7 @@ def test_grouped_step_default_engine_state_at_full_size(name, K, B, dmi, tol):
             out = S.train_step_grouped(model, elbo, cls, None, ilc, llc, iuc, sch, return_outputs=True)
         torch.cuda.synchronize()
         vals = {k: float(out[k]) for k in T.SCALARS}
+        all_vals.append(vals)
         grad = model.flat_parameters()[1].detach().double().clone()
         assert all(np.isfinite(v) for v in vals.values()), (rep, vals)
         assert bool(torch.isfinite(grad).all()), rep
@@ -104,15 +105,18 @@ def test_grouped_step_default_engine_state_at_full_size(name, K, B, dmi, tol):
             nbt = [int(v) for k, v in model.state_dict().items() if k.endswith("num_batches_tracked")]
             assert set(nbt) == {4}
         else:
-            # the same step again: only the order of the float atomics may differ
-            for k, v in vals.items():
-                # (the posterior terms are differences between the outputs of two forwards: twice the spread, as everywhere)
-                tk = 4e-3 if "_post_" in k else 2e-3
-                assert abs(v - first[k]) <= tk * max(abs(first[k]), 1e-3), (rep, k, v, first[k])
             cos = float(grad @ g0 / grad.norm() / g0.norm())
             worst_cos = min(worst_cos, cos)
             assert cos > 0.9, (rep, cos)
     print("[%s B=%d] 10 repeats of the timed path: lowest gradient cosine against the first %.4f" % (name, B, worst_cos))
+    # the same step ten times: only the order of the float atomics may differ -- every run within the spread of the MEDIAN run
+    # (a single reference run may itself be the outlier; the posterior terms are differences between the outputs of two
+    # forwards: twice the spread, as everywhere)
+    med = {k: sorted(v[k] for v in all_vals)[len(all_vals) // 2] for k in all_vals[0]}
+    for rep, v in enumerate(all_vals):
+        for k in v:
+            tk = 4e-3 if "_post_" in k else 2e-3
+            assert abs(v[k] - med[k]) <= tk * max(abs(med[k]), 1e-3), (rep, k, v[k], med[k])
     # (c) loss terms against the fp32 CPU oracle on the same inputs and noise
     st = {k: v.clone() for k, v in init.items()}
     with torch.no_grad():
@@ -120,7 +124,7 @@ def test_grouped_step_default_engine_state_at_full_size(name, K, B, dmi, tol):
     for k in T.SCALARS:
         r = float(orc[k])
         tk = 2 * tol if "_post_" in k else tol
-        assert abs(first[k] - r) <= tk * max(abs(r), 1e-6), ("vs fp32 oracle", k, first[k], r)
+        assert abs(med[k] - r) <= tk * max(abs(r), 1e-6), ("median run vs fp32 oracle", k, med[k], r)
 
 
 # Cin, H, N, images per group: the WRN-28-10 body at config 4's grouped size and the WRN-28-2 body at config 2's

@@ -156,7 +156,7 @@ def test_config4_full_size_step_default_dispatch_repeats():
     opt.zero_grad()
     ilc, llc, iuc = il.cuda(), ll.cuda(), iu.cuda()
     load = _HbmLoad()
-    first, g0, worst_cos, full_runs = None, None, 1.0, []
+    first, g0, worst_cos, full_runs, all_vals = None, None, 1.0, [], []
     for rep in range(20):
         opt.zero_grad()
         if rep % 4 == 3:
@@ -187,18 +187,22 @@ def test_config4_full_size_step_default_dispatch_repeats():
             assert abs(float(klc) - vals["klc_l"]) < 1e-3 * float(klc)
             assert 0.0 <= vals["kld_l"] <= np.log(K) + 1e-4
         else:
-            # the same step again: only the order of float atomics (BN statistics, gradient accumulation) may differ
-            # (the posterior terms are a difference of two KLs on a bf16 forward: twice the spread, measured 2.4e-3 once in
-            #  30 full-size repeats)
-            for k, v in vals.items():
-                tk = 4e-3 if "_post_" in k else 2e-3
-                assert abs(v - first[k]) <= tk * max(abs(first[k]), 1e-3), (rep, k, v, first[k])
+            all_vals.append(vals)
             # (bf16 rounding makes this step's gradient ill-conditioned -- DESIGN.md: cosine 0.91-0.97 against fp64 -- and
             #  a 1e-7 change of a BatchNorm statistic re-draws that rounding noise: two runs agree to ~0.97, measured)
             cos = float((grad.double() @ g0.double()) / grad.double().norm() / g0.double().norm())
             worst_cos = min(worst_cos, cos)
             assert cos > 0.9, (rep, cos)
     print("\n[config 4, 20 repeats] lowest gradient cosine against the first run %.4f" % worst_cos)
+    # the same step again and again: only the order of float atomics (BN statistics, gradient accumulation) may differ --
+    # every run within the spread of the MEDIAN run (the posterior terms, a difference of two KLs on a bf16 forward: twice
+    # the spread; 2.4e-3 measured once in 30 full-size repeats)
+    for k in first:
+        runs_k = [v[k] for v in [first] + all_vals if k in v]
+        mk = sorted(runs_k)[len(runs_k) // 2]
+        tk = 4e-3 if "_post_" in k else 2e-3
+        for rep, v in enumerate(runs_k):
+            assert abs(v - mk) <= tk * max(abs(mk), 1e-3), (rep, k, v, mk)
     # loss terms against the fp32 CPU oracle on the same inputs (bf16 tolerance of SURVEY.md 8d, doubled for K = 100)
     st = {k: v.clone() for k, v in init.items()}
     with torch.no_grad():
