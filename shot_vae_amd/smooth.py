@@ -430,7 +430,9 @@ def smooth_train_step(model, loss_fn, optimizer, unlabeled_data, labeled_data, l
 
 
 class GraphedSmoothStep:
-    """One trainer iteration (both forwards, the loss, backward, Adam) captured once into a hipGraph and replayed: the
+    """(Do not capture while an RCCL (`nccl`) process group has work in flight: its watchdog thread polls events, which is an
+    error during another thread's stream capture on this stack -- bench.py issues eagerly in that case.)
+    One trainer iteration (both forwards, the loss, backward, Adam) captured once into a hipGraph and replayed: the
     eager iteration is ~120 kernel launches plus torch glue and entirely host-bound (7 ms at batch 1024; SURVEY.md §8d
     config 5).  The optimizer must be graph-capturable (torch.optim.Adam(..., capturable=True)); the capacity schedule
     follows a device-side step counter; noise comes from torch's graph-safe Philox generator."""

@@ -354,7 +354,9 @@ def m2_train_step(model, elbo_criterion, cls_criterion, optimizer, image_l, labe
 
 
 class GraphedTrainStep:
-    """The two-stream step captured once into a hipGraph and replayed: ~1100 kernel launches per step stop costing
+    """(Do not capture while an RCCL (`nccl`) process group has work in flight: its watchdog thread polls events, which is an
+    error during another thread's stream capture on this stack -- bench.py issues eagerly in that case.)
+    The two-stream step captured once into a hipGraph and replayed: ~1100 kernel launches per step stop costing
     ~12 ms of host time (measured: the eager step is host-bound below that).  The graph holds the weight re-packing,
     the four forwards, both backwards and the deferred BN running-stat updates; the gradient all-reduce and the SGD
     kernel stay outside (eager), so the collective is an ordinary RCCL call and lr can change without re-capturing.

@@ -382,9 +382,11 @@ def test_step_matches_oracle_b64(dtype, tol_s, tol_t, tol_g):
 
 def test_step_matches_oracle_b64_bf16_atomic_path_median():
     """The same step through the production accumulation (float atomics; which bf16 roundings flip depends on the order of
-    the adders): the MEDIAN of five runs meets the same gates as the deterministic run, every single run torch-autocast's
+    the adders): the MEDIAN of nine runs meets the same gates as the deterministic run, every single run torch-autocast's
     own figures (the sanity bound the round-2 gate had drifted to)."""
-    runs = [_b64_run("bf16") for _ in range(5)]
+    # (nine runs: the draws of one process are correlated -- three of five cont_post_u errors at 5.1-5.7e-3 were seen once in
+    #  ~30 executions of this test, 24 single runs of tools/probes/b64_noise.py stay below 4.9e-3)
+    runs = [_b64_run("bf16") for _ in range(9)]
     med = lambda xs: sorted(xs)[len(xs) // 2]
     print("\n[bf16, atomic path] cosines %s" % ["%.4f" % r["cos"] for r in runs])
     for k in T.SCALARS:
