@@ -20,6 +20,9 @@
 #ifndef SV_IG_DMA2
 #define SV_IG_DMA2 2
 #endif
+#ifndef SV_IG_DMA2_UPTO
+#define SV_IG_DMA2_UPTO 2      // 128-row tiles while the 256-row tiles give fewer than this many blocks per CU (1 / 4 measured slower)
+#endif
 #ifndef SV_IG_DMA2_MIN
 #define SV_IG_DMA2_MIN 256     // blocks the 128 x 128 tiles must yield (below: 128 x 64)
 #endif
@@ -626,7 +629,7 @@ extern "C" int sv_igemm(const sv_geom* g, int dtype, const sv_igemm_args* a_in, 
         // small products (under one 256-row block per CU): 128-row tiles, twice the blocks
         {
             const int64_t mt128 = (M + 127) / 128 * g->nphase * sv_ngroups(a->groups);
-            if (dma && g->N % 128 == 0 && mt256 * (g->N / 128) < sv_wide_min_blocks() && mt128 * (g->N / 128) >= SV_IG_DMA2_MIN)
+            if (dma && g->N % 128 == 0 && mt256 * (g->N / 128) < SV_IG_DMA2_UPTO * sv_wide_min_blocks() && mt128 * (g->N / 128) >= SV_IG_DMA2_MIN)
                 return launch_dma<8, 2>(g, a, s);
 #if SV_IG_DMA2 > 1
             // ... and 128 x 64 tiles where even those leave half the chip idle (long-K products of the small decoder layers)
