@@ -18,7 +18,7 @@
 #include "epilogue.h"
 
 #ifndef SV_IG_DMA2
-#define SV_IG_DMA2 2
+#define SV_IG_DMA2 3
 #endif
 #ifndef SV_IG_DMA2_UPTO
 #define SV_IG_DMA2_UPTO 2      // 128-row tiles while the 256-row tiles give fewer than this many blocks per CU (1 / 4 measured slower)
@@ -633,6 +633,12 @@ extern "C" int sv_igemm(const sv_geom* g, int dtype, const sv_igemm_args* a_in, 
                 return launch_dma<8, 2>(g, a, s);
 #if SV_IG_DMA2 > 1
             // ... and 128 x 64 tiles where even those leave half the chip idle (long-K products of the small decoder layers)
+#if SV_IG_DMA2 > 2
+            // ... 128 x 32 tiles where 128 x 64 give under two blocks per CU and these give at least that
+            if (dma && g->N % 32 == 0 && mt128 * (g->N / 128) < SV_IG_DMA2_MIN && mt128 * (g->N / 64) < 2 * sv_wide_min_blocks() &&
+                mt128 * (g->N / 32) >= 2 * sv_wide_min_blocks())
+                return launch_dma<2, 2>(g, a, s);
+#endif
             if (dma && g->N % 64 == 0 && mt128 * (g->N / 128) < SV_IG_DMA2_MIN && mt128 * (g->N / 64) >= (sv_wide_min_blocks() + 1) / 2)
                 return launch_dma<4, 2>(g, a, s);
 #endif
