@@ -20,12 +20,6 @@
 #ifndef SV_IG_DMA2
 #define SV_IG_DMA2 3
 #endif
-#ifndef SV_IG_DMA2_UPTO
-#define SV_IG_DMA2_UPTO 2      // 128-row tiles while the 256-row tiles give fewer than this many blocks per CU (1 / 4 measured slower)
-#endif
-#ifndef SV_IG_DMA2_MIN
-#define SV_IG_DMA2_MIN 256     // blocks the 128 x 128 tiles must yield (below: 128 x 64)
-#endif
 #ifndef SV_IG_MIN_TILES
 #define SV_IG_MIN_TILES 512        // blocks a channel-tile width must yield to be taken (two per CU)
 #endif
@@ -626,22 +620,26 @@ extern "C" int sv_igemm(const sv_geom* g, int dtype, const sv_igemm_args* a_in, 
         const bool dma = !a->pro_scale && g->Cin % 32 == 0 && g->ldx % 8 == 0 && !sv_disabled(SV_K_IGEMM_DMA);
         if (dma && g->N % 160 == 0 && mt256 * (g->N / 160) >= sv_wide_min_blocks()) return launch_dma<10, 4>(g, a, s);
 #if SV_IG_DMA2
-        // small products (under one 256-row block per CU): 128-row tiles, twice the blocks
-        {
+        // Small products (the decoder's ConvTranspose layers and their data gradients): while the 256-row tiles give fewer
+        // than two blocks per CU, 128-row tiles of the WIDEST channel extent (128 / 64 / 32) that still yields two blocks per
+        // CU -- the kernel needs its second resident block to cover the k loop's latency -- else the narrowest one
+        // (measured at 4 x 512 / 2 x 512 images: ConvT 1024->512 forward 43 -> 36 us, 512->256 forward 74 -> 60,
+        //  512->256 data gradient 88 -> 69, 256->128 data gradient 68 -> 55, 128->64 data gradient 60 -> 44 us)
+        if (dma && g->N % 32 == 0 && mt256 * ((g->N + 127) / 128) < 2 * sv_wide_min_blocks()) {
             const int64_t mt128 = (M + 127) / 128 * g->nphase * sv_ngroups(a->groups);
-            if (dma && g->N % 128 == 0 && mt256 * (g->N / 128) < SV_IG_DMA2_UPTO * sv_wide_min_blocks() && mt128 * (g->N / 128) >= SV_IG_DMA2_MIN)
-                return launch_dma<8, 2>(g, a, s);
-#if SV_IG_DMA2 > 1
-            // ... and 128 x 64 tiles where even those leave half the chip idle (long-K products of the small decoder layers)
-#if SV_IG_DMA2 > 2
-            // ... 128 x 32 tiles where 128 x 64 give under two blocks per CU and these give at least that
-            if (dma && g->N % 32 == 0 && mt128 * (g->N / 128) < SV_IG_DMA2_MIN && mt128 * (g->N / 64) < 2 * sv_wide_min_blocks() &&
-                mt128 * (g->N / 32) >= 2 * sv_wide_min_blocks())
+            const int64_t two = 2 * sv_wide_min_blocks();
+            const bool ok8 = g->N % 128 == 0, ok4 = g->N % 64 == 0;
+            if (mt128 * (g->N / 32) >= (sv_wide_min_blocks() + 1) / 2) {
+                if (ok8 && mt128 * (g->N / 128) >= two) return launch_dma<8, 2>(g, a, s);
+                if (ok4 && mt128 * (g->N / 64) >= two) return launch_dma<4, 2>(g, a, s);
+#if SV_IG_DMA2 > 3
                 return launch_dma<2, 2>(g, a, s);
+#else
+                if (mt128 * (g->N / 32) >= sv_wide_min_blocks()) return launch_dma<2, 2>(g, a, s);      // at least one block per CU
+                if (ok4 && mt128 * (g->N / 64) >= (sv_wide_min_blocks() + 1) / 2) return launch_dma<4, 2>(g, a, s);
+                if (ok8 && mt128 * (g->N / 128) >= (sv_wide_min_blocks() + 1) / 2) return launch_dma<8, 2>(g, a, s);
 #endif
-            if (dma && g->N % 64 == 0 && mt128 * (g->N / 128) < SV_IG_DMA2_MIN && mt128 * (g->N / 64) >= (sv_wide_min_blocks() + 1) / 2)
-                return launch_dma<4, 2>(g, a, s);
-#endif
+            }
         }
 #endif
         if (dma && g->N % 128 == 0 && mt256 * (g->N / 128) >= (sv_wide_min_blocks() + 1) / 2) return launch_dma<8, 4>(g, a, s);
