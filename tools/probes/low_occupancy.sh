@@ -12,7 +12,8 @@ for r in rows:
     d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
     k = (r["Kernel_Name"][:70], nwg, wg)
     agg[k][0] += 1; agg[k][1] += d
-out = [(v[1] / v[0], v[0], k) for k, v in agg.items() if k[1] < 512 and v[1] / v[0] > 20]
+lim = int(__import__("os").environ.get("SV_LO_WGS", "512"))
+out = [(v[1] / v[0], v[0], k) for k, v in agg.items() if k[1] < lim and v[1] / v[0] > 20]
 for avg, n, k in sorted(out, reverse=True)[:40]:
     print("%7.1f us x%4d  wgs %5d x %3d  %s" % (avg, n, k[1], k[2], k[0]))
 PY
