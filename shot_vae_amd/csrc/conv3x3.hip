@@ -12,6 +12,9 @@
 #include "common.h"
 #include "epilogue.h"
 
+#ifndef SV_C3P_WREG
+#define SV_C3P_WREG 1
+#endif
 #ifndef SV_C3P_MODES
 #define SV_C3P_MODES 1         // fusion flags of conv3x3p at compile time for the step's three launch kinds (0: run-time flags only)
 #endif
@@ -337,6 +340,16 @@ __global__ __launch_bounds__(256, SV_C3P_WAVES) void conv3x3p_kernel(const sv_ge
     if (t_begin + 1 < t_end) load_halo(HB, t_begin + 1);
     store_halo(HA);
     __syncthreads();
+    // 32 input channels: the block's 18 weight fragments stay in registers (72 of them: with the fusion flags at compile time
+    // the variants hold 152-176 without) -- the nine taps read only the pixel fragments from LDS
+    constexpr bool WREG = SV_C3P_WREG && CCH == 1 && sizeof(T) == 2 && MODE != 0;
+    V wr[WREG ? 9 : 1][NT];
+    if (WREG) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int i = 0; i < NT; ++i) wr[t][i] = *reinterpret_cast<const V*>(wl + ((16 * i + fr) * 9 + t) * LDW + 8 * fq);
+    }
     // one tile of the pipeline; NEXT holds tile+1 (already requested), FREE receives the request for tile+2
     auto do_tile = [&](int tile, HStage& NEXT, HStage& FREE) {
         const int gr0 = tile * TR;
@@ -370,7 +383,7 @@ __global__ __launch_bounds__(256, SV_C3P_WAVES) void conv3x3p_kernel(const sv_ge
                 const V af1 = *reinterpret_cast<const V*>(halo + hbase[1] + sh + 32 * ck);
 #pragma unroll
                 for (int i = 0; i < NT; ++i) {
-                    const V wf = *reinterpret_cast<const V*>(wl + ((16 * i + fr) * 9 + t) * LDW + 32 * ck + 8 * fq);
+                    const V wf = WREG ? wr[WREG ? t : 0][i] : *reinterpret_cast<const V*>(wl + ((16 * i + fr) * 9 + t) * LDW + 32 * ck + 8 * fq);
                     mma32(acc[i][0], wf, af0);
                     mma32(acc[i][1], wf, af1);
                 }

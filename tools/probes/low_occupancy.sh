@@ -1,6 +1,6 @@
 # kernels of one step whose grid gives fewer than two workgroups per CU (512) and that run longer than 20 us
 cd /tmp && export TMPDIR=/tmp; rm -rf /tmp/lo
-rocprofv3 --kernel-trace --output-format csv -d /tmp/lo -o t -- python3 /root/repo/bench.py --steps 4 --warmup 3 --no-cpu-baseline --no-roofline --no-extras --wgrad-side 0 > /dev/null 2>&1
+rocprofv3 --kernel-trace --output-format csv -d /tmp/lo -o t -- python3 /root/repo/bench.py --steps 4 --warmup 3 --no-cpu-baseline --no-roofline --no-extras --wgrad-side 0 $SV_LO_ARGS > /dev/null 2>&1
 F=$(find /tmp/lo -name "*kernel_trace.csv" | head -1)
 python3 - "$F" <<'PY'
 import csv, sys, collections
