@@ -43,10 +43,8 @@
 #ifndef SV_X3_NOP
 #define SV_X3_NOP 1
 #endif
-#if SV_X3_NOP == 1
+#if SV_X3_NOP
 #define SV_X3_PRE "s_nop 1\n\t"
-#elif SV_X3_NOP == 3
-#define SV_X3_PRE "s_nop 3\n\t"
 #else
 #define SV_X3_PRE
 #endif

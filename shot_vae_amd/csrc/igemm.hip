@@ -18,7 +18,7 @@
 #include "epilogue.h"
 
 #ifndef SV_IG_DMA2
-#define SV_IG_DMA2 3
+#define SV_IG_DMA2 1            // 128-row LDS-DMA tiles for the small products (0: off, for A/B runs with tools/ab.sh)
 #endif
 #ifndef SV_IG_MIN_TILES
 #define SV_IG_MIN_TILES 512        // blocks a channel-tile width must yield to be taken (two per CU)
@@ -632,13 +632,9 @@ extern "C" int sv_igemm(const sv_geom* g, int dtype, const sv_igemm_args* a_in, 
             if (mt128 * (g->N / 32) >= (sv_wide_min_blocks() + 1) / 2) {
                 if (ok8 && mt128 * (g->N / 128) >= two) return launch_dma<8, 2>(g, a, s);
                 if (ok4 && mt128 * (g->N / 64) >= two) return launch_dma<4, 2>(g, a, s);
-#if SV_IG_DMA2 > 3
-                return launch_dma<2, 2>(g, a, s);
-#else
                 if (mt128 * (g->N / 32) >= sv_wide_min_blocks()) return launch_dma<2, 2>(g, a, s);      // at least one block per CU
                 if (ok4 && mt128 * (g->N / 64) >= (sv_wide_min_blocks() + 1) / 2) return launch_dma<4, 2>(g, a, s);
                 if (ok8 && mt128 * (g->N / 128) >= (sv_wide_min_blocks() + 1) / 2) return launch_dma<8, 2>(g, a, s);
-#endif
             }
         }
 #endif
