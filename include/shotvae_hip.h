@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define SV_ABI_VERSION 3
+#define SV_ABI_VERSION 4
 
 enum { SV_F32 = 0, SV_BF16 = 1 };
 enum { SV_OK = 0, SV_E_ARG = -1, SV_E_SHAPE = -2, SV_E_HIP = -3 };
@@ -279,6 +279,27 @@ typedef struct {
     float* d_rec; float* d_mu; float* d_ls; float* d_la;
 } sv_shot_loss_args;
 int sv_shot_loss_step(const sv_shot_loss_args* a, void* stream);
+
+/* ABI 4: the same stage for a step whose forwards were NOT one batched launch of four equal groups -- the ragged last
+ * batch of an epoch (main_shot_vae.py:280 zips a 4 000-label loader, 7 x 512 + 416, with the unlabelled one: B_l != B_u)
+ * and --om (lib/utils/mixup.py:9-18: the pairing of forward (4) needs the outputs of forward (3)).  Every group has its own
+ * pointers, order (1)(3)(2)(4) as above; groups (1), (2) have Bl rows, (3), (4) Bu rows; rec / d_rec: groups (1), (3).
+ * tgt [2 Bl D + 2 Bu D + Bl K + Bu K].  sv_shot_targets2 = sv_shot_targets with the two batch sizes.                     */
+typedef struct {
+    const float* rec[2]; const float* mu[4]; const float* ls[4]; const float* la[4];
+    const float* image_l; const float* image_u;
+    const int64_t* label_l; const int64_t* perm_l; const int64_t* perm_u;
+    float lam_l; const float* lam_l_dev; float lam_u; const float* lam_u_dev;
+    int32_t Bl, Bu, D, K, bce, reserved0; int64_t n_per_img; float x_sigma;
+    sv_shot_schedule sch;
+    float* terms; float* coef; float* tgt;
+    float* d_rec[2]; float* d_mu[4]; float* d_ls[4]; float* d_la[4];
+} sv_shot_loss_args2;
+int sv_shot_loss_step2(const sv_shot_loss_args2* a, void* stream);
+int sv_shot_targets2(const float* mu_l, const float* ls_l, const float* mu_u, const float* ls_u, const float* la_u,
+                     const int64_t* label_l, const int64_t* perm_l, const int64_t* perm_u, float lam_l, const float* lam_l_dev,
+                     float lam_u, const float* lam_u_dev, int Bl, int Bu, int D, int K, float* sm_mu, float* sm_sigma, float* lab_mix,
+                     float* mx_mu, float* mx_sigma, float* mx_alpha, void* stream);
 
 /* ---- K18 optimal-match pairing (lib/utils/mixup.py:9-18,93-99): index[i] = argmin_{j!=rank0} ----
  * second-smallest entry of row i of the pairwise Gaussian-KL matrix.                               */

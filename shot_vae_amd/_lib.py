@@ -68,6 +68,16 @@ class SvShotLossArgs(C.Structure):
                 ("d_rec", C.c_void_p), ("d_mu", C.c_void_p), ("d_ls", C.c_void_p), ("d_la", C.c_void_p)]
 
 
+class SvShotLossArgs2(C.Structure):
+    _fields_ = [("rec", C.c_void_p * 2), ("mu", C.c_void_p * 4), ("ls", C.c_void_p * 4), ("la", C.c_void_p * 4),
+                ("image_l", C.c_void_p), ("image_u", C.c_void_p), ("label_l", C.c_void_p), ("perm_l", C.c_void_p),
+                ("perm_u", C.c_void_p), ("lam_l", C.c_float), ("lam_l_dev", C.c_void_p), ("lam_u", C.c_float),
+                ("lam_u_dev", C.c_void_p), ("Bl", C.c_int32), ("Bu", C.c_int32), ("D", C.c_int32), ("K", C.c_int32),
+                ("bce", C.c_int32), ("reserved0", C.c_int32), ("n_per_img", C.c_int64), ("x_sigma", C.c_float),
+                ("sch", SvShotSchedule), ("terms", C.c_void_p), ("coef", C.c_void_p), ("tgt", C.c_void_p),
+                ("d_rec", C.c_void_p * 2), ("d_mu", C.c_void_p * 4), ("d_ls", C.c_void_p * 4), ("d_la", C.c_void_p * 4)]
+
+
 class SvBnBranch(C.Structure):
     _fields_ = [("g", C.c_void_p), ("bsums", C.c_void_p), ("gamma", C.c_void_p), ("dgamma", C.c_void_p),
                 ("dbeta", C.c_void_p), ("replicas", C.c_int32), ("sparse", C.c_int32)]
@@ -106,6 +116,8 @@ _PROTOS = {
     "sv_shot_compose": [P, C.POINTER(SvShotSchedule), P, P],
     "sv_shot_scale": [P, P, P, P, P],
     "sv_shot_loss_step": [C.POINTER(SvShotLossArgs), P],
+    "sv_shot_loss_step2": [C.POINTER(SvShotLossArgs2), P],
+    "sv_shot_targets2": [P, P, P, P, P, P, P, P, F, P, F, P, I, I, I, I, P, P, P, P, P, P, P],
     "sv_sgd": [P, P, P, I64, F, F, F, F, I, P],
     "sv_adam": [P, P, P, P, I64, F, F, F, F, F, P, F, P],
     "sv_smooth_latent_fwd": [I, P, I, P, P, P, F, I, I, I, I, I, P, P, P, P, P, P, P],

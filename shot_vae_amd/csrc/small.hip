@@ -958,25 +958,34 @@ __global__ __launch_bounds__(256) void rank_perm_kernel(const float* keys, int n
 __global__ __launch_bounds__(256) void shot_targets_kernel(const float* mu_l, const float* ls_l, const float* mu_u, const float* ls_u,
                                                            const float* la_u, const int64_t* label_l, const int64_t* perm_l,
                                                            const int64_t* perm_u, float lam_l, const float* lam_l_dev, float lam_u,
-                                                           const float* lam_u_dev, int B, int D, int K, float* sm_mu,
+                                                           const float* lam_u_dev, int Bl, int Bu, int D, int K, float* sm_mu,
                                                            float* sm_sigma, float* lab_mix, float* mx_mu, float* mx_sigma,
                                                            float* mx_alpha) {
     if (lam_l_dev) lam_l = lam_l_dev[0];
     if (lam_u_dev) lam_u = lam_u_dev[0];
-    const int b = blockIdx.x;
-    const int64_t pl = perm_l[b], pu = perm_u[b];
-    for (int j = threadIdx.x; j < D; j += blockDim.x) {
-        const int64_t i = (int64_t)b * D + j;
-        sm_mu[i] = lam_l * mu_l[i] + (1.f - lam_l) * mu_l[pl * D + j];
-        sm_sigma[i] = lam_l * expf(ls_l[i]) + (1.f - lam_l) * expf(ls_l[pl * D + j]);
-        mx_mu[i] = lam_u * mu_u[i] + (1.f - lam_u) * mu_u[pu * D + j];
-        mx_sigma[i] = lam_u * expf(ls_u[i]) + (1.f - lam_u) * expf(ls_u[pu * D + j]);
+    const int b = blockIdx.x;          // grid = max(Bl, Bu): the two loaders' batches may differ (the last labelled batch of an epoch)
+    if (b < Bl) {
+        const int64_t pl = perm_l[b];
+        for (int j = threadIdx.x; j < D; j += blockDim.x) {
+            const int64_t i = (int64_t)b * D + j;
+            sm_mu[i] = lam_l * mu_l[i] + (1.f - lam_l) * mu_l[pl * D + j];
+            sm_sigma[i] = lam_l * expf(ls_l[i]) + (1.f - lam_l) * expf(ls_l[pl * D + j]);
+        }
+        const int ya = (int)label_l[b], yb = (int)label_l[pl];
+        for (int k = threadIdx.x; k < K; k += blockDim.x)
+            lab_mix[(int64_t)b * K + k] = lam_l * (k == ya ? 1.f : 0.f) + (1.f - lam_l) * (k == yb ? 1.f : 0.f);
     }
-    const int ya = (int)label_l[b], yb = (int)label_l[pl];
-    for (int k = threadIdx.x; k < K; k += blockDim.x) {
-        const int64_t i = (int64_t)b * K + k;
-        lab_mix[i] = lam_l * (k == ya ? 1.f : 0.f) + (1.f - lam_l) * (k == yb ? 1.f : 0.f);
-        mx_alpha[i] = lam_u * expf(la_u[i]) + (1.f - lam_u) * expf(la_u[pu * K + k]);
+    if (b < Bu) {
+        const int64_t pu = perm_u[b];
+        for (int j = threadIdx.x; j < D; j += blockDim.x) {
+            const int64_t i = (int64_t)b * D + j;
+            mx_mu[i] = lam_u * mu_u[i] + (1.f - lam_u) * mu_u[pu * D + j];
+            mx_sigma[i] = lam_u * expf(ls_u[i]) + (1.f - lam_u) * expf(ls_u[pu * D + j]);
+        }
+        for (int k = threadIdx.x; k < K; k += blockDim.x) {
+            const int64_t i = (int64_t)b * K + k;
+            mx_alpha[i] = lam_u * expf(la_u[i]) + (1.f - lam_u) * expf(la_u[pu * K + k]);
+        }
     }
 }
 
@@ -1848,11 +1857,19 @@ int sv_shot_targets(const float* mu_l, const float* ls_l, const float* mu_u, con
                     const int64_t* label_l, const int64_t* perm_l, const int64_t* perm_u, float lam_l, const float* lam_l_dev,
                     float lam_u, const float* lam_u_dev, int B, int D, int K, float* sm_mu, float* sm_sigma, float* lab_mix,
                     float* mx_mu, float* mx_sigma, float* mx_alpha, void* stream) {
+    return sv_shot_targets2(mu_l, ls_l, mu_u, ls_u, la_u, label_l, perm_l, perm_u, lam_l, lam_l_dev, lam_u, lam_u_dev, B, B, D, K, sm_mu,
+                            sm_sigma, lab_mix, mx_mu, mx_sigma, mx_alpha, stream);
+}
+
+int sv_shot_targets2(const float* mu_l, const float* ls_l, const float* mu_u, const float* ls_u, const float* la_u,
+                     const int64_t* label_l, const int64_t* perm_l, const int64_t* perm_u, float lam_l, const float* lam_l_dev,
+                     float lam_u, const float* lam_u_dev, int Bl, int Bu, int D, int K, float* sm_mu, float* sm_sigma, float* lab_mix,
+                     float* mx_mu, float* mx_sigma, float* mx_alpha, void* stream) {
     SvProfScope prof_scope(stream);
     SV_REQUIRE(mu_l && ls_l && mu_u && ls_u && la_u && label_l && perm_l && perm_u && sm_mu && sm_sigma && lab_mix && mx_mu &&
-               mx_sigma && mx_alpha && B > 0 && D > 0 && K > 0, SV_E_ARG, "sv_shot_targets: bad argument");
-    hipLaunchKernelGGL(shot_targets_kernel, dim3(B), dim3(128), 0, (hipStream_t)stream, mu_l, ls_l, mu_u, ls_u, la_u, label_l,
-                       perm_l, perm_u, lam_l, lam_l_dev, lam_u, lam_u_dev, B, D, K, sm_mu, sm_sigma, lab_mix, mx_mu, mx_sigma,
+               mx_sigma && mx_alpha && Bl > 0 && Bu > 0 && D > 0 && K > 0, SV_E_ARG, "sv_shot_targets: bad argument");
+    hipLaunchKernelGGL(shot_targets_kernel, dim3(Bl > Bu ? Bl : Bu), dim3(128), 0, (hipStream_t)stream, mu_l, ls_l, mu_u, ls_u, la_u, label_l,
+                       perm_l, perm_u, lam_l, lam_l_dev, lam_u, lam_u_dev, Bl, Bu, D, K, sm_mu, sm_sigma, lab_mix, mx_mu, mx_sigma,
                        mx_alpha);
     return sv_check_launch("sv_shot_targets");
 }
@@ -1872,40 +1889,59 @@ int sv_shot_scale(const float* coef, const float* g_sup, const float* g_unsup, f
 }
 
 int sv_shot_loss_step(const sv_shot_loss_args* a, void* stream) {
-    SV_REQUIRE(a && a->rec && a->mu && a->ls && a->la && a->image_l && a->image_u && a->label_l && a->perm_l && a->perm_u && a->terms &&
-               a->coef && a->tgt && a->d_rec && a->d_mu && a->d_ls && a->d_la && a->B > 0 && a->D > 0 && a->K > 0, SV_E_ARG,
-               "sv_shot_loss_step: bad argument");
-    const int B = a->B, D = a->D, K = a->K;
+    SV_REQUIRE(a && a->rec && a->mu && a->ls && a->la && a->d_rec && a->d_mu && a->d_ls && a->d_la && a->B > 0 && a->D > 0 && a->K > 0,
+               SV_E_ARG, "sv_shot_loss_step: bad argument");
+    // the four groups back to back, B rows each, in the order (1)(3)(2)(4) -> the per-group form
+    sv_shot_loss_args2 b{};
+    const int64_t B = a->B, n = a->n_per_img;
+    for (int g = 0; g < 4; ++g) {
+        b.mu[g] = a->mu + g * B * a->D;  b.ls[g] = a->ls + g * B * a->D;  b.la[g] = a->la + g * B * a->K;
+        b.d_mu[g] = a->d_mu + g * B * a->D;  b.d_ls[g] = a->d_ls + g * B * a->D;  b.d_la[g] = a->d_la + g * B * a->K;
+    }
+    for (int g = 0; g < 2; ++g) { b.rec[g] = a->rec + g * B * n;  b.d_rec[g] = a->d_rec + g * B * n; }
+    b.image_l = a->image_l; b.image_u = a->image_u; b.label_l = a->label_l; b.perm_l = a->perm_l; b.perm_u = a->perm_u;
+    b.lam_l = a->lam_l; b.lam_l_dev = a->lam_l_dev; b.lam_u = a->lam_u; b.lam_u_dev = a->lam_u_dev;
+    b.Bl = b.Bu = a->B; b.D = a->D; b.K = a->K; b.bce = a->bce; b.n_per_img = n; b.x_sigma = a->x_sigma; b.sch = a->sch;
+    b.terms = a->terms; b.coef = a->coef; b.tgt = a->tgt;
+    return sv_shot_loss_step2(&b, stream);
+}
+
+int sv_shot_loss_step2(const sv_shot_loss_args2* a, void* stream) {
+    SV_REQUIRE(a && a->image_l && a->image_u && a->label_l && a->perm_l && a->perm_u && a->terms && a->coef && a->tgt && a->Bl > 0 &&
+               a->Bu > 0 && a->D > 0 && a->K > 0, SV_E_ARG, "sv_shot_loss_step2: bad argument");
+    for (int g = 0; g < 4; ++g)
+        SV_REQUIRE(a->mu[g] && a->ls[g] && a->la[g] && a->d_mu[g] && a->d_ls[g] && a->d_la[g], SV_E_ARG, "sv_shot_loss_step2: group %d: null", g);
+    SV_REQUIRE(a->rec[0] && a->rec[1] && a->d_rec[0] && a->d_rec[1], SV_E_ARG, "sv_shot_loss_step2: reconstruction: null");
+    const int Bl = a->Bl, Bu = a->Bu, D = a->D, K = a->K;
     const int64_t n = a->n_per_img;
-    auto g = [&](const float* t, int grp, int64_t row) { return t + (int64_t)grp * B * row; };
-    auto gm = [&](float* t, int grp, int64_t row) { return t + (int64_t)grp * B * row; };
+    // targets: sm_mu | sm_sigma [Bl][D], mx_mu | mx_sigma [Bu][D], lab_mix [Bl][K], mx_alpha [Bu][K]
     float* sm_mu = a->tgt;
-    float* sm_sigma = sm_mu + (int64_t)B * D;
-    float* mx_mu = sm_sigma + (int64_t)B * D;
-    float* mx_sigma = mx_mu + (int64_t)B * D;
-    float* lab_mix = mx_sigma + (int64_t)B * D;
-    float* mx_alpha = lab_mix + (int64_t)B * K;
+    float* sm_sigma = sm_mu + (int64_t)Bl * D;
+    float* mx_mu = sm_sigma + (int64_t)Bl * D;
+    float* mx_sigma = mx_mu + (int64_t)Bu * D;
+    float* lab_mix = mx_sigma + (int64_t)Bu * D;
+    float* mx_alpha = lab_mix + (int64_t)Bl * K;
     int rc;
 #define SV_TRY(call) do { rc = (call); if (rc != SV_OK) return rc; } while (0)
     // forward: ELBO terms of (1), (3); the targets of (2), (4); their posterior terms; the composition
-    SV_TRY(sv_elbo_fwd(a->image_l, g(a->rec, 0, n), n, g(a->mu, 0, D), g(a->ls, 0, D), g(a->la, 0, K), B, D, K, a->bce, a->x_sigma, a->terms, stream));
-    SV_TRY(sv_elbo_fwd(a->image_u, g(a->rec, 1, n), n, g(a->mu, 1, D), g(a->ls, 1, D), g(a->la, 1, K), B, D, K, a->bce, a->x_sigma, a->terms + 3, stream));
-    SV_TRY(sv_shot_targets(g(a->mu, 0, D), g(a->ls, 0, D), g(a->mu, 1, D), g(a->ls, 1, D), g(a->la, 1, K), a->label_l, a->perm_l, a->perm_u,
-                           a->lam_l, a->lam_l_dev, a->lam_u, a->lam_u_dev, B, D, K, sm_mu, sm_sigma, lab_mix, mx_mu, mx_sigma, mx_alpha, stream));
-    SV_TRY(sv_cls_fwd(g(a->la, 2, K), lab_mix, nullptr, B, K, a->terms + 6, stream));
-    SV_TRY(sv_post_fwd(g(a->mu, 2, D), g(a->ls, 2, D), sm_mu, sm_sigma, B, D, a->terms + 7, stream));
-    SV_TRY(sv_cls_fwd(g(a->la, 3, K), mx_alpha, nullptr, B, K, a->terms + 8, stream));
-    SV_TRY(sv_post_fwd(g(a->mu, 3, D), g(a->ls, 3, D), mx_mu, mx_sigma, B, D, a->terms + 9, stream));
+    SV_TRY(sv_elbo_fwd(a->image_l, a->rec[0], n, a->mu[0], a->ls[0], a->la[0], Bl, D, K, a->bce, a->x_sigma, a->terms, stream));
+    SV_TRY(sv_elbo_fwd(a->image_u, a->rec[1], n, a->mu[1], a->ls[1], a->la[1], Bu, D, K, a->bce, a->x_sigma, a->terms + 3, stream));
+    SV_TRY(sv_shot_targets2(a->mu[0], a->ls[0], a->mu[1], a->ls[1], a->la[1], a->label_l, a->perm_l, a->perm_u,
+                            a->lam_l, a->lam_l_dev, a->lam_u, a->lam_u_dev, Bl, Bu, D, K, sm_mu, sm_sigma, lab_mix, mx_mu, mx_sigma, mx_alpha, stream));
+    SV_TRY(sv_cls_fwd(a->la[2], lab_mix, nullptr, Bl, K, a->terms + 6, stream));
+    SV_TRY(sv_post_fwd(a->mu[2], a->ls[2], sm_mu, sm_sigma, Bl, D, a->terms + 7, stream));
+    SV_TRY(sv_cls_fwd(a->la[3], mx_alpha, nullptr, Bu, K, a->terms + 8, stream));
+    SV_TRY(sv_post_fwd(a->mu[3], a->ls[3], mx_mu, mx_sigma, Bu, D, a->terms + 9, stream));
     SV_TRY(sv_shot_compose(a->terms, &a->sch, a->coef, stream));
     // backward with upstream gradients 1: the coefficients are the `gout` operands; every slice is written once
-    SV_TRY(sv_elbo_bwd(a->image_l, g(a->rec, 0, n), n, g(a->mu, 0, D), g(a->ls, 0, D), g(a->la, 0, K), B, D, K, a->bce, a->x_sigma, a->coef,
-                       gm(a->d_rec, 0, n), gm(a->d_mu, 0, D), gm(a->d_ls, 0, D), gm(a->d_la, 0, K), stream));
-    SV_TRY(sv_elbo_bwd(a->image_u, g(a->rec, 1, n), n, g(a->mu, 1, D), g(a->ls, 1, D), g(a->la, 1, K), B, D, K, a->bce, a->x_sigma, a->coef + 3,
-                       gm(a->d_rec, 1, n), gm(a->d_mu, 1, D), gm(a->d_ls, 1, D), gm(a->d_la, 1, K), stream));
-    SV_TRY(sv_cls_bwd(lab_mix, nullptr, B, K, a->coef + 6, gm(a->d_la, 2, K), stream));
-    SV_TRY(sv_post_bwd(g(a->mu, 2, D), g(a->ls, 2, D), sm_mu, sm_sigma, B, D, a->coef + 7, gm(a->d_mu, 2, D), gm(a->d_ls, 2, D), stream));
-    SV_TRY(sv_cls_bwd(mx_alpha, nullptr, B, K, a->coef + 8, gm(a->d_la, 3, K), stream));
-    SV_TRY(sv_post_bwd(g(a->mu, 3, D), g(a->ls, 3, D), mx_mu, mx_sigma, B, D, a->coef + 9, gm(a->d_mu, 3, D), gm(a->d_ls, 3, D), stream));
+    SV_TRY(sv_elbo_bwd(a->image_l, a->rec[0], n, a->mu[0], a->ls[0], a->la[0], Bl, D, K, a->bce, a->x_sigma, a->coef,
+                       a->d_rec[0], a->d_mu[0], a->d_ls[0], a->d_la[0], stream));
+    SV_TRY(sv_elbo_bwd(a->image_u, a->rec[1], n, a->mu[1], a->ls[1], a->la[1], Bu, D, K, a->bce, a->x_sigma, a->coef + 3,
+                       a->d_rec[1], a->d_mu[1], a->d_ls[1], a->d_la[1], stream));
+    SV_TRY(sv_cls_bwd(lab_mix, nullptr, Bl, K, a->coef + 6, a->d_la[2], stream));
+    SV_TRY(sv_post_bwd(a->mu[2], a->ls[2], sm_mu, sm_sigma, Bl, D, a->coef + 7, a->d_mu[2], a->d_ls[2], stream));
+    SV_TRY(sv_cls_bwd(mx_alpha, nullptr, Bu, K, a->coef + 8, a->d_la[3], stream));
+    SV_TRY(sv_post_bwd(a->mu[3], a->ls[3], mx_mu, mx_sigma, Bu, D, a->coef + 9, a->d_mu[3], a->d_ls[3], stream));
 #undef SV_TRY
     return SV_OK;
 }

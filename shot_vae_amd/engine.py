@@ -554,7 +554,7 @@ class Engine:
         assert Bt % G == 0, "the groups of a batched forward have equal batch sizes"
         B = Bt // G
         Gd = G if rec_groups is None else int(rec_groups)
-        assert 1 <= Gd <= G
+        assert 0 <= Gd <= G
         dev = image.device
         T = self.tdtype
         st = self._stream()
@@ -696,6 +696,9 @@ class Engine:
         for i, cv in enumerate(p.dec_convs):
             ho = cv.Hout
             gl = G if i < 5 else Gd        # the last ConvTranspose (no BatchNorm behind it): only where rec is needed
+            if gl == 0:                    # a launch of mixed forwards only (the --om / ragged schedules): no reconstruction
+                f.h.append(None)
+                continue
             out = torch.empty(gl * B, ho, ho, cv.N, dtype=T, device=dev)
             if pro is not None and self.materialize_decoder_act and cv.Hin <= 4:
                 # weight-heavy layers (1x1 ... 4x4 maps, 1024 ... 256 channels): BatchNorm + ReLU once, as a pass over a few
@@ -713,9 +716,11 @@ class Engine:
                 pro = finalize(p.dec_bns[i], "h%d" % i, B * ho * ho)
                 f.dpro.append(pro)
                 x = out
-        rec = torch.empty(Gd * B, p.in_ch, p.img, p.img, dtype=torch.float32, device=dev)
-        L.call("sv_nhwc_to_nchw", self.code, _vp(f.h[5].data_ptr()), Gd * B, p.in_ch, p.img, p.img, p.dec_convs[5].N,
-               _vp(rec.data_ptr()), st)
+        rec = None
+        if Gd > 0:
+            rec = torch.empty(Gd * B, p.in_ch, p.img, p.img, dtype=torch.float32, device=dev)
+            L.call("sv_nhwc_to_nchw", self.code, _vp(f.h[5].data_ptr()), Gd * B, p.in_ch, p.img, p.img, p.dec_convs[5].N,
+                   _vp(rec.data_ptr()), st)
         if training:
             if defer:      # running stats + counter applied by apply_pending(), in slot order (= the reference's forward order)
                 slot = self.defer_slot if self.defer_slot is not None else len(self._pending)
@@ -784,6 +789,16 @@ class Engine:
     def backward(self, f, d_rec, d_mu, d_ls, d_la):
         """Gradients accumulate (+=) into self.grad; nothing is returned (inputs need no grad).  Batched like the
         forward it belongs to: every launch carries the G groups, the weight gradients sum over them."""
+        try:
+            self._backward(f, d_rec, d_mu, d_ls, d_la)
+        except BaseException:
+            # the operands kept alive for the side stream must not survive a failed backward into the next step
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
+            self._side_keep.clear()
+            raise
+
+    def _backward(self, f, d_rec, d_mu, d_ls, d_la):
         p = self.plan
         B, G, T = f.B, f.G, self.tdtype
         Bt = B * G
@@ -881,7 +896,11 @@ class Engine:
                 L.call("sv_sample_bwd", self.code, _vp(dl2[r0:].data_ptr()), _vp(f.ls[r0:].data_ptr()),
                        _vp(f.eps[r0:].data_ptr()), _vp(f.csoft[r0:].data_ptr()), mode, float(f.temperature), B, p.ldc, p.K,
                        p.Lpad, _vp(dmu[r0:].data_ptr()), _vp(dls[r0:].data_ptr()), _vp(dla[r0:].data_ptr()), st)
-        if self.bucket_hook is not None:          # grad[dec_off:] is complete once the launches issued so far have run
+        # grad[dec_off:] is complete once the launches issued so far have run -- but only a backward that DID run the decoder
+        # may say so: autograd visits forward (4) of the sequential step first, whose reconstruction enters no loss (Gd = 0);
+        # firing there would reduce the decoder bucket before forward (3)'s decoder gradients exist.  The hook stays armed
+        # (finish() falls back to the single all-reduce if no decoder backward follows).
+        if self.bucket_hook is not None and Gd > 0:
             hook, self.bucket_hook = self.bucket_hook, None
             hook()
         # ---- heads + pool ---------------------------------------------------------------------------------------

@@ -44,6 +44,10 @@ def optimal_match_index(z_mean, z_log_sigma):
 def device_permutation(n, device, count=1):
     """`count` random permutations of n drawn on the device (capturable into a hipGraph, unlike a CPU randperm + copy):
     uniform keys + one rank-counting launch (sv_rank_permutation).  Returns int64 [n] (count == 1) or [count, n]."""
+    if torch.device(device).type != "cuda" or n > 16384:
+        # host-side callers (gloo tests of the non-host-RNG path) and batches beyond the rank-counting kernel's LDS budget
+        perm = torch.rand(count, n, device=device).argsort(1)
+        return perm[0] if count == 1 else perm
     keys = torch.rand(count * n, device=device)
     perm = torch.empty(count, n, dtype=torch.int64, device=device)
     L.call("sv_rank_permutation", _p(keys), n, count, _p(perm), _st())

@@ -123,6 +123,9 @@ class FlatAdam:
                      capturable=self.step_dev is not None, differentiable=False, fused=None, decoupled_weight_decay=False,
                      params=list(range(len(self.params))))
         state = {}
+        if self.step_dev is not None:
+            # hipGraph replays advance only the captured device counter: it is the truth (a D2H read, outside any capture)
+            self.steps = int(round(float(self.step_dev.item())))
         if self.steps > 0:
             for i, (p, o) in enumerate(zip(self.params, self.offsets)):
                 state[i] = dict(step=torch.tensor(float(self.steps)), exp_avg=self.m[o:o + p.numel()].view(p.shape).clone(),

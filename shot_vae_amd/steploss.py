@@ -113,25 +113,33 @@ class _ShotLossFn(torch.autograd.Function):
         return (d_rec, d_mu, d_ls, d_la) + (None,) * 10
 
 
-def shot_loss_step(rec, mu, ls, la, image_l, image_u, label_l, perm_l, perm_u, lam_l, lam_u, sch, bce=True, x_sigma=1.0):
-    """The same stage WITHOUT autograd, for a step that drives the network's backward itself (train_step_grouped): the
+def shot_loss_step_groups(outs, grads, image_l, image_u, label_l, perm_l, perm_u, lam_l, lam_u, sch, bce=True, x_sigma=1.0):
+    """The loss stage WITHOUT autograd, for a step that drives the network's backward itself (train_step_grouped): the
     forward reductions and, with upstream gradients 1 for both objectives (`(loss_sup + loss_unsup).backward()`), the
     gradients w.r.t. the network outputs -- 9 + 6 launches issued back to back by ONE call into the library
-    (sv_shot_loss_step: at ~5 us per kernel the stage is bound by the per-launch host time of a Python caller).
-    Returns (terms[12], d_rec [2B], d_mu, d_ls, d_la [4B])."""
-    for t in (rec, mu, ls, la, image_l, image_u):
-        if not t.is_cuda:
-            raise L.ShotVaeHipError("shot_vae_amd losses run on an MI355X only (no CPU fallback)")
-    B, D, K = image_l.shape[0], mu.shape[1], la.shape[1]
-    f32 = dict(dtype=torch.float32, device=mu.device)
-    rec, mu, ls, la = rec.contiguous(), mu.contiguous(), ls.contiguous(), la.contiguous()
+    (sv_shot_loss_step2: at ~5 us per kernel the stage is bound by the per-launch host time of a Python caller).
+    outs[i] = (rec or None, mu, ls, la) of forward i in (1, 2, 3, 4), grads[i] = (d_rec or None, d_mu, d_ls, d_la): the
+    tensors the gradients are WRITTEN to (row slices of whatever the caller's launches need; forwards (1), (2) have B_l
+    rows, (3), (4) B_u rows).  Returns terms[12]."""
+    Bl, Bu, D, K = image_l.shape[0], image_u.shape[0], outs[1][1].shape[1], outs[1][3].shape[1]
+    for i in (1, 2, 3, 4):
+        for t in outs[i] + grads[i]:
+            if t is None:
+                continue
+            if not t.is_cuda:
+                raise L.ShotVaeHipError("shot_vae_amd losses run on an MI355X only (no CPU fallback)")
+            assert t.is_contiguous() and t.dtype == torch.float32 and t.shape[0] == (Bl if i < 3 else Bu), (i, t.shape, t.dtype)
+    f32 = dict(dtype=torch.float32, device=image_l.device)
     image_l, image_u = image_l.contiguous().float(), image_u.contiguous().float()
     label_l = label_l.long().contiguous()
     terms = torch.zeros(12, **f32)
-    scratch = torch.empty(10 + 4 * B * D + 2 * B * K, **f32)          # coef | the targets
-    d_rec, d_mu, d_ls, d_la = torch.empty_like(rec), torch.empty_like(mu), torch.empty_like(ls), torch.empty_like(la)
-    a = L.SvShotLossArgs()
-    a.rec, a.mu, a.ls, a.la = rec.data_ptr(), mu.data_ptr(), ls.data_ptr(), la.data_ptr()
+    scratch = torch.empty(10 + 2 * (Bl + Bu) * D + (Bl + Bu) * K, **f32)          # coef | the targets
+    a = L.SvShotLossArgs2()
+    for slot, i in enumerate((1, 3, 2, 4)):                 # the library's group order
+        a.mu[slot], a.ls[slot], a.la[slot] = (t.data_ptr() for t in outs[i][1:])
+        a.d_mu[slot], a.d_ls[slot], a.d_la[slot] = (t.data_ptr() for t in grads[i][1:])
+    for slot, i in enumerate((1, 3)):
+        a.rec[slot], a.d_rec[slot] = outs[i][0].data_ptr(), grads[i][0].data_ptr()
     a.image_l, a.image_u, a.label_l = image_l.data_ptr(), image_u.data_ptr(), label_l.data_ptr()
     a.perm_l, a.perm_u = perm_l.data_ptr(), perm_u.data_ptr()
     keep = []
@@ -141,11 +149,25 @@ def shot_loss_step(rec, mu, ls, la, image_l, image_u, label_l, perm_l, perm_u, l
             setattr(a, name + "_dev", v.data_ptr())
         else:
             setattr(a, name, float(v))
-    a.B, a.D, a.K, a.bce, a.n_per_img, a.x_sigma = B, D, K, int(bce), image_l[0].numel(), float(x_sigma)
+    a.Bl, a.Bu, a.D, a.K, a.bce, a.n_per_img, a.x_sigma = Bl, Bu, D, K, int(bce), image_l[0].numel(), float(x_sigma)
     a.sch = L.SvShotSchedule(*[float(sch[k]) for k in ("ew", "kl_beta_c", "kl_beta_d", "cmi", "dmi", "pwm", "ucw")])
     a.terms, a.coef, a.tgt = terms.data_ptr(), scratch.data_ptr(), scratch.data_ptr() + 40
-    a.d_rec, a.d_mu, a.d_ls, a.d_la = d_rec.data_ptr(), d_mu.data_ptr(), d_ls.data_ptr(), d_la.data_ptr()
-    L.call("sv_shot_loss_step", C.byref(a), _st())
+    L.call("sv_shot_loss_step2", C.byref(a), _st())
+    return terms
+
+
+def shot_loss_step(rec, mu, ls, la, image_l, image_u, label_l, perm_l, perm_u, lam_l, lam_u, sch, bce=True, x_sigma=1.0):
+    """shot_loss_step_groups for the outputs of ONE batched launch of four equal groups in the order (1) (3) (2) (4)
+    (rec: groups (1), (3) only).  Returns (terms[12], d_rec [2B], d_mu, d_ls, d_la [4B])."""
+    B = image_l.shape[0]
+    rec, mu, ls, la = rec.contiguous(), mu.contiguous(), ls.contiguous(), la.contiguous()
+    d_rec, d_mu, d_ls, d_la = torch.empty_like(rec), torch.empty_like(mu), torch.empty_like(ls), torch.empty_like(la)
+    g = lambda t, k: t[k * B:(k + 1) * B]
+    outs, grads = {}, {}
+    for slot, i in enumerate((1, 3, 2, 4)):
+        outs[i] = (g(rec, slot) if slot < 2 else None, g(mu, slot), g(ls, slot), g(la, slot))
+        grads[i] = (g(d_rec, slot) if slot < 2 else None, g(d_mu, slot), g(d_ls, slot), g(d_la, slot))
+    terms = shot_loss_step_groups(outs, grads, image_l, image_u, label_l, perm_l, perm_u, lam_l, lam_u, sch, bce, x_sigma)
     return terms, d_rec, d_mu, d_ls, d_la
 
 

@@ -7,8 +7,8 @@ import torch
 
 from . import dp
 from .criterion import continuous_posterior_loss
-from .mixup import _lerp, device_permutation, label_smoothing, mixup_vae_data
-from .steploss import TERMS, shot_loss_step
+from .mixup import _lerp, device_permutation, label_smoothing, mixup_vae_data, optimal_match_index
+from .steploss import TERMS, shot_loss_step_groups
 
 
 def alpha_schedule(epoch, max_epoch, alpha_max):
@@ -181,86 +181,157 @@ def train_step_overlapped(model, elbo_criterion, cls_criterion, optimizer, image
     return loss_sup.detach(), loss_unsup.detach()
 
 
+def _launch_plan(ragged, optimal_match):
+    """Which forwards of the step ((1) labelled, (2) smoothed labelled, (3) unlabelled, (4) mixed unlabelled) share a batched
+    launch sequence.  Inside a launch the forwards whose reconstruction enters the loss ((1), (3)) come first."""
+    if not ragged and not optimal_match:
+        return [[1, 3, 2, 4]]                       # the usual step: ONE launch sequence, four BatchNorm groups
+    if not ragged:
+        return [[1, 3, 2], [4]]                     # --om: the pairing of (4) needs mu / log_sigma of (3) (mixup.py:9-18)
+    if not optimal_match:
+        return [[1, 2], [3, 4]]                     # B_l != B_u (the last labelled batch of an epoch): one launch per loader
+    return [[1, 2], [3], [4]]
+
+
 def train_step_grouped(model, elbo_criterion, cls_criterion, optimizer, image_l, label_l, image_u, sch, epsilon=0.1,
-                       distributed=False, device_rng=None, label_u=None, return_outputs=False):
-    """The same step with the four forwards as ONE batched launch sequence and one backward.
+                       distributed=False, device_rng=None, label_u=None, return_outputs=False, optimal_match=False):
+    """The same step with the four forwards as batched launch sequences and no autograd graph.
     Legal because, without --om, the INPUTS of the mixed forwards (2) and (4) depend only on the raw images, a pairing and
     lambda (mixup.py:22,36) -- only their loss TARGETS depend on the outputs of (1) and (3) -- and all four use the same
     weights (optimizer.step comes last, main_shot_vae.py:365).  Each forward keeps its own BatchNorm batch statistics
     (groups of the batched launches) and the running statistics receive the four momentum updates in the reference's
-    order; `(loss_sup + loss_unsup).backward()` accumulates the same gradient sum as the reference's two backward()
-    calls.  A quarter of the launches at four times the rows per launch.
-    Needs B_l == B_u (the kernels batch equally sized groups) and no --om: otherwise use train_step.
+    order; the backward accumulates the same gradient sum as the reference's two backward() calls.
+
+    B_l == B_u, no --om: ONE launch sequence of four groups -- a quarter of the launches at four times the rows.
+    --om (`optimal_match`): groups (1)(3)(2) batched, then the pairing kernel on the outputs of (3), then (4) alone.
+    B_l != B_u (main_shot_vae.py:280 zips a 4 000-label loader, 7 x 512 + 416, with the unlabelled one): one launch
+    sequence per loader, (1)(2) and (3)(4).  Both together: (1)(2), (3), (4).
     Host RNG (model.rng == "host") is consumed in the reference's order, so identical seeds give identical noise."""
     plan = model._plan
     K, ldc = plan.K, plan.ldc
-    B = image_l.size(0)
-    if image_u.size(0) != B:
-        raise ValueError("train_step_grouped needs B_l == B_u (got %d, %d): use train_step" % (B, image_u.size(0)))
+    Bl, Bu = image_l.size(0), image_u.size(0)
+    rows = {1: Bl, 2: Bl, 3: Bu, 4: Bu}
     dev = image_l.device
+    eng = model._engine
     # ---- every random draw of the step, in the reference's order (SURVEY.md 3.1) ---------------------------------
-    # group order of the batched launches: (1) (3) (2) (4) -- the two forwards whose RECONSTRUCTION enters the loss first.
     # The reconstructions of the mixed forwards are dead values in the reference (main_shot_vae.py:311,356: `*_`): their last
-    # ConvTranspose and their whole decoder backward are skipped (forward_groups(rec_groups=2)); BatchNorm running
-    # statistics still receive the four updates in the reference's order (update_order).
-    if device_rng is None and model.rng == "host":
-        eps1 = torch.randn(B, ldc)
+    # ConvTranspose and their whole decoder backward are skipped (forward_groups(rec_groups=...)); BatchNorm running
+    # statistics still receive the four updates in the reference's order (update_order / defer slots).
+    eps, u = {}, {}
+    perm_u = None
+    device_noise = not (device_rng is None and model.rng == "host")
+    if not device_noise:
+        eps[1] = torch.randn(Bl, ldc)
         lam_l = np.random.beta(epsilon, epsilon) if epsilon > 0 else 1
-        perm_l = torch.randperm(B).to(dev)
-        eps2, eps3, u3 = torch.randn(B, ldc), torch.randn(B, ldc), torch.rand(B, K)
+        perm_l = torch.randperm(Bl).to(dev)
+        eps[2], eps[3], u[3] = torch.randn(Bl, ldc), torch.randn(Bu, ldc), torch.rand(Bu, K)
         lam_u = np.random.beta(2.0, 2.0)
-        perm_u = torch.randperm(B).to(dev)
-        eps4, u4 = torch.randn(B, ldc), torch.rand(B, K)
-        eps = torch.cat([eps1, eps3, eps2, eps4]).to(dev)
-        uz = torch.zeros(B, K)
-        u = torch.cat([uz, u3, uz, u4]).to(dev)
+        if not optimal_match:
+            perm_u = torch.randperm(Bu).to(dev)
+        eps[4], u[4] = torch.randn(Bu, ldc), torch.rand(Bu, K)
+        for k in eps:
+            eps[k] = eps[k].to(dev)
+        for k in u:
+            u[k] = u[k].to(dev)
     else:
-        eps = torch.randn(4 * B, ldc, device=dev)
-        u = torch.rand(4 * B, K, device=dev)
-        perm_l, perm_u = device_permutation(B, dev, 2)      # both pairings: one key draw, one launch
+        e_all = torch.randn(2 * (Bl + Bu), ldc, device=dev)
+        u_all = torch.rand(2 * (Bl + Bu), K, device=dev)
+        o = 0
+        for k in (1, 3, 2, 4):                              # (the order of the single launch: its tensors are used as they are)
+            eps[k], u[k] = e_all[o:o + rows[k]], u_all[o:o + rows[k]]
+            o += rows[k]
+        if Bl == Bu:
+            perm_l, perm_u = device_permutation(Bl, dev, 2)      # both pairings: one key draw, one launch
+        else:
+            perm_l, perm_u = device_permutation(Bl, dev), device_permutation(Bu, dev)
         if device_rng is not None:
             lam_l, lam_u = device_rng.next_lams()          # device scalars: capturable
         else:
             lam_l = np.random.beta(epsilon, epsilon) if epsilon > 0 else 1
             lam_u = np.random.beta(2.0, 2.0)
-    perm_l, perm_u = perm_l.long().contiguous(), perm_u.long().contiguous()
+    perm_l = perm_l.long().contiguous()
     model._last_lams = (lam_l, lam_u)          # (data-parallel runs check that every rank used the same pair)
     with torch.no_grad():
         sm_img = _lerp(image_l, perm_l, lam_l, False)                        # mixup.py:36
-        mx_img = _lerp(image_u, perm_u, lam_u, False)                        # mixup.py:22
         sm_label = label_l[perm_l]
+    images = {1: image_l, 2: sm_img, 3: image_u}
+    specs = {1: dict(disc_label=label_l), 3: dict(), 4: dict(),
+             2: dict(mixup=True, disc_label=label_l, disc_pseudo_label=sm_label, mixup_lam=lam_l)}
     # forward, loss stage and backward are driven from THIS thread, without an autograd graph: the step's structure is
     # fixed ((loss_sup + loss_unsup).backward() = upstream gradients 1), and the autograd engine's worker-thread hand-over
     # left the GPU idle between the loss kernels and the network's backward
-    rec, mu, ls, la, fctx = model.forward_groups_direct(
-        [image_l, image_u, sm_img, mx_img],
-        [dict(disc_label=label_l), dict(),
-         dict(mixup=True, disc_label=label_l, disc_pseudo_label=sm_label, mixup_lam=lam_l), dict()],
-        eps=eps, u=u, rec_groups=2, update_order=[0, 2, 1, 3])
-    rec1, rec3 = rec.split(B)
-    mu1, mu3, mu2, mu4 = mu.split(B)
-    ls1, ls3, ls2, ls4 = ls.split(B)
-    la1, la3, la2, la4 = la.split(B)
-    kl_inference = inference_kl(la3, label_u) if label_u is not None else None            # :330-339 (monitor)
+    launches = _launch_plan(Bl != Bu, optimal_match)
+    outs, ctxs = {}, []
+    mx_img = None
+    for li, ids in enumerate(launches):
+        if 4 in ids and mx_img is None:
+            with torch.no_grad():
+                if optimal_match:                                            # mixup.py:9-18 on the outputs of forward (3)
+                    perm_u = optimal_match_index(outs[3][1], outs[3][2])
+                perm_u = perm_u.long().contiguous()
+                mx_img = images[4] = _lerp(image_u, perm_u, lam_u, False)    # mixup.py:22
+        B = rows[ids[0]]
+        zu = None
+        us = []
+        for k in ids:
+            if k in u and specs[k].get("disc_label") is None:
+                us.append(u[k])
+            else:
+                zu = torch.zeros(B, K, device=dev) if zu is None else zu
+                us.append(zu)
+        if device_noise and len(launches) == 1:     # drawn in this launch's group order (uniform rows of label groups are unused)
+            e_cat, u_cat = e_all, u_all
+        else:
+            e_cat = torch.cat([eps[k] for k in ids]) if len(ids) > 1 else eps[ids[0]]
+            u_cat = torch.cat(us) if len(ids) > 1 else us[0]
+        nrec = sum(1 for k in ids if k in (1, 3))
+        order = sorted(range(len(ids)), key=lambda j: ids[j])                # running statistics: the reference's forward order
+        if len(launches) > 1:
+            eng.defer_slot = li          # (launch li holds forwards that all precede those of launch li + 1)
+        try:
+            rec, mu, ls, la, fctx = model.forward_groups_direct([images[k] for k in ids], [specs[k] for k in ids], eps=e_cat,
+                                                                u=u_cat, rec_groups=nrec, update_order=order)
+        finally:
+            eng.defer_slot = None
+        ctxs.append((ids, fctx, rec, mu, ls, la))
+        for j, k in enumerate(ids):
+            outs[k] = (rec[j * B:(j + 1) * B] if j < nrec else None, mu[j * B:(j + 1) * B], ls[j * B:(j + 1) * B],
+                       la[j * B:(j + 1) * B])
+    if len(launches) > 1:
+        eng.apply_pending()              # BatchNorm running statistics: slots in launch order, groups in forward order
+    kl_inference = inference_kl(outs[3][3], label_u) if label_u is not None else None            # :330-339 (monitor)
     # the loss stage (steploss.py): 9 launches forward, 6 backward, no tensor algebra in between        :289-323, :340-363
-    terms, d_rec, d_mu, d_ls, d_la = shot_loss_step(rec, mu, ls, la, image_l, image_u, label_l, perm_l, perm_u, lam_l, lam_u,
-                                                    sch, bce=elbo_criterion.bce_reconstruction,
-                                                    x_sigma=elbo_criterion.x_sigma)
+    grads, per_launch = {}, []
+    for ids, fctx, rec, mu, ls, la in ctxs:
+        B = rows[ids[0]]
+        d = (torch.empty_like(rec) if rec is not None else None, torch.empty_like(mu), torch.empty_like(ls), torch.empty_like(la))
+        per_launch.append(d)
+        for j, k in enumerate(ids):
+            grads[k] = (d[0][j * B:(j + 1) * B] if outs[k][0] is not None else None,) + tuple(t[j * B:(j + 1) * B] for t in d[1:])
+    terms = shot_loss_step_groups(outs, grads, image_l, image_u, label_l, perm_l, perm_u, lam_l, lam_u, sch,
+                                  bce=elbo_criterion.bce_reconstruction, x_sigma=elbo_criterion.x_sigma)
     loss_sup, loss_unsup = terms[10], terms[11]
-    if optimizer is not None and _bucketed(model, distributed) is not None:
-        _bucketed(model, distributed).arm()                                  # the step's only backward: decoder bucket overlaps it
-    model.backward_direct(fctx, d_rec, d_mu, d_ls, d_la)                     # :324 + :364
+    # backward(s): launches without a reconstruction first; the decoder-first gradient bucket of a data-parallel step is armed
+    # for the LAST backward that runs the decoder (its gradients are complete once that one has issued them)   :324 + :364
+    seq = sorted(range(len(ctxs)), key=lambda i: per_launch[i][0] is not None)
+    for n, i in enumerate(seq):
+        if n == len(seq) - 1 and optimizer is not None and _bucketed(model, distributed) is not None:
+            _bucketed(model, distributed).arm()
+        model.backward_direct(ctxs[i][1], *per_launch[i])
     if optimizer is not None:
         apply_update(model, optimizer, distributed)
     if not return_outputs:
         if label_u is not None:
             return loss_sup.detach(), loss_unsup.detach(), kl_inference
         return loss_sup.detach(), loss_unsup.detach()
-    loc = dict(locals())
-    loc.update({k: terms[i] for i, k in enumerate(TERMS)})
-    keys = TERMS + ["sm_img", "mx_img"] + ["%s%d" % (n, i) for i in (1, 2, 3, 4) for n in ("mu", "ls", "la")] + \
-        ["rec1", "rec3"] + (["kl_inference"] if label_u is not None else [])
-    return {k: loc[k].detach() for k in keys}        # (rec2 / rec4 are not computed: dead values of the reference step)
+    res = {k: terms[i].detach() for i, k in enumerate(TERMS)}
+    res.update(sm_img=sm_img, mx_img=mx_img, rec1=outs[1][0], rec3=outs[3][0], perm_u=perm_u)
+    for i in (1, 2, 3, 4):
+        for n, t in zip(("mu", "ls", "la"), outs[i][1:]):
+            res["%s%d" % (n, i)] = t
+    if label_u is not None:
+        res["kl_inference"] = kl_inference
+    return {k: v.detach() for k, v in res.items()}        # (rec2 / rec4 are not computed: dead values of the reference step)
 
 
 def train_step(model, elbo_criterion, cls_criterion, optimizer, image_l, label_l, image_u, sch, epsilon=0.1,
@@ -369,10 +440,8 @@ class GraphedTrainStep:
     def __init__(self, model, elbo_criterion, cls_criterion, optimizer, image_l, label_l, image_u, sch, epsilon=0.1,
                  distributed=False, seed=0, warmup=2, optimal_match=False, label_u=None, schedule="grouped"):
         assert model.rng == "device", "graph capture needs device-side noise: VariationalAutoEncoder(..., rng='device')"
-        # "grouped": the four forwards as one batched launch sequence (train_step_grouped); "two-stream": the labelled
-        # and the unlabelled branch on two HIP streams (train_step_overlapped; also the fallback for --om / B_l != B_u)
-        if optimal_match or image_l.size(0) != image_u.size(0):
-            schedule = "two-stream"
+        # "grouped": the four forwards as batched launch sequences (train_step_grouped; also --om and B_l != B_u);
+        # "two-stream": the labelled and the unlabelled branch on two HIP streams (train_step_overlapped)
         self.schedule = schedule
         self.model, self.opt, self.distributed = model, optimizer, distributed
         self.il, self.ll, self.iu = image_l.clone(), label_l.clone(), image_u.clone()
@@ -404,7 +473,7 @@ class GraphedTrainStep:
         eng = self.model._engine
         if self.schedule == "grouped":
             return train_step_grouped(self.model, e, c, None, self.il, self.ll, self.iu, sch, epsilon=eps,
-                                      device_rng=self.rng, label_u=self.lu)
+                                      device_rng=self.rng, label_u=self.lu, optimal_match=self.om)
         keep = eng.wgrad_side_stream
         # nested side streams inside the two branch streams crash hipGraph instantiation on ROCm 7.2 (and add
         # nothing to the two-stream schedule, measured), so the captured body keeps wgrads on the branch streams

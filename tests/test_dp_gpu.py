@@ -36,10 +36,16 @@ torch.manual_seed(100 + rank); torch.cuda.manual_seed(100 + rank)       # per-ra
 il, iu = torch.rand(B, 3, 32, 32, device="cuda"), torch.rand(B, 3, 32, 32, device="cuda")
 ll = torch.randint(0, K, (B,), device="cuda")
 rng = S.DeviceRng("cuda", seed=0)               # same seed everywhere: all ranks agree on the mixup lambdas
+import numpy as np
+np.random.seed(5)                               # (the sequential step draws its lambdas from numpy: same on every rank)
+SCHEDULE = %r
 losses = []
 for step in range(3):
-    ls, lu = S.train_step_grouped(model, elbo, cls, opt, il, ll, iu, S.schedule(10), distributed="bucketed" if step else True,
-                                  device_rng=rng)      # step 0: one all-reduce; then the decoder-first buckets
+    dmode = "bucketed" if step else True        # step 0: one all-reduce; then the decoder-first buckets
+    if SCHEDULE == "grouped":
+        ls, lu = S.train_step_grouped(model, elbo, cls, opt, il, ll, iu, S.schedule(10), distributed=dmode, device_rng=rng)
+    else:                                       # the reference's order: four autograd nodes, two backward() calls
+        ls, lu = S.train_step(model, elbo, cls, opt, il, ll, iu, S.schedule(10), distributed=dmode)
     losses.append((float(ls), float(lu)))
 p = model._engine.param.detach().cpu()
 gathered = [torch.zeros_like(p) for _ in range(world)]
@@ -53,24 +59,126 @@ dist.destroy_process_group()
 '''
 
 
-@pytest.mark.timeout(600)
-def test_two_ranks_on_one_gpu_keep_identical_parameters(tmp_path):
-    script = tmp_path / "worker.py"
-    script.write_text(WORKER % ROOT)
+def _run_two_ranks(script, port0=29600):
     procs = []
     for r in range(2):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(29600 + os.getpid() % 300), HSA_ENABLE_IPC_MODE_LEGACY="0")
+                   MASTER_PORT=str(port0 + os.getpid() % 300), HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.PIPE, text=True))
     outs = [p.communicate(timeout=560) for p in procs]
     assert all(p.returncode == 0 for p in procs), [o[1][-1500:] for o in outs]
     line = [ln for ln in outs[0][0].splitlines() if ln.startswith("{")][-1]
-    res = json.loads(line)
+    return json.loads(line)
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("schedule", ["grouped", "sequential"])
+def test_two_ranks_on_one_gpu_keep_identical_parameters(tmp_path, schedule):
+    """(sequential: autograd visits forward (4) -- no decoder gradient -- before forward (3); the decoder bucket must not be
+    reduced before (3)'s decoder backward has been issued, or the replicas keep rank-local decoder gradients and diverge)"""
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % (ROOT, schedule))
+    res = _run_two_ranks(script)
     assert res["finite"] and res["param_norm"] > 0
     # the ranks saw different data and noise, started from different weights, and still hold the same parameters
     assert res["max_param_diff"] == 0.0, res
     assert all(abs(a) < 1e3 for pair in res["losses"] for a in pair)
+
+
+EQUIV_WORKER = r'''
+import os, sys, json, torch
+sys.path.insert(0, %r)
+import torch.distributed as dist
+import shot_vae_amd as S
+from shot_vae_amd import dp
+from shot_vae_amd import _lib as L
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+torch.cuda.set_device(0)
+dist.init_process_group("gloo", rank=rank, world_size=world)
+K, B = 10, 16
+L.call("sv_set_option", L.OPT_DETERMINISTIC, 1)          # fixed summation order: the comparison is down to the exchange
+
+
+def make():
+    torch.manual_seed(3)
+    m = S.VariationalAutoEncoder("wideresnet-10-1", num_input_channels=3, img_size=(32, 32), data_parallel=True,
+                                 continuous_latent_dim=128, disc_latent_dim=K, small_input=True, compute_dtype="fp32",
+                                 rng="device").cuda().train()
+    o = S.FlatSGD(m, lr=0.05, momentum=0.9, weight_decay=5e-4)
+    o.zero_grad()
+    return m, o
+
+
+def shard_inputs(r):
+    """data shard + noise stream of rank r (what the DP worker seeds itself with)"""
+    torch.manual_seed(100 + r); torch.cuda.manual_seed(100 + r)
+    il, iu = torch.rand(B, 3, 32, 32, device="cuda"), torch.rand(B, 3, 32, 32, device="cuda")
+    return il, torch.randint(0, K, (B,), device="cuda"), iu
+
+
+elbo, cls = S.VAECriterion(discrete_dim=K).cuda(), S.ClsCriterion()
+sch = S.schedule(10)
+# ---- the data-parallel run: this rank's shard, one all-reduce, 1/world in the SGD kernel, two steps ------------------------
+model, opt = make()
+dp.broadcast_parameters(model)
+il, ll, iu = shard_inputs(rank)
+rng = S.DeviceRng("cuda", seed=0)
+for step in range(2):
+    S.train_step_grouped(model, elbo, cls, opt, il, ll, iu, sch, distributed=True, device_rng=rng)
+p_dp = model._engine.param.detach().clone()
+bufs_dp = model._engine.bufs.detach().clone()
+res = None
+if rank == 0:
+    # ---- ONE process over the concatenated shards, each shard with its own BatchNorm statistics: the shards' steps
+    #      accumulate into the flat gradient buffer (no update in between), then one SGD step on the mean ----------------
+    ref, ropt = make()
+    rng2 = S.DeviceRng("cuda", seed=0)
+    gens = {}
+    for step in range(2):
+        lams = rng2.next_lams()                     # both shards of a step use the SAME pair, like the ranks do
+        snap = ref._engine.bufs.detach().clone()
+        for r in range(world):
+            if step == 0:
+                gens[r] = shard_inputs(r) + (torch.cuda.get_rng_state(),)
+            il_r, ll_r, iu_r, state = gens[r]
+            torch.cuda.set_rng_state(state)         # continue rank r's device noise stream where its last step left it
+
+            class Fixed:                            # DeviceRng stand-in: this step's pair, for every shard
+                def next_lams(self):
+                    return lams
+            if r > 0:
+                ref._engine.bufs.copy_(snap)        # running statistics are rank-local: rank 0's are compared below
+            S.train_step_grouped(ref, elbo, cls, None, il_r, ll_r, iu_r, sch, device_rng=Fixed())
+            if r == 0:
+                bufs0 = ref._engine.bufs.detach().clone()
+            gens[r] = (il_r, ll_r, iu_r, torch.cuda.get_rng_state())
+        ref._engine.bufs.copy_(bufs0)
+        ropt.step(1.0 / world)
+        ropt.zero_grad()
+    p_ref = ref._engine.param.detach()
+    d = (p_dp - p_ref).abs().max() / p_ref.abs().max()
+    db = (bufs_dp - ref._engine.bufs).abs().max() / ref._engine.bufs.abs().max()
+    moved = (p_dp - make()[0]._engine.param).abs().max()
+    res = {"rel_param_diff": float(d), "rel_buf_diff": float(db), "moved": float(moved)}
+    print(json.dumps(res))
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+@pytest.mark.timeout(600)
+def test_two_rank_step_equals_single_process_over_both_shards(tmp_path):
+    """SURVEY.md 4, tier 5: an N-rank data-parallel run == ONE process running the shards as separate BatchNorm groups of
+    the same weights and stepping on the mean gradient.  Two ranks (gloo, one GPU), two steps with momentum and weight
+    decay; rank 0 then replays both shards itself (same data, same device noise streams, same lambdas, gradients
+    accumulated in the flat buffer, `FlatSGD.step(1 / world)`) and compares parameters and its BatchNorm running statistics."""
+    script = tmp_path / "equiv.py"
+    script.write_text(EQUIV_WORKER % ROOT)
+    res = _run_two_ranks(script, port0=29950)
+    assert res["moved"] > 1e-4, res                        # the steps did change the weights
+    assert res["rel_param_diff"] < 1e-5, res               # (sum order of the exchange vs in-buffer accumulation)
+    assert res["rel_buf_diff"] < 1e-5, res
 
 
 @pytest.mark.timeout(900)

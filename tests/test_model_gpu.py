@@ -669,11 +669,13 @@ def test_overlapped_step_passes_optimal_match_and_label_u_through():
     assert float((ga - gb).abs().max()) <= 2e-4 * float(ga.abs().max())
 
 
-@pytest.mark.parametrize("tag", [t for t, c in T.STEP_CASES.items() if c[2] == c[3] and not c[6]])
+@pytest.mark.parametrize("tag", list(T.STEP_CASES))
 def test_grouped_step_matches_reference_goldens_fp32(tag):
-    """train_step_grouped -- the four forwards as ONE batched launch sequence (groups of sv_igemm_args), one backward --
-    against the REFERENCE's outputs for the same step (the fixtures with B_l == B_u): losses, all sixteen output
-    tensors, gradients, parameters after SGD, BatchNorm running statistics after the four momentum updates."""
+    """train_step_grouped -- the four forwards as batched launch sequences (groups of sv_igemm_args), no autograd graph --
+    against the REFERENCE's outputs for the same step: losses, all sixteen output tensors, gradients, parameters after SGD,
+    BatchNorm running statistics after the four momentum updates.  Every fixture: B_l == B_u (ONE launch sequence of four
+    groups), the ragged B_l = 4 / B_u = 6 ones (one launch sequence per loader) and --om (the pairing kernel between the
+    launches: (1)(2), (3), pairing, (4))."""
     name, K, Bl, Bu, bce, x_sigma, om, dmi, steps = T.STEP_CASES[tag]
     g = T.load(tag)
     model = make_model(name, K, "fp32", C.make_state(name, K=K))
@@ -686,8 +688,9 @@ def test_grouped_step_matches_reference_goldens_fp32(tag):
     for s in range(steps):
         il, ll, iu, lu = C.make_batch(Bl, Bu, K, stream0=7000 + 10 * s)
         nz = C.make_noise(Bl, Bu, K, stream0=9000 + 100 * s)
-        with T.rng_for_step(nz):                                   # the reference's host-RNG order
-            out = S.train_step_grouped(model, elbo, cls, None, il.cuda(), ll.cuda(), iu.cuda(), sch, return_outputs=True)
+        with T.rng_for_step(nz, om):                               # the reference's host-RNG order
+            out = S.train_step_grouped(model, elbo, cls, None, il.cuda(), ll.cuda(), iu.cuda(), sch, return_outputs=True,
+                                       optimal_match=om)
         torch.cuda.synchronize()
         for k in T.SCALARS:
             ref = float(g["s%d.%s" % (s, k)])
@@ -715,11 +718,16 @@ def test_grouped_step_matches_reference_goldens_fp32(tag):
             assert T.rel_err(sd[key].numpy(), g[k]) < 1e-3, key
 
 
-@pytest.mark.parametrize("dtype,B,tol", [("fp32", 8, 2e-4), ("fp32", 128, 2e-4), ("bf16", 128, 3e-2)])
-def test_grouped_step_equals_sequential_step(dtype, B, tol):
-    """Batched (groups = 4) against per-forward launches on the same weights, inputs and noise: the grouped kernels see
-    exactly the per-group problems (blockIdx.y = group), so fp32 agrees to rounding; B = 128 is the size at which every
-    layer of the decoder fills whole 128-row tiles."""
+@pytest.mark.parametrize("dtype,B,tol,Bu,om", [("fp32", 8, 2e-4, 8, False), ("fp32", 128, 2e-4, 128, False),
+                                               ("bf16", 128, 3e-2, 128, False), ("fp32", 416, 2e-4, 512, False),
+                                               ("fp32", 24, 2e-4, 24, True), ("fp32", 20, 2e-4, 28, True),
+                                               ("bf16", 416, 3e-2, 512, False), ("bf16", 128, 3e-2, 128, True)])
+def test_grouped_step_equals_sequential_step(dtype, B, tol, Bu, om):
+    """Batched against per-forward launches on the same weights, inputs and noise: the grouped kernels see exactly the
+    per-group problems (blockIdx.y = group), so fp32 agrees to rounding; B = 128 is the size at which every layer of the
+    decoder fills whole 128-row tiles.  Also the launch plans of the real loop: B_l = 416 next to B_u = 512 (the last
+    labelled batch of an epoch, main_shot_vae.py:280: one launch sequence per loader) and --om (three groups, the pairing
+    kernel, the fourth)."""
     name, K = "wideresnet-10-1", 10
     st = C.make_state(name, K=K)
     m1, m2 = make_model(name, K, dtype, st), make_model(name, K, dtype, st)
@@ -727,14 +735,15 @@ def test_grouped_step_equals_sequential_step(dtype, B, tol):
     o1, o2 = S.FlatSGD(m1), S.FlatSGD(m2)
     o1.zero_grad()
     o2.zero_grad()
-    il, ll, iu, lu = C.make_batch(B, B, K)
-    nz = C.make_noise(B, B, K)
+    il, ll, iu, lu = C.make_batch(B, Bu, K)
+    nz = C.make_noise(B, Bu, K)
     sch = O.schedule(10)
-    with T.rng_for_step(nz):
-        a = S.train_step(m1, elbo, cls, None, il.cuda(), ll.cuda(), iu.cuda(), sch, return_outputs=True, label_u=lu.cuda())
-    with T.rng_for_step(nz):
+    with T.rng_for_step(nz, om):
+        a = S.train_step(m1, elbo, cls, None, il.cuda(), ll.cuda(), iu.cuda(), sch, return_outputs=True, label_u=lu.cuda(),
+                         optimal_match=om)
+    with T.rng_for_step(nz, om):
         b = S.train_step_grouped(m2, elbo, cls, None, il.cuda(), ll.cuda(), iu.cuda(), sch, return_outputs=True,
-                                 label_u=lu.cuda())
+                                 label_u=lu.cuda(), optimal_match=om)
     torch.cuda.synchronize()
     for k in T.SCALARS + ["kl_inference"]:
         assert abs(float(a[k]) - float(b[k])) <= tol * max(abs(float(a[k])), 1e-6), (k, float(a[k]), float(b[k]))
