@@ -51,10 +51,11 @@ def parse():
     ap.add_argument("--workload", default="shotvae", choices=["shotvae", "svhn"],
                     help="shotvae (default): the SHOT-VAE step of main_shot_vae.py:280-366 (BASELINE configs 2-4); svhn: one "
                          "smooth-ELBO iteration of svhn_VAE, main_smooth_ELBO_svhn.py:152-176 (config 5; --batch 1024)")
-    ap.add_argument("--allreduce", default="bucketed", choices=["bucketed", "single"],
-                    help="N > 1: bucketed (default) = the decoder's 88 %% of the gradient bytes are all-reduced on a communication "
-                         "stream while the encoder's backward runs, the encoder bucket after it (dp.DecoderFirstAllReduce); "
-                         "single = one blocking all-reduce of the flat buffer after the backward")
+    ap.add_argument("--allreduce", default="single", choices=["bucketed", "single"],
+                    help="N > 1: single (default, SURVEY.md 5.2) = ONE all-reduce of the flat gradient buffer after the backward; "
+                         "bucketed = the decoder's 88 %% of the gradient bytes are all-reduced on a communication stream while the "
+                         "encoder's backward runs, the encoder bucket after it (dp.DecoderFirstAllReduce) -- the documented "
+                         "deviation, to be switched on once an 8-GPU run shows the single exchange is not hidden")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the extra keys of the headline line (config-4 step, WRN-28-10 layer table)")
     ap.add_argument("--schedule", default="grouped", choices=["grouped", "two-stream", "sequential"],
@@ -184,36 +185,50 @@ def pmc_traffic(tag, a):
     return tab[tag]["traffic_bytes"], "profiles/%s: %s" % (os.path.basename(files[-1]), tab[tag]["formula"])
 
 
-def extras(S):
-    """Extra keys of the headline line (same JSON object, the headline fields are untouched): the BASELINE config-4 step and
-    the per-kernel table behind the north-star bar ">= 40 % of the bf16 MFMA roofline on the WRN-28-10 encoder conv at batch
-    512" (every body convolution is 0.2416 TFLOP per launch at B = 512, <= 242 us to pass), so that both are
-    in the driver-written record and not only under profiles/."""
-    import contextlib
-    from shot_vae_amd.train import train_step_grouped
-    res = {}
-    net, K, B = "wideresnet-28-10", 100, 256
+def _shot_setup(S, net, K, Bl, Bu, dtype="bf16", seed=4321, dmi=2.3):
     torch.manual_seed(1)
     model = S.VariationalAutoEncoder(net, num_input_channels=3, img_size=(32, 32), data_parallel=True,
                                      continuous_latent_dim=128, disc_latent_dim=K, small_input=True,
-                                     compute_dtype="bf16", rng="device").cuda().train()
+                                     compute_dtype=dtype, rng="device").cuda().train()
     elbo, cls = S.VAECriterion(discrete_dim=K, bce_reconstruction=True).cuda(), S.ClsCriterion()
     opt = S.FlatSGD(model, lr=0.02, momentum=0.9, weight_decay=5e-4)
     opt.zero_grad()
-    sch = S.schedule(10, dmi=4.6)
-    g = torch.Generator(device="cuda").manual_seed(4321)
-    il = torch.rand(B, 3, 32, 32, device="cuda", generator=g)
-    iu = torch.rand(B, 3, 32, 32, device="cuda", generator=g)
-    ll = torch.randint(0, K, (B,), device="cuda", generator=g)
-    warm, steps = 3, 8
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    il = torch.rand(Bl, 3, 32, 32, device="cuda", generator=g)
+    iu = torch.rand(Bu, 3, 32, 32, device="cuda", generator=g)
+    ll = torch.randint(0, K, (Bl,), device="cuda", generator=g)
+    return model, elbo, cls, opt, S.schedule(10, dmi=dmi), il, ll, iu
+
+
+def _time_ms(fn, warm, steps):
     for _ in range(warm):
-        train_step_grouped(model, elbo, cls, opt, il, ll, iu, sch)
+        fn()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
-        ls, lu = train_step_grouped(model, elbo, cls, opt, il, ll, iu, sch)
+        out = fn()
     torch.cuda.synchronize()
-    ms = (time.perf_counter() - t0) / steps * 1e3
+    return (time.perf_counter() - t0) / steps * 1e3, out
+
+
+def extras(S):
+    """Extra keys of the headline line (same JSON object, the headline fields are untouched), so that they are in the
+    driver-written record and not only under profiles/:
+      config4                 the BASELINE configs[3] step (WRN-28-10, K = 100, B = 256)
+      wrn28_10_layer_table    the per-kernel table behind the north-star bar ">= 40 % of the bf16 MFMA roofline on the WRN-28-10
+                              encoder conv at batch 512" (0.2416 TFLOP per launch at B = 512, <= 242 us to pass)
+      headline_variants       the headline network through the OTHER paths a real epoch takes: the ragged last labelled batch
+                              (B_l = 416, main_shot_vae.py:280), --om, the sequential (reference-order, autograd) step, the
+                              fp32-operand parity mode
+      per_rank_batch_table    single-GPU ms/step at the per-rank batches of a strong-scaling run (512 / N per loader), eager issue
+                              and hipGraph replay: the per-rank efficiency curve that bounds the strong-scaling result
+      config5                 BASELINE configs[4]: one smooth-ELBO iteration of svhn_VAE at B = 1024 per loader"""
+    from shot_vae_amd.train import GraphedTrainStep, train_step_grouped
+    res = {}
+    net, K, B = "wideresnet-28-10", 100, 256
+    model, elbo, cls, opt, sch, il, ll, iu = _shot_setup(S, net, K, B, B, dmi=4.6)
+    warm, steps = 3, 8
+    ms, (ls, lu) = _time_ms(lambda: train_step_grouped(model, elbo, cls, opt, il, ll, iu, sch), warm, steps)
     tflop_step = 32.43                     # SURVEY.md 8d: 63.34 GFLOP per dataloader image x 512
     res["config4"] = {"workload": "SHOT-VAE train step %s K=%d B_l=B_u=%d bf16 (BASELINE configs[3]), grouped, eager" % (net, K, B),
                       "ms_per_step": round(ms, 3), "images_per_s": round(2 * B / ms * 1e3, 1), "steps": steps, "warmup": warm,
@@ -222,27 +237,98 @@ def extras(S):
                       "finite": bool(torch.isfinite(ls).all() and torch.isfinite(lu).all())}
     del model, opt
     torch.cuda.empty_cache()
+    res.update(layer_table())
+
+    # ---- the headline network through the other paths of a real epoch -----------------------------------------------------
+    net, K = "wideresnet-28-2", 10
+    var = {}
+    model, elbo, cls, opt, sch, il, ll, iu = _shot_setup(S, net, K, 512, 512)
+    t, _ = _time_ms(lambda: train_step_grouped(model, elbo, cls, opt, il[:416], ll[:416], iu, sch), 3, 10)
+    var["ragged_Bl416_Bu512"] = {"ms_per_step": round(t, 3), "images_per_s": round(928 / t * 1e3, 1),
+                                 "schedule": "grouped: one launch sequence per loader, (1)(2) at 416 and (3)(4) at 512 images"}
+    t, _ = _time_ms(lambda: train_step_grouped(model, elbo, cls, opt, il, ll, iu, sch, optimal_match=True), 3, 10)
+    var["optimal_match"] = {"ms_per_step": round(t, 3), "images_per_s": round(1024 / t * 1e3, 1),
+                            "schedule": "grouped: (1)(3)(2) batched, sv_optimal_match on the outputs of (3), then (4)"}
+    t, _ = _time_ms(lambda: S.train_step(model, elbo, cls, opt, il, ll, iu, sch), 3, 10)
+    var["sequential"] = {"ms_per_step": round(t, 3), "images_per_s": round(1024 / t * 1e3, 1),
+                         "schedule": "the reference's order through autograd: 4 forwards, 2 backward() calls, one stream + side stream"}
+    del model, opt
+    torch.cuda.empty_cache()
+    model, elbo, cls, opt, sch, il, ll, iu = _shot_setup(S, net, K, 512, 512, dtype="fp32")
+    t, _ = _time_ms(lambda: train_step_grouped(model, elbo, cls, opt, il, ll, iu, sch), 2, 5)
+    var["fp32_parity_mode"] = {"ms_per_step": round(t, 3), "images_per_s": round(1024 / t * 1e3, 1),
+                               "note": "fp32 operands on v_mfma_f32_16x16x4_f32: the mode that meets the 1e-3 parity gate"}
+    del model, opt
+    torch.cuda.empty_cache()
+    res["headline_variants"] = var
+
+    # ---- per-rank batch sizes of a strong-scaling run, on this one GPU -----------------------------------------------------
+    rows = []
+    for Br in (256, 128, 64):
+        model, elbo, cls, opt, sch, il, ll, iu = _shot_setup(S, net, K, Br, Br)
+        te, _ = _time_ms(lambda: train_step_grouped(model, elbo, cls, opt, il, ll, iu, sch), 3, 12)
+        row = {"per_rank_batch": Br, "ranks_at_global_512": 512 // Br, "eager_ms": round(te, 3)}
+        try:
+            gs = GraphedTrainStep(model, elbo, cls, opt, il, ll, iu, sch)
+            tg, _ = _time_ms(gs, 3, 12)
+            row["graph_ms"] = round(tg, 3)
+            del gs
+        except Exception as e:
+            row["graph_ms"] = None
+            row["graph_error"] = type(e).__name__
+            torch.cuda.synchronize()
+        best = min(v for v in (row["eager_ms"], row["graph_ms"]) if v)
+        row["images_per_s_per_rank"] = round(2 * Br / best * 1e3, 1)
+        rows.append(row)
+        del model, opt
+        torch.cuda.empty_cache()
+    res["per_rank_batch_table"] = {
+        "note": "single GPU, no collective: ms/step of one rank of a strong-scaling run (global 512 per loader); N x images_per_s_per_rank "
+                "is the ceiling of that run before the all-reduce",
+        "rows": rows}
+
+    # ---- BASELINE configs[4] -------------------------------------------------------------------------------------------------
+    try:
+        c5 = svhn_measure(S, 1024, "bf16", steps=20, warmup=3, want=-1, multi=False, rank=0)
+        res["config5"] = {"workload": "svhn_VAE smooth-ELBO iteration (2 fwd + 1 bwd + Adam), B_u=B_l=1024, bf16 (BASELINE configs[4], "
+                                      "one GPU)", "ms_per_step": round(c5["ms"], 3),
+                          "images_per_s": round(2048 / c5["ms"] * 1e3, 1), "launch": c5["mode"], "launch_probe": c5["probe"],
+                          "finite": c5["finite"]}
+    except Exception as e:          # never lose the headline line to an extra
+        res["config5"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    return res
+
+
+def layer_table(windows=5):
+    """The nine WRN-28-10 body-convolution rows behind the north-star bar: `windows` short measurements per kernel, MEDIAN
+    and MIN of them (a 20-launch window is 4-6 ms: one clock / driver hiccup inside it doubles an average, so the minimum is
+    the kernel's speed and the median what a run sees); `passing` counts rows whose MEDIAN meets the bar."""
+    import contextlib
+    import statistics
     from tools import layer_bench as LB
     rows = []
     with contextlib.redirect_stdout(sys.stderr):          # (the tool prints its own table: keep stdout to the one JSON line)
         for Cc, H in ((160, 32), (320, 16), (640, 8)):
-            # best of three short measurements per kernel: a 20-launch window is 4-6 ms, and one driver / clock hiccup inside
-            # it doubles the average (seen once: 640-channel forward 439 us in one window, 198 us in every other)
             r = {}
-            for _ in range(3):
+            for _ in range(windows):
                 for k, us in LB.bench_layer(512, Cc, H, Cc).items():
-                    r[k] = min(us, r.get(k, us))
+                    r.setdefault(k, []).append(us)
             row = {"layer": "conv3x3 s1 %d->%d @%dx%d, B=512, 0.2416 TFLOP" % (Cc, Cc, H, H)}
-            for k, us in r.items():
-                row[k + "_us"] = round(us, 1)
-                row[k + "_frac"] = round(0.2416e12 / (us * 1e-6) / (MFMA_PEAK_TFLOPS["bf16"] * 1e12), 4)
+            for k, v in r.items():
+                med, mn = statistics.median(v), min(v)
+                row[k + "_us"] = round(med, 1)
+                row[k + "_us_min"] = round(mn, 1)
+                row[k + "_frac"] = round(0.2416e12 / (med * 1e-6) / (MFMA_PEAK_TFLOPS["bf16"] * 1e12), 4)
+                row[k + "_frac_best"] = round(0.2416e12 / (mn * 1e-6) / (MFMA_PEAK_TFLOPS["bf16"] * 1e12), 4)
             rows.append(row)
-    res["wrn28_10_layer_table"] = {"bar": "frac >= 0.40 (<= 242 us)", "peak_TFLOPs": MFMA_PEAK_TFLOPS["bf16"],
-                                   "method": "tools/layer_bench.py in-process: 3 warm-up + 20 launches per window, best of 3 windows",
-                                   "rows": rows,
-                                   "passing": sum(1 for r in rows for k in ("fwd", "dgrad", "wgrad") if r[k + "_frac"] >= 0.40),
-                                   "of": 3 * len(rows)}
-    return res
+    return {"wrn28_10_layer_table": {
+        "bar": "frac >= 0.40 (<= 242 us)", "peak_TFLOPs": MFMA_PEAK_TFLOPS["bf16"],
+        "method": "tools/layer_bench.py in-process: 3 warm-up + 20 launches per window, %d windows: *_us / *_frac = MEDIAN window, "
+                  "*_us_min / *_frac_best = fastest window" % windows,
+        "rows": rows,
+        "passing": sum(1 for r in rows for k in ("fwd", "dgrad", "wgrad") if r[k + "_frac"] >= 0.40),
+        "passing_best_window": sum(1 for r in rows for k in ("fwd", "dgrad", "wgrad") if r[k + "_frac_best"] >= 0.40),
+        "of": 3 * len(rows)}}
 
 
 def _multi(world):
@@ -251,20 +337,13 @@ def _multi(world):
     return world > 1 or os.environ.get("SV_DP_SINGLE_RANK") == "1"
 
 
-def svhn_workload(a, rank, world):
-    """--workload svhn: one smooth-ELBO iteration of svhn_VAE (BASELINE configs[4]; main_smooth_ELBO_svhn.py:152-176: unlabelled
-    forward + loss, labelled forward + loss, one backward, Adam) on --batch images per loader per GPU.  The iteration is ~130
-    launches of tens of microseconds: launch-bound, so the run probes eager issue against a hipGraph replay and keeps the faster
-    (both in the JSON); at N > 1 the graph holds forward + backward and ONE all-reduce of FlatAdam's flat gradient buffer +
-    the sv_adam launch follow it eagerly."""
-    import shot_vae_amd as S
-    multi = _multi(world)
-    B = a.batch if a.scaling == "weak" else a.batch // world
+def svhn_measure(S, B, dtype, steps, warmup, want, multi, rank, init_pg=None):
+    """One smooth-ELBO iteration of svhn_VAE at B images per loader on this GPU: eager issue against hipGraph replay
+    (want: 1 graph, 0 eager, -1 probe both and keep the faster).  `init_pg`: called AFTER the graph has been captured and
+    before anything is timed -- the RCCL process group must not be alive during a stream capture (its watchdog thread polls
+    events), a replay next to it is an ordinary launch; the parameters are broadcast once the group exists."""
     torch.manual_seed(1)
-    model = S.SmoothVAE((3, 32, 32), {"cont": 32, "disc": [10]}, temperature=0.67, compute_dtype=a.dtype).cuda().train()
-    if multi:
-        for p_ in model.parameters():
-            dist.broadcast(p_.data, 0)
+    model = S.SmoothVAE((3, 32, 32), {"cont": 32, "disc": [10]}, temperature=0.67, compute_dtype=dtype).cuda().train()
     loss_fn = S.SmoothELBOLoss()
     opt = S.FlatAdam(model.parameters(), lr=1e-3, capturable=True)
     torch.manual_seed(1 + rank)
@@ -273,6 +352,22 @@ def svhn_workload(a, rank, world):
     u = torch.rand(B, 3, 32, 32, device="cuda", generator=g) * 2 - 1
     l = torch.rand(B, 3, 32, 32, device="cuda", generator=g) * 2 - 1
     y = torch.randint(0, 10, (B,), device="cuda", generator=g)
+    mode, probe, graphed = "eager", None, None
+    if want != 0:
+        try:
+            graphed = S.GraphedSmoothStep(model, loss_fn, opt, u, l, y, warmup=2, distributed=multi)
+        except Exception as e:
+            mode = "eager (graph capture failed: %s)" % type(e).__name__
+            torch.cuda.synchronize()
+    if init_pg is not None:
+        init_pg()
+    if multi:
+        for p_ in model.parameters():           # (views of FlatAdam's flat buffer: the graph reads the same storage)
+            dist.broadcast(p_.data, 0)
+        for t_ in (opt.m, opt.v):
+            dist.broadcast(t_, 0)
+        if opt.step_dev is not None:
+            dist.broadcast(opt.step_dev, 0)
 
     def eager():
         return S.smooth_train_step(model, loss_fn, opt, u, l, y, distributed=multi)
@@ -290,20 +385,8 @@ def svhn_workload(a, rank, world):
         sync()
         return (time.perf_counter() - t) / n * 1e3, out
 
-    for _ in range(max(a.warmup, 2)):
+    for _ in range(max(warmup, 2)):
         eager()
-    mode, probe, graphed = "eager", None, None
-    want = a.graph if a.graph is not None else -1
-    if multi and dist.get_backend() == "nccl" and want != 0:
-        # no stream capture while an RCCL process group is alive: its watchdog thread polls hipEventQuery on outstanding
-        # work, which is an error during another thread's capture on this stack (seen as a watchdog abort in 2 of 5 runs)
-        want, mode = 0, "eager (no graph capture next to the RCCL watchdog)"
-    if want != 0:
-        try:
-            graphed = S.GraphedSmoothStep(model, loss_fn, opt, u, l, y, warmup=2, distributed=multi)
-        except Exception as e:
-            mode = "eager (graph capture failed: %s)" % type(e).__name__
-            torch.cuda.synchronize()
     if graphed is not None:
         if want < 0:
             pe, pg = timed(eager, 10)[0], timed(graphed, 10)[0]
@@ -319,12 +402,25 @@ def svhn_workload(a, rank, world):
         else:
             mode = "hipGraph replay"
     step = graphed if graphed is not None else eager
-    ms, loss = timed(step, a.steps)
+    ms, loss = timed(step, steps)
     dt = torch.tensor([ms], device="cuda", dtype=torch.float64)
     if multi:
         dist.all_reduce(dt, op=dist.ReduceOp.MAX)
-    ms = float(dt)
-    assert bool(torch.isfinite(loss).all()), "non-finite loss"
+    return {"ms": float(dt), "loss": float(loss), "finite": bool(torch.isfinite(loss).all()), "mode": mode, "probe": probe}
+
+
+def svhn_workload(a, rank, world, init_pg):
+    """--workload svhn: one smooth-ELBO iteration of svhn_VAE (BASELINE configs[4]; main_smooth_ELBO_svhn.py:152-176: unlabelled
+    forward + loss, labelled forward + loss, one backward, Adam) on --batch images per loader per GPU.  The iteration is ~130
+    launches of tens of microseconds: launch-bound, so the run probes eager issue against a hipGraph replay and keeps the faster
+    (both in the JSON); at N > 1 the graph holds forward + backward and ONE all-reduce of FlatAdam's flat gradient buffer +
+    the sv_adam launch follow it eagerly (the graph is captured before the process group is created)."""
+    import shot_vae_amd as S
+    multi = _multi(world)
+    B = a.batch if a.scaling == "weak" else a.batch // world
+    r = svhn_measure(S, B, a.dtype, a.steps, a.warmup, a.graph if a.graph is not None else -1, multi, rank, init_pg)
+    ms, mode, probe = r["ms"], r["mode"], r["probe"]
+    assert r["finite"], "non-finite loss"
     # algorithmic work (SURVEY.md 8d): 1.1332e7 MACs per forwarded image, x3 for forward + both gradients, x2 flop per MAC
     flops = 2 * B * 1.1332e7 * 2 * 3
     out = {"metric": "images/sec/step svhn_VAE smooth-ELBO bs%d (BASELINE configs[4])" % a.batch, "value": round(2 * B * world / ms * 1e3, 1),
@@ -334,7 +430,7 @@ def svhn_workload(a, rank, world):
                                   "[-1,1] in HBM, random init" % B, "global_batch": 2 * B * world, "parallelism": "dp%d" % world,
                       "launch": mode, "optimizer": "FlatAdam (one sv_adam launch on a flat buffer)",
                       "collective": "1 RCCL all-reduce of the flat gradient buffer (2.49 M floats) per iteration" if multi else "none"},
-           "loss": round(float(loss), 4), "TFLOPs": round(flops / ms / 1e9, 2),
+           "loss": round(r["loss"], 4), "TFLOPs": round(flops / ms / 1e9, 2),
            "note": "launch-bound workload (SURVEY.md 8d): 0.07 TFLOP and 0.43 GB per iteration"}
     if probe is not None:
         out["config"]["launch_probe"] = probe
@@ -376,16 +472,22 @@ def main():
         sys.exit("bench.py: %d ranks but %d visible GPUs (RCCL needs one device per rank)" % (world, ndev))
     torch.cuda.set_device(local % max(ndev, 1))
     multi = _multi(world)
-    if multi:
-        # "nccl" is RCCL on ROCm.  SV_DIST_BACKEND=gloo lets the N > 1 code path be exercised on a one-GPU box (both
-        # ranks on the same device, the collective through host memory): a functional check, not a measurement.
-        backend = os.environ.get("SV_DIST_BACKEND", "nccl")
-        # (device_id binds the communicator -- and every barrier -- to this rank's GPU instead of a guess from the rank)
-        kw = {"device_id": torch.device("cuda", local % max(ndev, 1))} if backend == "nccl" else {}
-        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+    # "nccl" is RCCL on ROCm.  SV_DIST_BACKEND=gloo lets the N > 1 code path be exercised on a one-GPU box (both
+    # ranks on the same device, the collective through host memory): a functional check, not a measurement.
+    backend = os.environ.get("SV_DIST_BACKEND", "nccl")
+
+    def init_pg():
+        """Creates the process group -- AFTER the step's hipGraph has been captured when one is wanted: no stream capture while
+        an RCCL process group is alive (its watchdog thread polls hipEventQuery on outstanding work, an error during another
+        thread's capture on this stack); replaying next to it is an ordinary launch, and the all-reduce + optimizer launch
+        stay outside the graph."""
+        if multi and not dist.is_initialized():
+            # (device_id binds the communicator -- and every barrier -- to this rank's GPU instead of a guess from the rank)
+            kw = {"device_id": torch.device("cuda", local % max(ndev, 1))} if backend == "nccl" else {}
+            dist.init_process_group(backend, rank=rank, world_size=world, **kw)
 
     if a.workload == "svhn":
-        return svhn_workload(a, rank, world)
+        return svhn_workload(a, rank, world, init_pg)
     import shot_vae_amd as S
     from shot_vae_amd import _lib as L
     from shot_vae_amd import dp
@@ -405,8 +507,6 @@ def main():
     model = S.VariationalAutoEncoder(a.net, num_input_channels=3, img_size=(32, 32), data_parallel=True,
                                      continuous_latent_dim=128, disc_latent_dim=K, small_input=True,
                                      compute_dtype=a.dtype, rng="device").cuda().train()
-    if multi:
-        dp.broadcast_parameters(model)
     # per-rank noise streams (eps, Gumbel u, pairings): torch seeds = seed + rank.  The mixup coefficients are the lambda
     # contract of SURVEY.md 5.2 -- every rank must use the SAME lambda_l / lambda_u in a step: the eager step draws them
     # from numpy's global generator, seeded IDENTICALLY on every rank here (and consumed in lockstep: two draws per step);
@@ -432,15 +532,19 @@ def main():
 
     mode = a.graph if a.graph is not None else (-1 if a.scaling == "strong" else 0)
     graphed, graph_note, probe = None, "eager, weight gradients on a side stream", None
-    if multi and dist.get_backend() == "nccl" and mode:
-        mode, graph_note = 0, "eager, weight gradients on a side stream (no graph capture next to the RCCL watchdog)"
     if mode and a.schedule != "sequential":
+        # captured BEFORE the process group exists (see init_pg): the constructor's warm-up steps are rank-local updates, the
+        # broadcast below re-synchronises parameters, BatchNorm buffers and the optimizer state
+        assert not dist.is_initialized()
         try:
             graphed = GraphedTrainStep(model, elbo, cls, opt, il, ll, iu, sch, distributed=dmode, schedule=a.schedule)
             graph_note = "hipGraph replay"
         except Exception as e:        # capture unsupported on this stack: run eagerly, say so in the output
             graphed, graph_note = None, "eager (graph capture failed: %s)" % type(e).__name__
             torch.cuda.synchronize()
+    init_pg()
+    if multi:
+        dp.broadcast_parameters(model, optimizer=opt)
 
     def eager_step():
         if a.schedule == "grouped":
@@ -540,38 +644,79 @@ def main():
     if lam_equal is not None:
         out["config"]["lambda_equal_across_ranks"] = lam_equal
 
-    # ---- roofline of the dominant kernel: HIP events around EVERY launch of the library (separate pass) ----
+    # ---- roofline: HIP events around EVERY launch of the library (separate single-stream passes of the same step) ----
     if not a.no_roofline:
         eng = model._engine
-        eng.prof_tags, eng.prof_cost = {}, {}
-        L.prof_tags = eng.prof_tags
-        L.lib().sv_prof_enable(1)
-        eng.wgrad_side_stream = False
-        for _ in range(a.prof_steps):       # eager, single stream: HIP events bracket every launch of the timed schedule
-            if a.schedule == "grouped":
-                train_step_grouped(model, elbo, cls, opt, il, ll, iu, sch, distributed=dmode)
-            else:
-                S.train_step(model, elbo, cls, opt, il, ll, iu, sch, distributed=dmode)
-        ntag = len(eng.prof_tags) + 1
-        ms = (ctypes.c_double * ntag)()
-        cnt = (ctypes.c_int * ntag)()
-        L.lib().sv_prof_collect(ntag, ms, cnt)
-        L.lib().sv_prof_enable(0)
-        tags = dict(eng.prof_tags)
-        L.prof_tags = eng.prof_tags = None
-        rows = []
-        for name, i in tags.items():
-            if not cnt[i]:
-                continue
-            nbytes, flops, nl = eng.prof_cost.get(name, (0.0, 0.0, 0))
-            rows.append(dict(name=name, total_ms=ms[i], launches=cnt[i], avg_us=1000 * ms[i] / cnt[i],
-                             bytes=nbytes / nl if nl else None, flops=flops / nl if nl else None))
+        peak_t = MFMA_PEAK_TFLOPS[a.dtype]
+
+        def prof_pass(paired):
+            """One stream (HIP events bracket every launch).  paired: the body convolutions' weight / data gradients with the
+            HALF block budgets they are launched with in the timed two-stream step (Engine.pair_blocks) -- what the timed step
+            issues, each kernel timed without its partner; not paired: every launch with the full budget."""
+            eng.prof_tags, eng.prof_cost = {}, {}
+            L.prof_tags = eng.prof_tags
+            L.lib().sv_prof_enable(1)
+            side, eng.wgrad_side_stream, eng.prof_paired = eng.wgrad_side_stream, False, bool(paired and eng.wgrad_side_stream)
+            try:
+                for _ in range(a.prof_steps):
+                    if a.schedule == "grouped":
+                        train_step_grouped(model, elbo, cls, opt, il, ll, iu, sch, distributed=dmode)
+                    else:
+                        S.train_step(model, elbo, cls, opt, il, ll, iu, sch, distributed=dmode)
+                ntag = len(eng.prof_tags) + 1
+                ms = (ctypes.c_double * ntag)()
+                cnt = (ctypes.c_int * ntag)()
+                L.lib().sv_prof_collect(ntag, ms, cnt)
+            finally:
+                L.lib().sv_prof_enable(0)
+                tags = dict(eng.prof_tags)
+                L.prof_tags = eng.prof_tags = None
+                eng.wgrad_side_stream, eng.prof_paired = side, False
+            rows = []
+            for name, i in tags.items():
+                if not cnt[i]:
+                    continue
+                nbytes, flops, nl = eng.prof_cost.get(name, (0.0, 0.0, 0))
+                rows.append(dict(name=name, total_ms=ms[i], launches=cnt[i], avg_us=1000 * ms[i] / cnt[i],
+                                 bytes=nbytes / nl if nl else None, flops=flops / nl if nl else None))
+            return rows
+
+        # every costed launch against ITS roofline, by family (floor = max(bytes / HBM peak, flops / MFMA peak) per launch):
+        # the body 3x3 layers, BatchNorm backward, and the odd layers (decoder, stride-2, 1x1 shortcuts, 16-channel layers)
+        def family(n):
+            if n.startswith("sv_"):
+                return n
+            body = any(n.endswith("conv3x3_%dx%d_s1" % (c, c)) for c in (32, 64, 128, 160, 320, 640))
+            return "body_conv3x3_" + n.split(":")[0] if body else "odd_layers_" + n.split(":")[0]
+
+        def families(rows):
+            fam = {}
+            for r in rows:
+                if not r["bytes"]:
+                    continue
+                f = fam.setdefault(family(r["name"]), {"ms": 0.0, "floor_ms": 0.0, "launches": 0})
+                floor_us = max(r["bytes"] / (HBM_PEAK_GBS * 1e3), r["flops"] / (peak_t * 1e6))
+                f["ms"] += r["total_ms"] / a.prof_steps
+                f["floor_ms"] += floor_us * r["launches"] / a.prof_steps / 1e3
+                f["launches"] += r["launches"] // a.prof_steps
+            return fam
+
+        def conv_block(fam):
+            """the convolution families together: time-weighted fraction of their rooflines (= sum of floors / sum of times)"""
+            conv = [v for k, v in fam.items() if not k.startswith("sv_")]
+            t, fl = sum(v["ms"] for v in conv), sum(v["floor_ms"] for v in conv)
+            return {"ms_per_step": round(t, 3), "floor_ms": round(fl, 3), "frac_of_roofline": round(fl / t, 4) if t else None,
+                    "launches_per_step": sum(v["launches"] for v in conv),
+                    "definition": "every conv-like launch (forward, data gradient, weight gradient; body and odd layers): "
+                                  "sum over launches of max(bytes / 8 TB/s, flops / MFMA peak) divided by the sum of their times"}
+
+        paired = a.schedule == "grouped" and eng.wgrad_side_stream and eng.pair_blocks > 0
+        rows = prof_pass(paired)
         tot = sum(r["total_ms"] for r in rows)
         costed = [r for r in rows if r["bytes"]]
         if costed:
             d = max(costed, key=lambda r: r["total_ms"])
             ai = d["flops"] / d["bytes"]
-            peak_t = MFMA_PEAK_TFLOPS[a.dtype]
             if ai < peak_t * 1e12 / (HBM_PEAK_GBS * 1e9):
                 ach = d["bytes"] / (d["avg_us"] * 1e-6) / 1e9
                 roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -586,37 +731,35 @@ def main():
                         algorithmic_bytes=d["bytes"], algorithmic_flops=d["flops"],
                         share_of_kernel_time=round(d["total_ms"] / tot, 3),
                         kernel_ms_per_step=round(tot / a.prof_steps, 3),
-                        launches_per_step_all=sum(r["launches"] for r in rows) // a.prof_steps)
+                        launches_per_step_all=sum(r["launches"] for r in rows) // a.prof_steps,
+                        block_budgets="paired: the body convolutions' weight / data gradients with %d blocks each, as the timed "
+                                      "two-stream step launches them (each timed alone here)" % eng.pair_blocks if paired else
+                                      "full budget for every launch")
             # the five largest entries of the same pass, so that no large kernel stays invisible behind the dominant one
             top = sorted(rows, key=lambda r: -r["total_ms"])[:5]
             roof["top5"] = [{"kernel": r["name"], "ms_per_step": round(r["total_ms"] / a.prof_steps, 3),
                              "launches_per_step": r["launches"] // a.prof_steps, "avg_us": round(r["avg_us"], 2),
                              "GBps": round(r["bytes"] / r["avg_us"] / 1e3, 1) if r["bytes"] else None} for r in top]
-            # every costed launch against ITS roofline, by family (the verdict's own arithmetic: floor = max(bytes / HBM peak,
-            # flops / MFMA peak) per launch): the body 3x3 layers, BatchNorm backward, and the odd layers (decoder, stride-2,
-            # 1x1 shortcuts, 16-channel layers)
-            def family(n):
-                if n.startswith("sv_"):
-                    return n
-                body = any(n.endswith("conv3x3_%dx%d_s1" % (c, c)) for c in (32, 64, 128, 160, 320, 640))
-                return "body_conv3x3_" + n.split(":")[0] if body else "odd_layers_" + n.split(":")[0]
-            fam = {}
-            for r in costed:
-                f = fam.setdefault(family(r["name"]), {"ms": 0.0, "floor_ms": 0.0, "launches": 0})
-                floor_us = max(r["bytes"] / (HBM_PEAK_GBS * 1e3), r["flops"] / (peak_t * 1e6))
-                f["ms"] += r["total_ms"] / a.prof_steps
-                f["floor_ms"] += floor_us * r["launches"] / a.prof_steps / 1e3
-                f["launches"] += r["launches"] // a.prof_steps
+            fam = families(rows)
+            roof["conv"] = conv_block(fam)
             roof["families"] = {k: {"ms_per_step": round(v["ms"], 3), "floor_ms": round(v["floor_ms"], 3),
                                     "frac_of_roofline": round(v["floor_ms"] / v["ms"], 3), "launches_per_step": v["launches"]}
                                 for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])}
+            if paired:          # the same step with the full block budget for every launch, for comparison
+                rows_full = prof_pass(False)
+                fam_full = families(rows_full)
+                roof["full_budget"] = {"kernel_ms_per_step": round(sum(r["total_ms"] for r in rows_full) / a.prof_steps, 3),
+                                       "conv": {k: v for k, v in conv_block(fam_full).items() if k != "definition"},
+                                       "families_frac": {k: round(v["floor_ms"] / v["ms"], 3) for k, v in
+                                                         sorted(fam_full.items(), key=lambda kv: -kv[1]["ms"])}}
             out["roofline"] = roof
             if rank == 0 and os.environ.get("SV_BENCH_TABLE"):
-                for r in sorted(rows, key=lambda r: -r["total_ms"]):
-                    print("# %-28s %6d launches  avg %9.2f us  total %8.3f ms/step  %9s GB/s  %9s TFLOP/s" % (
-                        r["name"], r["launches"] // a.prof_steps, r["avg_us"], r["total_ms"] / a.prof_steps,
-                        "%.1f" % (r["bytes"] / r["avg_us"] / 1e3) if r["bytes"] else "-",
-                        "%.2f" % (r["flops"] / r["avg_us"] / 1e6) if r["flops"] else "-"), file=sys.stderr)
+                for tag_, rr in (("", rows),) + ((("full-budget ", rows_full),) if paired else ()):
+                    for r in sorted(rr, key=lambda r: -r["total_ms"]):
+                        print("# %s%-28s %6d launches  avg %9.2f us  total %8.3f ms/step  %9s GB/s  %9s TFLOP/s" % (
+                            tag_, r["name"], r["launches"] // a.prof_steps, r["avg_us"], r["total_ms"] / a.prof_steps,
+                            "%.1f" % (r["bytes"] / r["avg_us"] / 1e3) if r["bytes"] else "-",
+                            "%.2f" % (r["flops"] / r["avg_us"] / 1e6) if r["flops"] else "-"), file=sys.stderr)
     if rank == 0 and world == 1 and headline and a.dtype == "bf16" and not a.no_extras:
         del model, opt, graphed
         torch.cuda.empty_cache()

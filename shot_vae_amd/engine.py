@@ -281,6 +281,9 @@ class Engine:
         # one-shot callback fired by backward() as soon as every decoder gradient has been ISSUED (main + side stream): the
         # data-parallel step starts the all-reduce of the decoder's 88 % of the gradient bytes there (dp.DecoderFirstAllReduce)
         self.bucket_hook = None
+        # bench.py's per-launch timing pass issues the step on ONE stream (HIP events bracket every launch); with this set it
+        # still gives the paired launches the block budgets they run with in the timed, two-stream step
+        self.prof_paired = False
         self._side_keep = {}          # main stream -> operands of the weight gradients in flight on its side stream
         for b in p.bns:
             self.bufs[b.rv_off: b.rv_off + b.C] = 1.0
@@ -925,8 +928,8 @@ class Engine:
             c = un["cout"]
             # paired launches: the weight gradient (side stream) and the data gradient (main stream) of a body convolution
             # each get `pair` persistent blocks as a per-launch argument (sv_igemm_args / sv_wgrad_args::block_budget)
-            pair = self.pair_blocks if (self.wgrad_side_stream and self.prof_tags is None and
-                                        not torch.cuda.is_current_stream_capturing()) else 0
+            pair = self.pair_blocks if ((self.wgrad_side_stream and self.prof_tags is None and
+                                         not torch.cuda.is_current_stream_capturing()) or self.prof_paired) else 0
             pair = min(pair, L.lib().sv_get_option(L.OPT_PERSISTENT_BLOCKS))
             g2 = torch.empty_like(c1)
             self._wgrad_async(un["conv2"].geom_fwd(B), c1, pro2, D, gbase + 4 * un["conv2"].master_off,

@@ -243,6 +243,23 @@ def test_bench_headline_step_through_rccl_single_rank(allreduce):
 
 
 @pytest.mark.timeout(900)
+@pytest.mark.parametrize("batch", [512, 64])
+def test_bench_graph_replay_next_to_rccl_single_rank(batch):
+    """Strong-scaling readiness: the step's hipGraph is captured BEFORE the RCCL process group is created (no stream capture
+    next to its watchdog), the group is created, parameters / optimizer state are broadcast, and the graph is then REPLAYED
+    with the all-reduce + sv_sgd launch following eagerly -- on one rank here (a one-GPU box), at the headline batch and at
+    the 64 images per rank of an 8-GPU strong-scaling run, where the eager step is host-bound."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "10", "--warmup", "3",
+                        "--batch", str(batch), "--graph", "1", "--no-cpu-baseline", "--no-roofline", "--no-extras"],
+                       capture_output=True, text=True, env=_single_rank_rccl_env(), timeout=850)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["config"]["launch"] == "hipGraph replay", out["config"]
+    assert "RCCL" in out["config"]["collective"] and out["value"] > 0
+    assert 0 < out["loss_sup"] < 1e4 and 0 < abs(out["loss_unsup"]) < 1e4
+
+
+@pytest.mark.timeout(900)
 def test_bench_svhn_through_rccl_single_rank():
     """BASELINE config 5's data-parallel iteration (graph of forwards + backward, one all-reduce of FlatAdam's flat gradient
     buffer, sv_adam with 1/world) with the all-reduce sent through RCCL: one rank, backend "nccl", B = 1024."""

@@ -753,7 +753,7 @@ def test_grouped_step_equals_sequential_step(dtype, B, tol, Bu, om):
         assert T.rel_err(b[k].float().cpu().numpy(), a[k].float().cpu().numpy()) < tol, k
     ga, gb = m1.flat_parameters()[1].double(), m2.flat_parameters()[1].double()
     if dtype == "fp32":
-        assert float((ga - gb).norm() / ga.norm()) < 2e-3
+        assert float((ga - gb).norm() / ga.norm()) < (2e-3 if B <= 128 else 5e-3)      # (float atomics: more adders per address at 416 / 512 images)
     else:
         assert float(ga @ gb / ga.norm() / gb.norm()) > 0.9
     sa, sb = m1.state_dict(), m2.state_dict()

@@ -1,0 +1,80 @@
+"""Does the speed of a wide body convolution depend on WHERE its tensors lie?  (bench extras once showed the 640-channel forward
+at 430 us in every window of one process and 198 us in another.)  The operands are carved from one arena at controlled
+offsets; the launch is timed for a few relative placements."""
+import ctypes as C
+import sys
+
+import torch
+
+sys.path.insert(0, __file__.rsplit("/", 3)[0])
+from shot_vae_amd import _lib as L          # noqa: E402
+from shot_vae_amd import geometry as G      # noqa: E402
+from tools.layer_bench import timed         # noqa: E402
+
+B, Cc, H = (int(v) for v in sys.argv[1:4]) if len(sys.argv) > 3 else (512, 640, 8)
+d = torch.device("cuda:0")
+st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+bf = torch.bfloat16
+n = B * H * H * Cc
+S = (2 * n + (1 << 21) - 1) >> 21 << 21            # tensor bytes rounded up to 2 MiB
+arena = torch.empty(4 * S + (64 << 20), dtype=torch.uint8, device=d)
+base = (arena.data_ptr() + (1 << 21) - 1) >> 21 << 21
+master = (torch.randn(Cc, 9, Cc, device=d) / (9 * Cc) ** 0.5).contiguous()
+g = G.conv_like(B, H, H, Cc, Cc, 3, 1, 1)
+wp = torch.zeros(G.packed_size(g), dtype=bf, device=d)
+L.call("sv_repack", L.SV_BF16, C.c_void_p(master.data_ptr()), Cc, 9, Cc, 0, C.byref(g), C.c_void_p(wp.data_ptr()), st)
+sc, sh = torch.rand(Cc, device=d) + 0.5, torch.randn(Cc, device=d) * 0.3
+stats = torch.zeros(8, 2 * Cc, device=d)
+arena.view(torch.int16)[:].fill_(0x3c00)
+print("arena %x base %x S %x wp %x stats %x" % (arena.data_ptr(), base, S, wp.data_ptr(), stats.data_ptr()))
+for dx, dr, do in ((0, 0, 0), (0, 4096, 8192), (0, 1 << 16, 1 << 17), (0, 1 << 20, 1 << 21 >> 1), (0, 3 << 12, 5 << 12),
+                   (0, 256, 512), (0, (1 << 20) + 4096, (1 << 19) + 12288), (0, 0, 0)):
+    a = L.SvIgemmArgs()
+    a.x, a.residual, a.out = base + dx, base + S + dr, base + 2 * S + (1 << 22) + do
+    a.w = wp.data_ptr()
+    a.pro_scale, a.pro_shift, a.pro_slope = sc.data_ptr(), sh.data_ptr(), 0.01
+    a.stats, a.replicas = stats.data_ptr(), 8
+    us = [timed(lambda: L.call("sv_igemm", C.byref(g), L.SV_BF16, C.byref(a), st)) for _ in range(3)]
+    print("x+%-8x res+%-8x out+%-8x  %s us" % (dx, dr, do, " ".join("%.1f" % u for u in us)), flush=True)
+# the allocator's own placement, as tools/layer_bench.py does it
+for rep in range(3):
+    x = torch.randn(B, H, H, Cc, device=d).to(bf)
+    out = torch.empty(B, H, H, Cc, dtype=bf, device=d)
+    resid = torch.randn(B, H, H, Cc, device=d).to(bf)
+    a = L.SvIgemmArgs()
+    a.x, a.residual, a.out, a.w = x.data_ptr(), resid.data_ptr(), out.data_ptr(), wp.data_ptr()
+    a.pro_scale, a.pro_shift, a.pro_slope = sc.data_ptr(), sh.data_ptr(), 0.01
+    a.stats, a.replicas = stats.data_ptr(), 8
+    us = [timed(lambda: L.call("sv_igemm", C.byref(g), L.SV_BF16, C.byref(a), st)) for _ in range(3)]
+    print("torch alloc: x %x res %x out %x  %s us" % (x.data_ptr(), resid.data_ptr(), out.data_ptr(), " ".join("%.1f" % u for u in us)), flush=True)
+    keep = torch.empty(37 << 20, dtype=torch.uint8, device=d)     # shift the next round's placement
+
+# ---- second question: the SMALL operands.  The prologue's coefficient vectors (scale, shift: re-loaded by every block in every
+# chunk) and the statistics accumulator (float atomics from every block's epilogue) come from torch's small-allocation pool
+# and may share a page / an L2 channel.  Carve them from one small arena at controlled distances.
+small = torch.zeros(8 << 20, dtype=torch.uint8, device=d)
+sb = (small.data_ptr() + 4095) >> 12 << 12
+x = torch.randn(B, H, H, Cc, device=d).to(bf)
+out = torch.empty(B, H, H, Cc, dtype=bf, device=d)
+resid = torch.randn(B, H, H, Cc, device=d).to(bf)
+nb = 4 * Cc
+
+
+def fill(ptr, t):
+    dst = small[ptr - small.data_ptr(): ptr - small.data_ptr() + t.numel() * 4].view(torch.float32)
+    dst.copy_(t)
+
+
+for name, o_sc, o_sh, o_st, R in (("adjacent", 0, nb, 2 * nb, 8), ("stats +64K", 0, nb, 1 << 16, 8), ("stats +1M", 0, nb, 1 << 20, 8),
+                                  ("all 1M apart", 0, 1 << 20, 2 << 20, 8), ("adjacent R=32", 0, nb, 2 * nb, 32),
+                                  ("stats -8K (before)", 1 << 16, (1 << 16) + nb, (1 << 16) - 8 * 2 * nb - 8192, 8),
+                                  ("adjacent", 0, nb, 2 * nb, 8)):
+    small.zero_()
+    fill(sb + o_sc, sc)
+    fill(sb + o_sh, sh)
+    a = L.SvIgemmArgs()
+    a.x, a.residual, a.out, a.w = x.data_ptr(), resid.data_ptr(), out.data_ptr(), wp.data_ptr()
+    a.pro_scale, a.pro_shift, a.pro_slope = sb + o_sc, sb + o_sh, 0.01
+    a.stats, a.replicas = sb + o_st, R
+    us = [timed(lambda: L.call("sv_igemm", C.byref(g), L.SV_BF16, C.byref(a), st)) for _ in range(3)]
+    print("%-22s sc %x sh %x stats %x R=%d  %s us" % (name, sb + o_sc, sb + o_sh, sb + o_st, R, " ".join("%.1f" % u for u in us)), flush=True)
