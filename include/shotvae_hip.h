@@ -90,6 +90,23 @@ typedef struct {
                                    three of four positions; its only consumer, sv_bn_bwd_apply with sv_bn_branch::sparse = 1,
                                    does not read them.  0: every output position is written.                              */
     int32_t reserved0;
+    /* ABI 4: BatchNorm finalisation FOLDED into the consumer.  fold_stats != NULL: the prologue's BatchNorm has not been
+       finalised yet -- fold_stats [R = fold_replicas][2 Cin] are the raw (sum, sum of squares) its producer accumulated over
+       fold_count samples per channel; pro_scale / pro_shift (and fold_mean / fold_rstd) are then OUTPUT locations [Cin]:
+       scale = gamma * rstd, shift = beta - mean * scale, exactly sv_bn_finalize's arithmetic.  A kernel that supports it
+       (the persistent 3x3 kernel of the narrow body layers) lets every block derive the coefficients of its channels
+       itself -- a few dozen loads at its start instead of a launch of its own between two layers -- and block 0 stores the
+       four vectors for the backward pass / sv_bn_running_update; for every other kernel sv_igemm runs sv_bn_finalize first.
+       Groups: fold_stats [G][R][2 Cin], the outputs [G][Cin].  (main_shot_vae.py has 33 BatchNorms per forward.)          */
+    const float* fold_stats;
+    const float* fold_gamma;
+    const float* fold_beta;
+    float* fold_mean;
+    float* fold_rstd;
+    float fold_count;
+    float fold_eps;
+    int32_t fold_replicas;
+    int32_t reserved1;
 } sv_igemm_args;
 
 int sv_igemm(const sv_geom* g, int dtype, const sv_igemm_args* a, void* stream);
@@ -431,7 +448,7 @@ int sv_debug_conv_chunk_program(int* items, int* waits);
 enum { SV_OPT_DISABLE_MASK = 0, SV_OPT_WIDE_MIN_BLOCKS = 1, SV_OPT_HALO_ALL = 2, SV_OPT_PERSISTENT_BLOCKS = 3,
        SV_OPT_DETERMINISTIC = 4 };
 enum { SV_K_CONV3X3 = 1, SV_K_CONV3X3P = 2, SV_K_CONV3X3M = 4, SV_K_CONV3X3W = 8, SV_K_CONV3X3X = 16,
-       SV_K_WGRAD3X3 = 32, SV_K_WGRAD3X3W = 64, SV_K_IGEMM_KV2 = 128, SV_K_HALO = 256, SV_K_HALOP = 512, SV_K_HWGRAD = 1024, SV_K_IGEMM_BIG = 2048, SV_K_WGRAD_WIDE = 4096, SV_K_IGEMM_ALIGNED = 8192, SV_K_IGEMM_DMA = 16384, SV_K_WGRAD_INCR = 32768 };
+       SV_K_WGRAD3X3 = 32, SV_K_WGRAD3X3W = 64, SV_K_IGEMM_KV2 = 128, SV_K_HALO = 256, SV_K_HALOP = 512, SV_K_HWGRAD = 1024, SV_K_IGEMM_BIG = 2048, SV_K_WGRAD_WIDE = 4096, SV_K_IGEMM_ALIGNED = 8192, SV_K_IGEMM_DMA = 16384, SV_K_WGRAD_INCR = 32768, SV_K_WGRAD3X3M = 65536 };
 int sv_set_option(int key, int value);
 int sv_get_option(int key);          /* -1 for an unknown key */
 

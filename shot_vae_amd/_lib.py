@@ -35,7 +35,10 @@ class SvIgemmArgs(C.Structure):
                 ("w", C.c_void_p), ("bias", C.c_void_p), ("residual", C.c_void_p), ("out", C.c_void_p),
                 ("stats", C.c_void_p), ("ex", C.c_void_p), ("ex_scale", C.c_void_p), ("ex_shift", C.c_void_p),
                 ("ex_mean", C.c_void_p), ("ex_rstd", C.c_void_p), ("ex_slope", C.c_float), ("bsums", C.c_void_p),
-                ("replicas", C.c_int32), ("groups", C.c_int32), ("block_budget", C.c_int32), ("flags", C.c_int32), ("sparse_out", C.c_int32), ("reserved0", C.c_int32)]
+                ("replicas", C.c_int32), ("groups", C.c_int32), ("block_budget", C.c_int32), ("flags", C.c_int32), ("sparse_out", C.c_int32), ("reserved0", C.c_int32),
+                ("fold_stats", C.c_void_p), ("fold_gamma", C.c_void_p), ("fold_beta", C.c_void_p), ("fold_mean", C.c_void_p),
+                ("fold_rstd", C.c_void_p), ("fold_count", C.c_float), ("fold_eps", C.c_float), ("fold_replicas", C.c_int32),
+                ("reserved1", C.c_int32)]
 
 
 class SvWgradArgs(C.Structure):
@@ -141,8 +144,8 @@ _PROTOS = {
     "sv_version": [],
 }
 OPT_DISABLE_MASK, OPT_WIDE_MIN_BLOCKS, OPT_HALO_ALL, OPT_PERSISTENT_BLOCKS, OPT_DETERMINISTIC = 0, 1, 2, 3, 4
-K_CONV3X3, K_CONV3X3P, K_CONV3X3M, K_CONV3X3W, K_CONV3X3X, K_WGRAD3X3, K_WGRAD3X3W, K_IGEMM_KV2, K_HALO, K_HALOP, K_HWGRAD, K_IGEMM_BIG, K_WGRAD_WIDE, K_IGEMM_ALIGNED, K_IGEMM_DMA, K_WGRAD_INCR = (
-    1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384, 32768)
+K_CONV3X3, K_CONV3X3P, K_CONV3X3M, K_CONV3X3W, K_CONV3X3X, K_WGRAD3X3, K_WGRAD3X3W, K_IGEMM_KV2, K_HALO, K_HALOP, K_HWGRAD, K_IGEMM_BIG, K_WGRAD_WIDE, K_IGEMM_ALIGNED, K_IGEMM_DMA, K_WGRAD_INCR, K_WGRAD3X3M = (
+    1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384, 32768, 65536)
 EXPORTS = sorted(list(_PROTOS) + ["sv_last_error"])
 
 _lib = None

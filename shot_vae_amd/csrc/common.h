@@ -99,6 +99,11 @@ inline sv_igemm_args_g sv_expand_groups(const sv_geom& g, const sv_igemm_args& a
             if (a.residual) r.residual = reinterpret_cast<const char*>(a.residual) + grp * os;
             if (a.ex) r.ex = reinterpret_cast<const char*>(a.ex) + grp * os;
             if (a.pro_scale) { r.pro_scale = a.pro_scale + grp * g.Cin; r.pro_shift = a.pro_shift + grp * g.Cin; }
+            if (a.fold_stats) {
+                r.fold_stats = a.fold_stats + grp * (int64_t)a.fold_replicas * 2 * g.Cin;
+                r.fold_mean = a.fold_mean + grp * g.Cin;
+                r.fold_rstd = a.fold_rstd + grp * g.Cin;
+            }
             if (a.stats) r.stats = a.stats + grp * (int64_t)a.replicas * 2 * g.N;
             if (a.ex) {
                 r.ex_scale = a.ex_scale + grp * g.N; r.ex_shift = a.ex_shift + grp * g.N;
@@ -128,6 +133,43 @@ inline sv_wg_g<P> sv_expand_wg(const sv_geom& g, const P& p, int groups, int es)
     return A;
 }
 
+// BatchNorm finalisation folded into a consumer kernel (sv_igemm_args::fold_*): all 256 threads of the block sum the R replicas
+// of (sum, sum of squares) of the C <= 64 channels (a fixed partition: thread tid takes channel tid % C and the replicas
+// tid / C, + 256 / C, ...; the partial sums meet in LDS in index order), derive scale / shift -- sv_bn_finalize's arithmetic --
+// into sc_out / sh_out (LDS, C floats each), and `writer` blocks also store scale / shift / mean / rstd to global memory.
+// `scratch`: 2 * 256 floats of LDS.  Ends with a barrier.
+__device__ __forceinline__ void sv_bn_fold_block(const sv_igemm_args& a, int C, float* scratch, float* sc_out, float* sh_out,
+                                                 bool writer) {
+    const int tid = threadIdx.x, c = tid % C, part = tid / C, parts = 256 / C;
+    float s1 = 0.f, s2 = 0.f;
+    if (part < parts)
+        for (int r = part; r < a.fold_replicas; r += parts) {
+            s1 += a.fold_stats[(size_t)r * 2 * C + c];
+            s2 += a.fold_stats[(size_t)r * 2 * C + C + c];
+        }
+    scratch[tid] = s1;
+    scratch[256 + tid] = s2;
+    __syncthreads();
+    if (tid < C) {
+        float t1 = 0.f, t2 = 0.f;
+        for (int q = 0; q < parts; ++q) { t1 += scratch[q * C + tid]; t2 += scratch[256 + q * C + tid]; }
+        const float mu = t1 / a.fold_count;
+        float var = t2 / a.fold_count - mu * mu;
+        var = var > 0.f ? var : 0.f;
+        const float rs = rsqrtf(var + a.fold_eps);
+        const float sc = a.fold_gamma[tid] * rs, sh = a.fold_beta[tid] - mu * sc;
+        sc_out[tid] = sc;
+        sh_out[tid] = sh;
+        if (writer) {
+            const_cast<float*>(a.pro_scale)[tid] = sc;
+            const_cast<float*>(a.pro_shift)[tid] = sh;
+            a.fold_mean[tid] = mu;
+            a.fold_rstd[tid] = rs;
+        }
+    }
+    __syncthreads();
+}
+
 // host side ------------------------------------------------------------------------------------------
 void sv_set_error(const char* fmt, ...);
 bool sv_disabled(int kernel_bit);        // sv_set_option(SV_OPT_DISABLE_MASK, ...): a specialised kernel is switched off
@@ -147,6 +189,7 @@ enum { SV_FLAG_DET = 1 };              // sv_igemm_args::flags
 // the grid) when the calling thread is inside a query -- the caller then returns SV_OK without launching.  In deterministic
 // mode it also checks the replica count of a real launch (returns true with *rc < 0 when it is too small).
 bool sv_dry_run(int grid_x, const sv_igemm_args* a, int* rc);
+bool sv_in_query();                    // the calling thread is inside sv_igemm_query_blocks (nothing may be launched)
 #define SV_LAUNCH_GATE(grid_x, a)                                \
     do {                                                         \
         int gate_rc_ = SV_OK;                                    \
@@ -162,6 +205,8 @@ struct SvProfScope {
     ~SvProfScope() { sv_prof_end(s); }
 };
 int sv_conv3x3_try(const sv_geom* g, int dtype, const sv_igemm_args* a, hipStream_t s, int* rc);
+bool sv_conv3x3_folds(const sv_geom* g, int dtype, const sv_igemm_args* a);   // sv_conv3x3_try would take a kernel that derives the
+                                                                             // prologue's BatchNorm coefficients itself (fold_*)
 int sv_hwgrad_try(const sv_geom* g, int dtype, const void* x, const float* pro_scale, const float* pro_shift, float pro_slope,
                   const void* dy, float* dw, float* ws, int64_t ws_elems, int groups, hipStream_t s, int* rc);
 int sv_halo_try(const sv_geom* g, int dtype, const sv_igemm_args* a, hipStream_t s, int* rc);

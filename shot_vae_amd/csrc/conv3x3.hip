@@ -280,7 +280,18 @@ __global__ __launch_bounds__(256, SV_C3P_WAVES) void conv3x3p_kernel(const sv_ge
     // registers for the whole kernel instead of being re-fetched (a dependent L2 round trip) every tile
     static_assert(256 % VPP == 0, "");
     f32x4 ps0 = {1.f, 1.f, 1.f, 1.f}, ps1 = ps0, pt0 = {0.f, 0.f, 0.f, 0.f}, pt1 = pt0;
-    if (has_pro) {
+    if (has_pro && a.fold_stats) {
+        // the BatchNorm in front of this layer has not been finalised: every block derives the coefficients from the raw
+        // statistics itself (sv_igemm_args::fold_*; the halo area is free until the first tile is stored), the first block
+        // of the launch also stores them for the backward pass
+        float* fs = reinterpret_cast<float*>(halo);
+        sv_bn_fold_block(a, CIN, fs, fs + 512, fs + 512 + CIN, blockIdx.x == 0);
+        ps0 = *reinterpret_cast<const f32x4*>(fs + 512 + hc[0]);
+        ps1 = *reinterpret_cast<const f32x4*>(fs + 512 + hc[0] + 4);
+        pt0 = *reinterpret_cast<const f32x4*>(fs + 512 + CIN + hc[0]);
+        pt1 = *reinterpret_cast<const f32x4*>(fs + 512 + CIN + hc[0] + 4);
+        __syncthreads();
+    } else if (has_pro) {
         ps0 = *reinterpret_cast<const f32x4*>(a.pro_scale + hc[0]);
         ps1 = *reinterpret_cast<const f32x4*>(a.pro_scale + hc[0] + 4);
         pt0 = *reinterpret_cast<const f32x4*>(a.pro_shift + hc[0]);
@@ -799,6 +810,20 @@ int launch_w(const sv_geom* g, const sv_igemm_args* a, hipStream_t s) {
 }
 
 }  // namespace
+
+// sv_conv3x3_try would take the persistent kernel, which folds the BatchNorm finalisation of its prologue (fold_*)
+bool sv_conv3x3_folds(const sv_geom* g, int dtype, const sv_igemm_args* a) {
+    if (!a->fold_stats || a->fold_replicas > 64 || sv_disabled(SV_K_CONV3X3) || sv_disabled(SV_K_CONV3X3P)) return false;
+    if (g->nphase != 1 || g->phase[0].ntap != 9 || g->sy != 1 || g->sx != 1 || g->osy != 1 || g->osx != 1) return false;
+    if (g->Hq != g->Hin || g->Wq != g->Win || g->Hout != g->Hin || g->Wout != g->Win || g->Hin != g->Win) return false;
+    if (g->Win != 8 && g->Win != 16 && g->Win != 32) return false;
+    if (g->Cin % CK != 0 || g->ldx != g->Cin || g->N % 32 != 0) return false;
+    if (g->phase[0].ooy != 0 || g->phase[0].oox != 0) return false;
+    for (int t = 0; t < 9; ++t)
+        if (g->phase[0].dy[t] < -1 || g->phase[0].dy[t] > 1 || g->phase[0].dx[t] < -1 || g->phase[0].dx[t] > 1) return false;
+    if ((g->B * g->Hin) % (128 / g->Win) != 0) return false;
+    return (dtype == SV_BF16 && (g->Cin == 32 || g->Cin == 64)) || (dtype == SV_F32 && g->Cin == 32);
+}
 
 // Returns 1 and sets *rc when the geometry is a stride-1 3x3 convolution this kernel covers.
 int sv_conv3x3_try(const sv_geom* g, int dtype, const sv_igemm_args* a, hipStream_t s, int* rc) {

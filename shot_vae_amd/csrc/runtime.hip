@@ -33,6 +33,7 @@ int g_persistent_blocks = 512;
 int g_deterministic = 0;
 thread_local int* tl_query_blocks = nullptr;
 }  // namespace
+bool sv_in_query() { return tl_query_blocks != nullptr; }
 bool sv_deterministic() { return g_deterministic != 0; }
 bool sv_dry_run(int grid_x, const sv_igemm_args* a, int* rc) {
     if (tl_query_blocks) {

@@ -736,6 +736,290 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3w_kernel(const sv_geom g, cons
     }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// Narrow layers (N, Cin <= 128: the WRN-28-2 body), round 4.  wgrad3x3_kernel above takes ~75 us for every width at 4 x 512
+// images although the layers differ 4x in bytes: its waves own 16 x 16 sub-blocks of a 32 x 32 slab, i.e. per 32-pixel chunk
+// 20 transposing LDS reads feed 9 short MFMAs (16x16x32: the matrix instruction holds the SIMD's issue port for half its
+// time), and every (n, c) slab block re-transforms (BatchNorm + LeakyReLU) the x halo of its pixel range -- twice at 64, four
+// times at 128 channels.  The SIMD issue port, not the matrix pipe / LDS / HBM, set the pace.  Here:
+//   * v_mfma_f32_32x32x16_bf16: a wave owns a whole 32 (n) x 32 (c) tile for all nine taps (144 accumulator registers); per
+//     16-pixel step 2 + 18 transposing reads feed nine 32-cycle MFMAs (half the reads and half the issue slots per flop);
+//   * a block owns NB = 32 or 64 output channels x 32 input channels: at 64 / 128 channels the halo transform is shared by
+//     two n tiles.  Waves: NB = 64: (n half) x (pixel half of the tile); NB = 32: the four pixel quarters.  The partial
+//     tiles of the pixel parts meet in LDS once per block (fixed order: plain read-modify-write between barriers);
+//   * every LDS image is [pixel][32 channels] with 64-byte rows: the four pixel rows a transposing read touches are 256
+//     contiguous bytes -- conflict-free without padding, and the dy tile goes global -> LDS by DMA (lane-linear image);
+//   * pipeline: halo registers of tile i + 2 and the dy DMA of tile i + 2 are requested at the top of iteration i, awaited
+//     by the ONE vmcnt(0) at the top of iteration i + 1 (a whole tile period later), transformed into the other halo stage
+//     and consumed in iteration i + 2; three dy stages, two halo stages, one barrier per tile.
+constexpr int LDM = 32;                         // elements per LDS row (64 bytes)
+template <int WLOG, int NB>
+__global__ __launch_bounds__(256, 2) void wgrad3x3m_kernel(const sv_geom g, const sv_wg_g<wg3_params> PG) {
+    const wg3_params& p = PG.g[blockIdx.y];
+    constexpr int W = 1 << WLOG, TR = 128 / W, WP = W + 2;
+    constexpr int HH = (TR < W) ? TR : W, SEG = TR / HH, LROWS = TR + SEG + 1;
+    constexpr int HP = LROWS * WP;
+    constexpr int HV = HP * 4, HI = (HV + 255) / 256;     // halo vectors (8 channels each)
+    constexpr int NP = NB / 32, PS = 4 / NP;               // n parts, pixel parts of a tile
+    constexpr int KS = 128 / PS / 16;                      // 16-pixel MFMA steps per wave and tile
+    constexpr int YB = NP * 128 * LDM, HB = ((HP * LDM + 511) / 512) * 512;       // elements per dy / halo stage
+    constexpr int YI = NP * 2;                             // dy DMA instructions per wave and tile (1 KiB each)
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16* const lds0 = reinterpret_cast<bf16*>(smem);      // [3][YB] dy stages, then [2][HB] halo stages
+    bf16* const halo0 = lds0 + 3 * YB;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+    const int np = NP == 2 ? (wave_s >> 1) : 0, pp = NP == 2 ? (wave_s & 1) : wave_s;      // this wave's n part / pixel part
+    const int H = g.Hin, BH = g.B * H, nT = BH / TR;
+    const int nCt = g.Cin / 32, nNt = g.N / NB, nNC = nCt * nNt;
+    const int L = blockIdx.x;
+    int nc, split;
+    if (p.splits % 8 == 0) {          // blocks L, L+8 share an XCD: all (n,c) slabs of one pixel range on one L2
+        const int xcd = L & 7, slot = L >> 3;
+        nc = slot % nNC;
+        split = (slot / nNC) * 8 + xcd;
+    } else {
+        nc = L % nNC;
+        split = L / nNC;
+    }
+    const int n0 = (nc / nCt) * NB, c0 = (nc % nCt) * 32;
+    const int t_begin = split * p.tiles_per, t_end = min(nT, t_begin + p.tiles_per);
+    const sv_phase& P = g.phase[0];
+    const uint64_t pdy = pack_taps(P.dy), pdx = pack_taps(P.dx);
+    const bf16* __restrict__ X = reinterpret_cast<const bf16*>(p.x);
+    const bf16* __restrict__ DY = reinterpret_cast<const bf16*>(p.dy);
+    const bool has_pro = p.pro_scale != nullptr;
+    float pslope = has_pro ? p.pro_slope : 1.f;
+    asm volatile("v_mov_b32 %0, %0" : "+v"(pslope));
+
+    const int v = tid & 3;
+    // without a prologue the transform is the identity (scale 1, shift 0, slope 1: exact bf16 -> fp32 -> bf16)
+    f32x4 s0 = {1.f, 1.f, 1.f, 1.f}, s1 = s0, t0 = {0.f, 0.f, 0.f, 0.f}, t1 = t0;
+    if (has_pro) {
+        s0 = *reinterpret_cast<const f32x4*>(p.pro_scale + c0 + 8 * v);
+        s1 = *reinterpret_cast<const f32x4*>(p.pro_scale + c0 + 8 * v + 4);
+        t0 = *reinterpret_cast<const f32x4*>(p.pro_shift + c0 + 8 * v);
+        t1 = *reinterpret_cast<const f32x4*>(p.pro_shift + c0 + 8 * v + 4);
+    }
+    // halo staging slots (as wgrad3x3_kernel).  kind: 0 = always zero, 1 = image row of this tile, 2 = row above the tile,
+    //                                                  3 = row below it (valid only inside the same image)
+    int hlds[HI], hkind[HI];
+    uint32_t hoff[HI];
+#pragma unroll
+    for (int i = 0; i < HI; ++i) {
+        const int idx = tid + 256 * i;
+        const int pix = min(idx, HV - 1) >> 2;
+        const int lr = pix / WP, xx = pix - lr * WP;
+        const int seg = lr / (HH + 1), off = lr - seg * (HH + 1);
+        int kind = 1, rel = lr - 1 - seg;
+        if (off == 0) {
+            if (SEG == 1) { kind = seg == 0 ? 2 : 3; rel = seg == 0 ? -1 : TR; }
+            else kind = 0;
+        }
+        if (xx == 0 || xx == WP - 1) kind = 0;
+        hkind[i] = kind;
+        const int hxc = min(max(xx - 1, 0), W - 1);
+        hoff[i] = (uint32_t)(((rel + 1) * W + hxc) * g.ldx + c0 + 8 * v) * 2u;
+        hlds[i] = idx < HV ? pix * LDM + 8 * v : -1;
+    }
+    const uint32_t hsafe = (uint32_t)(W * g.ldx + c0 + 8 * v) * 2u;
+    // dy DMA: instruction k of this wave moves 16 pixels x 32 channels (n part k / 2 ... see below) = 1 KiB, lane-linear
+    uint32_t yoff[YI];
+#pragma unroll
+    for (int k = 0; k < YI; ++k) {
+        const int inst = 4 * k + wave;                 // 0 .. 8 NP - 1: n part = inst / 8, 16-pixel block = inst % 8
+        const int px = 16 * (inst & 7) + (lane >> 2);
+        yoff[k] = (uint32_t)(px * g.ldo + n0 + 32 * (inst >> 3) + 8 * (lane & 3)) * 2u;
+    }
+    const uint32_t l0 = (uint32_t)(uintptr_t)(wg_lds_ptr)lds0;
+    const char* ybase = nullptr;
+    const char* hbase = nullptr;
+    bool top_ok = false, bot_ok = false;
+    auto bases = [&](int tile) {
+        const int gr0 = tile * TR;
+        top_ok = (gr0 & (H - 1)) != 0;
+        bot_ok = ((gr0 + TR) & (H - 1)) != 0;
+        hbase = reinterpret_cast<const char*>(X) + ((int64_t)gr0 - 1) * W * g.ldx * 2;
+        ybase = reinterpret_cast<const char*>(DY + (int64_t)gr0 * W * g.ldo);
+    };
+    // every VMEM instruction of the loop is spelled in assembly and awaited by the one vmcnt(0) per iteration: the compiler
+    // neither sees the DMA's LDS writes nor counts assembly loads
+    auto dma_y1 = [&](int ystage, auto K) {
+        constexpr int k = decltype(K)::value;
+        const uint32_t base = l0 + (uint32_t)ystage * (uint32_t)(YB * 2) + (uint32_t)wave_s * 1024u, yo = yoff[k];
+        const char* yb = ybase;
+        asm volatile("s_add_u32 m0, %0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3"
+                     :: "s"(base), "n"(k * 4096), "v"(yo), "s"(yb) : "memory", "scc");
+    };
+    auto dma_y = [&](int ystage) { static_for<YI>([&](auto K) { dma_y1(ystage, K); }); };
+    bf16x8 rh[HI];
+    bool hok[HI];
+    auto load_h1 = [&](auto I) {
+        constexpr int i = decltype(I)::value;
+        hok[i] = (hkind[i] == 1) | ((hkind[i] == 2) & top_ok) | ((hkind[i] == 3) & bot_ok);
+        const uint32_t o = hok[i] ? hoff[i] : hsafe;
+        const char* hb = hbase;
+        bf16x8 r;
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(r) : "v"(o), "s"(hb) : "memory");
+        rh[i] = r;
+    };
+    auto load_h = [&]() { static_for<HI>([&](auto I) { load_h1(I); }); };
+    auto drain = [&]() {          // to the compiler the halo registers are (re)defined HERE
+        if constexpr (HI == 4) {
+            bf16x8 r0 = rh[0], r1 = rh[1], r2 = rh[2], r3 = rh[3];
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3) :: "memory");
+            rh[0] = r0; rh[1] = r1; rh[2] = r2; rh[3] = r3;
+        } else {
+            static_assert(HI == 3, "halo register sets of 3 or 4 vectors");
+            bf16x8 r0 = rh[0], r1 = rh[1], r2 = rh[2];
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(r0), "+v"(r1), "+v"(r2) :: "memory");
+            rh[0] = r0; rh[1] = r1; rh[2] = r2;
+        }
+    };
+    bf16x8 zero;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) zero[j] = (bf16)0.f;
+    auto store_h = [&](int hstage) {
+        bf16* hs = halo0 + hstage * HB;
+#pragma unroll
+        for (int i = 0; i < HI; ++i) {
+#ifdef SV_WG3M_NO_XFORM
+            bf16x8 o = rh[i];
+#else
+            bf16x8 o = bn_act8(rh[i], s0, s1, t0, t1, pslope);
+#endif
+            if (!hok[i]) o = zero;
+            if (hlds[i] >= 0) *reinterpret_cast<bf16x8*>(hs + hlds[i]) = o;
+        }
+    };
+
+    // fragment addresses (bytes).  Lane l of a 32x32x16 operand: row / column l & 31, k = 8 (l >> 5) .. + 7 = two transposing
+    // reads of 4 pixels x 16 channels per 16-lane group: lane 4 q + p of a group addresses pixel q, channels 4 p .. 4 p + 3.
+    const int kg = lane >> 5, grp = (lane >> 4) & 1, q4 = (lane & 15) >> 2;
+    const int lpix = 8 * kg + q4;                           // this lane's pixel inside a 16-pixel step (second read: + 4)
+    const int px0 = pp * (128 / PS);                        // first tile pixel of this wave's pixel part
+    const int jrow0 = px0 >> WLOG;
+    const int lrow = (lpix >> WLOG), lcol = lpix & (W - 1);   // (a step spans two image rows only at W = 8)
+    const uint32_t chb = (uint32_t)(16 * grp + 4 * (lane & 3)) * 2u;
+    uint32_t yaddr = l0 + (uint32_t)(np * 128 * LDM + (px0 + lpix) * LDM) * 2u + chb;      // + ystage * YB * 2
+    uint32_t xaddr[9];                                                                       // + hstage * HB * 2
+    {
+        const int hrow = jrow0 + lrow;
+        const uint32_t hb0 = l0 + (uint32_t)(3 * YB) * 2u + (uint32_t)(((hrow + 1 + hrow / HH) * WP + lcol + 1) * LDM) * 2u + chb;
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+            xaddr[t] = hb0 + (uint32_t)((tap_off(pdy, t) * WP + tap_off(pdx, t)) * LDM * 2);
+    }
+    typedef __attribute__((address_space(3))) s16x4 lds_v4;
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    auto rd = [&](uint32_t addr) {       // one 16-pixel fragment = two transposing reads (pixels 0..3 and 4..7 of the lane's k group)
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(uintptr_t)addr);
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(uintptr_t)(addr + 4 * LDM * 2));
+        return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+    };
+    // byte offset of 16-pixel step ks inside this wave's pixel part: whole image rows (W <= 16) or half rows (W = 32)
+    auto step_off = [](int ks) {
+        const int pxs = 16 * ks, r = pxs >> WLOG, c = pxs & (W - 1);
+        return (uint32_t)((r * WP + c) * LDM * 2);
+    };
+
+    typedef float f32x16 __attribute__((ext_vector_type(16)));
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    if (t_begin < t_end) {
+        // prologue: tile t_begin complete in stage 0; tile t_begin + 1 requested (halo registers, dy into stage 1)
+        bases(t_begin);
+        dma_y(0);
+        load_h();
+        drain();
+        store_h(0);
+        bases(min(t_begin + 1, t_end - 1));
+        dma_y(1);
+        load_h();
+        __syncthreads();
+        int ys = 0, hs = 0;                     // stages of the tile on the MFMAs
+        for (int tile = t_begin; tile < t_end; ++tile) {
+            // the requests of the previous iteration (halo registers + dy of tile + 1) have had a whole tile period
+            drain();
+            const int ys1 = ys == 2 ? 0 : ys + 1, ys2 = ys1 == 2 ? 0 : ys1 + 1;
+#ifndef SV_WG3M_NO_HST
+            store_h(hs ^ 1);                    // halo of tile + 1 (nobody reads that stage: tile - 1 ended at the last barrier)
+#endif
+            bases(min(tile + 2, t_end - 1));    // (past the end: a harmless re-load of the last tile)
+#ifndef SV_WG3M_NO_LOAD
+            dma_y(ys2);
+            load_h();
+#endif
+            // ---- the MFMAs of `tile` ------------------------------------------------------------------------------
+#ifndef SV_WG3M_NO_MMA
+            const uint32_t yb = yaddr + (uint32_t)ys * (uint32_t)(YB * 2), hfl = (uint32_t)hs * (uint32_t)(HB * 2);
+            bf16x8 fy = rd(yb), fx[9];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) fx[t] = rd(xaddr[t] + hfl);
+            // rolling fragments: tap t's registers receive the next step's tap t right behind its MFMA -- eight MFMAs before
+            // they are needed; the sched_barrier keeps that order (left alone, the scheduler sinks every read down to its use
+            // to save registers and each MFMA then waits out a full LDS round trip)
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                bf16x8 fyn = fy;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fy, fx[t], acc[t], 0, 0, 0);
+                    if (ks + 1 < KS) {
+                        fx[t] = rd(xaddr[t] + hfl + step_off(ks + 1));
+                        if (t == 0) fyn = rd(yb + (uint32_t)(16 * (ks + 1) * LDM * 2));
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                fy = fyn;
+            }
+#endif
+            __syncthreads();
+            ys = ys1;
+            hs ^= 1;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the last (redundant) requests, before the stages are reused
+
+    // ---- the pixel parts of a tile meet in LDS (fixed order), then the block publishes ONE 9 x NB x 32 slab -------------
+    // D layout of 32x32: lane holds column c = lane & 31, rows n = 8 (r >> 2) + 4 (lane >> 5) + (r & 3), r = 0..15
+    float* const red = reinterpret_cast<float*>(smem);      // [9][NB][32] floats (fits the staging area)
+    __syncthreads();
+#pragma unroll
+    for (int part = 0; part < PS; ++part) {
+        if (pp == part) {
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float* q = red + ((t * NB + 32 * np + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3)) * 32 + (lane & 31));
+                    if (part == 0) *q = acc[t][r];
+                    else *q += acc[t][r];
+                }
+        }
+        __syncthreads();
+    }
+    const int64_t slab = (int64_t)g.N * g.T_orig * g.Cin;
+    float* dst = p.ws ? p.ws + ((int64_t)blockIdx.y * p.splits + split) * slab : p.dw;
+    for (int row = tid >> 3; row < 9 * NB; row += 32) {       // eight lanes per (tap, n) row of 32 floats
+        const int t = row / NB, n = row - t * NB;
+        const f32x4 val = *reinterpret_cast<const f32x4*>(red + row * 32 + 4 * (tid & 7));
+        float* o = dst + ((int64_t)(n0 + n) * g.T_orig + P.torig[t]) * g.Cin + c0 + 4 * (tid & 7);
+        if (p.ws) *reinterpret_cast<f32x4*>(o) = val;
+        else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) atomicAdd(o + j, val[j]);
+        }
+    }
+}
+
 // dw[i] += sum_s ws[s][i].  A block owns 256/G float4 columns; its G thread groups each sum every G-th slab, meet in
 // LDS, and ONE float atomic per output leaves the block (many small slabs -- 512 x 36 KB for the 32-channel stage --
 // used to meet in dw through 32 atomics per output, which cost more than reading the slabs).
@@ -815,6 +1099,32 @@ int launch(const sv_geom* g, const wg3_params& p, hipStream_t s) {
         launch_slab_reduce(p.ws, p.splits * p.groups, n, p.dw, s);
     }
     return sv_check_launch("sv_wgrad(3x3)");
+}
+
+template <int WLOG, int NB>
+int launch_m(const sv_geom* g, const wg3_params& p, hipStream_t s) {
+    constexpr int W = 1 << WLOG, TR = 128 / W;
+    constexpr int HHn = (TR < W) ? TR : W, LROWSn = TR + TR / HHn + 1, HPn = LROWSn * (W + 2);
+    constexpr int YB = (NB / 32) * 128 * LDM, HB = ((HPn * LDM + 511) / 512) * 512;
+    constexpr size_t stage_bytes = (size_t)(3 * YB + 2 * HB) * 2, red_bytes = (size_t)9 * NB * 32 * 4;
+    constexpr size_t lds = stage_bytes > red_bytes ? stage_bytes : red_bytes;
+    const int nNC = (g->N / NB) * (g->Cin / 32);
+    const int grid = p.splits * nNC;
+    static bool optin = false;
+    if (!optin) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3x3m_kernel<WLOG, NB>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return sv_check_launch("hipFuncSetAttribute(wgrad3x3m)");
+        optin = true;
+    }
+    sv_prof_begin(s);
+    hipLaunchKernelGGL((wgrad3x3m_kernel<WLOG, NB>), dim3(grid, p.groups), dim3(256), lds, s, *g, sv_expand_wg(*g, p, p.groups, 2));
+    sv_prof_end(s);
+    if (p.ws) {
+        const int64_t n = (int64_t)g->N * g->T_orig * g->Cin;
+        launch_slab_reduce(p.ws, p.splits * p.groups, n, p.dw, s);
+    }
+    return sv_check_launch("sv_wgrad(3x3 m)");
 }
 
 template <int WLOG>
@@ -910,7 +1220,10 @@ int sv_wgrad3x3_try(const sv_geom* g, int dtype, const void* x, const float* pro
         }
         return 1;
     }
-    const int nNC = (g->N / 32) * (g->Cin / 32);
+    // bf16: the 32x32x16 kernel with 64- (or 32-) channel n tiles
+    const bool use_m = dtype == SV_BF16 && !sv_disabled(SV_K_WGRAD3X3M);
+    const int NBm = use_m && g->N % 64 == 0 ? 64 : 32;
+    const int nNC = (g->N / NBm) * (g->Cin / 32);
     // ~two persistent blocks per CU; every block should still see a few tiles
     const int budget = sv_persistent_blocks();
     const int target = budget / groups > 32 ? budget / groups : 32;
@@ -924,6 +1237,14 @@ int sv_wgrad3x3_try(const sv_geom* g, int dtype, const void* x, const float* pro
     const int64_t need = (int64_t)splits * groups * g->N * g->T_orig * g->Cin;
     p.ws = (ws && ws_elems >= need && splits * groups > 1) ? ws : nullptr;    // no workspace: atomics straight into dw
     if (!p.ws && splits * groups > 1 && sv_deterministic()) return 0;
+    if (use_m) {
+        switch (g->Win) {
+            case 32: *rc = NBm == 64 ? launch_m<5, 64>(g, p, s) : launch_m<5, 32>(g, p, s); break;
+            case 16: *rc = NBm == 64 ? launch_m<4, 64>(g, p, s) : launch_m<4, 32>(g, p, s); break;
+            default: *rc = NBm == 64 ? launch_m<3, 64>(g, p, s) : launch_m<3, 32>(g, p, s); break;
+        }
+        return 1;
+    }
     switch (g->Win) {
         case 32: *rc = dtype == SV_BF16 ? launch<bf16, 5>(g, p, s) : launch<float, 5>(g, p, s); break;
         case 16: *rc = dtype == SV_BF16 ? launch<bf16, 4>(g, p, s) : launch<float, 4>(g, p, s); break;

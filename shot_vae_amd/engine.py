@@ -421,6 +421,11 @@ class Engine:
         a.x, a.w, a.out = x.data_ptr(), w_ptr, out.data_ptr()
         if pro is not None:
             a.pro_scale, a.pro_shift, a.pro_slope = pro[0], pro[1], pro[2]
+            if len(pro) > 3 and pro[3] is not None:
+                # the BatchNorm in front of this layer is finalised BY the launch (sv_igemm_args::fold_*): the persistent
+                # kernels derive the coefficients in every block, sv_igemm runs sv_bn_finalize first for the others
+                (a.fold_stats, a.fold_replicas, a.fold_count, a.fold_gamma, a.fold_beta, a.fold_mean, a.fold_rstd) = pro[3]
+                a.fold_eps = BN_EPS
         if bias is not None:
             a.bias = bias
         if residual is not None:
@@ -465,6 +470,7 @@ class Engine:
     wgrad_side_stream = True      # weight gradients on a side stream (they are off the backward's critical path)
     sparse_shortcut_grad = True      # stride-2 1x1 shortcuts: data gradient written / read at the even positions only
     materialize_decoder_act = True   # BatchNorm + ReLU of the first decoder layers' inputs as a pass of its own (see forward)
+    fold_bn = True                   # BatchNorm finalisation folded into the consuming sv_igemm launch (sv_igemm_args::fold_*)
 
     def _side(self):
         """side stream paired with the current stream"""
@@ -592,15 +598,22 @@ class Engine:
         bn_off, n_bnbuf = self._bn_layout(G)
         bnbuf = torch.empty(n_bnbuf, dtype=torch.float32, device=dev)
         nb = bnbuf.data_ptr()
-        defer = training and (self.defer_slot is not None or G > 1)
+        # running statistics: always through the deferred update (sv_bn_running_update_ex from the saved mean / rstd) -- a
+        # finalisation folded into its consumer kernel has no running-statistics side effect
+        defer = training
 
         def bn_ptrs(b):
             a = _align(G * b.C)
             o = nb + 4 * bn_off[b.index]
             return o, o + 4 * a, o + 8 * a, o + 12 * a       # scale, shift, mean, rstd: [G][C] each
 
-        def finalize(b, stat_name, count):
+        def finalize(b, stat_name, count, fold=False):
+            """(scale, shift, slope[, fold]) of BatchNorm b.  fold=True (the consumer is an sv_igemm launch): no launch here --
+            the consumer finalises (engine._igemm); not in deterministic mode (thousands of accumulator replicas)."""
             sc, sh, mn, rs = bn_ptrs(b)
+            if training and fold and self.fold_bn and not det:
+                return (sc, sh, b.slope, (sbase + 4 * stat_off[stat_name], stat_rep[stat_name], float(count),
+                                          pbase + 4 * b.gamma_off, pbase + 4 * b.beta_off, mn, rs))
             if training:
                 if det:
                     sp, sr = det_stats[stat_name][0].data_ptr(), det_stats[stat_name][1]
@@ -645,16 +658,16 @@ class Engine:
         for i, un in enumerate(p.units):
             cnt_in = B * h * h
             tin = f.t[-1]
-            pro1 = finalize(un["bn1"], "t%d" % i, cnt_in)
+            pro1 = finalize(un["bn1"], "t%d" % i, cnt_in, fold=True)
             ho = h // un["stride"]
             c1 = torch.empty(Bt, ho, ho, un["cout"], dtype=T, device=dev)
             self._igemm(un["conv1"].geom_fwd(B), tin, pk + es * un["conv1"].fwd_off, c1, pro=pro1,
                         stats=sptr("c1_%d" % i), tag="fwd:conv3x3_%dx%d_s%d" % (un["cin"], un["cout"], un["stride"]),
                         groups=G)
-            pro2 = finalize(un["bn2"], "c1_%d" % i, B * ho * ho)
+            pro2 = finalize(un["bn2"], "c1_%d" % i, B * ho * ho, fold=True)
             tout = torch.empty(Bt, ho, ho, un["cout"], dtype=T, device=dev)
             if "convi" in un:
-                proi = finalize(un["bni"], "t%d" % i, cnt_in)
+                proi = finalize(un["bni"], "t%d" % i, cnt_in, fold=True)
                 sc = torch.empty(Bt, ho, ho, un["cout"], dtype=T, device=dev)
                 self._igemm(un["convi"].geom_fwd(B), tin, pk + es * un["convi"].fwd_off, sc, pro=proi,
                             tag="fwd:conv1x1_%dx%d" % (un["cin"], un["cout"]), groups=G)
@@ -666,7 +679,7 @@ class Engine:
                         stats=sptr("t%d" % (i + 1)), tag="fwd:conv3x3_%dx%d_s1" % (un["cout"], un["cout"]), groups=G)
             f.c1.append(c1)
             f.t.append(tout)
-            f.pro.append((pro1, pro2, proi))
+            f.pro.append((pro1[:3], pro2[:3], proi[:3] if proi is not None else None))
             h = ho
         # transition BN + LeakyReLU + global average pool (wideresnet.py:90-91, vae.py:143)
         prot = finalize(p.bn_t, "t%d" % len(p.units), B * h * h)
@@ -716,8 +729,12 @@ class Engine:
                             stats=sptr("h%d" % i) if i < 5 else None, tag="fwd:dec%d" % i, groups=gl)
             f.h.append(out)
             if i < 5:
-                pro = finalize(p.dec_bns[i], "h%d" % i, B * ho * ho)
-                f.dpro.append(pro)
+                # (consumed by the next layer's sv_igemm prologue -- folded -- unless that layer takes the materialised form, or
+                #  is the last ConvTranspose of a launch that runs it for the reconstructed groups only: the running statistics
+                #  need the mean / rstd of EVERY group)
+                pro = finalize(p.dec_bns[i], "h%d" % i, B * ho * ho,
+                               fold=not (self.materialize_decoder_act and p.dec_convs[i + 1].Hin <= 4) and (i < 4 or Gd == G))
+                f.dpro.append(pro[:3])
                 x = out
         rec = None
         if Gd > 0:

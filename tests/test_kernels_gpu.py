@@ -263,7 +263,9 @@ def test_gemm_ragged_batch(dt):
 
 WG_CASES = CONV_CASES + [(40, 16, 16, 32, 3, 1, 1), (16, 32, 32, 32, 3, 1, 1), (32, 64, 64, 16, 3, 1, 1),
                          # wide layers (160 x 32 slabs, wgrad3x3w): several splits, two channel tiles, all image sizes
-                         (16, 160, 160, 32, 3, 1, 1), (8, 96, 320, 16, 3, 1, 1), (32, 160, 160, 8, 3, 1, 1)]
+                         (16, 160, 160, 32, 3, 1, 1), (8, 96, 320, 16, 3, 1, 1), (32, 160, 160, 8, 3, 1, 1),
+                         # the 32x32x16 narrow kernel (wgrad3x3m): 64-channel n tiles at every image size, 32-channel n tiles (N = 96)
+                         (32, 128, 128, 8, 3, 1, 1), (8, 64, 96, 16, 3, 1, 1), (16, 32, 64, 8, 3, 1, 1), (12, 64, 64, 32, 3, 1, 1)]
 
 
 @pytest.mark.parametrize("dt,use_tr", [("f32", 0), ("bf16", 0), ("bf16", 1)])
@@ -1059,3 +1061,63 @@ def test_sparse_stride2_shortcut_gradient(dt, case):
     # (the two runs accumulate the shortcut branch's sums with float atomics in their own order: equal to rounding)
     assert bool(torch.isfinite(dx1.float()).all()) and rel(dx1, dx0) < (1e-5 if dt == "f32" else 1e-2)
     assert rel(b1, b0) < 1e-5 and rel(dg1, dg0) < 1e-5 and rel(db1, db0) < 1e-5
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("B,Cin,N,H,k,stride,groups,R", [(8, 32, 32, 32, 3, 1, 1, 8), (16, 64, 64, 16, 3, 1, 4, 32),
+                                                       (4, 32, 64, 16, 3, 2, 2, 4), (8, 128, 128, 8, 3, 1, 1, 2),
+                                                       (6, 16, 32, 32, 1, 1, 3, 16)])
+def test_folded_batchnorm_finalisation(dt, B, Cin, N, H, k, stride, groups, R):
+    """sv_igemm_args::fold_* (ABI 4): the BatchNorm in front of a conv-like layer finalised BY the launch -- inside the
+    persistent 3x3 kernel (every block derives scale / shift from the raw statistics, block 0 stores the four vectors), or by
+    the sv_bn_finalize launch sv_igemm issues itself for the other kernels -- against sv_bn_finalize + the same launch with
+    finished coefficients: identical coefficient vectors (2e-6: the replicas are summed in another order) and outputs."""
+    code, tdt, tol = DT[dt]
+    if dt == "f32" and Cin > 32 and k == 3 and stride == 1:
+        pytest.skip("fp32 operands: the persistent kernel covers 32 input channels")
+    d = dev()
+    torch.manual_seed(17 + Cin + H)
+    pad = k // 2
+    g = G.conv_like(B, H, H, Cin, N, k, stride, pad)
+    x = (torch.randn(groups * B, H, H, Cin, device=d) * 1.5 + 0.3).to(tdt)
+    master = (torch.randn(N, k * k, Cin) / (k * k * Cin) ** 0.5)
+    w = repack(master, g, False, dt)
+    count = float(B * H * H)
+    # raw statistics of x per group, spread over R replicas as a producer would leave them
+    xf = x.float().view(groups, -1, Cin)
+    parts = torch.rand(groups, R, 1, device=d) + 0.1
+    parts = parts / parts.sum(1, keepdim=True)
+    stats = torch.cat([xf.sum(1)[:, None, :] * parts, (xf * xf).sum(1)[:, None, :] * parts], dim=2).contiguous()     # [G][R][2C]
+    gamma, beta = (torch.rand(Cin, device=d) + 0.5), torch.randn(Cin, device=d) * 0.2
+    Ho = g.Hout
+
+    def launch(fold):
+        coef = torch.zeros(4, groups, Cin, device=d)
+        out = torch.zeros(groups * B, Ho, Ho, N, dtype=tdt, device=d)
+        a = L.SvIgemmArgs()
+        a.x, a.w, a.out, a.groups, a.replicas = x.data_ptr(), w.data_ptr(), out.data_ptr(), groups, 1
+        a.pro_scale, a.pro_shift, a.pro_slope = coef[0].data_ptr(), coef[1].data_ptr(), 0.01
+        if fold:
+            a.fold_stats, a.fold_replicas, a.fold_count, a.fold_eps = stats.data_ptr(), R, count, 1e-5
+            a.fold_gamma, a.fold_beta = gamma.data_ptr(), beta.data_ptr()
+            a.fold_mean, a.fold_rstd = coef[2].data_ptr(), coef[3].data_ptr()
+        else:
+            L.call("sv_bn_finalize", p(stats), R, Cin, count, p(gamma), p(beta), 1e-5, 0.1, None, None, p(coef[0]), p(coef[1]),
+                   p(coef[2]), p(coef[3]), groups, st())
+        L.call("sv_igemm", C.byref(g), code, C.byref(a), st())
+        torch.cuda.synchronize()
+        return coef, out.float()
+
+    c0, o0 = launch(False)
+    c1, o1 = launch(True)
+    assert float((c0 - c1).abs().max() / c0.abs().max()) < 2e-6
+    assert float(c1[3].min()) > 0                                   # rstd written for every group
+    assert float((o0 - o1).abs().max() / o0.abs().max()) < (1e-5 if dt == "f32" else 1e-2)
+    # and against torch: batch-norm + LeakyReLU + convolution of group 0
+    xg = x[:B].float().permute(0, 3, 1, 2).cpu()
+    mu, var = xg.mean((0, 2, 3)), xg.var((0, 2, 3), unbiased=False)
+    yn = (xg - mu[None, :, None, None]) / torch.sqrt(var[None, :, None, None] + 1e-5) * gamma.cpu()[None, :, None, None] + beta.cpu()[None, :, None, None]
+    act = bq(F.leaky_relu(yn, 0.01), dt)
+    wt = bq(master, dt).view(N, k, k, Cin).permute(0, 3, 1, 2)
+    ref = F.conv2d(act, wt, None, stride, pad)
+    assert rel(nchw(o1[:B]), ref) < max(tol, 3e-3)

@@ -1,0 +1,64 @@
+"""Wall time of the phases of the default (grouped, eager, two-stream) step at the headline size: HIP events on the main
+stream between forward, loss stage, decoder backward, encoder backward and the update (averaged over steps)."""
+import sys
+
+import torch
+
+sys.path.insert(0, __file__.rsplit("/", 3)[0])
+import shot_vae_amd as S                      # noqa: E402
+import shot_vae_amd.train as TR               # noqa: E402
+
+net = sys.argv[1] if len(sys.argv) > 1 else "wideresnet-28-2"
+K = 100 if net.endswith("-10") else 10
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 512
+torch.manual_seed(1)
+model = S.VariationalAutoEncoder(net, num_input_channels=3, img_size=(32, 32), data_parallel=True, continuous_latent_dim=128,
+                                 disc_latent_dim=K, small_input=True, compute_dtype="bf16", rng="device").cuda().train()
+elbo, cls = S.VAECriterion(discrete_dim=K, bce_reconstruction=True).cuda(), S.ClsCriterion()
+opt = S.FlatSGD(model, lr=0.02, momentum=0.9, weight_decay=5e-4)
+opt.zero_grad()
+sch = S.schedule(10)
+il, iu = torch.rand(B, 3, 32, 32, device="cuda"), torch.rand(B, 3, 32, 32, device="cuda")
+ll = torch.randint(0, K, (B,), device="cuda")
+marks = []
+
+
+def mark(name):
+    e = torch.cuda.Event(enable_timing=True)
+    e.record()
+    marks.append((name, e))
+
+
+def wrap(obj, attr, before, after):
+    fn = getattr(obj, attr)
+
+    def w(*a, **k):
+        if before:
+            mark(before)
+        r = fn(*a, **k)
+        mark(after)
+        return r
+    setattr(obj, attr, w)
+
+
+wrap(model, "forward_groups_direct", "start_fwd", "end_fwd")
+wrap(TR, "shot_loss_step_groups", None, "end_loss")
+wrap(model, "backward_direct", None, "end_bwd")
+wrap(TR, "apply_update", None, "end_update")
+eng = model._engine
+steps, warm = 20, 5
+acc = {}
+for s in range(warm + steps):
+    marks.clear()
+    mark("step")
+    eng.bucket_hook = lambda: mark("end_dec_bwd")
+    S.train_step_grouped(model, elbo, cls, opt, il, ll, iu, sch)
+    torch.cuda.synchronize()
+    if s >= warm:
+        for (n0, e0), (n1, e1) in zip(marks[:-1], marks[1:]):
+            acc[n0 + " -> " + n1] = acc.get(n0 + " -> " + n1, 0.0) + e0.elapsed_time(e1)
+tot = 0.0
+for k, v in acc.items():
+    print("%-32s %8.3f ms" % (k, v / steps))
+    tot += v / steps
+print("%-32s %8.3f ms" % ("sum", tot))
