@@ -395,17 +395,42 @@ class SmoothELBOLoss:
         return loss, (terms[5], terms[6], terms[7], terms[8])
 
 
+def both_forwards(model, loss_fn, unlabeled_data, labeled_data, label):
+    """The two forwards of one trainer iteration (main_smooth_ELBO_svhn.py:157-168: model(unlabeled), model(labeled, label))
+    as ONE pass over the concatenated batch: these models have no BatchNorm -- no operation couples two samples -- so the
+    encoder, the head GEMM and the decoder see 2 B rows once instead of B rows twice (half the launches of a launch-bound
+    iteration, one weight re-pack per layer); only the samplers (the labelled half takes the one-hot label) and the two loss
+    evaluations stay per half.  Host RNG order of the reference: randn, rand of the unlabelled forward, then of the labelled
+    one.  Returns (loss_u, split_u, loss_l, split_l, rec_u, dist_u, rec_l, dist_l)."""
+    Bu = unlabeled_data.shape[0]
+    o = model._heads(torch.cat([unlabeled_data.float(), labeled_data.float()]))
+    mean_u, logvar_u, alpha_u, _, lat_u, _ = model._latent(o[:Bu], None)
+    mean_l, logvar_l, alpha_l, _, lat_l, _ = model._latent(o[Bu:], label)
+    rec = model._decode_padded(torch.cat([lat_u, lat_l]))
+    rec_u, rec_l = rec[:Bu], rec[Bu:]
+    dist_u = {"cont": [mean_u, logvar_u], "disc": [alpha_u]}
+    dist_l = {"cont": [mean_l, logvar_l], "disc": [alpha_l]}
+    loss_u, split_u = loss_fn(unlabeled_data, rec_u, dist_u)
+    loss_l, split_l = loss_fn(labeled_data, rec_l, dist_l, label)
+    return loss_u, split_u, loss_l, split_l, rec_u, dist_u, rec_l, dist_l
+
+
 def smooth_train_step(model, loss_fn, optimizer, unlabeled_data, labeled_data, label, return_outputs=False,
-                      distributed=False):
+                      distributed=False, batched=True):
     """One iteration of Trainer._train_epoch (main_smooth_ELBO_svhn.py:152-176).  distributed=True: one process per
-    GPU, every rank on its shard of both batches, ONE all-reduce of the bucketed gradients before the optimizer step."""
+    GPU, every rank on its shard of both batches, ONE all-reduce of the bucketed gradients before the optimizer step.
+    batched (default): both forwards as one pass over the concatenated batch (both_forwards); False: two model(...) calls."""
     loss_fn.num_steps += 1
     if optimizer is not None:
         optimizer.zero_grad()
-    rec_u, dist_u, _, _ = model(unlabeled_data)
-    loss_u, split_u = loss_fn(unlabeled_data, rec_u, dist_u)
-    rec_l, dist_l, _, _ = model(labeled_data, label)
-    loss_l, split_l = loss_fn(labeled_data, rec_l, dist_l, label)
+    if batched:
+        loss_u, split_u, loss_l, split_l, rec_u, dist_u, rec_l, dist_l = both_forwards(model, loss_fn, unlabeled_data,
+                                                                                       labeled_data, label)
+    else:
+        rec_u, dist_u, _, _ = model(unlabeled_data)
+        loss_u, split_u = loss_fn(unlabeled_data, rec_u, dist_u)
+        rec_l, dist_l, _, _ = model(labeled_data, label)
+        loss_l, split_l = loss_fn(labeled_data, rec_l, dist_l, label)
     loss = loss_u + loss_l
     loss.backward()
     scale = None
@@ -462,10 +487,7 @@ class GraphedSmoothStep:
         lf = self.loss_fn
         lf.steps_dev += 1
         self.opt.zero_grad(set_to_none=False)
-        rec_u, dist_u, _, _ = self.model(self.u)
-        loss_u, _ = lf(self.u, rec_u, dist_u)
-        rec_l, dist_l, _, _ = self.model(self.l, self.y)
-        loss_l, _ = lf(self.l, rec_l, dist_l, self.y)
+        loss_u, _, loss_l = both_forwards(self.model, lf, self.u, self.l, self.y)[:3]
         loss = loss_u + loss_l
         loss.backward()
         if not self.distributed:

@@ -145,10 +145,13 @@ def test_m2_baseline_step_matches_reference_golden_fp32():
     assert np.max(np.abs(pn - g["final.param_norm"]) / g["final.param_norm"]) < 1e-3
 
 
+@pytest.mark.parametrize("batched", [False, True])
 @pytest.mark.parametrize("kind,Bu,Bl", [("svhn", 6, 4), ("mnist", 4, 6)])
-def test_smooth_elbo_iteration_matches_reference_golden_fp32(kind, Bu, Bl):
+def test_smooth_elbo_iteration_matches_reference_golden_fp32(kind, Bu, Bl, batched):
     """SmoothVAE (svhn_VAE / mnist_VAE on the HIP gather-GEMMs), SmoothELBOLoss and one Adam iteration against the
-    reference model's own run (tests/golden/ref_smooth_*.npz; SURVEY.md §8f row 4, BASELINE configs 1 / 5)."""
+    reference model's own run (tests/golden/ref_smooth_*.npz; SURVEY.md §8f row 4, BASELINE configs 1 / 5) -- through two
+    model(...) calls as the reference's loop makes them, and through the step's ONE pass over the concatenated batch
+    (smooth.both_forwards: what smooth_train_step / GraphedSmoothStep issue)."""
     from oracle import smooth_oracle as SO
     g = T.load("ref_smooth_" + kind)
     img = (3, 32, 32) if kind == "svhn" else (1, 32, 32)
@@ -163,10 +166,15 @@ def test_smooth_elbo_iteration_matches_reference_golden_fp32(kind, Bu, Bl):
     with T.scripted_rng(randn=[nz["eps_u"], nz["eps_l"]], rand=[nz["u_u"], nz["u_l"]]):
         opt.zero_grad()
         loss_fn.num_steps += 1
-        rec_u, dist_u, _, _ = model(unl.cuda())
-        loss_u, split_u = loss_fn(unl.cuda(), rec_u, dist_u)
-        rec_l, dist_l, _, _ = model(lab.cuda(), label.cuda())
-        loss_l, split_l = loss_fn(lab.cuda(), rec_l, dist_l, label.cuda())
+        if batched:
+            from shot_vae_amd.smooth import both_forwards
+            loss_u, split_u, loss_l, split_l, rec_u, dist_u, rec_l, dist_l = both_forwards(model, loss_fn, unl.cuda(), lab.cuda(),
+                                                                                           label.cuda())
+        else:
+            rec_u, dist_u, _, _ = model(unl.cuda())
+            loss_u, split_u = loss_fn(unl.cuda(), rec_u, dist_u)
+            rec_l, dist_l, _, _ = model(lab.cuda(), label.cuda())
+            loss_l, split_l = loss_fn(lab.cuda(), rec_l, dist_l, label.cuda())
         loss = loss_u + loss_l
         loss.backward()
     torch.cuda.synchronize()

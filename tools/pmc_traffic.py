@@ -24,13 +24,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # B = the images ONE launch of the grouped step processes: 4 x 512 at BASELINE config 2, 4 x 256 at config 4 (a batched
 # launch of G groups of B images runs the same blocks as one group of G * B images)
 LAYERS = {
-    "wgrad:conv3x3_32x32_s1": (2048, 32, 32, 32, "wgrad", ["wgrad3x3_kernel", "slab_reduce_kernel"]),
+    "wgrad:conv3x3_32x32_s1": (2048, 32, 32, 32, "wgrad", ["wgrad3x3m_kernel", "wgrad3x3_kernel", "slab_reduce_kernel"]),
     "fwd:conv3x3_32x32_s1": (2048, 32, 32, 32, "fwd", ["conv3x3p_kernel"]),
     "dgrad:conv3x3_32x32_s1": (2048, 32, 32, 32, "dgrad", ["conv3x3p_kernel"]),
-    "wgrad:conv3x3_64x64_s1": (2048, 64, 16, 64, "wgrad", ["wgrad3x3_kernel", "slab_reduce_kernel"]),
+    "wgrad:conv3x3_64x64_s1": (2048, 64, 16, 64, "wgrad", ["wgrad3x3m_kernel", "wgrad3x3_kernel", "slab_reduce_kernel"]),
     "fwd:conv3x3_64x64_s1": (2048, 64, 16, 64, "fwd", ["conv3x3p_kernel"]),
     "dgrad:conv3x3_64x64_s1": (2048, 64, 16, 64, "dgrad", ["conv3x3p_kernel"]),
-    "wgrad:conv3x3_128x128_s1": (2048, 128, 8, 128, "wgrad", ["wgrad3x3_kernel", "slab_reduce_kernel"]),
+    "wgrad:conv3x3_128x128_s1": (2048, 128, 8, 128, "wgrad", ["wgrad3x3m_kernel", "wgrad3x3_kernel", "slab_reduce_kernel"]),
     "fwd:conv3x3_128x128_s1": (2048, 128, 8, 128, "fwd", ["conv3x3_kernel", "conv3x3w_kernel"]),
     "dgrad:conv3x3_128x128_s1": (2048, 128, 8, 128, "dgrad", ["conv3x3_kernel", "conv3x3w_kernel"]),
     "fwd:conv3x3_160x160_s1": (1024, 160, 32, 160, "fwd", ["conv3x3x_kernel", "conv3x3w_kernel"]),
@@ -62,6 +62,8 @@ def one_pass(tag, counter, outdir):
             if nm in row["Kernel_Name"]:
                 per.setdefault(nm, []).append(float(row["Counter_Value"]))
     total = 0.0
+    if "wgrad3x3m_kernel" in per:            # (substring of nothing else; "wgrad3x3_kernel" does not match it either)
+        per.pop("wgrad3x3_kernel", None)
     for nm, vals in per.items():
         n_launch = ITERS + WARM
         per_launch = len(vals) // n_launch           # dispatches of this kernel per launch of the layer
@@ -86,14 +88,22 @@ def step_pass(counter, outdir):
         raise RuntimeError("rocprofv3 failed: " + r.stderr[-2000:])
     files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
     assert files, "no counter_collection.csv under " + d
-    per = {}
+    per, rows = {}, []
     for row in csv.DictReader(open(files[0])):
         if row.get("Counter_Name") != counter:
             continue
+        rows.append((int(row.get("Dispatch_Id", len(rows))), row["Kernel_Name"], float(row["Counter_Value"])))
         for tag, nm in STEP_KERNELS.items():
             if nm in row["Kernel_Name"]:
                 per.setdefault(tag, []).append(float(row["Counter_Value"]))
-    return {tag: (sum(v) / len(v), len(v)) for tag, v in per.items()}
+    res = {tag: (sum(v) / len(v), len(v)) for tag, v in per.items()}
+    # the WHOLE step: every dispatch between the last two sgd_kernel launches (the second timed step), all kernels summed
+    rows.sort()
+    sgd = [i for i, r in enumerate(rows) if "sgd_kernel" in r[1]]
+    if len(sgd) >= 2:
+        seg = rows[sgd[-2] + 1: sgd[-1] + 1]
+        res["__step__"] = (sum(r[2] for r in seg), len(seg))
+    return res
 
 
 def main():
@@ -112,6 +122,14 @@ def main():
                     "formula": "(2*FETCH_SIZE + WRITE_SIZE)*1024, per launch, mean of the %d launches of 3 steps (2 timed + 1 warm-up) of "
                                "bench.py --no-extras" % n}
         print(tag, json.dumps(res[tag]), flush=True)
+    if "__step__" in fetch and "__step__" in write:
+        f, n = fetch["__step__"]
+        w, _ = write["__step__"]
+        res["whole_step"] = {"FETCH_SIZE_KiB": f, "WRITE_SIZE_KiB": w, "traffic_bytes": (2 * f + w) * 1024, "dispatches": n,
+                             "minimum_model_bytes": 14.26e9, "ratio_to_minimum": (2 * f + w) * 1024 / 14.26e9,
+                             "formula": "(2*FETCH_SIZE + WRITE_SIZE)*1024 summed over EVERY dispatch of one BASELINE config-2 step "
+                                        "(sgd_kernel to sgd_kernel) of bench.py --no-extras; SURVEY.md 8d's minimum model is 14.26 GB"}
+        print("whole_step", json.dumps(res["whole_step"]), flush=True)
     if len(sys.argv) > 2 and sys.argv[2] == "step":
         json.dump(res, open(out, "w"), indent=1)
         return
