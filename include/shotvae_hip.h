@@ -384,6 +384,12 @@ int sv_augment(int dtype, const uint8_t* data, const int64_t* index, const int32
 /* master fp32 [N][T_orig][C] -> packed `dtype` per phase [n'][ntap][c'] (transpose swaps n and c)  */
 int sv_repack(int dtype, const float* master, int N, int T_orig, int C, int transpose,
               const sv_geom* g, void* dst, void* stream);
+/* ABI 4: the same packing straight from a tensor in ANOTHER layout -- element (n, tap, c) at src[n * sn + tap * st + c * sc],
+ * zero beyond n_real / c_real (channel padding to the MFMA multiples): a torch Conv2d weight (OIHW: sn = c_real * T, st = 1,
+ * sc = T), a ConvTranspose2d weight (IOHW: sn = T, st = 1, sc = n_real * T) or a Linear weight, without the intermediate
+ * master copy (the smooth-ELBO models keep torch's own parameter tensors: smooth_vae_model/svhn_vae.py:62-132).          */
+int sv_repack_strided(int dtype, const float* src, int n_real, int c_real, int64_t sn, int64_t st, int64_t sc, int N, int T_orig,
+                      int C, int transpose, const sv_geom* g, void* dst, void* stream);
 
 /* All packs of a network in one launch (68 sv_repack launches per optimizer step otherwise).  jobs: DEVICE array, one
  * entry per (layer, direction, phase) with taps, sorted by block0; a job owns ceil(size / 1024) consecutive blocks from

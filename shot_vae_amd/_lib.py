@@ -132,6 +132,7 @@ _PROTOS = {
     "sv_nchw_to_nhwc": [I, P, I, I, I, I, I, P, P],
     "sv_nhwc_to_nchw": [I, P, I, I, I, I, I, P, P],
     "sv_repack": [I, P, I, I, I, I, C.POINTER(SvGeom), P, P],
+    "sv_repack_strided": [I, P, I, I, I64, I64, I64, I, I, I, I, C.POINTER(SvGeom), P, P],
     "sv_repack_batch": [I, P, P, I, I, P, P],
     "sv_augment": [I, P, P, P, I, I, I, I, I, I, P, P],
     "sv_prof_enable": [I],

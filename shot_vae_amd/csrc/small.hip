@@ -1419,6 +1419,8 @@ __global__ void augment_kernel(const uint8_t* data, const int64_t* index, const 
 
 struct repack_params {
     int N, T_orig, C, transpose, nphase;
+    int n_real, c_real;              // source extents (beyond them: zero padding)
+    int64_t sn, st, sc;              // source strides (elements) of (n, tap, c): master layout = (T_orig * C, C, 1)
     int ntap[SV_MAX_PHASES];
     int64_t w_off[SV_MAX_PHASES], size[SV_MAX_PHASES];
     int8_t torig[SV_MAX_PHASES][SV_MAX_TAPS];
@@ -1494,7 +1496,7 @@ __global__ void repack_kernel(const float* master, const repack_params p, T* dst
 #pragma unroll
     for (int k = 0; k < SV_MAX_TAPS; ++k)
         if (k == t) to = p.torig[ph][k];
-    dst[p.w_off[ph] + i] = (T)master[((int64_t)n * p.T_orig + to) * p.C + c];
+    dst[p.w_off[ph] + i] = (n < p.n_real && c < p.c_real) ? (T)master[n * p.sn + to * p.st + c * p.sc] : (T)0.f;
 }
 
 inline int nblocks(int64_t n, int bs, int cap = 2048) {
@@ -2105,10 +2107,17 @@ int sv_repack_batch(int dtype, const float* master_base, const sv_repack_job* jo
 }
 int sv_repack(int dtype, const float* master, int N, int T_orig, int C, int transpose, const sv_geom* g, void* dst,
               void* stream) {
+    return sv_repack_strided(dtype, master, N, C, (int64_t)T_orig * C, C, 1, N, T_orig, C, transpose, g, dst, stream);
+}
+
+int sv_repack_strided(int dtype, const float* src, int n_real, int c_real, int64_t sn, int64_t st, int64_t sc, int N, int T_orig,
+                      int C, int transpose, const sv_geom* g, void* dst, void* stream) {
     SvProfScope prof_scope(stream);
-    SV_REQUIRE(master && g && dst, SV_E_ARG, "sv_repack: null");
+    SV_REQUIRE(src && g && dst, SV_E_ARG, "sv_repack: null");
+    SV_REQUIRE(n_real >= 1 && n_real <= N && c_real >= 1 && c_real <= C, SV_E_ARG, "sv_repack: source extents %d x %d of %d x %d", n_real, c_real, N, C);
     repack_params p;
     p.N = N; p.T_orig = T_orig; p.C = C; p.transpose = transpose; p.nphase = g->nphase;
+    p.n_real = n_real; p.c_real = c_real; p.sn = sn; p.st = st; p.sc = sc;
     int64_t mx = 0;
     for (int i = 0; i < SV_MAX_PHASES; ++i) {
         p.ntap[i] = 0; p.w_off[i] = 0; p.size[i] = 0;
@@ -2123,7 +2132,7 @@ int sv_repack(int dtype, const float* master, int N, int T_orig, int C, int tran
     }
     if (mx == 0) return SV_OK;
     DISPATCH_T(dtype, hipLaunchKernelGGL((repack_kernel<T>), dim3((unsigned)((mx + 255) / 256), g->nphase), dim3(256),
-                                         0, (hipStream_t)stream, master, p, (T*)dst));
+                                         0, (hipStream_t)stream, src, p, (T*)dst));
     return sv_check_launch("sv_repack");
 }
 

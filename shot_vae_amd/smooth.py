@@ -42,6 +42,43 @@ def _pad16(n):
     return (n + 15) // 16 * 16
 
 
+_CONST = {}
+
+
+def _one_zero(n, dev):
+    """constant [n] vectors of ones / zeros (the identity BatchNorm coefficients of the ReLU prologue / epilogue), made once
+    per size and device instead of two fill launches per layer and direction"""
+    key = (n, dev)
+    v = _CONST.get(key)
+    if v is None:
+        v = _CONST[key] = (torch.ones(n, device=dev), torch.zeros(n, device=dev))
+    return v
+
+
+class _GradScratch:
+    """Zeroed fp32 scratch for the weight / bias gradients of ONE backward pass: the layers carve their accumulators (sv_wgrad
+    and sv_colsum add) out of one buffer that is cleared by a single launch (SmoothVAE.begin_iteration) instead of two fill
+    launches per layer.  Falls back to per-layer allocations when it has not been armed for this pass."""
+
+    def __init__(self):
+        self.buf, self.off, self.armed = None, 0, False
+
+    def arm(self, n, dev):
+        if self.buf is None or self.buf.numel() < n or self.buf.device != dev:
+            self.buf = torch.zeros(n, dtype=torch.float32, device=dev)
+        else:
+            self.buf.zero_()
+        self.off, self.armed = 0, True
+
+    def take(self, n, dev):
+        n_al = (n + 63) // 64 * 64
+        if not self.armed or self.buf is None or self.off + n_al > self.buf.numel() or self.buf.device != dev:
+            return torch.zeros(n, dtype=torch.float32, device=dev)
+        t = self.buf[self.off: self.off + n]
+        self.off += n_al
+        return t
+
+
 class _Layer:
     """Static description of one conv-like layer: kind 'conv' (Conv2d / Linear-as-conv) or 'convT'."""
 
@@ -51,6 +88,7 @@ class _Layer:
         self.cin_real, self.n_real = cin_real or cin, n_real or n
         self.T = k * k
         self._g = {}
+        self.scratch = _GradScratch()         # (shared by the layers of a model: SmoothVAE.__init__)
 
     @property
     def Hout(self):
@@ -72,6 +110,19 @@ class _Layer:
             g = self._g[("d", B)] = f(B, self.Hout, self.Hout, self.N, self.Cin, self.k, self.stride, self.pad)
         return g
 
+    def src_strides(self):
+        """(sn, st, sc): element strides of (n, tap, c) in the torch parameter -- Conv2d / Linear-as-conv OIHW, ConvTranspose2d IOHW"""
+        if self.kind == "conv":
+            return self.cin_real * self.T, 1, self.T
+        return self.T, 1, self.n_real * self.T
+
+    def grad_view(self, dwm):
+        """the weight gradient in master layout [N][tap][Cin] seen in the parameter's own layout and extent (a strided view)"""
+        m = dwm.view(self.N, self.k, self.k, self.Cin)
+        if self.kind == "conv":
+            return m.permute(0, 3, 1, 2)[: self.n_real, : self.cin_real]
+        return m.permute(3, 0, 1, 2)[: self.cin_real, : self.n_real]
+
     def master(self, w):
         """torch parameter (OIHW for conv, IOHW for convT, [out, in] for Linear given as OIHW view) -> fp32 master
         [N][tap][Cin], zero-padded to the MFMA channel multiples.  Differentiable (torch ops), so the weight gradient
@@ -88,43 +139,50 @@ class _ConvLikeFn(torch.autograd.Function):
     its epilogue), sv_wgrad, sv_colsum."""
 
     @staticmethod
-    def forward(ctx, x, master, bias, layer, relu_in, dtype):
+    def forward(ctx, x, w, bias, layer, relu_in, dtype):
+        """w: the layer's weight in torch's own layout (Conv2d / Linear-as-conv OIHW, ConvTranspose2d IOHW, real extents): packed
+        straight from it (sv_repack_strided) -- no intermediate master copy, no permute / pad kernels in either direction"""
         if not x.is_cuda:
             raise L.ShotVaeHipError("shot_vae_amd runs on an MI355X only (no CPU fallback)")
         code, tdt = (L.SV_BF16, torch.bfloat16) if dtype == "bf16" else (L.SV_F32, torch.float32)
         x = x.contiguous()
+        w = w.contiguous().float()
         B, dev = x.shape[0], x.device
         gf = layer.geom_fwd(B)
-        wp = torch.zeros(max(G.packed_size(gf), 1), dtype=tdt, device=dev)
-        L.call("sv_repack", code, _vp(master), layer.N, layer.T, layer.Cin, 0, C.byref(gf), _vp(wp), _st())
+        wp = torch.empty(max(G.packed_size(gf), 1), dtype=tdt, device=dev)
+        sn, st_, sc = layer.src_strides()
+        L.call("sv_repack_strided", code, _vp(w), layer.n_real, layer.cin_real, sn, st_, sc, layer.N, layer.T, layer.Cin, 0,
+               C.byref(gf), _vp(wp), _st())
         out = torch.empty(B, layer.Hout, layer.Hout, layer.N, dtype=tdt, device=dev)
         a = L.SvIgemmArgs()
         a.x, a.w, a.out, a.replicas = x.data_ptr(), wp.data_ptr(), out.data_ptr(), 1
         keep = [wp]
         if relu_in:
-            one, zero = torch.ones(layer.Cin, device=dev), torch.zeros(layer.Cin, device=dev)
+            one, zero = _one_zero(layer.Cin, dev)
             a.pro_scale, a.pro_shift, a.pro_slope = one.data_ptr(), zero.data_ptr(), 0.0
-            keep += [one, zero]
         if bias is not None:
             a.bias = bias.data_ptr()
         L.call("sv_igemm", C.byref(gf), code, C.byref(a), _st())
-        ctx.save_for_backward(x, master)
+        ctx.save_for_backward(x, w)
         ctx.layer, ctx.relu_in, ctx.code, ctx.tdt, ctx.has_bias = layer, relu_in, code, tdt, bias is not None
         ctx.keep = keep
         return out
 
     @staticmethod
     def backward(ctx, dy):
-        x, master = ctx.saved_tensors
+        x, w = ctx.saved_tensors
         layer, code, tdt = ctx.layer, ctx.code, ctx.tdt
         B, dev = x.shape[0], x.device
         dy = dy.contiguous()
         gf, gd = layer.geom_fwd(B), layer.geom_dgrad(B)
-        one, zero = torch.ones(layer.Cin, device=dev), torch.zeros(layer.Cin, device=dev)
+        one, zero = _one_zero(layer.Cin, dev)
+        gs = layer.scratch
         dx = None
         if ctx.needs_input_grad[0]:
-            wpd = torch.zeros(max(G.packed_size(gd), 1), dtype=tdt, device=dev)
-            L.call("sv_repack", code, _vp(master), layer.N, layer.T, layer.Cin, 1, C.byref(gd), _vp(wpd), _st())
+            wpd = torch.empty(max(G.packed_size(gd), 1), dtype=tdt, device=dev)
+            sn, st_, sc = layer.src_strides()
+            L.call("sv_repack_strided", code, _vp(w), layer.n_real, layer.cin_real, sn, st_, sc, layer.N, layer.T, layer.Cin, 1,
+                   C.byref(gd), _vp(wpd), _st())
             dx = torch.empty_like(x)
             a = L.SvIgemmArgs()
             a.x, a.w, a.out, a.replicas = dy.data_ptr(), wpd.data_ptr(), dx.data_ptr(), 1
@@ -133,17 +191,17 @@ class _ConvLikeFn(torch.autograd.Function):
                 a.ex_mean, a.ex_rstd, a.ex_slope, a.bsums = zero.data_ptr(), one.data_ptr(), 0.0, x.data_ptr()
                 if L.deterministic():        # (the sums are not used here, but the launch wants one replica per wave)
                     a.replicas = L.det_replicas(gd, code, a)
-                bs = torch.zeros(a.replicas * 2 * layer.Cin, device=dev)
+                bs = gs.take(a.replicas * 2 * layer.Cin, dev)          # (the sums of the identity BatchNorm: unused)
                 a.bsums = bs.data_ptr()
             L.call("sv_igemm", C.byref(gd), code, C.byref(a), _st())
-        dw = torch.zeros_like(master)
+        dw = gs.take(layer.N * layer.T * layer.Cin, dev).view(layer.N, layer.T, layer.Cin)
         L.call("sv_wgrad", C.byref(gf), code, _vp(x), _vp(one) if ctx.relu_in else None,
                _vp(zero) if ctx.relu_in else None, 0.0, _vp(dy), _vp(dw), 0, 1, None, 0, 1, _st())
         db = None
         if ctx.has_bias:
-            db = torch.zeros(layer.N, device=dev)
+            db = gs.take(layer.N, dev)
             L.call("sv_colsum", code, _vp(dy), dy.numel() // layer.N, layer.N, layer.N, _vp(db), _st())
-        return dx, dw, db, None, None, None
+        return dx, layer.grad_view(dw), db, None, None, None
 
 
 class _LatentFn(torch.autograd.Function):
@@ -282,14 +340,29 @@ class SmoothVAE(nn.Module):
             t1=_Layer("convT", 4, 2, 1, w3, d1, 4), t2=_Layer("convT", 4, 2, 1, d1, d2, 8),
             t3=_Layer("convT", 4, 2, 1, d2, 16, 16, n_real=ch))
         self._tdt = torch.bfloat16 if compute_dtype == "bf16" else torch.float32
+        self._scratch = _GradScratch()
+        for l_ in self._L.values():
+            l_.scratch = self._scratch
+        # floats one backward pass takes from the scratch: dW (master layout) + db + the unused epilogue sums, 64-aligned
+        self._scratch_need = sum((l_.N * l_.T * l_.Cin + 63) // 64 * 64 + (l_.N + 63) // 64 * 64 + (2 * l_.Cin + 63) // 64 * 64
+                                 for l_ in self._L.values())
+
+    def begin_iteration(self, device):
+        """arms the gradient scratch for the ONE backward pass that follows (both_forwards: one launch clears all of it).  Only
+        when every parameter already has its .grad (FlatAdam: views of its flat buffer; autograd then ADDS the returned
+        gradients in place) -- otherwise autograd may adopt a returned tensor as .grad, and that must not be a slice of a
+        buffer the next iteration clears."""
+        if all(p_.grad is not None for p_ in self.parameters()):
+            self._scratch.arm(self._scratch_need, device)
+        else:
+            self._scratch.armed = False
 
     # ---- layers --------------------------------------------------------------------------------------------------
     def _run(self, name, x, w, b, relu_in, npad=None):
         layer = self._L[name]
         if b is not None and layer.n_real != layer.N:
             b = F.pad(b, (0, layer.N - layer.n_real))
-        return _ConvLikeFn.apply(x, layer.master(w), b.float().contiguous() if b is not None else None, layer, relu_in,
-                                 self.compute_dtype)
+        return _ConvLikeFn.apply(x, w, b.float().contiguous() if b is not None else None, layer, relu_in, self.compute_dtype)
 
     def _code(self):
         return L.SV_BF16 if self.compute_dtype == "bf16" else L.SV_F32
@@ -366,6 +439,7 @@ class SmoothVAE(nn.Module):
         return self._decode_padded(z)
 
     def forward(self, x, label=None):
+        self._scratch.armed = False          # (a plain forward: its backward allocates its own accumulators)
         mean, logvar, alpha, gs, latent, latent_sample = self._latent(self._heads(x), label)
         latent_dist = {"cont": [mean, logvar], "disc": [alpha]}
         disc_sample = [gs] if label is not None else []      # drawn (and unused) for labelled data, as svhn_vae.py:205-207
@@ -403,6 +477,7 @@ def both_forwards(model, loss_fn, unlabeled_data, labeled_data, label):
     evaluations stay per half.  Host RNG order of the reference: randn, rand of the unlabelled forward, then of the labelled
     one.  Returns (loss_u, split_u, loss_l, split_l, rec_u, dist_u, rec_l, dist_l)."""
     Bu = unlabeled_data.shape[0]
+    model.begin_iteration(unlabeled_data.device)
     o = model._heads(torch.cat([unlabeled_data.float(), labeled_data.float()]))
     mean_u, logvar_u, alpha_u, _, lat_u, _ = model._latent(o[:Bu], None)
     mean_l, logvar_l, alpha_l, _, lat_l, _ = model._latent(o[Bu:], label)
