@@ -446,8 +446,9 @@ int sv_debug_conv_chunk_program(int* items, int* waits);
  *   - weight gradients: per-block partial slabs + the ordered slab reduction where the kernel has them (3x3 stride 1, the
  *     tap-fused thin layers -- they need the workspace), otherwise ONE M range and the groups of a batched launch one after
  *     the other (a single adder per weight); the cooperative wide kernel (float atomics over splits) is not taken;
- *   - the wide 3x3 kernels conv3x3w / conv3x3x (cross-wave LDS atomics in their epilogue) are not taken: their layers run on
- *     the general LDS-halo kernel (each is tested against it separately);
+ *   - the wide 3x3 kernel conv3x3w (cross-wave LDS atomics in its epilogue) is not taken: its layers run on the general
+ *     LDS-halo kernel (tested against it separately); conv3x3x (the 160-channel tiles of the WRN-28-10 body) IS taken since
+ *     round 4: its waves keep private channel sums, a block adds them in a fixed order and is the only adder of its replica;
  *   - the small reduction kernels (pool backward, head weight gradient, column sums, loss terms, BatchNorm dgamma / dbeta
  *     of a batched launch) run their fixed-order variants.
  * Default 0.                                                                                                          */

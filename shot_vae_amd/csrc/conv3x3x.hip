@@ -586,7 +586,7 @@ int launch_x4(const sv_geom* g, const sv_igemm_args* a, hipStream_t s) {
             return sv_check_launch("hipFuncSetAttribute(conv3x3x)");
         optin = true;
     }
-    SV_LAUNCH_GATE(grid, a);          // (query only: these kernels are not dispatched in deterministic mode)
+    SV_LAUNCH_GATE(grid, a);          // (deterministic mode: a replica per block -- the gate checks replicas >= 4 * grid)
     sv_prof_begin(s);
     hipLaunchKernelGGL((conv3x3x_kernel<WLOG, REV, MODE>), dim3(grid, G), dim3(256), lds, s, *g, sv_expand_groups(*g, *a, 2));
     sv_prof_end(s);

@@ -66,7 +66,9 @@ int sv_persistent_blocks() { return tl_block_budget > 0 ? tl_block_budget : g_pe
 bool sv_halo_all() { return g_halo_all != 0; }
 bool sv_disabled(int kernel_bit) {
     // deterministic mode: no kernel with cross-wave LDS float atomics / float atomics over splits (see shotvae_hip.h)
-    if (g_deterministic && (kernel_bit & (SV_K_CONV3X3W | SV_K_CONV3X3X | SV_K_WGRAD_WIDE))) return true;
+    // (conv3x3x is deterministic with a replica per block: its waves keep private channel sums, the block adds them in a fixed
+    //  order and is the only adder of its replica -- sv_igemm_query_blocks sizes the accumulators)
+    if (g_deterministic && (kernel_bit & (SV_K_CONV3X3W | SV_K_WGRAD_WIDE))) return true;
     return (g_disable_mask & kernel_bit) != 0;
 }
 int sv_wide_min_blocks() { return g_wide_min_blocks; }

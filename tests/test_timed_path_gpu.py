@@ -38,7 +38,7 @@ def _running(model):
     return {k: v.detach().float().cpu().clone() for k, v in model.state_dict().items() if "running_" in k}
 
 
-@pytest.mark.parametrize("name,K,B,dmi,tol", [("wideresnet-28-2", 10, 512, 2.3, 5e-3), ("wideresnet-28-10", 100, 256, 4.6, 1e-2)])
+@pytest.mark.parametrize("name,K,B,dmi,tol", [("wideresnet-28-2", 10, 512, 2.3, 5e-3), ("wideresnet-28-10", 100, 256, 4.6, 5e-3)])
 def test_grouped_step_default_engine_state_at_full_size(name, K, B, dmi, tol):
     torch.manual_seed(17)
     il, ll, iu = torch.rand(B, 3, 32, 32), torch.randint(0, K, (B,)), torch.rand(B, 3, 32, 32)
@@ -93,12 +93,14 @@ def test_grouped_step_default_engine_state_at_full_size(name, K, B, dmi, tol):
             assert abs(float(klc) - vals["klc_l"]) < 1e-3 * float(klc)
             assert 0.0 <= vals["kld_l"] <= np.log(K) + 1e-4
             # grouped = sequential: the batched kernels see exactly the per-forward problems
+            wseq = max(abs(vals[k] - ref[k]) / max(abs(ref[k]), 1e-6) / (2 if "_post_" in k else 1) for k in T.SCALARS)
+            print("\n[%s B=%d] grouped vs sequential: worst loss-scalar deviation %.2e of the gate unit (gate %.0e)" % (name, B, wseq, tol))
             for k in T.SCALARS:
                 tk = 2 * tol if "_post_" in k else tol
                 assert abs(vals[k] - ref[k]) <= tk * max(abs(ref[k]), 1e-6), ("grouped vs sequential", k, vals[k], ref[k])
             cos = float(grad @ g_seq / grad.norm() / g_seq.norm())
             print("\n[%s B=%d] grouped vs sequential: flat-gradient cosine %.4f" % (name, B, cos))
-            assert cos > 0.9, cos
+            assert cos > 0.95, cos          # (measured 0.968 - 0.978 over three runs of both configurations)
             run = _running(model)
             for k in run_seq:
                 assert T.rel_err(run[k].numpy(), run_seq[k].numpy()) < 2e-2, k
@@ -107,7 +109,7 @@ def test_grouped_step_default_engine_state_at_full_size(name, K, B, dmi, tol):
         else:
             cos = float(grad @ g0 / grad.norm() / g0.norm())
             worst_cos = min(worst_cos, cos)
-            assert cos > 0.9, (rep, cos)
+            assert cos > 0.95, (rep, cos)   # (float atomics: measured 0.968 - 0.983 against the first run)
     print("[%s B=%d] 10 repeats of the timed path: lowest gradient cosine against the first %.4f" % (name, B, worst_cos))
     # the same step ten times: only the order of the float atomics may differ -- every run within the spread of the MEDIAN run
     # (a single reference run may itself be the outlier; the posterior terms are differences between the outputs of two
@@ -121,6 +123,8 @@ def test_grouped_step_default_engine_state_at_full_size(name, K, B, dmi, tol):
     st = {k: v.clone() for k, v in init.items()}
     with torch.no_grad():
         orc = O.train_step(st, name, il, ll, iu, nz, sch, backward=False)
+    worc = max(abs(med[k] - float(orc[k])) / max(abs(float(orc[k])), 1e-6) / (2 if "_post_" in k else 1) for k in T.SCALARS)
+    print("[%s B=%d] median run vs fp32 oracle: worst loss-scalar deviation %.2e of the gate unit (gate %.0e)" % (name, B, worc, tol))
     for k in T.SCALARS:
         r = float(orc[k])
         tk = 2 * tol if "_post_" in k else tol
