@@ -65,6 +65,9 @@ def parse():
     ap.add_argument("--pair-blocks", type=int, default=-1,
                     help="Engine.pair_blocks: block budget of each kernel of a paired weight / data gradient launch (-1 = the "
                          "engine's default, 256; 0 = both with the full budget)")
+    ap.add_argument("--wgrad-after", type=int, default=0,
+                    help="experiment: 1 = a body layer's weight gradient (side stream) starts when its data gradient has finished "
+                         "instead of beside it (use with --pair-blocks 0)")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher check without a GPU: the ranks rendezvous over gloo, agree on a max-reduced time and "
                          "rank 0 prints a JSON stub (tests/test_bench_launch_cpu.py)")
@@ -528,6 +531,7 @@ def main():
     model._engine.wgrad_side_stream = bool(a.wgrad_side)
     if a.pair_blocks >= 0:
         model._engine.pair_blocks = a.pair_blocks
+    model._engine.wgrad_after = bool(a.wgrad_after)
     dmode = False if not multi else ("bucketed" if a.allreduce == "bucketed" else True)
 
     mode = a.graph if a.graph is not None else (-1 if a.scaling == "strong" else 0)

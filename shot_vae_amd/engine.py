@@ -470,6 +470,8 @@ class Engine:
     wgrad_side_stream = True      # weight gradients on a side stream (they are off the backward's critical path)
     sparse_shortcut_grad = True      # stride-2 1x1 shortcuts: data gradient written / read at the even positions only
     materialize_decoder_act = True   # BatchNorm + ReLU of the first decoder layers' inputs as a pass of its own (see forward)
+    materialize_max_hin = 4          # ... for the layers whose input map is at most this large
+    wgrad_after = False              # (experiment, tools: fork the weight gradient behind its data gradient instead of beside it)
     fold_bn = True                   # BatchNorm finalisation folded into the consuming sv_igemm launch (sv_igemm_args::fold_*)
 
     def _side(self):
@@ -497,8 +499,12 @@ class Engine:
             return then() if then is not None else None
         cur, side = self._side()
         ev = torch.cuda.Event()
-        ev.record(cur)
-        out = then() if then is not None else None
+        if self.wgrad_after:          # experiment: the weight gradient starts when the paired data gradient has FINISHED
+            out = then() if then is not None else None
+            ev.record(cur)
+        else:
+            ev.record(cur)
+            out = then() if then is not None else None
         side.wait_event(ev)
         with torch.cuda.stream(side):
             self._wgrad(g, x, pro, dy, dw_ptr, tag, groups, budget)
@@ -716,7 +722,7 @@ class Engine:
                 f.h.append(None)
                 continue
             out = torch.empty(gl * B, ho, ho, cv.N, dtype=T, device=dev)
-            if pro is not None and self.materialize_decoder_act and cv.Hin <= 4:
+            if pro is not None and self.materialize_decoder_act and cv.Hin <= self.materialize_max_hin:
                 # weight-heavy layers (1x1 ... 4x4 maps, 1024 ... 256 channels): BatchNorm + ReLU once, as a pass over a few
                 # MB, and a prologue-free GEMM (the LDS-DMA loader) -- fused, the transform was redone per channel tile
                 xa = torch.empty_like(x)
@@ -733,7 +739,7 @@ class Engine:
                 #  is the last ConvTranspose of a launch that runs it for the reconstructed groups only: the running statistics
                 #  need the mean / rstd of EVERY group)
                 pro = finalize(p.dec_bns[i], "h%d" % i, B * ho * ho,
-                               fold=not (self.materialize_decoder_act and p.dec_convs[i + 1].Hin <= 4) and (i < 4 or Gd == G))
+                               fold=not (self.materialize_decoder_act and p.dec_convs[i + 1].Hin <= self.materialize_max_hin) and (i < 4 or Gd == G))
                 f.dpro.append(pro[:3])
                 x = out
         rec = None

@@ -1,0 +1,48 @@
+"""Which gradient tensors differ between two runs of the SAME bf16 step on the production (float-atomic) path?  Per parameter
+tensor: cosine between the gradients of two repeats from the same state, and its share of the flat gradient's squared norm."""
+import sys
+
+import torch
+
+sys.path.insert(0, __file__.rsplit("/", 3)[0])
+import shot_vae_amd as S                      # noqa: E402
+from oracle import shotvae_oracle as O        # noqa: E402
+from tests import _cases as T                 # noqa: E402
+
+name, K, B = (sys.argv[1], int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else ("wideresnet-28-2", 10, 512)
+torch.manual_seed(17)
+il, ll, iu = torch.rand(B, 3, 32, 32), torch.randint(0, K, (B,)), torch.rand(B, 3, 32, 32)
+nz = O.make_noise(B, B, K, seed=23)
+nz["lam_l"] = 0.9
+sch = O.schedule(10, dmi=2.3 if K == 10 else 4.6)
+init = O.default_init(name, K=K, seed=5)
+elbo, cls = S.VAECriterion(discrete_dim=K, bce_reconstruction=True).cuda(), S.ClsCriterion()
+model = S.VariationalAutoEncoder(name, num_input_channels=3, img_size=(32, 32), data_parallel=False, continuous_latent_dim=128,
+                                 disc_latent_dim=K, small_input=True, compute_dtype="bf16")
+model.load_state_dict({k: v.detach() for k, v in init.items()})
+model = model.cuda().train()
+opt = S.FlatSGD(model)
+state0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
+grads = []
+for rep in range(3):
+    model.load_state_dict(state0)
+    opt.zero_grad()
+    with T.rng_for_step(nz):
+        S.train_step_grouped(model, elbo, cls, None, il.cuda(), ll.cuda(), iu.cuda(), sch)
+    torch.cuda.synchronize()
+    grads.append({k: p.grad.detach().double().clone() for k, p in model.named_parameters()})
+tot = sum(float((g * g).sum()) for g in grads[0].values())
+rows = []
+for k in grads[0]:
+    a, b = grads[0][k].reshape(-1), grads[1][k].reshape(-1)
+    cos = float(a @ b / (a.norm() * b.norm()).clamp_min(1e-300))
+    rows.append((cos, float((a * a).sum()) / tot, float((a - b).norm() / a.norm().clamp_min(1e-300)), k))
+fa = torch.cat([g.reshape(-1) for g in grads[0].values()])
+fb = torch.cat([g.reshape(-1) for g in grads[1].values()])
+print("%s B=%d: flat-gradient cosine between two repeats %.4f" % (name, B, float(fa @ fb / fa.norm() / fb.norm())))
+print("lowest per-tensor cosines (cosine, share of |g|^2, relative difference, tensor):")
+for r in sorted(rows)[:12]:
+    print("  %.4f  %8.5f  %.3f  %s" % r)
+print("largest shares of |g|^2:")
+for r in sorted(rows, key=lambda r: -r[1])[:8]:
+    print("  %.4f  %8.5f  %.3f  %s" % r)
