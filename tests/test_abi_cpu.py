@@ -194,6 +194,21 @@ assert lib.sv_set_option(99, 1) != 0 and lib.sv_set_option(3, 1) != 0
 order = (C.c_int32 * 4)(0, 2, 2, 3)            # not a permutation: refused before any launch
 assert lib.sv_bn_running_update_ex(4096, 4096, 1, 4096, 4096, 1e-5, 0.1, 64, 4, order, None) != 0
 assert lib.sv_igemm(None, 1, None, None) != 0 and b"null" in lib.sv_last_error()
+# ABI 4: an incomplete BatchNorm fold and an incomplete per-group loss stage are refused before any launch
+plan = Plan("wideresnet-28-2", K=10)
+g = plan.units[1]["conv1"].geom_fwd(8)
+a = L.SvIgemmArgs()
+a.x = a.w = a.out = a.pro_scale = a.pro_shift = a.fold_stats = 4096
+a.fold_replicas, a.fold_count = 8, 64.0            # gamma / beta / mean / rstd missing
+assert lib.sv_igemm(C.byref(g), L.SV_BF16, C.byref(a), None) != 0 and b"fold" in lib.sv_last_error()
+blocks = C.c_int(-1)
+a.fold_gamma = a.fold_beta = a.fold_mean = a.fold_rstd = 4096
+assert lib.sv_igemm_query_blocks(C.byref(g), L.SV_BF16, C.byref(a), C.byref(blocks)) == 0 and blocks.value > 0    # a query launches nothing
+b = L.SvShotLossArgs2()
+b.image_l = b.image_u = b.label_l = b.perm_l = b.perm_u = b.terms = b.coef = b.tgt = 4096
+b.Bl, b.Bu, b.D, b.K = 4, 6, 128, 10
+assert lib.sv_shot_loss_step2(C.byref(b), None) != 0 and b"group" in lib.sv_last_error()
+assert lib.sv_repack_strided(L.SV_BF16, 4096, 40, 8, 1, 1, 1, 32, 9, 16, 0, C.byref(g), 4096, None) != 0      # n_real > N
 print("ASAN_DRIVE_OK", n_ok, n_err)
 ''' % ROOT)
     env = dict(os.environ, LD_PRELOAD=rt[-1], ASAN_OPTIONS="detect_leaks=0:abort_on_error=0:exitcode=66",

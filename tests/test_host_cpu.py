@@ -116,3 +116,37 @@ def test_inference_kl_matches_reference_monitor():
         rec, mu, ls, la = O.vae_forward(st, name, iu, nz["eps3"], u=nz["u3"])
     assert float(S.inference_kl(la, lu)) == pytest.approx(float(g["kl_inference"]), rel=2e-5)
     assert np.isfinite(float(g["kl_inference"]))
+
+
+def test_grouped_step_launch_plans():
+    """Which forwards of a step share a batched launch sequence (train._launch_plan): one sequence of four groups for the usual
+    step; --om puts forward (4) behind the pairing kernel that needs the outputs of (3) (mixup.py:9-18); a ragged last batch
+    (B_l != B_u, main_shot_vae.py:280) gives one sequence per loader.  Inside a launch the forwards whose reconstruction enters
+    the loss -- (1), (3) -- come first (Engine.forward's rec_groups is a prefix), and every forward appears exactly once."""
+    from shot_vae_amd.train import _launch_plan
+    assert _launch_plan(False, False) == [[1, 3, 2, 4]]
+    assert _launch_plan(False, True) == [[1, 3, 2], [4]]
+    assert _launch_plan(True, False) == [[1, 2], [3, 4]]
+    assert _launch_plan(True, True) == [[1, 2], [3], [4]]
+    for ragged in (False, True):
+        for om in (False, True):
+            plan = _launch_plan(ragged, om)
+            assert sorted(k for ids in plan for k in ids) == [1, 2, 3, 4]
+            for ids in plan:
+                rec = [k in (1, 3) for k in ids]
+                assert rec == sorted(rec, reverse=True)                      # reconstructed forwards are a prefix
+                if ragged:
+                    assert len({k <= 2 for k in ids}) == 1                  # never a labelled and an unlabelled forward together
+            if om:                                                           # (3) strictly before (4): the pairing needs its outputs
+                i3 = [i for i, ids in enumerate(plan) if 3 in ids][0]
+                i4 = [i for i, ids in enumerate(plan) if 4 in ids][0]
+                assert i3 < i4
+
+
+def test_flat_adam_checkpoint_reads_the_device_step_counter():
+    """optim.FlatAdam.state_dict() must take `step` from the captured device counter when there is one (hipGraph replays advance
+    only that): checked on the source level here (the class needs a GPU), on the device in tests/test_kernels_gpu.py."""
+    import inspect
+    from shot_vae_amd import optim
+    src = inspect.getsource(optim.FlatAdam.state_dict)
+    assert "step_dev" in src and ".item()" in src
