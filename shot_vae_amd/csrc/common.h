@@ -190,6 +190,12 @@ enum { SV_FLAG_DET = 1 };              // sv_igemm_args::flags
 // mode it also checks the replica count of a real launch (returns true with *rc < 0 when it is too small).
 bool sv_dry_run(int grid_x, const sv_igemm_args* a, int* rc);
 bool sv_in_query();                    // the calling thread is inside sv_igemm_query_blocks (nothing may be launched)
+// BatchNorm fold protocol (runtime.hip): sv_igemm announces a pending fold; a launcher whose kernel folds claims it (can =
+// the kernel's own limits hold, e.g. fold_replicas <= 64) and passes fold_stats on, everybody else passes fold_stats = NULL;
+// an unclaimed fold is materialised by the launch gate (sv_bn_finalize as a launch of its own)
+void sv_fold_begin(const sv_geom* g, const sv_igemm_args* a, void* stream);
+void sv_fold_end();
+bool sv_fold_claim(bool can);
 #define SV_LAUNCH_GATE(grid_x, a)                                \
     do {                                                         \
         int gate_rc_ = SV_OK;                                    \
@@ -205,8 +211,6 @@ struct SvProfScope {
     ~SvProfScope() { sv_prof_end(s); }
 };
 int sv_conv3x3_try(const sv_geom* g, int dtype, const sv_igemm_args* a, hipStream_t s, int* rc);
-bool sv_conv3x3_folds(const sv_geom* g, int dtype, const sv_igemm_args* a);   // sv_conv3x3_try would take a kernel that derives the
-                                                                             // prologue's BatchNorm coefficients itself (fold_*)
 int sv_hwgrad_try(const sv_geom* g, int dtype, const void* x, const float* pro_scale, const float* pro_shift, float pro_slope,
                   const void* dy, float* dw, float* ws, int64_t ws_elems, int groups, hipStream_t s, int* rc);
 int sv_halo_try(const sv_geom* g, int dtype, const sv_igemm_args* a, hipStream_t s, int* rc);

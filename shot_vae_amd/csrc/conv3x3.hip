@@ -749,6 +749,9 @@ int launch_pm(const sv_geom* g, const sv_igemm_args* a, hipStream_t s) {
             return sv_check_launch("hipFuncSetAttribute(conv3x3p)");
         optin = true;
     }
+    sv_igemm_args b = *a;          // this kernel folds the BatchNorm finalisation of its prologue (<= 64 channels, <= 64 replicas)
+    if (!sv_fold_claim(b.fold_stats && b.fold_replicas <= 64)) b.fold_stats = nullptr;
+    a = &b;
     SV_LAUNCH_GATE(chunks * nNt, a);
     sv_prof_begin(s);
     hipLaunchKernelGGL((conv3x3p_kernel<T, WLOG, CCH, MODE>), dim3(chunks * nNt, sv_ngroups(a->groups)), dim3(256), lds, s, *g, sv_expand_groups(*g, *a, (int)sizeof(T)), tiles_per);
@@ -810,20 +813,6 @@ int launch_w(const sv_geom* g, const sv_igemm_args* a, hipStream_t s) {
 }
 
 }  // namespace
-
-// sv_conv3x3_try would take the persistent kernel, which folds the BatchNorm finalisation of its prologue (fold_*)
-bool sv_conv3x3_folds(const sv_geom* g, int dtype, const sv_igemm_args* a) {
-    if (!a->fold_stats || a->fold_replicas > 64 || sv_disabled(SV_K_CONV3X3) || sv_disabled(SV_K_CONV3X3P)) return false;
-    if (g->nphase != 1 || g->phase[0].ntap != 9 || g->sy != 1 || g->sx != 1 || g->osy != 1 || g->osx != 1) return false;
-    if (g->Hq != g->Hin || g->Wq != g->Win || g->Hout != g->Hin || g->Wout != g->Win || g->Hin != g->Win) return false;
-    if (g->Win != 8 && g->Win != 16 && g->Win != 32) return false;
-    if (g->Cin % CK != 0 || g->ldx != g->Cin || g->N % 32 != 0) return false;
-    if (g->phase[0].ooy != 0 || g->phase[0].oox != 0) return false;
-    for (int t = 0; t < 9; ++t)
-        if (g->phase[0].dy[t] < -1 || g->phase[0].dy[t] > 1 || g->phase[0].dx[t] < -1 || g->phase[0].dx[t] > 1) return false;
-    if ((g->B * g->Hin) % (128 / g->Win) != 0) return false;
-    return (dtype == SV_BF16 && (g->Cin == 32 || g->Cin == 64)) || (dtype == SV_F32 && g->Cin == 32);
-}
 
 // Returns 1 and sets *rc when the geometry is a stride-1 3x3 convolution this kernel covers.
 int sv_conv3x3_try(const sv_geom* g, int dtype, const sv_igemm_args* a, hipStream_t s, int* rc) {

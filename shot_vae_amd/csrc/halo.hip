@@ -513,7 +513,19 @@ __global__ __launch_bounds__(256, OCC) void halop_kernel(const sv_geom g, const 
         }
     }
     f32x4 ps0 = {1.f, 1.f, 1.f, 1.f}, ps1 = ps0, pt0 = {0.f, 0.f, 0.f, 0.f}, pt1 = pt0;
-    if (has_pro) {                                  // a thread's 8-channel group is the same for all of its slots (256 % VPP == 0)
+    if (has_pro && a.fold_stats) {
+        // the BatchNorm in front of this layer is finalised HERE (sv_igemm_args::fold_*, claimed by the launcher): every block
+        // derives the coefficients of the <= 64 input channels from the raw statistics -- the halo area is free until the first
+        // tile is stored --, the first block of the launch stores them for the backward pass
+        const int cv8 = 8 * (tid % VPP);
+        float* fs = reinterpret_cast<float*>(halo);
+        sv_bn_fold_block(a, Cin, fs, fs + 512, fs + 512 + Cin, blockIdx.x == 0);
+        ps0 = *reinterpret_cast<const f32x4*>(fs + 512 + cv8);
+        ps1 = *reinterpret_cast<const f32x4*>(fs + 512 + cv8 + 4);
+        pt0 = *reinterpret_cast<const f32x4*>(fs + 512 + Cin + cv8);
+        pt1 = *reinterpret_cast<const f32x4*>(fs + 512 + Cin + cv8 + 4);
+        __syncthreads();
+    } else if (has_pro) {                           // a thread's 8-channel group is the same for all of its slots (256 % VPP == 0)
         const int cv8 = 8 * (tid % VPP);
         ps0 = *reinterpret_cast<const f32x4*>(a.pro_scale + cv8);
         ps1 = *reinterpret_cast<const f32x4*>(a.pro_scale + cv8 + 4);
@@ -698,6 +710,10 @@ int launch_halop_pv(const sv_geom* g, const sv_igemm_args* a, const halo_cfg& c,
             return sv_check_launch("hipFuncSetAttribute(halop)");
         optin = true;
     }
+    sv_igemm_args b = *a;          // the persistent kernel folds the BatchNorm finalisation of its prologue (fold_*)
+    if (!sv_fold_claim(b.fold_stats && b.fold_replicas <= 64 && 256 % g->Cin == 0 && (size_t)c.HP * (g->Cin + 16) * sizeof(T) >= (512 + 2 * 64) * 4))
+        b.fold_stats = nullptr;
+    a = &b;
     SV_LAUNCH_GATE(chunks * nNt, a);
     sv_prof_begin(s);
     hipLaunchKernelGGL((halop_kernel<T, NT, CC, NPH, PV, OCC, MODE>), dim3(chunks * nNt, sv_ngroups(a->groups)), dim3(256), lds, s, *g,

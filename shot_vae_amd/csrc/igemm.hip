@@ -606,17 +606,10 @@ extern "C" int sv_igemm(const sv_geom* g, int dtype, const sv_igemm_args* a_in, 
     if (a->fold_stats) {
         SV_REQUIRE(a->pro_scale && a->pro_shift && a->fold_gamma && a->fold_beta && a->fold_mean && a->fold_rstd &&
                    a->fold_replicas >= 1 && a->fold_count > 0.f, SV_E_ARG, "sv_igemm: incomplete BatchNorm fold (fold_*)");
-        if (sv_in_query()) {
-            a_loc.fold_stats = nullptr;            // (a grid query: nothing is launched, the dispatch does not depend on it)
-        } else if (!sv_conv3x3_folds(g, dtype, a)) {
-            // the kernel this launch takes reads finished coefficients: finalise here, as a launch of its own
-            const int rc = sv_bn_finalize(a->fold_stats, a->fold_replicas, g->Cin, a->fold_count, a->fold_gamma, a->fold_beta,
-                                          a->fold_eps, 0.f, nullptr, nullptr, const_cast<float*>(a->pro_scale),
-                                          const_cast<float*>(a->pro_shift), a->fold_mean, a->fold_rstd, sv_ngroups(a->groups), stream);
-            if (rc != SV_OK) return rc;
-            a_loc.fold_stats = nullptr;
-        }
+        if (sv_in_query()) a_loc.fold_stats = nullptr;            // (a grid query: nothing is launched, the dispatch does not depend on it)
+        else sv_fold_begin(g, a, stream);
     }
+    struct FoldEnd { ~FoldEnd() { sv_fold_end(); } } fold_end;
     SvBudgetScope budget_scope(a->block_budget);
     {   // stride-1 3x3 convolutions take the LDS-halo kernels (conv3x3*.hip) unless switched off (tests: generic vs special)
         int rc = 0;

@@ -35,7 +35,33 @@ thread_local int* tl_query_blocks = nullptr;
 }  // namespace
 bool sv_in_query() { return tl_query_blocks != nullptr; }
 bool sv_deterministic() { return g_deterministic != 0; }
+// BatchNorm finalisation folded into an sv_igemm launch (sv_igemm_args::fold_*): sv_igemm announces it (sv_fold_begin); a
+// launcher whose kernel derives the coefficients itself claims it (sv_fold_claim); for every other kernel the launch gate
+// (sv_dry_run, in front of every launch of the family) runs sv_bn_finalize first.
+namespace {
+thread_local const sv_igemm_args* tl_fold = nullptr;
+thread_local const sv_geom* tl_fold_g = nullptr;
+thread_local void* tl_fold_stream = nullptr;
+}  // namespace
+void sv_fold_begin(const sv_geom* g, const sv_igemm_args* a, void* stream) { tl_fold = a; tl_fold_g = g; tl_fold_stream = stream; }
+void sv_fold_end() { tl_fold = nullptr; }
+bool sv_fold_claim(bool can) {
+    if (!tl_fold || !can) return false;
+    tl_fold = nullptr;
+    return true;
+}
+static int sv_fold_materialize() {
+    const sv_igemm_args* a = tl_fold;
+    tl_fold = nullptr;
+    return sv_bn_finalize(a->fold_stats, a->fold_replicas, tl_fold_g->Cin, a->fold_count, a->fold_gamma, a->fold_beta, a->fold_eps, 0.f,
+                          nullptr, nullptr, const_cast<float*>(a->pro_scale), const_cast<float*>(a->pro_shift), a->fold_mean,
+                          a->fold_rstd, sv_ngroups(a->groups), tl_fold_stream);
+}
 bool sv_dry_run(int grid_x, const sv_igemm_args* a, int* rc) {
+    if (tl_fold && !tl_query_blocks) {           // nobody claimed the fold: this kernel reads finished coefficients
+        const int r = sv_fold_materialize();
+        if (r != SV_OK) { *rc = r; return true; }
+    }
     if (tl_query_blocks) {
         *tl_query_blocks = grid_x;
         *rc = SV_OK;

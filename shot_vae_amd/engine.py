@@ -812,11 +812,11 @@ class Engine:
         return out
 
     # ------------------------------------------------------------------------------- backward
-    def backward(self, f, d_rec, d_mu, d_ls, d_la):
+    def backward(self, f, d_rec, d_mu, d_ls, d_la, own_grads=False):
         """Gradients accumulate (+=) into self.grad; nothing is returned (inputs need no grad).  Batched like the
         forward it belongs to: every launch carries the G groups, the weight gradients sum over them."""
         try:
-            self._backward(f, d_rec, d_mu, d_ls, d_la)
+            self._backward(f, d_rec, d_mu, d_ls, d_la, own_grads)
         except BaseException:
             # the operands kept alive for the side stream must not survive a failed backward into the next step
             if torch.cuda.is_available():
@@ -824,7 +824,7 @@ class Engine:
             self._side_keep.clear()
             raise
 
-    def _backward(self, f, d_rec, d_mu, d_ls, d_la):
+    def _backward(self, f, d_rec, d_mu, d_ls, d_la, own_grads=False):
         p = self.plan
         B, G, T = f.B, f.G, self.tdtype
         Bt = B * G
@@ -891,9 +891,15 @@ class Engine:
         #      the caller's loss does not use the reconstruction (d_rec is None: the mixed forwards of the sequential step) --
         Gd = f.Gd if d_rec is not None else 0
         Bd = B * Gd
-        dmu = d_mu.contiguous().float().clone() if d_mu is not None else torch.zeros_like(f.mu)
-        dls = d_ls.contiguous().float().clone() if d_ls is not None else torch.zeros_like(f.ls)
-        dla = d_la.contiguous().float().clone() if d_la is not None else torch.zeros_like(f.la)
+        # (the sampler's backward ADDS to these: a caller that hands over freshly written tensors of its own -- the grouped step's
+        #  loss stage -- passes own_grads and saves three copies; autograd's gradients are cloned)
+        def mine(t, like):
+            if t is None:
+                return torch.zeros_like(like)
+            if own_grads and t.is_contiguous() and t.dtype == torch.float32:
+                return t
+            return t.contiguous().float().clone()
+        dmu, dls, dla = mine(d_mu, f.mu), mine(d_ls, f.ls), mine(d_la, f.la)
         if Gd > 0:
             last = p.dec_convs[5]
             D = torch.empty(Bd, p.img, p.img, last.N, dtype=T, device=dev)

@@ -317,7 +317,7 @@ def train_step_grouped(model, elbo_criterion, cls_criterion, optimizer, image_l,
     for n, i in enumerate(seq):
         if n == len(seq) - 1 and optimizer is not None and _bucketed(model, distributed) is not None:
             _bucketed(model, distributed).arm()
-        model.backward_direct(ctxs[i][1], *per_launch[i])
+        model.backward_direct(ctxs[i][1], *per_launch[i], own_grads=True)
     if optimizer is not None:
         apply_update(model, optimizer, distributed)
     if not return_outputs:

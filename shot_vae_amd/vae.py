@@ -262,13 +262,14 @@ class VariationalAutoEncoder(nn.Module):
             return self._engine.forward(torch.cat([im.float() for im in images]), gs, eps, u, self._temperature,
                                         self.training, keep=True, rec_groups=rec_groups, update_order=update_order)
 
-    def backward_direct(self, ctx, d_rec, d_mu, d_ls, d_la):
-        """accumulates the parameter gradients of a forward_groups_direct() call into the flat gradient buffer (p.grad)"""
+    def backward_direct(self, ctx, d_rec, d_mu, d_ls, d_la, own_grads=False):
+        """accumulates the parameter gradients of a forward_groups_direct() call into the flat gradient buffer (p.grad).
+        own_grads: d_mu / d_ls / d_la are the caller's own, freshly written tensors and may be modified in place"""
         if not ctx.training:
             raise NotImplementedError("backward through an eval-mode forward (BatchNorm with running statistics) is not implemented")
         self._attach_grads()
         with torch.no_grad():
-            self._engine.backward(ctx, d_rec, d_mu, d_ls, d_la)
+            self._engine.backward(ctx, d_rec, d_mu, d_ls, d_la, own_grads)
 
     def _run(self, image, groups, eps, u, rec_groups=None, update_order=None):
         eng = self._engine

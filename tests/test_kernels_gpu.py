@@ -1064,15 +1064,19 @@ def test_sparse_stride2_shortcut_gradient(dt, case):
 
 
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("halo_all", [0, 1])
 @pytest.mark.parametrize("B,Cin,N,H,k,stride,groups,R", [(8, 32, 32, 32, 3, 1, 1, 8), (16, 64, 64, 16, 3, 1, 4, 32),
                                                        (4, 32, 64, 16, 3, 2, 2, 4), (8, 128, 128, 8, 3, 1, 1, 2),
-                                                       (6, 16, 32, 32, 1, 1, 3, 16)])
-def test_folded_batchnorm_finalisation(dt, B, Cin, N, H, k, stride, groups, R):
+                                                       (6, 16, 32, 32, 1, 1, 3, 16), (4, 16, 32, 32, 3, 1, 2, 64)])
+def test_folded_batchnorm_finalisation(dt, B, Cin, N, H, k, stride, groups, R, halo_all):
     """sv_igemm_args::fold_* (ABI 4): the BatchNorm in front of a conv-like layer finalised BY the launch -- inside the
     persistent 3x3 kernel (every block derives scale / shift from the raw statistics, block 0 stores the four vectors), or by
     the sv_bn_finalize launch sv_igemm issues itself for the other kernels -- against sv_bn_finalize + the same launch with
-    finished coefficients: identical coefficient vectors (2e-6: the replicas are summed in another order) and outputs."""
+    finished coefficients: identical coefficient vectors (2e-6: the replicas are summed in another order) and outputs.
+    halo_all = 1 sends the thin / strided shapes to the persistent LDS-halo kernel (halop), which folds too."""
     code, tdt, tol = DT[dt]
+    if halo_all and k == 3 and stride == 1 and Cin >= 32:
+        pytest.skip("stride-1 3x3 layers do not reach halo.hip")
     if dt == "f32" and Cin > 32 and k == 3 and stride == 1:
         pytest.skip("fp32 operands: the persistent kernel covers 32 input channels")
     d = dev()
@@ -1108,8 +1112,9 @@ def test_folded_batchnorm_finalisation(dt, B, Cin, N, H, k, stride, groups, R):
         torch.cuda.synchronize()
         return coef, out.float()
 
-    c0, o0 = launch(False)
-    c1, o1 = launch(True)
+    with L.options(halo_all=halo_all):
+        c0, o0 = launch(False)
+        c1, o1 = launch(True)
     assert float((c0 - c1).abs().max() / c0.abs().max()) < 2e-6
     assert float(c1[3].min()) > 0                                   # rstd written for every group
     assert float((o0 - o1).abs().max() / o0.abs().max()) < (1e-5 if dt == "f32" else 1e-2)

@@ -729,7 +729,9 @@ def test_grouped_step_matches_reference_goldens_fp32(tag):
 @pytest.mark.parametrize("dtype,B,tol,Bu,om", [("fp32", 8, 2e-4, 8, False), ("fp32", 128, 2e-4, 128, False),
                                                ("bf16", 128, 3e-2, 128, False), ("fp32", 416, 2e-4, 512, False),
                                                ("fp32", 24, 2e-4, 24, True), ("fp32", 20, 2e-4, 28, True),
-                                               ("bf16", 416, 3e-2, 512, False), ("bf16", 128, 3e-2, 128, True)])
+                                               ("bf16", 416, 3e-2, 512, False)])
+# (no bf16 --om case: the pairing is an argmin over pairwise KL terms of forward (3)'s outputs, and the float-atomic spread of
+#  two bf16 runs flips near-ties -- another pairing is another step; --om is compared in fp32, where the two paths agree to rounding)
 def test_grouped_step_equals_sequential_step(dtype, B, tol, Bu, om):
     """Batched against per-forward launches on the same weights, inputs and noise: the grouped kernels see exactly the
     per-group problems (blockIdx.y = group), so fp32 agrees to rounding; B = 128 is the size at which every layer of the

@@ -45,6 +45,8 @@ Engine._wgrad = wgrad
 import shot_vae_amd.engine as E               # noqa: E402
 E.L.call = call
 import os
+if os.environ.get("SV_FOLD"):
+    model._engine.fold_bn = bool(int(os.environ["SV_FOLD"]))
 if os.environ.get("SV_MAT_HIN"):
     model._engine.materialize_max_hin = int(os.environ["SV_MAT_HIN"])
 for m in sys.argv[1:] or ["none", "wgrad_body", "wgrad_all", "bn_apply", "bn_finalize", "none"]:
