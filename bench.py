@@ -65,6 +65,10 @@ def parse():
     ap.add_argument("--pair-blocks", type=int, default=-1,
                     help="Engine.pair_blocks: block budget of each kernel of a paired weight / data gradient launch (-1 = the "
                          "engine's default, 256; 0 = both with the full budget)")
+    ap.add_argument("--input-stream", type=int, default=0,
+                    help="1: the input side of the grouped step (noise, pairings, mixed batches, layout change) on a stream of its "
+                         "own, beside the previous step's backward (train_step_grouped(input_stream=True)); 0 (default): in front of "
+                         "the first convolution on the main stream -- measured the same (7.22 vs 7.21 ms)")
     ap.add_argument("--wgrad-after", type=int, default=0,
                     help="experiment: 1 = a body layer's weight gradient (side stream) starts when its data gradient has finished "
                          "instead of beside it (use with --pair-blocks 0)")
@@ -552,7 +556,7 @@ def main():
 
     def eager_step():
         if a.schedule == "grouped":
-            return train_step_grouped(model, elbo, cls, opt, il, ll, iu, sch, distributed=dmode)
+            return train_step_grouped(model, elbo, cls, opt, il, ll, iu, sch, distributed=dmode, input_stream=bool(a.input_stream))
         if a.schedule == "two-stream":
             return train_step_overlapped(model, elbo, cls, opt, il, ll, iu, sch, distributed=dmode)
         return S.train_step(model, elbo, cls, opt, il, ll, iu, sch, distributed=dmode)

@@ -545,7 +545,7 @@ class Engine:
             lay = self._bn_layouts[G] = (off, o)
         return lay
 
-    def forward(self, image, groups, eps, u, temperature, training, keep, rec_groups=None, update_order=None):
+    def forward(self, image, groups, eps, u, temperature, training, keep, rec_groups=None, update_order=None, x16=None):
         """One BATCHED forward of G = len(groups) independent instances of the network that share the weights (the
         forwards (1)-(4) of a SHOT-VAE step, main_shot_vae.py:288,311,329,356, or a single one): every launch carries
         the G groups (sv_igemm_args::groups), each with its OWN BatchNorm batch statistics -- the reference's
@@ -561,6 +561,8 @@ class Engine:
                 backward -- the decoder up to its last BatchNorm still runs for every group: its running statistics are
                 updated by every train-mode forward.  rec is then [Gd * B, ...].
         update_order  order[k] = the group of the reference's k-th forward (running-statistic updates; default group order)
+        x16     optional: the NHWC16 image tensor (sv_nchw_to_nhwc of `image`) when the caller has already made it -- the
+                grouped step converts on its input-side stream, beside the previous step's backward
         Returns (rec NCHW fp32, mu, ls, la, ctx-or-None), all [G * B, ...]."""
         self._require_gpu(image)
         p = self.plan
@@ -653,9 +655,8 @@ class Engine:
         f.Gd = Gd
         f.bnbuf, f.bn_off = bnbuf, bn_off
         # stem (wideresnet.py:13-14): NCHW fp32 -> NHWC16, conv3x3 + bias, stats of t0
-        x16 = torch.empty(Bt, p.img, p.img, CPAD, dtype=T, device=dev)
-        L.call("sv_nchw_to_nhwc", self.code, _vp(image.data_ptr()), Bt, p.in_ch, p.img, p.img, CPAD,
-               _vp(x16.data_ptr()), st)
+        if x16 is None:
+            x16 = self.to_nhwc16(image)
         t = torch.empty(Bt, p.img, p.img, 16, dtype=T, device=dev)
         self._igemm(p.stem.geom_fwd(B), x16, pk + es * p.stem.fwd_off, t, bias=pbase + 4 * p.stem_bias_off,
                     stats=sptr("t0"), tag="fwd:stem", groups=G)
@@ -761,6 +762,15 @@ class Engine:
         f.eps, f.csoft, f.latent = eps, csoft, latent
         f.keep = (groups, u, stats)
         return rec, mu, ls, la, f
+
+    def to_nhwc16(self, image):
+        """NCHW fp32 images -> the stem's NHWC tensor with 16 (zero-padded) channels in the compute dtype, on the current stream"""
+        p = self.plan
+        image = image.contiguous().float()
+        x16 = torch.empty(image.shape[0], p.img, p.img, CPAD, dtype=self.tdtype, device=image.device)
+        L.call("sv_nchw_to_nhwc", self.code, _vp(image.data_ptr()), image.shape[0], p.in_ch, p.img, p.img, CPAD,
+               _vp(x16.data_ptr()), self._stream())
+        return x16
 
     def _bn_counts(self, B):
         """samples per channel of every BatchNorm (in plan order) for batch size B"""

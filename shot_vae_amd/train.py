@@ -193,8 +193,20 @@ def _launch_plan(ragged, optimal_match):
     return [[1, 2], [3], [4]]
 
 
+def _input_stream(model, dev):
+    """the stream the input side of a grouped step is issued on (one per model and device)"""
+    pool = getattr(model, "_input_streams", None)
+    if pool is None:
+        pool = model._input_streams = {}
+    s = pool.get(dev)
+    if s is None:
+        s = pool[dev] = torch.cuda.Stream(device=dev)
+    return s
+
+
 def train_step_grouped(model, elbo_criterion, cls_criterion, optimizer, image_l, label_l, image_u, sch, epsilon=0.1,
-                       distributed=False, device_rng=None, label_u=None, return_outputs=False, optimal_match=False):
+                       distributed=False, device_rng=None, label_u=None, return_outputs=False, optimal_match=False,
+                       input_stream=False):
     """The same step with the four forwards as batched launch sequences and no autograd graph.
     Legal because, without --om, the INPUTS of the mixed forwards (2) and (4) depend only on the raw images, a pairing and
     lambda (mixup.py:22,36) -- only their loss TARGETS depend on the outputs of (1) and (3) -- and all four use the same
@@ -206,13 +218,53 @@ def train_step_grouped(model, elbo_criterion, cls_criterion, optimizer, image_l,
     --om (`optimal_match`): groups (1)(3)(2) batched, then the pairing kernel on the outputs of (3), then (4) alone.
     B_l != B_u (main_shot_vae.py:280 zips a 4 000-label loader, 7 x 512 + 416, with the unlabelled one): one launch
     sequence per loader, (1)(2) and (3)(4).  Both together: (1)(2), (3), (4).
-    Host RNG (model.rng == "host") is consumed in the reference's order, so identical seeds give identical noise."""
+    Host RNG (model.rng == "host") is consumed in the reference's order, so identical seeds give identical noise.
+
+    input_stream=True (the usual step only): the INPUT side -- noise, pairings, both mixed image batches, the concatenation
+    and the NHWC conversion, ~90 us of small kernels that depend on nothing but the batch -- is issued on a stream of its
+    own, so that it runs beside whatever the main stream still has queued (the previous step's backward: the host issues a
+    step in a third of the time the GPU takes) instead of in front of the first convolution.  The caller guarantees that
+    image_l / label_l / image_u are COMPLETE when the step is called (resident tensors, or produced on another stream
+    that has been synchronised with): the input stream does not wait for the main stream."""
     plan = model._plan
     K, ldc = plan.K, plan.ldc
     Bl, Bu = image_l.size(0), image_u.size(0)
     rows = {1: Bl, 2: Bl, 3: Bu, 4: Bu}
     dev = image_l.device
     eng = model._engine
+    launches = _launch_plan(Bl != Bu, optimal_match)
+    main = torch.cuda.current_stream() if image_l.is_cuda else None
+    side_in = None
+    if (input_stream and main is not None and len(launches) == 1 and not torch.cuda.is_current_stream_capturing()
+            and eng.prof_tags is None):
+        side_in = _input_stream(model, dev)
+        eng.ensure_packs()                    # (the weight re-pack belongs to the main stream, behind the optimizer step)
+        torch.cuda.set_stream(side_in)
+    try:
+        prep = _grouped_inputs(model, image_l, label_l, image_u, epsilon, device_rng, optimal_match, launches,
+                               side_in is not None)
+    finally:
+        if side_in is not None:
+            torch.cuda.set_stream(main)
+    if side_in is not None:
+        main.wait_stream(side_in)
+        for t in prep["tensors"]:                # allocated on the input stream's pool, used (and freed) on the main stream
+            if torch.is_tensor(t):
+                t.record_stream(main)
+    return _grouped_body(model, elbo_criterion, cls_criterion, optimizer, image_l, label_l, image_u, sch, distributed,
+                         label_u, return_outputs, optimal_match, launches, prep)
+
+
+def _grouped_inputs(model, image_l, label_l, image_u, epsilon, device_rng, optimal_match, launches, whole):
+    """The input side of a grouped step: every random draw in the reference's order, the smoothed labelled batch and -- for
+    the single-launch plan when `whole` -- the mixed unlabelled batch, the concatenated images and their NHWC16 form."""
+    plan = model._plan
+    K, ldc = plan.K, plan.ldc
+    Bl, Bu = image_l.size(0), image_u.size(0)
+    rows = {1: Bl, 2: Bl, 3: Bu, 4: Bu}
+    dev = image_l.device
+    eng = model._engine
+    e_all = u_all = None
     # ---- every random draw of the step, in the reference's order (SURVEY.md 3.1) ---------------------------------
     # The reconstructions of the mixed forwards are dead values in the reference (main_shot_vae.py:311,356: `*_`): their last
     # ConvTranspose and their whole decoder backward are skipped (forward_groups(rec_groups=...)); BatchNorm running
@@ -257,12 +309,35 @@ def train_step_grouped(model, elbo_criterion, cls_criterion, optimizer, image_l,
     images = {1: image_l, 2: sm_img, 3: image_u}
     specs = {1: dict(disc_label=label_l), 3: dict(), 4: dict(),
              2: dict(mixup=True, disc_label=label_l, disc_pseudo_label=sm_label, mixup_lam=lam_l)}
+    mx_img = image_cat = x16 = None
+    if whole:
+        with torch.no_grad():
+            perm_u = perm_u.long().contiguous()
+            mx_img = images[4] = _lerp(image_u, perm_u, lam_u, False)            # mixup.py:22
+            image_cat = torch.cat([images[k].float() for k in launches[0]])
+            x16 = eng.to_nhwc16(image_cat)
+    return dict(eps=eps, u=u, e_all=e_all, u_all=u_all, device_noise=device_noise, perm_l=perm_l, perm_u=perm_u, lam_l=lam_l,
+                lam_u=lam_u, sm_img=sm_img, sm_label=sm_label, images=images, specs=specs, mx_img=mx_img, image_cat=image_cat,
+                x16=x16, tensors=[e_all, u_all, perm_l, perm_u, sm_img, sm_label, mx_img, image_cat, x16, lam_l, lam_u] +
+                list(eps.values()) + list(u.values()))
+
+
+def _grouped_body(model, elbo_criterion, cls_criterion, optimizer, image_l, label_l, image_u, sch, distributed, label_u,
+                  return_outputs, optimal_match, launches, prep):
+    """forward(s), loss stage, backward(s) and the update of a grouped step on the prepared inputs"""
+    plan = model._plan
+    K, ldc = plan.K, plan.ldc
+    Bl, Bu = image_l.size(0), image_u.size(0)
+    rows = {1: Bl, 2: Bl, 3: Bu, 4: Bu}
+    dev = image_l.device
+    eng = model._engine
+    eps, u, e_all, u_all, device_noise = prep["eps"], prep["u"], prep["e_all"], prep["u_all"], prep["device_noise"]
+    perm_l, perm_u, lam_l, lam_u = prep["perm_l"], prep["perm_u"], prep["lam_l"], prep["lam_u"]
+    sm_img, images, specs, mx_img = prep["sm_img"], prep["images"], prep["specs"], prep["mx_img"]
     # forward, loss stage and backward are driven from THIS thread, without an autograd graph: the step's structure is
     # fixed ((loss_sup + loss_unsup).backward() = upstream gradients 1), and the autograd engine's worker-thread hand-over
     # left the GPU idle between the loss kernels and the network's backward
-    launches = _launch_plan(Bl != Bu, optimal_match)
     outs, ctxs = {}, []
-    mx_img = None
     for li, ids in enumerate(launches):
         if 4 in ids and mx_img is None:
             with torch.no_grad():
@@ -290,7 +365,9 @@ def train_step_grouped(model, elbo_criterion, cls_criterion, optimizer, image_l,
             eng.defer_slot = li          # (launch li holds forwards that all precede those of launch li + 1)
         try:
             rec, mu, ls, la, fctx = model.forward_groups_direct([images[k] for k in ids], [specs[k] for k in ids], eps=e_cat,
-                                                                u=u_cat, rec_groups=nrec, update_order=order)
+                                                                u=u_cat, rec_groups=nrec, update_order=order,
+                                                                image_cat=prep["image_cat"] if len(launches) == 1 else None,
+                                                                x16=prep["x16"] if len(launches) == 1 else None)
         finally:
             eng.defer_slot = None
         ctxs.append((ids, fctx, rec, mu, ls, la))

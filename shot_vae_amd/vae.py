@@ -253,14 +253,17 @@ class VariationalAutoEncoder(nn.Module):
                 u = torch.cat([uu if uu is not None else z for _, uu in pairs])
         return self._run(torch.cat([im.float() for im in images]), gs, eps, u, rec_groups, update_order)
 
-    def forward_groups_direct(self, images, specs, eps, u, rec_groups=None, update_order=None):
+    def forward_groups_direct(self, images, specs, eps, u, rec_groups=None, update_order=None, image_cat=None, x16=None):
         """forward_groups for a caller that runs the backward itself (no autograd node): returns (rec, mu, ls, la, ctx); pass
-        ctx and the gradients w.r.t. the four outputs to backward_direct()."""
+        ctx and the gradients w.r.t. the four outputs to backward_direct().  image_cat / x16: the concatenated images and
+        their NHWC16 form when the caller has already made them (train_step_grouped's input-side stream)."""
         gs = [self._group_spec(sp.get("mixup", False), sp.get("disc_label"), sp.get("disc_pseudo_label"),
                                sp.get("mixup_lam")) for sp in specs]
         with torch.no_grad():
-            return self._engine.forward(torch.cat([im.float() for im in images]), gs, eps, u, self._temperature,
-                                        self.training, keep=True, rec_groups=rec_groups, update_order=update_order)
+            if image_cat is None:
+                image_cat = torch.cat([im.float() for im in images])
+            return self._engine.forward(image_cat, gs, eps, u, self._temperature, self.training, keep=True,
+                                        rec_groups=rec_groups, update_order=update_order, x16=x16)
 
     def backward_direct(self, ctx, d_rec, d_mu, d_ls, d_la, own_grads=False):
         """accumulates the parameter gradients of a forward_groups_direct() call into the flat gradient buffer (p.grad).

@@ -902,3 +902,30 @@ def test_flat_adam_equals_torch_adam_and_shares_its_checkpoints():
     sb = b.state_dict()
     for k, v in a.state_dict().items():
         assert T.rel_err(v.cpu().numpy(), sb[k].cpu().numpy()) < 1e-6, k
+
+
+def test_grouped_step_input_stream_is_the_same_step():
+    """train_step_grouped(input_stream=True): the input side (noise, pairings, mixed batches, concatenation, NHWC conversion)
+    issued on a stream of its own -- the same tensors, so three consecutive steps (the second and third overlap their input
+    side with the previous step's backward) give bit-identical parameters in deterministic mode."""
+    from shot_vae_amd import _lib as L
+    name, K, B = "wideresnet-10-1", 10, 32
+    st = C.make_state(name, K=K)
+    il, ll, iu, lu = C.make_batch(B, B, K)
+    elbo, cls = S.VAECriterion(discrete_dim=K).cuda(), S.ClsCriterion()
+    sch = O.schedule(10)
+    ilc, llc, iuc = il.cuda(), ll.cuda(), iu.cuda()
+    torch.cuda.synchronize()                      # the inputs are complete: the input stream does not wait for the main stream
+    finals = []
+    with L.options(deterministic=1):
+        for use in (False, True):
+            m = make_model(name, K, "fp32", st)
+            opt = S.FlatSGD(m, lr=0.05, momentum=0.9)
+            opt.zero_grad()
+            for s in range(3):
+                nz = C.make_noise(B, B, K, stream0=9000 + 100 * s)
+                with T.rng_for_step(nz):
+                    S.train_step_grouped(m, elbo, cls, opt, ilc, llc, iuc, sch, input_stream=use)
+            torch.cuda.synchronize()
+            finals.append(m.flat_parameters()[0].detach().clone())
+    assert torch.equal(finals[0], finals[1])
