@@ -451,11 +451,14 @@ int sv_debug_conv_chunk_program(int* items, int* waits);
  *     round 4: its waves keep private channel sums, a block adds them in a fixed order and is the only adder of its replica;
  *   - the small reduction kernels (pool backward, head weight gradient, column sums, loss terms, BatchNorm dgamma / dbeta
  *     of a batched launch) run their fixed-order variants.
- * Default 0.                                                                                                          */
+ * Default 0.
+ * SV_OPT_ENABLE_MASK: OR of SV_K_* bits of kernels that are OFF by default.  SV_K_WGRAD3X3Q: the 64 x 64-block form of the
+ * narrow weight gradient (everything by LDS-DMA, transform and copies in the MFMA gaps: 54 / 51 us alone at 64 / 128 channels
+ * against 62 / 57) -- off because its 120 KB of LDS keep the paired data-gradient block off the CU: 7.55 against 7.32 ms/step. */
 enum { SV_OPT_DISABLE_MASK = 0, SV_OPT_WIDE_MIN_BLOCKS = 1, SV_OPT_HALO_ALL = 2, SV_OPT_PERSISTENT_BLOCKS = 3,
-       SV_OPT_DETERMINISTIC = 4 };
+       SV_OPT_DETERMINISTIC = 4, SV_OPT_ENABLE_MASK = 5 };
 enum { SV_K_CONV3X3 = 1, SV_K_CONV3X3P = 2, SV_K_CONV3X3M = 4, SV_K_CONV3X3W = 8, SV_K_CONV3X3X = 16,
-       SV_K_WGRAD3X3 = 32, SV_K_WGRAD3X3W = 64, SV_K_IGEMM_KV2 = 128, SV_K_HALO = 256, SV_K_HALOP = 512, SV_K_HWGRAD = 1024, SV_K_IGEMM_BIG = 2048, SV_K_WGRAD_WIDE = 4096, SV_K_IGEMM_ALIGNED = 8192, SV_K_IGEMM_DMA = 16384, SV_K_WGRAD_INCR = 32768, SV_K_WGRAD3X3M = 65536 };
+       SV_K_WGRAD3X3 = 32, SV_K_WGRAD3X3W = 64, SV_K_IGEMM_KV2 = 128, SV_K_HALO = 256, SV_K_HALOP = 512, SV_K_HWGRAD = 1024, SV_K_IGEMM_BIG = 2048, SV_K_WGRAD_WIDE = 4096, SV_K_IGEMM_ALIGNED = 8192, SV_K_IGEMM_DMA = 16384, SV_K_WGRAD_INCR = 32768, SV_K_WGRAD3X3M = 65536, SV_K_WGRAD3X3Q = 131072 };
 int sv_set_option(int key, int value);
 int sv_get_option(int key);          /* -1 for an unknown key */
 

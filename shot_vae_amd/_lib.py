@@ -144,9 +144,9 @@ _PROTOS = {
     "sv_get_option": [I],
     "sv_version": [],
 }
-OPT_DISABLE_MASK, OPT_WIDE_MIN_BLOCKS, OPT_HALO_ALL, OPT_PERSISTENT_BLOCKS, OPT_DETERMINISTIC = 0, 1, 2, 3, 4
-K_CONV3X3, K_CONV3X3P, K_CONV3X3M, K_CONV3X3W, K_CONV3X3X, K_WGRAD3X3, K_WGRAD3X3W, K_IGEMM_KV2, K_HALO, K_HALOP, K_HWGRAD, K_IGEMM_BIG, K_WGRAD_WIDE, K_IGEMM_ALIGNED, K_IGEMM_DMA, K_WGRAD_INCR, K_WGRAD3X3M = (
-    1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384, 32768, 65536)
+OPT_DISABLE_MASK, OPT_WIDE_MIN_BLOCKS, OPT_HALO_ALL, OPT_PERSISTENT_BLOCKS, OPT_DETERMINISTIC, OPT_ENABLE_MASK = 0, 1, 2, 3, 4, 5
+K_CONV3X3, K_CONV3X3P, K_CONV3X3M, K_CONV3X3W, K_CONV3X3X, K_WGRAD3X3, K_WGRAD3X3W, K_IGEMM_KV2, K_HALO, K_HALOP, K_HWGRAD, K_IGEMM_BIG, K_WGRAD_WIDE, K_IGEMM_ALIGNED, K_IGEMM_DMA, K_WGRAD_INCR, K_WGRAD3X3M, K_WGRAD3X3Q = (
+    1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384, 32768, 65536, 131072)
 EXPORTS = sorted(list(_PROTOS) + ["sv_last_error"])
 
 _lib = None
@@ -190,9 +190,9 @@ class options:
     """with options(disable=K_CONV3X3X, wide_min_blocks=1): ...  -- dispatcher options for the duration of a block
     (tests / tools: compare a specialised kernel with the general one)."""
 
-    def __init__(self, disable=None, wide_min_blocks=None, halo_all=None, persistent_blocks=None, deterministic=None):
+    def __init__(self, disable=None, wide_min_blocks=None, halo_all=None, persistent_blocks=None, deterministic=None, enable=None):
         self.new = {OPT_DISABLE_MASK: disable, OPT_WIDE_MIN_BLOCKS: wide_min_blocks, OPT_HALO_ALL: halo_all,
-                    OPT_PERSISTENT_BLOCKS: persistent_blocks, OPT_DETERMINISTIC: deterministic}
+                    OPT_PERSISTENT_BLOCKS: persistent_blocks, OPT_DETERMINISTIC: deterministic, OPT_ENABLE_MASK: enable}
 
     def __enter__(self):
         self.old = {k: lib().sv_get_option(k) for k in self.new}

@@ -174,6 +174,7 @@ __device__ __forceinline__ void sv_bn_fold_block(const sv_igemm_args& a, int C, 
 void sv_set_error(const char* fmt, ...);
 bool sv_disabled(int kernel_bit);        // sv_set_option(SV_OPT_DISABLE_MASK, ...): a specialised kernel is switched off
 int sv_wide_min_blocks();
+bool sv_enabled(int kernel_bit);       // sv_set_option(SV_OPT_ENABLE_MASK, ...): a kernel that is OFF by default is switched on
 bool sv_halo_all();
 int sv_persistent_blocks();            // block budget of the persistent kernels: the launch's own (sv_igemm_args::block_budget,
                                        // sv_wgrad_args::block_budget) if it has one, else sv_set_option(SV_OPT_PERSISTENT_BLOCKS, ...)

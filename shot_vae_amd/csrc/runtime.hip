@@ -31,6 +31,7 @@ int g_wide_min_blocks = 256;
 int g_halo_all = 0;
 int g_persistent_blocks = 512;
 int g_deterministic = 0;
+int g_enable_mask = 0;
 thread_local int* tl_query_blocks = nullptr;
 }  // namespace
 bool sv_in_query() { return tl_query_blocks != nullptr; }
@@ -98,6 +99,7 @@ bool sv_disabled(int kernel_bit) {
     return (g_disable_mask & kernel_bit) != 0;
 }
 int sv_wide_min_blocks() { return g_wide_min_blocks; }
+bool sv_enabled(int kernel_bit) { return (g_enable_mask & kernel_bit) != 0; }
 
 namespace {
 struct Rec { hipEvent_t a, b; int tag; };
@@ -167,6 +169,7 @@ int sv_set_option(int key, int value) {
             g_persistent_blocks = value;
             return SV_OK;
         case SV_OPT_DETERMINISTIC: g_deterministic = value ? 1 : 0; return SV_OK;
+        case SV_OPT_ENABLE_MASK: g_enable_mask = value; return SV_OK;
     }
     sv_set_error("sv_set_option: unknown key %d", key);
     return SV_E_ARG;
@@ -179,6 +182,7 @@ int sv_get_option(int key) {
         case SV_OPT_HALO_ALL: return g_halo_all;
         case SV_OPT_PERSISTENT_BLOCKS: return g_persistent_blocks;
         case SV_OPT_DETERMINISTIC: return g_deterministic;
+        case SV_OPT_ENABLE_MASK: return g_enable_mask;
     }
     return -1;
 }

@@ -188,7 +188,7 @@ assert lib.sv_debug_conv_chunk_program(items, waits) == 0
 for hv in (3, 4):
     it3, w5 = (C.c_int * (180 * 3))(), (C.c_int * 5)()
     assert lib.sv_debug_wgrad_tile_program(hv, it3, w5) == 0
-for key, val in ((0, 5), (1, 7), (2, 1), (3, 64), (4, 1)):
+for key, val in ((0, 5), (1, 7), (2, 1), (3, 64), (4, 1), (5, 131072)):
     assert lib.sv_set_option(key, val) == 0 and lib.sv_get_option(key) == val
 assert lib.sv_set_option(99, 1) != 0 and lib.sv_set_option(3, 1) != 0
 order = (C.c_int32 * 4)(0, 2, 2, 3)            # not a permutation: refused before any launch

@@ -286,9 +286,11 @@ def test_conv_wgrad(dt, use_tr, case):
     sc, sh = scale.to(d), shift.to(d)
     dw = torch.zeros(N, k * k, Cin, device=d)
     ws = torch.full((8 * 1024 * 1024,), float("nan"), device=d)      # workspace contents are irrelevant on entry
+    # (bf16 3x3 stride-1 layers with 64-channel extents: the second call through the 64 x 64-block kernel, off by default)
     for it in range(2):   # accumulates: two calls == 2x; once with and once without the slab workspace
-        L.call("sv_wgrad", C.byref(g), code, p(xd), p(sc), p(sh), 0.01, p(dyd), p(dw), 0, use_tr,
-               p(ws) if it else None, ws.numel() if it else 0, 1, st())
+        with L.options(enable=L.K_WGRAD3X3Q if it else 0):
+            L.call("sv_wgrad", C.byref(g), code, p(xd), p(sc), p(sh), 0.01, p(dyd), p(dw), 0, use_tr,
+                   p(ws) if it else None, ws.numel() if it else 0, 1, st())
     torch.cuda.synchronize()
     got = dw.cpu().view(N, k, k, Cin).permute(0, 3, 1, 2) / 2
     assert rel(got, wref) < tol, rel(got, wref)

@@ -206,6 +206,8 @@ if __name__ == "__main__":
         L.call("sv_set_option", L.OPT_PERSISTENT_BLOCKS, int(os.environ["SV_BENCH_PERSISTENT_BLOCKS"]))
     if os.environ.get("SV_BENCH_WIDE_MIN_BLOCKS"):      # threshold of the 256-row tiles of igemm.hip (default 256)
         L.call("sv_set_option", L.OPT_WIDE_MIN_BLOCKS, int(os.environ["SV_BENCH_WIDE_MIN_BLOCKS"]))
+    if os.environ.get("SV_BENCH_ENABLE"):             # kernels that are off by default (SV_OPT_ENABLE_MASK)
+        L.call("sv_set_option", L.OPT_ENABLE_MASK, int(os.environ["SV_BENCH_ENABLE"]))
     if os.environ.get("SV_BENCH_DISABLE"):
         L.call("sv_set_option", L.OPT_DISABLE_MASK, int(os.environ["SV_BENCH_DISABLE"]))
     if len(sys.argv) >= 5:
