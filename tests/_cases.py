@@ -16,6 +16,10 @@ STEP_CASES = {
     "ref_step_wrn28_2_br": ("wideresnet-28-2", 10, 4, 4, True, 1.0, False, 2.3, 1),
     "ref_step_wrn28_2_mse": ("wideresnet-28-2", 10, 4, 4, False, 0.5, False, 2.3, 1),
     "ref_step_wrn28_10_k100": ("wideresnet-28-10", 100, 2, 2, True, 1.0, False, 4.6, 1),
+    # round 4: a larger ragged batch (one launch sequence per loader in the grouped step) and --om with B_l == B_u (three groups,
+    # the pairing kernel, the fourth) on the headline network
+    "ref_step_wrn28_2_b16_24": ("wideresnet-28-2", 10, 16, 24, True, 1.0, False, 2.3, 1),
+    "ref_step_wrn28_2_om_b16": ("wideresnet-28-2", 10, 16, 16, True, 1.0, True, 2.3, 1),
 }
 SCALARS = ["recon_l", "klc_l", "kld_l", "recon_u", "klc_u", "kld_u", "disc_post_l", "cont_post_l",
            "disc_post_u", "cont_post_u", "loss_sup", "loss_unsup"]

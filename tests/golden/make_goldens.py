@@ -453,6 +453,10 @@ if __name__ == "__main__":
         run_keys_case("ref_state_keys")
         run_monitor_valid_case("ref_monitor_valid_wrn10_1", "wideresnet-10-1", 10)
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "round4":      # only the round-4 fixtures: larger, ragged batches and --om with B_l = B_u
+        run_step_case("ref_step_wrn28_2_b16_24", "wideresnet-28-2", 10, 16, 24, True)
+        run_step_case("ref_step_wrn28_2_om_b16", "wideresnet-28-2", 10, 16, 16, True, om=True)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "smooth":      # only the smooth-ELBO fixtures
         run_smooth_case("ref_smooth_svhn", "svhn", 6, 4)
         run_smooth_case("ref_smooth_mnist", "mnist", 4, 6)
@@ -464,6 +468,8 @@ if __name__ == "__main__":
     run_step_case("ref_step_wrn28_2_br", "wideresnet-28-2", 10, 4, 4, True)
     run_step_case("ref_step_wrn28_2_mse", "wideresnet-28-2", 10, 4, 4, False, x_sigma=0.5)
     run_step_case("ref_step_wrn28_10_k100", "wideresnet-28-10", 100, 2, 2, True, dmi=4.6)
+    run_step_case("ref_step_wrn28_2_b16_24", "wideresnet-28-2", 10, 16, 24, True)
+    run_step_case("ref_step_wrn28_2_om_b16", "wideresnet-28-2", 10, 16, 16, True, om=True)
     run_m2_case("ref_m2_step_wrn10_1", "wideresnet-10-1", 10, 6)
     run_smooth_case("ref_smooth_svhn", "svhn", 6, 4)
     run_smooth_case("ref_smooth_mnist", "mnist", 4, 6)
