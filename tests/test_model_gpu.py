@@ -748,12 +748,17 @@ def test_grouped_step_equals_sequential_step(dtype, B, tol, Bu, om):
     il, ll, iu, lu = C.make_batch(B, Bu, K)
     nz = C.make_noise(B, Bu, K)
     sch = O.schedule(10)
-    with T.rng_for_step(nz, om):
-        a = S.train_step(m1, elbo, cls, None, il.cuda(), ll.cuda(), iu.cuda(), sch, return_outputs=True, label_u=lu.cuda(),
-                         optimal_match=om)
-    with T.rng_for_step(nz, om):
-        b = S.train_step_grouped(m2, elbo, cls, None, il.cuda(), ll.cuda(), iu.cuda(), sch, return_outputs=True,
-                                 label_u=lu.cuda(), optimal_match=om)
+    # fp32: both paths in DETERMINISTIC mode -- what is compared is batched against per-forward launches, not two draws of the
+    # float-atomic order (whose spread alone reaches 3e-3 of the flat gradient on this network at 20 / 28 images: one of three
+    # repeats of the suite failed a 2e-3 gate on the atomic path); bf16: the production (atomic) path
+    from shot_vae_amd import _lib as L
+    with L.options(deterministic=int(dtype == "fp32")):
+        with T.rng_for_step(nz, om):
+            a = S.train_step(m1, elbo, cls, None, il.cuda(), ll.cuda(), iu.cuda(), sch, return_outputs=True, label_u=lu.cuda(),
+                             optimal_match=om)
+        with T.rng_for_step(nz, om):
+            b = S.train_step_grouped(m2, elbo, cls, None, il.cuda(), ll.cuda(), iu.cuda(), sch, return_outputs=True,
+                                     label_u=lu.cuda(), optimal_match=om)
     torch.cuda.synchronize()
     for k in T.SCALARS + ["kl_inference"]:
         assert abs(float(a[k]) - float(b[k])) <= tol * max(abs(float(a[k])), 1e-6), (k, float(a[k]), float(b[k]))
