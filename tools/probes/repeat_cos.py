@@ -9,12 +9,32 @@ import shot_vae_amd as S                      # noqa: E402
 from oracle import shotvae_oracle as O        # noqa: E402
 from tests import _cases as T                 # noqa: E402
 
+import os
+from shot_vae_amd import _lib as L            # noqa: E402
+import shot_vae_amd.engine as E               # noqa: E402
+# SV_DET_CALLS="sv_pool_bwd,sv_head_bwd": these entry points run their fixed-order variants (bisecting where the spread enters)
+DET = set(filter(None, os.environ.get("SV_DET_CALLS", "").split(",")))
+_orig_call = L.call
+
+
+def _call(nm, *a):
+    if nm in DET:
+        _orig_call("sv_set_option", L.OPT_DETERMINISTIC, 1)
+        try:
+            return _orig_call(nm, *a)
+        finally:
+            _orig_call("sv_set_option", L.OPT_DETERMINISTIC, 0)
+    return _orig_call(nm, *a)
+
+
+E.L.call = _call
 name, K, B = (sys.argv[1], int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else ("wideresnet-28-2", 10, 512)
 torch.manual_seed(17)
 il, ll, iu = torch.rand(B, 3, 32, 32), torch.randint(0, K, (B,)), torch.rand(B, 3, 32, 32)
 nz = O.make_noise(B, B, K, seed=23)
 nz["lam_l"] = 0.9
-sch = O.schedule(10, dmi=2.3 if K == 10 else 4.6)
+sch = O.schedule(int(os.environ.get("SV_EPOCH", "10")), dmi=2.3 if K == 10 else 4.6)
+print("schedule:", {k: round(float(v), 5) for k, v in sch.items()})
 init = O.default_init(name, K=K, seed=5)
 elbo, cls = S.VAECriterion(discrete_dim=K, bce_reconstruction=True).cuda(), S.ClsCriterion()
 model = S.VariationalAutoEncoder(name, num_input_channels=3, img_size=(32, 32), data_parallel=False, continuous_latent_dim=128,
@@ -28,8 +48,9 @@ for rep in range(3):
     model.load_state_dict(state0)
     opt.zero_grad()
     with T.rng_for_step(nz):
-        S.train_step_grouped(model, elbo, cls, None, il.cuda(), ll.cuda(), iu.cuda(), sch)
+        out = S.train_step_grouped(model, elbo, cls, None, il.cuda(), ll.cuda(), iu.cuda(), sch, return_outputs=True)
     torch.cuda.synchronize()
+    print("rep %d: klc_l %.6f kld_l %.6f klc_u %.6f kld_u %.6f" % (rep, float(out["klc_l"]), float(out["kld_l"]), float(out["klc_u"]), float(out["kld_u"])))
     grads.append({k: p.grad.detach().double().clone() for k, p in model.named_parameters()})
 tot = sum(float((g * g).sum()) for g in grads[0].values())
 rows = []
