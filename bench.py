@@ -72,6 +72,8 @@ def parse():
     ap.add_argument("--wgrad-after", type=int, default=0,
                     help="experiment: 1 = a body layer's weight gradient (side stream) starts when its data gradient has finished "
                          "instead of beside it (use with --pair-blocks 0)")
+    ap.add_argument("--deterministic", type=int, default=0,
+                    help="1: SV_OPT_DETERMINISTIC (fixed summation order everywhere: bit-reproducible steps; what it costs)")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher check without a GPU: the ranks rendezvous over gloo, agree on a max-reduced time and "
                          "rank 0 prints a JSON stub (tests/test_bench_launch_cpu.py)")
@@ -502,6 +504,8 @@ def main():
         L.call("sv_set_option", L.OPT_DISABLE_MASK, a.disable)
     if a.persistent_blocks:
         L.call("sv_set_option", L.OPT_PERSISTENT_BLOCKS, a.persistent_blocks)
+    if a.deterministic:
+        L.call("sv_set_option", L.OPT_DETERMINISTIC, 1)
 
     K = a.classes
     if a.scaling == "strong":

@@ -185,6 +185,7 @@ struct SvBudgetScope {
     ~SvBudgetScope();
 };
 bool sv_deterministic();               // sv_set_option(SV_OPT_DETERMINISTIC, 1)
+float* sv_det_scratch(size_t floats);  // deterministic mode: a slice of the library's scratch ring (nullptr + error text on failure)
 enum { SV_FLAG_DET = 1 };              // sv_igemm_args::flags
 // sv_igemm_query_blocks: the launch functions call sv_dry_run(grid) right before their launch; it returns true (and records
 // the grid) when the calling thread is inside a query -- the caller then returns SV_OK without launching.  In deterministic

@@ -36,6 +36,37 @@ thread_local int* tl_query_blocks = nullptr;
 }  // namespace
 bool sv_in_query() { return tl_query_blocks != nullptr; }
 bool sv_deterministic() { return g_deterministic != 0; }
+
+// Deterministic mode: per-block partial results of the two-pass reductions (sv_colsum, the loss sums, sv_pool_bwd, the replica
+// pre-pass of sv_bn_bwd_apply) live in a ring the library owns -- 32 MB, allocated at the first use, which therefore has to be
+// outside a stream capture (the warm-up iterations any capture needs anyway).  A slice is reused once the ring has wrapped:
+// a single call takes at most a few MB, two kernels that are in flight together on different streams are never that many
+// calls apart.
+namespace {
+float* g_det_ring = nullptr;
+size_t g_det_off = 0;
+constexpr size_t DET_RING_FLOATS = (size_t)8 << 20;
+}  // namespace
+float* sv_det_scratch(size_t floats) {
+    floats = (floats + 63) / 64 * 64;
+    if (floats > DET_RING_FLOATS) {
+        sv_set_error("deterministic mode: a reduction asks for %zu floats of scratch (ring: %zu)", floats, DET_RING_FLOATS);
+        return nullptr;
+    }
+    if (!g_det_ring) {
+        void* p = nullptr;
+        if (hipMalloc(&p, DET_RING_FLOATS * sizeof(float)) != hipSuccess) {
+            (void)hipGetLastError();
+            sv_set_error("deterministic mode: cannot allocate the scratch ring (first use inside a stream capture? run one step before capturing)");
+            return nullptr;
+        }
+        g_det_ring = static_cast<float*>(p);
+    }
+    if (g_det_off + floats > DET_RING_FLOATS) g_det_off = 0;
+    float* r = g_det_ring + g_det_off;
+    g_det_off += floats;
+    return r;
+}
 // BatchNorm finalisation folded into an sv_igemm launch (sv_igemm_args::fold_*): sv_igemm announces it (sv_fold_begin); a
 // launcher whose kernel derives the coefficients itself claims it (sv_fold_claim); for every other kernel the launch gate
 // (sv_dry_run, in front of every launch of the family) runs sv_bn_finalize first.
@@ -95,7 +126,7 @@ bool sv_disabled(int kernel_bit) {
     // deterministic mode: no kernel with cross-wave LDS float atomics / float atomics over splits (see shotvae_hip.h)
     // (conv3x3x is deterministic with a replica per block: its waves keep private channel sums, the block adds them in a fixed
     //  order and is the only adder of its replica -- sv_igemm_query_blocks sizes the accumulators)
-    if (g_deterministic && (kernel_bit & (SV_K_CONV3X3W | SV_K_WGRAD_WIDE))) return true;
+    if (g_deterministic && (kernel_bit & SV_K_CONV3X3W)) return true;      // (the wide weight gradient: per-split slabs, see sv_wgrad)
     return (g_disable_mask & kernel_bit) != 0;
 }
 int sv_wide_min_blocks() { return g_wide_min_blocks; }

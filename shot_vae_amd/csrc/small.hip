@@ -20,6 +20,45 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
     return t;
 }
 
+// ---------------------------------------------------------------------------------------- deterministic mode
+// Two-pass reductions: the blocks of the first pass own a slot each in the library's scratch ring (sv_det_scratch), the second
+// pass adds the slots in index order -- one add per output per call, whatever order the blocks ran in.
+//   out[o * n + i] += sum_p part[(o * P + p) * n + i],  p = 0 .. P-1 in order
+__global__ __launch_bounds__(256) void det_collect_kernel(const float* part, int P, int n, float* out) {
+    const int i = blockIdx.x * 256 + threadIdx.x, o = blockIdx.y;
+    if (i >= n) return;
+    const float* src = part + (int64_t)o * P * n + i;
+    float t = 0.f;
+#pragma unroll 8
+    for (int p = 0; p < P; ++p) t += src[(int64_t)p * n];
+    atomicAdd(out + (int64_t)o * n + i, t);
+}
+// Accumulator replicas [R][n] -> [ceil(R / 256)][n]: deterministic mode sizes the BatchNorm accumulators at a replica per producer
+// wave (thousands), and every block of sv_bn_bwd_apply summing all of them was 68 us per launch.  Thread (row group of 8, 4
+// columns) adds its rows in order, the 32 row groups meet in LDS in order.
+__global__ __launch_bounds__(256) void replica_fold_kernel(const float* src, int R, int n, float* dst) {
+    __shared__ f32x4 part[32][8];
+    const int v = threadIdx.x & 7, rg = threadIdx.x >> 3;
+    const int col = blockIdx.x * 32 + 4 * v;
+    const int r0 = blockIdx.y * 256 + rg * 8;
+    f32x4 t = {0.f, 0.f, 0.f, 0.f};
+    if (col < n) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (r0 + k < R) {
+                const f32x4 q = *reinterpret_cast<const f32x4*>(src + (int64_t)(r0 + k) * n + col);
+                t[0] += q[0]; t[1] += q[1]; t[2] += q[2]; t[3] += q[3];
+            }
+    }
+    part[rg][v] = t;
+    __syncthreads();
+    if (rg == 0 && col < n) {
+        f32x4 a = part[0][v];
+        for (int q = 1; q < 32; ++q) { const f32x4 b = part[q][v]; a[0] += b[0]; a[1] += b[1]; a[2] += b[2]; a[3] += b[3]; }
+        *reinterpret_cast<f32x4*>(dst + (int64_t)blockIdx.y * n + col) = a;
+    }
+}
+
 // ---------------------------------------------------------------------------------------- BatchNorm
 // 256 threads = 8 channels x 32 lanes; the lanes of a channel split the accumulator replicas (the loads
 // are independent and in flight together instead of one dependent chain per channel)
@@ -296,8 +335,9 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const T* x, const float* sc
 }
 
 template <typename T>
-__global__ void colsum_kernel(const T* y, int64_t M, int N, int ld, float* out) {
+__global__ void colsum_kernel(const T* y, int64_t M, int N, int ld, float* out, int ostride = 0) {
     // thread (n, slice): blockDim = (N<=64 ? N : 64, 256/that)
+    out += (int64_t)blockIdx.x * ostride;             // (deterministic mode: a slot per row range)
     const int n = blockIdx.y * blockDim.x + threadIdx.x;
     const int64_t rows_per_block = (M + gridDim.x - 1) / gridDim.x;
     const int64_t m0 = (int64_t)blockIdx.x * rows_per_block;
@@ -474,8 +514,9 @@ __global__ __launch_bounds__(256) void pool_bwd8_kernel(const T* x, const float*
     for (int i = threadIdx.x; i < 2 * C; i += 256) atomicAdd(dst + i, psum[i]);
 }
 
-// SV_OPT_DETERMINISTIC: ONE block per group walks the group's images; every thread sums its (image lane, 8-channel group)
-// in a fixed order, the image lanes meet in LDS slots and are added in index order, one add per channel leaves the block.
+// SV_OPT_DETERMINISTIC: gridDim.y blocks per group share the group's images; every thread sums its (image lane, 8-channel
+// group) in a fixed order, the image lanes meet in LDS slots and are added in index order, one add per channel leaves the block
+// into the block's own slot [group][blockIdx.y][2C] (the launcher collects the slots in order).
 template <typename T>
 __global__ __launch_bounds__(256) void pool_bwd_det_kernel(const T* x, const float* scale, const float* shift, float slope,
                                                            const float* mean, const float* rstd, const float* dfeat, int Bg, int HW,
@@ -493,7 +534,7 @@ __global__ __launch_bounds__(256) void pool_bwd_det_kernel(const T* x, const flo
         float sc[8], sh[8], mu[8], rs[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) sc[j] = scale[gc + j], sh[j] = shift[gc + j], mu[j] = mean[gc + j], rs[j] = rstd[gc + j];
-        for (int bi = im; bi < Bg; bi += lanes) {
+        for (int bi = im + lanes * blockIdx.y; bi < Bg; bi += lanes * gridDim.y) {
             const int64_t b = (int64_t)grp * Bg + bi;
             float d[8];
 #pragma unroll
@@ -524,7 +565,7 @@ __global__ __launch_bounds__(256) void pool_bwd_det_kernel(const T* x, const flo
     for (int i = threadIdx.x; i < 2 * C; i += 256) {
         float t = 0.f;
         for (int q = 0; q < lanes; ++q) t += psum[q * 2 * C + i];
-        atomicAdd(bsums + (size_t)grp * 2 * C + i, t);
+        atomicAdd(bsums + ((size_t)grp * gridDim.y + blockIdx.y) * 2 * C + i, t);
     }
 }
 
@@ -813,8 +854,9 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-
 __global__ __launch_bounds__(256) void elbo_fwd_kernel(const float* x, const float* xr, int64_t n_img,
                                                        const float* mu, const float* ls, const float* la,
                                                        int B, int ldc, int K, int bce, float x_sigma,
-                                                       float log_prior, float* out3) {
+                                                       float log_prior, float* out3, int ostride) {
     __shared__ float red[4];
+    out3 += (int64_t)blockIdx.x * ostride;         // (deterministic mode: a slot per block, det_collect adds them in order)
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     float s = 0.f;
@@ -878,8 +920,9 @@ __global__ __launch_bounds__(256) void elbo_bwd_kernel(const float* x, const flo
 }
 
 __global__ __launch_bounds__(256) void cls_fwd_kernel(const float* pred, const float* label, const float* w,
-                                                      int B, int K, float* out) {
+                                                      int B, int K, float* out, int ostride) {
     __shared__ float red[4];
+    out += (int64_t)blockIdx.x * ostride;
     float s = 0.f;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < (int64_t)B * K; i += (int64_t)gridDim.x * 256)
         s += pred[i] * label[i] * (w ? w[i / K] : 1.f);
@@ -913,8 +956,9 @@ __global__ __launch_bounds__(256) void topk_hits_kernel(const float* score, cons
 }
 
 __global__ __launch_bounds__(256) void post_fwd_kernel(const float* mu, const float* ls, const float* mt,
-                                                       const float* st, int B, int D, float* out) {
+                                                       const float* st, int B, int D, float* out, int ostride) {
     __shared__ float red[4];
+    out += (int64_t)blockIdx.x * ostride;
     float s = 0.f;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < (int64_t)B * D; i += (int64_t)gridDim.x * 256) {
         const float a = mu[i] - mt[i], b = expf(ls[i]) - st[i];
@@ -1231,8 +1275,9 @@ __global__ void tanh_to_nchw_bwd_kernel(const float* d_out, const float* out, in
 // (mean over B * D; 0 without labels).  t must be zeroed by the caller.
 __global__ __launch_bounds__(256) void smooth_elbo_fwd_kernel(const float* data, const float* rec, int64_t n, const float* mean,
                                                               const float* logvar, const float* alpha, const int64_t* label,
-                                                              int B, int Dc, int Dd, float* t) {
+                                                              int B, int Dc, int Dd, float* t, int ostride) {
     __shared__ float red[4];
+    t += (int64_t)blockIdx.x * ostride;
     const int64_t stride = (int64_t)gridDim.x * 256, t0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
     float s = 0.f;
     for (int64_t i = t0; i < n; i += stride) { const float d = rec[i] - data[i]; s += d * d; }
@@ -1562,6 +1607,19 @@ int sv_bn_eval_affine(int C, const float* gamma, const float* beta, const float*
     return sv_check_launch("sv_bn_eval_affine");
 }
 
+// deterministic mode: P zeroed slots of `outer * n` floats for the blocks of a first pass / the ordered second pass over them
+static float* det_slots(int P, int n, int outer, hipStream_t s) {
+    float* w = sv_det_scratch((size_t)P * n * outer);
+    if (w && hipMemsetAsync(w, 0, (size_t)P * n * outer * sizeof(float), s) != hipSuccess) {
+        sv_set_error("deterministic mode: clearing the scratch slots failed");
+        return nullptr;
+    }
+    return w;
+}
+static void det_collect(const float* part, int P, int n, int outer, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(det_collect_kernel, dim3((n + 255) / 256, outer), dim3(256), 0, s, part, P, n, out);
+}
+
 int sv_bn_bwd_apply(int dtype, int64_t M, int C, int ld, const void* x, const float* mean, const float* rstd,
                     float count, const sv_bn_branch* br, int nbranch, const void* residual, void* dx,
                     int groups, void* stream) {
@@ -1607,13 +1665,26 @@ int sv_bn_bwd_apply(int dtype, int64_t M, int C, int ld, const void* x, const fl
     // took the LDS-coefficient path at 3.5 TB/s
     const int nthr = 256 % cv == 0 ? 256 : (cv <= 256 ? 256 / cv * cv : 0);
     const bool reg = nthr >= 192 && (int64_t)grid * nthr >= cv;
-    if (sv_deterministic() && groups > 1) {
-        // dgamma / dbeta receive ONE add per launch (block 0): the groups one after the other, in stream order
+    if (sv_deterministic()) {
+        // dgamma / dbeta receive ONE add per launch (block 0): the groups one after the other, in stream order.  The accumulators
+        // of this mode hold a replica per producer wave: a pre-pass folds them 256 : 1 (in order) so that the blocks of the
+        // apply kernel do not each walk thousands of rows
         bnb_params_g A;
         DISPATCH_T(dtype, A = bnb_expand(p, groups, (int)sizeof(T)));
         for (int grp = 0; grp < groups; ++grp) {
             bnb_params_g one = A;
             one.g[0] = A.g[grp];
+            for (int k = 0; k < nbranch; ++k) {
+                const int R = one.g[0].br[k].replicas;
+                if (R <= 64) continue;
+                const int R2 = (R + 255) / 256;
+                float* w = sv_det_scratch((size_t)R2 * 2 * C);
+                if (!w) return SV_E_HIP;
+                hipLaunchKernelGGL(replica_fold_kernel, dim3((2 * C + 31) / 32, R2), dim3(256), 0, (hipStream_t)stream,
+                                   one.g[0].br[k].bsums, R, 2 * C, w);
+                one.g[0].br[k].bsums = w;
+                one.g[0].br[k].replicas = R2;
+            }
             if (reg) DISPATCH_T(dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<T, true>), dim3(grid, 1), dim3(nthr), lds, (hipStream_t)stream, one));
             else DISPATCH_T(dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<T, false>), dim3(grid, 1), dim3(256), lds, (hipStream_t)stream, one));
         }
@@ -1642,11 +1713,15 @@ int sv_bn_act(int dtype, const void* x, const float* scale, const float* shift, 
 int sv_colsum(int dtype, const void* y, int64_t M, int N, int ld, float* out, void* stream) {
     SvProfScope prof_scope(stream);
     SV_REQUIRE(y && out && N > 0, SV_E_ARG, "sv_colsum: null");
-    if (sv_deterministic()) {       // one block per channel slice, fixed order inside it: one add per output
+    if (sv_deterministic()) {       // row ranges in a fixed order inside a block into the block's slot; the slots in order
         const int bx = N < 64 ? N : 64;
         SV_REQUIRE(256 % bx == 0, SV_E_SHAPE, "sv_colsum: N=%d", N);
-        DISPATCH_T(dtype, hipLaunchKernelGGL((colsum_kernel<T>), dim3(1, (N + bx - 1) / bx), dim3(bx, 256 / bx), 0, (hipStream_t)stream,
-                                             (const T*)y, M, N, ld, out));
+        const int P = nblocks(M, 1024, 256);
+        float* w = P > 1 ? det_slots(P, N, 1, (hipStream_t)stream) : nullptr;
+        if (P > 1 && !w) return SV_E_HIP;
+        DISPATCH_T(dtype, hipLaunchKernelGGL((colsum_kernel<T>), dim3(P, (N + bx - 1) / bx), dim3(bx, 256 / bx), 0, (hipStream_t)stream,
+                                             (const T*)y, M, N, ld, P > 1 ? w : out, P > 1 ? N : 0));
+        if (P > 1) det_collect(w, P, N, 1, out, (hipStream_t)stream);
         return sv_check_launch("sv_colsum");
     }
     if (N % 8 == 0 && ld % 8 == 0 && N <= 2048 && M >= 4096) {
@@ -1694,10 +1769,16 @@ int sv_pool_bwd(int dtype, const void* x, const float* scale, const float* shift
     SV_REQUIRE(x && scale && shift && mean && rstd && dfeat && g && bsums, SV_E_ARG, "sv_pool_bwd: null");
     SV_REQUIRE(B % sv_ngroups(groups) == 0, SV_E_ARG, "sv_pool_bwd: B=%d is not a multiple of groups=%d", B, groups);
     if (sv_deterministic() && C % 8 == 0 && ld % 8 == 0 && C / 8 <= 256) {
-        const int cv = C / 8, lanes = 256 / cv;
-        DISPATCH_T(dtype, hipLaunchKernelGGL((pool_bwd_det_kernel<T>), dim3(sv_ngroups(groups)), dim3(256), (size_t)lanes * 2 * C * sizeof(float),
-                                             (hipStream_t)stream, (const T*)x, scale, shift, slope, mean, rstd, dfeat, B / sv_ngroups(groups),
-                                             HW, C, ld, (T*)g, bsums));
+        const int cv = C / 8, lanes = 256 / cv, G = sv_ngroups(groups), Bg = B / G;
+        int P = Bg / lanes;                    // blocks per group: at least one image per image lane
+        if (P > 64) P = 64;
+        if (P < 1) P = 1;
+        float* w = P > 1 ? det_slots(P, 2 * C, G, (hipStream_t)stream) : nullptr;
+        if (P > 1 && !w) return SV_E_HIP;
+        DISPATCH_T(dtype, hipLaunchKernelGGL((pool_bwd_det_kernel<T>), dim3(G, P), dim3(256), (size_t)lanes * 2 * C * sizeof(float),
+                                             (hipStream_t)stream, (const T*)x, scale, shift, slope, mean, rstd, dfeat, Bg,
+                                             HW, C, ld, (T*)g, P > 1 ? w : bsums));
+        if (P > 1) det_collect(w, P, 2 * C, G, bsums, (hipStream_t)stream);
         return sv_check_launch("sv_pool_bwd");
     }
     {
@@ -1792,8 +1873,12 @@ int sv_elbo_fwd(const float* x, const float* x_rec, int64_t n_per_img, const flo
     const int64_t n = n_per_img * B;
     // (three float atomics per block on the same three addresses: 256 blocks, not 1 024 -- the tail of serialised atomics
     //  was most of this kernel's 26 us)
-    hipLaunchKernelGGL(elbo_fwd_kernel, dim3(sv_deterministic() ? 1 : nblocks(n / 4, 1024, 256)), dim3(256), 0, (hipStream_t)stream, x, x_rec,
-                       n, mu, ls, la, B, ldc, K, bce, x_sigma, log_prior_f32(K), out3);
+    const int P = nblocks(n / 4, 1024, 256);
+    float* w = nullptr;
+    if (sv_deterministic() && P > 1 && !(w = det_slots(P, 3, 1, (hipStream_t)stream))) return SV_E_HIP;
+    hipLaunchKernelGGL(elbo_fwd_kernel, dim3(P), dim3(256), 0, (hipStream_t)stream, x, x_rec,
+                       n, mu, ls, la, B, ldc, K, bce, x_sigma, log_prior_f32(K), w ? w : out3, w ? 3 : 0);
+    if (w) det_collect(w, P, 3, 1, out3, (hipStream_t)stream);
     return sv_check_launch("sv_elbo_fwd");
 }
 
@@ -1811,8 +1896,11 @@ int sv_elbo_bwd(const float* x, const float* x_rec, int64_t n_per_img, const flo
 int sv_cls_fwd(const float* predict, const float* label, const float* weight, int B, int K, float* out, void* stream) {
     SvProfScope prof_scope(stream);
     SV_REQUIRE(predict && label && out, SV_E_ARG, "sv_cls_fwd: null");
-    hipLaunchKernelGGL(cls_fwd_kernel, dim3(sv_deterministic() ? 1 : nblocks((int64_t)B * K, 256, 64)), dim3(256), 0, (hipStream_t)stream,
-                       predict, label, weight, B, K, out);
+    const int P = nblocks((int64_t)B * K, 256, 64);
+    float* w = nullptr;
+    if (sv_deterministic() && P > 1 && !(w = det_slots(P, 1, 1, (hipStream_t)stream))) return SV_E_HIP;
+    hipLaunchKernelGGL(cls_fwd_kernel, dim3(P), dim3(256), 0, (hipStream_t)stream, predict, label, weight, B, K, w ? w : out, w ? 1 : 0);
+    if (w) det_collect(w, P, 1, 1, out, (hipStream_t)stream);
     return sv_check_launch("sv_cls_fwd");
 }
 int sv_cls_bwd(const float* label, const float* weight, int B, int K, const float* gout, float* dpredict, void* stream) {
@@ -1834,8 +1922,11 @@ int sv_post_fwd(const float* mu, const float* ls, const float* mu_t, const float
                 void* stream) {
     SvProfScope prof_scope(stream);
     SV_REQUIRE(mu && ls && mu_t && sigma_t && out, SV_E_ARG, "sv_post_fwd: null");
-    hipLaunchKernelGGL(post_fwd_kernel, dim3(sv_deterministic() ? 1 : nblocks((int64_t)B * D, 256, 64)), dim3(256), 0, (hipStream_t)stream, mu,
-                       ls, mu_t, sigma_t, B, D, out);
+    const int P = nblocks((int64_t)B * D, 256, 64);
+    float* w = nullptr;
+    if (sv_deterministic() && P > 1 && !(w = det_slots(P, 1, 1, (hipStream_t)stream))) return SV_E_HIP;
+    hipLaunchKernelGGL(post_fwd_kernel, dim3(P), dim3(256), 0, (hipStream_t)stream, mu, ls, mu_t, sigma_t, B, D, w ? w : out, w ? 1 : 0);
+    if (w) det_collect(w, P, 1, 1, out, (hipStream_t)stream);
     return sv_check_launch("sv_post_fwd");
 }
 int sv_post_bwd(const float* mu, const float* ls, const float* mu_t, const float* sigma_t, int B, int D,
@@ -2017,8 +2108,14 @@ int sv_smooth_elbo_fwd(const float* data, const float* rec, int64_t n_per_img, c
     SvProfScope prof_scope(stream);
     SV_REQUIRE(data && rec && mean && logvar && alpha && sch && terms && coef && B > 0, SV_E_ARG, "sv_smooth_elbo_fwd: bad argument");
     const int64_t n = n_per_img * B;
-    hipLaunchKernelGGL(smooth_elbo_fwd_kernel, dim3(sv_deterministic() ? 1 : nblocks(n, 1024, 1024)), dim3(256), 0, (hipStream_t)stream,
-                       data, rec, n, mean, logvar, alpha, label, B, Dc, Dd, terms);
+    {
+        const int P = nblocks(n, 1024, 1024);
+        float* w = nullptr;
+        if (sv_deterministic() && P > 1 && !(w = det_slots(P, 4, 1, (hipStream_t)stream))) return SV_E_HIP;
+        hipLaunchKernelGGL(smooth_elbo_fwd_kernel, dim3(P), dim3(256), 0, (hipStream_t)stream,
+                           data, rec, n, mean, logvar, alpha, label, B, Dc, Dd, w ? w : terms, w ? 4 : 0);
+        if (w) det_collect(w, P, 4, 1, terms, (hipStream_t)stream);
+    }
     smooth_caps c;
     c.cmin = sch->cont_min; c.cmax = sch->cont_max; c.citers = sch->cont_iters; c.cgamma = sch->cont_gamma;
     c.dmin = sch->disc_min; c.dmax = sch->disc_max; c.diters = sch->disc_iters; c.dgamma = sch->disc_gamma;

@@ -14,6 +14,8 @@
 
 #include "common.h"
 
+void sv_slab_reduce(const float* ws, int nslabs, int64_t n, float* dw, hipStream_t s);      // wgrad3x3.hip
+
 namespace {
 
 constexpr int RW = 32;   // rows (output positions) per wave per iteration = one MFMA k chunk
@@ -30,6 +32,8 @@ struct wg_params {
     int wsh, hwsh;              // log2(Wq), log2(Hq*Wq) or -1
     int ntap_total;
     int incr;                   // incremental addressing allowed (SV_K_WGRAD_INCR)
+    int64_t slab_stride;        // deterministic mode: m range `split` adds into dw + split * slab_stride (zeroed slabs, one adder
+                                // per element), a fixed-order pass sums the slabs afterwards; 0 = every split into dw
 };
 
 template <bool FAST>
@@ -292,11 +296,12 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const sv_geom g, const sv_wg
             for (int r = 0; r < 4; ++r)
                 red[wave * BNw * BCw + (16 * i + 4 * fq + r) * BCw + 16 * j + fr] = acc[i][j][r];
     __syncthreads();
+    float* const dwp = p.dw + (int64_t)split * p.slab_stride;
     for (int i = tid; i < BNw * BCw; i += 256) {
         const int n = n0 + i / BCw, c = c0 + i % BCw;
         const float v = red[i] + red[BNw * BCw + i] + red[2 * BNw * BCw + i] + red[3 * BNw * BCw + i];
         if (n < g.N && c < g.Cin)
-            atomicAdd(p.dw + ((int64_t)n * g.T_orig + torig) * g.Cin + c, v);
+            atomicAdd(dwp + ((int64_t)n * g.T_orig + torig) * g.Cin + c, v);
     }
 }
 
@@ -454,6 +459,7 @@ __global__ __launch_bounds__(256, 2) void wgradc_kernel(const sv_geom g, const s
     }
     // every wave owns its quarter of the tile: one global atomic per element per block
     const int fr = lane & 15, fq = lane >> 4;
+    float* const dwp = p.dw + (int64_t)split * p.slab_stride;
 #pragma unroll
     for (int i = 0; i < TNW; ++i)
 #pragma unroll
@@ -461,12 +467,28 @@ __global__ __launch_bounds__(256, 2) void wgradc_kernel(const sv_geom g, const s
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int n = n0 + 16 * (TNW * wn + i) + 4 * fq + r, c = c0 + 16 * (TCW * wc + j) + fr;
-                if (n < g.N && c < g.Cin) atomicAdd(p.dw + ((int64_t)n * g.T_orig + torig) * g.Cin + c, acc[i][j][r]);
+                if (n < g.N && c < g.Cin) atomicAdd(dwp + ((int64_t)n * g.T_orig + torig) * g.Cin + c, acc[i][j][r]);
             }
 }
 
+// deterministic mode: `splits` zeroed slabs of dw's size in the caller's workspace (p.dw -> the slabs); det_slabs_end adds them
+// to dw in a fixed order
+static int det_slabs_cap(const sv_geom* g, float* ws, int64_t ws_elems) {
+    const int64_t n = (int64_t)g->N * g->T_orig * g->Cin;
+    if (!ws || n % 4 != 0) return 0;
+    const int64_t cap = ws_elems / n;
+    return cap >= 2 ? (int)(cap > 64 ? 64 : cap) : 0;
+}
+static bool det_slabs_begin(const sv_geom* g, wg_params& p, float* ws, hipStream_t s) {
+    const int64_t n = (int64_t)g->N * g->T_orig * g->Cin;
+    if (hipMemsetAsync(ws, 0, (size_t)p.splits * n * sizeof(float), s) != hipSuccess) return false;
+    p.slab_stride = n;
+    p.dw = ws;
+    return true;
+}
+
 template <int TNW, int TCW>
-int launch_c(const sv_geom* g, wg_params p, int64_t M, hipStream_t s) {
+int launch_c(const sv_geom* g, wg_params p, int64_t M, hipStream_t s, float* det_ws = nullptr, int det_cap = 0) {
     constexpr int BNb = 32 * TNW, BCb = 32 * TCW;
     const int nNt = (g->N + BNb - 1) / BNb, nCt = (g->Cin + BCb - 1) / BCb;
     const int tiles = nNt * p.ntap_total * nCt;
@@ -490,11 +512,14 @@ int launch_c(const sv_geom* g, wg_params p, int64_t M, hipStream_t s) {
         }
         splits = best;
     }
+    if (det_ws && splits > det_cap) splits = det_cap >= 8 ? det_cap / 8 * 8 : det_cap;
     int64_t m_per = (M + splits - 1) / splits;
     m_per = (m_per + RW - 1) / RW * RW;
     if (splits < 8) splits = (int)((M + m_per - 1) / m_per);
     p.splits = splits;
     p.m_per = (int)m_per;
+    float* const dw_final = p.dw;
+    if (det_ws && !det_slabs_begin(g, p, det_ws, s)) return sv_check_launch("sv_wgrad(wide): slab clear");
     const size_t lds = (size_t)2 * RW * (BNb + 8 + BCb + 8) * sizeof(bf16);
     sv_prof_begin(s);
     if (p.hwsh >= 0)
@@ -502,6 +527,7 @@ int launch_c(const sv_geom* g, wg_params p, int64_t M, hipStream_t s) {
     else
         hipLaunchKernelGGL((wgradc_kernel<TNW, TCW, false>), dim3(splits * tiles, p.groups), dim3(256), lds, s, *g, sv_expand_wg(*g, p, p.groups, 2));
     sv_prof_end(s);
+    if (det_ws) sv_slab_reduce(det_ws, p.splits, (int64_t)g->N * g->T_orig * g->Cin, dw_final, s);
     return sv_check_launch("sv_wgrad(wide)");
 }
 
@@ -590,7 +616,10 @@ extern "C" int sv_wgrad(const sv_geom* g, int dtype, const void* x, const float*
         }
         return SV_OK;
     }
-    if (sv_deterministic()) splits = 1;          // (generic kernel: one M range = one adder per weight)
+    // deterministic mode, generic kernels: one adder per weight -- the m ranges write slabs of their own in the caller's
+    // workspace and a fixed-order pass adds them to dw (without a workspace: a single m range)
+    const int det_cap = sv_deterministic() ? det_slabs_cap(g, ws, ws_elems) : 0;
+    if (sv_deterministic()) splits = det_cap ? 0 : 1;
     if (dtype == SV_F32 || use_tr) {   // stride-1 3x3: LDS-halo kernels (wgrad3x3.hip) unless switched off
         int rc = 0;
         if (!sv_disabled(SV_K_WGRAD3X3) && sv_wgrad3x3_try(g, dtype, x, pro_scale, pro_shift, pro_slope, dy, dw, ws, ws_elems, sv_ngroups(groups), (hipStream_t)stream, &rc))
@@ -608,12 +637,13 @@ extern "C" int sv_wgrad(const sv_geom* g, int dtype, const void* x, const float*
     if (p.wsh < 0 || p.hwsh < 0) p.wsh = p.hwsh = -1;
     p.ntap_total = 0;
     p.incr = !sv_disabled(SV_K_WGRAD_INCR);
+    p.slab_stride = 0;
     for (int i = 0; i < g->nphase; ++i) p.ntap_total += g->phase[i].ntap;
     if (p.ntap_total == 0) return SV_OK;
     const int64_t M = (int64_t)g->B * g->Hq * g->Wq;
     if (dtype == SV_BF16 && use_tr && splits <= 0 && !sv_disabled(SV_K_WGRAD_WIDE) && g->N % 160 == 0 && g->Cin % 160 == 0 &&
-        M * p.groups >= (int64_t)256 * sv_wide_min_blocks())
-        return launch_c<5, 5>(g, p, M, (hipStream_t)stream);
+        M * p.groups >= (int64_t)256 * sv_wide_min_blocks() && (!sv_deterministic() || det_cap))
+        return launch_c<5, 5>(g, p, M, (hipStream_t)stream, det_cap ? ws : nullptr, det_cap);
     // tile: the widest of {64,32,16} that divides; fp32 is capped at 32 (LDS budget)
     auto pick = [&](int n) { int t = (n % 64 == 0) ? 4 : (n % 32 == 0 ? 2 : 1); if (n >= 64 && t == 1) t = (n % 32 == 0) ? 2 : 1; return t; };
     int tn = pick(g->N), tc = pick(g->Cin);
@@ -629,6 +659,7 @@ extern "C" int sv_wgrad(const sv_geom* g, int dtype, const void* x, const float*
         if (want < 1) want = 1;
         splits = (int)want;
     }
+    if (det_cap && splits > det_cap) splits = det_cap;
     if (splits >= 8) splits = splits / 8 * 8;     // multiple of 8: XCD-affine block mapping
     int64_t m_per = (M + splits - 1) / splits;
     m_per = (m_per + 127) / 128 * 128;
@@ -636,9 +667,14 @@ extern "C" int sv_wgrad(const sv_geom* g, int dtype, const void* x, const float*
     p.splits = splits;
     p.m_per = (int)m_per;
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == SV_BF16) {
-        if (use_tr) return dispatch<bf16, true>(g, p, tn, tc, s);
-        return dispatch<bf16, false>(g, p, tn, tc, s);
+    const bool slabs = det_cap && splits > 1;
+    if (slabs && !det_slabs_begin(g, p, ws, s)) return sv_check_launch("sv_wgrad: slab clear");
+    int rc;
+    if (dtype == SV_BF16) rc = use_tr ? dispatch<bf16, true>(g, p, tn, tc, s) : dispatch<bf16, false>(g, p, tn, tc, s);
+    else rc = dispatch<float, false>(g, p, tn, tc, s);
+    if (rc == SV_OK && slabs) {
+        sv_slab_reduce(ws, splits, (int64_t)g->N * g->T_orig * g->Cin, dw, s);
+        rc = sv_check_launch("sv_wgrad: slab reduce");
     }
-    return dispatch<float, false>(g, p, tn, tc, s);
+    return rc;
 }
