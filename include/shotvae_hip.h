@@ -439,18 +439,19 @@ int sv_debug_conv_chunk_program(int* items, int* waits);
  * SV_OPT_PERSISTENT_BLOCKS: block budget of the persistent narrow 3x3 kernels (conv3x3p, wgrad3x3), shared among the
  * groups of a batched launch.  Default 512 (two blocks per CU); tools/tune_blocks.py sweeps it.
  * SV_OPT_DETERMINISTIC: 1 = every floating-point accumulation of the library has a FIXED summation order, so that two runs
- * on the same inputs agree bit for bit (parity tests; slower, and the accumulator replicas grow with the grid):
+ * on the same inputs agree bit for bit (parity tests, reproducible training; since round 4 about 1.4x the step time of the
+ * default mode on WRN-28-2 and 1.8x on WRN-28-10; the accumulator replicas grow with the grid):
  *   - BatchNorm statistics / BatchNorm-backward sums of the conv-like kernels: no LDS float atomics, every wave of every
- *     block adds its partial sums to a replica of its own (ONE adder per address; needs replicas >= 4 * blocks, see
- *     sv_igemm_query_blocks; sv_igemm fails with SV_E_ARG otherwise); the consumers sum the replicas in index order;
- *   - weight gradients: per-block partial slabs + the ordered slab reduction where the kernel has them (3x3 stride 1, the
- *     tap-fused thin layers -- they need the workspace), otherwise ONE M range and the groups of a batched launch one after
- *     the other (a single adder per weight); the cooperative wide kernel (float atomics over splits) is not taken;
- *   - the wide 3x3 kernel conv3x3w (cross-wave LDS atomics in its epilogue) is not taken: its layers run on the general
- *     LDS-halo kernel (tested against it separately); conv3x3x (the 160-channel tiles of the WRN-28-10 body) IS taken since
- *     round 4: its waves keep private channel sums, a block adds them in a fixed order and is the only adder of its replica;
- *   - the small reduction kernels (pool backward, head weight gradient, column sums, loss terms, BatchNorm dgamma / dbeta
- *     of a batched launch) run their fixed-order variants.
+ *     block adds its partial sums to a replica of its own, or (conv3x3w / conv3x3x) the block adds its waves' private sums in a
+ *     fixed order (ONE adder per address; needs replicas >= 4 * blocks, see sv_igemm_query_blocks; sv_igemm fails with
+ *     SV_E_ARG otherwise); the consumers sum the replicas in index order (sv_bn_bwd_apply after a 256 : 1 pre-pass);
+ *   - weight gradients: partial slabs in the workspace + the ordered slab reduction (3x3 stride 1 and the tap-fused thin
+ *     layers: a slab per block; the generic and the cooperative wide kernel: a zeroed slab per M range); without a workspace
+ *     of at least two slabs ONE M range; the groups of a batched launch one after the other (a single adder per weight);
+ *   - the small reductions (pool backward, column sums, loss terms) run in two passes: the blocks of the first own a slot
+ *     each in a scratch ring the library allocates at the first use (32 MB; that first call must not be inside a stream
+ *     capture), the second adds the slots in index order; the head weight gradient one slice after the other; BatchNorm
+ *     dgamma / dbeta of a batched launch by one block, the groups in index order.
  * Default 0.
  * SV_OPT_ENABLE_MASK: OR of SV_K_* bits of kernels that are OFF by default.  SV_K_WGRAD3X3Q: the 64 x 64-block form of the
  * narrow weight gradient (everything by LDS-DMA, transform and copies in the MFMA gaps: 54 / 51 us alone at 64 / 128 channels

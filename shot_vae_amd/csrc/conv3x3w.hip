@@ -70,10 +70,15 @@ struct WCfg {
     static constexpr int WS = 4 * BN;                       // 16-byte slots of one weight buffer
     static constexpr int WI = (WS + 255) / 256;
     static constexpr int WBUF = WS * 16;
-    static constexpr int OFF_W = 2 * HB, OFF_CO = OFF_W + 3 * WBUF, OFF_SSUM = OFF_CO + 2048,
-                         LDS = OFF_SSUM + 2 * BN * 4;
+    static constexpr int OFF_W = 2 * HB, OFF_CO = OFF_W + 3 * WBUF,
+                         OFF_SSUM = OFF_CO + 2048;
+    // channel sums: one copy per wave (no LDS float atomics: the block adds the copies in a fixed order and is the only adder of
+    // its replica in deterministic mode).  Where four copies behind the buffers would cost the second block per CU (160-channel
+    // tiles at 8 x 8) copies 0..2 lie over the tail of the -- by then dead -- weight / coefficient buffers
+    static constexpr bool WS_ALIAS = 2 * (OFF_SSUM + 4 * 2 * BN * 4) > 160 * 1024;
+    static constexpr int OFF_WSUM = WS_ALIAS ? OFF_SSUM - 3 * 2 * BN * 4 : OFF_SSUM, LDS = OFF_WSUM + 4 * 2 * BN * 4;
     static constexpr int SCR = 64 * 36 * 4;                 // epilogue transpose scratch per wave
-    static_assert(4 * SCR + 4 * 4096 <= OFF_SSUM, "epilogue scratch must fit in the halo + weight + coefficient buffers");
+    static_assert(4 * SCR + 4 * 4096 + 5 * BN * 4 <= OFF_WSUM, "epilogue scratch must fit in the halo + weight + coefficient buffers");
     static_assert(HI <= 6, "transform schedule covers at most 6 slots per thread");
     static_assert(2 * LDS <= 160 * 1024, "two blocks per CU");
 };
@@ -88,7 +93,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3w_kernel(const sv_geom g, const
     constexpr int HS = C::HS, HB = C::HB, WS = C::WS, WBUF = C::WBUF, SWS = C::SWS;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* const ssum = reinterpret_cast<float*>(smem + C::OFF_SSUM);
+    float* const ssum = reinterpret_cast<float*>(smem + C::OFF_WSUM);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);        // scalar: DMA destinations stay in SGPRs
@@ -120,7 +125,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3w_kernel(const sv_geom g, const
                                    : 4u * lane;
     const uint32_t costep = has_pro ? 128u : 0u;
 
-    for (int c = tid; c < 2 * BN; c += 256) ssum[c] = 0.f;
 
     // ---- DMA slots (uniform instruction count per wave: the last, partial wave-instruction is shifted back so that it
     //      ends at the end of the image and re-copies a few slots -- same source, same destination) -----------------
@@ -354,7 +358,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3w_kernel(const sv_geom g, const
 #define SV_EPI_BASE 0
 #define SV_EPI_ALIAS 0
 #define SV_EPI_MODE MODE
-#define SV_EPI_WAVE_SUMS 0
+#define SV_EPI_WAVE_SUMS 1
 #include "conv3x3w_epilogue.inc"
 #undef SV_EPI_MODE
 #undef SV_EPI_WAVE_SUMS
@@ -376,7 +380,7 @@ int launch_w4(const sv_geom* g, const sv_igemm_args* a, hipStream_t s) {
             return sv_check_launch("hipFuncSetAttribute(conv3x3w)");
         optin = true;
     }
-    SV_LAUNCH_GATE(grid, a);          // (query only: these kernels are not dispatched in deterministic mode)
+    SV_LAUNCH_GATE(grid, a);          // (deterministic mode: a replica per block -- the gate checks replicas >= 4 * grid)
     sv_prof_begin(s);
     hipLaunchKernelGGL((conv3x3w_kernel<NF, WLOG, REV, MODE>), dim3(grid, sv_ngroups(a->groups)), dim3(256), lds, s, *g, sv_expand_groups(*g, *a, 2));
     sv_prof_end(s);

@@ -123,10 +123,8 @@ SvBudgetScope::~SvBudgetScope() { tl_block_budget = old; }
 int sv_persistent_blocks() { return tl_block_budget > 0 ? tl_block_budget : g_persistent_blocks; }
 bool sv_halo_all() { return g_halo_all != 0; }
 bool sv_disabled(int kernel_bit) {
-    // deterministic mode: no kernel with cross-wave LDS float atomics / float atomics over splits (see shotvae_hip.h)
-    // (conv3x3x is deterministic with a replica per block: its waves keep private channel sums, the block adds them in a fixed
-    //  order and is the only adder of its replica -- sv_igemm_query_blocks sizes the accumulators)
-    if (g_deterministic && (kernel_bit & SV_K_CONV3X3W)) return true;      // (the wide weight gradient: per-split slabs, see sv_wgrad)
+    // (deterministic mode: conv3x3w / conv3x3x keep per-wave channel sums that the block adds in a fixed order -- it is the only
+    //  adder of its replica, sv_igemm_query_blocks sizes the accumulators; the wide weight gradient writes per-split slabs)
     return (g_disable_mask & kernel_bit) != 0;
 }
 int sv_wide_min_blocks() { return g_wide_min_blocks; }

@@ -38,6 +38,8 @@ __global__ __launch_bounds__(256) void det_collect_kernel(const float* part, int
 // columns) adds its rows in order, the 32 row groups meet in LDS in order.
 __global__ __launch_bounds__(256) void replica_fold_kernel(const float* src, int R, int n, float* dst) {
     __shared__ f32x4 part[32][8];
+    src += (int64_t)blockIdx.z * R * n;                  // batched launch: group z, [G][R][n] -> [G][gridDim.y][n]
+    dst += (int64_t)blockIdx.z * gridDim.y * n;
     const int v = threadIdx.x & 7, rg = threadIdx.x >> 3;
     const int col = blockIdx.x * 32 + 4 * v;
     const int r0 = blockIdx.y * 256 + rg * 8;
@@ -151,7 +153,10 @@ struct bnb_params {
     void* dx;
 };
 
-struct bnb_params_g { bnb_params g[SV_MAX_GROUPS]; };
+struct bnb_params_g {
+    bnb_params g[SV_MAX_GROUPS];
+    int det_groups;       // deterministic mode: > 0 = block (0, 0) alone adds dgamma / dbeta, the groups in index order
+};
 // tensors [G][M][ld], mean / rstd [G][C], bsums [G][R][2C]
 static bnb_params_g bnb_expand(const bnb_params& p, int groups, int es) {
     bnb_params_g A;
@@ -171,6 +176,7 @@ static bnb_params_g bnb_expand(const bnb_params& p, int groups, int es) {
         }
         A.g[grp] = r;
     }
+    A.det_groups = 0;
     return A;
 }
 
@@ -223,9 +229,23 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bnb_params_g PG
                     cb[c] = p.br[k].gamma[c] * rs;
                     cb[p.C + c] = s1 * p.inv_count;
                     cb[2 * p.C + c] = s2 * p.inv_count;
-                    if (blockIdx.x == 0) {      // atomics: another stream's backward may add to the same slots
+                    if (blockIdx.x == 0 && !PG.det_groups) {      // atomics: another stream's backward may add to the same slots
                         if (p.br[k].dbeta) atomicAdd(p.br[k].dbeta + c, s1);
                         if (p.br[k].dgamma) atomicAdd(p.br[k].dgamma + c, s2);
+                    } else if (blockIdx.x == 0 && blockIdx.y == 0) {      // one adder per launch, groups and replicas in index order
+                        float a1 = 0.f, a2 = 0.f;
+                        for (int q = 0; q < PG.det_groups; ++q) {
+                            const sv_bn_branch& bq = PG.g[q].br[k];
+                            float t1 = 0.f, t2 = 0.f;
+                            for (int r = 0; r < bq.replicas; ++r) {
+                                t1 += bq.bsums[(size_t)r * 2 * p.C + c];
+                                t2 += bq.bsums[(size_t)r * 2 * p.C + p.C + c];
+                            }
+                            a1 += t1;
+                            a2 += t2;
+                        }
+                        if (p.br[k].dbeta) atomicAdd(p.br[k].dbeta + c, a1);
+                        if (p.br[k].dgamma) atomicAdd(p.br[k].dgamma + c, a2);
                     }
                 }
             }
@@ -1666,28 +1686,25 @@ int sv_bn_bwd_apply(int dtype, int64_t M, int C, int ld, const void* x, const fl
     const int nthr = 256 % cv == 0 ? 256 : (cv <= 256 ? 256 / cv * cv : 0);
     const bool reg = nthr >= 192 && (int64_t)grid * nthr >= cv;
     if (sv_deterministic()) {
-        // dgamma / dbeta receive ONE add per launch (block 0): the groups one after the other, in stream order.  The accumulators
-        // of this mode hold a replica per producer wave: a pre-pass folds them 256 : 1 (in order) so that the blocks of the
-        // apply kernel do not each walk thousands of rows
+        // dgamma / dbeta receive ONE add per launch: block (0, 0) walks the groups in index order.  The accumulators of this
+        // mode hold a replica per producer wave: a pre-pass folds them 256 : 1 (in order) so that the blocks of the apply
+        // kernel do not each walk thousands of rows
+        for (int k = 0; k < nbranch; ++k) {
+            const int R = p.br[k].replicas;
+            if (R <= 64) continue;
+            const int R2 = (R + 255) / 256;
+            float* w = sv_det_scratch((size_t)groups * R2 * 2 * C);
+            if (!w) return SV_E_HIP;
+            hipLaunchKernelGGL(replica_fold_kernel, dim3((2 * C + 31) / 32, R2, groups), dim3(256), 0, (hipStream_t)stream,
+                               p.br[k].bsums, R, 2 * C, w);
+            p.br[k].bsums = w;
+            p.br[k].replicas = R2;
+        }
         bnb_params_g A;
         DISPATCH_T(dtype, A = bnb_expand(p, groups, (int)sizeof(T)));
-        for (int grp = 0; grp < groups; ++grp) {
-            bnb_params_g one = A;
-            one.g[0] = A.g[grp];
-            for (int k = 0; k < nbranch; ++k) {
-                const int R = one.g[0].br[k].replicas;
-                if (R <= 64) continue;
-                const int R2 = (R + 255) / 256;
-                float* w = sv_det_scratch((size_t)R2 * 2 * C);
-                if (!w) return SV_E_HIP;
-                hipLaunchKernelGGL(replica_fold_kernel, dim3((2 * C + 31) / 32, R2), dim3(256), 0, (hipStream_t)stream,
-                                   one.g[0].br[k].bsums, R, 2 * C, w);
-                one.g[0].br[k].bsums = w;
-                one.g[0].br[k].replicas = R2;
-            }
-            if (reg) DISPATCH_T(dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<T, true>), dim3(grid, 1), dim3(nthr), lds, (hipStream_t)stream, one));
-            else DISPATCH_T(dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<T, false>), dim3(grid, 1), dim3(256), lds, (hipStream_t)stream, one));
-        }
+        A.det_groups = groups;
+        if (reg) DISPATCH_T(dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<T, true>), dim3(grid, groups), dim3(nthr), lds, (hipStream_t)stream, A));
+        else DISPATCH_T(dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<T, false>), dim3(grid, groups), dim3(256), lds, (hipStream_t)stream, A));
         return sv_check_launch("sv_bn_bwd_apply");
     }
     if (reg) {

@@ -932,7 +932,9 @@ def test_tap_fused_wgrad_convT(H, Cin, N, B):
 # ------------------------------------------------------------------------------------------ deterministic accumulation
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
 @pytest.mark.parametrize("case", [(8, 32, 32, 16, 3, 1, 1), (6, 64, 64, 16, 3, 1, 1), (5, 64, 128, 8, 3, 2, 1), (8, 16, 32, 32, 3, 1, 1),
-                                  (4, 32, 64, 16, 1, 2, 0), (4, 160, 160, 8, 3, 1, 1), (16, 128, 128, 8, 3, 1, 1)])
+                                  (4, 32, 64, 16, 1, 2, 0), (4, 160, 160, 8, 3, 1, 1), (16, 128, 128, 8, 3, 1, 1),
+                                  # several M ranges of the generic / the cooperative wide weight gradient: a zeroed slab each
+                                  (48, 64, 128, 16, 3, 2, 1), (24, 160, 320, 16, 3, 2, 1)])
 def test_deterministic_mode_reproduces_bit_for_bit(dt, case):
     """SV_OPT_DETERMINISTIC: the BatchNorm statistics of a forward, the BatchNorm-backward sums of a data gradient (groups =
     2) and the weight gradient are IDENTICAL over repeated launches (one adder per accumulator address: replicas sized by
@@ -993,6 +995,69 @@ def test_deterministic_mode_reproduces_bit_for_bit(dt, case):
     assert rel(first[5], ref[5]) < 2e-4 and torch.equal(first[0], ref[0]) and torch.equal(first[3], ref[3])
     with pytest.raises(L.ShotVaeHipError, match="replicas"):
         run(True, replicas=2)
+
+
+def test_deterministic_two_pass_reductions():
+    """SV_OPT_DETERMINISTIC at sizes where the small reductions take several blocks: column sums, the ELBO / classification /
+    posterior loss sums, the pooling backward (BatchNorm-backward sums) and sv_bn_bwd_apply over thousands of accumulator
+    replicas (folded 256 : 1 first; dgamma / dbeta of a batched launch by one block) -- per-block slots in the library's
+    scratch ring + an ordered second pass: bit-identical over repeats, equal to the default (atomic) mode to rounding."""
+    d = dev()
+    torch.manual_seed(21)
+    M, N = 300000, 16
+    y = torch.randn(M, N, device=d).to(torch.bfloat16)
+    B, ldc, K = 96, 128, 10
+    x = torch.rand(B, 3, 32, 32, device=d)
+    xr = torch.randn(B, 3, 32, 32, device=d) * 2
+    mu, ls = torch.randn(B, ldc, device=d) * 0.7, torch.randn(B, ldc, device=d) * 0.3 - 0.5
+    la = F.log_softmax(torch.randn(B, K, device=d) * 2, 1)
+    lab = torch.softmax(torch.randn(B, K, device=d), 1)
+    mt, stt = torch.randn(B, ldc, device=d), torch.rand(B, ldc, device=d)
+    Bp, Cc, HW, Gn = 512, 128, 64, 2
+    xp = torch.randn(Bp, HW, Cc, device=d).to(torch.bfloat16)
+    sc, sh = torch.rand(Gn, Cc, device=d) + 0.5, torch.randn(Gn, Cc, device=d) * 0.2
+    mn, rs = torch.randn(Gn, Cc, device=d) * 0.1, torch.rand(Gn, Cc, device=d) + 0.5
+    dfeat = torch.randn(Bp, Cc, device=d)
+    # sv_bn_bwd_apply: 2 groups, 2 branches, 1 536 replicas per group
+    Mb, Cb, R = 4096, 64, 1536
+    xb = torch.randn(Gn, Mb, Cb, device=d).to(torch.bfloat16)
+    g1, g2 = (torch.randn(Gn, Mb, Cb, device=d).to(torch.bfloat16) for _ in range(2))
+    bmean, brstd = torch.randn(Gn, Cb, device=d) * 0.1, torch.rand(Gn, Cb, device=d) + 0.5
+    bs1, bs2 = (torch.randn(Gn, R, 2 * Cb, device=d) for _ in range(2))
+    gam1, gam2 = torch.rand(Cb, device=d) + 0.5, torch.rand(Cb, device=d) + 0.5
+
+    def run(det):
+        with L.options(deterministic=int(det)):
+            cs = torch.full((N,), 0.5, device=d)
+            L.call("sv_colsum", L.SV_BF16, p(y), M, N, N, p(cs), st())
+            out3, oc, op = torch.zeros(3, device=d), torch.zeros(1, device=d), torch.zeros(1, device=d)
+            L.call("sv_elbo_fwd", p(x), p(xr), 3 * 32 * 32, p(mu), p(ls), p(la), B, ldc, K, 1, 1.0, p(out3), st())
+            L.call("sv_cls_fwd", p(la), p(lab), None, B, K, p(oc), st())
+            L.call("sv_post_fwd", p(mu), p(ls), p(mt), p(stt), B, ldc, p(op), st())
+            gd = torch.empty(Bp, HW, Cc, device=d, dtype=torch.bfloat16)
+            bs = torch.zeros(Gn, 2 * Cc, device=d)
+            L.call("sv_pool_bwd", L.SV_BF16, p(xp), p(sc), p(sh), 0.01, p(mn), p(rs), p(dfeat), Bp, HW, Cc, Cc, p(gd), p(bs), Gn, st())
+            br_ = (L.SvBnBranch * 2)()
+            dg = [torch.zeros(Cb, device=d) for _ in range(4)]
+            for k, (g_, b_, gm) in enumerate(((g1, bs1, gam1), (g2, bs2, gam2))):
+                br_[k].g, br_[k].bsums, br_[k].gamma, br_[k].replicas = g_.data_ptr(), b_.data_ptr(), gm.data_ptr(), R
+                br_[k].dgamma, br_[k].dbeta = dg[2 * k].data_ptr(), dg[2 * k + 1].data_ptr()
+            dx = torch.empty_like(xb)
+            L.call("sv_bn_bwd_apply", L.SV_BF16, Mb, Cb, Cb, p(xb), p(bmean), p(brstd), float(Mb), br_, 2, None, p(dx), Gn, st())
+            torch.cuda.synchronize()
+            return [cs, out3, oc, op, gd, bs, dx] + dg
+
+    ref = run(False)
+    first = run(True)
+    for _ in range(3):
+        again = run(True)
+        for a_, b_ in zip(again, first):
+            assert torch.equal(a_, b_)
+    names = ["colsum", "elbo", "cls", "post", "pool g", "pool sums", "bn dx", "dgamma1", "dbeta1", "dgamma2", "dbeta2"]
+    for nm, a_, b_ in zip(names, first, ref):
+        assert rel(a_.float(), b_.float()) < (1e-2 if nm == "bn dx" else 2e-4), nm
+    assert rel(first[0].cpu(), y.float().sum(0).cpu() + 0.5) < 1e-4
+    assert rel(first[7], bs1[:, :, Cb:].double().sum((0, 1)).float()) < 1e-4 and rel(first[8], bs1[:, :, :Cb].double().sum((0, 1)).float()) < 1e-4
 
 
 def test_rank_permutation():
