@@ -72,6 +72,10 @@ def parse():
     ap.add_argument("--wgrad-after", type=int, default=0,
                     help="experiment: 1 = a body layer's weight gradient (side stream) starts when its data gradient has finished "
                          "instead of beside it (use with --pair-blocks 0)")
+    ap.add_argument("--flag-fork", type=int, default=1, help="0: event forks for the paired weight gradients instead of the start signal")
+    ap.add_argument("--fork-every", type=int, default=0, help="weight gradients per side-stream fork (0 = the engine's default)")
+    ap.add_argument("--light-fork", type=int, default=1,
+                    help="0: the side-stream forks of the backward use ordinary events (system-scope fence) instead of sv_stream_fork's")
     ap.add_argument("--deterministic", type=int, default=0,
                     help="1: SV_OPT_DETERMINISTIC (fixed summation order everywhere: bit-reproducible steps; what it costs)")
     ap.add_argument("--dry-run", action="store_true",
@@ -540,6 +544,10 @@ def main():
     if a.pair_blocks >= 0:
         model._engine.pair_blocks = a.pair_blocks
     model._engine.wgrad_after = bool(a.wgrad_after)
+    model._engine.light_fork = bool(a.light_fork)
+    model._engine.flag_fork = bool(a.flag_fork)
+    if a.fork_every:
+        model._engine.fork_every = a.fork_every
     dmode = False if not multi else ("bucketed" if a.allreduce == "bucketed" else True)
 
     mode = a.graph if a.graph is not None else (-1 if a.scaling == "strong" else 0)
@@ -617,6 +625,9 @@ def main():
         dist.all_reduce(lo, op=dist.ReduceOp.MIN)
         lam_equal = bool(torch.equal(hi, lo))
         assert lam_equal, "ranks disagree on the mixup coefficients: max %s, min %s" % (hi.tolist(), lo.tolist())
+    # the device-side forks of the backward (sv_igemm_args::start_flag): a wait that gave up means a weight gradient ran early
+    n_to = L.lib().sv_flag_timeouts()
+    assert n_to == 0, "%d side-stream waits timed out: the timed steps are not valid" % n_to
     images = 2 * B * world * a.steps
     headline = a.net == "wideresnet-28-2" and K == 10 and a.batch == 512
     metric = "images/sec/step WRN-28-2 SHOT-VAE CIFAR-10 bs512" if headline else \

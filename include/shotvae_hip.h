@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define SV_ABI_VERSION 4
+#define SV_ABI_VERSION 5
 
 enum { SV_F32 = 0, SV_BF16 = 1 };
 enum { SV_OK = 0, SV_E_ARG = -1, SV_E_SHAPE = -2, SV_E_HIP = -3 };
@@ -107,6 +107,14 @@ typedef struct {
     float fold_eps;
     int32_t fold_replicas;
     int32_t reserved1;
+    /* ABI 5: start signal.  start_flag != NULL: the first block of the launch stores start_value to *start_flag (device
+       memory, 4 bytes) as soon as it starts -- i.e. when everything enqueued on the stream before this launch has completed.
+       A second stream that waits for the value (sv_stream_wait_flag) is thereby forked off IN FRONT of this launch without
+       an event in this stream's queue: the weight gradient beside its data gradient (an event record costs the recording
+       queue ~6 us of idle time in front of the next kernel on MI355X, 34 times per step).                                  */
+    uint32_t* start_flag;
+    uint32_t start_value;
+    int32_t reserved2;
 } sv_igemm_args;
 
 int sv_igemm(const sv_geom* g, int dtype, const sv_igemm_args* a, void* stream);
@@ -462,6 +470,21 @@ enum { SV_K_CONV3X3 = 1, SV_K_CONV3X3P = 2, SV_K_CONV3X3M = 4, SV_K_CONV3X3W = 8
        SV_K_WGRAD3X3 = 32, SV_K_WGRAD3X3W = 64, SV_K_IGEMM_KV2 = 128, SV_K_HALO = 256, SV_K_HALOP = 512, SV_K_HWGRAD = 1024, SV_K_IGEMM_BIG = 2048, SV_K_WGRAD_WIDE = 4096, SV_K_IGEMM_ALIGNED = 8192, SV_K_IGEMM_DMA = 16384, SV_K_WGRAD_INCR = 32768, SV_K_WGRAD3X3M = 65536, SV_K_WGRAD3X3Q = 131072 };
 int sv_set_option(int key, int value);
 int sv_get_option(int key);          /* -1 for an unknown key */
+
+/* Stream fork: everything enqueued on `from` so far happens-before whatever is enqueued on `to` afterwards (the step's weight
+ * gradients run on a side stream beside the data gradients).  hipEventRecord + hipStreamWaitEvent on an event from a pool the
+ * library owns; light != 0 creates the events with hipEventDisableSystemFence: the two streams are on one device, the
+ * system-scope release an ordinary event performs in `from` (cache writeback + an idle gap in front of the next kernel, ~6 us per
+ * fork on MI355X) is not needed for them.  Works under stream capture (the record becomes a graph edge).                  */
+int sv_stream_fork(void* from, void* to, int light);
+/* The device-side form of the fork (sv_igemm_args::start_flag).  sv_stream_flag_next: the flag word the library keeps for
+ * `stream` (device memory, allocated and zeroed at the first call -- not inside a stream capture) and the next value of its
+ * sequence; the caller passes both to the launch that is to signal and to sv_stream_wait_flag on the other stream.
+ * sv_stream_wait_flag: enqueues a one-wave kernel on `stream` that returns once (int32)(*flag - value) >= 0; it gives up after
+ * ~3 s (a signalling launch that never ran) and counts that in sv_flag_timeouts() (reads a device word: synchronises).      */
+int sv_stream_flag_next(void* stream, uint32_t** flag, uint32_t* value);
+int sv_stream_wait_flag(void* stream, const uint32_t* flag, uint32_t value);
+int sv_flag_timeouts(void);
 
 int sv_version(void);
 const char* sv_last_error(void);

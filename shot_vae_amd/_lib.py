@@ -38,7 +38,7 @@ class SvIgemmArgs(C.Structure):
                 ("replicas", C.c_int32), ("groups", C.c_int32), ("block_budget", C.c_int32), ("flags", C.c_int32), ("sparse_out", C.c_int32), ("reserved0", C.c_int32),
                 ("fold_stats", C.c_void_p), ("fold_gamma", C.c_void_p), ("fold_beta", C.c_void_p), ("fold_mean", C.c_void_p),
                 ("fold_rstd", C.c_void_p), ("fold_count", C.c_float), ("fold_eps", C.c_float), ("fold_replicas", C.c_int32),
-                ("reserved1", C.c_int32)]
+                ("reserved1", C.c_int32), ("start_flag", C.c_void_p), ("start_value", C.c_uint32), ("reserved2", C.c_int32)]
 
 
 class SvWgradArgs(C.Structure):
@@ -142,6 +142,10 @@ _PROTOS = {
     "sv_debug_conv_chunk_program": [C.POINTER(C.c_int), C.POINTER(C.c_int)],
     "sv_set_option": [I, I],
     "sv_get_option": [I],
+    "sv_stream_fork": [P, P, I],
+    "sv_stream_flag_next": [P, P, P],
+    "sv_stream_wait_flag": [P, P, C.c_uint32],
+    "sv_flag_timeouts": [],
     "sv_version": [],
 }
 OPT_DISABLE_MASK, OPT_WIDE_MIN_BLOCKS, OPT_HALO_ALL, OPT_PERSISTENT_BLOCKS, OPT_DETERMINISTIC, OPT_ENABLE_MASK = 0, 1, 2, 3, 4, 5

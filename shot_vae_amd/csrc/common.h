@@ -198,6 +198,11 @@ bool sv_in_query();                    // the calling thread is inside sv_igemm_
 void sv_fold_begin(const sv_geom* g, const sv_igemm_args* a, void* stream);
 void sv_fold_end();
 bool sv_fold_claim(bool can);
+// sv_igemm_args::start_flag: the first block of every kernel of the family announces its start (see shotvae_hip.h)
+__device__ __forceinline__ void sv_start_signal(const sv_igemm_args& a) {
+    if (a.start_flag && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
+        __hip_atomic_store(a.start_flag, a.start_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 #define SV_LAUNCH_GATE(grid_x, a)                                \
     do {                                                         \
         int gate_rc_ = SV_OK;                                    \

@@ -30,6 +30,7 @@ constexpr int LDC = CK + 16;    // LDS pixel / weight-row stride (elements): 96 
 template <typename T, int NT, int WLOG>
 __global__ __launch_bounds__(256) void conv3x3_kernel(const sv_geom g, const sv_igemm_args_g A) {
     const sv_igemm_args& a = A.g[blockIdx.y];
+    sv_start_signal(a);
     typedef typename V8<T>::type V;
     constexpr int W = 1 << WLOG, TR = 128 / W, WP = W + 2;
     constexpr int HP = (TR + 2) * WP;           // halo pixels
@@ -190,6 +191,7 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const sv_geom g, const sv_
 template <typename T, int WLOG, int CCH, int MODE>      // CCH = Cin / 32
 __global__ __launch_bounds__(256, SV_C3P_WAVES) void conv3x3p_kernel(const sv_geom g, const sv_igemm_args_g A, int tiles_per) {
     const sv_igemm_args& a = A.g[blockIdx.y];
+    sv_start_signal(a);
     typedef typename V8<T>::type V;
     typedef typename V4<T>::type Q;
     constexpr int NT = 2, BN = 32;
@@ -464,6 +466,7 @@ __global__ __launch_bounds__(256, SV_C3P_WAVES) void conv3x3p_kernel(const sv_ge
 template <typename T, int NT, int WLOG, int PT>
 __global__ __launch_bounds__(256) void conv3x3m_kernel(const sv_geom g, const sv_igemm_args_g A) {
     const sv_igemm_args& a = A.g[blockIdx.y];
+    sv_start_signal(a);
     typedef typename V8<T>::type V;
     typedef typename V4<T>::type Q;
     static_assert(PT == 2 || PT == 4, "");

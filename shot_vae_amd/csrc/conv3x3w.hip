@@ -88,6 +88,7 @@ struct WCfg {
 template <int NF, int WLOG, bool REV, int MODE>
 __global__ __launch_bounds__(256, 2) void conv3x3w_kernel(const sv_geom g, const sv_igemm_args_g AG) {
     const sv_igemm_args& a = AG.g[blockIdx.y];
+    sv_start_signal(a);
     using C = WCfg<NF, WLOG>;
     constexpr int BN = C::BN, W = C::W, TR = C::TR, WP = C::WP, HH = C::HH, SEG = C::SEG, HI = C::HI, WI = C::WI;
     constexpr int HS = C::HS, HB = C::HB, WS = C::WS, WBUF = C::WBUF, SWS = C::SWS;

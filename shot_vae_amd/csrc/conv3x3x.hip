@@ -212,6 +212,7 @@ struct XCfg {
 template <int WLOG, bool REV, int MODE>
 __global__ __launch_bounds__(256, 1) void conv3x3x_kernel(const sv_geom g, const sv_igemm_args_g AG) {
     const sv_igemm_args& a = AG.g[blockIdx.y];
+    sv_start_signal(a);
     using C = XCfg<WLOG>;
     constexpr int NF = C::NF, BN = C::BN, W = C::W, TR = C::TR, WP = C::WP, HH = C::HH, SEG = C::SEG;
     constexpr int HS = C::HS, HB = C::HB, WBUF = C::WBUF, SWS = C::SWS, HI = X_HI, HSTEPS = X_HSTEPS;

@@ -140,6 +140,7 @@ __global__ __launch_bounds__(256) void halo_kernel(const sv_geom g, const sv_ige
     constexpr int LDC = CC + 16;                // LDS pixel stride (elements): 96 B / 64 B rows
     constexpr int TPK = 32 / CC;                // taps per 32-deep k step
     const sv_igemm_args& a = AG.g[blockIdx.y];
+    sv_start_signal(a);
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     T* halo = reinterpret_cast<T*>(smem);                       // [HP][LDC]
@@ -422,6 +423,7 @@ __global__ __launch_bounds__(256, OCC) void halop_kernel(const sv_geom g, const 
     constexpr int BN = 16 * NT;
     constexpr int TPK = 32 / CC;
     const sv_igemm_args& a = AG.g[blockIdx.y];
+    sv_start_signal(a);
     const int Cin = g.Cin, VPP = Cin / 8, NCK = Cin / CC;       // NCK = 1 or 2 (Cin <= 64)
     const int ncklog = NCK > 1 ? 1 : 0;
     const int LDC = Cin + 16;                                   // LDS pixel stride (elements)

@@ -40,6 +40,7 @@ constexpr int BK = 32;
 template <typename T, int NT, int KV, int MS, bool AL>
 __global__ __launch_bounds__(256, MS == 4 ? 2 : 1) void igemm_kernel(const sv_geom g, const sv_igemm_args_g A) {
     const sv_igemm_args& a = A.g[blockIdx.y];
+    sv_start_signal(a);
     typedef typename V8<T>::type V;
     typedef typename V4<T>::type Q;
     constexpr int BM = 64 * MS;
@@ -339,6 +340,7 @@ typedef const __attribute__((address_space(1))) void* ig_glb_ptr;
 template <int NT, int MS>
 __global__ __launch_bounds__(256, 2) void igemm_dma_kernel(const sv_geom g, const sv_igemm_args_g A) {
     const sv_igemm_args& a = A.g[blockIdx.y];
+    sv_start_signal(a);
     typedef bf16 T;
     typedef bf16x8 V;
     constexpr int BM = 64 * MS, BN = 16 * NT;

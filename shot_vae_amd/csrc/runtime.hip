@@ -5,6 +5,8 @@
 
 #include <vector>
 
+#include <mutex>
+
 #include "common.h"
 
 static thread_local char g_err[512] = "";
@@ -214,6 +216,80 @@ int sv_get_option(int key) {
         case SV_OPT_ENABLE_MASK: return g_enable_mask;
     }
     return -1;
+}
+
+namespace {
+constexpr int FORK_POOL = 128;
+hipEvent_t g_fork_ev[2][FORK_POOL];
+int g_fork_n[2] = {0, 0}, g_fork_i[2] = {0, 0};
+std::mutex g_fork_mu;
+}  // namespace
+int sv_stream_fork(void* from, void* to, int light) {
+    const int k = light ? 1 : 0;
+    hipEvent_t e;
+    {
+        std::lock_guard<std::mutex> lk(g_fork_mu);
+        if (g_fork_n[k] < FORK_POOL) {
+            const unsigned flags = hipEventDisableTiming | (light ? hipEventDisableSystemFence : 0u);
+            if (hipEventCreateWithFlags(&g_fork_ev[k][g_fork_n[k]], flags) != hipSuccess) return sv_check_launch("sv_stream_fork: event");
+            ++g_fork_n[k];
+        }
+        // (an event is re-recorded FORK_POOL forks later: a wait captures the record that preceded it, later records do not move it)
+        e = g_fork_ev[k][g_fork_i[k]++ % g_fork_n[k]];
+    }
+    if (hipEventRecord(e, (hipStream_t)from) != hipSuccess || hipStreamWaitEvent((hipStream_t)to, e, 0) != hipSuccess)
+        return sv_check_launch("sv_stream_fork");
+    return SV_OK;
+}
+
+// ---- device-side fork: flag words + the kernel that waits for one --------------------------------------------------------
+namespace {
+constexpr int FLAG_WORDS = 1024;                 // word 0: time-out counter; 1..: one flag per stream
+uint32_t* g_flags = nullptr;
+struct FlagSlot { void* stream; uint32_t next; };
+std::vector<FlagSlot> g_flag_slots;
+
+__global__ void wait_flag_kernel(const uint32_t* flag, uint32_t value, uint32_t* timeouts) {
+    if (threadIdx.x != 0) return;
+    const uint64_t t0 = wall_clock64();          // 100 MHz
+    while ((int32_t)(__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - value) < 0) {
+        __builtin_amdgcn_s_sleep(32);
+        if (wall_clock64() - t0 > 300000000ull) {        // ~3 s: the signalling launch never ran
+            atomicAdd(timeouts, 1u);
+            break;
+        }
+    }
+}
+}  // namespace
+int sv_stream_flag_next(void* stream, uint32_t** flag, uint32_t* value) {
+    SV_REQUIRE(flag && value, SV_E_ARG, "sv_stream_flag_next: null argument");
+    std::lock_guard<std::mutex> lk(g_fork_mu);
+    if (!g_flags) {
+        void* p = nullptr;
+        if (hipMalloc(&p, FLAG_WORDS * sizeof(uint32_t)) != hipSuccess || hipMemset(p, 0, FLAG_WORDS * sizeof(uint32_t)) != hipSuccess)
+            return sv_check_launch("sv_stream_flag_next: flag memory (first use inside a stream capture?)");
+        g_flags = static_cast<uint32_t*>(p);
+    }
+    size_t i = 0;
+    while (i < g_flag_slots.size() && g_flag_slots[i].stream != stream) ++i;
+    if (i == g_flag_slots.size()) {
+        SV_REQUIRE((int)i + 1 < FLAG_WORDS, SV_E_ARG, "sv_stream_flag_next: more than %d streams", FLAG_WORDS - 1);
+        g_flag_slots.push_back(FlagSlot{stream, 0u});
+    }
+    *flag = g_flags + 1 + i;
+    *value = ++g_flag_slots[i].next;
+    return SV_OK;
+}
+int sv_stream_wait_flag(void* stream, const uint32_t* flag, uint32_t value) {
+    SV_REQUIRE(flag && g_flags, SV_E_ARG, "sv_stream_wait_flag: no flag (sv_stream_flag_next first)");
+    hipLaunchKernelGGL(wait_flag_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, flag, value, g_flags);
+    return sv_check_launch("sv_stream_wait_flag");
+}
+int sv_flag_timeouts(void) {
+    if (!g_flags) return 0;
+    uint32_t n = 0;
+    if (hipMemcpy(&n, g_flags, sizeof(n), hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    return (int)n;
 }
 
 int sv_version(void) { return SV_ABI_VERSION; }

@@ -285,6 +285,7 @@ class Engine:
         # still gives the paired launches the block budgets they run with in the timed, two-stream step
         self.prof_paired = False
         self._side_keep = {}          # main stream -> operands of the weight gradients in flight on its side stream
+        self._pending_wgrads = []     # weight gradients waiting for the next fork (fork_every)
         for b in p.bns:
             self.bufs[b.rv_off: b.rv_off + b.C] = 1.0
 
@@ -452,6 +453,8 @@ class Engine:
                 a.bsums, a.replicas = ex[6:]
         if tag:
             self._tag(tag, g, (residual is not None) + (ex is not None), groups=groups)
+        if self._start_signal is not None:       # (see _wgrad_async: this launch forks the side stream when it starts)
+            (a.start_flag, a.start_value), self._start_signal = self._start_signal, None
         L.call("sv_igemm", C.byref(g), self.code, C.byref(a), self._stream())
 
     _ws_elems = 16 * 1024 * 1024       # 64 MiB of fp32 partial-slab workspace for sv_wgrad
@@ -471,6 +474,11 @@ class Engine:
     sparse_shortcut_grad = True      # stride-2 1x1 shortcuts: data gradient written / read at the even positions only
     materialize_decoder_act = True   # BatchNorm + ReLU of the first decoder layers' inputs as a pass of its own (see forward)
     materialize_max_hin = 4          # ... for the layers whose input map is at most this large
+    light_fork = True                # fork events without the system-scope fence (sv_stream_fork)
+    fork_every = 1                   # weight gradients per side-stream fork
+    flag_fork = True                 # paired launches: the data gradient's start signal forks the side stream (no event)
+    _start_signal = None
+    _pending_wgrads = ()
     wgrad_after = False              # (experiment, tools: fork the weight gradient behind its data gradient instead of beside it)
     fold_bn = True                   # BatchNorm finalisation folded into the consuming sv_igemm launch (sv_igemm_args::fold_*)
 
@@ -498,24 +506,59 @@ class Engine:
             self._wgrad(g, x, pro, dy, dw_ptr, tag, groups, budget)
             return then() if then is not None else None
         cur, side = self._side()
-        ev = torch.cuda.Event()
-        if self.wgrad_after:          # experiment: the weight gradient starts when the paired data gradient has FINISHED
+        # `fork_every` weight gradients share one fork: every fork is a marker in the main stream's queue that costs it ~6 us of
+        # idle time in front of the next kernel (tools/probes/step_list.py: a gap before every data gradient)
+        self._pending_wgrads.append((g, x, pro, dy, dw_ptr, tag, groups, budget))
+        if len(self._pending_wgrads) < self.fork_every:
+            return then() if then is not None else None
+        if self.flag_fork and then is not None and not self.wgrad_after and len(self._pending_wgrads) == 1:
+            # device-side fork: the paired main-stream launch (`then`, an sv_igemm) announces its own START through a flag word
+            # (sv_igemm_args::start_flag) -- everything this weight gradient depends on has completed by then -- and the side
+            # stream waits for the flag: no event, no marker in the main stream's queue
+            flag, value = C.c_void_p(), C.c_uint32()
+            L.call("sv_stream_flag_next", _vp(cur.cuda_stream), C.byref(flag), C.byref(value))
+            self._start_signal = (flag.value, value.value)
+            try:
+                out = then()
+            finally:
+                armed, self._start_signal = self._start_signal, None
+            if armed is None:          # consumed by the launch
+                L.call("sv_stream_wait_flag", _vp(side.cuda_stream), flag, value)
+                return self._issue_pending(cur, side, out)
+            # (`then` launched nothing that could carry the signal: the ordinary fork, behind it)
+            L.call("sv_stream_fork", _vp(cur.cuda_stream), _vp(side.cuda_stream), int(self.light_fork))
+            return self._issue_pending(cur, side, out)
+        return self._flush_wgrads(cur, side, then)
+
+    def _flush_wgrads(self, cur, side, then=None):
+        """Fork the side stream off the main stream here and issue the pending weight gradients on it.  The fork is an event
+        of the library's pool WITHOUT the system-scope fence of an ordinary event (sv_stream_fork): both streams are on this
+        device."""
+        if self.wgrad_after:          # experiment: the weight gradients start when the paired data gradient has FINISHED
             out = then() if then is not None else None
-            ev.record(cur)
+            L.call("sv_stream_fork", _vp(cur.cuda_stream), _vp(side.cuda_stream), int(self.light_fork))
         else:
-            ev.record(cur)
+            L.call("sv_stream_fork", _vp(cur.cuda_stream), _vp(side.cuda_stream), int(self.light_fork))
             out = then() if then is not None else None
-        side.wait_event(ev)
+        return self._issue_pending(cur, side, out)
+
+    def _issue_pending(self, cur, side, out=None):
         with torch.cuda.stream(side):
-            self._wgrad(g, x, pro, dy, dw_ptr, tag, groups, budget)
+            for (g, x, pro, dy, dw_ptr, tag, groups, budget) in self._pending_wgrads:
+                self._wgrad(g, x, pro, dy, dw_ptr, tag, groups, budget)
         # the operands stay referenced until the streams are joined at the end of backward (no record_stream bookkeeping
         # per tensor: two allocator calls per weight gradient on the host's critical path)
-        self._side_keep.setdefault(cur.cuda_stream, []).append((x, dy))
+        keep = self._side_keep.setdefault(cur.cuda_stream, [])
+        for w in self._pending_wgrads:
+            keep.append((w[1], w[3]))
+        self._pending_wgrads = []
         return out
 
     def _join_side(self):
         if self.wgrad_side_stream and self.prof_tags is None and not torch.cuda.is_current_stream_capturing():
             cur, side = self._side()
+            if self._pending_wgrads:
+                self._flush_wgrads(cur, side)
             cur.wait_stream(side)
             # the side stream's operands may be released now: the main stream, on which the allocator will hand their
             # memory out again, is ordered behind everything the side stream did
@@ -832,6 +875,7 @@ class Engine:
             if torch.cuda.is_available():
                 torch.cuda.synchronize()
             self._side_keep.clear()
+            self._pending_wgrads = []
             raise
 
     def _backward(self, f, d_rec, d_mu, d_ls, d_la, own_grads=False):
@@ -944,6 +988,8 @@ class Engine:
         # (finish() falls back to the single all-reduce if no decoder backward follows).
         if self.bucket_hook is not None and Gd > 0:
             hook, self.bucket_hook = self.bucket_hook, None
+            if self._pending_wgrads:       # (fork_every > 1: the decoder's last weight gradients must be ISSUED before the hook)
+                self._flush_wgrads(*self._side())
             hook()
         # ---- heads + pool ---------------------------------------------------------------------------------------
         dfeat = torch.empty(Bt, p.cfeat, dtype=torch.float32, device=dev)

@@ -26,13 +26,13 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), "missing export " + n
     assert set(names) == set(L.EXPORTS), set(names) ^ set(L.EXPORTS)
-    assert L.lib().sv_version() == 4
+    assert L.lib().sv_version() == 5
 
 
 def test_struct_layout_matches_header():
     assert ctypes.sizeof(L.SvPhase) == 72
     assert ctypes.sizeof(L.SvGeom) == 72 + 4 * 72
-    assert ctypes.sizeof(L.SvIgemmArgs) == 26 * 8
+    assert ctypes.sizeof(L.SvIgemmArgs) == 28 * 8
     assert ctypes.sizeof(L.SvWgradArgs) == 10 * 8
     assert ctypes.sizeof(L.SvBnBranch) == 48
     assert ctypes.sizeof(L.SvRepackJob) == 64
@@ -163,7 +163,7 @@ sys.path.insert(0, %r)
 from shot_vae_amd import _lib as L
 from shot_vae_amd.engine import Plan
 lib = L.lib()
-assert lib.sv_version() == 4
+assert lib.sv_version() == 5
 n_ok = n_err = 0
 for net, K in (("wideresnet-28-2", 10), ("wideresnet-28-10", 100), ("wideresnet-10-1", 10)):
     plan = Plan(net, K=K)

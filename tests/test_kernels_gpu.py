@@ -1060,6 +1060,47 @@ def test_deterministic_two_pass_reductions():
     assert rel(first[7], bs1[:, :, Cb:].double().sum((0, 1)).float()) < 1e-4 and rel(first[8], bs1[:, :, :Cb].double().sum((0, 1)).float()) < 1e-4
 
 
+@pytest.mark.parametrize("case", [(64, 32, 32, 32, 3, 1, 1), (64, 128, 128, 8, 3, 1, 1), (32, 32, 64, 32, 3, 2, 1), (32, 32, 64, 32, 1, 2, 0),
+                                  (64, 256, 128, 4, 3, 1, 1), (16, 160, 160, 32, 3, 1, 1)])
+def test_start_signal_forks_a_second_stream(case):
+    """sv_igemm_args::start_flag / sv_stream_wait_flag (ABI 5): the first block of every kernel of the sv_igemm family stores
+    the value when it starts, i.e. after everything enqueued before it on its stream -- a second stream that waits for the flag
+    sees that work's results without an event between the streams.  Stream A: a long producer chain, then the signalling
+    convolution; stream B: the wait, then a copy of the producer's result.  Every dispatch target of the table (persistent
+    narrow / wide / 160-channel 3x3, stride-2 and 1x1 LDS-halo kernels, the generic gather GEMM) is one case."""
+    B, Cin, N, H, k, stride, pad = case
+    d = dev()
+    torch.manual_seed(3)
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    g = G.conv_like(B, H, H, Cin, N, k, stride, pad)
+    Ho = (H + 2 * pad - k) // stride + 1
+    w = bq(torch.randn(N, k * k, Cin) / (k * k * Cin) ** 0.5, "bf16")
+    wp = repack(w, g, False, "bf16")
+    x = torch.randn(B, H, H, Cin, device=d).to(torch.bfloat16)
+    out = torch.empty(B, Ho, Ho, N, device=d, dtype=torch.bfloat16)
+    big = torch.zeros(64 * 1024 * 1024, device=d)
+    got = torch.empty_like(big)
+    torch.cuda.synchronize()
+    for rep in range(3):
+        flag, value = C.c_void_p(), C.c_uint32()
+        L.call("sv_stream_flag_next", C.c_void_p(sa.cuda_stream), C.byref(flag), C.byref(value))
+        with torch.cuda.stream(sa):
+            for _ in range(6):
+                big.add_(1.0)                    # ~2 ms of producer work in front of the signalling launch
+            a = L.SvIgemmArgs()
+            a.x, a.w, a.out = x.data_ptr(), wp.data_ptr(), out.data_ptr()
+            a.start_flag, a.start_value = flag.value, value.value
+            L.call("sv_igemm", C.byref(g), L.SV_BF16, C.byref(a), C.c_void_p(sa.cuda_stream))
+        L.call("sv_stream_wait_flag", C.c_void_p(sb.cuda_stream), flag, value)
+        with torch.cuda.stream(sb):
+            got.copy_(big)
+        torch.cuda.synchronize()
+        assert float(got.min()) == 6.0 * (rep + 1) and float(got.max()) == 6.0 * (rep + 1)
+    assert L.lib().sv_flag_timeouts() == 0
+    ref = F.conv2d(nchw(x.float().cpu()), w.reshape(N, k, k, Cin).permute(0, 3, 1, 2), None, stride, pad)
+    assert rel(nchw(out.float().cpu()), ref) < DT["bf16"][2]
+
+
 def test_rank_permutation():
     """sv_rank_permutation: perm = argsort of the keys (ties: the lower index first), several batches per launch, sizes up
     to a full minibatch."""

@@ -1,0 +1,8 @@
+R=/root/repo
+lb() { python3 "$R/tools/layer_bench.py" "$@" 2>/dev/null | grep "of bf16" | cut -c1-110; }
+for m in 0 256 16384 16640 2048 8192 128; do
+echo "## disable=$m"
+SV_BENCH_DISABLE=$m SV_BENCH_T=1 lb 2048 512 2 256
+SV_BENCH_DISABLE=$m SV_BENCH_T=1 lb 2048 256 4 128
+SV_BENCH_DISABLE=$m SV_BENCH_T=1 lb 2048 128 8 64
+done
