@@ -232,7 +232,7 @@ def extras(S):
                               encoder conv at batch 512" (0.2416 TFLOP per launch at B = 512, <= 242 us to pass)
       headline_variants       the headline network through the OTHER paths a real epoch takes: the ragged last labelled batch
                               (B_l = 416, main_shot_vae.py:280), --om, the sequential (reference-order, autograd) step, the
-                              fp32-operand parity mode
+                              bit-reproducible deterministic mode, the fp32-operand parity mode
       per_rank_batch_table    single-GPU ms/step at the per-rank batches of a strong-scaling run (512 / N per loader), eager issue
                               and hipGraph replay: the per-rank efficiency curve that bounds the strong-scaling result
       config5                 BASELINE configs[4]: one smooth-ELBO iteration of svhn_VAE at B = 1024 per loader"""
@@ -265,6 +265,11 @@ def extras(S):
     t, _ = _time_ms(lambda: S.train_step(model, elbo, cls, opt, il, ll, iu, sch), 3, 10)
     var["sequential"] = {"ms_per_step": round(t, 3), "images_per_s": round(1024 / t * 1e3, 1),
                          "schedule": "the reference's order through autograd: 4 forwards, 2 backward() calls, one stream + side stream"}
+    from shot_vae_amd import _lib as L_
+    with L_.options(deterministic=1):
+        t, _ = _time_ms(lambda: train_step_grouped(model, elbo, cls, opt, il, ll, iu, sch), 3, 10)
+    var["deterministic_mode"] = {"ms_per_step": round(t, 3), "images_per_s": round(1024 / t * 1e3, 1),
+                                 "note": "SV_OPT_DETERMINISTIC: every accumulation in a fixed order, two runs agree bit for bit"}
     del model, opt
     torch.cuda.empty_cache()
     model, elbo, cls, opt, sch, il, ll, iu = _shot_setup(S, net, K, 512, 512, dtype="fp32")

@@ -481,7 +481,10 @@ int sv_stream_fork(void* from, void* to, int light);
  * `stream` (device memory, allocated and zeroed at the first call -- not inside a stream capture) and the next value of its
  * sequence; the caller passes both to the launch that is to signal and to sv_stream_wait_flag on the other stream.
  * sv_stream_wait_flag: enqueues a one-wave kernel on `stream` that returns once (int32)(*flag - value) >= 0; it gives up after
- * ~3 s (a signalling launch that never ran) and counts that in sv_flag_timeouts() (reads a device word: synchronises).      */
+ * ~3 s (a signalling launch that never ran) and counts that in sv_flag_timeouts() (reads a device word: synchronises).
+ * NOT for environments that serialise kernel dispatch across streams (rocprofv3 --pmc, AMD_SERIALIZE_KERNEL,
+ * HIP_LAUNCH_BLOCKING): the waiting kernel may then be dispatched in front of the one it waits for -- fork with
+ * sv_stream_fork there (the Python host layer checks the environment).                                                     */
 int sv_stream_flag_next(void* stream, uint32_t** flag, uint32_t* value);
 int sv_stream_wait_flag(void* stream, const uint32_t* flag, uint32_t value);
 int sv_flag_timeouts(void);

@@ -871,7 +871,7 @@ __global__ __launch_bounds__(128) void sample_bwd_kernel(const T* dlatent, const
 // ---------------------------------------------------------------------------------------- losses
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
 
-__global__ __launch_bounds__(256) void elbo_fwd_kernel(const float* x, const float* xr, int64_t n_img,
+__device__ __forceinline__ void elbo_fwd_dev(const float* x, const float* xr, int64_t n_img,
                                                        const float* mu, const float* ls, const float* la,
                                                        int B, int ldc, int K, int bce, float x_sigma,
                                                        float log_prior, float* out3, int ostride) {
@@ -913,8 +913,12 @@ __global__ __launch_bounds__(256) void elbo_fwd_kernel(const float* x, const flo
     kd = block_sum(kd, red);
     if (threadIdx.x == 0 && kd != 0.f) atomicAdd(out3 + 2, kd / (float)B);
 }
+__global__ __launch_bounds__(256) void elbo_fwd_kernel(const float* x, const float* xr, int64_t n_img,
+                                                       const float* mu, const float* ls, const float* la,
+                                                       int B, int ldc, int K, int bce, float x_sigma,
+                                                       float log_prior, float* out3, int ostride) { elbo_fwd_dev(x, xr, n_img, mu, ls, la, B, ldc, K, bce, x_sigma, log_prior, out3, ostride); }
 
-__global__ __launch_bounds__(256) void elbo_bwd_kernel(const float* x, const float* xr, int64_t n_img,
+__device__ __forceinline__ void elbo_bwd_dev(const float* x, const float* xr, int64_t n_img,
                                                        const float* mu, const float* ls, const float* la,
                                                        int B, int ldc, int K, int bce, float x_sigma,
                                                        float log_prior, const float* gout3, float* dxr,
@@ -938,8 +942,13 @@ __global__ __launch_bounds__(256) void elbo_bwd_kernel(const float* x, const flo
         dla[i] = c2 * expf(l) * (l - log_prior + 1.f);
     }
 }
+__global__ __launch_bounds__(256) void elbo_bwd_kernel(const float* x, const float* xr, int64_t n_img,
+                                                       const float* mu, const float* ls, const float* la,
+                                                       int B, int ldc, int K, int bce, float x_sigma,
+                                                       float log_prior, const float* gout3, float* dxr,
+                                                       float* dmu, float* dls, float* dla) { elbo_bwd_dev(x, xr, n_img, mu, ls, la, B, ldc, K, bce, x_sigma, log_prior, gout3, dxr, dmu, dls, dla); }
 
-__global__ __launch_bounds__(256) void cls_fwd_kernel(const float* pred, const float* label, const float* w,
+__device__ __forceinline__ void cls_fwd_dev(const float* pred, const float* label, const float* w,
                                                       int B, int K, float* out, int ostride) {
     __shared__ float red[4];
     out += (int64_t)blockIdx.x * ostride;
@@ -949,10 +958,13 @@ __global__ __launch_bounds__(256) void cls_fwd_kernel(const float* pred, const f
     s = block_sum(s, red);
     if (threadIdx.x == 0) atomicAdd(out, -s / (float)B);
 }
-__global__ void cls_bwd_kernel(const float* label, const float* w, int B, int K, const float* gout, float* dp) {
+__global__ __launch_bounds__(256) void cls_fwd_kernel(const float* pred, const float* label, const float* w,
+                                                      int B, int K, float* out, int ostride) { cls_fwd_dev(pred, label, w, B, K, out, ostride); }
+__device__ __forceinline__ void cls_bwd_dev(const float* label, const float* w, int B, int K, const float* gout, float* dp) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < (int64_t)B * K) dp[i] = -gout[0] * label[i] * (w ? w[i / K] : 1.f) / (float)B;
 }
+__global__ __launch_bounds__(256) void cls_bwd_kernel(const float* label, const float* w, int B, int K, const float* gout, float* dp) { cls_bwd_dev(label, w, B, K, gout, dp); }
 
 // top-k accuracy counts (main_shot_vae.py:441-447): rank of the true class among the K scores of a row = how many
 // classes score higher (ties: the lower index first, as a stable descending sort); hits[0] += rank < 1, hits[1] += rank < k
@@ -975,7 +987,7 @@ __global__ __launch_bounds__(256) void topk_hits_kernel(const float* score, cons
     if (threadIdx.x == 0) { atomicAdd(hits, h1); atomicAdd(hits + 1, hk); }
 }
 
-__global__ __launch_bounds__(256) void post_fwd_kernel(const float* mu, const float* ls, const float* mt,
+__device__ __forceinline__ void post_fwd_dev(const float* mu, const float* ls, const float* mt,
                                                        const float* st, int B, int D, float* out, int ostride) {
     __shared__ float red[4];
     out += (int64_t)blockIdx.x * ostride;
@@ -987,7 +999,9 @@ __global__ __launch_bounds__(256) void post_fwd_kernel(const float* mu, const fl
     s = block_sum(s, red);
     if (threadIdx.x == 0) atomicAdd(out, s / (float)B);
 }
-__global__ void post_bwd_kernel(const float* mu, const float* ls, const float* mt, const float* st, int B,
+__global__ __launch_bounds__(256) void post_fwd_kernel(const float* mu, const float* ls, const float* mt,
+                                                       const float* st, int B, int D, float* out, int ostride) { post_fwd_dev(mu, ls, mt, st, B, D, out, ostride); }
+__device__ __forceinline__ void post_bwd_dev(const float* mu, const float* ls, const float* mt, const float* st, int B,
                                 int D, const float* gout, float* dmu, float* dls) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t)B * D) return;
@@ -995,6 +1009,37 @@ __global__ void post_bwd_kernel(const float* mu, const float* ls, const float* m
     const float e = expf(ls[i]);
     dmu[i] = g * (mu[i] - mt[i]);
     dls[i] = g * (e - st[i]) * e;
+}
+__global__ __launch_bounds__(256) void post_bwd_kernel(const float* mu, const float* ls, const float* mt, const float* st, int B,
+                                int D, const float* gout, float* dmu, float* dls) { post_bwd_dev(mu, ls, mt, st, B, D, gout, dmu, dls); }
+
+// ---- the loss stage of a step in three launches (sv_shot_loss_step2): at ~5 us per launch the 12 reduction / gradient kernels
+//      of the stage cost more in launches than in work.  blockIdx.y selects the part; every part is the kernel above, unchanged.
+struct shot_elbo_part { const float* x; const float* xr; const float* mu; const float* ls; const float* la; int B; float* out3;
+                        const float* gout3; float* dxr; float* dmu; float* dls; float* dla; };
+struct shot_post_part { const float* la; const float* label; const float* mu; const float* ls; const float* mt; const float* st; int B;
+                        float* out_cls; float* out_post; const float* g_cls; const float* g_post; float* dla; float* dmu; float* dls; };
+struct shot_parts { shot_elbo_part e[2]; shot_post_part q[2]; int64_t n_per_img; int D, K, bce; float x_sigma, log_prior; };
+
+__global__ __launch_bounds__(256) void shot_elbo_fwd2_kernel(const shot_parts P) {
+    const shot_elbo_part& e = P.e[blockIdx.y];
+    elbo_fwd_dev(e.x, e.xr, P.n_per_img * e.B, e.mu, e.ls, e.la, e.B, P.D, P.K, P.bce, P.x_sigma, P.log_prior, e.out3, 0);
+}
+__global__ __launch_bounds__(256) void shot_post_fwd4_kernel(const shot_parts P) {
+    const shot_post_part& q = P.q[blockIdx.y >> 1];
+    if (blockIdx.y & 1) post_fwd_dev(q.mu, q.ls, q.mt, q.st, q.B, P.D, q.out_post, 0);
+    else cls_fwd_dev(q.la, q.label, nullptr, q.B, P.K, q.out_cls, 0);
+}
+__global__ __launch_bounds__(256) void shot_bwd6_kernel(const shot_parts P) {
+    const int y = blockIdx.y;
+    if (y < 2) {
+        const shot_elbo_part& e = P.e[y];
+        elbo_bwd_dev(e.x, e.xr, P.n_per_img * e.B, e.mu, e.ls, e.la, e.B, P.D, P.K, P.bce, P.x_sigma, P.log_prior, e.gout3, e.dxr, e.dmu, e.dls, e.dla);
+    } else {
+        const shot_post_part& q = P.q[(y - 2) >> 1];
+        if (y & 1) post_bwd_dev(q.mu, q.ls, q.mt, q.st, q.B, P.D, q.g_post, q.dmu, q.dls);
+        else cls_bwd_dev(q.label, nullptr, q.B, P.K, q.g_cls, q.dla);
+    }
 }
 
 // random permutations from uniform keys: perm[r] = i where r = rank of key i among the n keys of its batch (ties: the lower
@@ -2033,6 +2078,36 @@ int sv_shot_loss_step2(const sv_shot_loss_args2* a, void* stream) {
     float* mx_alpha = lab_mix + (int64_t)Bl * K;
     int rc;
 #define SV_TRY(call) do { rc = (call); if (rc != SV_OK) return rc; } while (0)
+    if (!sv_deterministic()) {
+        // three launches for the twelve reduction / gradient kernels of the stage (+ targets and composition)
+        SvProfScope prof_scope(stream);
+        shot_parts P;
+        P.n_per_img = n; P.D = D; P.K = K; P.bce = a->bce; P.x_sigma = a->x_sigma; P.log_prior = log_prior_f32(K);
+        const float* img[2] = {a->image_l, a->image_u};
+        const int Bs[2] = {Bl, Bu};
+        for (int i = 0; i < 2; ++i) {
+            shot_elbo_part& e = P.e[i];
+            e.x = img[i]; e.xr = a->rec[i]; e.mu = a->mu[i]; e.ls = a->ls[i]; e.la = a->la[i]; e.B = Bs[i]; e.out3 = a->terms + 3 * i;
+            e.gout3 = a->coef + 3 * i; e.dxr = a->d_rec[i]; e.dmu = a->d_mu[i]; e.dls = a->d_ls[i]; e.dla = a->d_la[i];
+            shot_post_part& q = P.q[i];
+            q.la = a->la[2 + i]; q.label = i ? mx_alpha : lab_mix; q.mu = a->mu[2 + i]; q.ls = a->ls[2 + i];
+            q.mt = i ? mx_mu : sm_mu; q.st = i ? mx_sigma : sm_sigma; q.B = Bs[i];
+            q.out_cls = a->terms + 6 + 2 * i; q.out_post = a->terms + 7 + 2 * i; q.g_cls = a->coef + 6 + 2 * i; q.g_post = a->coef + 7 + 2 * i;
+            q.dla = a->d_la[2 + i]; q.dmu = a->d_mu[2 + i]; q.dls = a->d_ls[2 + i];
+        }
+        const int Bmax = Bl > Bu ? Bl : Bu;
+        hipStream_t s_ = (hipStream_t)stream;
+        hipLaunchKernelGGL(shot_elbo_fwd2_kernel, dim3(nblocks(n * Bmax / 4, 1024, 256), 2), dim3(256), 0, s_, P);
+        SV_TRY(sv_shot_targets2(a->mu[0], a->ls[0], a->mu[1], a->ls[1], a->la[1], a->label_l, a->perm_l, a->perm_u,
+                                a->lam_l, a->lam_l_dev, a->lam_u, a->lam_u_dev, Bl, Bu, D, K, sm_mu, sm_sigma, lab_mix, mx_mu, mx_sigma, mx_alpha, stream));
+        hipLaunchKernelGGL(shot_post_fwd4_kernel, dim3(nblocks((int64_t)Bmax * D, 256, 64), 4), dim3(256), 0, s_, P);
+        SV_TRY(sv_shot_compose(a->terms, &a->sch, a->coef, stream));
+        int gx = nblocks(n * Bmax, 256, 2048);                 // (the cls / posterior parts index their elements directly)
+        const int need = (int)(((int64_t)Bmax * (D > K ? D : K) + 255) / 256);
+        if (gx < need) gx = need;
+        hipLaunchKernelGGL(shot_bwd6_kernel, dim3(gx, 6), dim3(256), 0, s_, P);
+        return sv_check_launch("sv_shot_loss_step2");
+    }
     // forward: ELBO terms of (1), (3); the targets of (2), (4); their posterior terms; the composition
     SV_TRY(sv_elbo_fwd(a->image_l, a->rec[0], n, a->mu[0], a->ls[0], a->la[0], Bl, D, K, a->bce, a->x_sigma, a->terms, stream));
     SV_TRY(sv_elbo_fwd(a->image_u, a->rec[1], n, a->mu[1], a->ls[1], a->la[1], Bu, D, K, a->bce, a->x_sigma, a->terms + 3, stream));

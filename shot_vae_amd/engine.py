@@ -14,6 +14,7 @@ Data layout in HBM
                   ([n][tap][c], k contiguous = MFMA operand order), refreshed after each optimizer step
 """
 import ctypes as C
+import os
 import math
 import re
 
@@ -228,6 +229,21 @@ class Plan:
                 out.append((b.key + ".running_var", "rv", b))
                 out.append((b.key + ".num_batches_tracked", "nbt", b))
         return out
+
+
+_SERIALISED = None
+
+
+def _dispatch_serialised():
+    """True when the environment serialises kernel dispatch across streams (rocprofv3 --pmc counter collection,
+    AMD_SERIALIZE_KERNEL, HIP_LAUNCH_BLOCKING): a kernel that WAITS for another stream's kernel to start (the device-side fork,
+    sv_stream_wait_flag) would then sit in front of it until its time-out -- those runs fork with events."""
+    global _SERIALISED
+    if _SERIALISED is None:
+        e = os.environ
+        _SERIALISED = (e.get("ROCPROF_COUNTER_COLLECTION", "0") not in ("", "0") or bool(e.get("ROCPROF_COUNTERS")) or
+                       e.get("AMD_SERIALIZE_KERNEL", "0") not in ("", "0") or e.get("HIP_LAUNCH_BLOCKING", "0") not in ("", "0"))
+    return _SERIALISED
 
 
 def _vp(x):
@@ -511,7 +527,7 @@ class Engine:
         self._pending_wgrads.append((g, x, pro, dy, dw_ptr, tag, groups, budget))
         if len(self._pending_wgrads) < self.fork_every:
             return then() if then is not None else None
-        if self.flag_fork and then is not None and not self.wgrad_after and len(self._pending_wgrads) == 1:
+        if self.flag_fork and not _dispatch_serialised() and then is not None and not self.wgrad_after and len(self._pending_wgrads) == 1:
             # device-side fork: the paired main-stream launch (`then`, an sv_igemm) announces its own START through a flag word
             # (sv_igemm_args::start_flag) -- everything this weight gradient depends on has completed by then -- and the side
             # stream waits for the flag: no event, no marker in the main stream's queue

@@ -82,7 +82,8 @@ def step_pass(counter, outdir):
     d = os.path.join(outdir, "step_" + counter)
     cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--",
            "python3", os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-roofline",
-           "--no-extras"]
+           "--no-extras", "--flag-fork", "0"]      # (counter collection serialises dispatch: a kernel that waits for another
+                                                    #  stream's kernel to start would sit in front of it; the engine also detects it)
     r = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT)
     if r.returncode != 0:
         raise RuntimeError("rocprofv3 failed: " + r.stderr[-2000:])
