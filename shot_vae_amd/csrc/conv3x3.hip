@@ -15,6 +15,9 @@
 #ifndef SV_C3P_WREG
 #define SV_C3P_WREG 1
 #endif
+#ifndef SV_C3P_INTERLEAVE
+#define SV_C3P_INTERLEAVE 1    // tile order of the persistent kernel: 1 = all blocks sweep one moving window, 0 = a contiguous range per block
+#endif
 #ifndef SV_C3P_MODES
 #define SV_C3P_MODES 1         // fusion flags of conv3x3p at compile time for the step's three launch kinds (0: run-time flags only)
 #endif
@@ -219,18 +222,26 @@ __global__ __launch_bounds__(256, SV_C3P_WAVES) void conv3x3p_kernel(const sv_ge
     const int H = g.Hin, BH = g.B * H, nT = BH / TR;
     const int nNt = g.N / BN;
     // the channel tiles of one pixel range read the same input: keep them on one XCD (blocks L, L+8, ... share an
-    // L2) so that only the first of them goes to HBM (PMC: 1.73x the algorithmic bytes at 64 channels before)
-    int in_i, chunk;
-    if (nNt > 1 && (gridDim.x / nNt) % 8 == 0) {
+    // L2) so that only the first of them goes to HBM (PMC: 1.73x the algorithmic bytes at 64 channels before).
+    // Tile order: INTERLEAVED -- at its step k a block takes tile k * NC + xsub, so that the NC blocks of the launch sweep a
+    // compact window of NC consecutive tiles together, front to back, instead of each walking a contiguous range of its own:
+    // hundreds of separate streams ran HBM at 3.3-5 TB/s where one moving window reaches 5.5-6.6 (tools/probes/mall_probe.hip).
+    // Inside the window an XCD owns NC / 8 consecutive tiles: vertically adjacent tiles share their halo rows through its L2.
+    const int NC = gridDim.x / nNt;
+    int in_i, xsub;
+    if (NC % 8 == 0) {
         const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
         in_i = slot % nNt;
-        chunk = (slot / nNt) * 8 + xcd;
+        xsub = SV_C3P_INTERLEAVE ? xcd * (NC / 8) + slot / nNt : (slot / nNt) * 8 + xcd;
     } else {
         in_i = blockIdx.x % nNt;
-        chunk = blockIdx.x / nNt;
+        xsub = blockIdx.x / nNt;
     }
     const int n0 = in_i * BN;
-    const int t_begin = chunk * tiles_per, t_end = min(nT, t_begin + tiles_per);
+    // step k of this block: tile k * tstep + t_begin, while it is < t_end
+    const int tstep = SV_C3P_INTERLEAVE ? NC : 1;
+    const int t_begin = SV_C3P_INTERLEAVE ? xsub : xsub * tiles_per;
+    const int t_end = SV_C3P_INTERLEAVE ? nT : min(nT, t_begin + tiles_per);
     if (t_begin >= t_end) return;
     const sv_phase& P = g.phase[0];
     const uint64_t pdy = pack_taps(P.dy), pdx = pack_taps(P.dx);
@@ -350,7 +361,7 @@ __global__ __launch_bounds__(256, SV_C3P_WAVES) void conv3x3p_kernel(const sv_ge
         for (int r = 0; r < 4; ++r) s1[i][r] = s2[i][r] = 0.f;
 
     load_halo(HA, t_begin);
-    if (t_begin + 1 < t_end) load_halo(HB, t_begin + 1);
+    if (t_begin + tstep < t_end) load_halo(HB, t_begin + tstep);
     store_halo(HA);
     __syncthreads();
     // 32 input channels: the block's 18 weight fragments stay in registers (72 of them: with the fusion flags at compile time
@@ -367,8 +378,8 @@ __global__ __launch_bounds__(256, SV_C3P_WAVES) void conv3x3p_kernel(const sv_ge
     auto do_tile = [&](int tile, HStage& NEXT, HStage& FREE) {
         const int gr0 = tile * TR;
         // ---- request the halo two tiles ahead + this tile's epilogue operands; they fly during the MFMAs ----
-        const bool more = tile + 1 < t_end;
-        if (tile + 2 < t_end) load_halo(FREE, tile + 2);
+        const bool more = tile + tstep < t_end;
+        if (tile + 2 * tstep < t_end) load_halo(FREE, tile + 2 * tstep);
         int64_t obase[2];
         Q eop[NT][2];
 #pragma unroll
@@ -443,9 +454,9 @@ __global__ __launch_bounds__(256, SV_C3P_WAVES) void conv3x3p_kernel(const sv_ge
         }
         __syncthreads();                               // next halo visible
     };
-    for (int tile = t_begin; tile < t_end; tile += 2) {
+    for (int tile = t_begin; tile < t_end; tile += 2 * tstep) {
         do_tile(tile, HB, HA);
-        if (tile + 1 < t_end) do_tile(tile + 1, HA, HB);
+        if (tile + tstep < t_end) do_tile(tile + tstep, HA, HB);
     }
     // ---- flush the per-channel sums once per block ---------------------------------------------------------
     if (want_sums) {
