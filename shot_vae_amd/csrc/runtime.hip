@@ -50,6 +50,8 @@ size_t g_det_off = 0;
 constexpr size_t DET_RING_FLOATS = (size_t)8 << 20;
 }  // namespace
 float* sv_det_scratch(size_t floats) {
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lk(mu);
     floats = (floats + 63) / 64 * 64;
     if (floats > DET_RING_FLOATS) {
         sv_set_error("deterministic mode: a reduction asks for %zu floats of scratch (ring: %zu)", floats, DET_RING_FLOATS);
