@@ -281,6 +281,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3w_kernel(const sv_geom g, const
     using I1 = std::integral_constant<int, 1>;
 
     // ---- prologue ---------------------------------------------------------------------------------------------
+    if (has_pro && a.fold_stats) {
+        // the BatchNorm in front of this layer has not been finalised (sv_igemm_args::fold_*): every block derives the
+        // coefficients from the raw statistics itself and stores them -- all blocks the same values -- where the chunk DMAs
+        // below read them (the halo buffers are free until the first DMA; the block's stores and its later loads take the
+        // same path through the CU's vector cache to L2, in order)
+        float* fs = reinterpret_cast<float*>(smem);
+        sv_bn_fold_block(a, Cin, fs, fs + 512, fs + 512 + Cin, true);
+        __threadfence_block();
+    }
     __syncthreads();                                   // ssum / identity coefficients visible (no DMA in flight yet)
     issue_h(0, 0);
     issue_w(0, 0, 0);
@@ -381,6 +390,11 @@ int launch_w4(const sv_geom* g, const sv_igemm_args* a, hipStream_t s) {
             return sv_check_launch("hipFuncSetAttribute(conv3x3w)");
         optin = true;
     }
+    // BatchNorm finalisation folded into this launch: the blocks sum the replicas themselves (256 threads = 256 / Cin parts)
+    sv_igemm_args b = *a;
+    if (!sv_fold_claim(b.fold_stats && 256 % g->Cin == 0 && b.fold_replicas <= 64 && (size_t)(512 + 2 * g->Cin) * 4 <= (size_t)C::HB))
+        b.fold_stats = nullptr;
+    a = &b;
     SV_LAUNCH_GATE(grid, a);          // (deterministic mode: a replica per block -- the gate checks replicas >= 4 * grid)
     sv_prof_begin(s);
     hipLaunchKernelGGL((conv3x3w_kernel<NF, WLOG, REV, MODE>), dim3(grid, sv_ngroups(a->groups)), dim3(256), lds, s, *g, sv_expand_groups(*g, *a, 2));

@@ -1175,11 +1175,15 @@ def test_sparse_stride2_shortcut_gradient(dt, case):
 @pytest.mark.parametrize("halo_all", [0, 1])
 @pytest.mark.parametrize("B,Cin,N,H,k,stride,groups,R", [(8, 32, 32, 32, 3, 1, 1, 8), (16, 64, 64, 16, 3, 1, 4, 32),
                                                        (4, 32, 64, 16, 3, 2, 2, 4), (8, 128, 128, 8, 3, 1, 1, 2),
-                                                       (6, 16, 32, 32, 1, 1, 3, 16), (4, 16, 32, 32, 3, 1, 2, 64)])
+                                                       (6, 16, 32, 32, 1, 1, 3, 16), (4, 16, 32, 32, 3, 1, 2, 64),
+                                                       # enough tiles for the wide kernel conv3x3w, which folds too (every block
+                                                       # stores the coefficients its chunk DMAs then read)
+                                                       (1024, 128, 128, 8, 3, 1, 1, 32), (512, 128, 128, 8, 3, 1, 2, 32)])
 def test_folded_batchnorm_finalisation(dt, B, Cin, N, H, k, stride, groups, R, halo_all):
     """sv_igemm_args::fold_* (ABI 4): the BatchNorm in front of a conv-like layer finalised BY the launch -- inside the
-    persistent 3x3 kernel (every block derives scale / shift from the raw statistics, block 0 stores the four vectors), or by
-    the sv_bn_finalize launch sv_igemm issues itself for the other kernels -- against sv_bn_finalize + the same launch with
+    persistent 3x3 kernel (every block derives scale / shift from the raw statistics, block 0 stores the four vectors), inside the
+    wide kernel conv3x3w (128 / 256 input channels: every block stores them), or by the sv_bn_finalize launch sv_igemm issues
+    itself for the other kernels -- against sv_bn_finalize + the same launch with
     finished coefficients: identical coefficient vectors (2e-6: the replicas are summed in another order) and outputs.
     halo_all = 1 sends the thin / strided shapes to the persistent LDS-halo kernel (halop), which folds too."""
     code, tdt, tol = DT[dt]
