@@ -150,3 +150,20 @@ def test_flat_adam_checkpoint_reads_the_device_step_counter():
     from shot_vae_amd import optim
     src = inspect.getsource(optim.FlatAdam.state_dict)
     assert "step_dev" in src and ".item()" in src
+
+
+def test_flag_fork_is_off_under_serialised_dispatch(monkeypatch):
+    """The device-side fork (a kernel on the side stream waits for the data gradient's start signal) must not be used where
+    kernel dispatch is serialised across streams -- rocprofv3 --pmc, AMD_SERIALIZE_KERNEL, HIP_LAUNCH_BLOCKING: the waiting
+    kernel could be dispatched in front of the one it waits for.  The engine reads the environment once."""
+    import shot_vae_amd.engine as E
+    for var, val, want in (("ROCPROF_COUNTER_COLLECTION", "1", True), ("ROCPROF_COUNTERS", "pmc: FETCH_SIZE", True),
+                           ("AMD_SERIALIZE_KERNEL", "3", True), ("HIP_LAUNCH_BLOCKING", "1", True),
+                           ("AMD_SERIALIZE_KERNEL", "0", False), (None, None, False)):
+        for k in ("ROCPROF_COUNTER_COLLECTION", "ROCPROF_COUNTERS", "AMD_SERIALIZE_KERNEL", "HIP_LAUNCH_BLOCKING"):
+            monkeypatch.delenv(k, raising=False)
+        if var:
+            monkeypatch.setenv(var, val)
+        monkeypatch.setattr(E, "_SERIALISED", None)
+        assert E._dispatch_serialised() is want, (var, val)
+    monkeypatch.setattr(E, "_SERIALISED", None)
