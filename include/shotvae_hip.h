@@ -89,7 +89,15 @@ typedef struct {
                                    unread) instead of zero-filled -- the data gradient of a stride-2 1x1 convolution is zero at
                                    three of four positions; its only consumer, sv_bn_bwd_apply with sv_bn_branch::sparse = 1,
                                    does not read them.  0: every output position is written.                              */
-    int32_t reserved0;
+    int32_t ex_mode;            /* ABI 5 (was reserved, 0): what a launch with the activation-backward epilogue (`ex`) does with g =
+                                   out * act'(.).  0: writes g to `out` and accumulates the two BatchNorm-backward sums (bsums).
+                                   1: accumulates the sums ONLY -- nothing is written to `out`.  2: the BatchNorm backward is APPLIED:
+                                   out = ex_apply[0][n] * (g - ex_apply[1][n] - xhat * ex_apply[2][n]) (+ residual), xhat = (ex -
+                                   ex_mean) * ex_rstd; no sums.  Modes 1 + 2 replace {mode 0, sv_bn_bwd_apply} where recomputing the
+                                   convolution is cheaper than a pass over g (HBM-bound 32-channel layers): 5 tensor passes instead
+                                   of 6 (measured on MI355X: slower than the streaming pass it saves -- 7.17 against 7.04 ms per step;
+                                   the host layer leaves it off).  Stride-1 3x3 layers of the persistent narrow kernel (bf16) only:
+                                   SV_E_ARG otherwise.                                                                              */
     /* ABI 4: BatchNorm finalisation FOLDED into the consumer.  fold_stats != NULL: the prologue's BatchNorm has not been
        finalised yet -- fold_stats [R = fold_replicas][2 Cin] are the raw (sum, sum of squares) its producer accumulated over
        fold_count samples per channel; pro_scale / pro_shift (and fold_mean / fold_rstd) are then OUTPUT locations [Cin]:
@@ -115,9 +123,15 @@ typedef struct {
     uint32_t* start_flag;
     uint32_t start_value;
     int32_t reserved2;
+    const float* ex_apply;      /* ex_mode 2: [3][N] (groups: [G][3][N]) = gamma * rstd, mean(g), mean(g * xhat) -- sv_bn_bwd_coef */
 } sv_igemm_args;
 
 int sv_igemm(const sv_geom* g, int dtype, const sv_igemm_args* a, void* stream);
+/* The coefficients of ex_mode 2 from the sums of ex_mode 1: coef[g][0][c] = gamma[c] * rstd[g][c], coef[g][1][c] = sum g / count,
+ * coef[g][2][c] = sum g xhat / count (bsums [G][R][2C], replicas in index order), and -- what sv_bn_bwd_apply does on the side --
+ * dbeta[c] += sum g, dgamma[c] += sum g xhat over all groups (either may be NULL).  C <= 256, 256 % C == 0.               */
+int sv_bn_bwd_coef(const float* bsums, int replicas, int C, float count, const float* gamma, const float* rstd, float* dgamma,
+                   float* dbeta, float* coef, int groups, void* stream);
 /* The grid (blocks in x) sv_igemm WOULD launch for these arguments under the current options; nothing is launched.  With
  * SV_OPT_DETERMINISTIC the per-channel accumulators (`stats` / `bsums`) need replicas >= 4 * blocks (next power of two):
  * every wave of every block then adds to a replica of its own.                                                        */

@@ -35,10 +35,11 @@ class SvIgemmArgs(C.Structure):
                 ("w", C.c_void_p), ("bias", C.c_void_p), ("residual", C.c_void_p), ("out", C.c_void_p),
                 ("stats", C.c_void_p), ("ex", C.c_void_p), ("ex_scale", C.c_void_p), ("ex_shift", C.c_void_p),
                 ("ex_mean", C.c_void_p), ("ex_rstd", C.c_void_p), ("ex_slope", C.c_float), ("bsums", C.c_void_p),
-                ("replicas", C.c_int32), ("groups", C.c_int32), ("block_budget", C.c_int32), ("flags", C.c_int32), ("sparse_out", C.c_int32), ("reserved0", C.c_int32),
+                ("replicas", C.c_int32), ("groups", C.c_int32), ("block_budget", C.c_int32), ("flags", C.c_int32), ("sparse_out", C.c_int32), ("ex_mode", C.c_int32),
                 ("fold_stats", C.c_void_p), ("fold_gamma", C.c_void_p), ("fold_beta", C.c_void_p), ("fold_mean", C.c_void_p),
                 ("fold_rstd", C.c_void_p), ("fold_count", C.c_float), ("fold_eps", C.c_float), ("fold_replicas", C.c_int32),
-                ("reserved1", C.c_int32), ("start_flag", C.c_void_p), ("start_value", C.c_uint32), ("reserved2", C.c_int32)]
+                ("reserved1", C.c_int32), ("start_flag", C.c_void_p), ("start_value", C.c_uint32), ("reserved2", C.c_int32),
+                ("ex_apply", C.c_void_p)]
 
 
 class SvWgradArgs(C.Structure):
@@ -142,6 +143,7 @@ _PROTOS = {
     "sv_debug_conv_chunk_program": [C.POINTER(C.c_int), C.POINTER(C.c_int)],
     "sv_set_option": [I, I],
     "sv_get_option": [I],
+    "sv_bn_bwd_coef": [P, I, I, F, P, P, P, P, P, I, P],
     "sv_stream_fork": [P, P, I],
     "sv_stream_flag_next": [P, P, P],
     "sv_stream_wait_flag": [P, P, C.c_uint32],

@@ -109,6 +109,7 @@ inline sv_igemm_args_g sv_expand_groups(const sv_geom& g, const sv_igemm_args& a
                 r.ex_scale = a.ex_scale + grp * g.N; r.ex_shift = a.ex_shift + grp * g.N;
                 r.ex_mean = a.ex_mean + grp * g.N; r.ex_rstd = a.ex_rstd + grp * g.N;
                 r.bsums = a.bsums + grp * (int64_t)a.replicas * 2 * g.N;
+                if (a.ex_apply) r.ex_apply = a.ex_apply + grp * 3 * g.N;
             }
         }
         A.g[grp] = r;
@@ -198,6 +199,9 @@ bool sv_in_query();                    // the calling thread is inside sv_igemm_
 void sv_fold_begin(const sv_geom* g, const sv_igemm_args* a, void* stream);
 void sv_fold_end();
 bool sv_fold_claim(bool can);
+void sv_exmode_begin();                 // sv_igemm_args::ex_mode != 0 announced / over / taken by the launcher that implements it
+void sv_exmode_end();
+void sv_exmode_claim();
 // sv_igemm_args::start_flag: the first block of every kernel of the family announces its start (see shotvae_hip.h)
 __device__ __forceinline__ void sv_start_signal(const sv_igemm_args& a) {
     if (a.start_flag && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)

@@ -190,7 +190,10 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const sv_geom g, const sv_
 // residual / raw tensor needed by tile i's epilogue are already in flight -- and the BatchNorm sums are
 // kept in registers across tiles and flushed once per block (one shuffle tree, one atomic per channel).
 // MODE: the fusion flags at compile time (0 = read from the arguments; 1 = prologue + statistics, 2 = prologue + residual +
-// statistics, 3 = activation-backward epilogue, no prologue -- the three launch kinds of the training step; no bias in 1..3)
+// statistics, 3 = activation-backward epilogue, no prologue -- the three launch kinds of the training step; no bias in 1..3;
+// 4 = activation backward, SUMS ONLY: nothing is stored (sv_igemm_args::ex_mode 1); 5 = activation backward with the BatchNorm
+// backward APPLIED from finished coefficients (+ residual if there is one), no sums (ex_mode 2): the pair 4 + 5 recomputes the
+// convolution instead of writing g and reading it back in sv_bn_bwd_apply)
 template <typename T, int WLOG, int CCH, int MODE>      // CCH = Cin / 32
 __global__ __launch_bounds__(256, SV_C3P_WAVES) void conv3x3p_kernel(const sv_geom g, const sv_igemm_args_g A, int tiles_per) {
     const sv_igemm_args& a = A.g[blockIdx.y];
@@ -248,12 +251,13 @@ __global__ __launch_bounds__(256, SV_C3P_WAVES) void conv3x3p_kernel(const sv_ge
     const T* __restrict__ X = reinterpret_cast<const T*>(a.x);
     const T* __restrict__ Wp = reinterpret_cast<const T*>(a.w) + P.w_off + (int64_t)n0 * 9 * CIN;
     T* __restrict__ O = reinterpret_cast<T*>(a.out);
-    const T* __restrict__ R = MODE == 0 || MODE == 2 ? reinterpret_cast<const T*>(a.residual) : nullptr;
-    const T* __restrict__ EX = MODE == 0 || MODE == 3 ? reinterpret_cast<const T*>(a.ex) : nullptr;
-    const bool hasR = MODE == 0 ? R != nullptr : MODE == 2, hasEX = MODE == 0 ? EX != nullptr : MODE == 3;
+    const T* __restrict__ R = MODE == 0 || MODE == 2 || MODE == 5 ? reinterpret_cast<const T*>(a.residual) : nullptr;
+    const T* __restrict__ EX = MODE == 0 || MODE >= 3 ? reinterpret_cast<const T*>(a.ex) : nullptr;
+    const bool hasR = MODE == 0 ? R != nullptr : MODE == 2, hasEX = MODE == 0 ? EX != nullptr : MODE >= 3;
+    const bool hasR5 = MODE == 5 && R != nullptr;           // (mode 5: the residual is a second epilogue operand beside `ex`)
     const bool has_stats = MODE == 0 ? a.stats != nullptr : (MODE == 1 || MODE == 2);
-    const bool has_pro = MODE == 0 ? a.pro_scale != nullptr : MODE != 3;
-    const bool want_sums = has_stats || hasEX;
+    const bool has_pro = MODE == 0 ? a.pro_scale != nullptr : MODE < 3;
+    const bool want_sums = has_stats || (hasEX && MODE != 5);
 
     if (tid < 2 * BN) ssum[tid] = 0.f;
     V zero;
@@ -342,7 +346,7 @@ __global__ __launch_bounds__(256, SV_C3P_WAVES) void conv3x3p_kernel(const sv_ge
         pcol[ms] = p & (W - 1);
         hbase[ms] = ((prow[ms] + 1 + prow[ms] / HH) * WP + pcol[ms] + 1) * LDW + 8 * fq;
     }
-    f32x4 bias[NT], esc[NT], esh[NT], emu[NT], ers[NT];
+    f32x4 bias[NT], esc[NT], esh[NT], emu[NT], ers[NT], eca[MODE == 5 ? NT : 1], em1[MODE == 5 ? NT : 1], em2[MODE == 5 ? NT : 1];
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
         const int n = n0 + 16 * i + 4 * fq;
@@ -352,6 +356,11 @@ __global__ __launch_bounds__(256, SV_C3P_WAVES) void conv3x3p_kernel(const sv_ge
             esh[i] = *reinterpret_cast<const f32x4*>(a.ex_shift + n);
             emu[i] = *reinterpret_cast<const f32x4*>(a.ex_mean + n);
             ers[i] = *reinterpret_cast<const f32x4*>(a.ex_rstd + n);
+        }
+        if (MODE == 5) {
+            eca[MODE == 5 ? i : 0] = *reinterpret_cast<const f32x4*>(a.ex_apply + n);
+            em1[MODE == 5 ? i : 0] = *reinterpret_cast<const f32x4*>(a.ex_apply + g.N + n);
+            em2[MODE == 5 ? i : 0] = *reinterpret_cast<const f32x4*>(a.ex_apply + 2 * g.N + n);
         }
     }
     float s1[NT][4], s2[NT][4];
@@ -381,7 +390,7 @@ __global__ __launch_bounds__(256, SV_C3P_WAVES) void conv3x3p_kernel(const sv_ge
         const bool more = tile + tstep < t_end;
         if (tile + 2 * tstep < t_end) load_halo(FREE, tile + 2 * tstep);
         int64_t obase[2];
-        Q eop[NT][2];
+        Q eop[NT][2], eopr[MODE == 5 ? NT : 1][2];
 #pragma unroll
         for (int ms = 0; ms < 2; ++ms) {
             obase[ms] = ((int64_t)(gr0 + prow[ms]) * W + pcol[ms]) * g.ldo;
@@ -390,6 +399,7 @@ __global__ __launch_bounds__(256, SV_C3P_WAVES) void conv3x3p_kernel(const sv_ge
                 const int n = n0 + 16 * i + 4 * fq;
                 if (hasR) eop[i][ms] = *reinterpret_cast<const Q*>(R + obase[ms] + n);
                 else if (hasEX) eop[i][ms] = *reinterpret_cast<const Q*>(EX + obase[ms] + n);
+                if (hasR5) eopr[MODE == 5 ? i : 0][ms] = *reinterpret_cast<const Q*>(R + obase[ms] + n);
             }
         }
         // ---- nine taps x CCH channel chunks out of LDS (padding is data: no masks) ---------------------------
@@ -430,7 +440,19 @@ __global__ __launch_bounds__(256, SV_C3P_WAVES) void conv3x3p_kernel(const sv_ge
 #pragma unroll
                     for (int r = 0; r < 4; ++r) vv[r] += to_f(eop[i][ms][r]);
                 }
-                if (hasEX) {
+                if (MODE == 5) {
+                    // g = conv * act'(.), then the BatchNorm backward with finished coefficients: a (g - mean g - xhat mean(g xhat))
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int i5 = MODE == 5 ? i : 0;
+                        const float xf = to_f(eop[i][ms][r]);
+                        const float gv = vv[r] * act_grad(xf * esc[i][r] + esh[i][r], a.ex_slope);
+                        const float xh = (xf - emu[i][r]) * ers[i][r];
+                        float dx = eca[i5][r] * (gv - em1[i5][r] - xh * em2[i5][r]);
+                        if (hasR5) dx += to_f(eopr[i5][ms][r]);
+                        vv[r] = dx;
+                    }
+                } else if (hasEX) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const float xf = to_f(eop[i][ms][r]);
@@ -446,10 +468,12 @@ __global__ __launch_bounds__(256, SV_C3P_WAVES) void conv3x3p_kernel(const sv_ge
                         s2[i][r] += vv[r] * vv[r];
                     }
                 }
-                Q o;
+                if (MODE != 4) {           // (mode 4: the sums are all this launch produces)
+                    Q o;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] = (T)vv[r];
-                *reinterpret_cast<Q*>(O + obase[ms] + n) = o;
+                    for (int r = 0; r < 4; ++r) o[r] = (T)vv[r];
+                    *reinterpret_cast<Q*>(O + obase[ms] + n) = o;
+                }
             }
         }
         __syncthreads();                               // next halo visible
@@ -778,6 +802,10 @@ template <typename T, int WLOG, int CCH>
 int launch_p(const sv_geom* g, const sv_igemm_args* a, hipStream_t s) {
 #if SV_C3P_MODES
     if constexpr (sizeof(T) == 2) {
+        if (a->ex_mode) {                  // recomputing data gradient: sums only / BatchNorm backward applied (sv_igemm checked the rest)
+            sv_exmode_claim();
+            return a->ex_mode == 1 ? launch_pm<T, WLOG, CCH, 4>(g, a, s) : launch_pm<T, WLOG, CCH, 5>(g, a, s);
+        }
         if (!a->bias) {
             if (a->pro_scale && a->stats && !a->ex) return a->residual ? launch_pm<T, WLOG, CCH, 2>(g, a, s) : launch_pm<T, WLOG, CCH, 1>(g, a, s);
             if (!a->pro_scale && a->ex && !a->residual && !a->stats) return launch_pm<T, WLOG, CCH, 3>(g, a, s);

@@ -93,7 +93,20 @@ static int sv_fold_materialize() {
                           nullptr, nullptr, const_cast<float*>(a->pro_scale), const_cast<float*>(a->pro_shift), a->fold_mean,
                           a->fold_rstd, sv_ngroups(a->groups), tl_fold_stream);
 }
+// sv_igemm_args::ex_mode 1 / 2 (recomputing data gradient): only the persistent narrow 3x3 kernel implements them -- its launcher
+// claims the request, the launch gate of every other kernel of the family refuses it
+namespace { thread_local bool tl_exmode = false; }
+void sv_exmode_begin() { tl_exmode = true; }
+void sv_exmode_end() { tl_exmode = false; }
+void sv_exmode_claim() { tl_exmode = false; }
 bool sv_dry_run(int grid_x, const sv_igemm_args* a, int* rc) {
+    if (tl_exmode && !tl_query_blocks) {
+        tl_exmode = false;
+        sv_set_error("sv_igemm: ex_mode %d is implemented by the persistent narrow 3x3 kernel only (bf16, stride-1 3x3, <= 64 input "
+                     "channels, 32-channel output tiles): this geometry / option set dispatches to another kernel", a ? a->ex_mode : -1);
+        *rc = SV_E_ARG;
+        return true;
+    }
     if (tl_fold && !tl_query_blocks) {           // nobody claimed the fold: this kernel reads finished coefficients
         const int r = sv_fold_materialize();
         if (r != SV_OK) { *rc = r; return true; }

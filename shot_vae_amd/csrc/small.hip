@@ -332,6 +332,34 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bnb_params_g PG
     }
 }
 
+// Coefficients of the BatchNorm backward for a data gradient that applies it itself (sv_igemm_args::ex_mode 2): block = group;
+// thread (channel tid % C, part tid / C) sums its share of the replicas, the parts meet in LDS in index order.
+__global__ __launch_bounds__(256) void bn_bwd_coef_kernel(const float* bsums, int R, int C, float inv_count, const float* gamma,
+                                                          const float* rstd, float* dgamma, float* dbeta, float* coef) {
+    __shared__ float part[2][256];
+    const int grp = blockIdx.x, tid = threadIdx.x, c = tid % C, pt = tid / C, parts = 256 / C;
+    const float* b = bsums + (size_t)grp * R * 2 * C;
+    float s1 = 0.f, s2 = 0.f;
+    if (pt < parts)
+        for (int r = pt; r < R; r += parts) {
+            s1 += b[(size_t)r * 2 * C + c];
+            s2 += b[(size_t)r * 2 * C + C + c];
+        }
+    part[0][tid] = s1;
+    part[1][tid] = s2;
+    __syncthreads();
+    if (tid < C) {
+        float t1 = 0.f, t2 = 0.f;
+        for (int q = 0; q < parts; ++q) { t1 += part[0][q * C + tid]; t2 += part[1][q * C + tid]; }
+        float* o = coef + (size_t)grp * 3 * C;
+        o[tid] = gamma[tid] * rstd[(size_t)grp * C + tid];
+        o[C + tid] = t1 * inv_count;
+        o[2 * C + tid] = t2 * inv_count;
+        if (dbeta) atomicAdd(dbeta + tid, t1);
+        if (dgamma) atomicAdd(dgamma + tid, t2);
+    }
+}
+
 // out = act(x * scale[c] + shift[c]) (BatchNorm-apply + LeakyReLU / ReLU as a pass of its own): for the weight-heavy decoder
 // layers the consumer GEMM re-applied this prologue once per output-channel tile and was VALU-bound by it
 // (9 VALU instructions per MFMA); materialised once, the GEMM takes the prologue-free LDS-DMA loader.
@@ -1758,6 +1786,18 @@ int sv_bn_bwd_apply(int dtype, int64_t M, int C, int ld, const void* x, const fl
         DISPATCH_T(dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<T, false>), dim3(grid, groups), dim3(256), lds, (hipStream_t)stream, bnb_expand(p, groups, (int)sizeof(T))));
     }
     return sv_check_launch("sv_bn_bwd_apply");
+}
+
+int sv_bn_bwd_coef(const float* bsums, int replicas, int C, float count, const float* gamma, const float* rstd, float* dgamma,
+                   float* dbeta, float* coef, int groups, void* stream) {
+    SvProfScope prof_scope(stream);
+    SV_REQUIRE(bsums && gamma && rstd && coef && replicas >= 1 && count > 0.f, SV_E_ARG, "sv_bn_bwd_coef: bad argument");
+    SV_REQUIRE(C >= 1 && C <= 256 && 256 % C == 0, SV_E_SHAPE, "sv_bn_bwd_coef: C=%d (a divisor of 256)", C);
+    groups = sv_ngroups(groups);
+    SV_REQUIRE(groups <= SV_MAX_GROUPS, SV_E_ARG, "sv_bn_bwd_coef: groups=%d (at most %d)", groups, SV_MAX_GROUPS);
+    hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3(groups), dim3(256), 0, (hipStream_t)stream, bsums, replicas, C, 1.f / count, gamma, rstd,
+                       dgamma, dbeta, coef);
+    return sv_check_launch("sv_bn_bwd_coef");
 }
 
 int sv_bn_act(int dtype, const void* x, const float* scale, const float* shift, float slope, int64_t M, int C, void* out,

@@ -368,7 +368,7 @@ class Engine:
                                     "move the model and its inputs to cuda first")
         L.lib()
 
-    def _tag(self, name, g=None, extra_out_reads=0, wgrad=False, groups=1):
+    def _tag(self, name, g=None, extra_out_reads=0, wgrad=False, groups=1, writes_out=True):
         """File the next launch under `name` for sv_prof_collect and remember its algorithmic cost:
         bytes = input + output (+ fused residual / raw-tensor reads) + weights, flops = 2*M*N*K."""
         if self.prof_tags is None:
@@ -386,7 +386,7 @@ class Engine:
             if wgrad:
                 nbytes = es * (n_in + n_out) + 4 * n_w
             else:
-                nbytes = es * (n_in + n_out * (1 + extra_out_reads) + n_w)
+                nbytes = es * (n_in + n_out * (int(writes_out) + extra_out_reads) + n_w)
             self._cost(name, nbytes, flops)
 
     def _cost(self, name, nbytes, flops=0.0):
@@ -430,9 +430,12 @@ class Engine:
         self._pack_key = key
 
     def _igemm(self, g, x, w_ptr, out, pro=None, bias=None, residual=None, stats=None, ex=None, tag=None, groups=1,
-               budget=0, sparse_out=False):
+               budget=0, sparse_out=False, ex_mode=0, ex_apply=None):
         a = L.SvIgemmArgs()
         a.groups = groups
+        a.ex_mode = ex_mode                     # 1: the sums only (nothing stored), 2: BatchNorm backward applied from ex_apply
+        if ex_apply is not None:
+            a.ex_apply = ex_apply.data_ptr()
         a.block_budget = budget
         a.sparse_out = int(bool(sparse_out))
         a.x, a.w, a.out = x.data_ptr(), w_ptr, out.data_ptr()
@@ -468,7 +471,7 @@ class Engine:
             else:
                 a.bsums, a.replicas = ex[6:]
         if tag:
-            self._tag(tag, g, (residual is not None) + (ex is not None), groups=groups)
+            self._tag(tag, g, (residual is not None) + (ex is not None), groups=groups, writes_out=ex_mode != 1)
         if self._start_signal is not None:       # (see _wgrad_async: this launch forks the side stream when it starts)
             (a.start_flag, a.start_value), self._start_signal = self._start_signal, None
         L.call("sv_igemm", C.byref(g), self.code, C.byref(a), self._stream())
@@ -492,6 +495,10 @@ class Engine:
     materialize_max_hin = 4          # ... for the layers whose input map is at most this large
     light_fork = True                # fork events without the system-scope fence (sv_stream_fork)
     fork_every = 1                   # weight gradients per side-stream fork
+    recompute_bn_bwd = False         # (measured slower, 7.04 -> 7.17 ms: bench.py --recompute 1) narrow layers: data gradient twice
+                                     # (sums, then BatchNorm backward applied) instead of g + sv_bn_bwd_apply
+    recompute_max_channels = 32
+    recompute_full_budget = False
     flag_fork = True                 # paired launches: the data gradient's start signal forks the side stream (no event)
     _start_signal = None
     _pending_wgrads = ()
@@ -957,6 +964,15 @@ class Engine:
                    _vp(dx.data_ptr()), Gx, st)
             return dx
 
+        def bn_coef(b, count):
+            """[G][3][C] = gamma * rstd, mean g, mean g xhat of BatchNorm b from its backward sums (one small launch, which also adds
+            dgamma / dbeta): the operand of a data gradient that applies the BatchNorm backward itself (ex_mode 2)"""
+            _, _, _, rs = bnp(b)
+            coef = torch.empty(G * 3 * b.C, dtype=torch.float32, device=dev)
+            L.call("sv_bn_bwd_coef", _vp(bs_off[b.index]), bs_rep[b.index], b.C, float(count), _vp(pbase + 4 * b.gamma_off), _vp(rs),
+                   _vp(gbase + 4 * b.gamma_off), _vp(gbase + 4 * b.beta_off), _vp(coef.data_ptr()), G, st)
+            return coef
+
         # ---- decoder: only the first Gd groups carry a reconstruction gradient (forward(..., rec_groups)); none at all when
         #      the caller's loss does not use the reconstruction (d_rec is None: the mixed forwards of the sequential step) --
         Gd = f.Gd if d_rec is not None else 0
@@ -1032,15 +1048,49 @@ class Engine:
             pair = self.pair_blocks if ((self.wgrad_side_stream and self.prof_tags is None and
                                          not torch.cuda.is_current_stream_capturing()) or self.prof_paired) else 0
             pair = min(pair, L.lib().sv_get_option(L.OPT_PERSISTENT_BLOCKS))
-            g2 = torch.empty_like(c1)
-            self._wgrad_async(un["conv2"].geom_fwd(B), c1, pro2, D, gbase + 4 * un["conv2"].master_off,
-                              tag="wgrad:conv3x3_%dx%d_s1" % (c, c), groups=G, budget=pair,
-                              then=lambda: self._igemm(un["conv2"].geom_dgrad(B), D, pk + es * un["conv2"].dgrad_off, g2,
-                                                       ex=ex_of(un["bn2"], c1), tag="dgrad:conv3x3_%dx%d_s1" % (c, c),
-                                                       groups=G, budget=pair))
-            dc1 = bn_apply(c1, [(g2, un["bn2"])], None, c1.numel() // c // G)
-            del g2
+            # (experiment, off: recompute_bn_bwd) HBM-bound narrow layers: the data gradient runs TWICE -- once for the
+            # BatchNorm-backward sums alone (nothing stored), once more applying the BatchNorm backward in its epilogue -- instead
+            # of writing g and reading it back in sv_bn_bwd_apply: 5 tensor passes per layer instead of 6 (sv_igemm_args::ex_mode).
+            # Measured: 105 + 6 + 98..113 us per layer against 120 + 72..91 -- a pass of the convolution kernel at the paired block
+            # budget moves 2.6-4 TB/s, the streaming pass it replaces 5.3
+            rec = self.recompute_bn_bwd and c <= self.recompute_max_channels and self.code == L.SV_BF16 and not det
+            same = un["stride"] == 1 and un["cin"] == c
+            pair_rec = 0 if self.recompute_full_budget else pair
+            cnt2 = c1.numel() // c // G
+            if rec:
+                ex2 = ex_of(un["bn2"], c1)
+                self._wgrad_async(un["conv2"].geom_fwd(B), c1, pro2, D, gbase + 4 * un["conv2"].master_off,
+                                  tag="wgrad:conv3x3_%dx%d_s1" % (c, c), groups=G, budget=pair,
+                                  then=lambda: self._igemm(un["conv2"].geom_dgrad(B), D, pk + es * un["conv2"].dgrad_off, c1,
+                                                           ex=ex2, groups=G, budget=pair_rec, ex_mode=1,
+                                                           tag="dgrad_sums:conv3x3_%dx%d_s1" % (c, c)))
+                dc1 = torch.empty_like(c1)
+                self._igemm(un["conv2"].geom_dgrad(B), D, pk + es * un["conv2"].dgrad_off, dc1, ex=ex2, groups=G, budget=pair_rec,
+                            ex_mode=2, ex_apply=bn_coef(un["bn2"], cnt2), tag="dgrad_apply:conv3x3_%dx%d_s1" % (c, c))
+            else:
+                g2 = torch.empty_like(c1)
+                self._wgrad_async(un["conv2"].geom_fwd(B), c1, pro2, D, gbase + 4 * un["conv2"].master_off,
+                                  tag="wgrad:conv3x3_%dx%d_s1" % (c, c), groups=G, budget=pair,
+                                  then=lambda: self._igemm(un["conv2"].geom_dgrad(B), D, pk + es * un["conv2"].dgrad_off, g2,
+                                                           ex=ex_of(un["bn2"], c1), tag="dgrad:conv3x3_%dx%d_s1" % (c, c),
+                                                           groups=G, budget=pair))
+                dc1 = bn_apply(c1, [(g2, un["bn2"])], None, cnt2)
+                del g2
             pair1 = pair if (un["stride"] == 1 and un["cin"] == c) else 0
+            cnt = tin.numel() // tin.shape[-1] // G
+            if rec and same and "convi" not in un:
+                ex1 = ex_of(un["bn1"], tin)
+                self._wgrad_async(un["conv1"].geom_fwd(B), tin, pro1, dc1, gbase + 4 * un["conv1"].master_off,
+                                  tag="wgrad:conv3x3_%dx%d_s%d" % (un["cin"], c, un["stride"]), groups=G, budget=pair1,
+                                  then=lambda: self._igemm(un["conv1"].geom_dgrad(B), dc1, pk + es * un["conv1"].dgrad_off, tin,
+                                                           ex=ex1, groups=G, budget=pair_rec, ex_mode=1,
+                                                           tag="dgrad_sums:conv3x3_%dx%d_s1" % (c, c)))
+                Dn = torch.empty_like(tin)
+                self._igemm(un["conv1"].geom_dgrad(B), dc1, pk + es * un["conv1"].dgrad_off, Dn, ex=ex1, residual=D, groups=G,
+                            budget=pair_rec, ex_mode=2, ex_apply=bn_coef(un["bn1"], cnt), tag="dgrad_apply:conv3x3_%dx%d_s1" % (c, c))
+                del dc1
+                D = Dn
+                continue
             g1 = torch.empty_like(tin)
             self._wgrad_async(un["conv1"].geom_fwd(B), tin, pro1, dc1, gbase + 4 * un["conv1"].master_off,
                               tag="wgrad:conv3x3_%dx%d_s%d" % (un["cin"], c, un["stride"]), groups=G, budget=pair1,

@@ -1101,6 +1101,86 @@ def test_start_signal_forks_a_second_stream(case):
     assert rel(nchw(out.float().cpu()), ref) < DT["bf16"][2]
 
 
+@pytest.mark.parametrize("B,Cc,H,Gn,with_res", [(16, 32, 32, 2, True), (8, 32, 32, 4, False), (8, 64, 16, 1, True)])
+def test_recomputing_data_gradient_equals_g_plus_bn_bwd_apply(B, Cc, H, Gn, with_res):
+    """sv_igemm_args::ex_mode (ABI 5): the data gradient of a narrow stride-1 3x3 layer run twice -- mode 1 accumulates the
+    BatchNorm-backward sums and stores nothing, sv_bn_bwd_coef turns them into coefficients (and adds dgamma / dbeta), mode 2
+    applies the BatchNorm backward (+ residual) in its epilogue -- against mode 0 (g written) + sv_bn_bwd_apply.  A geometry
+    that dispatches to another kernel refuses the modes."""
+    d = dev()
+    torch.manual_seed(23)
+    bf = torch.bfloat16
+    dy = torch.randn(Gn * B, H, H, Cc, device=d).to(bf)
+    x = (torch.randn(Gn * B, H, H, Cc, device=d) * 1.3 + 0.2).to(bf)              # the raw tensor of the BatchNorm (ex)
+    res = torch.randn(Gn * B, H, H, Cc, device=d).to(bf)
+    sc, sh = (torch.rand(Gn, Cc, device=d) + 0.5).contiguous(), (torch.randn(Gn, Cc, device=d) * 0.3).contiguous()
+    mean, rstd = (torch.randn(Gn, Cc, device=d) * 0.1).contiguous(), (torch.rand(Gn, Cc, device=d) + 0.5).contiguous()
+    gamma = torch.rand(Cc, device=d) + 0.5
+    w = bq(torch.randn(Cc, 9, Cc) / (9 * Cc) ** 0.5, "bf16")
+    gd = G.convT_like(B, H, H, Cc, Cc, 3, 1, 1)
+    wd = repack(w, gd, True, "bf16")
+    R, count = 8, float(B * H * H)
+
+    def dgrad(mode, out, bs, coef=None, residual=None):
+        a = L.SvIgemmArgs()
+        a.x, a.w, a.out, a.groups = dy.data_ptr(), wd.data_ptr(), out.data_ptr(), Gn
+        a.ex, a.ex_scale, a.ex_shift, a.ex_mean, a.ex_rstd = (t.data_ptr() for t in (x, sc, sh, mean, rstd))
+        a.ex_slope, a.bsums, a.replicas, a.ex_mode = 0.01, bs.data_ptr(), R, mode
+        if coef is not None:
+            a.ex_apply = coef.data_ptr()
+        if residual is not None:
+            a.residual = residual.data_ptr()
+        L.call("sv_igemm", C.byref(gd), L.SV_BF16, C.byref(a), st())
+
+    # reference: g written, then sv_bn_bwd_apply
+    g0, bs0 = torch.empty_like(x), torch.zeros(Gn, R, 2 * Cc, device=d)
+    dgrad(0, g0, bs0)
+    dg0, db0 = torch.zeros(Cc, device=d), torch.zeros(Cc, device=d)
+    br_ = (L.SvBnBranch * 1)()
+    br_[0].g, br_[0].bsums, br_[0].gamma, br_[0].replicas = g0.data_ptr(), bs0.data_ptr(), gamma.data_ptr(), R
+    br_[0].dgamma, br_[0].dbeta = dg0.data_ptr(), db0.data_ptr()
+    dx0 = torch.empty_like(x)
+    L.call("sv_bn_bwd_apply", L.SV_BF16, B * H * H, Cc, Cc, p(x), p(mean), p(rstd), count, br_, 1, p(res) if with_res else None,
+           p(dx0), Gn, st())
+    # recomputing pair
+    sentinel = torch.full_like(x, 7.0)
+    bs1 = torch.zeros(Gn, R, 2 * Cc, device=d)
+    dgrad(1, sentinel, bs1)
+    coef = torch.empty(Gn, 3, Cc, device=d)
+    dg1, db1 = torch.zeros(Cc, device=d), torch.zeros(Cc, device=d)
+    L.call("sv_bn_bwd_coef", p(bs1), R, Cc, count, p(gamma), p(rstd), p(dg1), p(db1), p(coef), Gn, st())
+    dx1 = torch.empty_like(x)
+    dgrad(2, dx1, bs1, coef=coef, residual=res if with_res else None)
+    torch.cuda.synchronize()
+    assert float(sentinel.float().min()) == 7.0 and float(sentinel.float().max()) == 7.0          # mode 1 stores nothing
+    assert rel(bs1.sum(1), bs0.sum(1)) < 1e-5
+    assert rel(dg1, dg0) < 1e-5 and rel(db1, db0) < 1e-5
+    s1, s2 = bs0.sum(1)[:, :Cc], bs0.sum(1)[:, Cc:]
+    assert rel(coef[:, 0], gamma[None] * rstd) < 1e-6 and rel(coef[:, 1], s1 / count) < 1e-5 and rel(coef[:, 2], s2 / count) < 1e-5
+    # (the reference pair rounds g to bf16 before the BatchNorm backward, the recomputing pair does not)
+    assert bool(torch.isfinite(dx1.float()).all()) and rel(dx1.float(), dx0.float()) < 1e-2
+    # fp64 statement of the same formula from the fp32 sums
+    gi = torch.arange(Gn * B, device=d) // B
+    gf = g0.double()
+    xh = (x.double() - mean[gi][:, None, None, :]) * rstd[gi][:, None, None, :]
+    want = (gamma[None] * rstd)[gi][:, None, None, :] * (gf - (s1 / count)[gi][:, None, None, :] - xh * (s2 / count)[gi][:, None, None, :])
+    if with_res:
+        want = want + res.double()
+    assert rel(dx1.float(), want) < 1e-2
+    # a geometry of another kernel (128 channels: conv3x3w / the generic kernels) refuses the modes
+    gw = G.convT_like(4, 8, 8, 128, 128, 3, 1, 1)
+    a = L.SvIgemmArgs()
+    big = torch.zeros(4, 8, 8, 128, device=d, dtype=bf)
+    wbig = repack(bq(torch.randn(128, 9, 128) * 0.03, "bf16"), gw, True, "bf16")
+    v128 = torch.ones(128, device=d)
+    a.x, a.w, a.out, a.ex = big.data_ptr(), wbig.data_ptr(), big.data_ptr(), big.data_ptr()
+    a.ex_scale = a.ex_shift = a.ex_mean = a.ex_rstd = v128.data_ptr()
+    bsb = torch.zeros(2 * 128 * 4, device=d)
+    a.bsums, a.replicas, a.ex_mode = bsb.data_ptr(), 4, 1
+    with pytest.raises(L.ShotVaeHipError, match="ex_mode"):
+        L.call("sv_igemm", C.byref(gw), L.SV_BF16, C.byref(a), st())
+
+
 def test_rank_permutation():
     """sv_rank_permutation: perm = argsort of the keys (ties: the lower index first), several batches per launch, sizes up
     to a full minibatch."""
