@@ -18,6 +18,9 @@
 #ifndef SV_C3P_INTERLEAVE
 #define SV_C3P_INTERLEAVE 1    // tile order of the persistent kernel: 1 = all blocks sweep one moving window, 0 = a contiguous range per block
 #endif
+#ifndef SV_C3P_EOP_AHEAD
+#define SV_C3P_EOP_AHEAD 1     // the epilogue operand of a tile is requested one tile ahead (0: inside its own tile)
+#endif
 #ifndef SV_C3P_MODES
 #define SV_C3P_MODES 1         // fusion flags of conv3x3p at compile time for the step's three launch kinds (0: run-time flags only)
 #endif
@@ -384,21 +387,42 @@ __global__ __launch_bounds__(256, SV_C3P_WAVES) void conv3x3p_kernel(const sv_ge
             for (int i = 0; i < NT; ++i) wr[t][i] = *reinterpret_cast<const V*>(wl + ((16 * i + fr) * 9 + t) * LDW + 8 * fq);
     }
     // one tile of the pipeline; NEXT holds tile+1 (already requested), FREE receives the request for tile+2
-    auto do_tile = [&](int tile, HStage& NEXT, HStage& FREE) {
+    // the epilogue operand (residual / raw tensor) of a tile: requested ONE TILE AHEAD, like the halo two tiles ahead -- loads
+    // return in order, so an operand requested inside its own tile made the epilogue wait for everything that tile had
+    // requested, the halo of tile + 2 included: one exposed memory round trip per tile (what bounded the kernel at one block per
+    // CU, the paired budget of the backward)
+    struct EStage { Q v[NT][2]; };
+    auto load_eop = [&](EStage& E, int tile) {
         const int gr0 = tile * TR;
-        // ---- request the halo two tiles ahead + this tile's epilogue operands; they fly during the MFMAs ----
+#pragma unroll
+        for (int ms = 0; ms < 2; ++ms) {
+            const int64_t ob = ((int64_t)(gr0 + prow[ms]) * W + pcol[ms]) * g.ldo;
+#pragma unroll
+            for (int i = 0; i < NT; ++i) {
+                const int n = n0 + 16 * i + 4 * fq;
+                if (hasR) E.v[i][ms] = *reinterpret_cast<const Q*>(R + ob + n);
+                else if (hasEX) E.v[i][ms] = *reinterpret_cast<const Q*>(EX + ob + n);
+            }
+        }
+    };
+    EStage EA, EB;
+    if (SV_C3P_EOP_AHEAD && (hasR || hasEX)) load_eop(EA, t_begin);
+    auto do_tile = [&](int tile, HStage& NEXT, HStage& FREE, EStage& ECUR, EStage& ENEXT) {
+        const int gr0 = tile * TR;
+        // ---- request the halo two tiles ahead + the NEXT tile's epilogue operands; they fly during the MFMAs ----
         const bool more = tile + tstep < t_end;
         if (tile + 2 * tstep < t_end) load_halo(FREE, tile + 2 * tstep);
+        if (SV_C3P_EOP_AHEAD) { if (more && (hasR || hasEX)) load_eop(ENEXT, tile + tstep); }
+        else if (hasR || hasEX) load_eop(ECUR, tile);
+        Q (&eop)[NT][2] = ECUR.v;
         int64_t obase[2];
-        Q eop[NT][2], eopr[MODE == 5 ? NT : 1][2];
+        Q eopr[MODE == 5 ? NT : 1][2];
 #pragma unroll
         for (int ms = 0; ms < 2; ++ms) {
             obase[ms] = ((int64_t)(gr0 + prow[ms]) * W + pcol[ms]) * g.ldo;
 #pragma unroll
             for (int i = 0; i < NT; ++i) {
                 const int n = n0 + 16 * i + 4 * fq;
-                if (hasR) eop[i][ms] = *reinterpret_cast<const Q*>(R + obase[ms] + n);
-                else if (hasEX) eop[i][ms] = *reinterpret_cast<const Q*>(EX + obase[ms] + n);
                 if (hasR5) eopr[MODE == 5 ? i : 0][ms] = *reinterpret_cast<const Q*>(R + obase[ms] + n);
             }
         }
@@ -479,8 +503,8 @@ __global__ __launch_bounds__(256, SV_C3P_WAVES) void conv3x3p_kernel(const sv_ge
         __syncthreads();                               // next halo visible
     };
     for (int tile = t_begin; tile < t_end; tile += 2 * tstep) {
-        do_tile(tile, HB, HA);
-        if (tile + tstep < t_end) do_tile(tile + tstep, HA, HB);
+        do_tile(tile, HB, HA, EA, EB);
+        if (tile + tstep < t_end) do_tile(tile + tstep, HA, HB, EB, EA);
     }
     // ---- flush the per-channel sums once per block ---------------------------------------------------------
     if (want_sums) {
