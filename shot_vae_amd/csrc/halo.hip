@@ -33,6 +33,10 @@ namespace {
 // Blocks per CU of the small-stage persistent variants (measured at 4 x 512 images, tools/thin_ab.sh: three blocks of the
 // 2-vector / 16-channel-tile variant: stem 66 -> 55 us, 1x1 16 -> 32 data gradient 54 -> 46 us; four blocks or any of the
 // 32-channel-tile variants spill -- 16 -> 32 forward 115 -> 176 / 290 us -- and stay at two)
+#ifndef SV_HALOP_EO_AHEAD
+#define SV_HALOP_EO_AHEAD 0    // 1: the epilogue operand of a tile is requested one tile ahead (measured mixed here: -4 % .. +6 % per layer, step flat;
+                                // conv3x3p, one block per CU in the paired backward, gains 17 % from the same change)
+#endif
 #ifndef SV_HALOP_MODES
 #define SV_HALOP_MODES 1
 #endif
@@ -596,15 +600,41 @@ __global__ __launch_bounds__(256, OCC) void halop_kernel(const sv_geom g, const 
     if (t_begin + 1 < t_end) load_halo(HB, t_begin + 1);
     store_halo(HA);
     __syncthreads();
-    auto do_tile = [&](int tile, HStage& NEXT, HStage& FREE) {
+    // the epilogue's extra operand (residual OR raw tensor) of every (phase, row, channel group) of a tile is requested ONE TILE
+    // AHEAD (clamped addresses: rows / channel groups beyond the tensor read a valid element and are not stored).  Requested
+    // inside the epilogue it was an exposed round trip per tile (waves of the thin layers waited 70 % of their cycles,
+    // tools/pmc_sq.py); requested at the top of its own tile, behind the halo of tile + 2, it still made the epilogue wait for
+    // that halo -- loads return in order (conv3x3p: data gradient 112 -> 93 us with the same change).
+    struct EStage { Q eo[NPH][2][NT]; };
+    auto load_eo = [&](EStage& E, int tile) {
+        const int R0 = tile * c.TR;
+#pragma unroll
+        for (int ms = 0; ms < 2; ++ms) {
+            const int grow = R0 + prow[ms];
+            const int growc = grow < BHq ? grow : BHq - 1;
+            const int b = growc >> c.hlog, qy = growc & (Hq - 1);
+#pragma unroll
+            for (int ph = 0; ph < NPH; ++ph) {
+                const sv_phase& P = g.phase[ph < g.nphase ? ph : 0];
+                const int64_t ob = ((int64_t)(b * g.Hout + qy * g.osy + P.ooy) * g.Wout + pcol[ms] * g.osx + P.oox) * g.ldo;
+                if ((hasR || hasEX) && ph < g.nphase && !(sparse && c.nks[ph] == 0)) {
+                    const T* __restrict__ E_ = R ? R : EX;
+#pragma unroll
+                    for (int i = 0; i < NT; ++i)
+                        E.eo[ph][ms][i] = *reinterpret_cast<const Q*>(E_ + ob + (nval[i] ? n0 + 16 * i + 4 * fq : 0));
+                }
+            }
+        }
+    };
+    EStage EA, EB;
+    if (SV_HALOP_EO_AHEAD && (hasR || hasEX)) load_eo(EA, t_begin);
+    auto do_tile = [&](int tile, HStage& NEXT, HStage& FREE, EStage& ECUR, EStage& ENEXT) {
         const int R0 = tile * c.TR;
         const bool more = tile + 1 < t_end;
         if (tile + 2 < t_end) load_halo(FREE, tile + 2);              // flies during this tile's and the next tile's MFMAs
-        // the epilogue's extra operand (residual OR raw tensor) of every (phase, row, channel group) is requested HERE, before
-        // the MFMAs (clamped addresses: rows / channel groups beyond the tensor read a valid element and are not stored):
-        // requested inside the epilogue it was an exposed round trip per tile -- waves of the thin layers waited 70 % of
-        // their cycles (tools/pmc_sq.py)
-        Q eo[NPH][2][NT];
+        if (SV_HALOP_EO_AHEAD) { if (more && (hasR || hasEX)) load_eo(ENEXT, tile + 1); }
+        else if (hasR || hasEX) load_eo(ECUR, tile);
+        Q (&eo)[NPH][2][NT] = ECUR.eo;
         int64_t obv[NPH][2];
         bool rokv[2];
 #pragma unroll
@@ -617,12 +647,6 @@ __global__ __launch_bounds__(256, OCC) void halop_kernel(const sv_geom g, const 
             for (int ph = 0; ph < NPH; ++ph) {
                 const sv_phase& P = g.phase[ph < g.nphase ? ph : 0];
                 obv[ph][ms] = ((int64_t)(b * g.Hout + qy * g.osy + P.ooy) * g.Wout + pcol[ms] * g.osx + P.oox) * g.ldo;
-                if ((hasR || hasEX) && ph < g.nphase && !(sparse && c.nks[ph] == 0)) {
-                    const T* __restrict__ E = R ? R : EX;
-#pragma unroll
-                    for (int i = 0; i < NT; ++i)
-                        eo[ph][ms][i] = *reinterpret_cast<const Q*>(E + obv[ph][ms] + (nval[i] ? n0 + 16 * i + 4 * fq : 0));
-                }
             }
         }
         f32x4 acc[NPH][NT][2];
@@ -688,8 +712,8 @@ __global__ __launch_bounds__(256, OCC) void halop_kernel(const sv_geom g, const 
         __syncthreads();                               // the next halo is visible
     };
     for (int tile = t_begin; tile < t_end; tile += 2) {
-        do_tile(tile, HB, HA);
-        if (tile + 1 < t_end) do_tile(tile + 1, HA, HB);
+        do_tile(tile, HB, HA, EA, EB);
+        if (tile + 1 < t_end) do_tile(tile + 1, HA, HB, EB, EA);
     }
     if (want_sums) flush_channel_sums<NT>(s1, s2, nval, ssum, hasEX ? a.bsums : a.stats, n0, g.N, a.replicas, a.flags);
 }
