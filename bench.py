@@ -687,6 +687,8 @@ def main():
             issues, each kernel timed without its partner; not paired: every launch with the full budget."""
             eng.prof_tags, eng.prof_cost = {}, {}
             L.prof_tags = eng.prof_tags
+            # (the BatchNorm finalisations sv_igemm issues itself for folded launches: a tag of their own, not the layer's)
+            L.lib().sv_prof_nested_tag(eng.prof_tags.setdefault("sv_bn_finalize(folded)", len(eng.prof_tags)))
             L.lib().sv_prof_enable(1)
             side, eng.wgrad_side_stream, eng.prof_paired = eng.wgrad_side_stream, False, bool(paired and eng.wgrad_side_stream)
             try:
@@ -701,6 +703,7 @@ def main():
                 L.lib().sv_prof_collect(ntag, ms, cnt)
             finally:
                 L.lib().sv_prof_enable(0)
+                L.lib().sv_prof_nested_tag(-1)
                 tags = dict(eng.prof_tags)
                 L.prof_tags = eng.prof_tags = None
                 eng.wgrad_side_stream, eng.prof_paired = side, False

@@ -429,6 +429,10 @@ int sv_repack_batch(int dtype, const float* master_base, const sv_repack_job* jo
  * sv_prof_collect synchronises the device and returns, per tag, total milliseconds and launches.   */
 int sv_prof_enable(int on);
 int sv_prof_tag(int tag);
+/* Launches the library issues on its own inside an entry point (the sv_bn_finalize of a folded sv_igemm whose kernel does not
+ * derive the coefficients itself) are filed under `tag`; -1 (default): they are not recorded -- never as a second launch of
+ * the layer's tag.                                                                                                        */
+int sv_prof_nested_tag(int tag);
 int sv_prof_collect(int max_tags, double* ms, int* count);
 
 /* ---- introspection (host only, no GPU): the compile-time "tile program" of the wide weight-gradient kernel.

@@ -137,6 +137,7 @@ _PROTOS = {
     "sv_repack_batch": [I, P, P, I, I, P, P],
     "sv_augment": [I, P, P, P, I, I, I, I, I, I, P, P],
     "sv_prof_enable": [I],
+    "sv_prof_nested_tag": [I],
     "sv_prof_tag": [I],
     "sv_prof_collect": [I, C.POINTER(C.c_double), C.POINTER(C.c_int)],
     "sv_debug_wgrad_tile_program": [I, C.POINTER(C.c_int), C.POINTER(C.c_int)],

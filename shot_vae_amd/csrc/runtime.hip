@@ -86,9 +86,13 @@ bool sv_fold_claim(bool can) {
     tl_fold = nullptr;
     return true;
 }
+int sv_prof_nested_scope(int enter);
 static int sv_fold_materialize() {
     const sv_igemm_args* a = tl_fold;
     tl_fold = nullptr;
+    // (in-situ timing: this launch is filed under its own tag -- sv_prof_nested_tag -- or not at all, never as a second launch
+    //  of the layer whose sv_igemm issued it)
+    struct Nested { Nested() { sv_prof_nested_scope(1); } ~Nested() { sv_prof_nested_scope(0); } } nested;
     return sv_bn_finalize(a->fold_stats, a->fold_replicas, tl_fold_g->Cin, a->fold_count, a->fold_gamma, a->fold_beta, a->fold_eps, 0.f,
                           nullptr, nullptr, const_cast<float*>(a->pro_scale), const_cast<float*>(a->pro_shift), a->fold_mean,
                           a->fold_rstd, sv_ngroups(a->groups), tl_fold_stream);
@@ -149,7 +153,7 @@ bool sv_enabled(int kernel_bit) { return (g_enable_mask & kernel_bit) != 0; }
 
 namespace {
 struct Rec { hipEvent_t a, b; int tag; };
-int g_prof_on = 0, g_tag = 0;
+int g_prof_on = 0, g_tag = 0, g_nested_tag = -1;
 std::vector<Rec> g_recs;
 std::vector<Rec> g_pool;
 constexpr size_t kMaxRecs = 1 << 17;
@@ -174,6 +178,22 @@ void sv_prof_end(hipStream_t s) {
     hipEventRecord(g_recs.back().b, s);
 }
 
+// launches the library issues on its own inside an entry point (the BatchNorm finalisation of a folded launch): timed under
+// g_nested_tag, or not at all when none is set
+int sv_prof_nested_scope(int enter) {
+    static thread_local int saved_tag = 0, saved_on = 0;
+    if (enter) {
+        saved_tag = g_tag;
+        saved_on = g_prof_on;
+        if (g_nested_tag >= 0) g_tag = g_nested_tag;
+        else g_prof_on = 0;
+    } else {
+        g_tag = saved_tag;
+        g_prof_on = saved_on;
+    }
+    return 0;
+}
+
 extern "C" {
 
 int sv_prof_enable(int on) {
@@ -183,6 +203,11 @@ int sv_prof_enable(int on) {
 
 int sv_prof_tag(int tag) {
     g_tag = tag;
+    return SV_OK;
+}
+
+int sv_prof_nested_tag(int tag) {
+    g_nested_tag = tag;
     return SV_OK;
 }
 
