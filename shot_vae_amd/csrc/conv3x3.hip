@@ -18,6 +18,10 @@
 #ifndef SV_C3P_INTERLEAVE
 #define SV_C3P_INTERLEAVE 1    // tile order of the persistent kernel: 1 = all blocks sweep one moving window, 0 = a contiguous range per block
 #endif
+#ifndef SV_C3P_DEPTH
+#define SV_C3P_DEPTH 2         // register stages of the halo (request distance in tiles); 3: one more stage, operands two tiles ahead
+                               // (measured: data gradient 92 -> 96 / 169 us without / with the weights in registers -- spills)
+#endif
 #ifndef SV_C3P_EOP_AHEAD
 #define SV_C3P_EOP_AHEAD 1     // the epilogue operand of a tile is requested one tile ahead (0: inside its own tile)
 #endif
@@ -320,7 +324,7 @@ __global__ __launch_bounds__(256, SV_C3P_WAVES) void conv3x3p_kernel(const sv_ge
     // two register stages: the halo of tile i+2 is requested while tile i is on the MFMAs, so every halo has
     // two full tile periods to arrive (at 2 blocks per CU one tile period does not cover the memory latency)
     struct HStage { V hv[HI]; bool hok[HI]; };
-    HStage HA, HB;
+    HStage HA, HB, HC;          // (HC: SV_C3P_DEPTH 3 only)
     auto load_halo = [&](HStage& S, int tile) {
         const int gr0 = tile * TR;
         const bool top_ok = (gr0 & (H - 1)) != 0, bot_ok = ((gr0 + TR) & (H - 1)) != 0;
@@ -374,6 +378,7 @@ __global__ __launch_bounds__(256, SV_C3P_WAVES) void conv3x3p_kernel(const sv_ge
 
     load_halo(HA, t_begin);
     if (t_begin + tstep < t_end) load_halo(HB, t_begin + tstep);
+    if (SV_C3P_DEPTH == 3 && t_begin + 2 * tstep < t_end) load_halo(HC, t_begin + 2 * tstep);
     store_halo(HA);
     __syncthreads();
     // 32 input channels: the block's 18 weight fragments stay in registers (72 of them: with the fusion flags at compile time
@@ -405,14 +410,19 @@ __global__ __launch_bounds__(256, SV_C3P_WAVES) void conv3x3p_kernel(const sv_ge
             }
         }
     };
-    EStage EA, EB;
-    if (SV_C3P_EOP_AHEAD && (hasR || hasEX)) load_eop(EA, t_begin);
+    EStage EA, EB, EC;
+    constexpr int HD = SV_C3P_DEPTH, ED = SV_C3P_DEPTH - 1;      // request distances in tiles: halo, epilogue operand
+    if (SV_C3P_EOP_AHEAD && (hasR || hasEX)) {
+        load_eop(EA, t_begin);
+        if (ED == 2 && t_begin + tstep < t_end) load_eop(EB, t_begin + tstep);
+    }
+    // FREE receives the halo of tile + HD, ENEXT the epilogue operand of tile + ED
     auto do_tile = [&](int tile, HStage& NEXT, HStage& FREE, EStage& ECUR, EStage& ENEXT) {
         const int gr0 = tile * TR;
-        // ---- request the halo two tiles ahead + the NEXT tile's epilogue operands; they fly during the MFMAs ----
+        // ---- request the halo HD tiles ahead + the epilogue operands ED tiles ahead; they fly during the MFMAs ----
         const bool more = tile + tstep < t_end;
-        if (tile + 2 * tstep < t_end) load_halo(FREE, tile + 2 * tstep);
-        if (SV_C3P_EOP_AHEAD) { if (more && (hasR || hasEX)) load_eop(ENEXT, tile + tstep); }
+        if (tile + HD * tstep < t_end) load_halo(FREE, tile + HD * tstep);
+        if (SV_C3P_EOP_AHEAD) { if (tile + ED * tstep < t_end && (hasR || hasEX)) load_eop(ENEXT, tile + ED * tstep); }
         else if (hasR || hasEX) load_eop(ECUR, tile);
         Q (&eop)[NT][2] = ECUR.v;
         int64_t obase[2];
@@ -502,9 +512,17 @@ __global__ __launch_bounds__(256, SV_C3P_WAVES) void conv3x3p_kernel(const sv_ge
         }
         __syncthreads();                               // next halo visible
     };
-    for (int tile = t_begin; tile < t_end; tile += 2 * tstep) {
-        do_tile(tile, HB, HA, EA, EB);
-        if (tile + tstep < t_end) do_tile(tile + tstep, HA, HB, EB, EA);
+    if (SV_C3P_DEPTH == 3) {
+        for (int tile = t_begin; tile < t_end; tile += 3 * tstep) {
+            do_tile(tile, HB, HA, EA, EC);
+            if (tile + tstep < t_end) do_tile(tile + tstep, HC, HB, EB, EA);
+            if (tile + 2 * tstep < t_end) do_tile(tile + 2 * tstep, HA, HC, EC, EB);
+        }
+    } else {
+        for (int tile = t_begin; tile < t_end; tile += 2 * tstep) {
+            do_tile(tile, HB, HA, EA, EB);
+            if (tile + tstep < t_end) do_tile(tile + tstep, HA, HB, EB, EA);
+        }
     }
     // ---- flush the per-channel sums once per block ---------------------------------------------------------
     if (want_sums) {
