@@ -795,7 +795,8 @@ def test_pool_kernels_vectorised(dt, B, Cc, HW, Gn):
 
 
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
-@pytest.mark.parametrize("M,N,ld", [(5000, 16, 16), (70001, 16, 16), (4099, 24, 32), (9000, 128, 128), (300, 16, 16), (4500, 4, 4)])
+@pytest.mark.parametrize("M,N,ld", [(5000, 16, 16), (70001, 16, 16), (4099, 24, 32), (9000, 128, 128), (300, 16, 16), (4500, 4, 4),
+                                    (2048, 256, 256), (2048, 1024, 1024)])   # (the linear layers of config 5: few rows, 128 per block)
 def test_colsum(dt, M, N, ld):
     """sv_colsum (bias gradients: column sums over all rows, accumulating into `out`): the 16-byte-load kernel (N and ld
     multiples of 8, >= 4096 rows; ragged row counts, a channel-group count that does not divide 256, a padded row
