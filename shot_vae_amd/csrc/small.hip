@@ -1373,7 +1373,17 @@ __global__ __launch_bounds__(256) void smooth_elbo_fwd_kernel(const float* data,
     t += (int64_t)blockIdx.x * ostride;
     const int64_t stride = (int64_t)gridDim.x * 256, t0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
     float s = 0.f;
-    for (int64_t i = t0; i < n; i += stride) { const float d = rec[i] - data[i]; s += d * d; }
+    {   // 16-byte loads (n is a multiple of 4: whole images), the tail element-wise
+        const int64_t n4 = n / 4;
+        const f32x4* r4 = reinterpret_cast<const f32x4*>(rec);
+        const f32x4* d4 = reinterpret_cast<const f32x4*>(data);
+        for (int64_t i = t0; i < n4; i += stride) {
+            const f32x4 a = r4[i], b = d4[i];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const float d = a[j] - b[j]; s += d * d; }
+        }
+        for (int64_t i = 4 * n4 + t0; i < n; i += stride) { const float d = rec[i] - data[i]; s += d * d; }
+    }
     float kc = 0.f;
     for (int64_t i = t0; i < (int64_t)B * Dc; i += stride) { const float m = mean[i], lv = logvar[i]; kc += -0.5f * (1.f + lv - m * m - expf(lv)); }
     float kd = 0.f, bc = 0.f;
@@ -2243,7 +2253,8 @@ int sv_smooth_elbo_fwd(const float* data, const float* rec, int64_t n_per_img, c
     SV_REQUIRE(data && rec && mean && logvar && alpha && sch && terms && coef && B > 0, SV_E_ARG, "sv_smooth_elbo_fwd: bad argument");
     const int64_t n = n_per_img * B;
     {
-        const int P = nblocks(n, 1024, 1024);
+        // (four float atomics per block on the same four addresses: 256 blocks, not 1 024 -- see sv_elbo_fwd)
+        const int P = nblocks(n / 4, 1024, 256);
         float* w = nullptr;
         if (sv_deterministic() && P > 1 && !(w = det_slots(P, 4, 1, (hipStream_t)stream))) return SV_E_HIP;
         hipLaunchKernelGGL(smooth_elbo_fwd_kernel, dim3(P), dim3(256), 0, (hipStream_t)stream,
