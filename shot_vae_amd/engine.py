@@ -520,9 +520,11 @@ class Engine:
         """Enqueue the weight gradient behind everything issued so far, on the side stream: the dgrad -> BN-apply
         chain continues on the main stream without waiting for it (joined at the end of backward).
         `then`: a callable that issues the main-stream launch paired with this weight gradient (the layer's data gradient).
-        It is issued FIRST -- the fork point is an event recorded before it -- so that the main stream, the critical path,
-        never waits for the host to finish the side stream's bookkeeping (tools/step_timeline.py showed ~8 us of idle main
-        stream per pair); the weight gradient still depends only on what preceded the pair."""
+        It is issued FIRST, so that the main stream, the critical path, never waits for the host to finish the side stream's
+        bookkeeping (tools/step_timeline.py showed ~8 us of idle main stream per pair), and it carries the fork: its first
+        block stores a sequence number the side stream waits for (sv_igemm_args::start_flag, sv_stream_wait_flag) -- no event
+        in the main stream's queue.  Without a `then` (or where dispatch is serialised: profilers) the fork is an event of the
+        library's pool.  Either way the weight gradient depends only on what preceded the pair."""
         # (not under hipGraph capture: a captured step replays a hundred cross-stream edges slower than one stream --
         #  11.6 against 11.05 ms, measured -- and tensors freed during capture would need to outlive the side stream)
         if not self.wgrad_side_stream or self.prof_tags is not None or torch.cuda.is_current_stream_capturing():
