@@ -72,6 +72,7 @@ def parse():
     ap.add_argument("--wgrad-after", type=int, default=0,
                     help="experiment: 1 = a body layer's weight gradient (side stream) starts when its data gradient has finished "
                          "instead of beside it (use with --pair-blocks 0)")
+    ap.add_argument("--compact-shortcut", type=int, default=1, help="0: the stride-2 shortcuts' data gradients in the strided (sparse_out) form")
     ap.add_argument("--recompute", type=int, default=0,
                     help="0: the narrow layers' data gradients write g and sv_bn_bwd_apply reads it back (instead of running twice)")
     ap.add_argument("--flag-fork", type=int, default=1, help="0: event forks for the paired weight gradients instead of the start signal")
@@ -554,6 +555,7 @@ def main():
     model._engine.light_fork = bool(a.light_fork)
     model._engine.flag_fork = bool(a.flag_fork)
     model._engine.recompute_bn_bwd = bool(a.recompute)
+    model._engine.compact_shortcut_grad = bool(a.compact_shortcut)
     model._engine.recompute_full_budget = a.recompute == 2
     if a.fork_every:
         model._engine.fork_every = a.fork_every

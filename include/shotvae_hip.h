@@ -210,11 +210,17 @@ typedef struct {
     int32_t replicas;           /* bsums is [replicas][2C]                                           */
     int32_t sparse;             /* wlog + 1 > 0: g is the data gradient of a STRIDE-2 layer written with sv_igemm_args::
                                    sparse_out -- defined at the even (row, column) positions of the 2^wlog-wide, 2^wlog-high
-                                   maps only and taken as zero elsewhere (not read there); 0: dense                    */
+                                   maps only and taken as zero elsewhere (not read there); 0: dense;
+                                   -(wlog + 1) < 0 (ABI 5): the same positions stored COMPACTLY, g [M / 4][ld] -- the data
+                                   gradient of a stride-2 1x1 layer computed as a dense 1x1 product over the stride-2 grid
+                                   (its raw tensor gathered with sv_gather_even)                                       */
 } sv_bn_branch;
 int sv_bn_bwd_apply(int dtype, int64_t M, int C, int ld, const void* x, const float* mean,
                     const float* rstd, float count, const sv_bn_branch* br, int nbranch,
                     const void* residual, void* dx, int groups, void* stream);
+
+/* out [B][H/2][W/2][C] = in [B][2y][2x][C]: the even positions of an NHWC tensor (C a multiple of 8)                      */
+int sv_gather_even(int dtype, const void* in, int B, int H, int W, int C, void* out, void* stream);
 
 /* ---- K8 global average pool fused with the transition BN+LeakyReLU (vae.py:107,143) ------------- */
 /* groups (0 = 1): B = ALL images, image b belongs to group b / (B / groups); coefficients [G][C], bsums [G][2C]     */

@@ -145,6 +145,7 @@ _PROTOS = {
     "sv_set_option": [I, I],
     "sv_get_option": [I],
     "sv_bn_bwd_coef": [P, I, I, F, P, P, P, P, P, I, P],
+    "sv_gather_even": [I, P, I, I, I, I, P, P],
     "sv_stream_fork": [P, P, I],
     "sv_stream_flag_next": [P, P, P],
     "sv_stream_wait_flag": [P, P, C.c_uint32],

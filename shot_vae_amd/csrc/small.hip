@@ -170,7 +170,7 @@ static bnb_params_g bnb_expand(const bnb_params& p, int groups, int es) {
             r.mean = p.mean + grp * p.C;
             r.rstd = p.rstd + grp * p.C;
             for (int k = 0; k < p.nbranch; ++k) {
-                r.br[k].g = reinterpret_cast<const char*>(p.br[k].g) + grp * ts;
+                r.br[k].g = reinterpret_cast<const char*>(p.br[k].g) + grp * (p.br[k].sparse < 0 ? ts / 4 : ts);
                 r.br[k].bsums = p.br[k].bsums + grp * p.br[k].replicas * 2 * p.C;
             }
         }
@@ -290,10 +290,14 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bnb_params_g PG
         for (int k = 0; k < 2; ++k) {
             if (k >= p.nbranch) break;
             // a sparse branch (stride-2 data gradient written with sv_igemm_args::sparse_out) exists at even (row, column) only
-            const int sp = p.br[k].sparse;
+            // (sparse < 0: the same positions stored COMPACTLY, [M / 4][ld]: the output of a dense 1x1 product over the stride-2 grid)
+            const int spr = p.br[k].sparse, sp = spr < 0 ? -spr : spr;
             if (sp > 0 && ((((int)(m >> (sp - 1))) | (int)m) & 1)) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) gv[k][j] = (T)0.f;
+            } else if (spr < 0) {
+                const int64_t mc = ((m >> (sp - 1)) >> 1 << (sp - 2)) + ((m & (((int64_t)1 << (sp - 1)) - 1)) >> 1);
+                gv[k] = __builtin_nontemporal_load(reinterpret_cast<const V*>(reinterpret_cast<const T*>(p.br[k].g) + mc * p.ld + c));
             } else {
                 gv[k] = __builtin_nontemporal_load(reinterpret_cast<const V*>(reinterpret_cast<const T*>(p.br[k].g) + off));
             }
@@ -1391,6 +1395,19 @@ __global__ __launch_bounds__(256) void tanh_to_nchw_bwd_px_kernel(const float* d
     for (int k = 1; k < ld / 8; ++k) row[k] = z;
 }
 
+// out[b][y][x][:] = in[b][2y][2x][:] -- the even positions of an NHWC tensor, compactly (the operand of a stride-2 1x1 layer's
+// data gradient run as a dense product over the stride-2 grid); one 16-byte vector per thread
+template <typename T>
+__global__ __launch_bounds__(256) void gather_even_kernel(const T* in, int64_t nvec, int Hq, int Wq, int cv, T* out) {
+    typedef typename V8<T>::type V;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= nvec) return;
+    const int v = (int)(i % cv);
+    const int64_t px = i / cv, x = px % Wq, by = px / Wq, y = by % Hq, b = by / Hq;
+    const int64_t src = ((b * (2 * Hq) + 2 * y) * (2 * Wq) + 2 * x) * cv + v;
+    reinterpret_cast<V*>(out)[i] = __builtin_nontemporal_load(reinterpret_cast<const V*>(in) + src);
+}
+
 // Trainer._loss_function (main_smooth_ELBO_svhn.py:228-310) raw terms: t[0] = num_pixels * MSE = sum (rec - x)^2 / B,
 // t[1] = KL_c (:312-335), t[2] = sum alpha log(alpha + EPS) / B (KL_d = log D + t[2], :368-388), t[3] = BCE(alpha, one-hot)
 // (mean over B * D; 0 without labels).  t must be zeroed by the caller.
@@ -1764,8 +1781,11 @@ int sv_bn_bwd_apply(int dtype, int64_t M, int C, int ld, const void* x, const fl
         p.br[k] = br[k];
         SV_REQUIRE(br[k].g && br[k].bsums && br[k].gamma && br[k].replicas >= 1, SV_E_ARG,
                    "sv_bn_bwd_apply: branch %d incomplete", k);
-        SV_REQUIRE(br[k].sparse >= 0 && br[k].sparse <= 16 && (br[k].sparse == 0 || M % ((int64_t)1 << (2 * (br[k].sparse - 1))) == 0),
-                   SV_E_ARG, "sv_bn_bwd_apply: branch %d sparse=%d does not match M", k, br[k].sparse);
+        {
+            const int sa = br[k].sparse < 0 ? -br[k].sparse : br[k].sparse;
+            SV_REQUIRE(sa <= 16 && (sa == 0 || M % ((int64_t)1 << (2 * (sa - 1))) == 0) && (br[k].sparse >= 0 || sa >= 2),
+                       SV_E_ARG, "sv_bn_bwd_apply: branch %d sparse=%d does not match M", k, br[k].sparse);
+        }
     }
     groups = sv_ngroups(groups);
     SV_REQUIRE(groups <= SV_MAX_GROUPS, SV_E_ARG, "sv_bn_bwd_apply: groups=%d (at most %d)", groups, SV_MAX_GROUPS);
@@ -2342,6 +2362,15 @@ int sv_nchw_to_nhwc(int dtype, const float* in, int B, int C, int H, int W, int 
     DISPATCH_T(dtype, hipLaunchKernelGGL((nchw_to_nhwc_kernel<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
                                          (hipStream_t)stream, in, B, C, H * W, Cpad, (T*)out));
     return sv_check_launch("sv_nchw_to_nhwc");
+}
+int sv_gather_even(int dtype, const void* in, int B, int H, int W, int C, void* out, void* stream) {
+    SvProfScope prof_scope(stream);
+    SV_REQUIRE(in && out && B > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, SV_E_ARG, "sv_gather_even: bad argument (B=%d H=%d W=%d)", B, H, W);
+    SV_REQUIRE(C % 8 == 0, SV_E_SHAPE, "sv_gather_even: C=%d must be a multiple of 8", C);
+    const int64_t nvec = (int64_t)B * (H / 2) * (W / 2) * (C / 8);
+    DISPATCH_T(dtype, hipLaunchKernelGGL((gather_even_kernel<T>), dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                                         (const T*)in, nvec, H / 2, W / 2, C / 8, (T*)out));
+    return sv_check_launch("sv_gather_even");
 }
 int sv_augment(int dtype, const uint8_t* data, const int64_t* index, const int32_t* params, int B, int H, int W, int C,
                int pad, int nhwc_cpad, void* out, void* stream) {

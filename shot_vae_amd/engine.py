@@ -22,6 +22,7 @@ import torch
 
 from . import _lib as L
 from . import geometry as G
+_GEOM = G          # (functions below use G for the number of groups)
 
 LEAKY_SLOPE = 0.01     # nn.LeakyReLU default, wideresnet.py:28
 BN_EPS = 1e-5
@@ -491,6 +492,7 @@ class Engine:
 
     wgrad_side_stream = True      # weight gradients on a side stream (they are off the backward's critical path)
     sparse_shortcut_grad = True      # stride-2 1x1 shortcuts: data gradient written / read at the even positions only
+    compact_shortcut_grad = True     # ... as a dense 1x1 product over the stride-2 grid, stored compactly (bf16)
     materialize_decoder_act = True   # BatchNorm + ReLU of the first decoder layers' inputs as a pass of its own (see forward)
     materialize_max_hin = 4          # ... for the layers whose input map is at most this large
     light_fork = True                # fork events without the system-scope fence (sv_stream_fork)
@@ -940,14 +942,14 @@ class Engine:
                 return (raw, sc, sh, mn, rs, b.slope, alloc, None)
             return (raw, sc, sh, mn, rs, b.slope, bs_off[b.index], bs_rep[b.index])
 
-        def bn_apply(raw, branches, residual, count, Gx=None, sparse=()):
+        def bn_apply(raw, branches, residual, count, Gx=None, sparse=(), compact=False):
             """branches: [(g tensor, BNSpec)] sharing `raw`; returns dL/d(raw) (+ residual).  count = rows of ONE group.
             sparse: indices of branches whose g was written with sparse_out (defined at even positions only)."""
             Gx = Gx or G
             arr = (L.SvBnBranch * len(branches))()
             for k, (g, b) in enumerate(branches):
                 arr[k].g = g.data_ptr()
-                arr[k].sparse = (int(raw.shape[2]).bit_length()) if k in sparse else 0     # log2(W) + 1
+                arr[k].sparse = ((-1 if compact else 1) * int(raw.shape[2]).bit_length()) if k in sparse else 0     # +-(log2(W) + 1)
                 arr[k].bsums = bs_off[b.index]
                 arr[k].gamma = pbase + 4 * b.gamma_off
                 arr[k].dgamma = gbase + 4 * b.gamma_off
@@ -1102,7 +1104,24 @@ class Engine:
                                                        groups=G, budget=pair1))
             del dc1
             cnt = tin.numel() // tin.shape[-1] // G
-            if "convi" in un:
+            if "convi" in un and un["stride"] == 2 and self.compact_shortcut_grad and self.code == L.SV_BF16 and not det:
+                # the stride-2 shortcut's data gradient as a DENSE 1x1 product over the stride-2 grid: the raw tensor's even
+                # positions are gathered once (sv_gather_even), the gradient is stored compactly and sv_bn_bwd_apply reads it
+                # that way (sv_bn_branch::sparse < 0) -- instead of a strided epilogue operand and strided 64-byte row stores
+                Hq = tin.shape[1] // 2
+                tin_c = torch.empty(tin.shape[0], Hq, Hq, un["cin"], dtype=tin.dtype, device=dev)
+                L.call("sv_gather_even", self.code, _vp(tin.data_ptr()), tin.shape[0], tin.shape[1], tin.shape[2], un["cin"],
+                       _vp(tin_c.data_ptr()), st)
+                gi_ = torch.empty_like(tin_c)
+                gdense = _GEOM.conv_like(B, Hq, Hq, c, un["cin"], 1, 1, 0)
+                self._wgrad_async(un["convi"].geom_fwd(B), tin, proi, D, gbase + 4 * un["convi"].master_off,
+                                  tag="wgrad:conv1x1_%dx%d" % (un["cin"], c), groups=G,
+                                  then=lambda: self._igemm(gdense, D, pk + es * un["convi"].dgrad_off, gi_,
+                                                           ex=ex_of(un["bni"], tin_c),
+                                                           tag="dgrad:conv1x1_%dx%d" % (un["cin"], c), groups=G))
+                D = bn_apply(tin, [(g1, un["bn1"]), (gi_, un["bni"])], None, cnt, sparse=(1,), compact=True)
+                del tin_c
+            elif "convi" in un:
                 gi_ = torch.empty_like(tin)
                 # a stride-2 shortcut's data gradient is zero at three of four positions: those are neither written nor read
                 sp = un["stride"] == 2 and self.sparse_shortcut_grad

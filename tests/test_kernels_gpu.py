@@ -1182,6 +1182,45 @@ def test_recomputing_data_gradient_equals_g_plus_bn_bwd_apply(B, Cc, H, Gn, with
         L.call("sv_igemm", C.byref(gw), L.SV_BF16, C.byref(a), st())
 
 
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("B,Cc,H,Gn", [(6, 32, 32, 2), (4, 64, 16, 1), (3, 16, 8, 3)])
+def test_compact_shortcut_branch_equals_strided(dt, B, Cc, H, Gn):
+    """sv_gather_even + sv_bn_branch::sparse < 0 (ABI 5): a BatchNorm-backward branch that exists at the even positions only,
+    stored compactly [M / 4][C] (the data gradient of a stride-2 1x1 layer run as a dense product over the stride-2 grid),
+    gives bit for bit the dx of the same branch in the strided form (sparse > 0); the gather returns exactly the even
+    positions."""
+    code, tdt, tol = DT[dt]
+    d = dev()
+    torch.manual_seed(31)
+    x = torch.randn(Gn * B, H, H, Cc, device=d).to(tdt)
+    g1 = torch.randn(Gn * B, H, H, Cc, device=d).to(tdt)
+    gs = torch.full((Gn * B, H, H, Cc), float("nan"), device=d).to(tdt)           # strided: odd positions are never read
+    gs[:, ::2, ::2] = torch.randn(Gn * B, H // 2, H // 2, Cc, device=d).to(tdt)
+    gc = torch.empty(Gn * B, H // 2, H // 2, Cc, device=d, dtype=tdt)
+    L.call("sv_gather_even", code, p(gs), Gn * B, H, H, Cc, p(gc), st())
+    torch.cuda.synchronize()
+    assert torch.equal(gc, gs[:, ::2, ::2].contiguous())
+    mean, rstd = (torch.randn(Gn, Cc, device=d) * 0.1).contiguous(), (torch.rand(Gn, Cc, device=d) + 0.5).contiguous()
+    gam1, gam2 = torch.rand(Cc, device=d) + 0.5, torch.rand(Cc, device=d) + 0.5
+    R = 4
+    bs1, bs2 = torch.randn(Gn, R, 2 * Cc, device=d), torch.randn(Gn, R, 2 * Cc, device=d)
+    wl1 = int(H).bit_length()
+
+    def run(g2, sparse):
+        br_ = (L.SvBnBranch * 2)()
+        dg = [torch.zeros(Cc, device=d) for _ in range(4)]
+        for k, (g_, b_, gm, sp) in enumerate(((g1, bs1, gam1, 0), (g2, bs2, gam2, sparse))):
+            br_[k].g, br_[k].bsums, br_[k].gamma, br_[k].replicas, br_[k].sparse = g_.data_ptr(), b_.data_ptr(), gm.data_ptr(), R, sp
+            br_[k].dgamma, br_[k].dbeta = dg[2 * k].data_ptr(), dg[2 * k + 1].data_ptr()
+        dx = torch.empty_like(x)
+        L.call("sv_bn_bwd_apply", code, B * H * H, Cc, Cc, p(x), p(mean), p(rstd), float(B * H * H), br_, 2, None, p(dx), Gn, st())
+        torch.cuda.synchronize()
+        return dx
+
+    a, b = run(gs, wl1), run(gc, -wl1)
+    assert bool(torch.isfinite(a.float()).all()) and torch.equal(a, b)
+
+
 def test_rank_permutation():
     """sv_rank_permutation: perm = argsort of the keys (ties: the lower index first), several batches per launch, sizes up
     to a full minibatch."""
