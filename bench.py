@@ -77,6 +77,10 @@ def parse():
     ap.add_argument("--fuse-bn-bwd", type=int, default=-1,
                     help="norm2's BatchNorm backward in the load path of conv1's data gradient (sv_igemm_args::x2): 0 = off (an "
                          "sv_bn_bwd_apply pass instead), 1 = the same-shape units (side output for the weight gradient), 2 = every unit, 3 = data AND weight gradient form it themselves (32 / 64 channels), -1 = the engine default")
+    ap.add_argument("--fused-bwd", type=int, default=-1,
+                    help="sv_bwd3x3, the one-launch backward of the 32-channel body convolutions: 0 = off (data / weight gradient pair + "
+                         "sv_bn_bwd_apply), 1 = conv1 of the same-shape units with norm2's BatchNorm backward in its load path, 2 = conv2 too, "
+                         "-1 = the engine default")
     ap.add_argument("--fuse-max-channels", type=int, default=0, help="(with --fuse-bn-bwd 3) widest fused layer (0 = the engine's default)")
     ap.add_argument("--fused-wgrad-paired", type=int, default=-1, help="(with --fuse-bn-bwd) block budget of the weight gradient forked behind the fused data gradient: 1 = the pair budget, 0 = full")
     ap.add_argument("--flag-fork", type=int, default=1, help="0: event forks for the paired weight gradients instead of the start signal")
@@ -584,6 +588,8 @@ def main():
     model._engine.flag_fork = bool(a.flag_fork)
     if a.fuse_bn_bwd >= 0:
         model._engine.fuse_bn_bwd = a.fuse_bn_bwd
+    if a.fused_bwd >= 0:
+        model._engine.fused_bwd = a.fused_bwd
     if a.fuse_max_channels:
         model._engine.fuse_max_channels = a.fuse_max_channels
     if a.fused_wgrad_paired >= 0:

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define SV_ABI_VERSION 6
+#define SV_ABI_VERSION 7
 
 enum { SV_F32 = 0, SV_BF16 = 1 };
 /* ABI 6: the per-channel ACCUMULATORS of the BatchNorm statistics and backward sums (sv_igemm_args::stats / bsums / fold_stats,
@@ -190,6 +190,45 @@ typedef struct {
     const float* dy_shift;
 } sv_wgrad_args;
 int sv_wgrad_ex(const sv_geom* g, int dtype, const sv_wgrad_args* a, void* stream);
+
+/* ---- fused backward of a narrow stride-1 3x3 convolution (ABI 7): data gradient + weight gradient in ONE launch ----------
+ * Replaces, for the 32 -> 32 channel body convolutions of WideResNet-28-2 (wideresnet.py:29-35 under autograd), the PAIR
+ *     sv_igemm(geom_dgrad, x = dy, ex = raw input ...)   +   sv_wgrad_ex(geom_fwd, x = raw input, dy ...)
+ * and, in the two-tensor form (dy2 != NULL), the sv_bn_bwd_apply pass in front of that pair too.  One persistent kernel stages a
+ * tile of dy (with its halo) and of the raw input ONCE and feeds both products from the same LDS image: 3 tensor passes (4 in the
+ * two-tensor form) where the pair makes 5 (8).  `g` is the layer's DATA-gradient geometry (one phase of nine taps); bf16 only.
+ *   out[q][c]         = act'(x[q][c] * x_scale[c] + x_shift[c]) * sum_{t,n} dyeff[q + d(t)][n] * w[c][t][n]        (= sv_igemm's
+ *                       ex epilogue, bit for bit), bsums[R][2C] += (sum out, sum out * (x - x_mean) * x_rstd)
+ *   dw[n][torig(t)][c] += sum_q dyeff[q + d(t)][n] * act(x[q][c] * x_scale[c] + x_shift[c])
+ *   dyeff = dy, or dy_scale[n] * dy + dy_scale2[n] * dy2 + dy_shift[n] (the coefficients of sv_bn_bwd_affine: the BatchNorm
+ *           backward of the layer BEHIND the convolution; same expression and rounding as sv_igemm_args::x2 / sv_wgrad_args::dy2)
+ * groups (0 = 1): as sv_igemm_args -- tensors [G][B][H][W][32], vectors [G][32], bsums [G][R][64]; dw sums over the groups.
+ * ws: caller-owned fp32 workspace of >= blocks * groups * 9216 floats (blocks <= block_budget, default 256), contents irrelevant:
+ * one partial slab per block, reduced into dw (+=, float atomics) by a second launch.  Not available under SV_OPT_DETERMINISTIC. */
+typedef struct {
+    const void* dy;             /* [G][B,H,W,32] gradient behind the convolution's output (or behind the BatchNorm after it)   */
+    const void* dy2;            /* NULL, or that BatchNorm's raw input (= the convolution's own output)                         */
+    const float* dy_scale;      /* [G][32] each; required with dy2                                                             */
+    const float* dy_scale2;
+    const float* dy_shift;
+    const void* x;              /* [G][B,H,W,32] RAW input of the BatchNorm in front of the convolution                        */
+    const float* x_scale;       /* [G][32] each: that BatchNorm's scale / shift / mean / rstd (sv_bn_finalize)                 */
+    const float* x_shift;
+    const float* x_mean;
+    const float* x_rstd;
+    float x_slope;              /* LeakyReLU slope in [0, 1]                                                                   */
+    const void* w;              /* the layer's data-gradient pack (sv_repack with geom_dgrad), bf16                            */
+    void* out;                  /* [G][B,H,W,32]                                                                                */
+    sv_acc_t* bsums;            /* [G][R][64]                                                                                   */
+    int32_t replicas;
+    int32_t groups;
+    float* dw;                  /* master layout [32][9][32], += */
+    float* ws;
+    int64_t ws_elems;
+    int32_t block_budget;       /* 0 = 256 */
+    int32_t reserved0;
+} sv_bwd3x3_args;
+int sv_bwd3x3(const sv_geom* g, int dtype, const sv_bwd3x3_args* a, void* stream);
 
 /* column sums: out[n] += sum_m y[m*ld + n]   (conv0 bias gradient)                                  */
 int sv_colsum(int dtype, const void* y, int64_t M, int N, int ld, float* out, void* stream);

@@ -13,6 +13,7 @@ LIB_PATH = os.environ.get("SV_LIB_PATH") or os.path.join(HERE, "libshotvae_hip.s
 CSRC = os.path.join(HERE, "csrc")
 
 SV_F32, SV_BF16 = 0, 1
+ABI_VERSION = 7                  # include/shotvae_hip.h: SV_ABI_VERSION
 MAX_TAPS, MAX_PHASES = 16, 4
 
 
@@ -47,6 +48,14 @@ class SvWgradArgs(C.Structure):
                 ("dy", C.c_void_p), ("dw", C.c_void_p), ("splits", C.c_int32), ("use_tr", C.c_int32), ("ws", C.c_void_p),
                 ("ws_elems", C.c_int64), ("groups", C.c_int32), ("block_budget", C.c_int32),
                 ("dy2", C.c_void_p), ("dy_scale", C.c_void_p), ("dy_scale2", C.c_void_p), ("dy_shift", C.c_void_p)]
+
+
+class SvBwd3x3Args(C.Structure):
+    _fields_ = [("dy", C.c_void_p), ("dy2", C.c_void_p), ("dy_scale", C.c_void_p), ("dy_scale2", C.c_void_p), ("dy_shift", C.c_void_p),
+                ("x", C.c_void_p), ("x_scale", C.c_void_p), ("x_shift", C.c_void_p), ("x_mean", C.c_void_p), ("x_rstd", C.c_void_p),
+                ("x_slope", C.c_float), ("w", C.c_void_p), ("out", C.c_void_p), ("bsums", C.c_void_p), ("replicas", C.c_int32),
+                ("groups", C.c_int32), ("dw", C.c_void_p), ("ws", C.c_void_p), ("ws_elems", C.c_int64), ("block_budget", C.c_int32),
+                ("reserved0", C.c_int32)]
 
 
 class SvRepackJob(C.Structure):
@@ -101,6 +110,7 @@ _PROTOS = {
     "sv_igemm_query_blocks": [C.POINTER(SvGeom), I, C.POINTER(SvIgemmArgs), C.POINTER(C.c_int)],
     "sv_wgrad": [C.POINTER(SvGeom), I, P, P, P, F, P, P, I, I, P, I64, I, P],
     "sv_wgrad_ex": [C.POINTER(SvGeom), I, C.POINTER(SvWgradArgs), P],
+    "sv_bwd3x3": [C.POINTER(SvGeom), I, C.POINTER(SvBwd3x3Args), P],
     "sv_colsum": [I, P, I64, I, I, P, P],
     "sv_bn_finalize": [P, I, I, F, P, P, F, F, P, P, P, P, P, P, I, P],
     "sv_bn_eval_affine": [I, P, P, P, P, F, P, P, P],
@@ -202,6 +212,10 @@ def lib():
             fn.restype = C.c_int
         L.sv_last_error.argtypes = []
         L.sv_last_error.restype = C.c_char_p
+        # the structs above mirror ONE ABI: a stale library would misread accumulator widths / struct sizes silently
+        if L.sv_version() != ABI_VERSION:
+            raise ShotVaeHipError("libshotvae_hip.so is ABI %d, this package is written for ABI %d: rebuild (make -C shot_vae_amd/csrc)"
+                                  % (L.sv_version(), ABI_VERSION))
         _lib = L
     return _lib
 
@@ -230,7 +244,7 @@ class options:
 # in-situ timing (bench.py): tag name -> id; every entry point is filed under its own name unless the engine filed the
 # launch under a per-layer tag first (Engine._tag, for sv_igemm / sv_wgrad)
 prof_tags = None
-_LAYER_TAGGED = ("sv_igemm", "sv_igemm_query_blocks", "sv_wgrad", "sv_wgrad_ex", "sv_prof_tag", "sv_prof_enable", "sv_set_option")
+_LAYER_TAGGED = ("sv_igemm", "sv_igemm_query_blocks", "sv_wgrad", "sv_wgrad_ex", "sv_bwd3x3", "sv_prof_tag", "sv_prof_enable", "sv_set_option")
 
 
 def deterministic():

@@ -517,6 +517,11 @@ class Engine:
     fused_wgrad_paired = True        # ... its weight gradient (forked behind the data gradient) with the paired block budget
     fuse_bn_bwd = 0
     fuse_max_channels = 64           # (mode 3) widest layer whose data AND weight gradient form dx themselves
+    # sv_bwd3x3 (ABI 7): data gradient + weight gradient of a 32 -> 32 channel body convolution in ONE launch that reads every
+    # operand once.  1 = conv1 of the same-shape units in the two-tensor form (norm2's BatchNorm backward formed in the kernel's
+    # load path: the sv_bn_bwd_apply pass between the unit's two data gradients disappears: 8 tensor passes -> 4);
+    # 2 = conv2 of every 32-channel unit as well (5 passes -> 3).  bf16, not in deterministic mode.
+    fused_bwd = 1
     flag_fork = True                 # paired launches: the data gradient's start signal forks the side stream (no event)
     _start_signal = None
     _pending_wgrads = ()
@@ -643,6 +648,29 @@ class Engine:
         a.splits, a.use_tr, a.ws, a.ws_elems = 0, self.use_tr, self._wg_ws().data_ptr(), self._ws_elems
         a.groups, a.block_budget = groups, budget          # the budget is an argument of THIS launch, not process state
         L.call("sv_wgrad_ex", C.byref(g), self.code, C.byref(a), self._stream())
+
+    def _bwd3x3(self, cv, B, dy, lin2, x, bn_ptrs, slope, out, bsums, replicas, tag, groups, budget=0):
+        """sv_bwd3x3: data gradient (activation-backward epilogue of the BatchNorm in front: bn_ptrs = scale, shift, mean, rstd) and
+        weight gradient of the stride-1 3x3 convolution `cv` in one launch; lin2 = (dy2 tensor, scale, scale2, shift pointers)"""
+        g = cv.geom_dgrad(B)
+        if tag:
+            # algorithmic cost: dy [+ dy2] and x read once, g written; both products' flops
+            n = groups * g.B * g.Hin * g.Win * g.Cin
+            es = self.packs.element_size()
+            if self.prof_tags is not None:
+                L.lib().sv_prof_tag(self.prof_tags.setdefault(tag, len(self.prof_tags)))
+            self._cost(tag, es * n * (3 + (lin2 is not None)) + 4 * 9 * g.Cin * g.N, 2 * 2.0 * n * 9 * g.N)
+        a = L.SvBwd3x3Args()
+        a.dy, a.x, a.out = dy.data_ptr(), x.data_ptr(), out.data_ptr()
+        if lin2 is not None:
+            a.dy2, a.dy_scale, a.dy_scale2, a.dy_shift = lin2[0].data_ptr(), lin2[1], lin2[2], lin2[3]
+        a.x_scale, a.x_shift, a.x_mean, a.x_rstd = bn_ptrs
+        a.x_slope = slope
+        a.w = self.packs.data_ptr() + self.packs.element_size() * cv.dgrad_off
+        a.bsums, a.replicas, a.groups = bsums, replicas, groups
+        a.dw = self.grad.data_ptr() + 4 * cv.master_off
+        a.ws, a.ws_elems, a.block_budget = self._wg_ws().data_ptr(), self._ws_elems, budget
+        L.call("sv_bwd3x3", C.byref(g), self.code, C.byref(a), self._stream())
 
     # ------------------------------------------------------------------------------- forward
     def _bn_layout(self, G):
@@ -1103,11 +1131,17 @@ class Engine:
             same = un["stride"] == 1 and un["cin"] == c
             cnt2 = c1.numel() // c // G
             g2 = torch.empty_like(c1)
-            self._wgrad_async(un["conv2"].geom_fwd(B), c1, pro2, D, gbase + 4 * un["conv2"].master_off,
-                              tag="wgrad:conv3x3_%dx%d_s1" % (c, c), groups=G, budget=pair,
-                              then=lambda: self._igemm(un["conv2"].geom_dgrad(B), D, pk + es * un["conv2"].dgrad_off, g2,
-                                                       ex=ex_of(un["bn2"], c1), tag="dgrad:conv3x3_%dx%d_s1" % (c, c),
-                                                       groups=G, budget=pair))
+            fb = self.fused_bwd if (self.code == L.SV_BF16 and not det and c == 32 and c1.shape[1] in (8, 16, 32)
+                                    and (B * c1.shape[1]) % (128 // c1.shape[1]) == 0) else 0
+            if fb >= 2:
+                self._bwd3x3(un["conv2"], B, D, None, c1, bnp(un["bn2"]), un["bn2"].slope, g2, bs_off[un["bn2"].index],
+                             bs_rep[un["bn2"].index], "bwd:conv3x3_%dx%d_s1" % (c, c), G)
+            else:
+                self._wgrad_async(un["conv2"].geom_fwd(B), c1, pro2, D, gbase + 4 * un["conv2"].master_off,
+                                  tag="wgrad:conv3x3_%dx%d_s1" % (c, c), groups=G, budget=pair,
+                                  then=lambda: self._igemm(un["conv2"].geom_dgrad(B), D, pk + es * un["conv2"].dgrad_off, g2,
+                                                           ex=ex_of(un["bn2"], c1), tag="dgrad:conv3x3_%dx%d_s1" % (c, c),
+                                                           groups=G, budget=pair))
             # (the in-situ table times every launch ALONE: the strided pair's budget only makes sense beside its weight gradient)
             pair1 = pair if same else (min(pair, self.pair_blocks_strided) if self.prof_tags is None else 0)
             cnt = tin.numel() // tin.shape[-1] // G
@@ -1116,7 +1150,15 @@ class Engine:
             fuse = self.fuse_bn_bwd if (self.code == L.SV_BF16 and not det) else 0
             if fuse >= 3 and not (same and c <= self.fuse_max_channels):
                 fuse = 0                  # (both consumers form dx themselves only on the persistent narrow kernels' shapes)
-            if fuse and (same or fuse == 2):
+            if fb >= 1 and same:
+                # conv1's WHOLE backward in one launch: dc1 = norm2's BatchNorm backward of g2 is formed in its load path from
+                # (g2, c1) and the finished sums (sv_bn_bwd_affine), both products run from that one LDS image
+                coef, sg, sx, sh = bn_affine(un["bn2"], cnt2)
+                self._bwd3x3(un["conv1"], B, g2, (c1, sg, sx, sh), tin, bnp(un["bn1"]), un["bn1"].slope, g1,
+                             bs_off[un["bn1"].index], bs_rep[un["bn1"].index], "bwd:" + tag1 + "+bn", G)
+                del coef
+                dc1 = None
+            elif fuse and (same or fuse == 2):
                 # norm2's backward is formed in the load path of conv1's data gradient (sv_igemm_args::x2): dx = scale_g * g2 +
                 # scale_x * c1 + shift from the finished sums (sv_bn_bwd_affine, one small launch), written once as a side
                 # output for the weight gradient -- no sv_bn_bwd_apply pass (two reads, one write) between the two data

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), "missing export " + n
     assert set(names) == set(L.EXPORTS), set(names) ^ set(L.EXPORTS)
-    assert L.lib().sv_version() == 6
+    assert L.lib().sv_version() == L.ABI_VERSION == 7
 
 
 def test_struct_layout_matches_header():
@@ -34,6 +34,7 @@ def test_struct_layout_matches_header():
     assert ctypes.sizeof(L.SvGeom) == 72 + 4 * 72
     assert ctypes.sizeof(L.SvIgemmArgs) == 31 * 8
     assert ctypes.sizeof(L.SvWgradArgs) == 14 * 8
+    assert ctypes.sizeof(L.SvBwd3x3Args) == 19 * 8
     assert ctypes.sizeof(L.SvParamJob) == 14 * 8
     assert ctypes.sizeof(L.SvBnBranch) == 48
     assert ctypes.sizeof(L.SvRepackJob) == 64
@@ -164,7 +165,7 @@ sys.path.insert(0, %r)
 from shot_vae_amd import _lib as L
 from shot_vae_amd.engine import Plan
 lib = L.lib()
-assert lib.sv_version() == 6
+assert lib.sv_version() == L.ABI_VERSION
 n_ok = n_err = 0
 for net, K in (("wideresnet-28-2", 10), ("wideresnet-28-10", 100), ("wideresnet-10-1", 10)):
     plan = Plan(net, K=K)
@@ -223,6 +224,20 @@ for cv in (plan.units[1]["conv1"], plan.units[0]["conv1"], plan.units[4]["conv1"
         blocks = C.c_int(-1)
         rc = lib.sv_igemm_query_blocks(C.byref(cv.geom_dgrad(8)), L.SV_BF16, C.byref(a), C.byref(blocks))
         assert rc != 0 or blocks.value > 0
+# ABI 7: the fused backward's argument checks (nothing is launched on a refusal)
+assert lib.sv_bwd3x3(None, L.SV_BF16, None, None) != 0 and b"null" in lib.sv_last_error()
+fb = L.SvBwd3x3Args()
+fb.dy = fb.x = fb.w = fb.out = fb.dw = fb.ws = fb.bsums = fb.x_scale = fb.x_shift = fb.x_mean = fb.x_rstd = 4096
+fb.replicas, fb.groups, fb.ws_elems, fb.x_slope = 4, 4, 1 << 22, 0.01
+assert lib.sv_bwd3x3(C.byref(plan.units[1]["conv1"].geom_dgrad(8)), L.SV_F32, C.byref(fb), None) != 0 and b"bf16" in lib.sv_last_error()
+assert lib.sv_bwd3x3(C.byref(plan.units[5]["conv1"].geom_dgrad(8)), L.SV_BF16, C.byref(fb), None) != 0 and b"32 input" in lib.sv_last_error()
+assert lib.sv_bwd3x3(C.byref(plan.units[1]["conv1"].geom_fwd(8)), L.SV_BF16, C.byref(fb), None) != 0 and b"tap" in lib.sv_last_error()
+assert lib.sv_bwd3x3(C.byref(plan.units[1]["conv1"].geom_dgrad(8)), L.SV_BF16, C.byref(fb), None) != 0 and b"deterministic" in lib.sv_last_error()
+assert lib.sv_set_option(4, 0) == 0
+fb.ws_elems = 100
+assert lib.sv_bwd3x3(C.byref(plan.units[1]["conv1"].geom_dgrad(8)), L.SV_BF16, C.byref(fb), None) != 0 and b"workspace" in lib.sv_last_error()
+fb.ws_elems, fb.dy2 = 1 << 22, 4096
+assert lib.sv_bwd3x3(C.byref(plan.units[1]["conv1"].geom_dgrad(8)), L.SV_BF16, C.byref(fb), None) != 0 and b"two-tensor" in lib.sv_last_error()
 assert lib.sv_bn_bwd_affine(None, 1, 32, 64.0, None, None, None, None, None, None, None, None, 1, None) != 0
 assert lib.sv_param_gather(L.SV_BF16, None, 3, 3, None, None) != 0 and lib.sv_param_scatter_add(None, 0, 0, None, None) != 0
 assert lib.sv_param_gather(L.SV_BF16, 4096, 0, 0, 4096, None) == 0            # an empty table launches nothing
