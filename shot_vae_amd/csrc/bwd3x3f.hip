@@ -52,16 +52,24 @@ constexpr int CH = 32;
 #ifndef SV_BWDF_ABL
 #define SV_BWDF_ABL 0
 #endif
+// Fragment sets of the weight-gradient waves (compute_g): 1 = all ten fragments of a 32-pixel chunk at once (40 registers), 2 = two
+// groups of 5 + 4 taps (24), 3 = two full sets, double-buffered (80).  Order of the weight-gradient waves' iteration (GFIRST): 1 = they
+// stage the next tile BEFORE their MFMAs.  Measured alone at 4 x 512 images (tools/probes/bwdf_ablate.sh): plain 125 / 115 / 121 us
+// with 2 / 1 / 3 (133 / 130 / 126 staged first); two-tensor 143 / 143 / 143 (143 / 135 / 137 staged first).  The two-tensor form at
+// 16- and 8-pixel maps keeps two groups: ten fragments spill there.
 #ifndef SV_BWDF_FRAGS
-#define SV_BWDF_FRAGS 2
+#define SV_BWDF_FRAGS 1
 #endif
 #ifndef SV_BWDF_FRAGS_LIN2
-#define SV_BWDF_FRAGS_LIN2 2
+#define SV_BWDF_FRAGS_LIN2 1
 #endif
 #ifndef SV_BWDF_GFIRST
-#define SV_BWDF_GFIRST 0          // 1: the weight-gradient waves stage the next tile BEFORE their MFMAs
+#define SV_BWDF_GFIRST 0
 #endif
-constexpr int wregs_of(bool lin2) { return lin2 ? SV_BWDF_WREGS_LIN2 : SV_BWDF_WREGS; }
+#ifndef SV_BWDF_GFIRST_LIN2
+#define SV_BWDF_GFIRST_LIN2 1
+#endif
+constexpr int wregs_of(bool lin2, int wlog) { return wlog != 5 ? (lin2 ? 0 : 1) : lin2 ? SV_BWDF_WREGS_LIN2 : SV_BWDF_WREGS; }      // (16- / 8-pixel maps: half of them, no spills)
 
 struct bwdf_params {
     const void* dy;
@@ -102,8 +110,10 @@ __global__ __launch_bounds__(512) void bwd3x3f_kernel(const sv_geom g, const bwd
     const bwdf_params& p = PG.g[blockIdx.y];
     typedef bf16x8 V;
     typedef bf16x4 Q;
-    constexpr int WREGS = wregs_of(LIN2);
-    constexpr int FRAGS = LIN2 ? SV_BWDF_FRAGS_LIN2 : SV_BWDF_FRAGS;       // fragment sets of the weight-gradient waves (see compute_g)
+    constexpr int WREGS = wregs_of(LIN2, WLOG);
+    // (tuned for the 32 x 32 maps the step runs it on; the other map sizes keep the variant that does not spill)
+    constexpr int FRAGS = WLOG != 5 ? 2 : LIN2 ? SV_BWDF_FRAGS_LIN2 : SV_BWDF_FRAGS;       // fragment sets of the weight-gradient waves
+    constexpr bool GFIRST = WLOG == 5 && (LIN2 ? SV_BWDF_GFIRST_LIN2 : SV_BWDF_GFIRST);
     constexpr int WLROWS = (2 - WREGS) * 16 * 9;       // LDS rows of weights [c][tap] of the tiles that are not register-resident
     constexpr int W = 1 << WLOG, TR = 128 / W, WP = W + 2;
     // LDS halo rows: row 0 / the last row are the vertical halo; when a tile holds two whole images (W = 8) a zero spacer row
@@ -434,10 +444,10 @@ __global__ __launch_bounds__(512) void bwd3x3f_kernel(const sv_geom g, const bwd
         auto iter = [&](int tile, int stage, Stage& S) __attribute__((always_inline)) {
             // (every request is issued UNCONDITIONALLY, past the end as a harmless re-load of the block's last tile: with a request
             //  behind a branch the compiler's wait for S must also be right for the path that skipped it, i.e. it drains the queue)
-            if (!SV_BWDF_GFIRST && !(SV_BWDF_ABL & 1)) compute_g(stage);
+            if (!GFIRST && !(SV_BWDF_ABL & 1)) compute_g(stage);
             if (!(SV_BWDF_ABL & 8)) store_stage(S, min(tile + tstep, t_last), stage ^ 1);
             if (!(SV_BWDF_ABL & 4)) load_stage(S, min(tile + 3 * tstep, t_last));
-            if (SV_BWDF_GFIRST && !(SV_BWDF_ABL & 1)) compute_g(stage);
+            if (GFIRST && !(SV_BWDF_ABL & 1)) compute_g(stage);
             tile_barrier();
         };
         load_stage(SA, t_begin);
@@ -478,7 +488,7 @@ template <int WLOG, bool LIN2>
 int launch(const sv_geom* g, const bwdf_g& PG, int grid, int groups, hipStream_t s) {
     constexpr int W = 1 << WLOG, TR = 128 / W, WP = W + 2;
     constexpr int HH = (TR < W) ? TR : W, LROWS = TR + TR / HH + 1, HP = LROWS * WP;
-    constexpr size_t lds = (size_t)2 * (HP * LDF + 128 * LDF + 128 * LDR) * 2 + 2 * CH * 8 + 8 * CH * 4 + (size_t)(2 - wregs_of(LIN2)) * 16 * 9 * LDF * 2;
+    constexpr size_t lds = (size_t)2 * (HP * LDF + 128 * LDF + 128 * LDR) * 2 + 2 * CH * 8 + 8 * CH * 4 + (size_t)(2 - wregs_of(LIN2, WLOG)) * 16 * 9 * LDF * 2;
     static bool optin = false;
     if (!optin) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&bwd3x3f_kernel<WLOG, LIN2>), hipFuncAttributeMaxDynamicSharedMemorySize,
