@@ -70,19 +70,11 @@ def parse():
                     help="1: the input side of the grouped step (noise, pairings, mixed batches, layout change) on a stream of its "
                          "own, beside the previous step's backward (train_step_grouped(input_stream=True)); 0 (default): in front of "
                          "the first convolution on the main stream -- measured the same (7.22 vs 7.21 ms)")
-    ap.add_argument("--wgrad-after", type=int, default=0,
-                    help="experiment: 1 = a body layer's weight gradient (side stream) starts when its data gradient has finished "
-                         "instead of beside it (use with --pair-blocks 0)")
     ap.add_argument("--compact-shortcut", type=int, default=1, help="0: the stride-2 shortcuts' data gradients in the strided (sparse_out) form")
-    ap.add_argument("--fuse-bn-bwd", type=int, default=-1,
-                    help="norm2's BatchNorm backward in the load path of conv1's data gradient (sv_igemm_args::x2): 0 = off (an "
-                         "sv_bn_bwd_apply pass instead), 1 = the same-shape units (side output for the weight gradient), 2 = every unit, 3 = data AND weight gradient form it themselves (32 / 64 channels), -1 = the engine default")
     ap.add_argument("--fused-bwd", type=int, default=-1,
                     help="sv_bwd3x3, the one-launch backward of the 32-channel body convolutions: 0 = off (data / weight gradient pair + "
                          "sv_bn_bwd_apply), 1 = conv1 of the same-shape units with norm2's BatchNorm backward in its load path, 2 = conv2 too, "
                          "-1 = the engine default")
-    ap.add_argument("--fuse-max-channels", type=int, default=0, help="(with --fuse-bn-bwd 3) widest fused layer (0 = the engine's default)")
-    ap.add_argument("--fused-wgrad-paired", type=int, default=-1, help="(with --fuse-bn-bwd) block budget of the weight gradient forked behind the fused data gradient: 1 = the pair budget, 0 = full")
     ap.add_argument("--flag-fork", type=int, default=1, help="0: event forks for the paired weight gradients instead of the start signal")
     ap.add_argument("--fork-every", type=int, default=0, help="weight gradients per side-stream fork (0 = the engine's default)")
     ap.add_argument("--light-fork", type=int, default=1,
@@ -583,17 +575,10 @@ def main():
         model._engine.pair_blocks = a.pair_blocks
     if a.pair_blocks_strided >= 0:
         model._engine.pair_blocks_strided = a.pair_blocks_strided
-    model._engine.wgrad_after = bool(a.wgrad_after)
     model._engine.light_fork = bool(a.light_fork)
     model._engine.flag_fork = bool(a.flag_fork)
-    if a.fuse_bn_bwd >= 0:
-        model._engine.fuse_bn_bwd = a.fuse_bn_bwd
     if a.fused_bwd >= 0:
         model._engine.fused_bwd = a.fused_bwd
-    if a.fuse_max_channels:
-        model._engine.fuse_max_channels = a.fuse_max_channels
-    if a.fused_wgrad_paired >= 0:
-        model._engine.fused_wgrad_paired = bool(a.fused_wgrad_paired)
     model._engine.compact_shortcut_grad = bool(a.compact_shortcut)
     if a.fork_every:
         model._engine.fork_every = a.fork_every
@@ -707,9 +692,11 @@ def main():
                                   "frac_of_hbm_peak": round(14.26e9 / t_s / (HBM_PEAK_GBS * 1e9), 4),
                                   "flops": 3.058e12, "TFLOPs": round(3.058e12 / t_s / 1e12, 1),
                                   "frac_of_mfma_peak": round(3.058e12 / t_s / (MFMA_PEAK_TFLOPS["bf16"] * 1e12), 4),
-                                  "tensor_passes_per_residual_unit_backward": 17,
-                                  "note": "17 algorithmic passes per unit (dgrad 3, bn-backward 3 / 4, wgrad 2, twice); the paired "
-                                          "weight gradients find dY / x in L2 (PMC 1.07-1.28x their own bytes)"}
+                                  "tensor_passes_per_residual_unit_backward": {"pair": 17, "fused_32ch": 13},
+                                  "note": "17 algorithmic passes per unit with the data / weight gradient pair (dgrad 3, bn-backward "
+                                          "3 / 4, wgrad 2, twice; the paired weight gradients find dY / x in L2: PMC 1.07-1.28x their own "
+                                          "bytes); 13 for the same-shape 32-channel units whose conv1 backward is ONE launch with norm2's "
+                                          "BatchNorm backward in its load path (sv_bwd3x3, Engine.fused_bwd: 4 passes instead of 8)"}
     if probe is not None:
         out["config"]["launch_probe"] = probe
     if lam_equal is not None:
@@ -728,8 +715,6 @@ def main():
             L.prof_tags = eng.prof_tags
             # (the BatchNorm finalisations sv_igemm issues itself for folded launches: a tag of their own, not the layer's)
             L.lib().sv_prof_nested_tag(eng.prof_tags.setdefault("sv_bn_finalize(folded)", len(eng.prof_tags)))
-            # (... and the two-tensor prologue of a data gradient whose kernel does not form it in its load path)
-            L.lib().sv_prof_nested_tag_kind(1, eng.prof_tags.setdefault("sv_bn_bwd(materialised prologue)", len(eng.prof_tags)))
             L.lib().sv_prof_enable(1)
             side, eng.wgrad_side_stream, eng.prof_paired = eng.wgrad_side_stream, False, bool(paired and eng.wgrad_side_stream)
             try:
@@ -745,7 +730,6 @@ def main():
             finally:
                 L.lib().sv_prof_enable(0)
                 L.lib().sv_prof_nested_tag(-1)
-                L.lib().sv_prof_nested_tag_kind(1, -1)
                 tags = dict(eng.prof_tags)
                 L.prof_tags = eng.prof_tags = None
                 eng.wgrad_side_stream, eng.prof_paired = side, False

@@ -122,28 +122,18 @@ typedef struct {
     uint32_t* start_flag;
     uint32_t start_value;
     int32_t reserved2;
-    /* ABI 6: TWO-TENSOR load prologue = the BatchNorm BACKWARD of the layer in front fused into this launch.  With x2 != NULL
-       the input of the convolution is  pro_scale[c] * x + pro_scale2[c] * x2 + pro_shift[c]  (pro_slope must be 1: no
-       activation) -- for x = g (the gradient behind a BatchNorm's output), x2 = the BatchNorm's raw input and the coefficients
-       of sv_bn_bwd_affine that is dx = gamma * rstd * (g - mean(g) - xhat * mean(g * xhat)), the autograd of
-       wideresnet.py:27,32 -- formed in the load path of the data gradient that consumes it instead of by a pass of its own
-       (sv_bn_bwd_apply: two reads and a write of the tensor between two layers).  pro_out: the transformed input is also
-       written there, once, same layout as x (for a weight gradient that reads it; NULL: not written -- sv_wgrad_args::dy2
-       forms it the same way).  Kernels that implement it: the persistent narrow 3x3 kernel (bf16, Cin = 32 / 64); for every
-       other geometry sv_igemm MATERIALISES the prologue first (one streaming launch into pro_out -- REQUIRED then --, followed by
-       the convolution on pro_out without a prologue): same results, same interface.
-       Groups: x2 / pro_out [G][...] like x, pro_scale2 [G][Cin].  Not with fold_stats.                                      */
-    const void* x2;
-    const float* pro_scale2;
-    void* pro_out;
 } sv_igemm_args;
 
 int sv_igemm(const sv_geom* g, int dtype, const sv_igemm_args* a, void* stream);
 /* The affine coefficients of a BatchNorm backward from its two sums (sv_igemm_args::bsums of the data gradient behind it, [G][R][2C],
  * replicas summed in index order):  with A = gamma * rstd, m1 = sum g / count, m2 = sum g xhat / count
  *     scale_g[g][c] = A,   scale_x[g][c] = -A * m2 * rstd,   shift[g][c] = -A * m1 + A * m2 * rstd * mean
- * so that scale_g * g + scale_x * x + shift = A * (g - m1 - xhat * m2) -- the operands of sv_igemm_args::x2 / pro_scale2 -- and, what
- * sv_bn_bwd_apply does on the side, dbeta[c] += sum g, dgamma[c] += sum g xhat over all groups (either may be NULL).           */
+ * so that scale_g * g + scale_x * x + shift = A * (g - m1 - xhat * m2), the autograd of wideresnet.py:27,32 -- the operands
+ * dy_scale / dy_scale2 / dy_shift of sv_bwd3x3_args, which forms that BatchNorm backward in its load path instead of a pass of its own
+ * (sv_bn_bwd_apply: two reads and a write of the tensor between two layers) -- and, what sv_bn_bwd_apply does on the side,
+ * dbeta[c] += sum g, dgamma[c] += sum g xhat over all groups (either may be NULL).
+ * (ABI 6 carried the same fusion as sv_igemm_args::x2 / sv_wgrad_args::dy2, each launch of the pair forming it for itself: one pass
+ *  saved, two consumers taxed, slower in the step -- docs/lab_notes_r05.md; removed in ABI 7.)                                      */
 int sv_bn_bwd_affine(const sv_acc_t* bsums, int replicas, int C, float count, const float* gamma, const float* mean, const float* rstd,
                      float* dgamma, float* dbeta, float* scale_g, float* scale_x, float* shift, int groups, void* stream);
 /* The grid (blocks in x) sv_igemm WOULD launch for these arguments under the current options; nothing is launched.  With
@@ -178,16 +168,6 @@ typedef struct {
     int64_t ws_elems;
     int32_t groups;
     int32_t block_budget;
-    /* ABI 6: two-tensor dy operand.  dy2 != NULL: the gradient the products are formed with is
-           dy_scale[n] * dy + dy_scale2[n] * dy2 + dy_shift[n]
-       -- with the coefficients of sv_bn_bwd_affine the BatchNorm backward of the layer behind this convolution (dy = the gradient
-       behind that BatchNorm's output, dy2 = its raw input), formed in the kernel's load path exactly as the data gradient of the
-       same layer forms it (sv_igemm_args::x2: bit-identical values), so the transformed tensor is never written or read.
-       Vectors [N] (groups: [G][N]); bf16 stride-1 3x3 layers of at most 128 channels (the 32x32x16 kernel): SV_E_ARG otherwise. */
-    const void* dy2;
-    const float* dy_scale;
-    const float* dy_scale2;
-    const float* dy_shift;
 } sv_wgrad_args;
 int sv_wgrad_ex(const sv_geom* g, int dtype, const sv_wgrad_args* a, void* stream);
 
@@ -579,7 +559,7 @@ int sv_debug_conv_chunk_program(int* items, int* waits);
 enum { SV_OPT_DISABLE_MASK = 0, SV_OPT_WIDE_MIN_BLOCKS = 1, SV_OPT_HALO_ALL = 2, SV_OPT_PERSISTENT_BLOCKS = 3,
        SV_OPT_DETERMINISTIC = 4, SV_OPT_ENABLE_MASK = 5 };
 enum { SV_K_CONV3X3 = 1, SV_K_CONV3X3P = 2, SV_K_CONV3X3M = 4, SV_K_CONV3X3W = 8, SV_K_CONV3X3X = 16,
-       SV_K_WGRAD3X3 = 32, SV_K_WGRAD3X3W = 64, SV_K_IGEMM_KV2 = 128, SV_K_HALO = 256, SV_K_HALOP = 512, SV_K_HWGRAD = 1024, SV_K_IGEMM_BIG = 2048, SV_K_WGRAD_WIDE = 4096, SV_K_IGEMM_ALIGNED = 8192, SV_K_IGEMM_DMA = 16384, SV_K_WGRAD_INCR = 32768, SV_K_WGRAD3X3M = 65536, SV_K_TCONVR = 131072, SV_K_TCONVR_EX = 262144, SV_K_SCONV = 524288, SV_K_CCONV = 1048576, SV_K_CCONV_EX = 2097152, SV_K_SWGRAD = 4194304, SV_K_PCONV = 8388608, SV_K_THCONV = 16777216, SV_K_THCONV_FWD = 33554432, SV_K_THWGRAD = 67108864, SV_K_S2WGRAD = 134217728 };
+       SV_K_WGRAD3X3 = 32, SV_K_WGRAD3X3W = 64, SV_K_IGEMM_KV2 = 128, SV_K_HALO = 256, SV_K_HALOP = 512, SV_K_HWGRAD = 1024, SV_K_IGEMM_BIG = 2048, SV_K_WGRAD_WIDE = 4096, SV_K_IGEMM_ALIGNED = 8192, SV_K_IGEMM_DMA = 16384, SV_K_WGRAD_INCR = 32768, SV_K_WGRAD3X3M = 65536, SV_K_TCONVR = 131072, SV_K_TCONVR_EX = 262144, SV_K_SCONV = 524288, SV_K_PCONV = 8388608, SV_K_THCONV = 16777216, SV_K_THWGRAD = 67108864, SV_K_S2WGRAD = 134217728 };
 int sv_set_option(int key, int value);
 int sv_get_option(int key);          /* -1 for an unknown key */
 

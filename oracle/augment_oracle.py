@@ -2,14 +2,17 @@
 
     transforms.Pad(4, padding_mode='reflect') -> RandomHorizontalFlip() -> RandomCrop(32) -> ToTensor()
 
-restated in numpy from torchvision 0.4's documented semantics (torchvision is not installed in this image, and the
-reference module cannot be imported without it, so this restatement is NOT pinned by reference outputs: "parity
-unpinned" for this row):
+restated in numpy from torchvision 0.4's documented semantics.  PARITY of this transform chain is UNPINNED by reference outputs:
+torchvision is not installed in this image and the chain's arithmetic lives there (the reference only composes it), so no fixture
+can be generated; tests/test_data_cpu.py holds the restatement to two independent formulations instead (a closed-form index map,
+torch's own reflect padding).  See DESIGN.md.
   * Pad(p, 'reflect') = numpy.pad(mode='reflect') on H and W (no edge repeat);
   * the flip acts on the PADDED image, before the crop;
   * RandomCrop(32) of the 40x40 padded image takes rows i..i+31, columns j..j+31, 0 <= i, j <= 8;
   * ToTensor: uint8 HWC -> float32 CHW divided by 255.
-Also ssl_split: get_cifar10_ssl_sampler (lib/dataloader.py:142-166) for given per-class permutations."""
+Also ssl_split: get_cifar10_ssl_sampler / get_cifar100_ssl_sampler (lib/dataloader.py:142-190) for given per-class permutations --
+PINNED: tests/golden/ref_ssl_samplers.npz holds the reference's own outputs (make_goldens.py `ssl` imports the two functions and
+scripts torch.randperm), tests/test_data_cpu.py::test_ssl_split_matches_the_reference_samplers."""
 import numpy as np
 
 

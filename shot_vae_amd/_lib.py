@@ -39,15 +39,13 @@ class SvIgemmArgs(C.Structure):
                 ("replicas", C.c_int32), ("groups", C.c_int32), ("block_budget", C.c_int32), ("flags", C.c_int32), ("sparse_out", C.c_int32), ("reserved0", C.c_int32),
                 ("fold_stats", C.c_void_p), ("fold_gamma", C.c_void_p), ("fold_beta", C.c_void_p), ("fold_mean", C.c_void_p),
                 ("fold_rstd", C.c_void_p), ("fold_count", C.c_float), ("fold_eps", C.c_float), ("fold_replicas", C.c_int32),
-                ("reserved1", C.c_int32), ("start_flag", C.c_void_p), ("start_value", C.c_uint32), ("reserved2", C.c_int32),
-                ("x2", C.c_void_p), ("pro_scale2", C.c_void_p), ("pro_out", C.c_void_p)]
+                ("reserved1", C.c_int32), ("start_flag", C.c_void_p), ("start_value", C.c_uint32), ("reserved2", C.c_int32)]
 
 
 class SvWgradArgs(C.Structure):
     _fields_ = [("x", C.c_void_p), ("pro_scale", C.c_void_p), ("pro_shift", C.c_void_p), ("pro_slope", C.c_float),
                 ("dy", C.c_void_p), ("dw", C.c_void_p), ("splits", C.c_int32), ("use_tr", C.c_int32), ("ws", C.c_void_p),
-                ("ws_elems", C.c_int64), ("groups", C.c_int32), ("block_budget", C.c_int32),
-                ("dy2", C.c_void_p), ("dy_scale", C.c_void_p), ("dy_scale2", C.c_void_p), ("dy_shift", C.c_void_p)]
+                ("ws_elems", C.c_int64), ("groups", C.c_int32), ("block_budget", C.c_int32)]
 
 
 class SvBwd3x3Args(C.Structure):
@@ -175,8 +173,10 @@ _PROTOS = {
     "sv_version": [],
 }
 OPT_DISABLE_MASK, OPT_WIDE_MIN_BLOCKS, OPT_HALO_ALL, OPT_PERSISTENT_BLOCKS, OPT_DETERMINISTIC, OPT_ENABLE_MASK = 0, 1, 2, 3, 4, 5
-K_CONV3X3, K_CONV3X3P, K_CONV3X3M, K_CONV3X3W, K_CONV3X3X, K_WGRAD3X3, K_WGRAD3X3W, K_IGEMM_KV2, K_HALO, K_HALOP, K_HWGRAD, K_IGEMM_BIG, K_WGRAD_WIDE, K_IGEMM_ALIGNED, K_IGEMM_DMA, K_WGRAD_INCR, K_WGRAD3X3M, K_TCONVR, K_TCONVR_EX, K_SCONV, K_CCONV, K_CCONV_EX, K_SWGRAD, K_PCONV, K_THCONV, K_THCONV_FWD, K_THWGRAD, K_S2WGRAD = (
-    1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384, 32768, 65536, 131072, 262144, 524288, 1048576, 2097152, 4194304, 8388608, 16777216, 33554432, 67108864, 134217728)
+(K_CONV3X3, K_CONV3X3P, K_CONV3X3M, K_CONV3X3W, K_CONV3X3X, K_WGRAD3X3, K_WGRAD3X3W, K_IGEMM_KV2, K_HALO, K_HALOP, K_HWGRAD, K_IGEMM_BIG,
+ K_WGRAD_WIDE, K_IGEMM_ALIGNED, K_IGEMM_DMA, K_WGRAD_INCR, K_WGRAD3X3M, K_TCONVR, K_TCONVR_EX, K_SCONV) = (1 << i for i in range(20))
+# (bits 20-22 and 25 belonged to round 5's experiments -- cconv / swgrad / the thconv forward forms: tools/experiments/)
+K_PCONV, K_THCONV, K_THWGRAD, K_S2WGRAD = 1 << 23, 1 << 24, 1 << 26, 1 << 27
 EXPORTS = sorted(list(_PROTOS) + ["sv_last_error"])
 
 _lib = None

@@ -57,6 +57,11 @@ class VAECriterion(nn.Module):
         self.x_sigma = x_sigma
         self.bce_reconstruction = bce_reconstruction
         self.discrete_dim = discrete_dim
+        # the reference's attribute (lib/criterion.py:29-30: the log of the uniform prior, [1, K] on the GPU); the kernel has the
+        # prior as the constant -log K, the tensor exists for callers that read it.  Like the reference's, it is a plain attribute
+        # (not a buffer: .cuda() / .to() do not move it, state_dict() does not hold it) -- created on the GPU when there is one.
+        prior = torch.full((1, discrete_dim), 1.0 / discrete_dim).log()
+        self.disc_log_prior_param = prior.cuda() if torch.cuda.is_available() else prior
 
     def forward(self, x, x_reconstructed, z_mean, z_log_sigma, disc_log_alpha):
         assert disc_log_alpha.shape[1] == self.discrete_dim

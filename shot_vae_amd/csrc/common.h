@@ -99,11 +99,6 @@ inline sv_igemm_args_g sv_expand_groups(const sv_geom& g, const sv_igemm_args& a
             if (a.residual) r.residual = reinterpret_cast<const char*>(a.residual) + grp * os;
             if (a.ex) r.ex = reinterpret_cast<const char*>(a.ex) + grp * os;
             if (a.pro_scale) { r.pro_scale = a.pro_scale + grp * g.Cin; r.pro_shift = a.pro_shift + grp * g.Cin; }
-            if (a.x2) {
-                r.x2 = reinterpret_cast<const char*>(a.x2) + grp * xs;
-                r.pro_scale2 = a.pro_scale2 + grp * g.Cin;
-                if (a.pro_out) r.pro_out = reinterpret_cast<char*>(a.pro_out) + grp * xs;
-            }
             if (a.fold_stats) {
                 r.fold_stats = a.fold_stats + grp * (int64_t)a.fold_replicas * 2 * g.Cin;
                 r.fold_mean = a.fold_mean + grp * g.Cin;
@@ -242,10 +237,6 @@ bool sv_in_query();                    // the calling thread is inside sv_igemm_
 void sv_fold_begin(const sv_geom* g, const sv_igemm_args* a, void* stream);
 void sv_fold_end();
 bool sv_fold_claim(bool can);
-// sv_igemm_args::x2 (two-tensor load prologue): does a kernel of the family implement it for this launch?  (conv3x3.hip; sv_igemm
-// materialises the prologue with sv_lin2_materialize -- small.hip -- for everybody else)
-bool sv_conv3x3_takes_x2(const sv_geom* g, int dtype, const sv_igemm_args* a);
-int sv_lin2_materialize(const sv_geom* g, int dtype, const sv_igemm_args* a, void* stream);
 // sv_igemm_args::start_flag: the first block of every kernel of the family announces its start (see shotvae_hip.h)
 __device__ __forceinline__ void sv_start_signal(const sv_igemm_args& a) {
     if (a.start_flag && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
@@ -271,7 +262,6 @@ int sv_hwgrad_try(const sv_geom* g, int dtype, const void* x, const float* pro_s
 int sv_halo_try(const sv_geom* g, int dtype, const sv_igemm_args* a, hipStream_t s, int* rc);
 int sv_tconvr_try(const sv_geom* g, int dtype, const sv_igemm_args* a, hipStream_t s, int* rc);
 int sv_sconv_try(const sv_geom* g, int dtype, const sv_igemm_args* a, hipStream_t s, int* rc);
-int sv_cconv_try(const sv_geom* g, int dtype, const sv_igemm_args* a, hipStream_t s, int* rc);
 int sv_pconv_try(const sv_geom* g, int dtype, const sv_igemm_args* a, hipStream_t s, int* rc);
 int sv_dconv_try(const sv_geom* g, int dtype, const sv_igemm_args* a, hipStream_t s, int* rc);
 int sv_thconv_try(const sv_geom* g, int dtype, const sv_igemm_args* a, hipStream_t s, int* rc);
@@ -279,15 +269,11 @@ int sv_thwgrad_try(const sv_geom* g, int dtype, const void* x, const float* pro_
                    const void* dy, float* dw, int groups, hipStream_t s, int* rc);
 int sv_s2wgrad_try(const sv_geom* g, int dtype, const void* x, const float* pro_scale, const float* pro_shift, float pro_slope,
                    const void* dy, float* dw, int groups, hipStream_t s, int* rc);
-int sv_swgrad_try(const sv_geom* g, int dtype, const void* x, const float* pro_scale, const float* pro_shift, float pro_slope,
-                  const void* dy, float* dw, int groups, hipStream_t s, int* rc);
 int sv_conv3x3w_try(const sv_geom* g, int dtype, const sv_igemm_args* a, hipStream_t s, int* rc);
 int sv_conv3x3x_try(const sv_geom* g, const sv_igemm_args* a, bool fwd, hipStream_t s, int* rc);
-// sv_wgrad_args::dy2: the weight gradient's dy operand from two tensors (set by sv_wgrad_ex for the duration of its call)
-struct sv_wg_lin2 { const void* dy2; const float* scale; const float* scale2; const float* shift; };
 int sv_wgrad3x3_try(const sv_geom* g, int dtype, const void* x, const float* pro_scale, const float* pro_shift,
                     float pro_slope, const void* dy, float* dw, float* ws, int64_t ws_elems, int groups, hipStream_t s,
-                    int* rc, const sv_wg_lin2* lin2 = nullptr);
+                    int* rc);
 
 #define SV_REQUIRE(cond, code, ...)                \
     do {                                           \

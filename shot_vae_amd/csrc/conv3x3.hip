@@ -28,9 +28,6 @@
 #ifndef SV_C3P_MODES
 #define SV_C3P_MODES 1         // fusion flags of conv3x3p at compile time for the step's three launch kinds (0: run-time flags only)
 #endif
-#ifndef SV_C3P_X2_STAGES
-#define SV_C3P_X2_STAGES 0     // register stages of the SECOND tensor of the two-tensor prologue: 0 = two at 32 input channels, one at 64
-#endif
 #ifndef SV_C3P_WAVES
 #define SV_C3P_WAVES 2          // waves per SIMD the persistent kernel is compiled for (3 => spills, measured slower)
 #endif
@@ -200,11 +197,9 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const sv_geom g, const sv_
 // residual / raw tensor needed by tile i's epilogue are already in flight -- and the BatchNorm sums are
 // kept in registers across tiles and flushed once per block (one shuffle tree, one atomic per channel).
 // MODE: the fusion flags at compile time (0 = read from the arguments; 1 = prologue + statistics, 2 = prologue + residual +
-// statistics, 3 = activation-backward epilogue, no prologue -- the three launch kinds of the training step; no bias in 1..3;
-// 6 = activation-backward epilogue behind the TWO-TENSOR prologue (sv_igemm_args::x2): the halo is formed from g and the raw
-// tensor of the BatchNorm in front, dx = scale * g + scale2 * x2 + shift -- that BatchNorm's backward -- and the blocks of the
-// first channel tile store it once to pro_out for the layer's weight gradient: sv_bn_bwd_apply's pass between the two data
-// gradients of a residual unit disappears)
+// statistics, 3 = activation-backward epilogue, no prologue -- the three launch kinds of the training step; no bias in 1..3).
+// (Round 5's mode 6 -- the BatchNorm backward of the layer in front formed in the load path from two tensors -- lost in the step and
+//  left in round 6: that fusion lives in bwd3x3f.hip, where ONE kernel forms it for the data and the weight gradient together.)
 template <typename T, int WLOG, int CCH, int MODE>      // CCH = Cin / 32
 __global__ __launch_bounds__(256, SV_C3P_WAVES) void conv3x3p_kernel(const sv_geom g, const sv_igemm_args_g A, int tiles_per) {
     const sv_igemm_args& a = A.g[blockIdx.y];
@@ -263,13 +258,10 @@ __global__ __launch_bounds__(256, SV_C3P_WAVES) void conv3x3p_kernel(const sv_ge
     const T* __restrict__ Wp = reinterpret_cast<const T*>(a.w) + P.w_off + (int64_t)n0 * 9 * CIN;
     T* __restrict__ O = reinterpret_cast<T*>(a.out);
     const T* __restrict__ R = MODE == 0 || MODE == 2 ? reinterpret_cast<const T*>(a.residual) : nullptr;
-    const T* __restrict__ EX = MODE == 0 || MODE >= 3 ? reinterpret_cast<const T*>(a.ex) : nullptr;
-    const bool hasR = MODE == 0 ? R != nullptr : MODE == 2, hasEX = MODE == 0 ? EX != nullptr : MODE >= 3;
+    const T* __restrict__ EX = MODE == 0 || MODE == 3 ? reinterpret_cast<const T*>(a.ex) : nullptr;
+    const bool hasR = MODE == 0 ? R != nullptr : MODE == 2, hasEX = MODE == 0 ? EX != nullptr : MODE == 3;
     const bool has_stats = MODE == 0 ? a.stats != nullptr : (MODE == 1 || MODE == 2);
     const bool has_pro = MODE == 0 ? a.pro_scale != nullptr : MODE < 3;
-    constexpr bool LIN2 = MODE == 6;                         // two-tensor prologue (never with the run-time flags of mode 0)
-    const T* __restrict__ X2 = LIN2 ? reinterpret_cast<const T*>(a.x2) : nullptr;
-    T* __restrict__ PO = LIN2 ? reinterpret_cast<T*>(a.pro_out) : nullptr;
     const bool want_sums = has_stats || hasEX;
 
     if (tid < 2 * BN) ssum[tid] = 0.0;
@@ -327,31 +319,10 @@ __global__ __launch_bounds__(256, SV_C3P_WAVES) void conv3x3p_kernel(const sv_ge
         pt0 = *reinterpret_cast<const f32x4*>(a.pro_shift + hc[0]);
         pt1 = *reinterpret_cast<const f32x4*>(a.pro_shift + hc[0] + 4);
     }
-    // (two-tensor prologue: its three coefficient vectors are used once per tile -- they live in LDS, not in 24 registers)
-    float* lin2c = reinterpret_cast<float*>(ssum + 2 * BN);  // [3][CIN]: scale (x), scale2 (x2), shift
-    if (LIN2) {
-        for (int i = tid; i < CIN; i += 256) {
-            lin2c[i] = a.pro_scale[i];
-            lin2c[CIN + i] = a.pro_scale2[i];
-            lin2c[2 * CIN + i] = a.pro_shift[i];
-        }
-    }
     // two register stages: the halo of tile i+2 is requested while tile i is on the MFMAs, so every halo has
     // two full tile periods to arrive (at 2 blocks per CU one tile period does not cover the memory latency)
-    // (two-tensor prologue: the second tensor rides in the same stage, requested right behind the first -- XD2 = 0 keeps ONE
-    //  copy of it, requested a single tile ahead, where two stages of both tensors do not fit the register budget)
-    constexpr bool XD2 = LIN2 && (SV_C3P_X2_STAGES == 2 || (SV_C3P_X2_STAGES == 0 && CCH == 1));
-    struct HStage { V hv[HI]; V hx[XD2 ? HI : 1]; bool hok[HI]; };
+    struct HStage { V hv[HI]; bool hok[HI]; };
     HStage HA, HB, HC;          // (HC: SV_C3P_DEPTH 3 only)
-    V hx1[LIN2 && !XD2 ? HI : 1];                            // the single-stage copy of the second tensor
-    auto load_x2 = [&](V (&dst)[LIN2 ? HI : 1], int tile) {
-        const int gr0 = tile * TR;
-#pragma unroll
-        for (int i = 0; i < (LIN2 ? HI : 1); ++i) {
-            const int grc = min(max(gr0 + hrel[i], 0), BH - 1);
-            dst[i] = *reinterpret_cast<const V*>(X2 + ((int64_t)grc * W + hxc[i]) * g.ldx + hc[i]);
-        }
-    };
     auto load_halo = [&](HStage& S, int tile) {
         const int gr0 = tile * TR;
         const bool top_ok = (gr0 & (H - 1)) != 0, bot_ok = ((gr0 + TR) & (H - 1)) != 0;
@@ -361,28 +332,12 @@ __global__ __launch_bounds__(256, SV_C3P_WAVES) void conv3x3p_kernel(const sv_ge
             const int grc = min(max(gr0 + hrel[i], 0), BH - 1);
             S.hv[i] = *reinterpret_cast<const V*>(X + ((int64_t)grc * W + hxc[i]) * g.ldx + hc[i]);
         }
-        if constexpr (XD2) load_x2(S.hx, tile);
     };
     auto store_halo = [&](HStage& S, int tile) {
 #pragma unroll
         for (int i = 0; i < HI; ++i) {
             V o = S.hv[i];
             if (has_pro) o = bn_act8(S.hv[i], ps0, ps1, pt0, pt1, a.pro_slope);          // LeakyReLU / ReLU for slope in [0,1]
-            if constexpr (LIN2) {
-                const V& x2v = XD2 ? S.hx[XD2 ? i : 0] : hx1[XD2 ? 0 : i];
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const f32x4 ca = *reinterpret_cast<const f32x4*>(lin2c + hc[0] + 4 * h);
-                    const f32x4 cb = *reinterpret_cast<const f32x4*>(lin2c + CIN + hc[0] + 4 * h);
-                    const f32x4 cc = *reinterpret_cast<const f32x4*>(lin2c + 2 * CIN + hc[0] + 4 * h);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        o[4 * h + j] = (T)(to_f(S.hv[i][4 * h + j]) * ca[j] + (to_f(x2v[4 * h + j]) * cb[j] + cc[j]));
-                }
-                // the transformed tensor, once: the rows of THIS tile (kind 1: no halo row, no padding column), first channel tile
-                if (PO && in_i == 0 && hkind[i] == 1)
-                    *reinterpret_cast<V*>(PO + ((int64_t)(tile * TR + hrel[i]) * W + hxc[i]) * g.ldx + hc[i]) = o;
-            }
             *reinterpret_cast<V*>(halo + hlds[i]) = S.hok[i] ? o : zero;
         }
     };
@@ -396,21 +351,12 @@ __global__ __launch_bounds__(256, SV_C3P_WAVES) void conv3x3p_kernel(const sv_ge
         pcol[ms] = p & (W - 1);
         hbase[ms] = ((prow[ms] + 1 + prow[ms] / HH) * WP + pcol[ms] + 1) * LDW + 8 * fq;
     }
-    // (two-tensor prologue at 64 input channels: the epilogue's four coefficient vectors are read from LDS once per tile as well)
-    constexpr bool ECL = LIN2 && CCH == 2;
-    float* ecl = lin2c + 3 * CIN;                            // [4][BN]: ex_scale, ex_shift, ex_mean, ex_rstd of this block's channels
-    if (ECL && tid < BN) {
-        ecl[tid] = a.ex_scale[n0 + tid];
-        ecl[BN + tid] = a.ex_shift[n0 + tid];
-        ecl[2 * BN + tid] = a.ex_mean[n0 + tid];
-        ecl[3 * BN + tid] = a.ex_rstd[n0 + tid];
-    }
     f32x4 bias[NT], esc[NT], esh[NT], emu[NT], ers[NT];
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
         const int n = n0 + 16 * i + 4 * fq;
         bias[i] = (MODE == 0 && a.bias) ? *reinterpret_cast<const f32x4*>(a.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
-        if (hasEX && !ECL) {
+        if (hasEX) {
             esc[i] = *reinterpret_cast<const f32x4*>(a.ex_scale + n);
             esh[i] = *reinterpret_cast<const f32x4*>(a.ex_shift + n);
             emu[i] = *reinterpret_cast<const f32x4*>(a.ex_mean + n);
@@ -424,15 +370,13 @@ __global__ __launch_bounds__(256, SV_C3P_WAVES) void conv3x3p_kernel(const sv_ge
         for (int r = 0; r < 4; ++r) s1[i][r] = s2[i][r] = 0.f;
 
     load_halo(HA, t_begin);
-    if constexpr (LIN2 && !XD2) load_x2(hx1, t_begin);
     if (t_begin + tstep < t_end) load_halo(HB, t_begin + tstep);
     if (SV_C3P_DEPTH == 3 && t_begin + 2 * tstep < t_end) load_halo(HC, t_begin + 2 * tstep);
-    if (LIN2) __syncthreads();                               // the coefficient vectors in LDS (requests above are in flight meanwhile)
     store_halo(HA, t_begin);
     __syncthreads();
     // 32 input channels: the block's 18 weight fragments stay in registers (72 of them: with the fusion flags at compile time
     // the variants hold 152-176 without) -- the nine taps read only the pixel fragments from LDS
-    constexpr bool WREG = SV_C3P_WREG && CCH == 1 && sizeof(T) == 2 && MODE != 0 && MODE != 6;
+    constexpr bool WREG = SV_C3P_WREG && CCH == 1 && sizeof(T) == 2 && MODE != 0;
     V wr[WREG ? 9 : 1][NT];
     if (WREG) {
 #pragma unroll
@@ -470,7 +414,6 @@ __global__ __launch_bounds__(256, SV_C3P_WAVES) void conv3x3p_kernel(const sv_ge
         const int gr0 = tile * TR;
         // ---- request the halo HD tiles ahead + the epilogue operands ED tiles ahead; they fly during the MFMAs ----
         const bool more = tile + tstep < t_end;
-        if constexpr (LIN2 && !XD2) { if (more) load_x2(hx1, tile + tstep); }      // (in front of the younger requests: loads return in order)
         if (tile + HD * tstep < t_end) load_halo(FREE, tile + HD * tstep);
         if (SV_C3P_EOP_AHEAD) { if (tile + ED * tstep < t_end && (hasR || hasEX)) load_eop(ENEXT, tile + ED * tstep); }
         else if (hasR || hasEX) load_eop(ECUR, tile);
@@ -517,12 +460,6 @@ __global__ __launch_bounds__(256, SV_C3P_WAVES) void conv3x3p_kernel(const sv_ge
                     for (int r = 0; r < 4; ++r) vv[r] += to_f(eop[i][ms][r]);
                 }
                 if (hasEX) {
-                    if constexpr (ECL) {
-                        esc[i] = *reinterpret_cast<const f32x4*>(ecl + 16 * i + 4 * fq);
-                        esh[i] = *reinterpret_cast<const f32x4*>(ecl + BN + 16 * i + 4 * fq);
-                        emu[i] = *reinterpret_cast<const f32x4*>(ecl + 2 * BN + 16 * i + 4 * fq);
-                        ers[i] = *reinterpret_cast<const f32x4*>(ecl + 3 * BN + 16 * i + 4 * fq);
-                    }
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const float xf = to_f(eop[i][ms][r]);
@@ -855,7 +792,7 @@ int launch_pm(const sv_geom* g, const sv_igemm_args* a, hipStream_t s) {
     if (chunks > nT) chunks = nT;
     const int tiles_per = (nT + chunks - 1) / chunks;
     chunks = (nT + tiles_per - 1) / tiles_per;
-    const size_t lds = (size_t)(HPIX + 32 * 9) * LDW * sizeof(T) + 2 * 32 * sizeof(double) + (MODE == 6 ? (3 * CIN + 4 * 32) * sizeof(float) : 0);
+    const size_t lds = (size_t)(HPIX + 32 * 9) * LDW * sizeof(T) + 2 * 32 * sizeof(double);
     static bool optin = false;
     if (lds > 64 * 1024 && !optin) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3p_kernel<T, WLOG, CCH, MODE>),
@@ -878,7 +815,6 @@ template <typename T, int WLOG, int CCH>
 int launch_p(const sv_geom* g, const sv_igemm_args* a, hipStream_t s) {
 #if SV_C3P_MODES
     if constexpr (sizeof(T) == 2) {
-        if (a->x2) return launch_pm<T, WLOG, CCH, 6>(g, a, s);      // (sv_conv3x3_takes_x2 holds: sv_igemm checked)
         if (!a->bias) {
             if (a->pro_scale && a->stats && !a->ex) return a->residual ? launch_pm<T, WLOG, CCH, 2>(g, a, s) : launch_pm<T, WLOG, CCH, 1>(g, a, s);
             if (!a->pro_scale && a->ex && !a->residual && !a->stats) return launch_pm<T, WLOG, CCH, 3>(g, a, s);
@@ -929,8 +865,6 @@ int launch_w(const sv_geom* g, const sv_igemm_args* a, hipStream_t s) {
 
 }  // namespace
 
-// sv_igemm_args::x2: the persistent kernel forms the two-tensor prologue in its load path -- bf16, 32 / 64 input channels, the
-// activation-backward epilogue alone (the data gradient of a body layer), compile-time fusion flags
 static bool conv3x3_covers(const sv_geom* g) {
     if (g->nphase != 1 || g->phase[0].ntap != 9 || g->sy != 1 || g->sx != 1 || g->osy != 1 || g->osx != 1) return false;
     if (g->Hq != g->Hin || g->Wq != g->Win || g->Hout != g->Hin || g->Wout != g->Win || g->Hin != g->Win) return false;
@@ -941,15 +875,6 @@ static bool conv3x3_covers(const sv_geom* g) {
         if (g->phase[0].dy[t] < -1 || g->phase[0].dy[t] > 1 || g->phase[0].dx[t] < -1 || g->phase[0].dx[t] > 1) return false;
     return (g->B * g->Hin) % (128 / g->Win) == 0;
 }
-bool sv_conv3x3_takes_x2(const sv_geom* g, int dtype, const sv_igemm_args* a) {
-#if SV_C3P_MODES
-    return conv3x3_covers(g) && !sv_disabled(SV_K_CONV3X3P) && dtype == SV_BF16 && (g->Cin == 32 || g->Cin == 64) && a->x2 && a->ex &&
-           !a->bias && !a->residual && !a->stats && !(a->flags & SV_FLAG_DET);
-#else
-    return false;
-#endif
-}
-
 // Returns 1 and sets *rc when the geometry is a stride-1 3x3 convolution this kernel covers.
 int sv_conv3x3_try(const sv_geom* g, int dtype, const sv_igemm_args* a, hipStream_t s, int* rc) {
     if (!conv3x3_covers(g)) return 0;

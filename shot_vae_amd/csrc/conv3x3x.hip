@@ -48,12 +48,6 @@
 #else
 #define SV_X3_PRE
 #endif
-#ifndef SV_X3_EPI2
-#define SV_X3_EPI2 0       // 1: the register-direct epilogue of the compile-time modes (measured: not faster, below); 0: conv3x3w_epilogue.inc's LDS transpose
-#endif
-#ifndef SV_X3_EPF
-#define SV_X3_EPF 2        // register-direct epilogue: 32-channel groups of residual / raw-tensor rows in flight (2 = one ahead)
-#endif
 #ifndef SV_X3_DRAIN
 #define SV_X3_DRAIN 1      // 1: the epilogue's stores have left before the K loop resumes
 #endif
@@ -635,153 +629,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3x_kernel(const sv_geom g, const
             asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
             if (item < 5) SV_X3_STAMP_AT(2 + 2 * item);
             const int n0 = cur.n0, gr0 = cur.gr0;
-            if constexpr (MODE != 0 && SV_X3_EPI2 != 0) {
-                // ---- register-direct epilogue (round 5; tested, OFF: SV_X3_EPI2): NO LDS transpose.  acc[f][i][4 gq + e] = channel 32 i + 8 gq + 4 h + e of
-                // pixel 32 f + r.  A lane loads / stores 16 bytes = 8 channels of ITS pixel (lanes 0-31: channels 16 p .. + 7, lanes
-                // 32-63: 16 p + 8 .. + 15 of the group's half p); v_permlane32_swap on the PACKED dwords moves a pair between that
-                // layout and the accumulators' (two swaps per 16 bytes in, two out: tconv.hip).  The math stays in the accumulator
-                // layout; the per-channel sums of a group (16 channels x 2 sums per lane, both pixel halves added in registers) are
-                // summed over the 32 pixel lanes by a wave-private LDS column sum.  SV_X3_EPF groups of operand rows are in flight.
-                // MEASURED (tools/probes/x3_stamps.py, -DSV_X3_STAMP=1): ~1 300 vector instructions against the transpose's ~2 000, and
-                // the same 16-17 k cycles per item (22 k for the data gradient) -- at a quarter of the chip as at the whole chip, so it
-                // is a per-CU bound, not an HBM burst.  The 16 up-front loads alone take 4.5 k cycles: an instruction covers 32 pixel
-                // rows x 32 bytes, i.e. a quarter of each of 32 cache lines, the four waves' lines in flight (256 KB) do not stay in
-                // the 32 KB L1, every instruction pulls its lines whole from L2 (4 x 16 x 32 x 128 B in 4.5 k cycles = 58 B / clk = the
-                // L2 -> L1 rate of a CU).  The accumulator layout fixes lane = pixel, so EVERY register-direct load is a partial-line
-                // load; full-line loads need the LDS round trip this epilogue set out to avoid.
-                constexpr bool has_R = MODE == 2, has_EX = MODE == 3, want_sums = true;
-                bf16* const O = reinterpret_cast<bf16*>(a.out);
-                const bf16* const esrc = has_R ? reinterpret_cast<const bf16*>(a.residual) : reinterpret_cast<const bf16*>(a.ex);
-                const float ex_slope = has_EX ? a.ex_slope : 1.f;
-                constexpr int RED = 64 * 36 * 4 + 128;                                                          // bytes per wave
-                float* const red = reinterpret_cast<float*>(smem + C::OFF_SCR + wave * RED);                    // [64 lanes][36], upper half-wave + 32 floats
-                f32x4* const cst = reinterpret_cast<f32x4*>(smem + C::OFF_SCR + 4 * RED);                       // [BN] {scale, shift, rstd, -mean rstd}
-                static_assert(4 * RED + BN * 16 <= 4 * C::SCR + 5 * BN * 4, "epilogue scratch");
-                if (has_EX && (item == 0 || nNt > 1)) {
-                    for (int c = tid; c < BN; c += 256) {
-                        const float rs = a.ex_rstd[n0 + c];
-                        cst[c] = f32x4{a.ex_scale[n0 + c], a.ex_shift[n0 + c], rs, -a.ex_mean[n0 + c] * rs};
-                    }
-                    __syncthreads();
-                }
-                const int64_t eoff = ((int64_t)gr0 * W + 64 * wave + r) * g.ldo + n0 + 8 * h;     // + 32 f ldo + 32 i + 16 p
-                const int fstep = 32 * g.ldo;
-                constexpr int EPF = SV_X3_EPF;                                                    // groups of operand rows in flight
-                u32x4 exr[EPF][2][2];                                                             // [i % EPF][f][p]
-                auto fetch = [&](auto I) __attribute__((always_inline)) {
-                    constexpr int i = decltype(I)::value;
-                    if constexpr (has_R || has_EX) {
-#pragma unroll
-                        for (int f = 0; f < 2; ++f)
-#pragma unroll
-                            for (int p = 0; p < 2; ++p) exr[i % EPF][f][p] = *reinterpret_cast<const u32x4*>(esrc + eoff + f * fstep + 32 * i + 16 * p);
-                    }
-                };
-                if (item == 1) SV_X3_STAMP_AT(12);
-                static_for<EPF - 1>([&](auto I) { fetch(I); });
-                if (item == 1) SV_X3_STAMP_AT(13);
-                static_for<NF>([&](auto I) {
-                    constexpr int i = decltype(I)::value;
-                    if (item == 1) SV_X3_STAMP_AT(14 + i);
-                    if constexpr (i + EPF - 1 < NF) fetch(std::integral_constant<int, i + EPF - 1>{});
-                    float ps1[16], ps2[16];
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) ps1[e] = ps2[e] = 0.f;
-#pragma unroll
-                    for (int p = 0; p < 2; ++p) {
-                        uint32_t xw[2][2][2], ow[2][2][2];        // [f][gq = 2 p + k][dword]
-                        if constexpr (has_R || has_EX) {
-#pragma unroll
-                            for (int f = 0; f < 2; ++f)
-#pragma unroll
-                                for (int d = 0; d < 2; ++d) {
-                                    const auto sw = __builtin_amdgcn_permlane32_swap(exr[i % EPF][f][p][d], exr[i % EPF][f][p][2 + d], false, false);
-                                    xw[f][0][d] = sw[0];
-                                    xw[f][1][d] = sw[1];
-                                }
-                        }
-#pragma unroll
-                        for (int k = 0; k < 2; ++k)
-#pragma unroll
-                            for (int d = 0; d < 2; ++d) {
-                                const int e0 = 4 * (2 * p + k) + 2 * d;           // accumulator elements e0, e0 + 1 = this dword's two channels
-                                f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0;
-                                if constexpr (has_EX) {
-                                    c0 = cst[32 * i + 8 * (2 * p + k) + 4 * h + 2 * d];
-                                    c1 = cst[32 * i + 8 * (2 * p + k) + 4 * h + 2 * d + 1];
-                                }
-#pragma unroll
-                                for (int f = 0; f < 2; ++f) {
-                                    float v0 = acc[f][i][e0], v1 = acc[f][i][e0 + 1];
-                                    if constexpr (has_R || has_EX) {
-                                        const uint32_t w = xw[f][k][d];
-                                        const float x0 = __builtin_bit_cast(float, w << 16), x1 = __builtin_bit_cast(float, w & 0xffff0000u);
-                                        if constexpr (has_R) {
-                                            v0 += x0;
-                                            v1 += x1;
-                                        } else {
-                                            v0 *= (x0 * c0[0] + c0[1] > 0.f) ? 1.f : ex_slope;
-                                            v1 *= (x1 * c1[0] + c1[1] > 0.f) ? 1.f : ex_slope;
-                                            ps1[e0] += v0;
-                                            ps2[e0] += v0 * (x0 * c0[2] + c0[3]);
-                                            ps1[e0 + 1] += v1;
-                                            ps2[e0 + 1] += v1 * (x1 * c1[2] + c1[3]);
-                                        }
-                                    }
-                                    if constexpr (!has_EX) {
-                                        ps1[e0] += v0;
-                                        ps2[e0] += v0 * v0;
-                                        ps1[e0 + 1] += v1;
-                                        ps2[e0 + 1] += v1 * v1;
-                                    }
-                                    typedef bf16 bf16x2 __attribute__((ext_vector_type(2)));
-                                    const bf16x2 pr = {(bf16)v0, (bf16)v1};
-                                    ow[f][k][d] = __builtin_bit_cast(uint32_t, pr);
-                                }
-                            }
-#pragma unroll
-                        for (int f = 0; f < 2; ++f) {
-#pragma unroll
-                            for (int d = 0; d < 2; ++d) {
-                                const auto sw = __builtin_amdgcn_permlane32_swap(ow[f][0][d], ow[f][1][d], false, false);
-                                ow[f][0][d] = sw[0];
-                                ow[f][1][d] = sw[1];
-                            }
-                            const u32x4 o = {ow[f][0][0], ow[f][0][1], ow[f][1][0], ow[f][1][1]};
-                            *reinterpret_cast<u32x4*>(O + eoff + f * fstep + 32 * i + 16 * p) = o;
-                        }
-                    }
-                    if constexpr (want_sums) {
-                        // the wave's 32 pixel lanes of each half-wave: lane (h', j) adds column j of the 32 rows of its half
-                        // (rows of 36 floats: conflict-free 16-byte writes; the upper half-wave's rows lie 32 floats further:
-                        //  its 32 reading lanes then sit on the other 32 banks)
-                        float* const mine = red + lane * 36 + 32 * h;
-#pragma unroll
-                        for (int q4 = 0; q4 < 4; ++q4) {
-                            *reinterpret_cast<f32x4*>(mine + 4 * q4) = f32x4{ps1[4 * q4], ps1[4 * q4 + 1], ps1[4 * q4 + 2], ps1[4 * q4 + 3]};
-                            *reinterpret_cast<f32x4*>(mine + 16 + 4 * q4) = f32x4{ps2[4 * q4], ps2[4 * q4 + 1], ps2[4 * q4 + 2], ps2[4 * q4 + 3]};
-                        }
-                        const float* const col = red + (32 * h) * 36 + 32 * h + r;
-                        float t = 0.f;
-#pragma unroll
-                        for (int q = 0; q < 32; ++q) t += col[q * 36];
-                        // j = r: sum j >> 4 of channel 32 i + 8 ((j >> 2) & 3) + 4 h + (j & 3)
-                        ssum[wave * 2 * BN + (r >> 4) * BN + 32 * i + 8 * ((r >> 2) & 3) + 4 * h + (r & 3)] = t;
-                    }
-                });
-                if (item == 1) SV_X3_STAMP_AT(19);
-                __syncthreads();
-                if (item == 1) SV_X3_STAMP_AT(20);
-                {
-                    double* dst = (has_EX ? a.bsums : a.stats) + (size_t)(blockIdx.x & (a.replicas - 1)) * 2 * g.N;
-                    for (int i = tid; i < 2 * BN; i += 256) {
-                        const int which = i / BN, nl = i - which * BN;
-                        const float v = ssum[i] + ssum[2 * BN + i] + ssum[4 * BN + i] + ssum[6 * BN + i];
-                        atomicAdd(dst + which * g.N + n0 + nl, (double)v);
-                    }
-                }
-                if (item == 1) SV_X3_STAMP_AT(21);
-            } else {
+            {
                 constexpr int SV_EPD = SV_X3_EPD;
 #define SV_EPI_NSCR 1
 #define SV_EPI_BASE C::OFF_SCR

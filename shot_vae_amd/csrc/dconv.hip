@@ -211,7 +211,7 @@ __global__ __launch_bounds__(512, 1) void dconv_kernel(const sv_geom g, const sv
 int sv_dconv_try(const sv_geom* g, int dtype, const sv_igemm_args* a, hipStream_t s, int* rc) {
     typedef dconv_cfg C;
     if (sv_disabled(SV_K_TCONVR_EX) || dtype != SV_BF16 || !a->ex) return 0;
-    if (a->bias || a->residual || a->x2 || a->sparse_out || a->stats || a->pro_scale || (a->flags & SV_FLAG_DET)) return 0;
+    if (a->bias || a->residual || a->sparse_out || a->stats || a->pro_scale || (a->flags & SV_FLAG_DET)) return 0;
     if (g->nphase != 1 || g->sy != 2 || g->sx != 2 || g->osy != 1 || g->osx != 1) return 0;
     const sv_phase& P = g->phase[0];
     if (P.ntap != 16 || P.ooy != 0 || P.oox != 0) return 0;

@@ -604,11 +604,6 @@ extern "C" int sv_igemm(const sv_geom* g, int dtype, const sv_igemm_args* a_in, 
                "sv_igemm: replicas=%d must be a power of two", a->replicas);
     SV_REQUIRE(a->block_budget == 0 || a->block_budget >= 8, SV_E_ARG, "sv_igemm: block_budget=%d", a->block_budget);
     SV_REQUIRE(!a->sparse_out || (!a->bias && !a->residual), SV_E_ARG, "sv_igemm: sparse_out with a bias / residual (the skipped positions would not be zero)");
-    if (a->x2) {
-        SV_REQUIRE(a->pro_scale && a->pro_shift && a->pro_scale2 && a->pro_slope == 1.f && !a->fold_stats, SV_E_ARG,
-                   "sv_igemm: the two-tensor prologue (x2) needs pro_scale, pro_scale2, pro_shift, pro_slope = 1 and no fold_stats");
-        SV_REQUIRE(g->ldx == g->Cin, SV_E_SHAPE, "sv_igemm: x2 needs a dense input tensor (ldx=%d, Cin=%d)", g->ldx, g->Cin);
-    }
     hipStream_t s = (hipStream_t)stream;
     if (a->fold_stats) {
         SV_REQUIRE(a->pro_scale && a->pro_shift && a->fold_gamma && a->fold_beta && a->fold_mean && a->fold_rstd &&
@@ -618,18 +613,6 @@ extern "C" int sv_igemm(const sv_geom* g, int dtype, const sv_igemm_args* a_in, 
     }
     struct FoldEnd { ~FoldEnd() { sv_fold_end(); } } fold_end;
     SvBudgetScope budget_scope(a->block_budget);
-    if (a->x2 && !(dtype == SV_BF16 && !sv_disabled(SV_K_CONV3X3) && sv_conv3x3_takes_x2(g, dtype, a))) {
-        // no kernel of the family forms this launch's two-tensor prologue in its load path: it is MATERIALISED -- one streaming
-        // launch writes pro_out = pro_scale * x + pro_scale2 * x2 + pro_shift, the convolution then reads pro_out as it is
-        SV_REQUIRE(a->pro_out, SV_E_ARG, "sv_igemm: this geometry's kernel does not form the two-tensor prologue in its load path: pro_out "
-                                         "is needed to materialise it");
-        if (!sv_in_query()) {
-            const int rc = sv_lin2_materialize(g, dtype, a, stream);
-            if (rc != SV_OK) return rc;
-        }
-        a_loc.x = a_loc.pro_out;
-        a_loc.x2 = nullptr; a_loc.pro_scale = a_loc.pro_shift = a_loc.pro_scale2 = nullptr; a_loc.pro_out = nullptr;
-    }
     {   // stride-1 3x3 convolutions take the LDS-halo kernels (conv3x3*.hip) unless switched off (tests: generic vs special)
         int rc = 0;
         // the last decoder layer's data gradient (4x4 stride-2 convolution 16 -> 64; dconv.hip)
@@ -638,8 +621,6 @@ extern "C" int sv_igemm(const sv_geom* g, int dtype, const sv_igemm_args* a_in, 
         if (sv_thconv_try(g, dtype, a, s, &rc)) return rc;
         // the 1x1 shortcut forwards: B fragments straight from global memory, no LDS (pconv.hip)
         if (sv_pconv_try(g, dtype, a, s, &rc)) return rc;
-        // the 64-channel body at 16x16 with register-resident weights (cconv.hip; SV_OPT_ENABLE_MASK)
-        if (sv_cconv_try(g, dtype, a, s, &rc)) return rc;
         if (!sv_disabled(SV_K_CONV3X3) && sv_conv3x3_try(g, dtype, a, s, &rc)) return rc;
         // ConvTranspose2d(4, 2, 1) 128 -> 64 forward: the weights of a phase register-resident (tconv.hip)
         if (sv_tconvr_try(g, dtype, a, s, &rc)) return rc;

@@ -137,7 +137,7 @@ int launch_pconv(const sv_geom* g, const sv_igemm_args* a, hipStream_t s) {
 // Returns 1 and sets *rc when the launch is a 1x1 forward convolution this kernel covers.
 int sv_pconv_try(const sv_geom* g, int dtype, const sv_igemm_args* a, hipStream_t s, int* rc) {
     if (sv_disabled(SV_K_PCONV) || dtype != SV_BF16) return 0;
-    if (a->bias || a->residual || a->ex || a->x2 || a->sparse_out || a->stats) return 0;
+    if (a->bias || a->residual || a->ex || a->sparse_out || a->stats) return 0;
     if (g->nphase != 1 || g->phase[0].ntap != 1 || g->phase[0].dy[0] != 0 || g->phase[0].dx[0] != 0) return 0;
     if (g->phase[0].ooy != 0 || g->phase[0].oox != 0 || g->osy != 1 || g->osx != 1 || g->sy != g->sx || g->sy < 1 || g->sy > 2) return 0;
     if (g->Hq != g->Hout || g->Wq != g->Wout || g->Hin != g->sy * g->Hout || g->Win != g->sx * g->Wout) return 0;

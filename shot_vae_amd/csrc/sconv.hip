@@ -322,7 +322,7 @@ int launch_sconv(const sv_geom* g, const sv_igemm_args* a, hipStream_t s) {
 // Returns 1 and sets *rc when the launch is a stride-2 3x3 forward convolution this kernel covers.
 int sv_sconv_try(const sv_geom* g, int dtype, const sv_igemm_args* a, hipStream_t s, int* rc) {
     if (sv_disabled(SV_K_SCONV) || dtype != SV_BF16) return 0;
-    if (a->bias || a->residual || a->ex || a->x2 || a->sparse_out) return 0;
+    if (a->bias || a->residual || a->ex || a->sparse_out) return 0;
     if ((a->flags & SV_FLAG_DET) && a->stats) return 0;
     if (g->nphase != 1 || g->sy != 2 || g->sx != 2 || g->osy != 1 || g->osx != 1) return 0;
     const sv_phase& P = g->phase[0];

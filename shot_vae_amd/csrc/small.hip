@@ -360,8 +360,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bnb_params_g PG
     }
 }
 
-// Affine coefficients of a BatchNorm backward (sv_bn_bwd_affine) for the two-tensor load prologue of the data gradient that consumes
-// it (sv_igemm_args::x2): block = (64 channels, group); thread (channel tid % 64, part tid / 64) sums its share of the replicas,
+// Affine coefficients of a BatchNorm backward (sv_bn_bwd_affine) for the two-tensor dy operand of the fused backward that consumes
+// it (sv_bwd3x3_args::dy2): block = (64 channels, group); thread (channel tid % 64, part tid / 64) sums its share of the replicas,
 // the four parts meet in LDS in index order.
 __global__ __launch_bounds__(256) void bn_bwd_affine_kernel(const double* bsums, int R, int C, float inv_count, const float* gamma,
                                                             const float* mean, const float* rstd, float* dgamma, float* dbeta,
@@ -389,37 +389,6 @@ __global__ __launch_bounds__(256) void bn_bwd_affine_kernel(const double* bsums,
         shift[o] = -A * m1 - bx * mean[o];
         if (dbeta) atomicAdd(dbeta + c, (float)t1);
         if (dgamma) atomicAdd(dgamma + c, (float)t2);
-    }
-}
-
-// out = sa[c] * x + sb[c] * x2 + sh[c]: the two-tensor prologue of sv_igemm_args::x2 as a pass of its own, for the kernels of the
-// family that do not form it in their load path (sv_lin2_materialize)
-template <typename T>
-__global__ __launch_bounds__(256) void lin2_kernel(const T* x, const T* x2, const float* sa, const float* sb, const float* sh,
-                                                   int64_t M, int C, T* out) {
-    typedef typename V8<T>::type V;
-    const int grp = blockIdx.y;
-    x += (int64_t)grp * M * C;
-    x2 += (int64_t)grp * M * C;
-    out += (int64_t)grp * M * C;
-    sa += (int64_t)grp * C;
-    sb += (int64_t)grp * C;
-    sh += (int64_t)grp * C;
-    // block size = a multiple of the C / 8 vectors of a row (host): a thread meets the same 8 channels at every step and keeps
-    // their coefficients in registers (as sv_bn_bwd_apply does)
-    const int cv = C / 8;
-    const int64_t gsz = (int64_t)gridDim.x * blockDim.x, gtid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int c0 = (int)(gtid % cv) * 8;
-    float ca[8], cb[8], cc[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { ca[j] = sa[c0 + j]; cb[j] = sb[c0 + j]; cc[j] = sh[c0 + j]; }
-    const int64_t nv = M * cv;
-    for (int64_t i = gtid; i < nv; i += gsz) {
-        const V a = __builtin_nontemporal_load(reinterpret_cast<const V*>(x) + i), b = __builtin_nontemporal_load(reinterpret_cast<const V*>(x2) + i);
-        V o;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = (T)(to_f(a[j]) * ca[j] + (to_f(b[j]) * cb[j] + cc[j]));
-        reinterpret_cast<V*>(out)[i] = o;
     }
 }
 
@@ -2566,21 +2535,3 @@ int sv_repack_strided(int dtype, const float* src, int n_real, int c_real, int64
 }
 
 }  // extern "C"
-
-// sv_igemm's fallback for sv_igemm_args::x2: pro_out = pro_scale * x + pro_scale2 * x2 + pro_shift as a launch of its own (timed
-// under the nested tag of kind 1, never as a second launch of the layer whose sv_igemm issued it)
-int sv_prof_nested_scope(int enter, int kind);
-int sv_lin2_materialize(const sv_geom* g, int dtype, const sv_igemm_args* a, void* stream) {
-    struct Nested { Nested() { sv_prof_nested_scope(1, 1); } ~Nested() { sv_prof_nested_scope(0, 1); } } nested;
-    SvProfScope prof_scope(stream);
-    const int64_t M = (int64_t)g->B * g->Hin * g->Win;
-    const int C = g->Cin, groups = sv_ngroups(a->groups);
-    SV_REQUIRE(C % 8 == 0 && g->ldx == C, SV_E_SHAPE, "sv_igemm: two-tensor prologue on Cin=%d ldx=%d", C, g->ldx);
-    const int cv = C / 8;
-    const int nthr = 256 % cv == 0 ? 256 : (cv <= 256 ? 256 / cv * cv : 0);
-    SV_REQUIRE(nthr > 0, SV_E_SHAPE, "sv_igemm: two-tensor prologue on Cin=%d (at most 2048 channels)", C);
-    DISPATCH_T(dtype, hipLaunchKernelGGL((lin2_kernel<T>), dim3(nblocks(M * cv, nthr, 2048), groups), dim3(nthr), 0, (hipStream_t)stream,
-                                         (const T*)a->x, (const T*)a->x2, a->pro_scale, a->pro_scale2, a->pro_shift, M, C, (T*)a->pro_out));
-    return sv_check_launch("sv_igemm(two-tensor prologue, materialised)");
-}
-

@@ -877,7 +877,7 @@ int launch_tconvx16(const sv_geom* g, const sv_igemm_args* a, hipStream_t s) {
 // Returns 1 and sets *rc when the launch is a ConvTranspose2d(4, 2, 1) forward this kernel covers.
 int sv_tconvr_try(const sv_geom* g, int dtype, const sv_igemm_args* a, hipStream_t s, int* rc) {
     if (sv_disabled(SV_K_TCONVR) || dtype != SV_BF16) return 0;
-    if (a->bias || a->residual || a->x2 || a->sparse_out) return 0;
+    if (a->bias || a->residual || a->sparse_out) return 0;
     if (a->ex && (a->stats || a->pro_scale || sv_disabled(SV_K_TCONVR_EX))) return 0;
     if ((a->flags & SV_FLAG_DET) && (a->stats || a->ex)) return 0;            // (fixed-order statistics: the LDS-halo kernel's per-wave slots)
     if (g->nphase != 4 || g->sy != 1 || g->sx != 1 || g->osy != 2 || g->osx != 2) return 0;

@@ -1,13 +1,16 @@
-// Stride-1 3x3 convolutions of the THIN layers at 32x32 (16 / 32 channels: the stem, wideresnet.py:13-14; the first convolution of
-// block 1, 16 -> 32, wideresnet.py:29-30, and its data gradient 32 -> 16) with register-resident weights.  gfx950.
+// The data gradient of the THIN stride-1 3x3 convolution at 32x32 (block 1's first convolution 16 -> 32, wideresnet.py:29-30: its
+// data gradient 32 -> 16 with the activation-backward epilogue) with register-resident weights.  gfx950.
+// (Round 5 also carried FORWARD forms of this kernel -- stem 16 -> 16 with bias, 16 -> 32 with the folded BatchNorm finalisation --:
+//  as exact as the kernels they replace, but their different rounding of the first two layers moved the bf16 step's posterior term over
+//  a 5e-3 gate for 19 us; they left the library in round 6, docs/lab_notes_r05.md.)
 // These layers move 134-268 MB against 1-5 GFLOP: they are HBM-bound, and the LDS-halo kernels ran them at 2.4-3.8 TB/s.  sconv.hip's
 // scheme at stride 1: unit of work = a band of 8 output rows (10 input rows), a persistent block of eight waves = the band's eight
 // rows (a wave: one row of 32 pixels = one MFMA tile, all output channels); the few weights ([32 or 16 (padded to 32 rows)][9 taps x
-// CIN]: 9 / 18 A fragments) live in registers; the band is staged once -- BatchNorm + LeakyReLU applied on the way in -- into a
+// CIN]: 9 / 18 A fragments) live in registers; the band is staged once into a
 // zero-bordered LDS image of 16-channel planes (k-step = immediate offset, tap = per-lane base; a pixel's two 16-byte halves are
 // swapped where (column >> 3) is odd, which makes a ds_read_b128 lane group -- columns 0-3, 12-15, 20-27 of one row -- conflict-
-// free for every tap shift); two bands, one barrier per band; epilogue out of the accumulators (bias, statistics, or the
-// activation-backward form with the raw tensor redistributed by v_permlane32_swap), 16-byte stores.
+// free for every tap shift); two bands, one barrier per band; epilogue out of the accumulators (the activation-backward form with the
+// raw tensor redistributed by v_permlane32_swap), 16-byte stores.
 // Same sv_geom / packed weights / sv_igemm_args contract as sv_igemm: a fast path inside it (SV_K_THCONV disables).
 #include <type_traits>
 
@@ -25,12 +28,12 @@ struct thconv_cfg {
     static constexpr int NTH = 512, VROW = W * CPP, NVEC = 10 * VROW, VPT = (NVEC + NTH - 1) / NTH;
     static constexpr int NG = NOUT / 16;                            // 16-byte stores per lane and pixel (16 channels per lane pair each)
     static constexpr int OFF_WSUM = 2 * TILE;                      // [8 waves][2][32] floats
-    static constexpr int OFF_COEF = OFF_WSUM + 8 * 2 * 32 * 4;     // [CIN] pairs {scale, shift}  /  (EX) [NOUT] x {scale, shift, rstd, -mean rstd}
+    static constexpr int OFF_COEF = OFF_WSUM + 8 * 2 * 32 * 4;     // [NOUT] x {scale, shift, rstd, -mean rstd}
     static constexpr int LDS = OFF_COEF + 32 * 16;
     static_assert(NTH % VROW == 0 && LDS <= 64 * 1024, "staging / LDS");
 };
 
-template <int CIN, int NOUT, bool EX>
+template <int CIN, int NOUT>
 __global__ __launch_bounds__(512, 1) void thconv_kernel(const sv_geom g, const sv_igemm_args_g AG) {
     typedef thconv_cfg<CIN, NOUT> C;
     constexpr int W = C::W, KC = C::KC, KS = C::KS, CPP = C::CPP, PITCH = C::PITCH, PLANE = C::PLANE, TILE = C::TILE, NTH = C::NTH;
@@ -81,27 +84,14 @@ __global__ __launch_bounds__(512, 1) void thconv_kernel(const sv_geom g, const s
             wf[ks] = f;
         }
     }
-    const bool has_pro = !EX && a.pro_scale != nullptr;
     float* const coef = reinterpret_cast<float*>(smem + C::OFF_COEF);
-    const float slope = has_pro ? a.pro_slope : 1.f;
     {
         bf16x8 z;
 #pragma unroll
         for (int j = 0; j < 8; ++j) z[j] = (bf16)0.f;
         for (int i = tid; i < 2 * TILE / 16; i += NTH) *reinterpret_cast<bf16x8*>(smem + 16 * i) = z;
     }
-    // (BatchNorm finalisation folded into the launch: the scratch lies in the image area -- fold first, zero after)
-    if (!EX && a.fold_stats) {
-        __syncthreads();
-        sv_bn_fold_block512(a, CIN, reinterpret_cast<double*>(smem), coef, blockIdx.x == 0);
-        bf16x8 z;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) z[j] = (bf16)0.f;
-        for (int i = tid; i < 8192 / 16; i += NTH) *reinterpret_cast<bf16x8*>(smem + 16 * i) = z;
-    } else if (has_pro && tid < 2 * CIN) {
-        coef[tid] = (tid & 1) ? a.pro_shift[tid >> 1] : a.pro_scale[tid >> 1];
-    }
-    if (EX && tid < NOUT) {
+    if (tid < NOUT) {
         const float rs = a.ex_rstd[tid];
         reinterpret_cast<f32x4*>(coef)[tid] = f32x4{a.ex_scale[tid], a.ex_shift[tid], rs, -a.ex_mean[tid] * rs};     // xhat = x rstd - mean rstd
     }
@@ -113,24 +103,10 @@ __global__ __launch_bounds__(512, 1) void thconv_kernel(const sv_geom g, const s
         sdst = (sc >> 1) * PLANE + (r * PITCH + xx) * 32 + ((((sc & 1) ^ (xx >> 3)) & 1) << 4);
     }
     auto stage = [&](int buf, int bd, const bf16x8 (&xr)[VPT]) __attribute__((always_inline)) {
-        const int b = bd % BPI;
-        f32x4 s0 = {1.f, 1.f, 1.f, 1.f}, s1 = s0, t0 = {0.f, 0.f, 0.f, 0.f}, t1 = t0;
-        if (has_pro) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const f32x4 c = *reinterpret_cast<const f32x4*>(coef + 16 * sc + 4 * j);        // channels 8 sc + 2 j, + 1
-                (j < 2 ? s0 : s1)[2 * (j & 1)] = c[0]; (j < 2 ? t0 : t1)[2 * (j & 1)] = c[1];
-                (j < 2 ? s0 : s1)[2 * (j & 1) + 1] = c[2]; (j < 2 ? t0 : t1)[2 * (j & 1) + 1] = c[3];
-            }
-        }
 #pragma unroll
         for (int i = 0; i < VPT; ++i) {
             const int v = tid + NTH * i;
-            if (v < C::NVEC) {
-                // (a padding row stays zero: it is not transformed)
-                const bf16x8 val = (has_pro && row_ok(b, v)) ? bn_act8(xr[i], s0, s1, t0, t1, slope) : xr[i];
-                *reinterpret_cast<bf16x8*>(smem + buf * TILE + sdst + i * ((NTH / VROW) * PITCH * 32)) = val;
-            }
+            if (v < C::NVEC) *reinterpret_cast<bf16x8*>(smem + buf * TILE + sdst + i * ((NTH / VROW) * PITCH * 32)) = xr[i];
         }
     };
     // B fragments: output pixel (row wave, column q) at tap (dy, dx) reads LDS row wave + dy + 1, column q + dx + 1, channels 16 kc + 8 h ..
@@ -141,9 +117,7 @@ __global__ __launch_bounds__(512, 1) void thconv_kernel(const sv_geom g, const s
         rb[t] = (rr * PITCH + xx) * 32 + (((h ^ (xx >> 3)) & 1) << 4);
     }
     const int opix = (wave * W + q) * g.ldo + 8 * h;
-    const bool want_stats = EX || a.stats != nullptr;
-    const bool has_bias = !EX && a.bias != nullptr;
-    const float ex_slope = EX ? a.ex_slope : 1.f;
+    const float ex_slope = a.ex_slope;
     float ps1[8 * NG], ps2[8 * NG];               // this lane's NOUT / 2 channels
 #pragma unroll
     for (int e = 0; e < 8 * NG; ++e) ps1[e] = ps2[e] = 0.f;
@@ -162,11 +136,9 @@ __global__ __launch_bounds__(512, 1) void thconv_kernel(const sv_geom g, const s
         if (nx2 < nband) request(nx2, xfar);
         const int im = band / BPI, b = band - im * BPI;
         const int64_t obase = ((int64_t)im * W + 8 * b) * W * g.ldo;
-        u32x4 opr[NG];                        // (EX) the raw tensor at this lane's 16-byte store positions
-        if (EX) {
+        u32x4 opr[NG];                        // the raw tensor at this lane's 16-byte store positions
 #pragma unroll
-            for (int gp = 0; gp < NG; ++gp) opr[gp] = *reinterpret_cast<const u32x4*>(EXP + obase + opix + 16 * gp);
-        }
+        for (int gp = 0; gp < NG; ++gp) opr[gp] = *reinterpret_cast<const u32x4*>(EXP + obase + opix + 16 * gp);
         f32x16 acc;
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[e] = 0.f;
@@ -188,14 +160,12 @@ __global__ __launch_bounds__(512, 1) void thconv_kernel(const sv_geom g, const s
 #pragma unroll
         for (int gp = 0; gp < NG; ++gp) {
             uint32_t xw[2][2], ow[2][2];
-            if (EX) {
 #pragma unroll
-                for (int d = 0; d < 2; ++d) {
-                    // loaded: lanes 0-31 channels 16 gp + 0 .. 7, lanes 32-63 channels 16 gp + 8 .. 15; wanted: 8 gq + 4 h + e
-                    const auto rr = __builtin_amdgcn_permlane32_swap(opr[gp][d], opr[gp][2 + d], false, false);
-                    xw[0][d] = rr[0];
-                    xw[1][d] = rr[1];
-                }
+            for (int d = 0; d < 2; ++d) {
+                // loaded: lanes 0-31 channels 16 gp + 0 .. 7, lanes 32-63 channels 16 gp + 8 .. 15; wanted: 8 gq + 4 h + e
+                const auto rr = __builtin_amdgcn_permlane32_swap(opr[gp][d], opr[gp][2 + d], false, false);
+                xw[0][d] = rr[0];
+                xw[1][d] = rr[1];
             }
 #pragma unroll
             for (int k = 0; k < 2; ++k)
@@ -203,7 +173,7 @@ __global__ __launch_bounds__(512, 1) void thconv_kernel(const sv_geom g, const s
                 for (int d = 0; d < 2; ++d) {
                     const int gq = 2 * gp + k, e0 = 4 * gq + 2 * d, cch = 8 * gq + 4 * h + 2 * d;
                     float g0 = acc[e0], g1 = acc[e0 + 1];
-                    if (EX) {
+                    {
                         const f32x4 c0 = reinterpret_cast<const f32x4*>(coef)[cch], c1 = reinterpret_cast<const f32x4*>(coef)[cch + 1];
                         const uint32_t w = xw[k][d];
                         const float x0 = __builtin_bit_cast(float, w << 16), x1 = __builtin_bit_cast(float, w & 0xffff0000u);
@@ -213,12 +183,6 @@ __global__ __launch_bounds__(512, 1) void thconv_kernel(const sv_geom g, const s
                         ps2[e0] += g0 * (x0 * c0[2] + c0[3]);
                         ps1[e0 + 1] += g1;
                         ps2[e0 + 1] += g1 * (x1 * c1[2] + c1[3]);
-                    } else {
-                        if (has_bias) { g0 += a.bias[cch]; g1 += a.bias[cch + 1]; }
-                        if (want_stats) {
-                            ps1[e0] += g0; ps2[e0] += g0 * g0;
-                            ps1[e0 + 1] += g1; ps2[e0 + 1] += g1 * g1;
-                        }
                     }
                     typedef bf16 bf16x2 __attribute__((ext_vector_type(2)));
                     const bf16x2 pr = {(bf16)g0, (bf16)g1};
@@ -244,7 +208,7 @@ __global__ __launch_bounds__(512, 1) void thconv_kernel(const sv_geom g, const s
         band += step;
     }
     // ---- sums: 32 pixel lanes -> lanes 0 / 32, the eight waves through LDS, one double atomic per channel and block
-    if (want_stats) {
+    {
         float* const wsum = reinterpret_cast<float*>(smem + C::OFF_WSUM) + wave * 64;
 #pragma unroll
         for (int e = 0; e < 8 * NG; ++e) {
@@ -267,12 +231,12 @@ __global__ __launch_bounds__(512, 1) void thconv_kernel(const sv_geom g, const s
             float v = 0.f;
 #pragma unroll
             for (int m = 0; m < 8; ++m) v += ws[m * 64];
-            atomicAdd((EX ? a.bsums : a.stats) + (size_t)(blockIdx.x & (a.replicas - 1)) * 2 * NOUT + tid, (double)v);
+            atomicAdd(a.bsums + (size_t)(blockIdx.x & (a.replicas - 1)) * 2 * NOUT + tid, (double)v);
         }
     }
 }
 
-template <int CIN, int NOUT, bool EX>
+template <int CIN, int NOUT>
 int launch_thconv(const sv_geom* g, const sv_igemm_args* a, hipStream_t s) {
     typedef thconv_cfg<CIN, NOUT> C;
     const int G = sv_ngroups(a->groups);
@@ -282,12 +246,9 @@ int launch_thconv(const sv_geom* g, const sv_igemm_args* a, hipStream_t s) {
     if (per > nband) per = nband;
     const int rounds = (nband + per - 1) / per;
     const int grid = (nband + rounds - 1) / rounds;
-    sv_igemm_args b = *a;          // the forward form folds the BatchNorm finalisation of its prologue
-    if (!sv_fold_claim(!EX && b.fold_stats != nullptr)) b.fold_stats = nullptr;
-    a = &b;
     SV_LAUNCH_GATE(grid, a);
     sv_prof_begin(s);
-    hipLaunchKernelGGL((thconv_kernel<CIN, NOUT, EX>), dim3(grid, G), dim3(C::NTH), C::LDS, s, *g, sv_expand_groups(*g, *a, 2));
+    hipLaunchKernelGGL((thconv_kernel<CIN, NOUT>), dim3(grid, G), dim3(C::NTH), C::LDS, s, *g, sv_expand_groups(*g, *a, 2));
     sv_prof_end(s);
     return sv_check_launch("sv_igemm(thconv)");
 }
@@ -297,14 +258,10 @@ int launch_thconv(const sv_geom* g, const sv_igemm_args* a, hipStream_t s) {
 // Returns 1 and sets *rc when the launch is a thin stride-1 3x3 convolution at 32x32 this kernel covers.
 int sv_thconv_try(const sv_geom* g, int dtype, const sv_igemm_args* a, hipStream_t s, int* rc) {
     if (sv_disabled(SV_K_THCONV) || dtype != SV_BF16) return 0;
-    // The FORWARD forms are off by default (SV_OPT_ENABLE_MASK, SV_K_THCONV_FWD).  They are as exact as the kernels they replace
-    // (statistics 1e-8 and outputs bit-comparable against fp64: tools/probes/thconv_stats_err.py), but they round other elements of
-    // the first two layers' outputs, and the bf16 step's posterior terms -- which sit at 2-5e-3 of the fp32 oracle under ANY kernel set
-    // (tools/probes/b64_scalars.py) -- landed at 5.27e-3 with them, over the 5e-3 gate of tests/test_model_gpu.py, for 19 us.
-    if (!a->ex && !sv_enabled(SV_K_THCONV_FWD)) return 0;
-    if (a->residual || a->x2 || a->sparse_out) return 0;
-    if (a->ex && (a->stats || a->pro_scale || a->bias)) return 0;
-    if ((a->flags & SV_FLAG_DET) && (a->stats || a->ex)) return 0;
+    if (!a->ex) return 0;
+    if (a->residual || a->sparse_out) return 0;
+    if (a->stats || a->pro_scale || a->bias || a->fold_stats) return 0;
+    if (a->flags & SV_FLAG_DET) return 0;
     if (g->nphase != 1 || g->sy != 1 || g->sx != 1 || g->osy != 1 || g->osx != 1) return 0;
     const sv_phase& P = g->phase[0];
     if (P.ntap != 9 || P.ooy != 0 || P.oox != 0) return 0;
@@ -312,8 +269,6 @@ int sv_thconv_try(const sv_geom* g, int dtype, const sv_igemm_args* a, hipStream
         if (P.dy[t] < -1 || P.dy[t] > 1 || P.dx[t] < -1 || P.dx[t] > 1) return 0;
     if (g->Hin != 32 || g->Win != 32 || g->Hout != 32 || g->Wout != 32 || g->Hq != 32 || g->Wq != 32) return 0;
     if (g->ldx != g->Cin || g->ldo % 8 != 0 || (int64_t)g->B * 1024 * g->ldo >= ((int64_t)1 << 31)) return 0;
-    if (g->Cin == 16 && g->N == 32 && !a->ex) { *rc = launch_thconv<16, 32, false>(g, a, s); return 1; }
-    if (g->Cin == 16 && g->N == 16 && !a->ex) { *rc = launch_thconv<16, 16, false>(g, a, s); return 1; }
-    if (g->Cin == 32 && g->N == 16 && a->ex) { *rc = launch_thconv<32, 16, true>(g, a, s); return 1; }
+    if (g->Cin == 32 && g->N == 16) { *rc = launch_thconv<32, 16>(g, a, s); return 1; }
     return 0;
 }

@@ -582,21 +582,12 @@ int dispatch(const sv_geom* g, const wg_params& p, int tn, int tc, hipStream_t s
 
 }  // namespace
 
-static_assert(sizeof(sv_wgrad_args) == 112 && sizeof(sv_igemm_args) == 248 && sizeof(sv_param_job) == 112, "ABI 6 struct layout (tests/test_abi_cpu.py)");
-
-// sv_wgrad_args::dy2 travels to the dispatcher through the calling thread (sv_wgrad's positional signature is ABI 1)
-static thread_local const sv_wg_lin2* tl_lin2 = nullptr;
+static_assert(sizeof(sv_wgrad_args) == 80 && sizeof(sv_igemm_args) == 224 && sizeof(sv_param_job) == 112 && sizeof(sv_bwd3x3_args) == 152, "ABI 7 struct layout (tests/test_abi_cpu.py)");
 
 extern "C" int sv_wgrad_ex(const sv_geom* g, int dtype, const sv_wgrad_args* a, void* stream) {
     SV_REQUIRE(g && a, SV_E_ARG, "sv_wgrad_ex: null argument");
     SV_REQUIRE(a->block_budget == 0 || a->block_budget >= 8, SV_E_ARG, "sv_wgrad_ex: block_budget=%d", a->block_budget);
     SvBudgetScope budget_scope(a->block_budget);
-    sv_wg_lin2 l2{a->dy2, a->dy_scale, a->dy_scale2, a->dy_shift};
-    if (a->dy2) {
-        SV_REQUIRE(a->dy_scale && a->dy_scale2 && a->dy_shift, SV_E_ARG, "sv_wgrad_ex: the two-tensor dy operand (dy2) needs dy_scale, dy_scale2 and dy_shift");
-        tl_lin2 = &l2;
-    }
-    struct Clear { ~Clear() { tl_lin2 = nullptr; } } clear;
     return sv_wgrad(g, dtype, a->x, a->pro_scale, a->pro_shift, a->pro_slope, a->dy, a->dw, a->splits, a->use_tr, a->ws,
                     a->ws_elems, a->groups, stream);
 }
@@ -612,17 +603,6 @@ extern "C" int sv_wgrad(const sv_geom* g, int dtype, const void* x, const float*
     SV_REQUIRE(groups >= 0 && groups <= SV_MAX_GROUPS, SV_E_ARG, "sv_wgrad: groups=%d (at most %d)", groups, SV_MAX_GROUPS);
     SV_REQUIRE(!pro_scale || (pro_slope >= 0.f && pro_slope <= 1.f), SV_E_ARG,
                "sv_wgrad: activation slope %g outside [0, 1]", (double)pro_slope);
-    if (tl_lin2) {
-        // two-tensor dy operand: implemented by the narrow stride-1 3x3 kernel (bf16, 32x32x16 form) only -- refused elsewhere
-        int rc = 0;
-        const sv_wg_lin2* l2 = tl_lin2;
-        if (dtype == SV_BF16 && use_tr && !sv_deterministic() && !sv_disabled(SV_K_WGRAD3X3) && g->N <= 128 && g->Cin <= 128 &&
-            sv_wgrad3x3_try(g, dtype, x, pro_scale, pro_shift, pro_slope, dy, dw, ws, ws_elems, sv_ngroups(groups), (hipStream_t)stream, &rc, l2))
-            return rc;
-        sv_set_error("sv_wgrad_ex: dy2 (two-tensor dy operand) is implemented for bf16 stride-1 3x3 layers of at most 128 channels on "
-                     "the 32x32x16 kernel only (not in deterministic mode)");
-        return SV_E_ARG;
-    }
     if (sv_deterministic() && sv_ngroups(groups) > 1) {
         // fixed summation order: the groups of a batched launch one after the other (stream order), each a launch whose
         // blocks add ONCE per weight (partial slabs + ordered reduction, or a single M range of the generic kernel)
@@ -649,9 +629,6 @@ extern "C" int sv_wgrad(const sv_geom* g, int dtype, const void* x, const float*
             return rc;
         // the stride-2 3x3 layer 32 -> 64: the whole gradient in every block, bands staged once (s2wgrad.hip)
         if (use_tr && sv_s2wgrad_try(g, dtype, x, pro_scale, pro_shift, pro_slope, dy, dw, sv_ngroups(groups), (hipStream_t)stream, &rc))
-            return rc;
-        // the stride-2 3x3 layer 64 -> 128: the whole gradient in one block's registers (swgrad.hip)
-        if (use_tr && sv_swgrad_try(g, dtype, x, pro_scale, pro_shift, pro_slope, dy, dw, sv_ngroups(groups), (hipStream_t)stream, &rc))
             return rc;
         // the other layers with a spatial extent: tap-fused LDS-halo weight gradient (hwgrad.hip)
         if (use_tr && sv_hwgrad_try(g, dtype, x, pro_scale, pro_shift, pro_slope, dy, dw, ws, ws_elems, sv_ngroups(groups), (hipStream_t)stream, &rc))

@@ -54,11 +54,6 @@ struct wg3_params {
     int splits, tiles_per;        // 128-pixel tiles: range [split*tiles_per, ...)
     int unit;                     // wide kernel: channel chunks per XCD-affinity unit (0: plain block order)
     int groups;                   // batched launch: blockIdx.y = group; slab index = group * splits + split
-    // two-tensor dy (sv_wgrad_args::dy2, wgrad3x3m only): the operand is dy_scale * dy + dy_scale2 * dy2 + dy_shift per channel
-    const void* dy2;
-    const float* dy_scale;
-    const float* dy_scale2;
-    const float* dy_shift;
 };
 
 // 8 consecutive pixels (k = 8g + j) of one (shifted) image row, 16 channels starting at col0: k-major
@@ -757,14 +752,8 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3w_kernel(const sv_geom g, cons
 //   * pipeline: halo registers of tile i + 2 and the dy DMA of tile i + 2 are requested at the top of iteration i, awaited
 //     by the ONE vmcnt(0) at the top of iteration i + 1 (a whole tile period later), transformed into the other halo stage
 //     and consumed in iteration i + 2; three dy stages, two halo stages, one barrier per tile.
-//   * LIN2 (round 5): the dy operand is formed from TWO tensors, dy_scale * dy + dy_scale2 * dy2 + dy_shift per channel -- the
-//     BatchNorm backward of the layer between this convolution and the gradient that arrives (sv_wgrad_args::dy2; the data
-//     gradient of the same layer forms the same values in its load path, sv_igemm_args::x2, so no transformed tensor is ever
-//     written).  dy2 rides in ONE more LDS stage by DMA, lane for lane like dy; after the iteration's vmcnt(0) every lane
-//     combines the slots IT copied (its own DMA writes are visible to it: no barrier) in place into the dy stage that the
-//     iteration's barrier then publishes, and re-requests the dy2 stage for the tile after.
 constexpr int LDM = 32;                         // elements per LDS row (64 bytes)
-template <int WLOG, int NB, bool LIN2>
+template <int WLOG, int NB>
 __global__ __launch_bounds__(256, 2) void wgrad3x3m_kernel(const sv_geom g, const sv_wg_g<wg3_params> PG) {
     const wg3_params& p = PG.g[blockIdx.y];
     constexpr int W = 1 << WLOG, TR = 128 / W, WP = W + 2;
@@ -777,10 +766,8 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3m_kernel(const sv_geom g, cons
     constexpr int YI = NP * 2;                             // dy DMA instructions per wave and tile (1 KiB each)
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    bf16* const lds0 = reinterpret_cast<bf16*>(smem);      // [3][YB] dy stages, then [2][HB] halo stages (LIN2: + [YB] dy2, [3][NB] floats)
+    bf16* const lds0 = reinterpret_cast<bf16*>(smem);      // [3][YB] dy stages, then [2][HB] halo stages
     bf16* const halo0 = lds0 + 3 * YB;
-    bf16* const y2s = halo0 + 2 * HB;
-    float* const cf = reinterpret_cast<float*>(y2s + YB);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wave_s = __builtin_amdgcn_readfirstlane(wave);
@@ -803,19 +790,9 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3m_kernel(const sv_geom g, cons
     const uint64_t pdy = pack_taps(P.dy), pdx = pack_taps(P.dx);
     const bf16* __restrict__ X = reinterpret_cast<const bf16*>(p.x);
     const bf16* __restrict__ DY = reinterpret_cast<const bf16*>(p.dy);
-    const bf16* __restrict__ DY2 = LIN2 ? reinterpret_cast<const bf16*>(p.dy2) : nullptr;
     const bool has_pro = p.pro_scale != nullptr;
     float pslope = has_pro ? p.pro_slope : 1.f;
     asm volatile("v_mov_b32 %0, %0" : "+v"(pslope));
-    if (LIN2) {
-        if (threadIdx.x < NB) {
-            cf[threadIdx.x] = p.dy_scale[n0 + threadIdx.x];
-            cf[NB + threadIdx.x] = p.dy_scale2[n0 + threadIdx.x];
-            cf[2 * NB + threadIdx.x] = p.dy_shift[n0 + threadIdx.x];
-        }
-        __syncthreads();
-    }
-
     const int v = tid & 3;
     // without a prologue the transform is the identity (scale 1, shift 0, slope 1: exact bf16 -> fp32 -> bf16)
     f32x4 s0 = {1.f, 1.f, 1.f, 1.f}, s1 = s0, t0 = {0.f, 0.f, 0.f, 0.f}, t1 = t0;
@@ -857,7 +834,6 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3m_kernel(const sv_geom g, cons
     }
     const uint32_t l0 = (uint32_t)(uintptr_t)(wg_lds_ptr)lds0;
     const char* ybase = nullptr;
-    const char* y2base = nullptr;
     const char* hbase = nullptr;
     bool top_ok = false, bot_ok = false;
     auto bases = [&](int tile) {
@@ -866,7 +842,6 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3m_kernel(const sv_geom g, cons
         bot_ok = ((gr0 + TR) & (H - 1)) != 0;
         hbase = reinterpret_cast<const char*>(X) + ((int64_t)gr0 - 1) * W * g.ldx * 2;
         ybase = reinterpret_cast<const char*>(DY + (int64_t)gr0 * W * g.ldo);
-        if (LIN2) y2base = reinterpret_cast<const char*>(DY2 + (int64_t)gr0 * W * g.ldo);
     };
     // every VMEM instruction of the loop is spelled in assembly and awaited by the one vmcnt(0) per iteration: the compiler
     // neither sees the DMA's LDS writes nor counts assembly loads
@@ -878,42 +853,6 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3m_kernel(const sv_geom g, cons
                      :: "s"(base), "n"(k * 4096), "v"(yo), "s"(yb) : "memory", "scc");
     };
     auto dma_y = [&](int ystage) { static_for<YI>([&](auto K) { dma_y1(ystage, K); }); };
-    // the second tensor of the dy operand: ONE stage behind the halo stages, same lane-linear image as a dy stage
-    auto dma_y2 = [&]() {
-        if constexpr (LIN2) {
-            static_for<YI>([&](auto K) {
-                constexpr int k = decltype(K)::value;
-                const uint32_t base = l0 + (uint32_t)((3 * YB + 2 * HB) * 2) + (uint32_t)wave_s * 1024u, yo = yoff[k];
-                const char* yb = y2base;
-                asm volatile("s_add_u32 m0, %0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3"
-                             :: "s"(base), "n"(k * 4096), "v"(yo), "s"(yb) : "memory", "scc");
-            });
-        }
-    };
-    // after the vmcnt(0): this lane's own 16-byte slots of dy stage `ystage` and of the dy2 stage -> the combined operand, in place
-    auto combine = [&](int ystage) {
-        if constexpr (LIN2) {
-            static_for<YI>([&](auto K) {
-                constexpr int k = decltype(K)::value;
-                const int slot = (wave_s * 1024 + k * 4096) / 2 + lane * 8;            // elements
-                bf16* gp = lds0 + ystage * YB + slot;
-                const bf16x8 gv = *reinterpret_cast<const bf16x8*>(gp);
-                const bf16x8 xv = *reinterpret_cast<const bf16x8*>(y2s + slot);
-                const int ch = 32 * ((4 * k + wave_s) >> 3) + 8 * (lane & 3);
-                bf16x8 o;
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const f32x4 ca = *reinterpret_cast<const f32x4*>(cf + ch + 4 * h);
-                    const f32x4 cb = *reinterpret_cast<const f32x4*>(cf + NB + ch + 4 * h);
-                    const f32x4 cc = *reinterpret_cast<const f32x4*>(cf + 2 * NB + ch + 4 * h);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        o[4 * h + j] = (bf16)(to_f(gv[4 * h + j]) * ca[j] + (to_f(xv[4 * h + j]) * cb[j] + cc[j]));
-                }
-                *reinterpret_cast<bf16x8*>(gp) = o;
-            });
-        }
-    };
     bf16x8 rh[HI];
     bool hok[HI];
     auto load_h1 = [&](auto I) {
@@ -996,14 +935,11 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3m_kernel(const sv_geom g, cons
         // prologue: tile t_begin complete in stage 0; tile t_begin + 1 requested (halo registers, dy into stage 1)
         bases(t_begin);
         dma_y(0);
-        dma_y2();
         load_h();
         drain();
-        combine(0);
         store_h(0);
         bases(min(t_begin + 1, t_end - 1));
         dma_y(1);
-        dma_y2();
         load_h();
         __syncthreads();
         int ys = 0, hs = 0;                     // stages of the tile on the MFMAs
@@ -1011,14 +947,12 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3m_kernel(const sv_geom g, cons
             // the requests of the previous iteration (halo registers + dy of tile + 1) have had a whole tile period
             drain();
             const int ys1 = ys == 2 ? 0 : ys + 1, ys2 = ys1 == 2 ? 0 : ys1 + 1;
-            combine(ys1);                       // (LIN2) dy of tile + 1 from its two tensors, published by this iteration's barrier
 #ifndef SV_WG3M_NO_HST
             store_h(hs ^ 1);                    // halo of tile + 1 (nobody reads that stage: tile - 1 ended at the last barrier)
 #endif
             bases(min(tile + 2, t_end - 1));    // (past the end: a harmless re-load of the last tile)
 #ifndef SV_WG3M_NO_LOAD
             dma_y(ys2);
-            dma_y2();
             load_h();
 #endif
             // ---- the MFMAs of `tile` ------------------------------------------------------------------------------
@@ -1167,32 +1101,25 @@ int launch(const sv_geom* g, const wg3_params& p, hipStream_t s) {
     return sv_check_launch("sv_wgrad(3x3)");
 }
 
-template <int WLOG, int NB, bool LIN2 = false>
+template <int WLOG, int NB>
 int launch_m(const sv_geom* g, const wg3_params& p, hipStream_t s) {
     constexpr int W = 1 << WLOG, TR = 128 / W;
     constexpr int HHn = (TR < W) ? TR : W, LROWSn = TR + TR / HHn + 1, HPn = LROWSn * (W + 2);
     constexpr int YB = (NB / 32) * 128 * LDM, HB = ((HPn * LDM + 511) / 512) * 512;
-    constexpr size_t stage_bytes = (size_t)(3 * YB + 2 * HB + (LIN2 ? YB : 0)) * 2 + (LIN2 ? 3 * NB * 4 : 0), red_bytes = (size_t)9 * NB * 32 * 4;
+    constexpr size_t stage_bytes = (size_t)(3 * YB + 2 * HB) * 2, red_bytes = (size_t)9 * NB * 32 * 4;
     constexpr size_t lds = stage_bytes > red_bytes ? stage_bytes : red_bytes;
     const int nNC = (g->N / NB) * (g->Cin / 32);
     const int grid = p.splits * nNC;
     static bool optin = false;
     if (!optin) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3x3m_kernel<WLOG, NB, LIN2>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3x3m_kernel<WLOG, NB>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return sv_check_launch("hipFuncSetAttribute(wgrad3x3m)");
         optin = true;
     }
     auto PG = sv_expand_wg(*g, p, p.groups, 2);
-    if (LIN2)
-        for (int64_t grp = 1; grp < p.groups; ++grp) {          // the second dy tensor and its coefficient vectors follow the groups too
-            PG.g[grp].dy2 = reinterpret_cast<const char*>(p.dy2) + grp * ((int64_t)g->B * g->Hout * g->Wout * g->ldo * 2);
-            PG.g[grp].dy_scale = p.dy_scale + grp * g->N;
-            PG.g[grp].dy_scale2 = p.dy_scale2 + grp * g->N;
-            PG.g[grp].dy_shift = p.dy_shift + grp * g->N;
-        }
     sv_prof_begin(s);
-    hipLaunchKernelGGL((wgrad3x3m_kernel<WLOG, NB, LIN2>), dim3(grid, p.groups), dim3(256), lds, s, *g, PG);
+    hipLaunchKernelGGL((wgrad3x3m_kernel<WLOG, NB>), dim3(grid, p.groups), dim3(256), lds, s, *g, PG);
     sv_prof_end(s);
     if (p.ws) {
         const int64_t n = (int64_t)g->N * g->T_orig * g->Cin;
@@ -1232,7 +1159,7 @@ void sv_slab_reduce(const float* ws, int nslabs, int64_t n, float* dw, hipStream
 // Returns 1 and sets *rc when the geometry is a stride-1 3x3 convolution this kernel covers.
 int sv_wgrad3x3_try(const sv_geom* g, int dtype, const void* x, const float* pro_scale, const float* pro_shift,
                     float pro_slope, const void* dy, float* dw, float* ws, int64_t ws_elems, int groups, hipStream_t s,
-                    int* rc, const sv_wg_lin2* lin2) {
+                    int* rc) {
     if (g->nphase != 1 || g->phase[0].ntap != 9 || g->sy != 1 || g->sx != 1 || g->osy != 1 || g->osx != 1) return 0;
     if (g->Hq != g->Hin || g->Wq != g->Win || g->Hout != g->Hin || g->Wout != g->Win || g->Hin != g->Win) return 0;
     if (g->Win != 8 && g->Win != 16 && g->Win != 32) return 0;
@@ -1246,15 +1173,8 @@ int sv_wgrad3x3_try(const sv_geom* g, int dtype, const void* x, const float* pro
     p.x = x; p.pro_scale = pro_scale; p.pro_shift = pro_shift; p.pro_slope = pro_slope; p.dy = dy; p.dw = dw;
     p.unit = 0;
     p.groups = groups;
-    p.dy2 = nullptr; p.dy_scale = p.dy_scale2 = p.dy_shift = nullptr;
-    if (lin2) {
-        // the two-tensor dy operand: the 32x32x16 kernel with 32-channel n tiles only (its fourth dy stage must still fit beside
-        // the paired data gradient's block in the CU's LDS)
-        if (dtype != SV_BF16 || sv_disabled(SV_K_WGRAD3X3M) || sv_deterministic()) return 0;
-        p.dy2 = lin2->dy2; p.dy_scale = lin2->scale; p.dy_scale2 = lin2->scale2; p.dy_shift = lin2->shift;
-    }
     const int nT = g->B * g->Hin / TR;          // per group
-    if (!lin2 && !sv_disabled(SV_K_WGRAD3X3W) && dtype == SV_BF16 && g->N % 160 == 0 && g->Cin >= 96) {
+    if (!sv_disabled(SV_K_WGRAD3X3W) && dtype == SV_BF16 && g->N % 160 == 0 && g->Cin >= 96) {
         // wide layers: 160 x 32 slabs, one block (one wave per SIMD) per CU.  Pick the split count and the affinity unit
         // (a divisor of the chunk count) that minimise the modelled time:
         //   compute: rounds-of-32-CUs-per-XCD x (tiles per block + publishing a 160 x 32 x 9 slab, ~4 tiles) x 2.0 us
@@ -1303,7 +1223,7 @@ int sv_wgrad3x3_try(const sv_geom* g, int dtype, const void* x, const float* pro
     }
     // bf16: the 32x32x16 kernel with 64- (or 32-) channel n tiles
     const bool use_m = dtype == SV_BF16 && !sv_disabled(SV_K_WGRAD3X3M);
-    const int NBm = use_m && g->N % 64 == 0 && !lin2 ? 64 : 32;
+    const int NBm = use_m && g->N % 64 == 0 ? 64 : 32;
     const int nNC = (g->N / NBm) * (g->Cin / 32);
     // ~two persistent blocks per CU; every block should still see a few tiles
     const int budget = sv_persistent_blocks();
@@ -1318,14 +1238,6 @@ int sv_wgrad3x3_try(const sv_geom* g, int dtype, const void* x, const float* pro
     const int64_t need = (int64_t)splits * groups * g->N * g->T_orig * g->Cin;
     p.ws = (ws && ws_elems >= need && splits * groups > 1) ? ws : nullptr;    // no workspace: atomics straight into dw
     if (!p.ws && splits * groups > 1 && sv_deterministic()) return 0;
-    if (lin2) {
-        switch (g->Win) {
-            case 32: *rc = launch_m<5, 32, true>(g, p, s); break;
-            case 16: *rc = launch_m<4, 32, true>(g, p, s); break;
-            default: *rc = launch_m<3, 32, true>(g, p, s); break;
-        }
-        return 1;
-    }
     if (use_m) {
         switch (g->Win) {
             case 32: *rc = NBm == 64 ? launch_m<5, 64>(g, p, s) : launch_m<5, 32>(g, p, s); break;

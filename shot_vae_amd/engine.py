@@ -435,15 +435,9 @@ class Engine:
         self._pack_key = key
 
     def _igemm(self, g, x, w_ptr, out, pro=None, bias=None, residual=None, stats=None, ex=None, tag=None, groups=1,
-               budget=0, sparse_out=False, lin2=None):
+               budget=0, sparse_out=False):
         a = L.SvIgemmArgs()
         a.groups = groups
-        if lin2 is not None:
-            # two-tensor load prologue (sv_igemm_args::x2): the input is pro[0] * x + lin2[1] * lin2[0] + pro[1], also written
-            # to lin2[2] -- the BatchNorm backward of the layer in front, formed in this launch's load path
-            a.x2, a.pro_scale2 = lin2[0].data_ptr(), lin2[1]
-            if lin2[2] is not None:
-                a.pro_out = lin2[2].data_ptr()
         a.block_budget = budget
         a.sparse_out = int(bool(sparse_out))
         a.x, a.w, a.out = x.data_ptr(), w_ptr, out.data_ptr()
@@ -479,9 +473,7 @@ class Engine:
             else:
                 a.bsums, a.replicas = ex[6:]
         if tag:
-            # (two-tensor prologue: one more read and one more write of an INPUT-sized tensor)
-            self._tag(tag, g, (residual is not None) + (ex is not None), groups=groups,
-                      extra_in=0 if lin2 is None else (2 if lin2[2] is not None else 1))
+            self._tag(tag, g, (residual is not None) + (ex is not None), groups=groups)
         if self._start_signal is not None:       # (see _wgrad_async: this launch forks the side stream when it starts)
             (a.start_flag, a.start_value), self._start_signal = self._start_signal, None
         L.call("sv_igemm", C.byref(g), self.code, C.byref(a), self._stream())
@@ -506,17 +498,6 @@ class Engine:
     materialize_max_hin = 4          # ... for the layers whose input map is at most this large
     light_fork = True                # fork events without the system-scope fence (sv_stream_fork)
     fork_every = 1                   # weight gradients per side-stream fork
-    # norm2's BatchNorm backward formed in the load path of conv1's data gradient (sv_igemm_args::x2) instead of by an
-    # sv_bn_bwd_apply pass between the two data gradients of a unit: 1 = the same-shape units, 2 = every unit.  Measured with the
-    # transformed tensor written as a SIDE OUTPUT for the weight gradient (round 5, config 2): the kernels gain (bn_bwd_apply
-    # 1.28 -> 0.92 ms, the fused data gradients + 0.25 ms), the step LOSES -- 7.00 -> 7.51 ms -- because the weight gradient
-    # can no longer start beside its own data gradient (it consumes that launch's output): the pair's L2 sharing and the
-    # co-resident blocks are worth more (0.4 ms) than the pass saved; releasing every weight gradient by the NEXT pair's start signal
-    # instead (a shifted pairing, measured and removed) does not recover it (7.49).  3 = the weight gradient forms dx itself too
-    # (sv_wgrad_args::dy2: nothing written, the pair starts together): 7.06 against 6.95 -- still slower.  DESIGN.md 4, round 5.
-    fused_wgrad_paired = True        # ... its weight gradient (forked behind the data gradient) with the paired block budget
-    fuse_bn_bwd = 0
-    fuse_max_channels = 64           # (mode 3) widest layer whose data AND weight gradient form dx themselves
     # sv_bwd3x3 (ABI 7): data gradient + weight gradient of a 32 -> 32 channel body convolution in ONE launch that reads every
     # operand once.  1 = conv1 of the same-shape units in the two-tensor form (norm2's BatchNorm backward formed in the kernel's
     # load path: the sv_bn_bwd_apply pass between the unit's two data gradients disappears: 8 tensor passes -> 4);
@@ -525,7 +506,6 @@ class Engine:
     flag_fork = True                 # paired launches: the data gradient's start signal forks the side stream (no event)
     _start_signal = None
     _pending_wgrads = ()
-    wgrad_after = False              # (experiment, tools: fork the weight gradient behind its data gradient instead of beside it)
     fold_bn = True                   # BatchNorm finalisation folded into the consuming sv_igemm launch (sv_igemm_args::fold_*)
 
     def _side(self):
@@ -539,7 +519,7 @@ class Engine:
             s = pool[cur.cuda_stream] = torch.cuda.Stream()
         return cur, s
 
-    def _wgrad_async(self, g, x, pro, dy, dw_ptr, tag=None, groups=1, budget=0, then=None, after=False, lin2=None):
+    def _wgrad_async(self, g, x, pro, dy, dw_ptr, tag=None, groups=1, budget=0, then=None):
         """Enqueue the weight gradient behind everything issued so far, on the side stream: the dgrad -> BN-apply
         chain continues on the main stream without waiting for it (joined at the end of backward).
         `then`: a callable that issues the main-stream launch paired with this weight gradient (the layer's data gradient).
@@ -551,23 +531,15 @@ class Engine:
         # (not under hipGraph capture: a captured step replays a hundred cross-stream edges slower than one stream --
         #  11.6 against 11.05 ms, measured -- and tensors freed during capture would need to outlive the side stream)
         if not self.wgrad_side_stream or self.prof_tags is not None or torch.cuda.is_current_stream_capturing():
-            if after:                 # (the weight gradient reads what `then` writes)
-                out = then()
-                self._wgrad(g, x, pro, dy, dw_ptr, tag, groups, budget, lin2)
-                return out
-            self._wgrad(g, x, pro, dy, dw_ptr, tag, groups, budget, lin2)
+            self._wgrad(g, x, pro, dy, dw_ptr, tag, groups, budget)
             return then() if then is not None else None
         cur, side = self._side()
         # `fork_every` weight gradients share one fork: every fork is a marker in the main stream's queue that costs it ~6 us of
         # idle time in front of the next kernel (tools/probes/step_list.py: a gap before every data gradient)
-        self._pending_wgrads.append((g, x, pro, dy, dw_ptr, tag, groups, budget, lin2))
+        self._pending_wgrads.append((g, x, pro, dy, dw_ptr, tag, groups, budget))
         if len(self._pending_wgrads) < self.fork_every:
             return then() if then is not None else None
-        if after:                     # the weight gradient consumes what `then` produces: fork BEHIND it
-            out = then()
-            L.call("sv_stream_fork", _vp(cur.cuda_stream), _vp(side.cuda_stream), int(self.light_fork))
-            return self._issue_pending(cur, side, out)
-        if self.flag_fork and not _dispatch_serialised() and then is not None and not self.wgrad_after and len(self._pending_wgrads) == 1:
+        if self.flag_fork and not _dispatch_serialised() and then is not None and len(self._pending_wgrads) == 1:
             # device-side fork: the paired main-stream launch (`then`, an sv_igemm) announces its own START through a flag word
             # (sv_igemm_args::start_flag) -- everything this weight gradient depends on has completed by then -- and the side
             # stream waits for the flag: no event, no marker in the main stream's queue
@@ -590,23 +562,19 @@ class Engine:
         """Fork the side stream off the main stream here and issue the pending weight gradients on it.  The fork is an event
         of the library's pool WITHOUT the system-scope fence of an ordinary event (sv_stream_fork): both streams are on this
         device."""
-        if self.wgrad_after:          # experiment: the weight gradients start when the paired data gradient has FINISHED
-            out = then() if then is not None else None
-            L.call("sv_stream_fork", _vp(cur.cuda_stream), _vp(side.cuda_stream), int(self.light_fork))
-        else:
-            L.call("sv_stream_fork", _vp(cur.cuda_stream), _vp(side.cuda_stream), int(self.light_fork))
-            out = then() if then is not None else None
+        L.call("sv_stream_fork", _vp(cur.cuda_stream), _vp(side.cuda_stream), int(self.light_fork))
+        out = then() if then is not None else None
         return self._issue_pending(cur, side, out)
 
     def _issue_pending(self, cur, side, out=None):
         with torch.cuda.stream(side):
-            for (g, x, pro, dy, dw_ptr, tag, groups, budget, lin2) in self._pending_wgrads:
-                self._wgrad(g, x, pro, dy, dw_ptr, tag, groups, budget, lin2)
+            for (g, x, pro, dy, dw_ptr, tag, groups, budget) in self._pending_wgrads:
+                self._wgrad(g, x, pro, dy, dw_ptr, tag, groups, budget)
         # the operands stay referenced until the streams are joined at the end of backward (no record_stream bookkeeping
         # per tensor: two allocator calls per weight gradient on the host's critical path)
         keep = self._side_keep.setdefault(cur.cuda_stream, [])
         for w in self._pending_wgrads:
-            keep.append((w[1], w[3], w[8]))
+            keep.append((w[1], w[3]))
         self._pending_wgrads = []
         return out
 
@@ -634,15 +602,11 @@ class Engine:
             # memory out again, is ordered behind everything the side stream did
             self._side_keep.pop(cur.cuda_stream, None)
 
-    def _wgrad(self, g, x, pro, dy, dw_ptr, tag=None, groups=1, budget=0, lin2=None):
+    def _wgrad(self, g, x, pro, dy, dw_ptr, tag=None, groups=1, budget=0):
         if tag:
-            self._tag(tag, g, wgrad=True, groups=groups, extra_out_reads=1 if lin2 is not None else 0)
+            self._tag(tag, g, wgrad=True, groups=groups)
         a = L.SvWgradArgs()
         a.x, a.dy, a.dw = x.data_ptr(), dy.data_ptr(), dw_ptr
-        if lin2 is not None:
-            # two-tensor dy operand (sv_wgrad_args::dy2): dy_scale * dy + dy_scale2 * dy2 + dy_shift -- lin2 = (dy2 tensor, scale,
-            # scale2, shift pointers[, what keeps them alive])
-            a.dy2, a.dy_scale, a.dy_scale2, a.dy_shift = lin2[0].data_ptr(), lin2[1], lin2[2], lin2[3]
         if pro is not None:
             a.pro_scale, a.pro_shift, a.pro_slope = pro[0], pro[1], pro[2]
         a.splits, a.use_tr, a.ws, a.ws_elems = 0, self.use_tr, self._wg_ws().data_ptr(), self._ws_elems
@@ -1147,9 +1111,6 @@ class Engine:
             cnt = tin.numel() // tin.shape[-1] // G
             g1 = torch.empty_like(tin)
             tag1 = "conv3x3_%dx%d_s%d" % (un["cin"], c, un["stride"])
-            fuse = self.fuse_bn_bwd if (self.code == L.SV_BF16 and not det) else 0
-            if fuse >= 3 and not (same and c <= self.fuse_max_channels):
-                fuse = 0                  # (both consumers form dx themselves only on the persistent narrow kernels' shapes)
             if fb >= 1 and same:
                 # conv1's WHOLE backward in one launch: dc1 = norm2's BatchNorm backward of g2 is formed in its load path from
                 # (g2, c1) and the finished sums (sv_bn_bwd_affine), both products run from that one LDS image
@@ -1158,30 +1119,6 @@ class Engine:
                              bs_off[un["bn1"].index], bs_rep[un["bn1"].index], "bwd:" + tag1 + "+bn", G)
                 del coef
                 dc1 = None
-            elif fuse and (same or fuse == 2):
-                # norm2's backward is formed in the load path of conv1's data gradient (sv_igemm_args::x2): dx = scale_g * g2 +
-                # scale_x * c1 + shift from the finished sums (sv_bn_bwd_affine, one small launch), written once as a side
-                # output for the weight gradient -- no sv_bn_bwd_apply pass (two reads, one write) between the two data
-                # gradients.  The weight gradient consumes that side output: it is forked BEHIND the data gradient.
-                coef, sg, sx, sh = bn_affine(un["bn2"], cnt2)
-                dc1 = None
-                if fuse >= 3:
-                    # ... and in the load path of conv1's WEIGHT gradient too (sv_wgrad_args::dy2): the transformed tensor is
-                    # never written, and the pair starts together as before
-                    self._wgrad_async(un["conv1"].geom_fwd(B), tin, pro1, g2, gbase + 4 * un["conv1"].master_off,
-                                      tag="wgrad:" + tag1, groups=G, budget=pair1, lin2=(c1, sg, sx, sh, coef),
-                                      then=lambda: self._igemm(un["conv1"].geom_dgrad(B), g2, pk + es * un["conv1"].dgrad_off, g1,
-                                                               pro=(sg, sh, 1.0), lin2=(c1, sx, None), ex=ex_of(un["bn1"], tin),
-                                                               tag="dgrad:" + tag1, groups=G, budget=pair1))
-                else:
-                    dc1 = torch.empty_like(c1)
-                    self._wgrad_async(un["conv1"].geom_fwd(B), tin, pro1, dc1, gbase + 4 * un["conv1"].master_off,
-                                      tag="wgrad:" + tag1, groups=G, budget=pair1 if self.fused_wgrad_paired else 0,
-                                      then=lambda: self._igemm(un["conv1"].geom_dgrad(B), g2, pk + es * un["conv1"].dgrad_off, g1,
-                                                               pro=(sg, sh, 1.0), lin2=(c1, sx, dc1), ex=ex_of(un["bn1"], tin),
-                                                               tag="dgrad:" + tag1, groups=G),
-                                      after=True)
-                del coef
             else:
                 dc1 = bn_apply(c1, [(g2, un["bn2"])], None, cnt2)
                 self._wgrad_async(un["conv1"].geom_fwd(B), tin, pro1, dc1, gbase + 4 * un["conv1"].master_off,

@@ -8,18 +8,24 @@ import torch
 from . import _lib as L
 
 
-class FlatSGD:
+class FlatSGD(torch.optim.Optimizer):
+    """A torch.optim.Optimizer (one param group over model.parameters()): torch.optim.lr_scheduler.MultiStepLR(FlatSGD(...)) -- the
+    reference's schedule, main_shot_vae.py:199,252-254 -- and anything else that walks param_groups works on it; step() is one
+    sv_sgd launch on the engine's flat buffers, not the per-tensor loop."""
+
     def __init__(self, model, lr=0.1, momentum=0.9, weight_decay=5e-4):
         self.model = model
-        self.param_groups = [dict(lr=lr, momentum=momentum, weight_decay=weight_decay)]
         self._steps = 0
+        super().__init__([p for p, _, _ in model._views], dict(lr=lr, momentum=momentum, weight_decay=weight_decay))
 
-    def zero_grad(self):
+    def zero_grad(self, set_to_none=False):          # (the gradients are views of ONE buffer: zeroed, never dropped)
         eng = self.model._engine
         eng.grad.zero_()
         self.model._attach_grads()
 
-    def step(self, grad_scale=1.0):
+    def step(self, closure=None, grad_scale=1.0):
+        if closure is not None:
+            raise NotImplementedError("FlatSGD.step: no closure (the reference's loop has none, main_shot_vae.py:365)")
         eng = self.model._engine
         g = self.param_groups[0]
         if eng.mom is None or eng.mom.device != eng.param.device:
@@ -53,9 +59,11 @@ class FlatSGD:
     def load_state_dict(self, sd):
         eng = self.model._engine
         g = sd["param_groups"][0]
-        self.param_groups = [dict(lr=g["lr"], momentum=g["momentum"], weight_decay=g["weight_decay"])]
         if g.get("nesterov") or g.get("dampening", 0) != 0:
             raise NotImplementedError("FlatSGD implements the reference's SGD (no Nesterov, dampening 0)")
+        self.param_groups[0].update(lr=g["lr"], momentum=g["momentum"], weight_decay=g["weight_decay"])
+        if "initial_lr" in g:                      # (written by an lr scheduler: it resumes from there)
+            self.param_groups[0]["initial_lr"] = g["initial_lr"]
         state = sd.get("state", {})
         bufs = {int(k): v.get("momentum_buffer") for k, v in state.items()}
         if not any(b is not None for b in bufs.values()):

@@ -103,7 +103,7 @@ class _WeightPlan:
         self.n_pass = goff
         self.key = self.gkey = None
         self.model = model
-        self.flushed, self.cb_queued = True, False
+        self.flushed, self.cb_task = True, None
 
     # ---- job tables ---------------------------------------------------------------------------------------------------------
     @staticmethod
@@ -198,6 +198,7 @@ class _WeightPlan:
         if for_backward:
             self.gscr.zero_()
             self.flushed = False
+            self.cb_task = None            # (a backward pass that died before its callback ran must not mute the next one)
 
     def _grad_table(self, model):
         for p in model.parameters():
@@ -214,13 +215,19 @@ class _WeightPlan:
         if self.flushed:
             self.gscr.zero_()
             self.flushed = False
-        if not self.cb_queued:
-            self.cb_queued = True
+        # one flush per BACKWARD PASS, keyed by the autograd engine's graph task -- not by a sticky flag: the engine drops its queued
+        # callbacks when a node of the pass raises (OOM retry, KeyboardInterrupt, ShotVaeHipError), a flag set there would never be
+        # cleared and every later pass would leave .grad untouched without an error
+        task = torch._C._current_graph_task_id()
+        if task != self.cb_task or task < 0:
+            if self.cb_task is not None and not self.flushed:
+                self.gscr.zero_()          # the pass that queued last never flushed: its partial gradients are not this pass's
+            self.cb_task = task
             torch.autograd.Variable._execution_engine.queue_callback(self.flush)
 
     def flush(self):
         """end of a backward pass: the scratch's weight / bias gradients += the parameters' .grad (one launch)"""
-        self.cb_queued = False
+        self.cb_task = None
         if self.flushed:
             return
         self._grad_table(self.model)

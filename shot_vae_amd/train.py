@@ -65,7 +65,7 @@ def apply_update(model, optimizer, distributed=False):
     else:
         scale = dp.all_reduce_gradients(grad) if distributed else 1.0
     if hasattr(optimizer, "_steps"):
-        optimizer.step(scale)
+        optimizer.step(grad_scale=scale)
     else:
         if scale != 1.0:
             grad.mul_(scale)

@@ -443,6 +443,38 @@ def run_monitor_valid_case(tag, name, K):
     print(tag, {k: (float(v) if v.ndim == 0 else v.shape) for k, v in rec.items()})
 
 
+def run_ssl_sampler_case(tag):
+    """lib/dataloader.py:142-190 -- get_cifar10_ssl_sampler / get_cifar100_ssl_sampler, the semi-supervised index split of
+    main_shot_vae.py:156-167 -- imported from the reference and driven with SCRIPTED torch.randperm draws.  The module's top-level
+    `from torchvision import transforms, datasets` (torchvision is not installed here; the two functions use torch alone) is
+    satisfied by an empty stub module IN THIS GENERATOR ONLY.  Records labels, the per-class permutations and the three index lists
+    (SubsetRandomSampler.indices) of each sampler."""
+    import types
+    if "torchvision" not in sys.modules:
+        tv = types.ModuleType("torchvision")
+        tv.transforms, tv.datasets = types.ModuleType("torchvision.transforms"), types.ModuleType("torchvision.datasets")
+        sys.modules.update({"torchvision": tv, "torchvision.transforms": tv.transforms, "torchvision.datasets": tv.datasets})
+    sys.path.insert(0, REF)
+    from lib.dataloader import get_cifar10_ssl_sampler, get_cifar100_ssl_sampler
+    rec = {}
+    g = torch.Generator().manual_seed(20260)
+    for name, fn, K, N, nv, na in (("c10", get_cifar10_ssl_sampler, 10, 230, 5, 4), ("c100", get_cifar100_ssl_sampler, 100, 900, 2, 3),
+                                   ("c10_ragged", get_cifar10_ssl_sampler, 10, 97, 3, 20)):      # annotated > what a class has left
+        labels = torch.randint(0, K, (N,), generator=g)
+        counts = [int((labels == c).sum()) for c in range(K)]
+        perms = [torch.randperm(n, generator=g) for n in counts]
+        with scripted_rng(randperm=perms):
+            sv, sl, su = fn(labels, nv, na, K)
+        rec[name + ".labels"] = labels.numpy()
+        rec[name + ".perm_cat"] = torch.cat(perms).numpy()
+        rec[name + ".args"] = np.array([nv, na, K])
+        rec[name + ".valid"] = np.array(list(sv.indices), dtype=np.int64)
+        rec[name + ".train_l"] = np.array(list(sl.indices), dtype=np.int64)
+        rec[name + ".train_u"] = np.array(list(su.indices), dtype=np.int64)
+    np.savez_compressed(os.path.join(HERE, tag + ".npz"), **rec)
+    print(tag, {k: v.shape for k, v in rec.items()})
+
+
 if __name__ == "__main__":
     assert os.path.isdir(REF), "reference not mounted; goldens are generated in the build container"
     torch.set_num_threads(8)
@@ -456,6 +488,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "round4":      # only the round-4 fixtures: larger, ragged batches and --om with B_l = B_u
         run_step_case("ref_step_wrn28_2_b16_24", "wideresnet-28-2", 10, 16, 24, True)
         run_step_case("ref_step_wrn28_2_om_b16", "wideresnet-28-2", 10, 16, 16, True, om=True)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "ssl":         # only the round-6 fixture: the semi-supervised samplers
+        run_ssl_sampler_case("ref_ssl_samplers")
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "smooth":      # only the smooth-ELBO fixtures
         run_smooth_case("ref_smooth_svhn", "svhn", 6, 4)
@@ -475,3 +510,4 @@ if __name__ == "__main__":
     run_smooth_case("ref_smooth_mnist", "mnist", 4, 6)
     run_keys_case("ref_state_keys")
     run_monitor_valid_case("ref_monitor_valid_wrn10_1", "wideresnet-10-1", 10)
+    run_ssl_sampler_case("ref_ssl_samplers")

@@ -32,8 +32,8 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layout_matches_header():
     assert ctypes.sizeof(L.SvPhase) == 72
     assert ctypes.sizeof(L.SvGeom) == 72 + 4 * 72
-    assert ctypes.sizeof(L.SvIgemmArgs) == 31 * 8
-    assert ctypes.sizeof(L.SvWgradArgs) == 14 * 8
+    assert ctypes.sizeof(L.SvIgemmArgs) == 28 * 8
+    assert ctypes.sizeof(L.SvWgradArgs) == 10 * 8
     assert ctypes.sizeof(L.SvBwd3x3Args) == 19 * 8
     assert ctypes.sizeof(L.SvParamJob) == 14 * 8
     assert ctypes.sizeof(L.SvBnBranch) == 48
@@ -206,24 +206,7 @@ assert lib.sv_igemm(C.byref(g), L.SV_BF16, C.byref(a), None) != 0 and b"fold" in
 blocks = C.c_int(-1)
 a.fold_gamma = a.fold_beta = a.fold_mean = a.fold_rstd = 4096
 assert lib.sv_igemm_query_blocks(C.byref(g), L.SV_BF16, C.byref(a), C.byref(blocks)) == 0 and blocks.value > 0    # a query launches nothing
-# ABI 6: the two-tensor load prologue -- incomplete / with an activation: refused; complete: a query dispatches (the persistent
-# narrow kernel takes it itself, every other geometry is planned with the materialised prologue) and launches nothing
 gd = plan.units[1]["conv1"].geom_dgrad(8)
-a = L.SvIgemmArgs()
-a.x = a.w = a.out = a.x2 = a.pro_scale = a.pro_shift = 4096
-a.pro_slope, a.replicas = 1.0, 1
-assert lib.sv_igemm(C.byref(gd), L.SV_BF16, C.byref(a), None) != 0 and b"two-tensor" in lib.sv_last_error()
-a.pro_scale2 = a.pro_out = 4096
-a.pro_slope = 0.01
-assert lib.sv_igemm(C.byref(gd), L.SV_BF16, C.byref(a), None) != 0 and b"two-tensor" in lib.sv_last_error()
-a.pro_slope = 1.0
-a.ex = a.ex_scale = a.ex_shift = a.ex_mean = a.ex_rstd = a.bsums = 4096
-for cv in (plan.units[1]["conv1"], plan.units[0]["conv1"], plan.units[4]["conv1"], plan.units[9]["conv1"]):
-    for groups in (1, 4):
-        a.groups = groups
-        blocks = C.c_int(-1)
-        rc = lib.sv_igemm_query_blocks(C.byref(cv.geom_dgrad(8)), L.SV_BF16, C.byref(a), C.byref(blocks))
-        assert rc != 0 or blocks.value > 0
 # ABI 7: the fused backward's argument checks (nothing is launched on a refusal)
 assert lib.sv_bwd3x3(None, L.SV_BF16, None, None) != 0 and b"null" in lib.sv_last_error()
 fb = L.SvBwd3x3Args()

@@ -86,6 +86,73 @@ def test_two_ranks_on_one_gpu_keep_identical_parameters(tmp_path, schedule):
     assert all(abs(a) < 1e3 for pair in res["losses"] for a in pair)
 
 
+STRAGGLER_WORKER = r'''
+import os, sys, json, time, torch
+sys.path.insert(0, %r)
+import torch.distributed as dist
+import shot_vae_amd as S
+from shot_vae_amd import dp
+from shot_vae_amd import _lib as L
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+torch.cuda.set_device(0)
+dist.init_process_group("gloo", rank=rank, world_size=world)
+torch.manual_seed(1 + 7 * rank)
+K, B = 10, 16
+model = S.VariationalAutoEncoder("wideresnet-10-1", num_input_channels=3, img_size=(32, 32), data_parallel=True,
+                                 continuous_latent_dim=128, disc_latent_dim=K, small_input=True, compute_dtype="bf16",
+                                 rng="device").cuda().train()
+dp.broadcast_parameters(model)
+elbo, cls = S.VAECriterion(discrete_dim=K).cuda(), S.ClsCriterion()
+opt = S.FlatSGD(model, lr=0.05)
+opt.zero_grad()
+torch.manual_seed(100 + rank); torch.cuda.manual_seed(100 + rank)
+il, iu = torch.rand(B, 3, 32, 32, device="cuda"), torch.rand(B, 3, 32, 32, device="cuda")
+ll = torch.randint(0, K, (B,), device="cuda")
+rng = S.DeviceRng("cuda", seed=0)
+eng = model._engine
+real_backward = eng.backward
+stalls = []
+def slow_backward(*a, **k):
+    # the straggler: host AND device stall between this rank's forward and its backward -- the other rank has long issued its
+    # backward, fired its decoder bucket and waits in the collective; this rank's side stream forks by start signal behind the stall
+    time.sleep(0.4)
+    torch.cuda._sleep(int(3e8))
+    stalls.append(time.time())
+    return real_backward(*a, **k)
+for step in range(4):
+    eng.backward = slow_backward if rank == (step %% world) else real_backward      # the ranks take turns
+    t0 = time.time()
+    ls, lu = S.train_step_grouped(model, elbo, cls, opt, il, ll, iu, S.schedule(10), distributed="bucketed", device_rng=rng)
+    torch.cuda.synchronize()
+p = eng.param.detach().cpu()
+gathered = [torch.zeros_like(p) for _ in range(world)]
+dist.all_gather(gathered, p)
+timeouts = torch.tensor([float(L.lib().sv_flag_timeouts())])
+dist.all_reduce(timeouts)
+if rank == 0:
+    print(json.dumps({"max_param_diff": float((gathered[0] - gathered[1]).abs().max()), "finite": bool(torch.isfinite(p).all()),
+                      "param_norm": float(p.norm()), "flag_timeouts": float(timeouts), "stalls": len(stalls),
+                      "flag_fork": bool(eng.flag_fork)}))
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+@pytest.mark.timeout(600)
+def test_two_ranks_with_a_straggler_keep_identical_parameters(tmp_path):
+    """ADVICE r04 / VERDICT r05: the decoder-first bucket and the start-signal fork under a STRAGGLER.  The ranks take turns stalling
+    (host sleep + device spin) between their forward and their backward, four bucketed steps in bf16: the early rank sits in the
+    decoder bucket's collective with its encoder backward still running, the late rank's side stream waits for start signals behind
+    a stalled main queue.  No wait may time out (the fail-closed counter stays 0 on both ranks), the replicas must hold bit-identical
+    parameters."""
+    script = tmp_path / "straggler.py"
+    script.write_text(STRAGGLER_WORKER % ROOT)
+    res = _run_two_ranks(script, port0=29950)
+    assert res["finite"] and res["param_norm"] > 0 and res["stalls"] == 2
+    assert res["flag_timeouts"] == 0.0, res
+    assert res["max_param_diff"] == 0.0, res
+
+
 EQUIV_WORKER = r'''
 import os, sys, json, torch
 sys.path.insert(0, %r)
@@ -154,7 +221,7 @@ if rank == 0:
                 bufs0 = ref._engine.bufs.detach().clone()
             gens[r] = (il_r, ll_r, iu_r, torch.cuda.get_rng_state())
         ref._engine.bufs.copy_(bufs0)
-        ropt.step(1.0 / world)
+        ropt.step(grad_scale=1.0 / world)
         ropt.zero_grad()
     p_ref = ref._engine.param.detach()
     d = (p_dp - p_ref).abs().max() / p_ref.abs().max()

@@ -167,3 +167,31 @@ def test_flag_fork_is_off_under_serialised_dispatch(monkeypatch):
         monkeypatch.setattr(E, "_SERIALISED", None)
         assert E._dispatch_serialised() is want, (var, val)
     monkeypatch.setattr(E, "_SERIALISED", None)
+
+
+def test_flat_sgd_is_a_torch_optimizer_and_takes_the_reference_schedule():
+    """main_shot_vae.py:199,252-254: MultiStepLR over the optimizer after a linear warm-up that writes param_groups[...]['lr'] -- both
+    work on FlatSGD (a torch.optim.Optimizer over model.parameters()); a scheduler's 'initial_lr' survives a checkpoint round trip."""
+    m = _model("wideresnet-10-1", 10, False)
+    opt = S.FlatSGD(m, lr=0.1, momentum=0.9, weight_decay=5e-4)
+    assert isinstance(opt, torch.optim.Optimizer)
+    assert [id(p) for p in opt.param_groups[0]["params"]] == [id(p) for p in m.parameters()]
+    sched = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=[2, 4], gamma=0.1)
+    for g in opt.param_groups:                         # the warm-up of :223-225
+        g["lr"] = 0.02
+    assert opt.param_groups[0]["lr"] == 0.02
+    for g in opt.param_groups:
+        g["lr"] = 0.1
+    lrs = []
+    for _ in range(5):
+        lrs.append(opt.param_groups[0]["lr"])
+        sched.step()
+    assert lrs == pytest.approx([0.1, 0.1, 0.01, 0.01, 0.001])
+    sd = opt.state_dict()
+    opt2 = S.FlatSGD(_model("wideresnet-10-1", 10, False))
+    sd["param_groups"][0]["initial_lr"] = 0.1
+    opt2.load_state_dict(sd)
+    assert opt2.param_groups[0]["lr"] == pytest.approx(0.001) and opt2.param_groups[0]["initial_lr"] == 0.1
+    assert len(opt2.param_groups[0]["params"]) == len(list(m.parameters()))
+    with pytest.raises(NotImplementedError):
+        opt.step(closure=lambda: None)

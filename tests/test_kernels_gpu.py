@@ -227,66 +227,6 @@ def test_register_resident_stride2_forward(B, pro, stats, Gn, budget, Cc, N, H):
     assert rel(out, ref_out) < 6e-3
 
 
-@pytest.mark.parametrize("Cc,N,kind", [(16, 32, "pro"), (16, 16, "bias"), (16, 32, "fold")])
-@pytest.mark.parametrize("B,Gn,budget", [(1, 1, 0), (3, 1, 0), (37, 3, 0), (130, 4, 0), (64, 2, 16)])
-def test_thin_layers_forward(B, Gn, budget, Cc, N, kind):
-    """thconv.hip, forward forms: the first convolution of block 1 (16 -> 32 at 32x32, BatchNorm + LeakyReLU prologue -- finished or
-    folded --, statistics; wideresnet.py:27-30) and the stem (16 (3 padded) -> 16, bias + statistics, no prologue; wideresnet.py:13-14)
-    against torch fp32 on the same bf16 operands -- all four bands of an image (padding rows at the top / bottom, shared rows
-    between bands), groups, a small block budget -- and against the LDS-halo kernels they replace."""
-    torch.manual_seed(B + N)
-    d = dev()
-    H = 32
-    x = bq(torch.randn(Gn * B, Cc, H, H) * 1.2 + 0.2, "bf16")
-    w = bq(torch.randn(N, Cc, 3, 3) / (Cc * 9) ** 0.5, "bf16")
-    bias = torch.randn(N) * 0.2
-    g = G.conv_like(B, H, H, Cc, N, 3, 1, 1)
-    wp = repack(w.permute(0, 2, 3, 1).reshape(N, 9, Cc).contiguous(), g, False, "bf16")
-    xd = nhwc(x).to(d, torch.bfloat16).contiguous()
-    gamma, beta = (torch.rand(Cc, device=d) + 0.5), torch.randn(Cc, device=d) * 0.2
-    count, R, Rf = float(B * H * H), 4, 16
-    xf = xd.float().view(Gn, -1, Cc)
-    fstats = torch.cat([xf.sum(1)[:, None, :] / Rf, (xf * xf).sum(1)[:, None, :] / Rf], dim=2).repeat(1, Rf, 1).to(ACC).contiguous()
-    coef = torch.zeros(4, Gn, Cc, device=d)
-    L.call("sv_bn_finalize", p(fstats), Rf, Cc, count, p(gamma), p(beta), 1e-5, 0.1, None, None, p(coef[0]), p(coef[1]), p(coef[2]), p(coef[3]), Gn, st())
-    bd = bias.to(d)
-
-    def run(enable, folded):
-        out = torch.full((Gn * B, H, H, N), 7.0, dtype=torch.bfloat16, device=d)
-        sums = torch.zeros(Gn, R, 2 * N, device=d, dtype=ACC)
-        c2 = torch.zeros(4, Gn, Cc, device=d)
-        a = L.SvIgemmArgs()
-        a.x, a.w, a.out, a.replicas, a.groups, a.block_budget, a.stats = xd.data_ptr(), wp.data_ptr(), out.data_ptr(), R, Gn, budget, sums.data_ptr()
-        if kind == "bias":
-            a.bias = bd.data_ptr()
-        elif folded:
-            a.pro_scale, a.pro_shift, a.pro_slope = c2[0].data_ptr(), c2[1].data_ptr(), 0.01
-            a.fold_stats, a.fold_replicas, a.fold_count, a.fold_eps = fstats.data_ptr(), Rf, count, 1e-5
-            a.fold_gamma, a.fold_beta, a.fold_mean, a.fold_rstd = gamma.data_ptr(), beta.data_ptr(), c2[2].data_ptr(), c2[3].data_ptr()
-        else:
-            a.pro_scale, a.pro_shift, a.pro_slope = coef[0].data_ptr(), coef[1].data_ptr(), 0.01
-        with L.options(enable=enable):
-            L.call("sv_igemm", C.byref(g), L.SV_BF16, C.byref(a), st())
-        torch.cuda.synchronize()
-        if folded and kind != "bias":
-            assert rel(c2, coef) < 2e-6
-        return out.float().cpu(), sums.sum(1).float().cpu()
-
-    out, sums = run(L.K_THCONV_FWD, kind == "fold")          # (the forward forms are switched on through the ENABLE mask)
-    ref_out, ref_sums = run(0, False)
-    sc, sh = coef[0].cpu(), coef[1].cpu()
-    for gi in range(Gn):
-        xs = x[gi * B:(gi + 1) * B]
-        if kind == "bias":
-            y = F.conv2d(xs, w, bias, 1, 1)
-        else:
-            y = F.conv2d(bq(F.leaky_relu(xs * sc[gi][None, :, None, None] + sh[gi][None, :, None, None], 0.01), "bf16"), w, None, 1, 1)
-        o = nchw(out[gi * B:(gi + 1) * B])
-        assert rel(o, y) < 4e-3, (gi, rel(o, y))
-        assert rel(sums[gi, :N], y.sum((0, 2, 3))) < 3e-3 and rel(sums[gi, N:], (y * y).sum((0, 2, 3))) < 3e-3
-    assert rel(out, ref_out) < 6e-3 and rel(sums, ref_sums) < 1e-3
-
-
 @pytest.mark.parametrize("B", [1, 3, 70, 300])
 def test_thin_layers_dgrad(B):
     """thconv.hip, activation-backward form: the data gradient of the 16 -> 32 convolution of block 1 (32 -> 16 at 32x32) against
@@ -334,66 +274,6 @@ def test_pointwise_shortcut_forward(B, pro, Gn, Cc, N, H, stride):
         assert rel(o, y) < 4e-3, (gi, rel(o, y))
         assert (o - bq(y, "bf16")).abs().max() <= 2.0 ** -6 * y.abs().max()
     assert rel(out, ref_out) < 6e-3
-
-
-@pytest.mark.parametrize("B,pro,stats,res,Gn,budget", [(1, True, True, True, 1, 0), (3, True, True, False, 1, 0), (70, True, True, True, 1, 0),
-                                                      (37, False, False, False, 1, 0), (300, True, True, True, 1, 0), (65, True, True, True, 4, 0),
-                                                      (64, True, False, True, 2, 0), (96, True, True, True, 1, 8)])
-def test_register_resident_body_64_forward(B, pro, stats, res, Gn, budget):
-    """cconv.hip (the stride-1 3x3 convolutions 64 -> 64 at 16x16 of WideResNet block 2, wideresnet.py:29-35,46-49; switched on through
-    SV_OPT_ENABLE_MASK) against torch fp32 on the same bf16 operands: prologue, residual add, statistics, groups, a small block
-    budget -- and against the persistent LDS-weight kernel (conv3x3p) that takes these layers otherwise."""
-    torch.manual_seed(B)
-    d = dev()
-    Cc, N, H = 64, 64, 16
-    x = bq(torch.randn(Gn * B, Cc, H, H), "bf16")
-    w = bq(torch.randn(N, Cc, 3, 3) / (Cc * 9) ** 0.5, "bf16")
-    rs = bq(torch.randn(Gn * B, N, H, H), "bf16")
-    scale, shift = torch.rand(Gn, Cc) + 0.5, torch.randn(Gn, Cc) * 0.3
-    master = w.permute(0, 2, 3, 1).reshape(N, 9, Cc).contiguous()
-    g = G.conv_like(B, H, H, Cc, N, 3, 1, 1)
-    wp = repack(master, g, False, "bf16")
-    xd, rd = nhwc(x).to(d, torch.bfloat16).contiguous(), nhwc(rs).to(d, torch.bfloat16).contiguous()
-    scd, shd = scale.to(d).contiguous(), shift.to(d).contiguous()
-    R = 4
-
-    def run(enable):
-        out = torch.full((Gn * B, H, H, N), 7.0, dtype=torch.bfloat16, device=d)
-        sums = torch.zeros(Gn, R, 2 * N, device=d, dtype=ACC)
-        a = L.SvIgemmArgs()
-        a.x, a.w, a.out, a.replicas, a.groups, a.block_budget = xd.data_ptr(), wp.data_ptr(), out.data_ptr(), R, Gn, budget
-        if pro:
-            a.pro_scale, a.pro_shift, a.pro_slope = scd.data_ptr(), shd.data_ptr(), 0.01
-        if stats:
-            a.stats = sums.data_ptr()
-        if res:
-            a.residual = rd.data_ptr()
-        with L.options(enable=enable):
-            L.call("sv_igemm", C.byref(g), L.SV_BF16, C.byref(a), st())
-        torch.cuda.synchronize()
-        return out.float().cpu(), sums.sum(1).float().cpu()
-
-    out, sums = run(L.K_CCONV)
-    ref_out, ref_sums = run(0)
-    for gi in range(Gn):
-        xs = x[gi * B:(gi + 1) * B]
-        act = bq(F.leaky_relu(xs * scale[gi][None, :, None, None] + shift[gi][None, :, None, None], 0.01), "bf16") if pro else xs
-        y = F.conv2d(act, w, None, 1, 1) + (rs[gi * B:(gi + 1) * B] if res else 0.0)
-        o = nchw(out[gi * B:(gi + 1) * B])
-        assert rel(o, y) < 4e-3, (gi, rel(o, y))
-        assert (o - bq(y, "bf16")).abs().max() <= 2.0 ** -6 * y.abs().max()
-        if stats:
-            assert rel(sums[gi, :N], y.sum((0, 2, 3))) < 3e-3
-            assert rel(sums[gi, N:], (y * y).sum((0, 2, 3))) < 3e-3
-            assert rel(sums[gi], ref_sums[gi]) < 1e-3
-    assert rel(out, ref_out) < 6e-3
-
-
-@pytest.mark.parametrize("B", [1, 3, 70, 300])
-def test_register_resident_body_64_dgrad(B):
-    """... and its data-gradient form (activation-backward epilogue, bsums) against torch fp32."""
-    with L.options(enable=L.K_CCONV_EX):
-        test_conv_dgrad_with_activation_backward("bf16", (B, 64, 64, 16, 3, 1, 1))
 
 
 @pytest.mark.parametrize("B", [1, 3, 70, 300])
@@ -633,44 +513,6 @@ def test_banded_stride2_wgrad(B, Gn, budget, pro, Cin, N, H):
         return (dw.cpu() - 0.5).view(N, 3, 3, Cin).permute(0, 3, 1, 2)
 
     got, ref = run(0), run(L.K_S2WGRAD)
-    assert rel(got, wref) < 2e-3, rel(got, wref)
-    assert rel(got, ref) < 2e-3, rel(got, ref)
-
-
-@pytest.mark.parametrize("B,Gn,budget", [(1, 1, 0), (3, 1, 0), (70, 1, 0), (33, 4, 0), (96, 2, 16)])
-def test_register_resident_stride2_wgrad_64_128(B, Gn, budget):
-    """swgrad.hip (weight gradient of the stride-2 3x3 convolution 64 -> 128 at 16x16, wideresnet.py:29-30: the whole gradient in one
-    block's registers, every image staged once) against torch fp32 on the same bf16 operands -- one image per block, several with an
-    odd count, batched groups with their own prologue coefficients (the gradient of the shared weights sums over them), a small
-    block budget, accumulation into a non-zero gradient -- and against the generic kernel.  (Off by default: its final atomics cost
-    more than the loop saves; SV_OPT_ENABLE_MASK.)"""
-    torch.manual_seed(B)
-    d = dev()
-    Cin, N, H = 64, 128, 16
-    x = bq(torch.randn(Gn * B, Cin, H, H), "bf16")
-    dy = bq(torch.randn(Gn * B, N, H // 2, H // 2), "bf16")
-    scale, shift = torch.rand(Gn, Cin) + 0.5, torch.randn(Gn, Cin) * 0.3
-    wref = torch.zeros(N, Cin, 3, 3)
-    for gi in range(Gn):
-        xs = x[gi * B:(gi + 1) * B]
-        a = bq(F.leaky_relu(xs * scale[gi][None, :, None, None] + shift[gi][None, :, None, None], 0.01), "bf16")
-        wref += torch.nn.grad.conv2d_weight(a, (N, Cin, 3, 3), dy[gi * B:(gi + 1) * B], 2, 1)
-    g = G.conv_like(B, H, H, Cin, N, 3, 2, 1)
-    xd, dyd = nhwc(x).to(d, torch.bfloat16).contiguous(), nhwc(dy).to(d, torch.bfloat16).contiguous()
-    sc, sh = scale.to(d).contiguous(), shift.to(d).contiguous()
-    ws = torch.full((8 * 1024 * 1024,), float("nan"), device=d)
-
-    def run(enable):
-        dw = torch.full((N, 9, Cin), 0.5, device=d)
-        a = L.SvWgradArgs()
-        a.x, a.pro_scale, a.pro_shift, a.pro_slope, a.dy, a.dw = xd.data_ptr(), sc.data_ptr(), sh.data_ptr(), 0.01, dyd.data_ptr(), dw.data_ptr()
-        a.splits, a.use_tr, a.ws, a.ws_elems, a.groups, a.block_budget = 0, 1, ws.data_ptr(), ws.numel(), Gn, budget
-        with L.options(enable=enable):
-            L.call("sv_wgrad_ex", C.byref(g), L.SV_BF16, C.byref(a), st())
-        torch.cuda.synchronize()
-        return (dw.cpu() - 0.5).view(N, 3, 3, Cin).permute(0, 3, 1, 2)
-
-    got, ref = run(L.K_SWGRAD), run(0)
     assert rel(got, wref) < 2e-3, rel(got, wref)
     assert rel(got, ref) < 2e-3, rel(got, ref)
 
@@ -1702,218 +1544,6 @@ def test_flag_fork_fails_closed_on_a_timeout():
     # (the signal arrives late: the stream's sequence stays consistent for the tests that follow)
     a = torch.zeros(1, device=d)
     assert L.lib().sv_flag_timeouts() == 0 and float(a) == 0.0
-
-
-# B (per group), cin, c, H (of conv1's input), stride, groups -- conv1 of a residual unit: cin -> c, its data gradient c -> cin
-FUSED_BN_BWD_CASES = [(16, 32, 32, 32, 1, 2),       # persistent narrow 3x3 kernel: the prologue in its load path (two stages of x2)
-                      (8, 64, 64, 16, 1, 4),        # ... 64 channels (one stage of x2, epilogue constants in LDS), four groups
-                      (24, 32, 32, 32, 1, 1),       # ... more tiles than blocks * 2: the steady state of the register pipeline
-                      (6, 64, 64, 8, 1, 1),         # ... 8 x 8 maps: two images per tile (spacer rows in the LDS halo)
-                      (4, 128, 128, 8, 1, 2),       # conv3x3w: materialised by sv_igemm (one streaming launch, then the convolution)
-                      (4, 16, 32, 32, 1, 2),        # thin persistent kernel (16 -> 32): materialised
-                      (4, 32, 64, 32, 2, 2),        # stride-2 data gradient (four sub-pixel phases): materialised
-                      (2, 160, 160, 16, 1, 2)]      # the 160-channel kernel of WRN-28-10: materialised
-
-
-@pytest.mark.parametrize("B,cin,c,H,stride,Gn", FUSED_BN_BWD_CASES)
-def test_fused_bn_backward_prologue_against_torch_autograd(B, cin, c, H, stride, Gn):
-    """sv_igemm_args::x2 (ABI 6): the BatchNorm backward of norm2 formed in the load path of conv1's data gradient -- against
-    TORCH's own fp32 autograd of  BatchNorm2d(train) -> [conv1's input gradient]  (wideresnet.py:27-35 backward), not against
-    sv_bn_bwd_apply.  Given g2 = dL/d(norm2's output) and c1 = norm2's raw input:  sv_bn_bwd_affine turns the two sums of g2
-    into per-channel coefficients (and adds dgamma / dbeta), ONE sv_igemm launch then reads g2 and c1, forms dc1 = dL/dc1 on
-    the way in (also written once: the weight gradient's operand), runs the transposed convolution and the activation-backward
-    epilogue of norm1 (its output g1 and its two sums).  Geometries other kernels serve are materialised by sv_igemm itself:
-    same interface, same results."""
-    d = dev()
-    torch.manual_seed(1000 + B + c)
-    bf = torch.bfloat16
-    Ho = H // stride
-    g2 = torch.randn(Gn * B, Ho, Ho, c, device=d).to(bf)
-    c1 = (torch.randn(Gn * B, Ho, Ho, c, device=d) * 1.7 + 0.4).to(bf)
-    tin = torch.randn(Gn * B, H, H, cin, device=d).to(bf)
-    gamma2 = (torch.rand(c, device=d) + 0.5)
-    w = bq(torch.randn(c, 9, cin) / (9 * cin) ** 0.5, "bf16")          # conv1's master weights [N][tap][Cin]
-    sc1, sh1 = (torch.rand(Gn, cin, device=d) + 0.5).contiguous(), (torch.randn(Gn, cin, device=d) * 0.3).contiguous()
-    mean1, rstd1 = (torch.randn(Gn, cin, device=d) * 0.1).contiguous(), (torch.rand(Gn, cin, device=d) + 0.5).contiguous()
-    slope, eps = 0.01, 1e-5
-    count = float(B * Ho * Ho)
-    # ---- torch fp32 autograd, group by group (every group has its own batch statistics) -------------------------------------
-    wt = w.reshape(c, 3, 3, cin).permute(0, 3, 1, 2).contiguous().to(d)
-    dc1_ref, g1_ref, dgam_ref, dbet_ref = [], [], torch.zeros(c, device=d), torch.zeros(c, device=d)
-    mean2, rstd2 = torch.empty(Gn, c, device=d), torch.empty(Gn, c, device=d)
-    for gi in range(Gn):
-        sl = slice(gi * B, (gi + 1) * B)
-        xg = nchw(c1[sl].float()).requires_grad_(True)
-        gam, bet = gamma2.clone().requires_grad_(True), torch.zeros(c, device=d, requires_grad=True)
-        y = F.batch_norm(xg, None, None, gam, bet, True, 0.1, eps)
-        y.backward(nchw(g2[sl].float()))
-        dc1_ref.append(nhwc(xg.grad))
-        dgam_ref += gam.grad
-        dbet_ref += bet.grad
-        mean2[gi] = xg.detach().mean((0, 2, 3))
-        rstd2[gi] = (xg.detach().var((0, 2, 3), unbiased=False) + eps).rsqrt()
-        # conv1's input gradient of dc1 (rounded to the storage type, as the kernel's MFMA operand is), then norm1's activation backward
-        z = torch.zeros(B, cin, H, H, device=d, requires_grad=True)
-        F.conv2d(z, wt, None, stride, 1).backward(nchw(bq(nhwc(xg.grad), "bf16")))
-        u = tin[sl].float() * sc1[gi] + sh1[gi]
-        g1_ref.append(nhwc(z.grad) * torch.where(u > 0, torch.ones_like(u), torch.full_like(u, slope)))
-    dc1_ref, g1_ref = torch.cat(dc1_ref), torch.cat(g1_ref)
-    # ---- the HIP path --------------------------------------------------------------------------------------------------------
-    gi_ = torch.arange(Gn * B, device=d) // B
-    xh2 = (c1.float() - mean2[gi_][:, None, None, :]) * rstd2[gi_][:, None, None, :]
-    R = 4                                                     # the sums of g2 as the data gradient behind norm2 leaves them: R replicas
-    gf = g2.float().view(Gn, B * Ho * Ho, c)
-    bs2 = torch.zeros(Gn, R, 2 * c, device=d, dtype=ACC)
-    for r in range(R):
-        rows = slice(r * (B * Ho * Ho) // R, (r + 1) * (B * Ho * Ho) // R)
-        bs2[:, r, :c] = gf[:, rows].sum(1)
-        bs2[:, r, c:] = (gf * xh2.view(Gn, -1, c))[:, rows].sum(1)
-    coef = torch.empty(3, Gn, c, device=d)
-    dgam, dbet = torch.zeros(c, device=d), torch.zeros(c, device=d)
-    L.call("sv_bn_bwd_affine", p(bs2), R, c, count, p(gamma2), p(mean2), p(rstd2), p(dgam), p(dbet), p(coef[0]), p(coef[1]), p(coef[2]),
-           Gn, st())
-    gd = G.convT_like(B, Ho, Ho, c, cin, 3, stride, 1)
-    wd = repack(w, gd, True, "bf16")
-    g1 = torch.full((Gn * B, H, H, cin), 7.0, device=d, dtype=bf)
-    dc1 = torch.full_like(c1, 7.0)
-    bs1 = torch.zeros(Gn, R, 2 * cin, device=d, dtype=ACC)
-    a = L.SvIgemmArgs()
-    a.x, a.w, a.out, a.groups = g2.data_ptr(), wd.data_ptr(), g1.data_ptr(), Gn
-    a.pro_scale, a.pro_scale2, a.pro_shift, a.pro_slope = coef[0].data_ptr(), coef[1].data_ptr(), coef[2].data_ptr(), 1.0
-    a.x2, a.pro_out = c1.data_ptr(), dc1.data_ptr()
-    a.ex, a.ex_scale, a.ex_shift, a.ex_mean, a.ex_rstd = (t.data_ptr() for t in (tin, sc1, sh1, mean1, rstd1))
-    a.ex_slope, a.bsums, a.replicas = slope, bs1.data_ptr(), R
-    L.call("sv_igemm", C.byref(gd), L.SV_BF16, C.byref(a), st())
-    torch.cuda.synchronize()
-    # the coefficients' side effect: dgamma / dbeta of norm2 exactly as autograd has them (fp32 sums)
-    assert rel(dgam, dgam_ref) < 1e-4 and rel(dbet, dbet_ref) < 1e-4
-    # dc1: ONE bf16 rounding of torch's BatchNorm backward; every element written exactly once
-    assert bool(torch.isfinite(dc1.float()).all())
-    assert rel(dc1.float(), dc1_ref) < 6e-3, rel(dc1.float(), dc1_ref)
-    # g1: the convolution of the SAME rounded dc1 + norm1's activation backward
-    assert rel(g1.float(), g1_ref) < DT["bf16"][2], rel(g1.float(), g1_ref)
-    # ... and its two sums (norm1's backward): against the fp32 reference tensor
-    xh1 = (tin.float() - mean1[gi_][:, None, None, :]) * rstd1[gi_][:, None, None, :]
-    s1 = g1_ref.view(Gn, -1, cin).sum(1)
-    s2 = (g1_ref * xh1).view(Gn, -1, cin).sum(1)
-    got = bs1.sum(1)
-    tol = 2e-2 * float(g1_ref.abs().mean()) * (B * H * H) ** 0.5 * 4          # a sum of rounding errors, not of the values
-    assert float((got[:, :cin] - s1).abs().max()) < tol and float((got[:, cin:] - s2).abs().max()) < 3 * tol
-    # the plain form of the same launch (dc1 handed over as x, no prologue) gives the same g1 bit for bit where the kernel is the
-    # same one, to rounding where sv_igemm materialised
-    g1b = torch.empty_like(g1)
-    bs1b = torch.zeros_like(bs1)
-    b_ = L.SvIgemmArgs()
-    b_.x, b_.w, b_.out, b_.groups = dc1.data_ptr(), wd.data_ptr(), g1b.data_ptr(), Gn
-    b_.ex, b_.ex_scale, b_.ex_shift, b_.ex_mean, b_.ex_rstd = (t.data_ptr() for t in (tin, sc1, sh1, mean1, rstd1))
-    b_.ex_slope, b_.bsums, b_.replicas = slope, bs1b.data_ptr(), R
-    L.call("sv_igemm", C.byref(gd), L.SV_BF16, C.byref(b_), st())
-    torch.cuda.synchronize()
-    assert torch.equal(g1b, g1), float((g1b.float() - g1.float()).abs().max())
-
-
-@pytest.mark.parametrize("B,c,H,Gn,budget", [(16, 32, 32, 2, 0), (8, 64, 16, 4, 256), (12, 128, 8, 1, 0), (40, 32, 32, 1, 64)])
-def test_weight_gradient_with_two_tensor_dy_against_torch_autograd(B, c, H, Gn, budget):
-    """sv_wgrad_args::dy2 (ABI 6): conv1's weight gradient with its dy operand formed from g2 and c1 in the kernel's load path --
-    against torch's fp32 autograd of  conv1 -> BatchNorm2d(train)  (the weight gradient of wideresnet.py:29-32 for the gradient g2
-    behind the BatchNorm), summed over the groups; and BIT FOR BIT against the plain kernel on the tensor that the data gradient's
-    side output (sv_igemm_args::pro_out) holds: both form the same bf16 values."""
-    d = dev()
-    torch.manual_seed(77 + B + c)
-    bf = torch.bfloat16
-    g2 = torch.randn(Gn * B, H, H, c, device=d).to(bf)
-    c1 = (torch.randn(Gn * B, H, H, c, device=d) * 1.3 - 0.2).to(bf)
-    tin = torch.randn(Gn * B, H, H, c, device=d).to(bf)
-    gamma2 = torch.rand(c, device=d) + 0.5
-    sc1, sh1 = (torch.rand(Gn, c, device=d) + 0.5).contiguous(), (torch.randn(Gn, c, device=d) * 0.3).contiguous()
-    slope, eps = 0.01, 1e-5
-    count = float(B * H * H)
-    dw_ref = torch.zeros(c, c, 3, 3, device=d)
-    mean2, rstd2 = torch.empty(Gn, c, device=d), torch.empty(Gn, c, device=d)
-    dc1_ref = []
-    for gi in range(Gn):
-        sl = slice(gi * B, (gi + 1) * B)
-        xg = nchw(c1[sl].float()).requires_grad_(True)
-        y = F.batch_norm(xg, None, None, gamma2, torch.zeros(c, device=d), True, 0.1, eps)
-        y.backward(nchw(g2[sl].float()))
-        dc1_ref.append(nhwc(xg.grad))
-        mean2[gi] = xg.detach().mean((0, 2, 3))
-        rstd2[gi] = (xg.detach().var((0, 2, 3), unbiased=False) + eps).rsqrt()
-        u = tin[sl].float() * sc1[gi] + sh1[gi]
-        act = bq(torch.where(u > 0, u, u * slope), "bf16")                      # conv1's input as the kernel's MFMA operand
-        dw_ref += torch.nn.grad.conv2d_weight(nchw(act), (c, c, 3, 3), nchw(bq(nhwc(xg.grad), "bf16")), 1, 1)
-    # coefficients from the sums of g2 (as the data gradient behind norm2 leaves them)
-    gi_ = torch.arange(Gn * B, device=d) // B
-    xh2 = (c1.float() - mean2[gi_][:, None, None, :]) * rstd2[gi_][:, None, None, :]
-    bs2 = torch.zeros(Gn, 1, 2 * c, device=d, dtype=ACC)
-    bs2[:, 0, :c] = g2.float().view(Gn, -1, c).sum(1)
-    bs2[:, 0, c:] = (g2.float() * xh2).view(Gn, -1, c).sum(1)
-    coef = torch.empty(3, Gn, c, device=d)
-    L.call("sv_bn_bwd_affine", p(bs2), 1, c, count, p(gamma2), p(mean2), p(rstd2), None, None, p(coef[0]), p(coef[1]), p(coef[2]), Gn, st())
-    g = G.conv_like(B, H, H, c, c, 3, 1, 1)
-    ws = torch.empty(16 * 1024 * 1024, device=d)
-
-    def wgrad(dy, lin2):
-        dw = torch.zeros(c, 9, c, device=d)
-        a = L.SvWgradArgs()
-        a.x, a.pro_scale, a.pro_shift, a.pro_slope = tin.data_ptr(), sc1.data_ptr(), sh1.data_ptr(), slope
-        a.dy, a.dw, a.use_tr, a.ws, a.ws_elems, a.groups, a.block_budget = dy.data_ptr(), dw.data_ptr(), 1, ws.data_ptr(), ws.numel(), Gn, budget
-        if lin2:
-            a.dy2, a.dy_scale, a.dy_scale2, a.dy_shift = c1.data_ptr(), coef[0].data_ptr(), coef[1].data_ptr(), coef[2].data_ptr()
-        L.call("sv_wgrad_ex", C.byref(g), L.SV_BF16, C.byref(a), st())
-        torch.cuda.synchronize()
-        return dw
-
-    dw = wgrad(g2, True)
-    got = dw.view(c, 3, 3, c).permute(0, 3, 1, 2)
-    assert rel(got, dw_ref) < 2e-3, rel(got, dw_ref)                 # same bf16 operands, fp32 accumulation: only the sum order differs
-    # the transformed tensor as the DATA gradient's side output holds it (sv_igemm_args::pro_out: the same expression, the same
-    # rounding -- where sv_igemm forms it natively and where it materialises it) through the plain weight gradient: bit for bit
-    # with 32-channel n tiles (64 / 128 channels: the plain dispatch takes 64-channel n tiles, another sum order)
-    gd = G.convT_like(B, H, H, c, c, 3, 1, 1)
-    wd = repack(bq(torch.randn(c, 9, c) / (9 * c) ** 0.5, "bf16"), gd, True, "bf16")
-    dc1, g1_, bs1 = torch.full_like(c1, 7.0), torch.empty_like(tin), torch.zeros(Gn, 4, 2 * c, device=d, dtype=ACC)
-    mean1, rstd1 = torch.zeros(Gn, c, device=d), torch.ones(Gn, c, device=d)
-    ia = L.SvIgemmArgs()
-    ia.x, ia.w, ia.out, ia.groups = g2.data_ptr(), wd.data_ptr(), g1_.data_ptr(), Gn
-    ia.pro_scale, ia.pro_scale2, ia.pro_shift, ia.pro_slope = coef[0].data_ptr(), coef[1].data_ptr(), coef[2].data_ptr(), 1.0
-    ia.x2, ia.pro_out = c1.data_ptr(), dc1.data_ptr()
-    ia.ex, ia.ex_scale, ia.ex_shift, ia.ex_mean, ia.ex_rstd = (t.data_ptr() for t in (tin, sc1, sh1, mean1, rstd1))
-    ia.ex_slope, ia.bsums, ia.replicas = slope, bs1.data_ptr(), 4
-    L.call("sv_igemm", C.byref(gd), L.SV_BF16, C.byref(ia), st())
-    torch.cuda.synchronize()
-    assert rel(dc1.float(), torch.cat(dc1_ref)) < 6e-3
-    dw_plain = wgrad(dc1, False)
-    if c == 32:
-        assert torch.equal(dw_plain, dw), float((dw_plain - dw).abs().max())
-    else:
-        assert rel(dw, dw_plain) < 1e-4
-    # a geometry the kernel does not cover refuses the operand
-    g16 = G.conv_like(2, 8, 8, 16, 32, 3, 1, 1)
-    a = L.SvWgradArgs()
-    t16 = torch.zeros(2, 8, 8, 32, device=d, dtype=bf)
-    a.x, a.dy, a.dw, a.use_tr, a.dy2 = t16.data_ptr(), t16.data_ptr(), ws.data_ptr(), 1, t16.data_ptr()
-    a.dy_scale = a.dy_scale2 = a.dy_shift = coef.data_ptr()
-    with pytest.raises(L.ShotVaeHipError, match="dy2"):
-        L.call("sv_wgrad_ex", C.byref(g16), L.SV_BF16, C.byref(a), st())
-
-
-def test_two_tensor_prologue_argument_checks():
-    """an incomplete two-tensor prologue is refused before any launch"""
-    d = dev()
-    bf = torch.bfloat16
-    gd = G.convT_like(2, 8, 8, 32, 32, 3, 1, 1)
-    t = torch.zeros(2, 8, 8, 32, device=d, dtype=bf)
-    wd = repack(bq(torch.randn(32, 9, 32) * 0.05, "bf16"), gd, True, "bf16")
-    v = torch.ones(32, device=d)
-    a = L.SvIgemmArgs()
-    a.x, a.w, a.out, a.x2 = t.data_ptr(), wd.data_ptr(), t.data_ptr(), t.data_ptr()
-    a.pro_scale, a.pro_shift, a.pro_slope = v.data_ptr(), v.data_ptr(), 1.0
-    with pytest.raises(L.ShotVaeHipError, match="two-tensor prologue"):
-        L.call("sv_igemm", C.byref(gd), L.SV_BF16, C.byref(a), st())              # no pro_scale2 / pro_out
-    a.pro_scale2, a.pro_out, a.pro_slope = v.data_ptr(), t.data_ptr(), 0.01
-    with pytest.raises(L.ShotVaeHipError, match="two-tensor prologue"):
-        L.call("sv_igemm", C.byref(gd), L.SV_BF16, C.byref(a), st())              # an activation on top of it
 
 
 @pytest.mark.parametrize("dt", ["f32", "bf16"])

@@ -226,6 +226,53 @@ def test_smooth_elbo_bf16_tracks_fp32_and_trains():
     assert abs(losses["bf16"][0] - losses["fp32"][0]) < 2e-2 * abs(losses["fp32"][0]), losses
 
 
+def test_smooth_backward_that_raises_does_not_mute_the_next_one():
+    """the weight plan hands every gradient to .grad through ONE callback at the end of the backward pass.  Autograd drops
+    its queued callbacks when a node raises; the plan must queue again for the next pass (keyed by the engine's graph task, not by a
+    sticky flag) -- otherwise training would continue on stale gradients without an error.  A backward that dies midway, then (a) a
+    second backward over the SAME graph and (b) a fresh iteration must both leave the gradients an undisturbed model computes."""
+    from oracle import smooth_oracle as SO
+    unl, lab, label, nz = SO.make_inputs("svhn", 16, 8)
+    unl = unl.cuda()
+
+    def grads(break_first, same_graph):
+        model = S.SmoothVAE((3, 32, 32), {"cont": 32, "disc": [10]}, compute_dtype="fp32").cuda().train()
+        model.load_state_dict(SO.make_state("svhn"))
+        lf = S.SmoothELBOLoss()
+        lf.num_steps = 1
+        def fwd():
+            with T.scripted_rng(randn=[nz["eps_u"]], rand=[nz["u_u"]]):
+                rec, dist, _, _ = model(unl)
+            return dist, lf(unl, rec, dist)[0]
+        dist, loss = fwd()
+        if break_first:
+            class Boom(RuntimeError):
+                pass
+
+            def hook(g):
+                raise Boom("a node of the backward pass fails")
+            # the posterior mean lies between decoder and encoder: when its hook fires, the decoder's layers have run their backward
+            # (queued the plan's callback, filled its gradient scratch) and the encoder's have not
+            h = dist["cont"][0].register_hook(hook)
+            with pytest.raises(Boom):
+                loss.backward(retain_graph=True)
+            h.remove()
+            for q in model.parameters():
+                q.grad = None
+            if not same_graph:
+                dist, loss = fwd()
+        loss.backward()
+        torch.cuda.synchronize()
+        return [q.grad.clone() for q in model.parameters()]
+
+    ref = grads(False, False)
+    for same_graph in (True, False):
+        got = grads(True, same_graph)
+        assert all(g is not None and float(g.abs().sum()) > 0 or float(r.abs().sum()) == 0 for g, r in zip(got, ref))
+        for g, r in zip(got, ref):
+            assert float((g - r).abs().max()) <= 1e-5 * float(r.abs().max()) + 1e-7, same_graph
+
+
 def test_smooth_elbo_graphed_iteration_equals_eager():
     """GraphedSmoothStep (hipGraph replay of the smooth-ELBO iteration, capturable Adam, device step counter) against
     the eager smooth_train_step with the device noise frozen."""

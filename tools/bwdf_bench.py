@@ -37,7 +37,7 @@ def main():
     tensor_bytes = Gn * B * H * H * CH * 2
     for lin2 in (False, True):
         t = _inputs(B, H, Gn, lin2, 7)
-        g_ref, bs_ref, dw_ref, po, wd, gd = _pair(t, B, H, Gn, 0, 0.01, 4)
+        g_ref, bs_ref, dw_ref, _, wd, gd = _pair(t, B, H, Gn, 0, 0.01, 4)
         ws = torch.empty(4 * 1024 * 1024, device=d)
         g, bs, dw = _fused(t, wd, gd, Gn, budget, 0.01, 4, ws=ws)
         ok = torch.equal(g, g_ref)

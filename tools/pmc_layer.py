@@ -1,6 +1,6 @@
 """PMC traffic of ONE conv-like layer (run on the GPU box):  SV_BENCH_K=1 SV_BENCH_S=2 python tools/pmc_layer.py B Cin H N kind
-Same two counter passes and the same formula as tools/pmc_traffic.py; the kernel is matched by `igemm_kernel` and the other
-conv-like kernel names."""
+Same two counter passes and the same formula as tools/pmc_traffic.py; the launch's kernels are matched against pmc_traffic.ALL_KERNELS
+(every conv-like kernel of the library) unless kernel-name substrings follow `kind`."""
 import os
 import sys
 
@@ -9,7 +9,7 @@ import pmc_traffic as P      # noqa: E402
 
 B, Cin, H, N = map(int, sys.argv[1:5])
 kind = sys.argv[5]
-names = sys.argv[6:] or ["igemm_kernel", "halo", "wgrad_kernel", "slab_reduce_kernel", "hwgrad_kernel"]
+names = sys.argv[6:] or P.ALL_KERNELS
 TAG = "probe_%d_%d_%d_%d_%s_k%s_s%s" % (B, Cin, H, N, kind, os.environ.get("SV_BENCH_K", "3"), os.environ.get("SV_BENCH_S", "1"))
 P.LAYERS[TAG] = (B, Cin, H, N, kind, names)
 outdir = os.path.join(P.ROOT, "gpurun_out", "pmc")

@@ -13,8 +13,21 @@ run() {   # name, env..., -- args
   env "${envs[@]}" python3 "$R/tools/pmc_layer.py" "$@" 2>&1 | tail -1
   env "${envs[@]}" python3 "$R/tools/pmc_sq.py" "$@" 2>&1 | grep -v "^  SQ_[A-Z_]* *[0-9]*$"
 }
-run "fwd:dec4 (ConvT 128->64, 8x8 -> 16x16)" SV_BENCH_T=1 -- 2048 128 8 64 fwd
+# (every launch is matched against tools/pmc_traffic.py's ALL_KERNELS: the register-resident kernels of round 5 included)
+run "fwd:dec4 (ConvT 128->64, 8x8 -> 16x16; tconvr)" SV_BENCH_T=1 -- 2048 128 8 64 fwd
 run "wgrad:dec2 (ConvT 512->256, 2x2 -> 4x4)" SV_BENCH_T=1 -- 2048 512 2 256 wgrad
 run "fwd:dec1 (ConvT 1024->512, 1x1 -> 2x2)" SV_BENCH_T=1 -- 2048 1024 1 512 fwd
-run "dgrad:conv3x3_64x128_s2" SV_BENCH_K=3 SV_BENCH_S=2 -- 2048 64 16 128 dgrad
+run "dgrad:conv3x3_64x128_s2 (tconvr, activation-backward form)" SV_BENCH_K=3 SV_BENCH_S=2 -- 2048 64 16 128 dgrad
+run "dgrad:conv3x3_32x64_s2 (tconvr)" SV_BENCH_K=3 SV_BENCH_S=2 -- 2048 32 32 64 dgrad
+run "fwd:conv3x3_32x64_s2 (sconv)" SV_BENCH_K=3 SV_BENCH_S=2 -- 2048 32 32 64 fwd
+run "fwd:conv3x3_64x128_s2 (sconv)" SV_BENCH_K=3 SV_BENCH_S=2 -- 2048 64 16 128 fwd
+run "wgrad:conv3x3_32x64_s2 (s2wgrad)" SV_BENCH_K=3 SV_BENCH_S=2 -- 2048 32 32 64 wgrad
+run "wgrad:conv3x3_64x128_s2 (s2wgrad)" SV_BENCH_K=3 SV_BENCH_S=2 -- 2048 64 16 128 wgrad
+run "fwd:conv1x1_16x32 (pconv)" SV_BENCH_K=1 SV_BENCH_S=1 -- 2048 16 32 32 fwd
+run "fwd:conv1x1_32x64 s2 (pconv)" SV_BENCH_K=1 SV_BENCH_S=2 -- 2048 32 32 64 fwd
+run "fwd:dec5 (ConvT 64->16, 16x16 -> 32x32; tconvx16)" SV_BENCH_T=1 -- 1024 64 16 16 fwd
+run "dgrad:dec5 (dconv)" SV_BENCH_T=1 -- 1024 64 16 16 dgrad
+run "dgrad:conv3x3_16x32_s1 (thconv)" SV_BENCH_NOPRO=1 -- 2048 16 32 32 dgrad
+run "wgrad:stem (thwgrad)" SV_BENCH_NOPRO=1 -- 2048 16 32 16 wgrad
+run "wgrad:conv3x3_16x32_s1 (thwgrad)" SV_BENCH_NOPRO=1 -- 2048 16 32 32 wgrad
 run "fwd:stem" SV_BENCH_NOPRO=1 -- 2048 16 32 16 fwd

@@ -23,7 +23,9 @@ ITERS, WARM = 3, 1
 def main():
     B, Cin, H, N = sys.argv[1:5]
     kind = sys.argv[5]
-    names = sys.argv[6:] or ["igemm_kernel", "wgradc_kernel", "wgrad_kernel", "halo", "conv3x3", "wgrad3x3"]
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import pmc_traffic as P
+    names = sys.argv[6:] or [n for n in P.ALL_KERNELS if n != "slab_reduce_kernel"]
     out = {}
     for i, ctrs in enumerate(PASSES):
         d = os.path.join(ROOT, "gpurun_out", "pmc_sq", "p%d_%d" % (os.getpid(), i))
@@ -36,9 +38,9 @@ def main():
             continue
         files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
         for row in csv.DictReader(open(files[0])):
-            for nm in names:
-                if nm in row["Kernel_Name"]:
-                    out.setdefault(nm, {}).setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+            nm = P.kernel_of(row["Kernel_Name"], names)
+            if nm:
+                out.setdefault(nm, {}).setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
     for nm, cs in out.items():
         v = {k: sum(x[-ITERS:]) / ITERS for k, x in cs.items()}       # mean of the timed launches (last ITERS dispatches)
         print("== %s  (B=%s Cin=%s H=%s N=%s %s k=%s s=%s)" % (nm, B, Cin, H, N, kind, os.environ.get("SV_BENCH_K", "3"),
