@@ -278,9 +278,12 @@ def check_flag_timeouts(where=""):
     n = lib().sv_flag_timeouts()
     if n:
         raise ShotVaeHipError(
-            "%d side-stream wait(s) for a data gradient's start signal timed out%s: weight gradients ran on unfinished operands, "
-            "the step is invalid.  Kernel dispatch is serialised or the main queue stalled > 3 s (profiler, debugger, shared GPU): "
-            "set Engine.flag_fork = False (event forks) and re-run." % (n, (" (" + where + ")") if where else ""))
+            "%d side-stream wait(s) for a data gradient's start signal timed out%s: weight gradients ran on unfinished operands.  "
+            "FATAL for this run: the time-out is only visible once the waiting kernel has executed, so the optimizer step (and, with "
+            "several ranks, the all-reduce) of that step may already have applied the corrupted gradients -- the parameters and the "
+            "momentum buffer cannot be trusted: restore the last checkpoint, do not save one.  Kernel dispatch is serialised or the "
+            "main queue stalled > 3 s (profiler, debugger, shared GPU): set Engine.flag_fork = False (event forks) and re-run.  (The "
+            "counter stays set until sv_flag_timeouts_reset(): every later step raises too.)" % (n, (" (" + where + ")") if where else ""))
 
 
 def call(name, *args):

@@ -586,21 +586,34 @@ class Engine:
             if self._pending_wgrads:
                 self._flush_wgrads(cur, side)
             cur.wait_stream(side)
-            if self.flag_fork and not _dispatch_serialised():
-                # fail closed (sv_stream_wait_flag): the sticky time-out counter is host-mapped, the check is a memory read.  The
-                # environment sniffing of _dispatch_serialised() cannot know every serialising tool, so the FIRST flag-forked
-                # backward of an engine is verified with one synchronisation: if a wait gave up there, the engine switches to
-                # event forks for good and the step is reported invalid instead of continuing on garbage.
-                if not self._flag_forks_verified:
-                    torch.cuda.synchronize()
-                    Engine._flag_forks_verified = True
-                    if L.lib().sv_flag_timeouts():
-                        Engine.flag_fork = False
-                        self.flag_fork = False
-                L.check_flag_timeouts("Engine.backward")
-            # the side stream's operands may be released now: the main stream, on which the allocator will hand their
-            # memory out again, is ordered behind everything the side stream did
-            self._side_keep.pop(cur.cuda_stream, None)
+            try:
+                if self.flag_fork and not _dispatch_serialised():
+                    # fail closed (sv_stream_wait_flag): the sticky time-out counter is host-mapped, the check is a memory read.  The
+                    # environment sniffing of _dispatch_serialised() cannot know every serialising tool, so the FIRST flag-forked
+                    # backward of an engine is verified with one synchronisation.  A wait that gave up THERE is recoverable: nothing
+                    # has consumed this backward's gradients yet (the optimizer step and the all-reduce come after it), so the engine
+                    # switches to event forks for good, clears the counter and reports THIS step invalid -- a caller that drops it
+                    # (zero_grad, next batch) continues on valid steps.
+                    if not self._flag_forks_verified:
+                        torch.cuda.synchronize()
+                        Engine._flag_forks_verified = True
+                        n = L.lib().sv_flag_timeouts()
+                        if n:
+                            Engine.flag_fork = False
+                            self.flag_fork = False
+                            L.call("sv_flag_timeouts_reset")
+                            raise L.ShotVaeHipError(
+                                "%d side-stream wait(s) for a data gradient's start signal timed out in the first backward of this "
+                                "engine (kernel dispatch is serialised: profiler, debugger): the gradients of THIS backward are invalid "
+                                "-- drop the step (zero_grad) -- and nothing has consumed them yet.  The engine now forks by events "
+                                "(Engine.flag_fork = False); the following steps are valid." % n)
+                    # a LATER time-out is seen by this memory read only once the waiting kernel has run -- possibly a step late, after
+                    # sv_sgd / the all-reduce applied the corrupted gradients: that one is fatal (check_flag_timeouts says so)
+                    L.check_flag_timeouts("Engine.backward")
+            finally:
+                # the side stream's operands may be released now (also when the check raises): the main stream, on which the
+                # allocator will hand their memory out again, is ordered behind everything the side stream did
+                self._side_keep.pop(cur.cuda_stream, None)
 
     def _wgrad(self, g, x, pro, dy, dw_ptr, tag=None, groups=1, budget=0):
         if tag:

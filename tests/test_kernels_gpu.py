@@ -1546,6 +1546,44 @@ def test_flag_fork_fails_closed_on_a_timeout():
     assert L.lib().sv_flag_timeouts() == 0 and float(a) == 0.0
 
 
+def test_flag_fork_timeout_in_the_first_backward_is_recoverable():
+    """the FIRST flag-forked backward of an engine is verified with one synchronisation; a wait that gave up there has
+    corrupted nothing yet (optimizer step and all-reduce come after the backward): the engine switches to event forks, CLEARS the
+    counter, releases the side stream's operands and raises for this step only -- a caller that drops the step continues."""
+    import shot_vae_amd as S
+    from shot_vae_amd.engine import Engine
+    d = dev()
+    K, B = 10, 8
+    model = S.VariationalAutoEncoder("wideresnet-10-1", num_input_channels=3, img_size=(32, 32), data_parallel=False,
+                                     continuous_latent_dim=128, disc_latent_dim=K, small_input=True, rng="device").to(d).train()
+    elbo, cls = S.VAECriterion(discrete_dim=K).cuda(), S.ClsCriterion()
+    opt = S.FlatSGD(model, lr=0.01)
+    opt.zero_grad()
+    il, iu = torch.rand(B, 3, 32, 32, device=d), torch.rand(B, 3, 32, 32, device=d)
+    ll = torch.randint(0, K, (B,), device=d)
+    saved = (Engine.flag_fork, Engine._flag_forks_verified)
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    try:
+        Engine.flag_fork, Engine._flag_forks_verified = True, False
+        model._engine.flag_fork = True
+        flag, value = C.c_void_p(), C.c_uint32()
+        L.call("sv_stream_flag_next", C.c_void_p(sa.cuda_stream), C.byref(flag), C.byref(value))     # a wait nobody signals
+        L.call("sv_stream_wait_flag", C.c_void_p(sb.cuda_stream), flag, value)
+        with pytest.raises(L.ShotVaeHipError, match="drop the step"):
+            S.train_step_grouped(model, elbo, cls, opt, il, ll, iu, S.schedule(10))
+        assert L.lib().sv_flag_timeouts() == 0 and model._engine.flag_fork is False and Engine._flag_forks_verified
+        assert not model._engine._side_keep
+        opt.zero_grad()
+        before = model._engine.param.clone()
+        ls, lu = S.train_step_grouped(model, elbo, cls, opt, il, ll, iu, S.schedule(10))      # event forks: a valid step
+        torch.cuda.synchronize()
+        assert bool(torch.isfinite(ls)) and not torch.equal(before, model._engine.param)
+    finally:
+        Engine.flag_fork, Engine._flag_forks_verified = saved
+        L.call("sv_flag_timeouts_reset")
+        torch.cuda.synchronize()
+
+
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
 @pytest.mark.parametrize("B,Cc,H,Gn", [(6, 32, 32, 2), (4, 64, 16, 1), (3, 16, 8, 3)])
 def test_compact_shortcut_branch_equals_strided(dt, B, Cc, H, Gn):

@@ -50,7 +50,82 @@ def test_bf16_loss_curve_overlays_fp32_oracle():
             # per step, amplified).  Floor = 0.10: the ratio gate then sits just inside the absolute one (0.35) for those terms.
             small = k.startswith("kld") or "_post_" in k
             assert v <= 3.0 * max(dev["fp32"][k], 0.10 if small else 0.0) + 2e-2, (run, k, v, dev["fp32"][k])
-    # fp32-operand mode at the first step: the single-step parity gate (1e-3) still holds inside this harness
+    # Gates that do NOT depend on chaotic drift: the FIRST step of every run -- no trajectory yet -- at the single-step
+    # parity gates of SURVEY.md 8d: 1e-3 in fp32-operand mode, 5e-3 in bf16, sequential and grouped schedule.  The posterior terms are
+    # squared DIFFERENCES between the outputs of two forwards (main_shot_vae.py:319-321): at this harness's default initialisation the
+    # labelled continuous one reads 1.19e-2 off the oracle in bf16 (measured, round 6; 2-5e-3 on the closed-form weights of
+    # test_step_matches_oracle_b64) -- gated at 2e-2 here
     first = LC.run_hip(name, K, B, 1, lr, sch, "fp32")[0]
     for k in LC.TERMS:
         assert abs(first[k] - ref[0][k]) <= 1e-3 * max(abs(ref[0][k]), 1e-6), (k, first[k], ref[0][k])
+    for grouped in (False, True):
+        first = LC.run_hip(name, K, B, 1, lr, sch, "bf16", grouped=grouped)[0]
+        for k in LC.TERMS:
+            tk = 2e-2 if "_post_" in k else 5e-3
+            assert abs(first[k] - ref[0][k]) <= tk * max(abs(ref[0][k]), 1e-6), ("bf16 first step", grouped, k, first[k], ref[0][k])
+
+
+@pytest.mark.timeout(900)
+def test_bf16_gradient_at_a_conditioned_point():
+    """a gradient-fidelity check at a CONDITIONED point.  The bf16 gradient gates of the step-level tests are wide
+    (cosine > 0.914, relative L2 < 0.416) because their fixtures sit at the ill-conditioned initial weights.  Here: default
+    initialisation, 60 SGD steps of the fp32 oracle (the loss-curve run: loss_sup 2.34 -> 0.46), then ONE step from that state -- the
+    HIP path (sequential and grouped: the timed path's kernels incl. the fused backward) against the oracle's backward on the same
+    batch and noise.
+      * fp32-operand mode: flat-gradient cosine >= 0.9999, relative L2 <= 1.5e-2 -- the kernels compute the reference's gradient;
+      * bf16: what bf16 OPERANDS cost on this network is measured on the reference arithmetic itself -- torch's CPU bf16 autocast of
+        the oracle against its own fp32 gradient at this very point: cosine 0.9527, relative L2 0.309
+        (tools/probes/autocast_conditioned.py; 0.899 / 0.450 at the initial weights).  The verdict's hoped-for 0.99 / 0.1 is not what
+        bf16 gives here; the HIP path must beat the autocast numbers: cosine >= 0.955, relative L2 <= 0.30 (measured 0.964 / 0.269),
+        per-tensor norm ratios of every conv / linear weight within 10 %."""
+    import loss_curve as LC
+    import shot_vae_amd as S
+    from oracle import closed_form as C
+    from oracle import shotvae_oracle as O
+    from tests import _cases as T
+    name, K, B, steps, lr = "wideresnet-28-2", 10, 64, 60, 0.02
+    sch = O.schedule(10)
+    torch.set_num_threads(min(32, os.cpu_count() or 8))
+    curve, st = LC.run_oracle(name, K, B, steps, lr, sch, return_state=True)
+    assert curve[-1]["loss_sup"] < 0.3 * curve[0]["loss_sup"]
+    il, ll, iu, lu = LC.batches(4, B, K)[steps % 4]
+    nz = C.make_noise(B, B, K, stream0=9000 + 100 * steps)
+    ost = {k: v.clone() for k, v in st.items()}
+    for k in ost:
+        if O.is_param(k):
+            ost[k].requires_grad_(True)
+    orc = O.train_step(ost, name, il, ll, iu, nz, sch)
+    for dtype, grouped in (("fp32", False), ("bf16", False), ("bf16", True)):
+        model = S.VariationalAutoEncoder(name, num_input_channels=3, img_size=(32, 32), data_parallel=True, continuous_latent_dim=128,
+                                         disc_latent_dim=K, small_input=True, compute_dtype=dtype)
+        model.load_state_dict({k: v.detach() for k, v in st.items()})
+        model = model.cuda().train()
+        elbo, cls = S.VAECriterion(discrete_dim=K, bce_reconstruction=True).cuda(), S.ClsCriterion()
+        S.FlatSGD(model).zero_grad()
+        step = S.train_step_grouped if grouped else S.train_step
+        with T.rng_for_step(nz):
+            out = step(model, elbo, cls, None, il.cuda(), ll.cuda(), iu.cuda(), sch, return_outputs=True)
+        torch.cuda.synchronize()
+        for k in T.SCALARS:
+            tk = (2e-2 if "_post_" in k else 5e-3) if dtype == "bf16" else 1e-3
+            assert abs(float(out[k]) - float(orc[k])) <= tk * max(abs(float(orc[k])), 1e-6), (dtype, grouped, k, float(out[k]), float(orc[k]))
+        sdg = {k.replace(".module.", "."): p for k, p in model.named_parameters()}
+        fa, fb, ratios = [], [], {}
+        for k in ost:
+            if not O.is_param(k) or k.endswith("conv0.bias"):      # conv0.bias: analytically zero gradient (a BatchNorm follows)
+                continue
+            a_, b_ = sdg[k].grad.detach().double().cpu().flatten(), ost[k].grad.double().flatten()
+            fa.append(a_)
+            fb.append(b_)
+            ratios[k] = float(a_.norm() / b_.norm().clamp_min(1e-30))
+        fa, fb = torch.cat(fa), torch.cat(fb)
+        cos = float(fa @ fb / fa.norm() / fb.norm())
+        grel = float((fa - fb).norm() / fb.norm())
+        big = {k: r for k, r in ratios.items() if "weight" in k and "norm" not in k and ".bias" not in k}
+        print("\n[conditioned point, %s %s] vs fp32 oracle gradient: flat cosine %.5f, relative L2 %.4f, conv / linear weight norm "
+              "ratios %.3f .. %.3f" % (dtype, "grouped" if grouped else "sequential", cos, grel, min(big.values()), max(big.values())))
+        if dtype == "fp32":
+            assert cos >= 0.9999 and grel <= 1.5e-2, (cos, grel)
+        else:
+            assert cos >= 0.955 and grel <= 0.30, (grouped, cos, grel)
+            assert 0.9 < min(big.values()) and max(big.values()) < 1.1, sorted(big.items(), key=lambda kv: kv[1])[:3]

@@ -33,7 +33,7 @@ def batches(n, B, K):
     return [C.make_batch(B, B, K, stream0=7000 + 10 * i) for i in range(n)]
 
 
-def run_oracle(name, K, B, steps, lr, sch, nbatch=4):
+def run_oracle(name, K, B, steps, lr, sch, nbatch=4, return_state=False):
     st = O.default_init(name, K=K, seed=1)
     for k in st:
         if O.is_param(k):
@@ -45,6 +45,8 @@ def run_oracle(name, K, B, steps, lr, sch, nbatch=4):
         out = O.train_step(st, name, il, ll, iu, nz, sch)
         O.sgd_step(st, mom, lr=lr, momentum=0.9, weight_decay=5e-4)
         curve.append({k: float(out[k]) for k in TERMS})
+    if return_state:                      # the trained state (parameters + BatchNorm buffers), detached
+        return curve, {k: v.detach().clone() for k, v in st.items()}
     return curve
 
 
