@@ -73,8 +73,10 @@ def parse():
     ap.add_argument("--compact-shortcut", type=int, default=1, help="0: the stride-2 shortcuts' data gradients in the strided (sparse_out) form")
     ap.add_argument("--fused-bwd", type=int, default=-1,
                     help="sv_bwd3x3, the one-launch backward of the 32-channel body convolutions: 0 = off (data / weight gradient pair + "
-                         "sv_bn_bwd_apply), 1 = conv1 of the same-shape units with norm2's BatchNorm backward in its load path, 2 = conv2 too, "
-                         "-1 = the engine default")
+                         "sv_bn_bwd_apply), 1 = conv1 of the same-shape units with norm2's BatchNorm backward in its load path, 2 = also conv2 "
+                         "of the unit in front with the unit boundary's BatchNorm backward + skip connection in its load path, 3 = every "
+                         "other 32-channel conv2 too, -1 = the engine default")
+    ap.add_argument("--fused-blocks", type=int, default=0, help="Engine.fused_blocks: blocks of a fused-backward launch (0 = the engine's default, 248)")
     ap.add_argument("--flag-fork", type=int, default=1, help="0: event forks for the paired weight gradients instead of the start signal")
     ap.add_argument("--fork-every", type=int, default=0, help="weight gradients per side-stream fork (0 = the engine's default)")
     ap.add_argument("--light-fork", type=int, default=1,
@@ -579,6 +581,8 @@ def main():
     model._engine.flag_fork = bool(a.flag_fork)
     if a.fused_bwd >= 0:
         model._engine.fused_bwd = a.fused_bwd
+    if a.fused_blocks:
+        model._engine.fused_blocks = a.fused_blocks
     model._engine.compact_shortcut_grad = bool(a.compact_shortcut)
     if a.fork_every:
         model._engine.fork_every = a.fork_every
@@ -749,7 +753,7 @@ def main():
         def family(n):
             if n.startswith("sv_"):
                 return n
-            body = any(n.endswith("conv3x3_%dx%d_s1" % (c, c)) for c in (32, 64, 128, 160, 320, 640))
+            body = any(n.split("+")[0].endswith("conv3x3_%dx%d_s1" % (c, c)) for c in (32, 64, 128, 160, 320, 640))
             return "body_conv3x3_" + n.split(":")[0] if body else "odd_layers_" + n.split(":")[0]
 
         def families(rows):

@@ -191,6 +191,12 @@ typedef struct {
     const float* dy_scale;      /* [G][32] each; required with dy2                                                             */
     const float* dy_scale2;
     const float* dy_shift;
+    const void* dy3;            /* NULL, or (with dy2) a third tensor ADDED to the two-tensor form: dyeff = dy_scale * dy + dy_scale2 *
+                                   dy2 + dy_shift + dy3 -- for conv2 of a residual unit: (dy, dy2) = the data gradient behind the NEXT
+                                   unit's norm1 and that BatchNorm's raw input (this unit's output), dy3 = the gradient arriving at the
+                                   next unit's output: BatchNorm backward + skip connection of wideresnet.py:45-49 in the load path      */
+    void* dy_out;               /* required with dy3: receives dyeff (the gradient at this unit's output: the previous unit's skip
+                                   branch needs the tensor), every element written once                                                  */
     const void* x;              /* [G][B,H,W,32] RAW input of the BatchNorm in front of the convolution                        */
     const float* x_scale;       /* [G][32] each: that BatchNorm's scale / shift / mean / rstd (sv_bn_finalize)                 */
     const float* x_shift;

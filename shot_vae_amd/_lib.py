@@ -50,7 +50,7 @@ class SvWgradArgs(C.Structure):
 
 class SvBwd3x3Args(C.Structure):
     _fields_ = [("dy", C.c_void_p), ("dy2", C.c_void_p), ("dy_scale", C.c_void_p), ("dy_scale2", C.c_void_p), ("dy_shift", C.c_void_p),
-                ("x", C.c_void_p), ("x_scale", C.c_void_p), ("x_shift", C.c_void_p), ("x_mean", C.c_void_p), ("x_rstd", C.c_void_p),
+                ("dy3", C.c_void_p), ("dy_out", C.c_void_p), ("x", C.c_void_p), ("x_scale", C.c_void_p), ("x_shift", C.c_void_p), ("x_mean", C.c_void_p), ("x_rstd", C.c_void_p),
                 ("x_slope", C.c_float), ("w", C.c_void_p), ("out", C.c_void_p), ("bsums", C.c_void_p), ("replicas", C.c_int32),
                 ("groups", C.c_int32), ("dw", C.c_void_p), ("ws", C.c_void_p), ("ws_elems", C.c_int64), ("block_budget", C.c_int32),
                 ("reserved0", C.c_int32)]

@@ -4,13 +4,20 @@
 //   g  [q][c]       = act'(x[q][c] * scale[c] + shift[c]) * sum_{t,n} dy[q + d(t)][n] * Wd[c][t][n]     (+ the two sums of g)
 //   dW [n][to(t)][c] += sum_q dy[q + d(t)][n] * act(x[q][c] * scale[c] + shift[c])
 //
-// replaces the PAIR sv_igemm (ex epilogue) + sv_wgrad_ex of such a layer (wideresnet.py:29-35 under autograd) -- and, in the
-// two-tensor form, the sv_bn_bwd_apply pass in front of the pair as well: dy = dy_scale * dy + dy_scale2 * dy2 + dy_shift is the
-// BatchNorm backward of the layer behind the convolution (coefficients of sv_bn_bwd_affine), formed ONCE in the load path.
+// replaces the PAIR sv_igemm (ex epilogue) + sv_wgrad_ex of such a layer (wideresnet.py:29-35 under autograd) -- and the
+// sv_bn_bwd_apply pass in front of the pair as well, because the gradient dy it works on can be FORMED IN ITS LOAD PATH:
+//   MODE 0   dy                                                  (a tensor that exists)
+//   MODE 1   dy_scale * dy + dy_scale2 * dy2 + dy_shift          = the BatchNorm backward of the layer behind the convolution
+//                                                                  (norm2 between conv1 and conv2 of a unit; sv_bn_bwd_affine)
+//   MODE 2   dy_scale * dy + dy_scale2 * dy2 + dy_shift + dy3    = the same plus the residual branch's gradient: the backward of
+//                                                                  the NEXT unit's norm1 and the skip connection (wideresnet.py:45-49);
+//                                                                  the tile's own rows of it are also written to dy_out, once (the
+//                                                                  previous unit's skip gradient needs the tensor)
 //
-// Why one kernel: the pair reads dy twice and x twice (5 tensor passes, 8 with the BatchNorm-backward pass); both launches of
-// the pair are HBM-bound at 32 channels, so the sum of their bytes is what the step pays.  Here a tile's operands are read
-// once: 3 passes (dy, x in; g out), 4 in the two-tensor form.  Both products run from ONE LDS image of the tile:
+// Why one kernel: the pair reads dy twice and x twice (5 tensor passes; 8 with sv_bn_bwd_apply's 3, 9 with its 4 in the residual
+// form); both launches of the pair are HBM-bound at 32 channels, so the sum of their bytes is what the step pays.  Here a tile's
+// operands are read once: 3 passes (MODE 0), 4 (MODE 1), 6 (MODE 2: three inputs + x, two outputs).  Both products run from ONE
+// LDS image of the tile:
 //   * the dy HALO tile [(TR + 2) x (W + 2) pixels][32 n] (zero padding stored as data) serves the nine taps of the data
 //     gradient (16-byte pixel fragments, weights register-resident: 72 registers) and -- read k-major with the transposing
 //     ds_read_b64_tr_b16 at tap-shifted addresses -- is the A operand of the weight gradient;
@@ -19,11 +26,14 @@
 //   * the RAW input of the same pixels stays in LDS for the epilogue (activation derivative, xhat).
 // Block = 8 waves, one block per CU.  Waves 0-3: the data gradient of 32 pixels each (v_mfma_f32_16x16x32_bf16, the accumulation
 // order of conv3x3p_kernel: outputs bit-equal to it).  Waves 4-7: one 16 x 16 quadrant of dW each for all nine taps over the
-// tile's 128 pixels.  36 MFMAs per wave and tile on either side; a SIMD hosts one wave of each kind, and the two kinds run their
-// staging at opposite ends of the iteration (data-gradient waves: stage, multiply, epilogue; weight-gradient waves: multiply,
-// stage), so one wave's vector work runs under the other's MFMAs.  Pipeline: LDS double-buffered (one barrier per tile), two
-// register stages (a tile's operands are requested two tiles ahead).  Tiles are dealt interleaved (conv3x3p_kernel): the launch
-// sweeps one compact window of the tensors front to back, an XCD owns consecutive tiles (their halo rows meet in its L2).
+// tile's 128 pixels.  36 MFMAs per wave and tile on either side; a SIMD hosts one wave of each kind.  ALL waves load and stage
+// (weight-gradient waves two halo vectors + one centre vector per tensor and tile, data-gradient waves one + one); the two kinds
+// run SEPARATE loops with the same barriers and do their staging at opposite ends of the iteration (data-gradient waves: stage,
+// multiply, epilogue; weight-gradient waves: multiply, stage), so one wave's vector work runs under the other's MFMAs.
+// Pipeline: LDS double-buffered (one LDS-only barrier per tile), two register stages (a tile's operands are requested two tiles
+// ahead; every request is unconditional and the loops run whole pairs of tiles, so the compiler's waits are COUNTED: the other
+// stage stays in flight).  Tiles are dealt interleaved (conv3x3p_kernel): the launch sweeps one compact window of the tensors front
+// to back, an XCD owns consecutive tiles (their halo rows meet in its L2).
 // The weight gradient leaves the block as ONE 36 KB slab per block (plain stores) + sv_slab_reduce.
 #include "common.h"
 #include "epilogue.h"
@@ -36,44 +46,36 @@ constexpr int LDF = 48;     // LDS row of the dy halo and of the activated input
                             // the 16-byte fragment reads (conv3x3.hip) and for the transposing 8-byte reads (wgrad3x3.hip)
 constexpr int LDR = 40;     // LDS row of the raw input (80 bytes: the epilogue's 8-byte reads of 16 pixels hit 16 bank pairs)
 constexpr int CH = 32;
-#ifndef SV_BWDF_FRAG2
-#define SV_BWDF_FRAG2 0
-#endif
-// 16-channel tiles of the data gradient whose weight fragments live in registers (36 each); the others are read from LDS.  2 = all
-// in registers: the kernel then spills ~30 registers, and a scratch re-load behind the tile prefetch waits for it (loads return in order)
-#ifndef SV_BWDF_WREGS
-#define SV_BWDF_WREGS 2
-#endif
-#ifndef SV_BWDF_WREGS_LIN2
-#define SV_BWDF_WREGS_LIN2 2
-#endif
-// timing ablations (tools/probes/bwdf_ablate.sh; results wrong by construction): 1 = no weight-gradient MFMAs, 2 = no data-gradient
-// MFMAs / epilogue, 4 = no global loads in the loop, 8 = no staging (transform + LDS stores), 16 = data gradient without its epilogue
-#ifndef SV_BWDF_ABL
-#define SV_BWDF_ABL 0
-#endif
 // Fragment sets of the weight-gradient waves (compute_g): 1 = all ten fragments of a 32-pixel chunk at once (40 registers), 2 = two
-// groups of 5 + 4 taps (24), 3 = two full sets, double-buffered (80).  Order of the weight-gradient waves' iteration (GFIRST): 1 = they
-// stage the next tile BEFORE their MFMAs.  Measured alone at 4 x 512 images (tools/probes/bwdf_ablate.sh): plain 125 / 115 / 121 us
-// with 2 / 1 / 3 (133 / 130 / 126 staged first); two-tensor 143 / 143 / 143 (143 / 135 / 137 staged first).  The two-tensor form at
-// 16- and 8-pixel maps keeps two groups: ten fragments spill there.
+// groups of 5 + 4 taps (24), 3 = two full sets, double-buffered (80).  Measured alone at 4 x 512 images (tools/probes/bwdf_ablate.sh,
+// round 6, loader = the weight-gradient waves only): plain 125 / 115 / 121 us with 2 / 1 / 3; two-tensor 143 / 143 / 143.
 #ifndef SV_BWDF_FRAGS
 #define SV_BWDF_FRAGS 1
 #endif
-#ifndef SV_BWDF_FRAGS_LIN2
-#define SV_BWDF_FRAGS_LIN2 1
+// 16-channel tiles of the data gradient whose weight fragments live in registers (36 each); the others are read from LDS
+#ifndef SV_BWDF_WREGS
+#define SV_BWDF_WREGS 2
+#endif
+// timing ablations (tools/probes/bwdf_ablate.sh; results wrong by construction): 1 = no weight-gradient MFMAs, 2 = no data-gradient
+// MFMAs / epilogue, 4 = no global loads in the loop, 8 = no staging (transform + LDS stores), 16 = data gradient without its epilogue
+// order of an iteration: 1 = the wave stages the next tile BEFORE its MFMAs.  Data-gradient waves: always (computing first: two-tensor
+// form 167 vs 149 us, residual form 253 vs 158).  Weight-gradient waves (-1 = by form): behind their MFMAs where dy is a tensor (123 vs
+// 126 us), in front of them in the two- and three-tensor forms (138 vs 149, 156 vs 158 us; tools/probes/bwdf_ablate.sh, round 6)
+#ifndef SV_BWDF_DFIRST
+#define SV_BWDF_DFIRST 1
 #endif
 #ifndef SV_BWDF_GFIRST
-#define SV_BWDF_GFIRST 0
+#define SV_BWDF_GFIRST -1
 #endif
-#ifndef SV_BWDF_GFIRST_LIN2
-#define SV_BWDF_GFIRST_LIN2 1
+#ifndef SV_BWDF_ABL
+#define SV_BWDF_ABL 0
 #endif
-constexpr int wregs_of(bool lin2, int wlog) { return wlog != 5 ? (lin2 ? 0 : 1) : lin2 ? SV_BWDF_WREGS_LIN2 : SV_BWDF_WREGS; }      // (16- / 8-pixel maps: half of them, no spills)
 
 struct bwdf_params {
     const void* dy;
     const void* dy2;
+    const void* dy3;
+    void* dy_out;
     const float* dy_scale;
     const float* dy_scale2;
     const float* dy_shift;
@@ -105,21 +107,30 @@ __device__ __forceinline__ bf16x8 ftr(const bf16* S, int pix_elem_q, int col0, i
     return u.b;
 }
 
-template <int WLOG, bool LIN2>
+// one register stage of a thread: NS halo vectors of every dy tensor + one centre vector of x
+template <int NS, int MODE>
+struct bwdf_stage {
+    bf16x8 gv[NS];
+    bf16x8 yv[MODE >= 1 ? NS : 1];
+    bf16x8 rv[MODE == 2 ? NS : 1];
+    bf16x8 xv;
+};
+
+template <int WLOG, int MODE>
 __global__ __launch_bounds__(512) void bwd3x3f_kernel(const sv_geom g, const bwdf_g PG) {
     const bwdf_params& p = PG.g[blockIdx.y];
     typedef bf16x8 V;
     typedef bf16x4 Q;
-    constexpr int WREGS = wregs_of(LIN2, WLOG);
-    // (tuned for the 32 x 32 maps the step runs it on; the other map sizes keep the variant that does not spill)
-    constexpr int FRAGS = WLOG != 5 ? 2 : LIN2 ? SV_BWDF_FRAGS_LIN2 : SV_BWDF_FRAGS;       // fragment sets of the weight-gradient waves
-    constexpr bool GFIRST = WLOG == 5 && (LIN2 ? SV_BWDF_GFIRST_LIN2 : SV_BWDF_GFIRST);
+    constexpr int WREGS = WLOG == 5 ? SV_BWDF_WREGS : (MODE == 0 ? 1 : 0);      // (the variants that do not spill)
+    constexpr int FRAGS = WLOG == 5 ? SV_BWDF_FRAGS : 2;                       // fragment sets of the weight-gradient waves
+    constexpr bool GFIRST = SV_BWDF_GFIRST < 0 ? MODE >= 1 : SV_BWDF_GFIRST != 0;
     constexpr int WLROWS = (2 - WREGS) * 16 * 9;       // LDS rows of weights [c][tap] of the tiles that are not register-resident
     constexpr int W = 1 << WLOG, TR = 128 / W, WP = W + 2;
     // LDS halo rows: row 0 / the last row are the vertical halo; when a tile holds two whole images (W = 8) a zero spacer row
     // separates them -- zero padding is DATA in LDS, the nine taps need no masks (conv3x3p_kernel)
     constexpr int HH = (TR < W) ? TR : W, SEG = TR / HH, LROWS = TR + SEG + 1, HP = LROWS * WP;
-    constexpr int HV = LROWS * W * 4, HI = (HV + 255) / 256; // halo vectors (8 channels each; the two padding columns are zeroed once), slots per LOADER thread (waves 4-7)
+    constexpr int HV = LROWS * W * 4;                  // halo vectors (8 channels each; the two padding columns are zeroed once)
+    static_assert(HV > 512 && HV <= 768, "slots: vectors 0..511 on the weight-gradient waves (two each), 512.. on the others (one each)");
     constexpr int SDY = HP * LDF, SAC = 128 * LDF, SXR = 128 * LDR, STG = SDY + SAC + SXR;      // elements per LDS stage
     static_assert((SDY * 2) % 16 == 0 && (SAC * 2) % 16 == 0 && (STG * 2) % 16 == 0, "16-byte aligned LDS images");
 
@@ -144,14 +155,16 @@ __global__ __launch_bounds__(512) void bwd3x3f_kernel(const sv_geom g, const bwd
     // the geometry, the 36 + 18 tap-shifted addresses of the unrolled loops were hoisted and spilled
     const sv_phase& P = g.phase[0];
     const char* __restrict__ DY = reinterpret_cast<const char*>(p.dy);
-    const char* __restrict__ DY2 = LIN2 ? reinterpret_cast<const char*>(p.dy2) : nullptr;
+    const char* __restrict__ DY2 = MODE >= 1 ? reinterpret_cast<const char*>(p.dy2) : nullptr;
+    const char* __restrict__ DY3 = MODE == 2 ? reinterpret_cast<const char*>(p.dy3) : nullptr;
+    char* __restrict__ DYO = MODE == 2 ? reinterpret_cast<char*>(p.dy_out) : nullptr;
     const char* __restrict__ X = reinterpret_cast<const char*>(p.x);
     bf16* __restrict__ O = reinterpret_cast<bf16*>(p.out);
     float slope = p.x_slope;
     asm volatile("v_mov_b32 %0, %0" : "+v"(slope));          // pinned in a vector register (no re-load from the argument segment)
 
     if (tid < CH) {
-        if (LIN2) {
+        if (MODE >= 1) {
             cf[tid] = p.dy_scale[tid];
             cf[CH + tid] = p.dy_scale2[tid];
             cf[2 * CH + tid] = p.dy_shift[tid];
@@ -172,19 +185,18 @@ __global__ __launch_bounds__(512) void bwd3x3f_kernel(const sv_geom g, const bwd
     }
 
     // ---- staging slots: everything that does not depend on the tile --------------------------------------------------------
-    // halo slot kind: 0 = always zero (padding column / spacer / dummy), 1 = image row of this tile, 2 = row above the tile,
-    // 3 = row below it (valid only inside the same image).  A thread's 8-channel group v is the same for all of its slots.
-    // The LOADERS are the weight-gradient waves (4-7) alone: on gfx950 loads and stores share one counter (vmcnt) and may retire out
-    // of order against each other, so a wave with a store in flight can only wait for a load with vmcnt(0) -- the data-gradient
-    // waves store the output tile every iteration and would drain the whole prefetch queue each time (the compiler does exactly
-    // that: first version of this kernel, 2.6 us per tile).  A wave that only loads waits with a COUNT: the other stage stays in flight.
-    const int ltid = tid & 255;
+    // halo slot kind: 0 = always zero (spacer / dummy), 1 = image row of this tile, 2 = row above the tile, 3 = row below it (valid
+    // only inside the same image).  A thread's 8-channel group v is the same for all of its slots.  Weight-gradient waves (4-7)
+    // hold halo vectors ltid and ltid + 256, data-gradient waves vector 512 + tid (most of them: HV = 768 / 640 / 608).
+    // (The first version of this kernel loaded on the weight-gradient waves only -- believing that a wave with stores in flight can
+    //  only wait with vmcnt(0).  What drained the queue were REQUESTS BEHIND BRANCHES: with every request unconditional the compiler
+    //  counts, stores or not.  Sharing the staging halves the longest wave's vector work.)
     const int v = tid & 3;
-    int hlds[HI];                     // LDS element offset (a multiple of 8) | kind in the two low bits; -1: no slot
-    uint32_t hoff[HI];
+    int hlds[2];                      // LDS element offset (a multiple of 8) | kind in the two low bits; -1: no slot
+    uint32_t hoff[2];
 #pragma unroll
-    for (int i = 0; i < HI; ++i) {
-        const int idx = ltid + 256 * i;
+    for (int i = 0; i < 2; ++i) {
+        const int idx = wave >= 4 ? (tid - 256) + 256 * i : (i == 0 ? 512 + tid : HV);
         const int pix = min(idx, HV - 1) >> 2;
         const int lr = pix >> WLOG, xx = pix & (W - 1);
         const int seg = lr / (HH + 1), off = lr - seg * (HH + 1);
@@ -197,49 +209,58 @@ __global__ __launch_bounds__(512) void bwd3x3f_kernel(const sv_geom g, const bwd
         hlds[i] = idx < HV ? (((lr * WP + xx + 1) * LDF + 8 * v) | kind) : -1;
     }
     const uint32_t hsafe = (uint32_t)(W * CH + 8 * v) * 2u;                   // (slots that are zero for this tile read its first pixel)
-    const int cp = ltid >> 2;                                                 // this thread's center pixels: cp, cp + 64
+    const int cp = tid >> 2;                                                  // this thread's centre pixel
     const uint32_t coff = (uint32_t)(cp * CH + 8 * v) * 2u;
 
-    struct Stage { V gv[HI]; V yv[LIN2 ? HI : 1]; V xv[2]; };
-    Stage SA, SB;
-    auto load_stage = [&](Stage& S, int tile) __attribute__((always_inline)) {
+    auto load_stage = [&](auto& S, int tile) __attribute__((always_inline)) {
+        constexpr int NS = sizeof(S.gv) / sizeof(V);
         const int gr0 = tile * TR;
         const bool top_ok = (gr0 & (H - 1)) != 0, bot_ok = ((gr0 + TR) & (H - 1)) != 0;
         const int64_t hb = ((int64_t)gr0 - 1) * W * CH * 2;
 #pragma unroll
-        for (int i = 0; i < HI; ++i) {
+        for (int i = 0; i < NS; ++i) {
             const int kind = hlds[i] & 3;
-            const bool ok = kind == 1 || (kind == 2 && top_ok) || (kind == 3 && bot_ok);
+            const bool ok = hlds[i] >= 0 && (kind == 1 || (kind == 2 && top_ok) || (kind == 3 && bot_ok));
             const uint32_t o = ok ? hoff[i] : hsafe;
             S.gv[i] = *reinterpret_cast<const V*>(DY + hb + o);
-            if constexpr (LIN2) S.yv[i] = *reinterpret_cast<const V*>(DY2 + hb + o);
+            if constexpr (MODE >= 1) S.yv[i] = *reinterpret_cast<const V*>(DY2 + hb + o);
+            if constexpr (MODE == 2) S.rv[i] = *reinterpret_cast<const V*>(DY3 + hb + o);
         }
-#pragma unroll
-        for (int j = 0; j < 2; ++j) S.xv[j] = *reinterpret_cast<const V*>(X + (int64_t)gr0 * W * CH * 2 + coff + j * (64 * CH * 2));
+        S.xv = *reinterpret_cast<const V*>(X + (int64_t)gr0 * W * CH * 2 + coff);
     };
     V zero;
 #pragma unroll
     for (int j = 0; j < 8; ++j) zero[j] = (bf16)0.f;
-    auto store_stage = [&](Stage& S, int tile, int stage) __attribute__((always_inline)) {
+    auto store_stage = [&](auto& S, int tile, int stage) __attribute__((always_inline)) {
+        constexpr int NS = sizeof(S.gv) / sizeof(V);
         bf16* sb = st0 + stage * STG;
         const int gr0 = tile * TR;
         const bool top_ok = (gr0 & (H - 1)) != 0, bot_ok = ((gr0 + TR) & (H - 1)) != 0;
+        const int64_t hb = ((int64_t)gr0 - 1) * W * CH * 2;
 #pragma unroll
-        for (int i = 0; i < HI; ++i) {
+        for (int i = 0; i < NS; ++i) {
             const int kind = hlds[i] & 3;
             const bool ok = kind == 1 || (kind == 2 && top_ok) || (kind == 3 && bot_ok);
             V o = S.gv[i];
-            if constexpr (LIN2) {
-                // the BatchNorm backward of the layer behind the convolution: the expression (and rounding) of conv3x3p_kernel's
-                // two-tensor prologue and of wgrad3x3m_kernel's dy2 operand
+            if constexpr (MODE >= 1) {
+                // the BatchNorm backward of the layer behind the convolution as ONE expression (two fused multiply-adds, one rounding
+                // to bf16); MODE 2 adds the skip connection's gradient in fp32 before that rounding
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     const f32x4 ca = *reinterpret_cast<const f32x4*>(cf + 8 * v + 4 * h);
                     const f32x4 cb = *reinterpret_cast<const f32x4*>(cf + CH + 8 * v + 4 * h);
                     const f32x4 cc = *reinterpret_cast<const f32x4*>(cf + 2 * CH + 8 * v + 4 * h);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        o[4 * h + j] = (bf16)(to_f(S.gv[i][4 * h + j]) * ca[j] + (to_f(S.yv[LIN2 ? i : 0][4 * h + j]) * cb[j] + cc[j]));
+                    for (int j = 0; j < 4; ++j) {
+                        float t = to_f(S.gv[i][4 * h + j]) * ca[j] + (to_f(S.yv[MODE >= 1 ? i : 0][4 * h + j]) * cb[j] + cc[j]);
+                        if constexpr (MODE == 2) t += to_f(S.rv[MODE == 2 ? i : 0][4 * h + j]);
+                        o[4 * h + j] = (bf16)t;
+                    }
+                }
+                // MODE 2: the tile's own rows of the formed gradient, once (no halo row, no padding column: every element of the
+                // tensor belongs to exactly one tile's kind-1 slots)
+                if constexpr (MODE == 2) {
+                    if (hlds[i] >= 0 && kind == 1) *reinterpret_cast<V*>(DYO + hb + hoff[i]) = o;
                 }
             }
             if (!ok) o = zero;
@@ -247,11 +268,8 @@ __global__ __launch_bounds__(512) void bwd3x3f_kernel(const sv_geom g, const bwd
         }
         const f32x4 s0 = *reinterpret_cast<const f32x4*>(cf + 3 * CH + 8 * v), s1 = *reinterpret_cast<const f32x4*>(cf + 3 * CH + 8 * v + 4);
         const f32x4 t0 = *reinterpret_cast<const f32x4*>(cf + 4 * CH + 8 * v), t1 = *reinterpret_cast<const f32x4*>(cf + 4 * CH + 8 * v + 4);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            *reinterpret_cast<V*>(sb + SDY + (cp + 64 * j) * LDF + 8 * v) = bn_act8(S.xv[j], s0, s1, t0, t1, slope);
-            *reinterpret_cast<V*>(sb + SDY + SAC + (cp + 64 * j) * LDR + 8 * v) = S.xv[j];
-        }
+        *reinterpret_cast<V*>(sb + SDY + cp * LDF + 8 * v) = bn_act8(S.xv, s0, s1, t0, t1, slope);
+        *reinterpret_cast<V*>(sb + SDY + SAC + cp * LDR + 8 * v) = S.xv;
     };
 
     // ---- data-gradient waves (0-3): 32 pixels of the tile each, both 16-channel tiles ------------------------------------------
@@ -335,7 +353,10 @@ __global__ __launch_bounds__(512) void bwd3x3f_kernel(const sv_geom g, const bwd
         }
     };
 
-    // ---- weight-gradient waves (4-7): the 16 x 16 quadrant (wi, wj) of dW for all nine taps --------------------------------------
+    // ---- weight-gradient waves (4-7) -----------------------------------------------------------------------------------------------
+    // one 16 x 16 quadrant (wi, wj) of dW for all nine taps over the tile's 128 pixels.  (Round 6 also tried v_mfma_f32_32x32x16_bf16 here
+    // -- the whole 32 x 32 tile of five taps over half the pixels per wave: 96 instead of 160 KB of fragment reads per tile -- and
+    // it was SLOWER: gonly 56 vs 47 us, launch 129 vs 123 us: these waves wait for LDS latency, not bandwidth; docs/lab_notes_r06.md)
     const int wi = (wave >> 1) & 1, wj = wave & 1;
     f32x4 dacc[9];
 #pragma unroll
@@ -407,19 +428,39 @@ __global__ __launch_bounds__(512) void bwd3x3f_kernel(const sv_geom g, const bwd
 
     // ---- pipeline ---------------------------------------------------------------------------------------------------------------------
     // The barrier between two tiles orders LDS traffic only.  __syncthreads() is also a release fence: behind the epilogue's global
-    // stores it waits for their acknowledgements (vmcnt(0)), a memory round trip per tile on the data-gradient waves.
+    // stores it waits for their acknowledgements (vmcnt(0)), a memory round trip per tile.
     auto tile_barrier = [&]() __attribute__((always_inline)) { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
     // The two kinds of wave run SEPARATE loops (the same number of barriers each): in one loop body behind a branch the register
     // allocator kept both kinds' loop-carried state alive together (weights + sums + both register stages + dW: spills).
+    // In both: S holds tile + tstep (requested two iterations ago); it goes to the other LDS stage and is re-requested with
+    // tile + 3 tstep.  Every request is issued UNCONDITIONALLY (past the end as a harmless re-load of the block's last tile) and the
+    // loops run whole PAIRS of tiles, an odd last tile behind them: with a request -- or the second half of a pair -- behind a branch
+    // the compiler's wait for S must also be right for the path that skipped it, i.e. it drains the queue.
+    const int t_last = t_begin + (nT - 1 - t_begin) / tstep * tstep;          // the block's last tile (the launcher guarantees t_begin < nT)
+    const int n_tiles = (nT - 1 - t_begin) / tstep + 1;
     if (wave < 4) {
-        // data-gradient waves: MFMAs, epilogue, stores -- no load, no wait
-        __syncthreads();                                      // the coefficient vectors in LDS
-        __syncthreads();                                      // tile t_begin staged
-        int stage = 0;
-        for (int tile = t_begin; tile < nT; tile += tstep) {
-            if (!(SV_BWDF_ABL & 2)) compute_d(tile, stage);
+        bwdf_stage<1, MODE> SA, SB;
+        auto iter = [&](int tile, int stage, bwdf_stage<1, MODE>& S) __attribute__((always_inline)) {
+            if (!SV_BWDF_DFIRST && !(SV_BWDF_ABL & 2)) compute_d(tile, stage);
+            if (!(SV_BWDF_ABL & 8)) store_stage(S, min(tile + tstep, t_last), stage ^ 1);
+            if (!(SV_BWDF_ABL & 4)) load_stage(S, min(tile + 3 * tstep, t_last));
+            if (SV_BWDF_DFIRST && !(SV_BWDF_ABL & 2)) compute_d(tile, stage);
             tile_barrier();
-            stage ^= 1;
+        };
+        load_stage(SA, t_begin);
+        load_stage(SB, min(t_begin + tstep, t_last));
+        __syncthreads();                                      // the coefficient vectors in LDS
+        store_stage(SA, t_begin, 0);
+        load_stage(SA, min(t_begin + 2 * tstep, t_last));
+        __syncthreads();                                      // tile t_begin staged
+        int tile = t_begin;
+        for (int k = 0; k + 1 < n_tiles; k += 2, tile += 2 * tstep) {
+            iter(tile, 0, SB);
+            iter(tile + tstep, 1, SA);
+        }
+        if (n_tiles & 1) {
+            if (!(SV_BWDF_ABL & 2)) compute_d(tile, 0);
+            tile_barrier();
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -438,12 +479,8 @@ __global__ __launch_bounds__(512) void bwd3x3f_kernel(const sv_geom g, const bwd
                 }
         }
     } else {
-        // weight-gradient waves: S holds tile + tstep (requested two iterations ago); after the MFMAs of `tile` it goes to the other
-        // LDS stage and is re-requested with tile + 3 tstep
-        const int t_last = t_begin + (nT - 1 - t_begin) / tstep * tstep;      // the block's last tile (the launcher guarantees t_begin < nT)
-        auto iter = [&](int tile, int stage, Stage& S) __attribute__((always_inline)) {
-            // (every request is issued UNCONDITIONALLY, past the end as a harmless re-load of the block's last tile: with a request
-            //  behind a branch the compiler's wait for S must also be right for the path that skipped it, i.e. it drains the queue)
+        bwdf_stage<2, MODE> SA, SB;
+        auto iter = [&](int tile, int stage, bwdf_stage<2, MODE>& S) __attribute__((always_inline)) {
             if (!GFIRST && !(SV_BWDF_ABL & 1)) compute_g(stage);
             if (!(SV_BWDF_ABL & 8)) store_stage(S, min(tile + tstep, t_last), stage ^ 1);
             if (!(SV_BWDF_ABL & 4)) load_stage(S, min(tile + 3 * tstep, t_last));
@@ -456,25 +493,21 @@ __global__ __launch_bounds__(512) void bwd3x3f_kernel(const sv_geom g, const bwd
         store_stage(SA, t_begin, 0);
         load_stage(SA, min(t_begin + 2 * tstep, t_last));
         __syncthreads();
-        // whole PAIRS in the loop, an odd last tile behind it: with the second half of a pair behind a branch the queue order at the
-        // loop head ([SB][SA] or [SA][SB]) is unknown to the compiler and the first half's waits drain it
-        const int n = (nT - 1 - t_begin) / tstep + 1;
         int tile = t_begin;
-        for (int k = 0; k + 1 < n; k += 2, tile += 2 * tstep) {
+        for (int k = 0; k + 1 < n_tiles; k += 2, tile += 2 * tstep) {
             iter(tile, 0, SB);
             iter(tile + tstep, 1, SA);
         }
-        if (n & 1) {
-            compute_g(0);
+        if (n_tiles & 1) {
+            if (!(SV_BWDF_ABL & 1)) compute_g(0);
             tile_barrier();
         }
         // D layout: the lane holds column c = 16 wj + fr, rows n = 16 wi + 4 fq + r
         float* dst = p.ws + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (9 * CH * CH);
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
-            const int to = t;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) dst[((16 * wi + 4 * fq + r) * 9 + to) * CH + 16 * wj + fr] = dacc[t][r];
+            for (int r = 0; r < 4; ++r) dst[((16 * wi + 4 * fq + r) * 9 + t) * CH + 16 * wj + fr] = dacc[t][r];
         }
     }
     __syncthreads();
@@ -484,20 +517,21 @@ __global__ __launch_bounds__(512) void bwd3x3f_kernel(const sv_geom g, const bwd
     }
 }
 
-template <int WLOG, bool LIN2>
+template <int WLOG, int MODE>
 int launch(const sv_geom* g, const bwdf_g& PG, int grid, int groups, hipStream_t s) {
     constexpr int W = 1 << WLOG, TR = 128 / W, WP = W + 2;
     constexpr int HH = (TR < W) ? TR : W, LROWS = TR + TR / HH + 1, HP = LROWS * WP;
-    constexpr size_t lds = (size_t)2 * (HP * LDF + 128 * LDF + 128 * LDR) * 2 + 2 * CH * 8 + 8 * CH * 4 + (size_t)(2 - wregs_of(LIN2, WLOG)) * 16 * 9 * LDF * 2;
+    constexpr int WREGS = WLOG == 5 ? SV_BWDF_WREGS : (MODE == 0 ? 1 : 0);      // (as in the kernel)
+    constexpr size_t lds = (size_t)2 * (HP * LDF + 128 * LDF + 128 * LDR) * 2 + 2 * CH * 8 + 8 * CH * 4 + (size_t)(2 - WREGS) * 16 * 9 * LDF * 2;
     static bool optin = false;
     if (!optin) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&bwd3x3f_kernel<WLOG, LIN2>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&bwd3x3f_kernel<WLOG, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds) != hipSuccess)
             return sv_check_launch("hipFuncSetAttribute(bwd3x3f)");
         optin = true;
     }
     sv_prof_begin(s);
-    hipLaunchKernelGGL((bwd3x3f_kernel<WLOG, LIN2>), dim3(grid, groups), dim3(512), lds, s, *g, PG);
+    hipLaunchKernelGGL((bwd3x3f_kernel<WLOG, MODE>), dim3(grid, groups), dim3(512), lds, s, *g, PG);
     sv_prof_end(s);               // (the event bracket times the main kernel only, like the weight-gradient launchers)
     return sv_check_launch("sv_bwd3x3");
 }
@@ -512,6 +546,8 @@ extern "C" int sv_bwd3x3(const sv_geom* g, int dtype, const sv_bwd3x3_args* a, v
     SV_REQUIRE(a->x_slope >= 0.f && a->x_slope <= 1.f, SV_E_ARG, "sv_bwd3x3: slope %g outside [0, 1]", (double)a->x_slope);
     SV_REQUIRE(!a->dy2 || (a->dy_scale && a->dy_scale2 && a->dy_shift), SV_E_ARG,
                "sv_bwd3x3: the two-tensor dy operand needs dy_scale, dy_scale2 and dy_shift");
+    SV_REQUIRE((a->dy3 != nullptr) == (a->dy_out != nullptr) && (!a->dy3 || a->dy2), SV_E_ARG,
+               "sv_bwd3x3: the residual form needs dy2 (+ coefficients), dy3 AND dy_out");
     const int groups = sv_ngroups(a->groups);
     SV_REQUIRE(groups <= SV_MAX_GROUPS, SV_E_ARG, "sv_bwd3x3: groups=%d", groups);
     SV_REQUIRE(a->replicas >= 1 && (a->replicas & (a->replicas - 1)) == 0, SV_E_ARG, "sv_bwd3x3: replicas=%d", a->replicas);
@@ -544,6 +580,8 @@ extern "C" int sv_bwd3x3(const sv_geom* g, int dtype, const sv_bwd3x3_args* a, v
         bwdf_params& r = PG.g[grp];
         r.dy = reinterpret_cast<const char*>(a->dy) + q * ts;
         r.dy2 = a->dy2 ? reinterpret_cast<const char*>(a->dy2) + q * ts : nullptr;
+        r.dy3 = a->dy3 ? reinterpret_cast<const char*>(a->dy3) + q * ts : nullptr;
+        r.dy_out = a->dy_out ? reinterpret_cast<char*>(a->dy_out) + q * ts : nullptr;
         r.dy_scale = a->dy2 ? a->dy_scale + q * CH : nullptr;
         r.dy_scale2 = a->dy2 ? a->dy_scale2 + q * CH : nullptr;
         r.dy_shift = a->dy2 ? a->dy_shift + q * CH : nullptr;
@@ -560,11 +598,17 @@ extern "C" int sv_bwd3x3(const sv_geom* g, int dtype, const sv_bwd3x3_args* a, v
         r.ws = a->ws;
     }
     int rc;
-    const bool lin2 = a->dy2 != nullptr;
-    switch (g->Win) {
-        case 32: rc = lin2 ? launch<5, true>(g, PG, grid, groups, s) : launch<5, false>(g, PG, grid, groups, s); break;
-        case 16: rc = lin2 ? launch<4, true>(g, PG, grid, groups, s) : launch<4, false>(g, PG, grid, groups, s); break;
-        default: rc = lin2 ? launch<3, true>(g, PG, grid, groups, s) : launch<3, false>(g, PG, grid, groups, s); break;
+    const int mode = a->dy3 ? 2 : a->dy2 ? 1 : 0;
+    switch (g->Win * 4 + mode) {
+        case 32 * 4 + 0: rc = launch<5, 0>(g, PG, grid, groups, s); break;
+        case 32 * 4 + 1: rc = launch<5, 1>(g, PG, grid, groups, s); break;
+        case 32 * 4 + 2: rc = launch<5, 2>(g, PG, grid, groups, s); break;
+        case 16 * 4 + 0: rc = launch<4, 0>(g, PG, grid, groups, s); break;
+        case 16 * 4 + 1: rc = launch<4, 1>(g, PG, grid, groups, s); break;
+        case 16 * 4 + 2: rc = launch<4, 2>(g, PG, grid, groups, s); break;
+        case 8 * 4 + 0: rc = launch<3, 0>(g, PG, grid, groups, s); break;
+        case 8 * 4 + 1: rc = launch<3, 1>(g, PG, grid, groups, s); break;
+        default: rc = launch<3, 2>(g, PG, grid, groups, s); break;
     }
     if (rc != SV_OK) return rc;
     sv_slab_reduce(a->ws, grid * groups, slab, a->dw, s);

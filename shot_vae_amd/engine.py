@@ -501,8 +501,16 @@ class Engine:
     # sv_bwd3x3 (ABI 7): data gradient + weight gradient of a 32 -> 32 channel body convolution in ONE launch that reads every
     # operand once.  1 = conv1 of the same-shape units in the two-tensor form (norm2's BatchNorm backward formed in the kernel's
     # load path: the sv_bn_bwd_apply pass between the unit's two data gradients disappears: 8 tensor passes -> 4);
-    # 2 = conv2 of every 32-channel unit as well (5 passes -> 3).  bf16, not in deterministic mode.
-    fused_bwd = 1
+    # 2 = also conv2 of the unit IN FRONT of such a unit in the residual form: the NEXT unit's norm1 backward + skip connection
+    # (the sv_bn_bwd_apply pass at the unit boundary, 4 passes) formed in its load path and written once as a side output
+    # (9 passes -> 6); 3 = every other 32-channel conv2 as well (5 passes -> 3: slower than the two-stream pair, an A/B switch).
+    # bf16, not in deterministic mode.
+    fused_bwd = 2
+    # blocks of a fused-backward launch (one 512-thread block per CU: a block's eight waves fill the SIMDs' register files).  NOT 256:
+    # a single CU that hosts anything else -- the side stream's spinning wait_flag_kernel, the tail of a slab reduction -- cannot take
+    # a block, the 256th block then runs as a second round and the launch takes twice as long (152 -> 240-247 us in the step's
+    # trace, round 6).  248 = 31 per XCD leaves every XCD one CU for the neighbours.
+    fused_blocks = 248
     flag_fork = True                 # paired launches: the data gradient's start signal forks the side stream (no event)
     _start_signal = None
     _pending_wgrads = ()
@@ -626,9 +634,10 @@ class Engine:
         a.groups, a.block_budget = groups, budget          # the budget is an argument of THIS launch, not process state
         L.call("sv_wgrad_ex", C.byref(g), self.code, C.byref(a), self._stream())
 
-    def _bwd3x3(self, cv, B, dy, lin2, x, bn_ptrs, slope, out, bsums, replicas, tag, groups, budget=0):
+    def _bwd3x3(self, cv, B, dy, lin2, x, bn_ptrs, slope, out, bsums, replicas, tag, groups, budget=0, res=None):
         """sv_bwd3x3: data gradient (activation-backward epilogue of the BatchNorm in front: bn_ptrs = scale, shift, mean, rstd) and
-        weight gradient of the stride-1 3x3 convolution `cv` in one launch; lin2 = (dy2 tensor, scale, scale2, shift pointers)"""
+        weight gradient of the stride-1 3x3 convolution `cv` in one launch; lin2 = (dy2 tensor, scale, scale2, shift pointers);
+        res = (dy3 tensor, dy_out tensor): the residual form"""
         g = cv.geom_dgrad(B)
         if tag:
             # algorithmic cost: dy [+ dy2] and x read once, g written; both products' flops
@@ -636,17 +645,19 @@ class Engine:
             es = self.packs.element_size()
             if self.prof_tags is not None:
                 L.lib().sv_prof_tag(self.prof_tags.setdefault(tag, len(self.prof_tags)))
-            self._cost(tag, es * n * (3 + (lin2 is not None)) + 4 * 9 * g.Cin * g.N, 2 * 2.0 * n * 9 * g.N)
+            self._cost(tag, es * n * (3 + (lin2 is not None) + 2 * (res is not None)) + 4 * 9 * g.Cin * g.N, 2 * 2.0 * n * 9 * g.N)
         a = L.SvBwd3x3Args()
         a.dy, a.x, a.out = dy.data_ptr(), x.data_ptr(), out.data_ptr()
         if lin2 is not None:
             a.dy2, a.dy_scale, a.dy_scale2, a.dy_shift = lin2[0].data_ptr(), lin2[1], lin2[2], lin2[3]
+        if res is not None:
+            a.dy3, a.dy_out = res[0].data_ptr(), res[1].data_ptr()
         a.x_scale, a.x_shift, a.x_mean, a.x_rstd = bn_ptrs
         a.x_slope = slope
         a.w = self.packs.data_ptr() + self.packs.element_size() * cv.dgrad_off
         a.bsums, a.replicas, a.groups = bsums, replicas, groups
         a.dw = self.grad.data_ptr() + 4 * cv.master_off
-        a.ws, a.ws_elems, a.block_budget = self._wg_ws().data_ptr(), self._ws_elems, budget
+        a.ws, a.ws_elems, a.block_budget = self._wg_ws().data_ptr(), self._ws_elems, budget or self.fused_blocks
         L.call("sv_bwd3x3", C.byref(g), self.code, C.byref(a), self._stream())
 
     # ------------------------------------------------------------------------------- forward
@@ -1095,6 +1106,7 @@ class Engine:
                _vp(dfeat.data_ptr()), Bt, hw, p.cfeat, p.cfeat, _vp(g.data_ptr()), _vp(bs_off[p.bn_t.index]), G, st)
         D = bn_apply(tl, [(g, p.bn_t)], None, B * hw)
         # ---- encoder units, last to first (wideresnet.py:45-49 backward) ------------------------
+        deferred = None
         for i in range(len(p.units) - 1, -1, -1):
             un = p.units[i]
             tin, c1 = f.t[i], f.c1[i]
@@ -1110,7 +1122,18 @@ class Engine:
             g2 = torch.empty_like(c1)
             fb = self.fused_bwd if (self.code == L.SV_BF16 and not det and c == 32 and c1.shape[1] in (8, 16, 32)
                                     and (B * c1.shape[1]) % (128 // c1.shape[1]) == 0) else 0
-            if fb >= 2:
+            if deferred is not None:
+                # the unit BEHIND this one left its boundary pass to this launch: D = dL/d(this unit's output) = norm1's BatchNorm
+                # backward of g1n + the skip connection's gradient, formed in conv2's load path from (g1n, the next unit's raw input
+                # = this unit's output, the gradient at the next unit's output) and written once (the previous unit's skip needs it)
+                g1n, tinn, bn1n, Dres, cntn = deferred
+                deferred = None
+                coefn, sgn, sxn, shn = bn_affine(bn1n, cntn)
+                D = torch.empty_like(Dres)
+                self._bwd3x3(un["conv2"], B, g1n, (tinn, sgn, sxn, shn), c1, bnp(un["bn2"]), un["bn2"].slope, g2,
+                             bs_off[un["bn2"].index], bs_rep[un["bn2"].index], "bwd:conv3x3_%dx%d_s1+bn+skip" % (c, c), G, res=(Dres, D))
+                del coefn, g1n, Dres
+            elif fb >= 3:
                 self._bwd3x3(un["conv2"], B, D, None, c1, bnp(un["bn2"]), un["bn2"].slope, g2, bs_off[un["bn2"].index],
                              bs_rep[un["bn2"].index], "bwd:conv3x3_%dx%d_s1" % (c, c), G)
             else:
@@ -1168,8 +1191,13 @@ class Engine:
                                                            ex=ex_of(un["bni"], tin), sparse_out=sp,
                                                            tag="dgrad:conv1x1_%dx%d" % (un["cin"], c), groups=G))
                 D = bn_apply(tin, [(g1, un["bn1"]), (gi_, un["bni"])], None, cnt, sparse=(1,) if sp else ())
+            elif fb >= 2 and same and i > 0 and p.units[i - 1]["cout"] == c:
+                # the boundary pass (norm1's backward + the skip connection) is left to conv2 of the unit in front (see above)
+                deferred = (g1, tin, un["bn1"], D, cnt)
+                D = None
             else:
                 D = bn_apply(tin, [(g1, un["bn1"])], D, cnt)
+        assert deferred is None
         # ---- stem: weight + bias gradients (the image needs none) ---------------------------------
         self._wgrad_async(p.stem.geom_fwd(B), f.x16, None, D, gbase + 4 * p.stem.master_off, tag="wgrad:stem", groups=G)
         L.call("sv_colsum", self.code, _vp(D.data_ptr()), D.numel() // 16, 16, 16, _vp(gbase + 4 * p.stem_bias_off), st)

@@ -21,14 +21,14 @@ from shot_vae_amd import geometry as G      # noqa: E402
 from tests.test_kernels_gpu import ACC, bq, dev, nchw, nhwc, p, rel, repack, st      # noqa: E402
 
 CH = 32
-# B (per group), H, groups, block budget, two-tensor dy
-CASES = [(16, 32, 2, 0, False), (16, 32, 2, 0, True),
-         (3, 32, 1, 0, False),                    # fewer tiles than blocks
-         (24, 32, 1, 0, True),                    # the steady state of the register pipeline (> 3 tiles per block at budget 64)
-         (40, 32, 4, 64, True), (40, 32, 4, 64, False),
-         (8, 16, 1, 0, True), (8, 16, 3, 0, False),          # 16 x 16 maps: eight rows per tile
-         (6, 8, 2, 0, True), (6, 8, 1, 16, False),           # 8 x 8 maps: two images per tile (spacer rows in the LDS halo)
-         (130, 32, 4, 0, True)]                   # 4 x 130 images: many tiles per block, all four groups
+# B (per group), H, groups, block budget, form of dy: 0 = a tensor, 1 = two-tensor (BatchNorm backward), 2 = + residual and side output
+CASES = [(16, 32, 2, 0, 0), (16, 32, 2, 0, 1), (16, 32, 2, 0, 2),
+         (3, 32, 1, 0, 0), (3, 32, 1, 0, 2),      # fewer tiles than blocks
+         (24, 32, 1, 0, 1),                       # the steady state of the register pipeline (> 3 tiles per block at budget 64)
+         (40, 32, 4, 64, 1), (40, 32, 4, 64, 0), (40, 32, 4, 64, 2),
+         (8, 16, 1, 0, 1), (8, 16, 3, 0, 0), (8, 16, 2, 0, 2),           # 16 x 16 maps: eight rows per tile
+         (6, 8, 2, 0, 1), (6, 8, 1, 16, 0), (6, 8, 2, 0, 2),             # 8 x 8 maps: two images per tile (spacer rows in the LDS halo)
+         (130, 32, 4, 0, 1), (130, 32, 4, 0, 2)]  # 4 x 130 images: many tiles per block, all four groups
 
 
 def _inputs(B, H, Gn, lin2, seed):
@@ -38,6 +38,7 @@ def _inputs(B, H, Gn, lin2, seed):
     t = {}
     t["dy"] = torch.randn(Gn * B, H, H, CH, device=d).to(bf)
     t["c1"] = (torch.randn(Gn * B, H, H, CH, device=d) * 1.3 - 0.2).to(bf) if lin2 else None
+    t["res"] = (torch.randn(Gn * B, H, H, CH, device=d) * 0.8).to(bf) if lin2 == 2 else None
     t["x"] = (torch.randn(Gn * B, H, H, CH, device=d) * 0.9 + 0.1).to(bf)
     t["w"] = bq(torch.randn(CH, 9, CH) / (9 * CH) ** 0.5, "bf16")          # master weights [N][tap][Cin]
     t["sc"] = (torch.rand(Gn, CH, device=d) + 0.5).contiguous()
@@ -60,7 +61,10 @@ def materialise(t, B):
     gi = torch.arange(t["dy"].shape[0], device=t["dy"].device) // B
     ca, cb, cc = (t["coef"][k][gi][:, None, None, :].double() for k in range(3))
     inner = (t["c1"].double() * cb + cc).float()
-    return (t["dy"].double() * ca + inner.double()).float().to(torch.bfloat16)
+    out = (t["dy"].double() * ca + inner.double()).float()
+    if t.get("res") is not None:
+        out = out + t["res"].float()             # the skip connection's gradient: a plain fp32 add behind the two multiply-adds
+    return out.to(torch.bfloat16)
 
 
 def _pair(t, B, H, Gn, budget, slope, R):
@@ -99,6 +103,9 @@ def _fused(t, wd, gd, Gn, budget, slope, R, ws=None):
     if t["coef"] is not None:
         a.dy2, a.dy_scale, a.dy_scale2, a.dy_shift = (t["c1"].data_ptr(), t["coef"][0].data_ptr(), t["coef"][1].data_ptr(),
                                                       t["coef"][2].data_ptr())
+    if t.get("res") is not None:
+        t["dy_out"] = torch.full_like(t["dy"], 5.0)
+        a.dy3, a.dy_out = t["res"].data_ptr(), t["dy_out"].data_ptr()
     a.x_scale, a.x_shift, a.x_mean, a.x_rstd, a.x_slope = (t["sc"].data_ptr(), t["sh"].data_ptr(), t["mean"].data_ptr(),
                                                            t["rstd"].data_ptr(), slope)
     a.bsums, a.replicas, a.groups, a.dw, a.ws, a.ws_elems, a.block_budget = (bs.data_ptr(), R, Gn, dw.data_ptr(), ws.data_ptr(),
@@ -112,9 +119,11 @@ def _fused(t, wd, gd, Gn, budget, slope, R, ws=None):
 def test_fused_backward_equals_the_pair_it_replaces(B, H, Gn, budget, lin2):
     slope, R = 0.01, 4
     t = _inputs(B, H, Gn, lin2, 4000 + B + H + Gn)
-    g_ref, bs_ref, dw_ref, _, wd, gd = _pair(t, B, H, Gn, budget, slope, R)
+    g_ref, bs_ref, dw_ref, dy_eff, wd, gd = _pair(t, B, H, Gn, budget, slope, R)
     g, bs, dw = _fused(t, wd, gd, Gn, budget, slope, R)
     assert bool(torch.isfinite(g.float()).all()) and bool(torch.isfinite(dw).all())
+    if lin2 == 2:                                 # the side output: the formed gradient itself, every element written exactly once
+        assert torch.equal(t["dy_out"], dy_eff), float((t["dy_out"].float() - dy_eff.float()).abs().max())
     assert torch.equal(g, g_ref), float((g.float() - g_ref.float()).abs().max())
     s, s_ref = bs.sum(1), bs_ref.sum(1)
     scale = float(s_ref.abs().max())
@@ -125,7 +134,7 @@ def test_fused_backward_equals_the_pair_it_replaces(B, H, Gn, budget, lin2):
     assert torch.equal(g2, g) and rel(dw2, dw) < 1e-6
 
 
-@pytest.mark.parametrize("B,H,Gn,lin2", [(6, 32, 2, False), (6, 32, 2, True), (4, 16, 1, True), (4, 8, 2, False)])
+@pytest.mark.parametrize("B,H,Gn,lin2", [(6, 32, 2, 0), (6, 32, 2, 1), (6, 32, 2, 2), (4, 16, 1, 1), (4, 8, 2, 0), (4, 8, 1, 2)])
 def test_fused_backward_against_torch_autograd(B, H, Gn, lin2):
     """against torch fp32 on the operands the kernel multiplies (dy and act(x) rounded to bf16), group by group"""
     d = dev()

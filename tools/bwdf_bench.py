@@ -35,7 +35,7 @@ def main():
     d = torch.device("cuda:0")
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     tensor_bytes = Gn * B * H * H * CH * 2
-    for lin2 in (False, True):
+    for lin2 in (0, 1, 2):
         t = _inputs(B, H, Gn, lin2, 7)
         g_ref, bs_ref, dw_ref, _, wd, gd = _pair(t, B, H, Gn, 0, 0.01, 4)
         ws = torch.empty(4 * 1024 * 1024, device=d)
@@ -43,10 +43,10 @@ def main():
         ok = torch.equal(g, g_ref)
         err = float((dw - dw_ref).abs().max() / dw_ref.abs().max())
         us = timed(lambda: _fused_nosync(t, wd, gd, Gn, budget, ws))
-        passes = 4 if lin2 else 3
+        passes = (3, 4, 6)[lin2]
         us_pair = timed(lambda: _pair_nosync(t, B, H, Gn, wd, gd))
         print("%s  fused %7.1f us  %6.0f GB/s of %d passes (%.0f MB)   pair back to back %7.1f us   g bit-equal %s  dw rel %.1e"
-              % ("two-tensor" if lin2 else "plain     ", us, passes * tensor_bytes / us / 1e3, passes, passes * tensor_bytes / 1e6,
+              % (("plain     ", "two-tensor", "residual  ")[lin2], us, passes * tensor_bytes / us / 1e3, passes, passes * tensor_bytes / 1e6,
                  us_pair, ok, err))
 
 
@@ -54,7 +54,7 @@ _bufs = {}
 
 
 def _fused_nosync(t, wd, gd, Gn, budget, ws):
-    key = ("f", t["coef"] is not None)
+    key = ("f", t["coef"] is not None, t.get("res") is not None)
     if key not in _bufs:
         d = t["x"].device
         _bufs[key] = (torch.empty_like(t["x"]), torch.zeros(Gn, 4, 2 * CH, device=d, dtype=torch.float64), torch.zeros(CH, 9, CH, device=d))
@@ -64,6 +64,8 @@ def _fused_nosync(t, wd, gd, Gn, budget, ws):
     if t["coef"] is not None:
         a.dy2, a.dy_scale, a.dy_scale2, a.dy_shift = (t["c1"].data_ptr(), t["coef"][0].data_ptr(), t["coef"][1].data_ptr(),
                                                       t["coef"][2].data_ptr())
+    if t.get("res") is not None:
+        a.dy3, a.dy_out = t["res"].data_ptr(), t["dy_out"].data_ptr()
     a.x_scale, a.x_shift, a.x_mean, a.x_rstd, a.x_slope = (t["sc"].data_ptr(), t["sh"].data_ptr(), t["mean"].data_ptr(),
                                                            t["rstd"].data_ptr(), 0.01)
     a.bsums, a.replicas, a.groups, a.dw, a.ws, a.ws_elems, a.block_budget = (bs.data_ptr(), 4, Gn, dw.data_ptr(), ws.data_ptr(),
@@ -74,7 +76,7 @@ def _fused_nosync(t, wd, gd, Gn, budget, ws):
 def _pair_nosync(t, B, H, Gn, wd, gd):
     """what the step runs for such a layer today, on ONE stream: [sv_bn_bwd_apply], data gradient, weight gradient"""
     d = t["x"].device
-    key = ("p", t["coef"] is not None)
+    key = ("p", t["coef"] is not None, t.get("res") is not None)
     if key not in _bufs:
         _bufs[key] = (torch.empty_like(t["x"]), torch.zeros(Gn, 4, 2 * CH, device=d, dtype=torch.float64), torch.zeros(CH, 9, CH, device=d),
                       torch.empty(16 * 1024 * 1024, device=d), torch.empty_like(t["x"]), G.conv_like(B, H, H, CH, CH, 3, 1, 1))
@@ -87,8 +89,8 @@ def _pair_nosync(t, B, H, Gn, wd, gd):
         arr[0].g, arr[0].bsums, arr[0].gamma, arr[0].replicas = t["dy"].data_ptr(), bs.data_ptr(), t["sc"].data_ptr(), 4
         arr[0].dgamma = arr[0].dbeta = None
         L.call("sv_bn_bwd_apply", L.SV_BF16, Gn * 0 + t["x"].numel() // CH // Gn, CH, CH, C.c_void_p(t["c1"].data_ptr()),
-               C.c_void_p(t["mean"].data_ptr()), C.c_void_p(t["rstd"].data_ptr()), float(B * H * H), arr, 1, None,
-               C.c_void_p(dc1.data_ptr()), Gn, st)
+               C.c_void_p(t["mean"].data_ptr()), C.c_void_p(t["rstd"].data_ptr()), float(B * H * H), arr, 1,
+               C.c_void_p(t["res"].data_ptr()) if t.get("res") is not None else None, C.c_void_p(dc1.data_ptr()), Gn, st)
         dy = dc1
     a = L.SvIgemmArgs()
     a.x, a.w, a.out, a.groups = dy.data_ptr(), wd.data_ptr(), g.data_ptr(), Gn
