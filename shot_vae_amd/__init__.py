@@ -11,3 +11,4 @@ from .evaluate import Evaluator, evaluate       # noqa: F401
 from .data import DeviceDataset, ssl_split      # noqa: F401
 from .smooth import (SmoothVAE, svhn_VAE, mnist_VAE, SmoothELBOLoss, smooth_train_step,      # noqa: F401
                      GraphedSmoothStep)
+from .trace import StepLogger, step_range, enable_ranges     # noqa: F401

@@ -9,6 +9,7 @@ from . import dp
 from .criterion import continuous_posterior_loss
 from .mixup import _lerp, device_permutation, label_smoothing, mixup_vae_data, optimal_match_index
 from .steploss import TERMS, shot_loss_step_groups
+from .trace import step_range
 
 
 def alpha_schedule(epoch, max_epoch, alpha_max):
@@ -241,8 +242,9 @@ def train_step_grouped(model, elbo_criterion, cls_criterion, optimizer, image_l,
         eng.ensure_packs()                    # (the weight re-pack belongs to the main stream, behind the optimizer step)
         torch.cuda.set_stream(side_in)
     try:
-        prep = _grouped_inputs(model, image_l, label_l, image_u, epsilon, device_rng, optimal_match, launches,
-                               side_in is not None)
+        with step_range("inputs"):
+            prep = _grouped_inputs(model, image_l, label_l, image_u, epsilon, device_rng, optimal_match, launches,
+                                   side_in is not None)
     finally:
         if side_in is not None:
             torch.cuda.set_stream(main)
@@ -364,10 +366,11 @@ def _grouped_body(model, elbo_criterion, cls_criterion, optimizer, image_l, labe
         if len(launches) > 1:
             eng.defer_slot = li          # (launch li holds forwards that all precede those of launch li + 1)
         try:
-            rec, mu, ls, la, fctx = model.forward_groups_direct([images[k] for k in ids], [specs[k] for k in ids], eps=e_cat,
-                                                                u=u_cat, rec_groups=nrec, update_order=order,
-                                                                image_cat=prep["image_cat"] if len(launches) == 1 else None,
-                                                                x16=prep["x16"] if len(launches) == 1 else None)
+            with step_range("forward"):
+                rec, mu, ls, la, fctx = model.forward_groups_direct([images[k] for k in ids], [specs[k] for k in ids], eps=e_cat,
+                                                                    u=u_cat, rec_groups=nrec, update_order=order,
+                                                                    image_cat=prep["image_cat"] if len(launches) == 1 else None,
+                                                                    x16=prep["x16"] if len(launches) == 1 else None)
         finally:
             eng.defer_slot = None
         ctxs.append((ids, fctx, rec, mu, ls, la))
@@ -385,8 +388,9 @@ def _grouped_body(model, elbo_criterion, cls_criterion, optimizer, image_l, labe
         per_launch.append(d)
         for j, k in enumerate(ids):
             grads[k] = (d[0][j * B:(j + 1) * B] if outs[k][0] is not None else None,) + tuple(t[j * B:(j + 1) * B] for t in d[1:])
-    terms = shot_loss_step_groups(outs, grads, image_l, image_u, label_l, perm_l, perm_u, lam_l, lam_u, sch,
-                                  bce=elbo_criterion.bce_reconstruction, x_sigma=elbo_criterion.x_sigma)
+    with step_range("loss"):
+        terms = shot_loss_step_groups(outs, grads, image_l, image_u, label_l, perm_l, perm_u, lam_l, lam_u, sch,
+                                      bce=elbo_criterion.bce_reconstruction, x_sigma=elbo_criterion.x_sigma)
     loss_sup, loss_unsup = terms[10], terms[11]
     # backward(s): launches without a reconstruction first; the decoder-first gradient bucket of a data-parallel step is armed
     # for the LAST backward that runs the decoder (its gradients are complete once that one has issued them)   :324 + :364
@@ -394,9 +398,11 @@ def _grouped_body(model, elbo_criterion, cls_criterion, optimizer, image_l, labe
     for n, i in enumerate(seq):
         if n == len(seq) - 1 and optimizer is not None and _bucketed(model, distributed) is not None:
             _bucketed(model, distributed).arm()
-        model.backward_direct(ctxs[i][1], *per_launch[i], own_grads=True)
+        with step_range("backward"):
+            model.backward_direct(ctxs[i][1], *per_launch[i], own_grads=True)
     if optimizer is not None:
-        apply_update(model, optimizer, distributed)
+        with step_range("update"):
+            apply_update(model, optimizer, distributed)
     if not return_outputs:
         if label_u is not None:
             return loss_sup.detach(), loss_unsup.detach(), kl_inference

@@ -195,3 +195,30 @@ def test_flat_sgd_is_a_torch_optimizer_and_takes_the_reference_schedule():
     assert len(opt2.param_groups[0]["params"]) == len(list(m.parameters()))
     with pytest.raises(NotImplementedError):
         opt.step(closure=lambda: None)
+
+
+def test_step_logger_and_ranges(tmp_path):
+    """shot_vae_amd.trace: the per-step JSONL of the loss terms (what the reference logs through TensorBoard / its progress line,
+    main_shot_vae.py:367-383) and the roctx phase ranges (no-ops unless enabled; libroctx64.so loads without a GPU)."""
+    path = tmp_path / "log" / "steps.jsonl"
+    out = {k: torch.tensor(float(i) + 0.5) for i, k in enumerate(S.trace.SCALARS)}
+    out["kl_inference"] = torch.tensor(0.25)
+    out["rec1"] = torch.zeros(2, 3)                       # (tensors that are not scalars of the log are ignored)
+    with S.StepLogger(str(path)) as lg:
+        lg.log(out)
+        rec = lg.log(out, step=7, lr=0.02)
+    lines = [json.loads(ln) for ln in open(path)]
+    assert len(lines) == 2 and lines[0]["step"] == 0 and lines[1]["step"] == 7 and lines[1]["lr"] == 0.02
+    assert lines[1]["loss_unsup"] == 11.5 and lines[1]["kl_inference"] == 0.25 and "rec1" not in lines[1] and rec == lines[1]
+    assert [k for k in lines[0] if k in S.trace.SCALARS] == list(S.trace.SCALARS)
+    was = S.trace.ranges_enabled()
+    try:
+        S.enable_ranges(False)
+        with S.step_range("forward"):
+            pass
+        if S.enable_ranges(True):                          # the library is in the ROCm image: a pushed range is popped again
+            with S.step_range("backward"):
+                with S.step_range("nested"):
+                    pass
+    finally:
+        S.enable_ranges(was)

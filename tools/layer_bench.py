@@ -80,9 +80,34 @@ def bench_layer(B, Cin, H, N, what=("fwd", "dgrad", "wgrad")):
                                             C.c_void_p(sc.data_ptr()), C.c_void_p(sh.data_ptr()), C.c_float(0.01),
                                             C.c_void_p(dy.data_ptr()), C.c_void_p(dw.data_ptr()), 0, 1,
                                             C.c_void_p(ws.data_ptr()), ws.numel(), 1, st))
+    for form, kind in enumerate(("bwd", "bwd2", "bwd3")):
+        # sv_bwd3x3, the fused backward (32 channels): dy a tensor / two-tensor form / residual form; one group of B images
+        if kind not in what:
+            continue
+        assert Cin == 32 and N == 32, "sv_bwd3x3: 32 -> 32 channels"
+        g = G.convT_like(B, H, H, N, Cin, 3, 1, 1)
+        wp = torch.zeros(G.packed_size(g), dtype=bf, device=d)
+        L.call("sv_repack", L.SV_BF16, C.c_void_p(master.data_ptr()), N, 9, Cin, 1, C.byref(g), C.c_void_p(wp.data_ptr()), st)
+        out, dyo = torch.empty(B, H, H, Cin, dtype=bf, device=d), torch.empty(B, H, H, N, dtype=bf, device=d)
+        y2, r3 = torch.randn(B, H, H, N, device=d).to(bf), torch.randn(B, H, H, N, device=d).to(bf)
+        vec = [torch.rand(Cin, device=d) + 0.5 for _ in range(4)]
+        cof = [torch.rand(N, device=d) + 0.5, torch.randn(N, device=d) * 0.2, torch.randn(N, device=d) * 0.05]
+        bs = torch.zeros(R, 2 * Cin, device=d, dtype=torch.float64)
+        dw, ws = torch.zeros(N, 9, Cin, device=d), torch.empty(4 << 20, device=d)
+        a = L.SvBwd3x3Args()
+        a.dy, a.x, a.w, a.out = dy.data_ptr(), x.data_ptr(), wp.data_ptr(), out.data_ptr()
+        if form >= 1:
+            a.dy2, a.dy_scale, a.dy_scale2, a.dy_shift = y2.data_ptr(), cof[0].data_ptr(), cof[1].data_ptr(), cof[2].data_ptr()
+        if form == 2:
+            a.dy3, a.dy_out = r3.data_ptr(), dyo.data_ptr()
+        a.x_scale, a.x_shift, a.x_mean, a.x_rstd, a.x_slope = [t.data_ptr() for t in vec] + [0.01]
+        a.bsums, a.replicas, a.groups, a.dw, a.ws, a.ws_elems = bs.data_ptr(), R, 1, dw.data_ptr(), ws.data_ptr(), ws.numel()
+        a.block_budget = int(os.environ.get("SV_BENCH_FUSED_BLOCKS", "248"))
+        res[kind] = timed(lambda: L.call("sv_bwd3x3", C.byref(g), L.SV_BF16, C.byref(a), st))
     for k, us in res.items():
-        print(f"B={B} Cin={Cin} N={N} H={H} {k:6s} {us:9.1f} us  {flops / us / 1e6:8.1f} TFLOP/s  "
-              f"{flops / us / 1e-6 / PEAK:6.3f} of bf16 MFMA peak", flush=True)
+        fl = flops * (2 if k.startswith("bwd") else 1)
+        print(f"B={B} Cin={Cin} N={N} H={H} {k:6s} {us:9.1f} us  {fl / us / 1e6:8.1f} TFLOP/s  "
+              f"{fl / us / 1e-6 / PEAK:6.3f} of bf16 MFMA peak", flush=True)
     return res
 
 

@@ -33,6 +33,8 @@ LAYERS = {
     "wgrad:conv3x3_128x128_s1": (2048, 128, 8, 128, "wgrad", ["wgrad3x3m_kernel", "wgrad3x3_kernel", "slab_reduce_kernel"]),
     "fwd:conv3x3_128x128_s1": (2048, 128, 8, 128, "fwd", ["conv3x3_kernel", "conv3x3w_kernel"]),
     "dgrad:conv3x3_128x128_s1": (2048, 128, 8, 128, "dgrad", ["conv3x3_kernel", "conv3x3w_kernel"]),
+    "bwd:conv3x3_32x32_s1+bn": (2048, 32, 32, 32, "bwd2", ["bwd3x3f_kernel", "slab_reduce_kernel"]),
+    "bwd:conv3x3_32x32_s1+bn+skip": (2048, 32, 32, 32, "bwd3", ["bwd3x3f_kernel", "slab_reduce_kernel"]),
     "fwd:conv3x3_160x160_s1": (1024, 160, 32, 160, "fwd", ["conv3x3x_kernel", "conv3x3w_kernel"]),
     "wgrad:conv3x3_160x160_s1": (1024, 160, 32, 160, "wgrad", ["wgrad3x3w_kernel", "slab_reduce_kernel"]),
 }
@@ -153,6 +155,8 @@ def main():
         es = 2
         if kind == "wgrad":
             alg = es * B * H * H * (Cin + N) + 4 * 9 * Cin * N
+        elif kind in ("bwd2", "bwd3"):     # the fused backward: two-tensor form 4 passes, residual form 6, + the slabs (written, read back)
+            alg = es * B * H * H * Cin * (4 if kind == "bwd2" else 6) + es * 9 * Cin * N + 4 * 9 * Cin * N
         else:       # forward: x, y, residual (+ weights); data gradient: dy, dx, the raw tensor of the activation backward
             alg = es * B * H * H * (Cin + 2 * N) + es * 9 * Cin * N
         res[tag] = {"FETCH_SIZE_KiB": fetch, "WRITE_SIZE_KiB": write,
