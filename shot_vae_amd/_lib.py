@@ -175,7 +175,7 @@ _PROTOS = {
 OPT_DISABLE_MASK, OPT_WIDE_MIN_BLOCKS, OPT_HALO_ALL, OPT_PERSISTENT_BLOCKS, OPT_DETERMINISTIC, OPT_ENABLE_MASK = 0, 1, 2, 3, 4, 5
 (K_CONV3X3, K_CONV3X3P, K_CONV3X3M, K_CONV3X3W, K_CONV3X3X, K_WGRAD3X3, K_WGRAD3X3W, K_IGEMM_KV2, K_HALO, K_HALOP, K_HWGRAD, K_IGEMM_BIG,
  K_WGRAD_WIDE, K_IGEMM_ALIGNED, K_IGEMM_DMA, K_WGRAD_INCR, K_WGRAD3X3M, K_TCONVR, K_TCONVR_EX, K_SCONV) = (1 << i for i in range(20))
-# (bits 20-22 and 25 belonged to round 5's experiments -- cconv / swgrad / the thconv forward forms: tools/experiments/)
+# (bits 20-22 and 25 belonged to experiments -- cconv / swgrad / the thconv forward forms / fwd3x3f: tools/experiments/)
 K_PCONV, K_THCONV, K_THWGRAD, K_S2WGRAD = 1 << 23, 1 << 24, 1 << 26, 1 << 27
 EXPORTS = sorted(list(_PROTOS) + ["sv_last_error"])
 

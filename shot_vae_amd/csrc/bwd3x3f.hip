@@ -147,9 +147,7 @@ __global__ __launch_bounds__(512) void bwd3x3f_kernel(const sv_geom g, const bwd
     // interleaved tile order: at its step k the block takes tile k * NC + xsub; an XCD (blocks L, L + 8, ...) owns NC / 8
     // consecutive tiles of every window
     const int NC = gridDim.x;
-    int xsub = blockIdx.x;
-    if (NC % 8 == 0) xsub = (blockIdx.x & 7) * (NC / 8) + (blockIdx.x >> 3);
-    const int tstep = NC, t_begin = xsub;
+    const int tstep = NC, t_begin = sv_window_slot(NC, blockIdx.y, blockIdx.x);
     // the taps of a stride-1 3x3 data gradient are FIXED (geometry.convT_like: tap t = 3 ky + kx reads dy at (1 - ky, 1 - kx) and
     // is master tap t; sv_bwd3x3 checks it): as compile-time constants every LDS fragment address is base + immediate -- read from
     // the geometry, the 36 + 18 tap-shifted addresses of the unrolled loops were hoisted and spilled
@@ -567,7 +565,6 @@ extern "C" int sv_bwd3x3(const sv_geom* g, int dtype, const sv_bwd3x3_args* a, v
     int budget = a->block_budget > 0 ? a->block_budget : 256;
     int grid = budget / groups;
     if (grid > nT) grid = nT;
-    if (grid >= 8) grid = grid / 8 * 8;
     if (grid < 1) grid = 1;
     const int64_t slab = 9 * CH * CH;
     SV_REQUIRE(a->ws_elems >= (int64_t)grid * groups * slab, SV_E_ARG, "sv_bwd3x3: workspace of %lld floats, %lld needed",

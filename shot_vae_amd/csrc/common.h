@@ -208,6 +208,22 @@ __device__ __forceinline__ void sv_bn_fold_block512(const sv_igemm_args& a, int 
     __syncthreads();
 }
 
+// Interleaved tile order of the one-block-per-CU kernels (bwd3x3f.hip, fwd3x3f.hip) for ANY grid size: at its step k a block takes tile
+// k * NC + slot of its group, and the blocks that share an XCD (the hardware deals blocks to the eight XCDs round-robin in linear
+// block-id order, x fastest) own CONSECUTIVE slots, so that vertically adjacent tiles -- which share halo rows -- meet in one L2.
+// (With NC a multiple of 8 this is conv3x3p_kernel's mapping; a batched launch of four groups on 248 blocks has NC = 62.)
+__device__ __forceinline__ int sv_window_slot(int NC, int group, int bx) {
+    const int l0 = group * NC;                                   // linear id of the group's first block
+    const int xcd = (l0 + bx) & 7;
+    int prefix = 0;
+    for (int y = 0; y < 8; ++y) {
+        const int first = (y - l0) & 7;                          // first bx of the group on XCD y
+        const int cnt = first < NC ? (NC - first + 7) >> 3 : 0;
+        if (y < xcd) prefix += cnt;
+    }
+    return prefix + ((bx - ((xcd - l0) & 7)) >> 3);
+}
+
 // host side ------------------------------------------------------------------------------------------
 void sv_set_error(const char* fmt, ...);
 bool sv_disabled(int kernel_bit);        // sv_set_option(SV_OPT_DISABLE_MASK, ...): a specialised kernel is switched off
