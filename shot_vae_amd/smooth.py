@@ -104,6 +104,10 @@ class _WeightPlan:
         self.key = self.gkey = None
         self.model = model
         self.flushed, self.cb_task = True, None
+        self.wver = None                 # version stamp of the parameter VALUES the packs hold (sum of the tensors' version counters)
+        self.ran = set()                 # layers whose backward ran in the current pass
+        self._gbuf = {}                  # persistent .grad buffers (id(param) -> tensor): re-attached, zeroed, never re-allocated
+        self._fresh = []                 # parameters whose .grad this pass had to create (None before it)
 
     # ---- job tables ---------------------------------------------------------------------------------------------------------
     @staticmethod
@@ -191,6 +195,7 @@ class _WeightPlan:
         if k != self.key:
             self._build(model, False)
             self.key = k
+        self.wver = sum(p._version for p in model.parameters())
         raw, n, nb = self.wjobs
         L.call("sv_param_gather", self.code, _vp(raw), n, nb, _vp(self.pack), _st())
         raw, n, nb = self.bjobs
@@ -201,20 +206,41 @@ class _WeightPlan:
             self.cb_task = None            # (a backward pass that died before its callback ran must not mute the next one)
 
     def _grad_table(self, model):
+        """Every parameter gets a .grad the scatter can add into.  The buffers are PERSISTENT: torch's default
+        `zero_grad(set_to_none=True)` drops .grad every iteration -- a fresh tensor each time moved every pointer of the scatter table,
+        i.e. a table rebuild and a synchronous host-to-device upload per iteration; the same tensors are zeroed (one
+        foreach launch) and re-attached instead.  Parameters that had no .grad before this pass are remembered: flush() hands
+        .grad = None back to those whose layer took no part in it (torch leaves them None, and Adam skips them)."""
+        self._fresh, zero = [], []
         for p in model.parameters():
             if p.grad is None or not p.grad.is_contiguous() or p.grad.dtype != torch.float32:
-                p.grad = torch.zeros_like(p, memory_format=torch.contiguous_format)          # (the scatter adds into it)
+                buf = self._gbuf.get(id(p))
+                if buf is None or buf.shape != p.shape or buf.device != p.device:
+                    buf = self._gbuf[id(p)] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                else:
+                    zero.append(buf)
+                p.grad = buf
+                self._fresh.append(p)
+        if zero:
+            torch._foreach_zero_(zero)
         k = tuple(p.grad.data_ptr() for p in model.parameters()) + (L.det_stats(),)
         if k != self.gkey:
             self._build(model, True)
             self.gkey = k
 
-    def before_layer_backward(self, model):
+    def before_layer_backward(self, model, name=None, wver=None):
         """called by every layer's backward: a SECOND backward pass without a forward in between starts from a cleared scratch;
         the first layer of a pass queues the flush for the end of that pass"""
+        if wver is not None and wver != self.wver:
+            # (torch raises its in-place version error here: the graph was built on other parameter values than the packs hold now)
+            raise RuntimeError("shot_vae_amd.smooth: the parameters were modified (optimizer step / in-place update) after the forward "
+                               "pass this backward belongs to -- its data gradients would use the NEW weights.  Run the forward again.")
         if self.flushed:
             self.gscr.zero_()
             self.flushed = False
+            self.ran = set()
+        if name is not None:
+            self.ran.add(name)
         # one flush per BACKWARD PASS, keyed by the autograd engine's graph task -- not by a sticky flag: the engine drops its queued
         # callbacks when a node of the pass raises (OOM retry, KeyboardInterrupt, ShotVaeHipError), a flag set there would never be
         # cleared and every later pass would leave .grad untouched without an error (ADVICE r05)
@@ -222,6 +248,7 @@ class _WeightPlan:
         if task != self.cb_task or task < 0:
             if self.cb_task is not None and not self.flushed:
                 self.gscr.zero_()          # the pass that queued last never flushed: its partial gradients are not this pass's
+                self.ran = {name} if name is not None else set()
             self.cb_task = task
             torch.autograd.Variable._execution_engine.queue_callback(self.flush)
 
@@ -234,6 +261,19 @@ class _WeightPlan:
         raw, n, nb = self.gjobs
         L.call("sv_param_scatter_add", _vp(raw), n, nb, _vp(self.gscr), _st())
         self.flushed = True
+        if self._fresh and len(self.ran) < len(self.layers):
+            # layers this pass never reached (e.g. the decoder under a loss on encode() alone): their scratch is zero, the scatter
+            # added nothing -- parameters that had no .grad before the pass get None back, as torch leaves them
+            idle = set()
+            srcs = self.model._sources()
+            for lname in self.layers:
+                if lname not in self.ran:
+                    for (w, b, *_rest) in srcs[lname]:
+                        idle.update((id(w), id(b)))
+            for p in self._fresh:
+                if id(p) in idle:
+                    p.grad = None
+        self._fresh = []
 
 
 class _Layer:
@@ -293,6 +333,7 @@ class _ConvLikeFn(torch.autograd.Function):
         L.call("sv_igemm", C.byref(gf), code, C.byref(a), _st())
         ctx.save_for_backward(x)
         ctx.cfg = (model, name, relu_in)
+        ctx.wver = plan.wver
         return out
 
     @staticmethod
@@ -301,7 +342,7 @@ class _ConvLikeFn(torch.autograd.Function):
         model, name, relu_in = ctx.cfg
         plan, layer = model._plan_for(x.device), model._L[name]
         code = plan.code
-        plan.before_layer_backward(model)
+        plan.before_layer_backward(model, name, ctx.wver)
         B, dev = x.shape[0], x.device
         dy = dy.contiguous()
         gf, gd = layer.geom_fwd(B), layer.geom_dgrad(B)

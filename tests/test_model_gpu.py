@@ -273,6 +273,69 @@ def test_smooth_backward_that_raises_does_not_mute_the_next_one():
             assert float((g - r).abs().max()) <= 1e-5 * float(r.abs().max()) + 1e-7, same_graph
 
 
+def test_smooth_weight_plan_gradient_table_behaviour():
+    """ADVICE r05 (smooth.py:202): (a) a backward whose forward ran on OTHER parameter values than the packs hold now raises (torch's
+    own in-place version check has no view of the packs); (b) layers that took no part in a pass keep .grad = None, as torch leaves
+    them; (c) with zero_grad(set_to_none=True) every iteration the plan re-attaches the SAME gradient tensors: its scatter table
+    is built once, not once per iteration."""
+    from oracle import smooth_oracle as SO
+    unl, lab, label, nz = SO.make_inputs("svhn", 16, 8)
+    unl = unl.cuda()
+    model = S.SmoothVAE((3, 32, 32), {"cont": 32, "disc": [10]}, compute_dtype="fp32").cuda().train()
+    model.load_state_dict(SO.make_state("svhn"))
+    lf = S.SmoothELBOLoss()
+    lf.num_steps = 1
+    plan = model._plan_for(unl.device)
+
+    # (b) a loss on the encoder alone
+    mean, logvar, alpha = model.encode(unl)
+    (mean.square().sum() + logvar.sum() + alpha[:, 0].sum()).backward()
+    enc = {id(q) for m in (model.img_to_features, model.features_to_hidden, model.fc_mean, model.fc_log_var, *model.fc_alphas)
+           for q in m.parameters()}
+    for k, q in model.named_parameters():
+        if id(q) in enc:
+            assert q.grad is not None and float(q.grad.abs().sum()) > 0, k
+        else:
+            assert q.grad is None, k
+
+    # (c) full iterations, gradients dropped in between
+    builds = []
+    real_build = plan._build
+    plan._build = lambda m, grads: (builds.append(grads), real_build(m, grads))[1]
+    ptrs, first = None, None
+    for it in range(3):
+        for q in model.parameters():
+            q.grad = None
+        with T.scripted_rng(randn=[nz["eps_u"]], rand=[nz["u_u"]]):
+            rec, dist, _, _ = model(unl)
+        lf(unl, rec, dist)[0].backward()
+        torch.cuda.synchronize()
+        now = [q.grad.data_ptr() for q in model.parameters()]
+        g = [q.grad.clone() for q in model.parameters()]
+        if it == 0:
+            ptrs, first = now, g
+        else:
+            assert now == ptrs
+            assert all(torch.equal(a, b) for a, b in zip(g, first))          # (re-zeroed, not accumulated)
+    assert builds.count(True) <= 1, builds
+
+    # (a) parameters stepped between forward and backward
+    with T.scripted_rng(randn=[nz["eps_u"]], rand=[nz["u_u"]]):
+        rec, dist, _, _ = model(unl)
+    loss = lf(unl, rec, dist)[0]
+    with torch.no_grad():
+        next(model.parameters()).mul_(1.0)
+    with pytest.raises(RuntimeError, match="modified"):
+        loss.backward()
+    for q in model.parameters():
+        q.grad = None
+    with T.scripted_rng(randn=[nz["eps_u"]], rand=[nz["u_u"]]):
+        rec, dist, _, _ = model(unl)
+    lf(unl, rec, dist)[0].backward()                                          # (and the next iteration is whole)
+    torch.cuda.synchronize()
+    assert all(torch.equal(q.grad, b) for q, b in zip(model.parameters(), first))
+
+
 def test_smooth_elbo_graphed_iteration_equals_eager():
     """GraphedSmoothStep (hipGraph replay of the smooth-ELBO iteration, capturable Adam, device step counter) against
     the eager smooth_train_step with the device noise frozen."""
