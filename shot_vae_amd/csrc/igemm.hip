@@ -660,7 +660,10 @@ extern "C" int sv_igemm(const sv_geom* g, int dtype, const sv_igemm_args* a_in, 
         if (dma && g->N % 128 == 0 && mt256 * (g->N / 128) >= (sv_wide_min_blocks() + 1) / 2) return launch_dma<8, 4>(g, a, s);
         if (g->N % 160 == 0 && mt256 * (g->N / 160) >= sv_wide_min_blocks()) return launch_kv<bf16, 10, 1, 4>(g, a, s);
         // (128-channel tiles from half a block per slot: the 4x4 stride-2 data gradient of ConvT 512 -> 256, 128 tiles, 163 -> 142 us)
-        if (g->N % 128 == 0 && mt256 * (g->N / 128) >= (sv_wide_min_blocks() + 1) / 2) return launch_kv<bf16, 8, 1, 4>(g, a, s);
+        // (single-phase launches WITH a load prologue want a whole block per slot: svhn_VAE's third convolution -- 4x4 stride 2, 64 -> 128
+        //  at 2 048 images, 128 tiles -- 56 -> 36 us and its Linear 512 -> 2048 34 -> 24 us on the 128-row tiles below)
+        if (g->N % 128 == 0 && mt256 * (g->N / 128) >= (g->nphase == 1 ? sv_wide_min_blocks() : (sv_wide_min_blocks() + 1) / 2))
+            return launch_kv<bf16, 8, 1, 4>(g, a, s);
     }
     const int64_t mtiles = (M + 127) / 128 * g->nphase;
     // widest channel tile that still yields >= 2 blocks per CU; never below 32 channels unless N is

@@ -1101,15 +1101,16 @@ def test_register_resident_last_decoder_layer(B, pro, Gn, fold):
     assert rel(out, ref_out) < 6e-3
 
 
+@pytest.mark.parametrize("Cin", [64, 32])
 @pytest.mark.parametrize("B,Gn,budget", [(1, 1, 0), (3, 1, 0), (70, 2, 0), (300, 1, 0), (64, 2, 16)])
-def test_register_resident_last_decoder_layer_dgrad(B, Gn, budget):
+def test_register_resident_last_decoder_layer_dgrad(B, Gn, budget, Cin):
     """dconv.hip: the data gradient of ConvTranspose2d(64, 16 (3 padded), 4, 2, 1) -- a 4x4 stride-2 convolution 16 -> 64 at 32x32
     (decoder.py:58) -- with the activation-backward epilogue of the BatchNorm + ReLU in front of that layer, against torch fp32 on the
     same bf16 operands (both bands of an image: top / bottom padding rows, the row shared by the bands) and against the LDS-halo
-    kernel it replaces."""
+    kernel it replaces.  Cin = 32: the same for svhn_VAE's last layer, ConvTranspose2d(32, 3, 4, 2, 1) (svhn_vae.py:131; one band)."""
     torch.manual_seed(B)
     d = dev()
-    Cin, N, H = 64, 16, 16                       # the ConvTranspose's channels: its data gradient maps N -> Cin
+    N, H = 16, 16                                # the ConvTranspose's channels: its data gradient maps N -> Cin
     w = bq(torch.randn(Cin, N, 4, 4) / (Cin * 4) ** 0.5, "bf16")
     dy = bq(torch.randn(Gn * B, N, 2 * H, 2 * H), "bf16")
     xraw = bq(torch.randn(Gn * B, Cin, H, H), "bf16")
@@ -1145,6 +1146,40 @@ def test_register_resident_last_decoder_layer_dgrad(B, Gn, budget):
         assert rel(sums[gi, :Cin], gref.sum((0, 2, 3))) < 3e-3
         assert rel(sums[gi, Cin:], (gref * xh).sum((0, 2, 3))) < 3e-3
     assert rel(out, ref_out) < 6e-3 and rel(sums, ref_sums) < 2e-3
+
+
+@pytest.mark.parametrize("B,Gn,budget", [(1, 1, 0), (5, 1, 0), (70, 2, 0), (300, 1, 0), (64, 2, 16)])
+def test_register_resident_first_svhn_convolution(B, Gn, budget):
+    """dconv.hip's bias form: svhn_VAE's first layer, Conv2d(3 (16 padded), 32, 4, 2, 1) with its bias (svhn_vae.py:62), against
+    torch fp32 on the same bf16 operands and against the LDS-halo kernel it replaces."""
+    torch.manual_seed(B)
+    d = dev()
+    Cin, N, H = 16, 32, 32
+    w = bq(torch.randn(N, Cin, 4, 4) / (3 * 16) ** 0.5, "bf16")
+    w[:, 3:] = 0
+    x = bq(torch.randn(Gn * B, Cin, H, H), "bf16")
+    x[:, 3:] = 0
+    bias = torch.randn(N) * 0.2                  # (shared by the groups of a batched launch)
+    g = G.conv_like(B, H, H, Cin, N, 4, 2, 1)
+    wp = repack(w.permute(0, 2, 3, 1).reshape(N, 16, Cin).contiguous(), g, False, "bf16")
+    xd, bd = nhwc(x).to(d, torch.bfloat16).contiguous(), bias.to(d).contiguous()
+
+    def run(disable):
+        out = torch.full((Gn * B, H // 2, H // 2, N), 7.0, dtype=torch.bfloat16, device=d)
+        a = L.SvIgemmArgs()
+        a.x, a.w, a.out, a.replicas, a.groups, a.block_budget = xd.data_ptr(), wp.data_ptr(), out.data_ptr(), 1, Gn, budget
+        a.bias = bd.data_ptr()
+        with L.options(disable=disable):
+            L.call("sv_igemm", C.byref(g), L.SV_BF16, C.byref(a), st())
+        torch.cuda.synchronize()
+        return out.float().cpu()
+
+    out, ref_out = run(0), run(L.K_TCONVR_EX)
+    for gi in range(Gn):
+        sl = slice(gi * B, (gi + 1) * B)
+        y = F.conv2d(x[sl], w, bias, 2, 1)
+        assert rel(nchw(out[sl]), y) < 4e-3
+    assert rel(out, ref_out) < 6e-3
 
 
 @pytest.mark.parametrize("B,groups,R", [(5, 1, 8), (40, 4, 32), (3, 2, 256)])

@@ -1,10 +1,5 @@
+python -m pytest tests/test_kernels_gpu.py -x -q -m gpu -k "register_resident_last_decoder or first_svhn" 2>&1 | tail -5
 python -m pytest tests/test_model_gpu.py -x -q -m gpu -k "smooth" 2>&1 | tail -3
-cd /tmp && export TMPDIR=/tmp
-R=/root/repo
-for k in fwd dgrad wgrad; do
-  for s in "2048 64 16 64" "2048 128 8 128"; do
-    python3 $R/tools/layer_bench.py $s $k 2>/dev/null | grep "of bf16"
-    python3 $R/tools/pmc_sq.py $s $k 2>&1 | grep -v "^  SQ_[A-Z_]* *[0-9]*$"
-  done
-done > $R/gpurun_out/pmc_body_r06.txt 2>&1
-cat $R/gpurun_out/pmc_body_r06.txt
+python tools/probes/svhn_layers.py 1024 10 2>&1 | grep "sv_igemm\|^sum\|^wall"
+python bench.py --workload svhn --batch 1024 --steps 30 --warmup 5 2>/dev/null | tail -1 | cut -c1-300
+python bench.py --steps 20 --warmup 5 --no-extras --no-cpu-baseline --no-roofline 2>/dev/null | tail -1 | cut -c1-200

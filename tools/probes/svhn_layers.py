@@ -1,6 +1,7 @@
 """Per-call time table of one config-5 iteration (svhn_VAE smooth-ELBO, B per loader): every library call of the eager
 iteration bracketed by events on the current stream (torch's own glue kernels fall between the brackets and are not listed).
-    python tools/probes/svhn_layers.py [B=1024] [iters=10]"""
+    python tools/probes/svhn_layers.py [B=1024] [iters=10] [sweep]
+sweep: the same table under several dispatcher option sets side by side (which general kernel serves a layer best)."""
 import collections
 import os
 import sys
@@ -48,26 +49,38 @@ def call(name, *args):
 
 L.call = call
 SM.L.call = call
-for it in range(3):
-    SM.smooth_train_step(model, loss_fn, opt, u, l, y)
-torch.cuda.synchronize()
-recording[0] = True
-w0 = torch.cuda.Event(enable_timing=True)
-w1 = torch.cuda.Event(enable_timing=True)
-w0.record()
-for it in range(iters):
-    SM.smooth_train_step(model, loss_fn, opt, u, l, y)
-w1.record()
-torch.cuda.synchronize()
-n = len(log) // iters
-tab = collections.OrderedDict()
-for i, (d, e0, e1) in enumerate(log):
-    k = (i % n, d)
-    tab.setdefault(k, []).append(e0.elapsed_time(e1) * 1e3)
-tot = 0.0
-for (i, d), v in tab.items():
-    v.sort()
-    med = v[len(v) // 2]
-    tot += med
-    print("%3d %8.1f us  %s" % (i, med, d))
-print("sum of library calls %.3f ms; wall %.3f ms per iteration (eager, event-bracketed: slower than the timed step)" % (tot / 1e3, w0.elapsed_time(w1) / iters))
+
+
+def table(opts):
+    del log[:]
+    recording[0] = False
+    with L.options(**opts):
+        for it in range(3):
+            SM.smooth_train_step(model, loss_fn, opt, u, l, y)
+        torch.cuda.synchronize()
+        recording[0] = True
+        w0, w1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        w0.record()
+        for it in range(iters):
+            SM.smooth_train_step(model, loss_fn, opt, u, l, y)
+        w1.record()
+        torch.cuda.synchronize()
+    recording[0] = False
+    n = len(log) // iters
+    tab = collections.OrderedDict()
+    for i, (d, e0, e1) in enumerate(log):
+        tab.setdefault((i % n, d), []).append(e0.elapsed_time(e1) * 1e3)
+    return [(k, sorted(v)[len(v) // 2]) for k, v in tab.items()], w0.elapsed_time(w1) / iters
+
+
+SETS = [("default", {})]
+if len(sys.argv) > 3:
+    SETS += [("no BIG", dict(disable=L.K_IGEMM_BIG)), ("no DMA", dict(disable=L.K_IGEMM_DMA)), ("no HALO/P", dict(disable=L.K_HALO | L.K_HALOP)),
+             ("HALO_ALL", dict(halo_all=1)), ("no ALIGNED", dict(disable=L.K_IGEMM_ALIGNED)), ("no KV2", dict(disable=L.K_IGEMM_KV2)),
+             ("no WG_WIDE", dict(disable=L.K_WGRAD_WIDE)), ("no WG_INCR", dict(disable=L.K_WGRAD_INCR)), ("no HWGRAD", dict(disable=L.K_HWGRAD))]
+cols = [table(o) for _, o in SETS]
+print(" " * 4 + "".join("%11s" % nm for nm, _ in SETS))
+for r, ((i, d), _) in enumerate(cols[0][0]):
+    print("%3d " % i + "".join("%11.1f" % c[0][r][1] for c in cols) + "  " + d)
+print("sum " + "".join("%11.1f" % sum(v for _, v in c[0]) for c in cols) + "  us of library calls (event-bracketed)")
+print("wall" + "".join("%11.3f" % c[1] for c in cols) + "  ms per iteration (eager, bracketed: slower than the timed step)")
