@@ -283,6 +283,9 @@ int sv_dconv_try(const sv_geom* g, int dtype, const sv_igemm_args* a, hipStream_
 int sv_thconv_try(const sv_geom* g, int dtype, const sv_igemm_args* a, hipStream_t s, int* rc);
 int sv_thwgrad_try(const sv_geom* g, int dtype, const void* x, const float* pro_scale, const float* pro_shift, float pro_slope,
                    const void* dy, float* dw, int groups, hipStream_t s, int* rc);
+// k4wgrad.hip: the thin 4x4 stride-2 layers of svhn_VAE (16 channels at 32x32 <-> 32 channels at 16x16)
+int sv_k4wgrad_try(const sv_geom* g, int dtype, const void* x, const float* pro_scale, const float* pro_shift, float pro_slope,
+                   const void* dy, float* dw, float* ws, int64_t ws_elems, int groups, hipStream_t s, int* rc);
 int sv_s2wgrad_try(const sv_geom* g, int dtype, const void* x, const float* pro_scale, const float* pro_shift, float pro_slope,
                    const void* dy, float* dw, int groups, hipStream_t s, int* rc);
 int sv_conv3x3w_try(const sv_geom* g, int dtype, const sv_igemm_args* a, hipStream_t s, int* rc);

@@ -627,6 +627,9 @@ extern "C" int sv_wgrad(const sv_geom* g, int dtype, const void* x, const float*
         // the thin 3x3 layers at 32x32 (16 input channels): the whole gradient in every block (thwgrad.hip)
         if (use_tr && sv_thwgrad_try(g, dtype, x, pro_scale, pro_shift, pro_slope, dy, dw, sv_ngroups(groups), (hipStream_t)stream, &rc))
             return rc;
+        // svhn_VAE's thin 4x4 stride-2 layers (first convolution, last transposed convolution): the whole gradient in every block (k4wgrad.hip)
+        if (use_tr && sv_k4wgrad_try(g, dtype, x, pro_scale, pro_shift, pro_slope, dy, dw, ws, ws_elems, sv_ngroups(groups), (hipStream_t)stream, &rc))
+            return rc;
         // the stride-2 3x3 layer 32 -> 64: the whole gradient in every block, bands staged once (s2wgrad.hip)
         if (use_tr && sv_s2wgrad_try(g, dtype, x, pro_scale, pro_shift, pro_slope, dy, dw, sv_ngroups(groups), (hipStream_t)stream, &rc))
             return rc;

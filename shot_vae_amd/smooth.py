@@ -104,6 +104,7 @@ class _WeightPlan:
         self.key = self.gkey = None
         self.model = model
         self.flushed, self.cb_task = True, None
+        self.wg_ws = torch.empty(512 * 8192, dtype=torch.float32, device=dev)     # sv_wgrad's workspace (16 MB: the launches of a pass run one after the other)
         self.wver = None                 # version stamp of the parameter VALUES the packs hold (sum of the tensors' version counters)
         self.ran = set()                 # layers whose backward ran in the current pass
         self._gbuf = {}                  # persistent .grad buffers (id(param) -> tensor): re-attached, zeroed, never re-allocated
@@ -362,8 +363,10 @@ class _ConvLikeFn(torch.autograd.Function):
                     ctx.bs_keep = torch.zeros(2 * a.replicas * 2 * layer.Cin, dtype=torch.float32, device=dev)
                     a.bsums = ctx.bs_keep.data_ptr()
             L.call("sv_igemm", C.byref(gd), code, C.byref(a), _st())
+        # (the workspace: per-block slabs of the thin layers' gradients, k4wgrad.hip -- 256 blocks adding 8 192 floats each to the same
+        #  addresses cost more than the whole product)
         L.call("sv_wgrad", C.byref(gf), code, _vp(x), _vp(one) if relu_in else None, _vp(zero) if relu_in else None, 0.0, _vp(dy),
-               C.c_void_p(gbase + 4 * plan.dw_off[name]), 0, 1, None, 0, 1, _st())
+               C.c_void_p(gbase + 4 * plan.dw_off[name]), 0, 1, _vp(plan.wg_ws), plan.wg_ws.numel(), 1, _st())
         if name not in BIAS_FROM_NEXT or L.det_stats():      # (see _WeightPlan: most bias gradients are a by-product of the next layer's data gradient)
             L.call("sv_colsum", code, _vp(dy), dy.numel() // layer.N, layer.N, layer.N, C.c_void_p(gbase + 4 * plan.db_off[name]), _st())
         return dx, None, None, None, None

@@ -477,6 +477,61 @@ def test_thin_layers_wgrad(B, Gn, budget, N, pro):
     assert rel(got, ref) < 2e-3, rel(got, ref)
 
 
+@pytest.mark.parametrize("kind,pro", [("conv", False), ("conv", True), ("convT", True), ("convT", False)])
+@pytest.mark.parametrize("B,Gn,budget", [(1, 1, 0), (3, 1, 0), (70, 1, 0), (33, 4, 0), (96, 2, 16), (600, 1, 0)])
+def test_thin_4x4_stride2_wgrad(B, Gn, budget, kind, pro):
+    """k4wgrad.hip (weight gradients of svhn_VAE's thin 4x4 stride-2 layers: Conv2d(3 (16 padded), 32, 4, 2, 1) at 32x32, svhn_vae.py:62,
+    and ConvTranspose2d(32, 3 (16 padded), 4, 2, 1) at 16x16, svhn_vae.py:131; the whole gradient in every block, every image staged
+    once) against torch fp32 on the same bf16 operands -- the load prologue on the layer's input, batched groups with their own
+    coefficients, a small block budget, more images than blocks, accumulation into a non-zero gradient -- and against the generic
+    gather kernel it replaces."""
+    torch.manual_seed(B + len(kind))
+    d = dev()
+    if kind == "conv":
+        Cin, N, H = 16, 32, 32
+        g = G.conv_like(B, H, H, Cin, N, 4, 2, 1)
+        Ho = H // 2
+    else:
+        Cin, N, H = 32, 16, 16
+        g = G.convT_like(B, H, H, Cin, N, 4, 2, 1)
+        Ho = 2 * H
+    x = bq(torch.randn(Gn * B, Cin, H, H), "bf16")
+    dy = bq(torch.randn(Gn * B, N, Ho, Ho), "bf16")
+    scale, shift = torch.rand(Gn, Cin) + 0.5, torch.randn(Gn, Cin) * 0.3
+    wref = torch.zeros(N, 16, Cin)                       # master layout [n][ky * 4 + kx][c]
+    for gi in range(Gn):
+        xs = x[gi * B:(gi + 1) * B]
+        a = bq(F.leaky_relu(xs * scale[gi][None, :, None, None] + shift[gi][None, :, None, None], 0.01), "bf16") if pro else xs
+        if kind == "conv":
+            wref += torch.nn.grad.conv2d_weight(a, (N, Cin, 4, 4), dy[gi * B:(gi + 1) * B], 2, 1).permute(0, 2, 3, 1).reshape(N, 16, Cin)
+        else:
+            w0 = torch.zeros(Cin, N, 4, 4, requires_grad=True)
+            (F.conv_transpose2d(a, w0, None, 2, 1) * dy[gi * B:(gi + 1) * B]).sum().backward()
+            wref += w0.grad.permute(1, 2, 3, 0).reshape(N, 16, Cin)
+    xd, dyd = nhwc(x).to(d, torch.bfloat16).contiguous(), nhwc(dy).to(d, torch.bfloat16).contiguous()
+    sc, sh = scale.to(d).contiguous(), shift.to(d).contiguous()
+    ws = torch.full((8 * 1024 * 1024,), float("nan"), device=d)
+
+    def run(disable, with_ws=True):
+        dw = torch.full((N, 16, Cin), 0.5, device=d)
+        a = L.SvWgradArgs()
+        a.x, a.dy, a.dw = xd.data_ptr(), dyd.data_ptr(), dw.data_ptr()
+        if pro:
+            a.pro_scale, a.pro_shift, a.pro_slope = sc.data_ptr(), sh.data_ptr(), 0.01
+        a.splits, a.use_tr, a.groups, a.block_budget = 0, 1, Gn, budget
+        if with_ws:                       # (per-block slabs + sv_slab_reduce; without: the blocks add to dw themselves)
+            a.ws, a.ws_elems = ws.data_ptr(), ws.numel()
+        with L.options(disable=disable):
+            L.call("sv_wgrad_ex", C.byref(g), L.SV_BF16, C.byref(a), st())
+        torch.cuda.synchronize()
+        return dw.cpu() - 0.5
+
+    got, got_atomic, ref = run(0), run(0, False), run(L.K_THWGRAD)
+    assert rel(got, wref) < 2e-3, rel(got, wref)
+    assert rel(got_atomic, wref) < 2e-3, rel(got_atomic, wref)
+    assert rel(got, ref) < 2e-3, rel(got, ref)
+
+
 @pytest.mark.parametrize("Cin,N,H", [(32, 64, 32), (64, 128, 16)])
 @pytest.mark.parametrize("B,Gn,budget,pro", [(1, 1, 0, True), (3, 1, 0, False), (70, 1, 0, True), (33, 4, 0, True), (96, 2, 16, True), (512, 1, 256, True)])
 def test_banded_stride2_wgrad(B, Gn, budget, pro, Cin, N, H):
