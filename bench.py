@@ -76,6 +76,9 @@ def parse():
                          "sv_bn_bwd_apply), 1 = conv1 of the same-shape units with norm2's BatchNorm backward in its load path, 2 = also conv2 "
                          "of the unit in front with the unit boundary's BatchNorm backward + skip connection in its load path, 3 = every "
                          "other 32-channel conv2 too, -1 = the engine default")
+    ap.add_argument("--event-fork-after-fused", type=int, default=1,
+                    help="Engine.event_fork_after_fused: 0 = the pair behind fused-backward launches forks by flag like every other pair (the "
+                         "side stream's wait_flag_kernel then spins through the fused launches: A/B)")
     ap.add_argument("--fused-blocks", type=int, default=0, help="Engine.fused_blocks: blocks of a fused-backward launch (0 = the engine's default, 248)")
     ap.add_argument("--flag-fork", type=int, default=1, help="0: event forks for the paired weight gradients instead of the start signal")
     ap.add_argument("--fork-every", type=int, default=0, help="weight gradients per side-stream fork (0 = the engine's default)")
@@ -583,6 +586,7 @@ def main():
         model._engine.fused_bwd = a.fused_bwd
     if a.fused_blocks:
         model._engine.fused_blocks = a.fused_blocks
+    model._engine.event_fork_after_fused = bool(a.event_fork_after_fused)
     model._engine.compact_shortcut_grad = bool(a.compact_shortcut)
     if a.fork_every:
         model._engine.fork_every = a.fork_every

@@ -4,8 +4,8 @@
 // -- costs 1.2 M adds per launch.  So: a persistent block owns all of dW, stages every band of 16 rows ONCE (the input through the
 // BatchNorm + LeakyReLU prologue, with its halo; dy as it is), a wave takes two rows of the band (a row's 32 pixels = the k dimension of
 // one v_mfma_f32_16x16x32_bf16 step, both operands read k-major with ds_read_b64_tr_b16 as in wgrad.hip / swgrad.hip), accumulates
-// [N][9 taps][16] in 36 / 72 registers over the block's bands, and at the end the eight waves meet in an LDS copy of dW (LDS float
-// atomics) that the block adds to the fp32 gradient.  The layers move 134 / 201 MB against 1-2 GFLOP: HBM-bound; the tap-fused
+// [N][9 taps][16] in 36 / 72 registers over the block's bands, and at the end the eight waves meet in an LDS copy of dW (one wave
+// after the other, 16-byte adds) that the block adds to the fp32 gradient.  The layers move 134 / 201 MB against 1-2 GFLOP: HBM-bound; the tap-fused
 // LDS-halo kernel (hwgrad.hip) ran them at 2.2-2.3 TB/s.
 // Same sv_wgrad contract: a fast path inside it (SV_K_THWGRAD disables); declines the deterministic mode.
 #include "common.h"
@@ -160,21 +160,36 @@ __global__ __launch_bounds__(512, 1) void thwgrad_kernel(const sv_geom g, const 
             __syncthreads();
         }
     }
-    // ---- the eight waves meet in the LDS copy of dW, the block adds it to the gradient:
-    // acc[a][t][e] = (n = 16 a + 4 gq + e, c = li)
+    // ---- the eight waves meet in the LDS copy of dW, the block adds it to the gradient: acc[a][t][e] = (n = 16 a + 4 gq + e, c = li).
+    // One wave after the other adds its registers to the copy with 16-byte reads / writes (layout [a][gq][t][c][e]: a lane's four
+    // values are contiguous).  Round 6: the LDS float atomics this replaces (36 / 72 instructions per wave, the four gq groups of an
+    // instruction on the same banks) were a third to a half of the launch (stem 64.5 -> 40.4 us, 16 -> 32: 100 -> 50.8 us; k4wgrad.hip:
+    // ~70 of ~100 us).  (Per-block slabs + sv_slab_reduce instead of the global atomics below: -3 / -5 us alone, nothing in the step.)
     {
-        float* const red = reinterpret_cast<float*>(smem + C::OFF_RED);
+        f32x4* const red4 = reinterpret_cast<f32x4*>(smem + C::OFF_RED);
+        const float* const red = reinterpret_cast<const float*>(smem + C::OFF_RED);
+        for (int w = 0; w < 8; ++w) {
+            if (wave == w) {
 #pragma unroll
-        for (int a_ = 0; a_ < NH; ++a_)
+                for (int a_ = 0; a_ < NH; ++a_)
 #pragma unroll
-            for (int t = 0; t < 9; ++t)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) atomicAdd(red + ((16 * a_ + 4 * gq + e) * 9 + t) * CIN + li, acc[a_][t][e]);
-        __syncthreads();
+                    for (int t = 0; t < 9; ++t) {
+                        f32x4* const q = red4 + ((a_ * 4 + gq) * 9 + t) * CIN + li;
+                        f32x4 v = acc[a_][t];
+                        if (w > 0) {
+                            const f32x4 o = *q;
+                            v[0] += o[0]; v[1] += o[1]; v[2] += o[2]; v[3] += o[3];
+                        }
+                        *q = v;
+                    }
+            }
+            __syncthreads();
+        }
         const int T = g.T_orig;
         for (int i = tid; i < NOUT * 9 * CIN; i += NTH) {
             const int c = i % CIN, t = (i / CIN) % 9, n = i / (9 * CIN);
-            atomicAdd(p.dw + ((size_t)(n0 + n) * T + P.torig[t]) * CIN + c, red[i]);
+            const float v = red[((((n >> 4) * 4 + ((n >> 2) & 3)) * 9 + t) * CIN + c) * 4 + (n & 3)];
+            atomicAdd(p.dw + ((size_t)(n0 + n) * T + P.torig[t]) * CIN + c, v);
         }
     }
 }

@@ -512,6 +512,8 @@ class Engine:
     # trace, round 6).  248 = 31 per XCD leaves every XCD one CU for the neighbours.
     fused_blocks = 248
     flag_fork = True                 # paired launches: the data gradient's start signal forks the side stream (no event)
+    _fused_since_fork = False        # an sv_bwd3x3 launch has been issued since the last fork of the side stream
+    event_fork_after_fused = True    # (A/B switch: bench.py --event-fork-after-fused 0)
     _start_signal = None
     _pending_wgrads = ()
     fold_bn = True                   # BatchNorm finalisation folded into the consuming sv_igemm launch (sv_igemm_args::fold_*)
@@ -547,7 +549,12 @@ class Engine:
         self._pending_wgrads.append((g, x, pro, dy, dw_ptr, tag, groups, budget))
         if len(self._pending_wgrads) < self.fork_every:
             return then() if then is not None else None
-        if self.flag_fork and not _dispatch_serialised() and then is not None and len(self._pending_wgrads) == 1:
+        # (the first pair behind fused-backward launches forks by event: the host runs ahead, the side stream's wait_flag_kernel for
+        #  this pair would start as soon as the side stream is idle and spin on a CU THROUGH the fused launches in between -- 825 us in
+        #  the trace -- and a fused launch whose waves fill the SIMDs' register files cannot share a CU with it: the workgroups the
+        #  dispatcher had dealt to that CU's shader engine waited for a second round, 137 -> 236 us per launch of the residual form)
+        after_fused, self._fused_since_fork = self._fused_since_fork and self.event_fork_after_fused, False
+        if self.flag_fork and not after_fused and not _dispatch_serialised() and then is not None and len(self._pending_wgrads) == 1:
             # device-side fork: the paired main-stream launch (`then`, an sv_igemm) announces its own START through a flag word
             # (sv_igemm_args::start_flag) -- everything this weight gradient depends on has completed by then -- and the side
             # stream waits for the flag: no event, no marker in the main stream's queue
@@ -658,6 +665,7 @@ class Engine:
         a.bsums, a.replicas, a.groups = bsums, replicas, groups
         a.dw = self.grad.data_ptr() + 4 * cv.master_off
         a.ws, a.ws_elems, a.block_budget = self._wg_ws().data_ptr(), self._ws_elems, budget or self.fused_blocks
+        self._fused_since_fork = True
         L.call("sv_bwd3x3", C.byref(g), self.code, C.byref(a), self._stream())
 
     # ------------------------------------------------------------------------------- forward
