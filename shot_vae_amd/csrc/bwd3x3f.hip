@@ -39,6 +39,7 @@
 #include "epilogue.h"
 
 void sv_slab_reduce(const float* ws, int nslabs, int64_t n, float* dw, hipStream_t s);      // wgrad3x3.hip
+int sv_bwd3x3_64(const sv_geom* g, const sv_bwd3x3_args* a, hipStream_t s);                 // bwd3x3g.hip: 64 channels on 16 x 16 maps
 
 namespace {
 
@@ -552,15 +553,17 @@ extern "C" int sv_bwd3x3(const sv_geom* g, int dtype, const sv_bwd3x3_args* a, v
     // the geometry is the layer's DATA-gradient geometry (geometry.convT_like of a stride-1 3x3 convolution): one phase of nine taps
     const bool shape_ok = g->nphase == 1 && g->phase[0].ntap == 9 && g->T_orig == 9 && g->sy == 1 && g->sx == 1 && g->osy == 1 &&
                           g->osx == 1 && g->Hq == g->Hin && g->Wq == g->Win && g->Hout == g->Hin && g->Wout == g->Win &&
-                          g->Hin == g->Win && (g->Win == 8 || g->Win == 16 || g->Win == 32) && g->Cin == CH && g->N == CH &&
-                          g->ldx == CH && g->ldo == CH && g->phase[0].ooy == 0 && g->phase[0].oox == 0;
-    SV_REQUIRE(shape_ok, SV_E_SHAPE, "sv_bwd3x3: stride-1 3x3 layers with 32 input and 32 output channels on 8 / 16 / 32-pixel maps only");
+                          g->Hin == g->Win && g->Cin == g->N && g->ldx == g->Cin && g->ldo == g->N && g->phase[0].ooy == 0 &&
+                          g->phase[0].oox == 0 &&
+                          ((g->Cin == CH && (g->Win == 8 || g->Win == 16 || g->Win == 32)) || (g->Cin == 64 && g->Win == 16));
+    SV_REQUIRE(shape_ok, SV_E_SHAPE, "sv_bwd3x3: stride-1 3x3 layers with 32 -> 32 channels on 8 / 16 / 32-pixel maps or 64 -> 64 channels on 16-pixel maps only");
     for (int t = 0; t < 9; ++t)
         SV_REQUIRE(g->phase[0].dy[t] == 1 - t / 3 && g->phase[0].dx[t] == 1 - t % 3 && g->phase[0].torig[t] == t, SV_E_SHAPE,
                    "sv_bwd3x3: tap %d is not the data-gradient tap of geometry.convT_like(k = 3, stride = 1, pad = 1)", t);
-    const int TR = 128 / g->Win;
+    const int TR = g->Cin == 64 ? 4 : 128 / g->Win;
     SV_REQUIRE((g->B * g->Hin) % TR == 0, SV_E_SHAPE, "sv_bwd3x3: B * H = %d is not a multiple of the %d-row tile", g->B * g->Hin, TR);
     SV_REQUIRE(!sv_deterministic() && !sv_det_stats(), SV_E_ARG, "sv_bwd3x3: not available in deterministic mode (use the pair)");
+    if (g->Cin == 64) return sv_bwd3x3_64(g, a, (hipStream_t)stream);
     const int nT = g->B * g->Hin / TR;
     int budget = a->block_budget > 0 ? a->block_budget : 256;
     int grid = budget / groups;

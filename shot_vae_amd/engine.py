@@ -506,6 +506,7 @@ class Engine:
     # (9 passes -> 6); 3 = every other 32-channel conv2 as well (5 passes -> 3: slower than the two-stream pair, an A/B switch).
     # bf16, not in deterministic mode.
     fused_bwd = 2
+    fused_channels = (32, 64)        # body widths that take sv_bwd3x3 (64: bwd3x3g.hip, 16 x 16 maps; same-box A/B 6.19-6.23 -> 6.09-6.12 ms)
     # blocks of a fused-backward launch (one 512-thread block per CU: a block's eight waves fill the SIMDs' register files).  NOT 256:
     # a single CU that hosts anything else -- the side stream's spinning wait_flag_kernel, the tail of a slab reduction -- cannot take
     # a block, the 256th block then runs as a second round and the launch takes twice as long (152 -> 240-247 us in the step's
@@ -1128,8 +1129,9 @@ class Engine:
             same = un["stride"] == 1 and un["cin"] == c
             cnt2 = c1.numel() // c // G
             g2 = torch.empty_like(c1)
-            fb = self.fused_bwd if (self.code == L.SV_BF16 and not det and c == 32 and c1.shape[1] in (8, 16, 32)
-                                    and (B * c1.shape[1]) % (128 // c1.shape[1]) == 0) else 0
+            hmap = c1.shape[1]
+            fusable = (c == 32 and hmap in (8, 16, 32) and (B * hmap) % (128 // hmap) == 0) or (c == 64 and hmap == 16)
+            fb = self.fused_bwd if (self.code == L.SV_BF16 and not det and fusable and c in self.fused_channels) else 0
             if deferred is not None:
                 # the unit BEHIND this one left its boundary pass to this launch: D = dL/d(this unit's output) = norm1's BatchNorm
                 # backward of g1n + the skip connection's gradient, formed in conv2's load path from (g1n, the next unit's raw input

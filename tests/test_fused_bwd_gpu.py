@@ -97,7 +97,7 @@ def _fused(t, wd, gd, Gn, budget, slope, R, ws=None):
     g = torch.full_like(t["x"], 7.0)
     bs = torch.zeros(Gn, R, 2 * CH, device=d, dtype=ACC)
     dw = torch.zeros(CH, 9, CH, device=d)
-    ws = ws if ws is not None else torch.full((4 * 1024 * 1024,), float("nan"), device=d)
+    ws = ws if ws is not None else torch.full((10 * 1024 * 1024,), float("nan"), device=d)
     a = L.SvBwd3x3Args()
     a.dy, a.x, a.w, a.out = t["dy"].data_ptr(), t["x"].data_ptr(), wd.data_ptr(), g.data_ptr()
     if t["coef"] is not None:
@@ -176,8 +176,11 @@ def test_fused_backward_argument_checks():
     wd = repack(t["w"], gd, True, "bf16")
     with pytest.raises(L.ShotVaeHipError, match="workspace"):
         _fused(t, wd, gd, 1, 0, 0.01, 2, ws=torch.empty(1024, device=d))
-    g64 = G.convT_like(4, 16, 16, 64, 64, 3, 1, 1)
-    with pytest.raises(L.ShotVaeHipError, match="32 input and 32 output"):
+    g128 = G.convT_like(4, 8, 8, 128, 128, 3, 1, 1)
+    with pytest.raises(L.ShotVaeHipError, match="32 -> 32 channels"):
+        _fused(t, wd, g128, 1, 0, 0.01, 2)
+    g64 = G.convT_like(4, 32, 32, 64, 64, 3, 1, 1)          # 64 channels: 16-pixel maps only
+    with pytest.raises(L.ShotVaeHipError, match="64 -> 64 channels on 16-pixel maps"):
         _fused(t, wd, g64, 1, 0, 0.01, 2)
     gf = G.conv_like(4, 32, 32, CH, CH, 3, 1, 1)          # the FORWARD geometry: taps in the other order
     with pytest.raises(L.ShotVaeHipError, match="data-gradient tap"):
@@ -256,3 +259,32 @@ def test_two_tensor_form_against_torch_autograd(B, H, Gn):
     got_s = bs1.sum(1)
     tol = 2e-2 * float(g1_ref.abs().mean()) * (B * H * H) ** 0.5 * 4          # a sum of rounding errors, not of the values
     assert float((got_s[:, :c] - s1).abs().max()) < tol and float((got_s[:, c:] - s2).abs().max()) < 3 * tol
+
+
+# ---- 64 channels on 16 x 16 maps (bwd3x3g.hip): the same checks with the module's channel count switched ------------------------------
+CASES64 = [(16, 16, 2, 0, 0), (16, 16, 2, 0, 1), (16, 16, 2, 0, 2),
+           (1, 16, 1, 0, 1), (3, 16, 1, 0, 2),        # fewer tiles than blocks (4 / 12 tiles)
+           (40, 16, 4, 64, 1), (40, 16, 4, 64, 0), (40, 16, 4, 64, 2),
+           (70, 16, 1, 0, 1), (33, 16, 2, 24, 2),     # odd tile counts per block: the tail behind the pairs
+           (130, 16, 4, 0, 1), (130, 16, 4, 0, 2), (130, 16, 4, 0, 0)]
+
+
+@pytest.fixture
+def ch64(monkeypatch):
+    import sys
+    monkeypatch.setattr(sys.modules[__name__], "CH", 64)
+
+
+@pytest.mark.parametrize("B,H,Gn,budget,lin2", CASES64)
+def test_fused_backward_64_channels_equals_the_pair_it_replaces(ch64, B, H, Gn, budget, lin2):
+    test_fused_backward_equals_the_pair_it_replaces(B, H, Gn, budget, lin2)
+
+
+@pytest.mark.parametrize("B,H,Gn,lin2", [(6, 16, 2, 0), (6, 16, 2, 1), (6, 16, 2, 2), (20, 16, 1, 1)])
+def test_fused_backward_64_channels_against_torch_autograd(ch64, B, H, Gn, lin2):
+    test_fused_backward_against_torch_autograd(B, H, Gn, lin2)
+
+
+@pytest.mark.parametrize("B,H,Gn", [(16, 16, 2), (24, 16, 1), (8, 16, 4)])
+def test_two_tensor_form_64_channels_against_torch_autograd(ch64, B, H, Gn):
+    test_two_tensor_form_against_torch_autograd(B, H, Gn)

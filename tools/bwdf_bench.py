@@ -1,7 +1,7 @@
 """sv_bwd3x3 alone at the headline size (4 x 512 images, 32 channels, 32 x 32): time, GB/s of its algorithmic bytes (3 passes, 4 in the
 two-tensor form), beside the launches it replaces run back to back on one stream (sv_bn_bwd_apply + sv_igemm + sv_wgrad_ex).
 
-    python tools/bwdf_bench.py [B] [H] [groups] [budget]"""
+    python tools/bwdf_bench.py [B] [H] [groups] [budget] [channels]"""
 import ctypes as C
 import os
 import sys
@@ -11,7 +11,11 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from shot_vae_amd import _lib as L          # noqa: E402
 from shot_vae_amd import geometry as G      # noqa: E402
-from tests.test_fused_bwd_gpu import CH, _fused, _inputs, _pair      # noqa: E402
+import tests.test_fused_bwd_gpu as T        # noqa: E402
+from tests.test_fused_bwd_gpu import _fused, _inputs, _pair      # noqa: E402
+
+CH = int(sys.argv[5]) if len(sys.argv) > 5 else 32          # 64: bwd3x3g.hip (16 x 16 maps)
+T.CH = CH
 
 
 def timed(fn, reps=20, warm=3):
@@ -38,7 +42,7 @@ def main():
     for lin2 in (0, 1, 2):
         t = _inputs(B, H, Gn, lin2, 7)
         g_ref, bs_ref, dw_ref, _, wd, gd = _pair(t, B, H, Gn, 0, 0.01, 4)
-        ws = torch.empty(4 * 1024 * 1024, device=d)
+        ws = torch.empty(10 * 1024 * 1024, device=d)
         g, bs, dw = _fused(t, wd, gd, Gn, budget, 0.01, 4, ws=ws)
         ok = torch.equal(g, g_ref)
         err = float((dw - dw_ref).abs().max() / dw_ref.abs().max())
