@@ -36,7 +36,14 @@ constexpr size_t LDS_BYTES = (size_t)2 * STG * 2 + 2 * CH * 8 + 8 * CH * 4 + (si
 #define SV_BWDG_PD 2          // steps the data-gradient waves' fragment reads run ahead of their MFMAs
 #endif
 #ifndef SV_BWDG_WREG
-#define SV_BWDG_WREG 1        // 1: the weights of a data-gradient wave's FIRST 16-channel tile live in registers (18 fragments)
+#define SV_BWDG_WREG 0        // 16-channel tiles (of a data-gradient wave's two) whose weights live in registers (18 fragments each) in the
+                             // residual form; the other forms take SV_BWDG_WREG01
+#endif
+#ifndef SV_BWDG_WREG01
+#define SV_BWDG_WREG01 1        // (2: 177-186 spilled registers)
+#endif
+#ifndef SV_BWDG_HSTG2
+#define SV_BWDG_HSTG2 0        // (1: 135 vs 126 us -- slower)
 #endif
 #ifndef SV_BWDG_ABL
 #define SV_BWDG_ABL 0        // timing ablations as in bwd3x3f.hip: 1 no weight-gradient MFMAs, 2 no data gradient, 4 no loads, 8 no staging, 16 no epilogue
@@ -235,7 +242,8 @@ __global__ __launch_bounds__(512) void bwd3x3g_kernel(const sv_geom g, const bwd
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) s1[i][r] = s2[i][r] = 0.f;
-    V wr[SV_BWDG_WREG ? 18 : 1];                     // [tap][k-step] of channel 32 dc + fr
+    constexpr int NWR = MODE == 2 ? SV_BWDG_WREG : SV_BWDG_WREG01;
+    V wr[NWR > 0 ? NWR : 1][18];                     // [tile][tap, k-step] of channel 32 dc + 16 tile + fr
     {
         const bf16* Wp = reinterpret_cast<const bf16*>(p.w) + P.w_off;          // [c][tap][n]: the layer's data-gradient pack
         for (int idx = tid; idx < WLROWS * VPP; idx += 512)                     // (visible after the prologue's barriers)
@@ -253,14 +261,14 @@ __global__ __launch_bounds__(512) void bwd3x3g_kernel(const sv_geom g, const bwd
         // PD + 1 fragment sets: left to itself the compiler kept three fragment registers and put every read right in front of its
         // MFMA (s_waitcnt lgkmcnt(0) before each of them: the whole LDS latency per MFMA, 85 us for these waves alone)
         constexpr int PD = SV_BWDG_PD, NB = PD + 1;
-        V fa0[NB], fa1[NB], fw0[SV_BWDG_WREG ? 1 : NB], fw1[NB];
+        V fa0[NB], fa1[NB], fw0[NWR >= 1 ? 1 : NB], fw1[NWR >= 2 ? 1 : NB];
         auto rd = [&](int s_) __attribute__((always_inline)) {
             const int t = s_ >> 1, k = s_ & 1, b = s_ % NB;
             const int sh = ((1 - t / 3) * WP + (1 - t % 3)) * LDF + 32 * k;
             fa0[b] = *reinterpret_cast<const V*>(dyh + hbase[0] + sh);
             fa1[b] = *reinterpret_cast<const V*>(dyh + hbase[1] + sh);
-            if (!SV_BWDG_WREG) fw0[SV_BWDG_WREG ? 0 : b] = *reinterpret_cast<const V*>(wl + ((32 * dc + fr) * 9 + t) * LDF + 32 * k + 8 * fq);
-            fw1[b] = *reinterpret_cast<const V*>(wl + ((32 * dc + 16 + fr) * 9 + t) * LDF + 32 * k + 8 * fq);
+            if (NWR < 1) fw0[NWR >= 1 ? 0 : b] = *reinterpret_cast<const V*>(wl + ((32 * dc + fr) * 9 + t) * LDF + 32 * k + 8 * fq);
+            if (NWR < 2) fw1[NWR >= 2 ? 0 : b] = *reinterpret_cast<const V*>(wl + ((32 * dc + 16 + fr) * 9 + t) * LDF + 32 * k + 8 * fq);
         };
 #pragma unroll
         for (int s_ = 0; s_ < PD; ++s_) rd(s_);
@@ -269,11 +277,12 @@ __global__ __launch_bounds__(512) void bwd3x3g_kernel(const sv_geom g, const bwd
             if (s_ + PD < 18) rd(s_ + PD);
             __builtin_amdgcn_sched_barrier(0);
             const int b = s_ % NB;
-            const V w0 = SV_BWDG_WREG ? wr[SV_BWDG_WREG ? s_ : 0] : fw0[SV_BWDG_WREG ? 0 : b];
+            const V w0 = NWR >= 1 ? wr[0][s_] : fw0[NWR >= 1 ? 0 : b];
+            const V w1 = NWR >= 2 ? wr[NWR >= 2 ? 1 : 0][s_] : fw1[NWR >= 2 ? 0 : b];
             mma32(acc[0][0], w0, fa0[b]);
             mma32(acc[0][1], w0, fa1[b]);
-            mma32(acc[1][0], fw1[b], fa0[b]);
-            mma32(acc[1][1], fw1[b], fa1[b]);
+            mma32(acc[1][0], w1, fa0[b]);
+            mma32(acc[1][1], w1, fa1[b]);
             __builtin_amdgcn_sched_barrier(0);
         }
         const int gr0 = tile * TR;
@@ -350,29 +359,35 @@ __global__ __launch_bounds__(512) void bwd3x3g_kernel(const sv_geom g, const bwd
     const int t_last = t_begin + (nT - 1 - t_begin) / tstep * tstep;
     const int n_tiles = (nT - 1 - t_begin) / tstep + 1;
     if (wave < 4) {
-        if (SV_BWDG_WREG) {           // (inside this branch: loaded in front of it the 72 registers stayed allocated through the other one)
+        {                             // (inside this branch: loaded in front of it the registers stayed allocated through the other one)
             const bf16* Wp = reinterpret_cast<const bf16*>(p.w) + P.w_off;
 #pragma unroll
-            for (int s_ = 0; s_ < 18; ++s_) wr[SV_BWDG_WREG ? s_ : 0] = *reinterpret_cast<const V*>(Wp + ((32 * dc + fr) * 9 + (s_ >> 1)) * CH + 32 * (s_ & 1) + 8 * fq);
+            for (int i = 0; i < NWR; ++i)
+#pragma unroll
+                for (int s_ = 0; s_ < 18; ++s_)
+                    wr[i][s_] = *reinterpret_cast<const V*>(Wp + ((32 * dc + 16 * i + fr) * 9 + (s_ >> 1)) * CH + 32 * (s_ & 1) + 8 * fq);
         }
         // ONE register stage (bwd3x3f.hip has two): a tile takes ~3 us here, the request issued at the top of an iteration has a whole
         // iteration to arrive -- and the second stage's 24 / 48 / 72 registers are what the register-resident weights need
-        bwdg_halo<MODE> S;
-        auto iter = [&](int tile, int stage) __attribute__((always_inline)) {
-            if (!(SV_BWDG_ABL & 8)) store_halo(S, min(tile + tstep, t_last), stage ^ 1);
-            if (!(SV_BWDG_ABL & 4)) load_halo(S, min(tile + 2 * tstep, t_last));
+        // (SV_BWDG_HSTG2: a second stage in the residual form, whose six tensor passes make it the HBM-bound one)
+        constexpr bool TWO = MODE == 2 && SV_BWDG_HSTG2;
+        bwdg_halo<MODE> S, S2;
+        auto iter = [&](int tile, int stage, bwdg_halo<MODE>& Q_) __attribute__((always_inline)) {
+            if (!(SV_BWDG_ABL & 8)) store_halo(Q_, min(tile + tstep, t_last), stage ^ 1);
+            if (!(SV_BWDG_ABL & 4)) load_halo(Q_, min(tile + (TWO ? 3 : 2) * tstep, t_last));
             if (!(SV_BWDG_ABL & 2)) compute_d(tile, stage);
             tile_barrier();
         };
         load_halo(S, t_begin);
+        if (TWO) load_halo(S2, min(t_begin + tstep, t_last));
         __syncthreads();                                      // the coefficient vectors and the weights in LDS
         store_halo(S, t_begin, 0);
-        load_halo(S, min(t_begin + tstep, t_last));
+        load_halo(S, min(t_begin + (TWO ? 2 : 1) * tstep, t_last));
         __syncthreads();                                      // tile t_begin staged
         int tile = t_begin;
         for (int k = 0; k + 1 < n_tiles; k += 2, tile += 2 * tstep) {
-            iter(tile, 0);
-            iter(tile + tstep, 1);
+            iter(tile, 0, TWO ? S2 : S);
+            iter(tile + tstep, 1, S);
         }
         if (n_tiles & 1) {
             if (!(SV_BWDG_ABL & 2)) compute_d(tile, 0);

@@ -81,10 +81,10 @@ def bench_layer(B, Cin, H, N, what=("fwd", "dgrad", "wgrad")):
                                             C.c_void_p(dy.data_ptr()), C.c_void_p(dw.data_ptr()), 0, 1,
                                             C.c_void_p(ws.data_ptr()), ws.numel(), 1, st))
     for form, kind in enumerate(("bwd", "bwd2", "bwd3")):
-        # sv_bwd3x3, the fused backward (32 channels): dy a tensor / two-tensor form / residual form; one group of B images
+        # sv_bwd3x3, the fused backward (32 / 64 channels): dy a tensor / two-tensor form / residual form; one group of B images
         if kind not in what:
             continue
-        assert Cin == 32 and N == 32, "sv_bwd3x3: 32 -> 32 channels"
+        assert (Cin == 32 and N == 32) or (Cin == 64 and N == 64 and H == 16), "sv_bwd3x3: 32 -> 32 channels, or 64 -> 64 on 16 x 16 maps"
         g = G.convT_like(B, H, H, N, Cin, 3, 1, 1)
         wp = torch.zeros(G.packed_size(g), dtype=bf, device=d)
         L.call("sv_repack", L.SV_BF16, C.c_void_p(master.data_ptr()), N, 9, Cin, 1, C.byref(g), C.c_void_p(wp.data_ptr()), st)
@@ -93,7 +93,7 @@ def bench_layer(B, Cin, H, N, what=("fwd", "dgrad", "wgrad")):
         vec = [torch.rand(Cin, device=d) + 0.5 for _ in range(4)]
         cof = [torch.rand(N, device=d) + 0.5, torch.randn(N, device=d) * 0.2, torch.randn(N, device=d) * 0.05]
         bs = torch.zeros(R, 2 * Cin, device=d, dtype=torch.float64)
-        dw, ws = torch.zeros(N, 9, Cin, device=d), torch.empty(4 << 20, device=d)
+        dw, ws = torch.zeros(N, 9, Cin, device=d), torch.empty(10 << 20, device=d)
         a = L.SvBwd3x3Args()
         a.dy, a.x, a.w, a.out = dy.data_ptr(), x.data_ptr(), wp.data_ptr(), out.data_ptr()
         if form >= 1:

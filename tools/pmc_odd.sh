@@ -34,3 +34,5 @@ run "fwd:stem" SV_BENCH_NOPRO=1 -- 2048 16 32 16 fwd
 # round 6: the fused backward of the 32-channel body (bwd3x3f.hip) in the two forms the step runs
 run "bwd:conv3x3_32x32_s1+bn (bwd3x3f, two-tensor form)" SV_BENCH_FUSED_BLOCKS=248 -- 2048 32 32 32 bwd2
 run "bwd:conv3x3_32x32_s1+bn+skip (bwd3x3f, residual form)" SV_BENCH_FUSED_BLOCKS=248 -- 2048 32 32 32 bwd3
+run "bwd:conv3x3_64x64_s1+bn (bwd3x3g, two-tensor form)" SV_BENCH_FUSED_BLOCKS=248 -- 2048 64 16 64 bwd2
+run "bwd:conv3x3_64x64_s1+bn+skip (bwd3x3g, residual form)" SV_BENCH_FUSED_BLOCKS=248 -- 2048 64 16 64 bwd3

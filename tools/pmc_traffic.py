@@ -35,6 +35,8 @@ LAYERS = {
     "dgrad:conv3x3_128x128_s1": (2048, 128, 8, 128, "dgrad", ["conv3x3_kernel", "conv3x3w_kernel"]),
     "bwd:conv3x3_32x32_s1+bn": (2048, 32, 32, 32, "bwd2", ["bwd3x3f_kernel", "slab_reduce_kernel"]),
     "bwd:conv3x3_32x32_s1+bn+skip": (2048, 32, 32, 32, "bwd3", ["bwd3x3f_kernel", "slab_reduce_kernel"]),
+    "bwd:conv3x3_64x64_s1+bn": (2048, 64, 16, 64, "bwd2", ["bwd3x3g_kernel", "slab_reduce_kernel"]),
+    "bwd:conv3x3_64x64_s1+bn+skip": (2048, 64, 16, 64, "bwd3", ["bwd3x3g_kernel", "slab_reduce_kernel"]),
     "fwd:conv3x3_160x160_s1": (1024, 160, 32, 160, "fwd", ["conv3x3x_kernel", "conv3x3w_kernel"]),
     "wgrad:conv3x3_160x160_s1": (1024, 160, 32, 160, "wgrad", ["wgrad3x3w_kernel", "slab_reduce_kernel"]),
 }
@@ -46,7 +48,7 @@ ITERS, WARM = 4, 1
 ALL_KERNELS = ["igemm_kernel", "igemm_dma_kernel", "halo_kernel", "halop_kernel", "hwgrad_kernel", "wgrad_kernel", "wgradc_kernel",
                "slab_reduce_kernel", "conv3x3_kernel", "conv3x3p_kernel", "conv3x3m_kernel", "conv3x3w_kernel", "conv3x3x_kernel",
                "wgrad3x3_kernel", "wgrad3x3m_kernel", "wgrad3x3w_kernel", "tconvr_kernel", "tconvx16_kernel", "sconv_kernel",
-               "pconv_kernel", "dconv_kernel", "thconv_kernel", "thwgrad_kernel", "s2wgrad_kernel", "bwd3x3f_kernel"]
+               "pconv_kernel", "dconv_kernel", "thconv_kernel", "thwgrad_kernel", "s2wgrad_kernel", "bwd3x3f_kernel", "bwd3x3g_kernel", "k4wgrad_kernel"]
 
 
 def kernel_of(mangled, names):
