@@ -703,10 +703,10 @@ def main():
                                   "frac_of_hbm_peak": round(14.26e9 / t_s / (HBM_PEAK_GBS * 1e9), 4),
                                   "flops": 3.058e12, "TFLOPs": round(3.058e12 / t_s / 1e12, 1),
                                   "frac_of_mfma_peak": round(3.058e12 / t_s / (MFMA_PEAK_TFLOPS["bf16"] * 1e12), 4),
-                                  "tensor_passes_per_residual_unit_backward": {"pair": 17, "fused_32ch": 10},
+                                  "tensor_passes_per_residual_unit_backward": {"pair": 17, "fused_32ch": 10, "fused_64ch": 10},
                                   "note": "17 algorithmic passes per unit with the data / weight gradient pair (dgrad 3, bn-backward "
                                           "3 / 4, wgrad 2, twice; the paired weight gradients find dY / x in L2: PMC 1.07-1.28x their own "
-                                          "bytes); 10 for the same-shape 32-channel units, whose backward is TWO launches of sv_bwd3x3 "
+                                          "bytes); 10 for the same-shape 32- and 64-channel units, whose backward is TWO launches of sv_bwd3x3 "
                                           "(Engine.fused_bwd = 2): conv1's data + weight gradient with norm2's BatchNorm backward in the "
                                           "load path (4 passes instead of 8), conv2's with the next unit's norm1 backward + skip "
                                           "gradient in it (6 instead of 9)"}

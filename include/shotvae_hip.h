@@ -172,7 +172,8 @@ typedef struct {
 int sv_wgrad_ex(const sv_geom* g, int dtype, const sv_wgrad_args* a, void* stream);
 
 /* ---- fused backward of a narrow stride-1 3x3 convolution (ABI 7): data gradient + weight gradient in ONE launch ----------
- * Replaces, for the 32 -> 32 channel body convolutions of WideResNet-28-2 (wideresnet.py:29-35 under autograd), the PAIR
+ * Replaces, for the 32 -> 32 channel body convolutions of WideResNet-28-2 (wideresnet.py:29-35 under autograd; 8 / 16 / 32-pixel
+ * maps) and the 64 -> 64 channel ones (16-pixel maps; C below is the channel count), the PAIR
  *     sv_igemm(geom_dgrad, x = dy, ex = raw input ...)   +   sv_wgrad_ex(geom_fwd, x = raw input, dy ...)
  * and, in the two-tensor form (dy2 != NULL), the sv_bn_bwd_apply pass in front of that pair too.  One persistent kernel stages a
  * tile of dy (with its halo) and of the raw input ONCE and feeds both products from the same LDS image: 3 tensor passes (4 in the
@@ -182,8 +183,8 @@ int sv_wgrad_ex(const sv_geom* g, int dtype, const sv_wgrad_args* a, void* strea
  *   dw[n][torig(t)][c] += sum_q dyeff[q + d(t)][n] * act(x[q][c] * x_scale[c] + x_shift[c])
  *   dyeff = dy, or dy_scale[n] * dy + dy_scale2[n] * dy2 + dy_shift[n] (the coefficients of sv_bn_bwd_affine: the BatchNorm
  *           backward of the layer BEHIND the convolution; same expression and rounding as sv_igemm_args::x2 / sv_wgrad_args::dy2)
- * groups (0 = 1): as sv_igemm_args -- tensors [G][B][H][W][32], vectors [G][32], bsums [G][R][64]; dw sums over the groups.
- * ws: caller-owned fp32 workspace of >= blocks * groups * 9216 floats (blocks <= block_budget, default 256), contents irrelevant:
+ * groups (0 = 1): as sv_igemm_args -- tensors [G][B][H][W][C], vectors [G][C], bsums [G][R][2C]; dw sums over the groups.
+ * ws: caller-owned fp32 workspace of >= blocks * groups * 9 C^2 floats (blocks <= block_budget, default 256), contents irrelevant:
  * one partial slab per block, reduced into dw (+=, float atomics) by a second launch.  Not available under SV_OPT_DETERMINISTIC. */
 typedef struct {
     const void* dy;             /* [G][B,H,W,32] gradient behind the convolution's output (or behind the BatchNorm after it)   */

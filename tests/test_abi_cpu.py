@@ -213,7 +213,7 @@ fb = L.SvBwd3x3Args()
 fb.dy = fb.x = fb.w = fb.out = fb.dw = fb.ws = fb.bsums = fb.x_scale = fb.x_shift = fb.x_mean = fb.x_rstd = 4096
 fb.replicas, fb.groups, fb.ws_elems, fb.x_slope = 4, 4, 1 << 22, 0.01
 assert lib.sv_bwd3x3(C.byref(plan.units[1]["conv1"].geom_dgrad(8)), L.SV_F32, C.byref(fb), None) != 0 and b"bf16" in lib.sv_last_error()
-assert lib.sv_bwd3x3(C.byref(plan.units[5]["conv1"].geom_dgrad(8)), L.SV_BF16, C.byref(fb), None) != 0 and b"32 input" in lib.sv_last_error()
+assert lib.sv_bwd3x3(C.byref(plan.units[9]["conv1"].geom_dgrad(8)), L.SV_BF16, C.byref(fb), None) != 0 and b"32 -> 32 channels" in lib.sv_last_error()
 assert lib.sv_bwd3x3(C.byref(plan.units[1]["conv1"].geom_fwd(8)), L.SV_BF16, C.byref(fb), None) != 0 and b"tap" in lib.sv_last_error()
 assert lib.sv_bwd3x3(C.byref(plan.units[1]["conv1"].geom_dgrad(8)), L.SV_BF16, C.byref(fb), None) != 0 and b"deterministic" in lib.sv_last_error()
 assert lib.sv_set_option(4, 0) == 0
