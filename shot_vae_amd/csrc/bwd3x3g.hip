@@ -33,7 +33,7 @@ static_assert((SDY * 2) % 16 == 0 && (SAC * 2) % 16 == 0 && (STG * 2) % 16 == 0,
 constexpr size_t LDS_BYTES = (size_t)2 * STG * 2 + 2 * CH * 8 + 8 * CH * 4 + (size_t)WLROWS * LDF * 2;
 
 #ifndef SV_BWDG_PD
-#define SV_BWDG_PD 2          // steps the data-gradient waves' fragment reads run ahead of their MFMAs
+#define SV_BWDG_PD 1          // steps the data-gradient waves' fragment reads run ahead of their MFMAs
 #endif
 #ifndef SV_BWDG_WREG
 #define SV_BWDG_WREG 0        // 16-channel tiles (of a data-gradient wave's two) whose weights live in registers (18 fragments each) in the
@@ -44,6 +44,9 @@ constexpr size_t LDS_BYTES = (size_t)2 * STG * 2 + 2 * CH * 8 + 8 * CH * 4 + (si
 #endif
 #ifndef SV_BWDG_HSTG2
 #define SV_BWDG_HSTG2 0        // (1: 135 vs 126 us -- slower)
+#endif
+#ifndef SV_BWDG_DPP
+#define SV_BWDG_DPP 1
 #endif
 #ifndef SV_BWDG_ABL
 #define SV_BWDG_ABL 0        // timing ablations as in bwd3x3f.hip: 1 no weight-gradient MFMAs, 2 no data gradient, 4 no loads, 8 no staging, 16 no epilogue
@@ -260,29 +263,59 @@ __global__ __launch_bounds__(512) void bwd3x3g_kernel(const sv_geom g, const bwd
         // 18 steps (tap t, k-step k) of four fragment reads + four MFMAs, the reads of a step issued PD steps ahead into a ring of
         // PD + 1 fragment sets: left to itself the compiler kept three fragment registers and put every read right in front of its
         // MFMA (s_waitcnt lgkmcnt(0) before each of them: the whole LDS latency per MFMA, 85 us for these waves alone)
+        // Pixel fragments: a 16-pixel fragment is a WHOLE image row (W = 16), so the fragments of the taps left and right of the centre
+        // column are the centre fragment moved by one lane with ZERO coming in at the end of the row (the convolution's padding):
+        // one LDS read + two DPP row shifts per (kernel row, k-step, pixel tile) instead of three reads -- 12 instead of 36 pixel-fragment
+        // reads per tile and wave on a kernel that is bound by the LDS port (SV_BWDG_DPP 0: three reads).  Bit-identical operands.
         constexpr int PD = SV_BWDG_PD, NB = PD + 1;
-        V fa0[NB], fa1[NB], fw0[NWR >= 1 ? 1 : NB], fw1[NWR >= 2 ? 1 : NB];
-        auto rd = [&](int s_) __attribute__((always_inline)) {
+        V fw0[NWR >= 1 ? 1 : NB], fw1[NWR >= 2 ? 1 : NB];
+        V pc[2][2][2];                              // [buffer][k-step][pixel tile]: the centre-column fragments of a kernel row
+        auto rdw = [&](int s_) __attribute__((always_inline)) {
             const int t = s_ >> 1, k = s_ & 1, b = s_ % NB;
-            const int sh = ((1 - t / 3) * WP + (1 - t % 3)) * LDF + 32 * k;
-            fa0[b] = *reinterpret_cast<const V*>(dyh + hbase[0] + sh);
-            fa1[b] = *reinterpret_cast<const V*>(dyh + hbase[1] + sh);
             if (NWR < 1) fw0[NWR >= 1 ? 0 : b] = *reinterpret_cast<const V*>(wl + ((32 * dc + fr) * 9 + t) * LDF + 32 * k + 8 * fq);
             if (NWR < 2) fw1[NWR >= 2 ? 0 : b] = *reinterpret_cast<const V*>(wl + ((32 * dc + 16 + fr) * 9 + t) * LDF + 32 * k + 8 * fq);
         };
+        auto rdp = [&](int ty) __attribute__((always_inline)) {
 #pragma unroll
-        for (int s_ = 0; s_ < PD; ++s_) rd(s_);
+            for (int k = 0; k < 2; ++k)
+#pragma unroll
+                for (int ms = 0; ms < 2; ++ms) pc[ty & 1][k][ms] = *reinterpret_cast<const V*>(dyh + hbase[ms] + (1 - ty) * WP * LDF + 32 * k);
+        };
+        auto shifted = [&](const V& c, int tx) __attribute__((always_inline)) -> V {
+            if (tx == 1) return c;
+            typedef uint32_t u32x4_ __attribute__((ext_vector_type(4)));
+            const u32x4_ in = __builtin_bit_cast(u32x4_, c);
+            u32x4_ o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)      // tap column 0 reads pixel x + 1 (the lane above: row_shl), column 2 pixel x - 1 (row_shr); bound_ctrl: 0 comes in
+                o[j] = tx == 0 ? (uint32_t)__builtin_amdgcn_update_dpp(0, (int)in[j], 0x101, 0xf, 0xf, true)
+                               : (uint32_t)__builtin_amdgcn_update_dpp(0, (int)in[j], 0x111, 0xf, 0xf, true);
+            return __builtin_bit_cast(V, o);
+        };
+        rdp(0);
+#pragma unroll
+        for (int s_ = 0; s_ < PD; ++s_) rdw(s_);
 #pragma unroll
         for (int s_ = 0; s_ < 18; ++s_) {
-            if (s_ + PD < 18) rd(s_ + PD);
+            const int t = s_ >> 1, k = s_ & 1, ty = t / 3, tx = t % 3, b = s_ % NB;
+            if (s_ % 6 == 0 && ty < 2) rdp(ty + 1);
+            if (s_ + PD < 18) rdw(s_ + PD);
             __builtin_amdgcn_sched_barrier(0);
-            const int b = s_ % NB;
+            V a0, a1;
+            if (SV_BWDG_DPP) {
+                a0 = shifted(pc[ty & 1][k][0], tx);
+                a1 = shifted(pc[ty & 1][k][1], tx);
+            } else {
+                const int sh = ((1 - ty) * WP + (1 - tx)) * LDF + 32 * k;
+                a0 = *reinterpret_cast<const V*>(dyh + hbase[0] + sh);
+                a1 = *reinterpret_cast<const V*>(dyh + hbase[1] + sh);
+            }
             const V w0 = NWR >= 1 ? wr[0][s_] : fw0[NWR >= 1 ? 0 : b];
             const V w1 = NWR >= 2 ? wr[NWR >= 2 ? 1 : 0][s_] : fw1[NWR >= 2 ? 0 : b];
-            mma32(acc[0][0], w0, fa0[b]);
-            mma32(acc[0][1], w0, fa1[b]);
-            mma32(acc[1][0], w1, fa0[b]);
-            mma32(acc[1][1], w1, fa1[b]);
+            mma32(acc[0][0], w0, a0);
+            mma32(acc[0][1], w0, a1);
+            mma32(acc[1][0], w1, a0);
+            mma32(acc[1][1], w1, a1);
             __builtin_amdgcn_sched_barrier(0);
         }
         const int gr0 = tile * TR;
