@@ -4,7 +4,7 @@
 R="$(cd "$(dirname "$0")/../.." && pwd)"
 cd "$R/shot_vae_amd/csrc" || exit 1
 FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -munsafe-fp-atomics -I../../include -Wno-unused-function"
-declare -A V=( [base]="" [nog]="-DSV_BWDG_ABL=1" [nod]="-DSV_BWDG_ABL=2" [noload]="-DSV_BWDG_ABL=4" [nostage]="-DSV_BWDG_ABL=8" [onlymma]="-DSV_BWDG_ABL=12" [donly]="-DSV_BWDG_ABL=13" [gonly]="-DSV_BWDG_ABL=14" [memonly]="-DSV_BWDG_ABL=3" [noepi]="-DSV_BWDG_ABL=16" [dpp0]="-DSV_BWDG_DPP=0 -DSV_BWDG_PD=2" [hs1]="-DSV_BWDG_HSTG2=0" [w0]="-DSV_BWDG_WREG=0" [pd1]="-DSV_BWDG_PD=1" [pd3]="-DSV_BWDG_PD=3" [pd3donly]="-DSV_BWDG_PD=3 -DSV_BWDG_ABL=13" )
+declare -A V=( [base]="" [nog]="-DSV_BWDG_ABL=1" [nod]="-DSV_BWDG_ABL=2" [noload]="-DSV_BWDG_ABL=4" [nostage]="-DSV_BWDG_ABL=8" [onlymma]="-DSV_BWDG_ABL=12" [donly]="-DSV_BWDG_ABL=13" [gonly]="-DSV_BWDG_ABL=14" [memonly]="-DSV_BWDG_ABL=3" [noepi]="-DSV_BWDG_ABL=16" [ks0]="-DSV_BWDG_KSHIFT=0" [dpp0]="-DSV_BWDG_DPP=0 -DSV_BWDG_PD=2" [hs1]="-DSV_BWDG_HSTG2=0" [w0]="-DSV_BWDG_WREG=0" [pd1]="-DSV_BWDG_PD=1" [pd3]="-DSV_BWDG_PD=3" [pd3donly]="-DSV_BWDG_PD=3 -DSV_BWDG_ABL=13" )
 [ -n "$SV_BWDG_TAGS" ] || SV_BWDG_TAGS="base nog nod noload nostage onlymma donly gonly memonly noepi"
 mkdir -p "$R/build/ab"
 if [ "$1" = "build" ]; then
