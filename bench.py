@@ -79,6 +79,7 @@ def parse():
     ap.add_argument("--event-fork-after-fused", type=int, default=1,
                     help="Engine.event_fork_after_fused: 0 = the pair behind fused-backward launches forks by flag like every other pair (the "
                          "side stream's wait_flag_kernel then spins through the fused launches: A/B)")
+    ap.add_argument("--fold-bn-bwd", type=int, default=1, help="Engine.fold_bn_bwd (0: a sv_bn_bwd_affine launch in front of every fused backward: A/B)")
     ap.add_argument("--fused-channels", default="", help="Engine.fused_channels, comma-separated (default: the engine's; '32,64' adds the 64-channel stage)")
     ap.add_argument("--fused-blocks", type=int, default=0, help="Engine.fused_blocks: blocks of a fused-backward launch (0 = the engine's default, 248)")
     ap.add_argument("--flag-fork", type=int, default=1, help="0: event forks for the paired weight gradients instead of the start signal")
@@ -588,6 +589,7 @@ def main():
     if a.fused_blocks:
         model._engine.fused_blocks = a.fused_blocks
     model._engine.event_fork_after_fused = bool(a.event_fork_after_fused)
+    model._engine.fold_bn_bwd = bool(a.fold_bn_bwd)
     if a.fused_channels:
         model._engine.fused_channels = tuple(int(v) for v in a.fused_channels.split(","))
     model._engine.compact_shortcut_grad = bool(a.compact_shortcut)

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define SV_ABI_VERSION 7
+#define SV_ABI_VERSION 8
 
 enum { SV_F32 = 0, SV_BF16 = 1 };
 /* ABI 6: the per-channel ACCUMULATORS of the BatchNorm statistics and backward sums (sv_igemm_args::stats / bsums / fold_stats,
@@ -214,6 +214,17 @@ typedef struct {
     int64_t ws_elems;
     int32_t block_budget;       /* 0 = 256 */
     int32_t reserved0;
+    /* ABI 8: the coefficients of the two- / three-tensor forms derived IN the launch (sv_bn_bwd_affine's arithmetic, every block from the
+       raw sums; block 0 of a group adds dgamma / dbeta): one small launch less in front of every fused backward.  With fold_bsums set,
+       dy_scale / dy_scale2 / dy_shift are not read (may be NULL). */
+    const sv_acc_t* fold_bsums; /* NULL, or (with dy2) [G][fold_replicas][2C]: the backward sums of the BatchNorm BEHIND the convolution  */
+    const float* fold_gamma;    /* [C]                                                                                               */
+    const float* fold_mean;     /* [G][C]                                                                                            */
+    const float* fold_rstd;     /* [G][C]                                                                                            */
+    float* fold_dgamma;         /* [C], += ; may be NULL                                                                             */
+    float* fold_dbeta;          /* [C], += ; may be NULL                                                                             */
+    float fold_count;           /* elements per channel and group (B * H * W)                                                        */
+    int32_t fold_replicas;
 } sv_bwd3x3_args;
 int sv_bwd3x3(const sv_geom* g, int dtype, const sv_bwd3x3_args* a, void* stream);
 

@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("SV_LIB_PATH") or os.path.join(HERE, "libshotvae_hip.s
 CSRC = os.path.join(HERE, "csrc")
 
 SV_F32, SV_BF16 = 0, 1
-ABI_VERSION = 7                  # include/shotvae_hip.h: SV_ABI_VERSION
+ABI_VERSION = 8                  # include/shotvae_hip.h: SV_ABI_VERSION
 MAX_TAPS, MAX_PHASES = 16, 4
 
 
@@ -53,7 +53,9 @@ class SvBwd3x3Args(C.Structure):
                 ("dy3", C.c_void_p), ("dy_out", C.c_void_p), ("x", C.c_void_p), ("x_scale", C.c_void_p), ("x_shift", C.c_void_p), ("x_mean", C.c_void_p), ("x_rstd", C.c_void_p),
                 ("x_slope", C.c_float), ("w", C.c_void_p), ("out", C.c_void_p), ("bsums", C.c_void_p), ("replicas", C.c_int32),
                 ("groups", C.c_int32), ("dw", C.c_void_p), ("ws", C.c_void_p), ("ws_elems", C.c_int64), ("block_budget", C.c_int32),
-                ("reserved0", C.c_int32)]
+                ("reserved0", C.c_int32),
+                ("fold_bsums", C.c_void_p), ("fold_gamma", C.c_void_p), ("fold_mean", C.c_void_p), ("fold_rstd", C.c_void_p),
+                ("fold_dgamma", C.c_void_p), ("fold_dbeta", C.c_void_p), ("fold_count", C.c_float), ("fold_replicas", C.c_int32)]
 
 
 class SvRepackJob(C.Structure):

@@ -91,6 +91,14 @@ struct bwdf_params {
     double* bsums;
     int replicas;
     float* ws;
+    const double* fold_bsums;      // sv_bwd3x3_args::fold_* of this group (null: the coefficients are given)
+    const float* fold_gamma;
+    const float* fold_mean;
+    const float* fold_rstd;
+    float* fold_dgamma;
+    float* fold_dbeta;
+    float fold_inv_count;
+    int fold_replicas;
 };
 struct bwdf_g { bwdf_params g[SV_MAX_GROUPS]; };
 
@@ -162,8 +170,13 @@ __global__ __launch_bounds__(512) void bwd3x3f_kernel(const sv_geom g, const bwd
     float slope = p.x_slope;
     asm volatile("v_mov_b32 %0, %0" : "+v"(slope));          // pinned in a vector register (no re-load from the argument segment)
 
+    if (MODE >= 1 && p.fold_bsums) {
+        // (ABI 8) the BatchNorm backward's coefficients from its raw sums, in every block; the stage area is free until the first tile is stored
+        sv_bn_bwd_affine_block512<CH>(p.fold_bsums, p.fold_replicas, p.fold_inv_count, p.fold_gamma, p.fold_mean, p.fold_rstd,
+                                      p.fold_dgamma, p.fold_dbeta, blockIdx.x == 0, reinterpret_cast<double*>(smem), cf);
+    }
     if (tid < CH) {
-        if (MODE >= 1) {
+        if (MODE >= 1 && !p.fold_bsums) {
             cf[tid] = p.dy_scale[tid];
             cf[CH + tid] = p.dy_scale2[tid];
             cf[2 * CH + tid] = p.dy_shift[tid];
@@ -543,8 +556,10 @@ extern "C" int sv_bwd3x3(const sv_geom* g, int dtype, const sv_bwd3x3_args* a, v
     SV_REQUIRE(a->dy && a->x && a->w && a->out && a->dw && a->ws && a->bsums, SV_E_ARG, "sv_bwd3x3: null tensor");
     SV_REQUIRE(a->x_scale && a->x_shift && a->x_mean && a->x_rstd, SV_E_ARG, "sv_bwd3x3: the BatchNorm vectors of x are required");
     SV_REQUIRE(a->x_slope >= 0.f && a->x_slope <= 1.f, SV_E_ARG, "sv_bwd3x3: slope %g outside [0, 1]", (double)a->x_slope);
-    SV_REQUIRE(!a->dy2 || (a->dy_scale && a->dy_scale2 && a->dy_shift), SV_E_ARG,
-               "sv_bwd3x3: the two-tensor dy operand needs dy_scale, dy_scale2 and dy_shift");
+    SV_REQUIRE(!a->dy2 || a->fold_bsums || (a->dy_scale && a->dy_scale2 && a->dy_shift), SV_E_ARG,
+               "sv_bwd3x3: the two-tensor dy operand needs dy_scale, dy_scale2 and dy_shift (or the fold_* sums)");
+    SV_REQUIRE(!a->fold_bsums || (a->dy2 && a->fold_gamma && a->fold_mean && a->fold_rstd && a->fold_replicas >= 1 && a->fold_count > 0.f),
+               SV_E_ARG, "sv_bwd3x3: incomplete BatchNorm-backward fold (fold_* need dy2, gamma, mean, rstd, replicas >= 1, count > 0)");
     SV_REQUIRE((a->dy3 != nullptr) == (a->dy_out != nullptr) && (!a->dy3 || a->dy2), SV_E_ARG,
                "sv_bwd3x3: the residual form needs dy2 (+ coefficients), dy3 AND dy_out");
     const int groups = sv_ngroups(a->groups);
@@ -582,9 +597,18 @@ extern "C" int sv_bwd3x3(const sv_geom* g, int dtype, const sv_bwd3x3_args* a, v
         r.dy2 = a->dy2 ? reinterpret_cast<const char*>(a->dy2) + q * ts : nullptr;
         r.dy3 = a->dy3 ? reinterpret_cast<const char*>(a->dy3) + q * ts : nullptr;
         r.dy_out = a->dy_out ? reinterpret_cast<char*>(a->dy_out) + q * ts : nullptr;
-        r.dy_scale = a->dy2 ? a->dy_scale + q * CH : nullptr;
-        r.dy_scale2 = a->dy2 ? a->dy_scale2 + q * CH : nullptr;
-        r.dy_shift = a->dy2 ? a->dy_shift + q * CH : nullptr;
+        const bool fold = a->dy2 && a->fold_bsums;
+        r.dy_scale = a->dy2 && !fold ? a->dy_scale + q * CH : nullptr;
+        r.dy_scale2 = a->dy2 && !fold ? a->dy_scale2 + q * CH : nullptr;
+        r.dy_shift = a->dy2 && !fold ? a->dy_shift + q * CH : nullptr;
+        r.fold_bsums = fold ? a->fold_bsums + q * (int64_t)a->fold_replicas * 2 * CH : nullptr;
+        r.fold_gamma = a->fold_gamma;
+        r.fold_mean = fold ? a->fold_mean + q * CH : nullptr;
+        r.fold_rstd = fold ? a->fold_rstd + q * CH : nullptr;
+        r.fold_dgamma = a->fold_dgamma;
+        r.fold_dbeta = a->fold_dbeta;
+        r.fold_inv_count = fold ? 1.f / a->fold_count : 0.f;
+        r.fold_replicas = a->fold_replicas;
         r.x = reinterpret_cast<const char*>(a->x) + q * ts;
         r.x_scale = a->x_scale + q * CH;
         r.x_shift = a->x_shift + q * CH;

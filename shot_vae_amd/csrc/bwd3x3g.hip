@@ -71,6 +71,14 @@ struct bwdg_params {
     double* bsums;
     int replicas;
     float* ws;
+    const double* fold_bsums;      // sv_bwd3x3_args::fold_* of this group (null: the coefficients are given)
+    const float* fold_gamma;
+    const float* fold_mean;
+    const float* fold_rstd;
+    float* fold_dgamma;
+    float* fold_dbeta;
+    float fold_inv_count;
+    int fold_replicas;
 };
 struct bwdg_g { bwdg_params g[SV_MAX_GROUPS]; };
 
@@ -124,8 +132,13 @@ __global__ __launch_bounds__(512) void bwd3x3g_kernel(const sv_geom g, const bwd
     float slope = p.x_slope;
     asm volatile("v_mov_b32 %0, %0" : "+v"(slope));
 
+    if (MODE >= 1 && p.fold_bsums) {
+        // (ABI 8) the BatchNorm backward's coefficients from its raw sums, in every block; the stage area is free until the first tile is stored
+        sv_bn_bwd_affine_block512<CH>(p.fold_bsums, p.fold_replicas, p.fold_inv_count, p.fold_gamma, p.fold_mean, p.fold_rstd,
+                                      p.fold_dgamma, p.fold_dbeta, blockIdx.x == 0, reinterpret_cast<double*>(smem), cf);
+    }
     if (tid < CH) {
-        if (MODE >= 1) {
+        if (MODE >= 1 && !p.fold_bsums) {
             cf[tid] = p.dy_scale[tid];
             cf[CH + tid] = p.dy_scale2[tid];
             cf[2 * CH + tid] = p.dy_shift[tid];
@@ -520,9 +533,18 @@ int sv_bwd3x3_64(const sv_geom* g, const sv_bwd3x3_args* a, hipStream_t s) {
         r.dy2 = a->dy2 ? reinterpret_cast<const char*>(a->dy2) + q * ts : nullptr;
         r.dy3 = a->dy3 ? reinterpret_cast<const char*>(a->dy3) + q * ts : nullptr;
         r.dy_out = a->dy_out ? reinterpret_cast<char*>(a->dy_out) + q * ts : nullptr;
-        r.dy_scale = a->dy2 ? a->dy_scale + q * CH : nullptr;
-        r.dy_scale2 = a->dy2 ? a->dy_scale2 + q * CH : nullptr;
-        r.dy_shift = a->dy2 ? a->dy_shift + q * CH : nullptr;
+        const bool fold = a->dy2 && a->fold_bsums;
+        r.dy_scale = a->dy2 && !fold ? a->dy_scale + q * CH : nullptr;
+        r.dy_scale2 = a->dy2 && !fold ? a->dy_scale2 + q * CH : nullptr;
+        r.dy_shift = a->dy2 && !fold ? a->dy_shift + q * CH : nullptr;
+        r.fold_bsums = fold ? a->fold_bsums + q * (int64_t)a->fold_replicas * 2 * CH : nullptr;
+        r.fold_gamma = a->fold_gamma;
+        r.fold_mean = fold ? a->fold_mean + q * CH : nullptr;
+        r.fold_rstd = fold ? a->fold_rstd + q * CH : nullptr;
+        r.fold_dgamma = a->fold_dgamma;
+        r.fold_dbeta = a->fold_dbeta;
+        r.fold_inv_count = fold ? 1.f / a->fold_count : 0.f;
+        r.fold_replicas = a->fold_replicas;
         r.x = reinterpret_cast<const char*>(a->x) + q * ts;
         r.x_scale = a->x_scale + q * CH;
         r.x_shift = a->x_shift + q * CH;

@@ -218,3 +218,37 @@ __device__ __forceinline__ void gemm_epilogue(const f32x4 (&acc)[NT][MS], const 
     }
 }
 
+// sv_bn_bwd_affine inside a 512-thread block (sv_bwd3x3_args::fold_*, ABI 8): scale_g / scale_x / shift [C] of a BatchNorm's backward from
+// its raw sums [R][2C] into `out` (three rows of C floats; LDS), sv_bn_bwd_affine's arithmetic; `scratch` = 2 x 512 doubles of LDS.
+// Every block of a launch derives the same values (fixed summation order); `add` = this block also adds dgamma / dbeta.
+template <int C>
+__device__ __forceinline__ void sv_bn_bwd_affine_block512(const double* __restrict__ bsums, int R, float inv_count, const float* gamma,
+                                                          const float* mean, const float* rstd, float* dgamma, float* dbeta, bool add,
+                                                          double* scratch, float* out) {
+    static_assert(512 % C == 0, "");
+    constexpr int PARTS = 512 / C;
+    const int tid = threadIdx.x, c = tid % C, pt = tid / C;
+    double s1 = 0.0, s2 = 0.0;
+    for (int r = pt; r < R; r += PARTS) {
+        s1 += bsums[(size_t)r * 2 * C + c];
+        s2 += bsums[(size_t)r * 2 * C + C + c];
+    }
+    scratch[tid] = s1;
+    scratch[512 + tid] = s2;
+    __syncthreads();
+    if (tid < C) {
+        double t1 = 0.0, t2 = 0.0;
+#pragma unroll
+        for (int q = 0; q < PARTS; ++q) { t1 += scratch[q * C + tid]; t2 += scratch[512 + q * C + tid]; }
+        const float rs = rstd[tid], A = gamma[tid] * rs, m1 = (float)(t1 * (double)inv_count), m2 = (float)(t2 * (double)inv_count);
+        const float bx = -A * m2 * rs;
+        out[tid] = A;
+        out[C + tid] = bx;
+        out[2 * C + tid] = -A * m1 - bx * mean[tid];
+        if (add) {
+            if (dbeta) atomicAdd(dbeta + tid, (float)t1);
+            if (dgamma) atomicAdd(dgamma + tid, (float)t2);
+        }
+    }
+    __syncthreads();
+}

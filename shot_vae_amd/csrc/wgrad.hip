@@ -582,7 +582,7 @@ int dispatch(const sv_geom* g, const wg_params& p, int tn, int tc, hipStream_t s
 
 }  // namespace
 
-static_assert(sizeof(sv_wgrad_args) == 80 && sizeof(sv_igemm_args) == 224 && sizeof(sv_param_job) == 112 && sizeof(sv_bwd3x3_args) == 168, "ABI 7 struct layout (tests/test_abi_cpu.py)");
+static_assert(sizeof(sv_wgrad_args) == 80 && sizeof(sv_igemm_args) == 224 && sizeof(sv_param_job) == 112 && sizeof(sv_bwd3x3_args) == 224, "ABI 8 struct layout (tests/test_abi_cpu.py)");
 
 extern "C" int sv_wgrad_ex(const sv_geom* g, int dtype, const sv_wgrad_args* a, void* stream) {
     SV_REQUIRE(g && a, SV_E_ARG, "sv_wgrad_ex: null argument");

@@ -498,7 +498,7 @@ class Engine:
     materialize_max_hin = 4          # ... for the layers whose input map is at most this large
     light_fork = True                # fork events without the system-scope fence (sv_stream_fork)
     fork_every = 1                   # weight gradients per side-stream fork
-    # sv_bwd3x3 (ABI 7): data gradient + weight gradient of a 32 -> 32 channel body convolution in ONE launch that reads every
+    # sv_bwd3x3 (ABI 7 / 8): data gradient + weight gradient of a 32 -> 32 (64 -> 64) channel body convolution in ONE launch that reads every
     # operand once.  1 = conv1 of the same-shape units in the two-tensor form (norm2's BatchNorm backward formed in the kernel's
     # load path: the sv_bn_bwd_apply pass between the unit's two data gradients disappears: 8 tensor passes -> 4);
     # 2 = also conv2 of the unit IN FRONT of such a unit in the residual form: the NEXT unit's norm1 backward + skip connection
@@ -506,6 +506,7 @@ class Engine:
     # (9 passes -> 6); 3 = every other 32-channel conv2 as well (5 passes -> 3: slower than the two-stream pair, an A/B switch).
     # bf16, not in deterministic mode.
     fused_bwd = 2
+    fold_bn_bwd = True               # (ABI 8) sv_bwd3x3 derives the BatchNorm backward's coefficients itself: no sv_bn_bwd_affine launch
     fused_channels = (32, 64)        # body widths that take sv_bwd3x3 (64: bwd3x3g.hip, 16 x 16 maps; same-box A/B 6.19-6.23 -> 6.09-6.12 ms)
     # blocks of a fused-backward launch (one 512-thread block per CU: a block's eight waves fill the SIMDs' register files).  NOT 256:
     # a single CU that hosts anything else -- the side stream's spinning wait_flag_kernel, the tail of a slab reduction -- cannot take
@@ -656,7 +657,12 @@ class Engine:
             self._cost(tag, es * n * (3 + (lin2 is not None) + 2 * (res is not None)) + 4 * 9 * g.Cin * g.N, 2 * 2.0 * n * 9 * g.N)
         a = L.SvBwd3x3Args()
         a.dy, a.x, a.out = dy.data_ptr(), x.data_ptr(), out.data_ptr()
-        if lin2 is not None:
+        if lin2 is not None and len(lin2) == 2:
+            # (ABI 8) the coefficients derived in the launch from the BatchNorm's raw backward sums: lin2 = (dy2 tensor, (bsums, replicas,
+            # count, gamma, mean, rstd, dgamma, dbeta))
+            a.dy2 = lin2[0].data_ptr()
+            (a.fold_bsums, a.fold_replicas, a.fold_count, a.fold_gamma, a.fold_mean, a.fold_rstd, a.fold_dgamma, a.fold_dbeta) = lin2[1]
+        elif lin2 is not None:
             a.dy2, a.dy_scale, a.dy_scale2, a.dy_shift = lin2[0].data_ptr(), lin2[1], lin2[2], lin2[3]
         if res is not None:
             a.dy3, a.dy_out = res[0].data_ptr(), res[1].data_ptr()
@@ -1035,6 +1041,13 @@ class Engine:
                    _vp(dx.data_ptr()), Gx, st)
             return dx
 
+        def bn_fold(b, count):
+            """the arguments of sv_bwd3x3_args::fold_* for BatchNorm b (the launch derives its backward's coefficients itself and adds
+            dgamma / dbeta: no sv_bn_bwd_affine launch in front of it)"""
+            _, _, mn, rs = bnp(b)
+            return (bs_off[b.index], bs_rep[b.index], float(count), pbase + 4 * b.gamma_off, mn, rs, gbase + 4 * b.gamma_off,
+                    gbase + 4 * b.beta_off)
+
         def bn_affine(b, count):
             """scale_g, scale_x, shift [G][C] of BatchNorm b's backward from its sums (one small launch, which also adds dgamma /
             dbeta): the coefficients of a data gradient that forms dx = scale_g * g + scale_x * x + shift in its load path"""
@@ -1138,11 +1151,15 @@ class Engine:
                 # = this unit's output, the gradient at the next unit's output) and written once (the previous unit's skip needs it)
                 g1n, tinn, bn1n, Dres, cntn = deferred
                 deferred = None
-                coefn, sgn, sxn, shn = bn_affine(bn1n, cntn)
                 D = torch.empty_like(Dres)
-                self._bwd3x3(un["conv2"], B, g1n, (tinn, sgn, sxn, shn), c1, bnp(un["bn2"]), un["bn2"].slope, g2,
+                if self.fold_bn_bwd:
+                    lin2n = (tinn, bn_fold(bn1n, cntn))
+                else:
+                    coefn, sgn, sxn, shn = bn_affine(bn1n, cntn)
+                    lin2n = (tinn, sgn, sxn, shn)
+                self._bwd3x3(un["conv2"], B, g1n, lin2n, c1, bnp(un["bn2"]), un["bn2"].slope, g2,
                              bs_off[un["bn2"].index], bs_rep[un["bn2"].index], "bwd:conv3x3_%dx%d_s1+bn+skip" % (c, c), G, res=(Dres, D))
-                del coefn, g1n, Dres
+                del lin2n, g1n, Dres
             elif fb >= 3:
                 self._bwd3x3(un["conv2"], B, D, None, c1, bnp(un["bn2"]), un["bn2"].slope, g2, bs_off[un["bn2"].index],
                              bs_rep[un["bn2"].index], "bwd:conv3x3_%dx%d_s1" % (c, c), G)
@@ -1160,10 +1177,14 @@ class Engine:
             if fb >= 1 and same:
                 # conv1's WHOLE backward in one launch: dc1 = norm2's BatchNorm backward of g2 is formed in its load path from
                 # (g2, c1) and the finished sums (sv_bn_bwd_affine), both products run from that one LDS image
-                coef, sg, sx, sh = bn_affine(un["bn2"], cnt2)
-                self._bwd3x3(un["conv1"], B, g2, (c1, sg, sx, sh), tin, bnp(un["bn1"]), un["bn1"].slope, g1,
+                if self.fold_bn_bwd:
+                    lin21 = (c1, bn_fold(un["bn2"], cnt2))
+                else:
+                    coef, sg, sx, sh = bn_affine(un["bn2"], cnt2)
+                    lin21 = (c1, sg, sx, sh)
+                self._bwd3x3(un["conv1"], B, g2, lin21, tin, bnp(un["bn1"]), un["bn1"].slope, g1,
                              bs_off[un["bn1"].index], bs_rep[un["bn1"].index], "bwd:" + tag1 + "+bn", G)
-                del coef
+                del lin21
                 dc1 = None
             else:
                 dc1 = bn_apply(c1, [(g2, un["bn2"])], None, cnt2)

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), "missing export " + n
     assert set(names) == set(L.EXPORTS), set(names) ^ set(L.EXPORTS)
-    assert L.lib().sv_version() == L.ABI_VERSION == 7
+    assert L.lib().sv_version() == L.ABI_VERSION == 8
 
 
 def test_struct_layout_matches_header():
@@ -34,7 +34,7 @@ def test_struct_layout_matches_header():
     assert ctypes.sizeof(L.SvGeom) == 72 + 4 * 72
     assert ctypes.sizeof(L.SvIgemmArgs) == 28 * 8
     assert ctypes.sizeof(L.SvWgradArgs) == 10 * 8
-    assert ctypes.sizeof(L.SvBwd3x3Args) == 21 * 8
+    assert ctypes.sizeof(L.SvBwd3x3Args) == 28 * 8
     assert ctypes.sizeof(L.SvParamJob) == 14 * 8
     assert ctypes.sizeof(L.SvBnBranch) == 48
     assert ctypes.sizeof(L.SvRepackJob) == 64

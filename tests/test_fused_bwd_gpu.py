@@ -100,7 +100,12 @@ def _fused(t, wd, gd, Gn, budget, slope, R, ws=None):
     ws = ws if ws is not None else torch.full((10 * 1024 * 1024,), float("nan"), device=d)
     a = L.SvBwd3x3Args()
     a.dy, a.x, a.w, a.out = t["dy"].data_ptr(), t["x"].data_ptr(), wd.data_ptr(), g.data_ptr()
-    if t["coef"] is not None:
+    if t.get("fold") is not None:                 # (ABI 8) the coefficients derived in the launch from the raw sums
+        a.dy2 = t["c1"].data_ptr()
+        bs2, R2, count, gamma2, mean2, rstd2, dgam, dbet = t["fold"]
+        a.fold_bsums, a.fold_replicas, a.fold_count = bs2.data_ptr(), R2, count
+        a.fold_gamma, a.fold_mean, a.fold_rstd, a.fold_dgamma, a.fold_dbeta = (q.data_ptr() for q in (gamma2, mean2, rstd2, dgam, dbet))
+    elif t["coef"] is not None:
         a.dy2, a.dy_scale, a.dy_scale2, a.dy_shift = (t["c1"].data_ptr(), t["coef"][0].data_ptr(), t["coef"][1].data_ptr(),
                                                       t["coef"][2].data_ptr())
     if t.get("res") is not None:
@@ -249,6 +254,13 @@ def test_two_tensor_form_against_torch_autograd(B, H, Gn):
     g1, bs1, dw = _fused(t, wd, gd, Gn, 0, slope, R)
     # the coefficients' side effect: dgamma / dbeta of norm2 exactly as autograd has them (fp32 sums)
     assert rel(dgam, dgam_ref) < 1e-4 and rel(dbet, dbet_ref) < 1e-4
+    # (ABI 8) the same launch deriving the coefficients itself from the raw sums: the same outputs (the sums' partial order differs: the
+    # coefficients agree to rounding, an element of the formed gradient may round the other way), dgamma / dbeta added once
+    dgam8, dbet8 = torch.zeros(c, device=d), torch.zeros(c, device=d)
+    t8 = dict(t, coef=None, fold=(bs2, R, count, gamma2, mean2, rstd2, dgam8, dbet8))
+    g18, bs18, dw8 = _fused(t8, wd, gd, Gn, 0, slope, R)
+    assert rel(dgam8, dgam) < 1e-6 and rel(dbet8, dbet) < 1e-6
+    assert rel(g18.float(), g1.float()) < 2e-3 and rel(dw8, dw) < 1e-3 and rel(bs18.sum(1).float(), bs1.sum(1).float()) < 1e-3
     # g1: the transposed convolution of ONE bf16 rounding of torch's BatchNorm backward + norm1's activation backward
     assert rel(g1.float(), g1_ref) < 2.5e-2, rel(g1.float(), g1_ref)
     got = dw.view(c, 3, 3, c).permute(0, 3, 1, 2)
