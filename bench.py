@@ -206,7 +206,13 @@ def pmc_traffic(tag, a):
     tab = json.load(open(files[-1]))
     if tag not in tab:
         return None, "kernel not in " + os.path.basename(files[-1])
-    return tab[tag]["traffic_bytes"], "profiles/%s: %s" % (os.path.basename(files[-1]), tab[tag]["formula"])
+    src = "profiles/%s: %s" % (os.path.basename(files[-1]), tab[tag]["formula"])
+    if tab[tag].get("algorithmic_bytes"):
+        # (the counter pass measures ONE form of the tag -- e.g. the forward WITH its residual operand -- while `algorithmic_bytes` of the
+        #  timed pass averages the step's launches of that tag: the ratio that speaks of re-reads is traffic / this figure)
+        src += "; the measured launch's own algorithmic bytes: %d (traffic / that = %.3f)" % (
+            tab[tag]["algorithmic_bytes"], tab[tag]["traffic_bytes"] / tab[tag]["algorithmic_bytes"])
+    return tab[tag]["traffic_bytes"], src
 
 
 def _shot_setup(S, net, K, Bl, Bu, dtype="bf16", seed=4321, dmi=2.3):
