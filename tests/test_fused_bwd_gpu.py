@@ -273,6 +273,35 @@ def test_two_tensor_form_against_torch_autograd(B, H, Gn):
     assert float((got_s[:, :c] - s1).abs().max()) < tol and float((got_s[:, c:] - s2).abs().max()) < 3 * tol
 
 
+@pytest.mark.parametrize("ch,B,H,Gn,res", [(32, 12, 32, 2, True), (32, 12, 32, 1, False), (64, 12, 16, 2, True), (64, 12, 16, 4, False)])
+def test_fold_derives_the_coefficients_of_sv_bn_bwd_affine(monkeypatch, ch, B, H, Gn, res):
+    """ABI 8 (sv_bwd3x3_args::fold_*): the launch that derives dy_scale / dy_scale2 / dy_shift from the raw backward sums itself against
+    the same launch with the coefficients sv_bn_bwd_affine makes of those sums -- two-tensor and residual form, both kernels; dgamma /
+    dbeta are added exactly once (by block 0 of every group)."""
+    import sys
+    monkeypatch.setattr(sys.modules[__name__], "CH", ch)
+    d = dev()
+    t = _inputs(B, H, Gn, 2 if res else 1, 77 + ch + Gn)
+    R, count = 8, float(B * H * H)
+    bs2 = (torch.randn(Gn, R, 2 * ch, device=d) * 40).to(ACC).contiguous()
+    gamma2, mean2, rstd2 = torch.rand(ch, device=d) + 0.5, (torch.randn(Gn, ch, device=d) * 0.2).contiguous(), (torch.rand(Gn, ch, device=d) + 0.5).contiguous()
+    coef = torch.empty(3, Gn, ch, device=d)
+    dgam, dbet = torch.zeros(ch, device=d), torch.zeros(ch, device=d)
+    L.call("sv_bn_bwd_affine", p(bs2), R, ch, count, p(gamma2), p(mean2), p(rstd2), p(dgam), p(dbet), p(coef[0]), p(coef[1]), p(coef[2]), Gn, st())
+    gd = G.convT_like(B, H, H, ch, ch, 3, 1, 1)
+    wd = repack(t["w"], gd, True, "bf16")
+    ta = dict(t, coef=coef)
+    g_a, bs_a, dw_a = _fused(ta, wd, gd, Gn, 0, 0.01, 4)
+    out_a = ta.get("dy_out")
+    dgam8, dbet8 = torch.zeros(ch, device=d), torch.zeros(ch, device=d)
+    tb = dict(t, coef=None, fold=(bs2, R, count, gamma2, mean2, rstd2, dgam8, dbet8))
+    g_b, bs_b, dw_b = _fused(tb, wd, gd, Gn, 0, 0.01, 4)
+    assert rel(dgam8, dgam) < 1e-6 and rel(dbet8, dbet) < 1e-6
+    assert rel(g_b.float(), g_a.float()) < 2e-3 and rel(dw_b, dw_a) < 1e-3 and rel(bs_b.sum(1).float(), bs_a.sum(1).float()) < 1e-3
+    if res:
+        assert rel(tb["dy_out"].float(), out_a.float()) < 2e-3
+
+
 # ---- 64 channels on 16 x 16 maps (bwd3x3g.hip): the same checks with the module's channel count switched ------------------------------
 CASES64 = [(16, 16, 2, 0, 0), (16, 16, 2, 0, 1), (16, 16, 2, 0, 2),
            (1, 16, 1, 0, 1), (3, 16, 1, 0, 2),        # fewer tiles than blocks (4 / 12 tiles)
